@@ -1,0 +1,179 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (imported from /root/reference)
+on CPU in the build container.  Fixtures hold only inputs-by-seed and expected outputs (plain
+arrays); weights are regenerated everywhere from oracle/detweights.py.  Run:
+
+    python tools/gen_goldens.py            # writes tests/golden/
+    python tools/gen_goldens.py --check    # additionally checks oracle/lgteun_oracle.py against them
+
+Never runs on the GPU box (there is no /root/reference there).
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+
+from _ref_import import import_reference  # noqa: E402
+from oracle import detweights as dw  # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def build_ref(R, C, K, dtype=torch.float32, salt=0):
+    net = R.Pansharpening(R.Config(ms_chans=C), None, stage=K)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = dw.fill_state_dict(shapes, salt=salt, dtype=np.float64)
+    net = net.to(dtype)
+    net.load_state_dict({k: torch.from_numpy(v).to(dtype) for k, v in sd.items()})
+    net.eval()
+    return net, shapes
+
+
+def t(a, dtype=torch.float32):
+    return torch.from_numpy(np.asarray(a)).to(dtype)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--check', action='store_true')
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    R = import_reference()
+    manifest = {}
+
+    # ---------------------------------------------------------------- per-op goldens (C=4 and C=8)
+    for C in (4, 8):
+        net, shapes = build_ref(R, C, 1)
+        E = 4 * C
+        rng = np.random.default_rng(100 + C)
+        out = {}
+        x_ms = rng.uniform(0, 1, (2, C, 8, 8)).astype(np.float32)
+        out['resample_in'] = x_ms
+        out['resample_x4'] = R.bmu.sampling_(t(x_ms), 4).numpy()
+        out['resample_x2'] = R.bmu.sampling_(t(x_ms), 2).numpy()
+        x_big = rng.uniform(0, 1, (2, C, 32, 32)).astype(np.float32)
+        out['z_in'] = x_big
+        out['resample_half'] = R.bmu.sampling_(t(x_big), 0.5).numpy()
+        out['resample_x1'] = R.bmu.sampling_(t(x_big), 1).numpy()
+        pan = rng.uniform(0, 1, (2, 1, 32, 32)).astype(np.float32)
+        out['pan_in'] = pan
+        with torch.no_grad():
+            out['D'] = net.D(t(x_big)).numpy()
+            out['DT'] = net.DT(t(x_ms)).numpy()
+            z = t(x_big)
+            ms_term = net.DT(net.D(z) - t(x_ms))
+            pan_term = net.RT(net.R(z) - t(pan))
+            out['data_step'] = (z - net.eta[0] * (ms_term + pan_term)).numpy()
+            lg = net.prior_module[0]
+            out['patch_embed'] = lg.patch_embed(t(x_big)).numpy()
+            blk = lg.encoder_layers[0][0].blocks[0]
+            mixer = blk[0].fn.fn           # LGMixer
+            ffn = blk[1].fn.fn
+            feat = rng.standard_normal((2, 32, 32, E)).astype(np.float32)
+            # negative-DC planes on the global half of sample 1 pin the angle()=pi branch
+            feat[1, :, :, E // 2:] -= 1.5
+            out['feat_in'] = feat
+            out['local_mixer'] = mixer.local_mixer(t(feat[..., :E // 2]).contiguous()).numpy()
+            out['global_mixer'] = mixer.global_mixer(t(feat[..., E // 2:]).contiguous()).numpy()
+            out['lg_mixer'] = mixer(t(feat)).numpy()
+            out['feed_forward'] = ffn(t(feat)).numpy()
+            out['lgb'] = lg.encoder_layers[0][0](t(feat)).numpy()       # NCHW out
+            out['lgt'] = lg(t(x_big)).numpy()
+        np.savez_compressed(os.path.join(GOLD, f'ops_c{C}.npz'), **out)
+        manifest[f'ops_c{C}'] = dict(C=C, K=1, salt=0, keys=sorted(out))
+
+    # ---------------------------------------------------------------- whole-net eval forward
+    cases = [
+        dict(name='net_c4_k2_p32', C=4, K=2, B=2, h=8, kind='dn'),
+        dict(name='net_c8_k2_p32', C=8, K=2, B=1, h=8, kind='smooth'),
+        dict(name='net_c4_k4_p64', C=4, K=4, B=1, h=16, kind='smooth'),
+        dict(name='net_c4_k4_p128', C=4, K=4, B=1, h=32, kind='dn'),
+        dict(name='net_c8_k4_p128', C=8, K=4, B=1, h=32, kind='dn'),
+    ]
+    for cs in cases:
+        C, K, B, h = cs['C'], cs['K'], cs['B'], cs['h']
+        ms, pan, gt = dw.make_inputs(B, C, h, h, seed=19971118, kind=cs['kind'])
+        net, _ = build_ref(R, C, K)
+        with torch.no_grad():
+            y32 = net(t(ms), t(pan)).numpy()
+        net64, _ = build_ref(R, C, K, dtype=torch.float64)
+        with torch.no_grad():
+            y64 = net64(t(ms, torch.float64), t(pan, torch.float64)).numpy()
+        import models.base.metrics as mtc
+        o = np.transpose(y32[0], (1, 2, 0)).astype(np.float64) * 2047.5
+        g = np.transpose(gt[0], (1, 2, 0)).astype(np.float64) * 2047.5
+        met = np.array([mtc.psnr(o, g), mtc.sam(o, g), mtc.ergas(o, g)])
+        np.savez_compressed(os.path.join(GOLD, cs['name'] + '.npz'), out_fp32=y32,
+                            out_fp64=y64.astype(np.float32), metrics=met)
+        manifest[cs['name']] = dict(cs, seed=19971118, salt=0,
+                                    rel_fp32_vs_fp64=float(np.linalg.norm(y32 - y64) / np.linalg.norm(y64)))
+        print(cs['name'], 'fp32-vs-fp64 rel', manifest[cs['name']]['rel_fp32_vs_fp64'], 'metrics', met)
+
+    # ---------------------------------------------------------------- gradients (dropout off: eval())
+    for cs in [dict(name='grad_c4_k2_p32', C=4, K=2, B=2, h=8), dict(name='grad_c8_k2_p32', C=8, K=2, B=1, h=8)]:
+        C, K, B, h = cs['C'], cs['K'], cs['B'], cs['h']
+        ms, pan, gt = dw.make_inputs(B, C, h, h, seed=7, kind='smooth')
+        net, _ = build_ref(R, C, K)
+        y = net(t(ms), t(pan))
+        loss = torch.nn.L1Loss()(y, t(gt))
+        loss.backward()
+        grads, none_names = {}, []
+        for k, p in net.named_parameters():
+            if p.grad is None:
+                none_names.append(k)
+            else:
+                grads[k.replace('.', '/')] = p.grad.numpy()
+        np.savez_compressed(os.path.join(GOLD, cs['name'] + '.npz'), loss=np.array(loss.item()), **grads)
+        manifest[cs['name']] = dict(cs, seed=7, kind='smooth', salt=0, none_grad=none_names)
+        print(cs['name'], 'loss', loss.item(), 'live', len(grads), 'none', len(none_names))
+
+    # ---------------------------------------------------------------- runner-level: 3 train_iter
+    # (UnlgFormer.train_iter, Adam + StepLR per iteration, modules kept in eval() -> dropout off)
+    import logging
+    cfg = R.Config(ms_chans=4, work_dir='/tmp/lgteun_gold', datas='GF-2', cuda=False, max_iter=3,
+                   loss_cfg={'rec_loss': dict(type='l1', w=1.)},
+                   optim_cfg={'core_module': dict(type='Adam', betas=(0.9, 0.999), lr=1.5e-3)},
+                   sched_cfg=dict(step_size=2, gamma=0.85),
+                   model_cfg={'core_module': dict(stage=2)})
+    logger = logging.getLogger('gold')
+    runner = R.UnlgFormer(cfg, logger, None, None, None)
+    core = runner.module_dict['core_module']
+    shapes = {k: tuple(v.shape) for k, v in core.state_dict().items()}
+    sd = dw.fill_state_dict(shapes, salt=0)
+    core.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    core.eval()
+    runner.set_optim()
+    runner.set_sched()
+    import mmcv
+    runner.timer = mmcv.Timer()
+    ms, pan, gt = dw.make_inputs(2, 4, 8, 8, seed=11, kind='smooth')
+    losses, lrs = [], []
+    logged = []
+    runner.print_train_log = lambda it, res, freq=10: logged.append(res['full_loss'])
+    for it in range(1, 4):
+        lrs.append(runner.optim_dict['core_module'].param_groups[0]['lr'])
+        runner.train_iter(it, dict(input_lr=t(ms), input_pan=t(pan), target=t(gt), image_id=['a', 'b']))
+        runner.sched_dict['core_module'].step()
+    final = {k.replace('.', '/'): v.detach().numpy() for k, v in core.state_dict().items()
+             if not k.startswith('prior_module.0.')}
+    np.savez_compressed(os.path.join(GOLD, 'train3_c4_k2_p32.npz'), losses=np.array(logged), lrs=np.array(lrs),
+                        **final)
+    manifest['train3_c4_k2_p32'] = dict(C=4, K=2, B=2, h=8, seed=11, kind='smooth', salt=0, step_size=2,
+                                        gamma=0.85, lr=1.5e-3)
+    print('train3 losses', logged, 'lrs', lrs)
+
+    with open(os.path.join(GOLD, 'manifest.json'), 'w') as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print('wrote', GOLD)
+
+
+if __name__ == '__main__':
+    main()
