@@ -1,0 +1,20 @@
+# Builds the gfx950 HIP library (C ABI in include/lgteun_hip.h) in-tree.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := lgteun_amd/csrc
+SRCS  := $(CSRC)/api.hip $(CSRC)/k_pixel.hip $(CSRC)/k_fft.hip $(CSRC)/k_attn.hip $(CSRC)/k_ffn.hip $(CSRC)/k_bwd.hip
+OBJS  := $(SRCS:.hip=.o)
+LIB   := lgteun_amd/_lgteun_hip.so
+FLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+
+all: $(LIB)
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/workspace.h $(CSRC)/backward.h include/lgteun_hip.h
+	$(HIPCC) $(FLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
+
+clean:
+	rm -f $(OBJS) $(LIB)
+.PHONY: all clean

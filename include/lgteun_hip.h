@@ -1,0 +1,102 @@
+/*
+ * lgteun_hip.h -- C ABI of the MI355X-native (gfx950) LGTEUN unfolding hot path.
+ *
+ * The reference (lms-07/LGTEUN) has no FFI: its hot path is a Python nn.Module,
+ *   Pansharpening.forward            models/unlg_former.py:50-67
+ *   LGT.forward and its sub-modules  models/common/LGT.py:64-344
+ *   sampling_/dep_conv/point_conv    models/common/basic_module_unformer_v2.py:13-53
+ *   L1 loss + Adam + StepLR          models/unlg_former.py:87-113, models/base/base_model.py:116-147
+ * This library replaces the ATen op sequences behind those lines.  It is bound from Python with
+ * ctypes (lgteun_amd/_lib.py); INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked host.
+ *  - the caller (PyTorch) owns all memory: parameters, gradients, optimizer state, workspace.
+ *    The library allocates nothing and keeps no mutable global state.
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*); no implicit sync.
+ *  - return value: 0 ok; <0 invalid argument / unsupported shape (see lg_last_error());
+ *    >0 a hipError_t.  Nothing throws across the boundary.
+ *  - parameters live in ONE flat fp32 buffer; `offsets[i]` (in floats) locates the i-th tensor of
+ *    Pansharpening.state_dict() in its canonical order (12 shared, K eta, 119 per stage;
+ *    SURVEY.md section 8b).  Gradients use the same offsets in a second flat buffer.
+ *  - module I/O is NCHW fp32 like the reference: ms [B,C,h,w], pan [B,1,4h,4w], out [B,C,4h,4w].
+ */
+#ifndef LGTEUN_HIP_H
+#define LGTEUN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LG_TENSORS_SHARED 12
+#define LG_TENSORS_PER_STAGE 119
+
+/* flags for lgteun_forward */
+#define LG_FLAG_FAITHFUL 1 /* run every stage's LGT like the reference does (results of stages 0..K-2 are dead) */
+#define LG_FLAG_SAVE 2     /* keep what lgteun_backward needs in the workspace */
+#define LG_FLAG_DROPOUT 4  /* training-mode Dropout(0.1) after LGMixer.proj (LGT.py:198,215), counter-hash RNG */
+
+typedef struct lg_config {
+    int32_t C;       /* MS bands: 4 or 8                      (cfg.ms_chans, unlg_former.py:24) */
+    int32_t K;       /* unfolding stages                      (stage kwarg, unlg_former.py:22)  */
+    int32_t H, W;    /* PAN size = 4 x MS size; multiples of 16, H == W, power of two <= 128 for the FFT mixer */
+    int32_t precision; /* 0 = fp32 storage/compute (parity mode); 1 = bf16 storage of FFN hidden tensors */
+} lg_config;
+
+typedef struct lg_plan lg_plan; /* host-side, immutable after creation */
+
+const char* lg_version(void);
+const char* lg_last_error(void); /* thread-local, host string */
+
+/* offsets: host array of n_offsets = 12 + K + 119*K int64 (float offsets into the flat parameter buffer). */
+int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int32_t n_offsets, lg_plan** out);
+void lg_plan_destroy(lg_plan* plan);
+/* bytes of workspace lgteun_forward/backward need for batch B (forward-only if !train). */
+size_t lg_workspace_bytes(const lg_plan* plan, int32_t B, int32_t train);
+
+/* Pansharpening.forward (unlg_former.py:50-67).  seed: dropout counter seed (used with LG_FLAG_DROPOUT). */
+int lgteun_forward(const lg_plan* plan, const float* params, const float* ms, const float* pan, float* out,
+                   void* workspace, size_t workspace_bytes, int32_t B, int32_t flags, uint64_t seed, void* stream);
+
+/* Backward of the same graph (autograd of unlg_former.py:50-67): needs the workspace of a forward run
+ * with LG_FLAG_SAVE.  dout [B,C,H,W].  Accumulates (+=) into `grads` for the live tensors only
+ * (shared D/DT/R/RT, eta, last stage's LGT); dead-stage slots are never written. */
+int lgteun_backward(const lg_plan* plan, const float* params, float* grads, const float* ms, const float* pan,
+                    const float* dout, void* workspace, size_t workspace_bytes, int32_t B, int32_t flags,
+                    uint64_t seed, void* stream);
+
+/* nn.L1Loss(mean) forward+backward (losses.py:19-40; unlg_former.py:99-104): loss_sum[0] += sum|out-gt|/N and
+ * dout = sign(out-gt) * scale / N.   N = number of elements of the GLOBAL batch (DDP: pass n_global). */
+int lg_l1_loss(const float* out, const float* gt, float* dout, float* loss_accum, int64_t n_local, int64_t n_global,
+               float scale, void* stream);
+
+/* torch.optim.Adam step (base_model.py:123-124; no weight decay / amsgrad) over [begin,end) float ranges of the
+ * flat buffers.  ranges: DEVICE int64 pairs, n_ranges of them (the live tensors).  step is 1-based. */
+int lg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* ranges,
+                 int32_t n_ranges, int64_t max_range, int32_t step, float lr, float beta1, float beta2, float eps,
+                 float grad_scale, void* stream);
+
+/* ---- per-op entry points (unit-tested against the oracle; same kernels the orchestrators launch) ---- */
+/* bmu.sampling_ bicubic (basic_module_unformer_v2.py:21-23): mode 0: x0.5, 1: x2, 2: x4.  x [planes,hi,wi]. */
+int lg_op_resample(const float* x, float* y, int32_t planes, int32_t hi, int32_t wi, int32_t mode, void* stream);
+/* one data step (unlg_former.py:58-61) for stage `stage`: z_in -> z_out [B,C,H,W]; tmp: 3*B*C*H*W/4 floats. */
+int lg_op_data_step(const lg_plan* plan, const float* params, int32_t stage, const float* z_in, const float* ms,
+                    const float* pan, float* z_out, float* tmp, int32_t B, void* stream);
+/* one LGT forward (LGT.py:314-344) with stage `stage`'s weights: z [B,C,H,W] -> out [B,C,H,W]. */
+int lg_op_lgt(const lg_plan* plan, const float* params, int32_t stage, const float* z, float* out, void* workspace,
+              size_t workspace_bytes, int32_t B, int32_t flags, uint64_t seed, void* stream);
+/* pieces of one LGB block `blk` (0,1: encoder; 2: bottleneck; 3,4: decoder) of stage `stage`, on NHWC x:
+ *  which = 0: global_mixer on LN(x)[..., e/2:]  -> y planar [B,e/2,h,w]        (LGT.py:149-180)
+ *          1: x + LGMixer(LN(x))                -> y [B,h,w,e]                 (LGT.py:183-219,231-248)
+ *          2: x + feed_forward(LN(x))           -> y [B,h,w,e]                 (LGT.py:91-109)
+ *  h,w,e are implied by blk (level 0: H,W,4C; level 1: H/2,W/2,8C). */
+int lg_op_block(const lg_plan* plan, const float* params, int32_t stage, int32_t blk, int32_t which, const float* x,
+                float* y, void* workspace, size_t workspace_bytes, int32_t B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,73 @@
+"""ctypes binding of the gfx950 HIP library (C ABI: include/lgteun_hip.h).
+
+Loaded lazily so modules stay picklable (the reference pickles whole module objects,
+models/base/base_model.py:354-369).  There is NO fallback: if the shared object is missing the
+product path raises -- the CPU restatement in oracle/ is test infrastructure only.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, '_lgteun_hip.so')
+
+LG_FLAG_FAITHFUL = 1
+LG_FLAG_SAVE = 2
+LG_FLAG_DROPOUT = 4
+
+
+class LgConfig(ctypes.Structure):
+    _fields_ = [('C', c_int32), ('K', c_int32), ('H', c_int32), ('W', c_int32), ('precision', c_int32)]
+
+
+class LgteunHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/lgteun_hip.h declares
+SIGNATURES = {
+    'lg_version': (c_char_p, []),
+    'lg_last_error': (c_char_p, []),
+    'lg_plan_create': (c_int32, [POINTER(LgConfig), POINTER(c_int64), c_int32, POINTER(c_void_p)]),
+    'lg_plan_destroy': (None, [c_void_p]),
+    'lg_workspace_bytes': (c_size_t, [c_void_p, c_int32, c_int32]),
+    'lgteun_forward': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_int32,
+                                 c_uint64, c_void_p]),
+    'lgteun_backward': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int32,
+                                  c_int32, c_uint64, c_void_p]),
+    'lg_l1_loss': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p]),
+    'lg_adam_step': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_float, c_float,
+                               c_float, c_float, c_float, c_void_p]),
+    'lg_op_resample': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'lg_op_data_step': (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                  c_void_p]),
+    'lg_op_lgt': (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_int32, c_uint64,
+                            c_void_p]),
+    'lg_op_block': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_int32,
+                              c_void_p]),
+}
+
+
+def lib():
+    """Load (once) and return the ctypes library.  Raises LgteunHipError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LgteunHipError(
+                f'HIP extension not built: {LIB_PATH} is missing. Run `make` (or __graft_entry__.build()). '
+                'lgteun_amd has no CPU/PyTorch fallback.')
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().lg_last_error().decode(errors='replace')
+        raise LgteunHipError(f'{what} failed (rc={rc}): {msg}')

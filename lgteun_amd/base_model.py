@@ -1,0 +1,192 @@
+"""Runner counterpart of reference models/base/base_model.py restricted to the hot path's callers:
+add_module :56, set_cuda :91 (one process per GPU + RCCL instead of nn.DataParallel), load_checkpoint :102,
+set_optim :116 (Adam -> fused HIP Adam), set_sched :137 (StepLR stepped EVERY iteration :197-199),
+train :164, test :267 (PSNR/SAM/ERGAS only), save :354."""
+import os.path as osp
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.optim import SGD, Adam, AdamW, RMSprop, lr_scheduler
+
+from . import metrics as mtc
+from .compat import Timer, mkdir_or_exist
+from .losses import get_loss_module
+
+
+def data_normalize(img_dict, bit_depth):
+    """reference dataset/utils.py:232-249"""
+    max_value = 2 ** bit_depth - .5
+    return {k: (v if k == 'image_id' else v / max_value) for k, v in img_dict.items()}
+
+
+def data_denormalize(img, bit_depth):
+    """reference dataset/utils.py:252-263"""
+    return img * (2 ** bit_depth - .5)
+
+
+def smart_time(second):
+    second = int(second)
+    return f'{second // 3600}h {second % 3600 // 60}m {second % 60}s'
+
+
+class Base_model:
+    def __init__(self, cfg, logger, train_data_loader, test_data_loader0, test_data_loader1):
+        self.cfg = cfg
+        self.work_dir = cfg.work_dir
+        self.logger = logger
+        self.train_data_loader = train_data_loader
+        self.test_data_loader0 = test_data_loader0
+        self.test_data_loader1 = test_data_loader1
+        self.datas = cfg.datas
+        mkdir_or_exist(self.work_dir)
+        self.eval_results = {}
+        self.module_dict = {}
+        self.optim_dict = {}
+        self.sched_dict = {}
+        self.switch_dict = {}
+        self.loss_module = get_loss_module(full_cfg=cfg, logger=logger)
+        self.last_iter = 0
+        self.timer = Timer()
+
+    def add_module(self, module_name, module, switch=True):
+        assert isinstance(module, nn.Module)
+        self.module_dict[module_name] = module
+        self.switch_dict[module_name] = switch
+
+    def print_total_params(self):
+        count = sum(sum(p.numel() for p in m.parameters()) for m in self.module_dict.values())
+        self.logger.info(f'total params: {count},{round(count / (1000 ** 2), 4)} M')
+        return count
+
+    def init(self):
+        pass
+
+    def set_cuda(self):
+        """one process per GPU (torch.distributed/RCCL set up by the launcher) -- replaces nn.DataParallel."""
+        dev = torch.device('cuda', torch.cuda.current_device())
+        for name in self.module_dict:
+            self.module_dict[name] = self.module_dict[name].to(dev)
+        for name in self.loss_module:
+            self.loss_module[name] = self.loss_module[name].to(dev)
+
+    def _load_modules(self, checkpoint):
+        for module_name, module in self.module_dict.items():
+            src = checkpoint[module_name]
+            module.load_state_dict(src.state_dict() if hasattr(src, 'state_dict') else src)
+
+    def load_checkpoint(self, path):
+        checkpoint = torch.load(path, weights_only=False)
+        self.last_iter = checkpoint['iter_num']
+        self._load_modules(checkpoint)
+
+    def load_pretrained(self, path):
+        self._load_modules(torch.load(path, weights_only=False))
+
+    def set_optim(self):
+        from .engine import FusedAdam
+        optim_cfg = self.cfg.get('optim_cfg', {})
+        for module_name, module in self.module_dict.items():
+            if module_name in optim_cfg:
+                cfg = dict(optim_cfg[module_name])
+                typ = cfg.pop('type')
+                fused = cfg.pop('fused', True)
+                if typ == 'Adam':
+                    self.optim_dict[module_name] = (FusedAdam if fused else Adam)(module.parameters(), **cfg)
+                elif typ == 'RMSprop':
+                    self.optim_dict[module_name] = RMSprop(module.parameters(), **cfg)
+                elif typ == 'SGD':
+                    self.optim_dict[module_name] = SGD(module.parameters(), **cfg)
+                elif typ == 'AdamW':
+                    self.optim_dict[module_name] = AdamW(module.parameters(), **cfg)
+                else:
+                    raise SystemExit(f'No such type optim:{typ}')
+            else:
+                self.optim_dict[module_name] = Adam(module.parameters(), betas=(0.9, 0.999), lr=1e-4)
+
+    def set_sched(self):
+        sched_cfg = dict(self.cfg.get('sched_cfg', dict(step_size=10000, gamma=0.99)))
+        for name, optim in self.optim_dict.items():
+            self.sched_dict[name] = lr_scheduler.StepLR(optimizer=optim, **sched_cfg)
+
+    def train(self):
+        for freq_str in ['save_freq', 'test_freq', 'eval_freq']:
+            self.cfg.setdefault(freq_str, 10000)
+        self.cfg.setdefault('max_iter', 100000)
+        self.timer = Timer()
+        iter_id = self.last_iter
+        dev = next(iter(self.module_dict.values())).parameters().__next__().device
+        while iter_id < self.cfg.max_iter:
+            for input_batch in self.train_data_loader:
+                input_batch = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in input_batch.items()}
+                if self.cfg.get('norm_input', True):
+                    input_batch = data_normalize(input_batch, self.cfg.bit_depth)
+                iter_id += 1
+                for module in self.module_dict.values():
+                    module.train()
+                self.train_iter(iter_id=iter_id, input_batch=input_batch)
+
+                def should(freq):
+                    return (freq != -1) and (iter_id % freq == 0) and (iter_id != self.cfg.max_iter)
+                if should(self.cfg.save_freq):
+                    self.save(iter_id=iter_id)
+                if should(self.cfg.eval_freq) and self.test_data_loader1 is not None:
+                    self.test(iter_id=iter_id, save=False, ref=True)
+                for name, sched in self.sched_dict.items():
+                    if self.switch_dict[name]:
+                        sched.step()                      # StepLR per ITERATION (base_model.py:197-199)
+                if iter_id == self.cfg.max_iter:
+                    break
+
+    def print_train_log(self, iter_id, loss_res, log_freq=10):
+        if iter_id % log_freq == 0 and self.logger is not None:
+            avg_iter_time = self.timer.since_last_check() / log_freq
+            remain_time = avg_iter_time * (self.cfg.max_iter - iter_id)
+            self.logger.info(f'===> training iteration[{iter_id}/{self.cfg.max_iter}] '
+                             f'lr: {self.optim_dict["core_module"].param_groups[0]["lr"]:.6f}, '
+                             f'ETA: {smart_time(remain_time)}')
+            self.logger.info(f'full loss: {loss_res["full_loss"]:.6f}')
+
+    def get_model_output(self, input_batch):
+        raise NotImplementedError
+
+    def train_iter(self, iter_id, input_batch, log_freq=10):
+        raise NotImplementedError
+
+    @torch.no_grad()
+    def test(self, iter_id, save=False, ref=True):
+        """reduced-resolution evaluation (base_model.py:267-352): PSNR / SAM / ERGAS mean +- std."""
+        loader = self.test_data_loader1 if ref else self.test_data_loader0
+        for module in self.module_dict.values():
+            module.eval()
+        dev = next(iter(self.module_dict.values())).parameters().__next__().device
+        res = []
+        for input_batch in loader:
+            input_batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in input_batch.items()}
+            if self.cfg.get('norm_input', True):
+                input_batch = data_normalize(input_batch, self.cfg.bit_depth)
+            out = self.get_model_output(input_batch)
+            out = data_denormalize(out, self.cfg.bit_depth).permute(0, 2, 3, 1).cpu().numpy()
+            if ref:
+                gt = data_denormalize(input_batch['target'], self.cfg.bit_depth).permute(0, 2, 3, 1).cpu().numpy()
+                for i in range(out.shape[0]):
+                    res.append(mtc.ref_evaluate(out[i], gt[i]))
+        if res:
+            res = np.array(res)
+            self.eval_results = dict(PSNR=(res[:, 0].mean(), res[:, 0].std()), SAM=(res[:, 1].mean(), res[:, 1].std()),
+                                     ERGAS=(res[:, 2].mean(), res[:, 2].std()))
+            if self.logger is not None:
+                self.logger.info(f'iter {iter_id} eval: {self.eval_results}')
+        return self.eval_results
+
+    def save(self, iter_id):
+        """reference pickles whole module objects + iter_num (base_model.py:354-369); additionally stores the
+        optimizer state (absent in the reference)."""
+        mkdir_or_exist(f'{self.work_dir}/{self.datas}')
+        path = osp.join(self.work_dir, self.datas, f'model_iter_{iter_id}.pth')
+        ckpt = {'iter_num': iter_id}
+        for name, module in self.module_dict.items():
+            ckpt[name] = module.module if hasattr(module, 'module') else module
+        ckpt['optim'] = {k: v.state_dict() for k, v in self.optim_dict.items()}
+        torch.save(ckpt, path)
+        return path

@@ -1,0 +1,367 @@
+// C ABI entry points (include/lgteun_hip.h): plan, forward orchestration, per-op entries, L1 loss, Adam.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#include "kernels.h"
+#include "workspace.h"
+#include "backward.h"
+
+static thread_local char g_err[512] = "";
+
+void lg_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* lg_version(void) { return "lgteun_hip 0.1 (gfx950)"; }
+extern "C" const char* lg_last_error(void) { return g_err; }
+
+extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int32_t n_offsets, lg_plan** out) {
+    if (!cfg || !offsets || !out) { lg_set_error("plan_create: null argument"); return -1; }
+    if (cfg->C != 4 && cfg->C != 8) { lg_set_error("plan_create: C must be 4 or 8 (got %d)", cfg->C); return -2; }
+    if (cfg->K < 1 || cfg->K > LG_MAX_K) { lg_set_error("plan_create: K out of range (%d)", cfg->K); return -2; }
+    if (cfg->H % 16 || cfg->W % 16 || cfg->H <= 0 || cfg->W <= 0) { lg_set_error("plan_create: H,W must be positive multiples of 16"); return -2; }
+    if (cfg->H != cfg->W || (cfg->H & (cfg->H - 1)) || cfg->H > 128) {
+        lg_set_error("plan_create: FFT mixer supports square power-of-two PAN sizes <= 128 (got %dx%d)", cfg->H, cfg->W);
+        return -2;
+    }
+    const int expect = S_NSHARED + cfg->K + L_NSLOT * cfg->K;
+    if (n_offsets != expect) { lg_set_error("plan_create: expected %d offsets, got %d", expect, n_offsets); return -2; }
+    for (int i = 0; i < n_offsets; ++i)
+        if (offsets[i] < 0 || (offsets[i] & 3)) { lg_set_error("plan_create: offset %d (=%lld) must be a non-negative multiple of 4 floats", i, (long long)offsets[i]); return -2; }
+    lg_plan* p = new lg_plan;
+    p->cfg = *cfg;
+    p->n_offsets = n_offsets;
+    p->off = (int64_t*)malloc(sizeof(int64_t) * n_offsets);
+    memcpy(p->off, offsets, sizeof(int64_t) * n_offsets);
+    *out = p;
+    return 0;
+}
+
+extern "C" void lg_plan_destroy(lg_plan* plan) {
+    if (!plan) return;
+    free(plan->off);
+    delete plan;
+}
+
+extern "C" size_t lg_workspace_bytes(const lg_plan* plan, int32_t B, int32_t train) {
+    if (!plan || B <= 0) return 0;
+    NetBufs nb;
+    carve(plan, B, train, nullptr, nb);
+    size_t fwd = nb.bytes;
+    if (train) fwd += bwd_workspace_bytes(plan, B);
+    return fwd;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward pieces
+// ------------------------------------------------------------------------------------------------
+static int data_step_fwd(const lg_plan* pl, const float* P, int stage, const float* z_in, const float* ms, const float* pan,
+                         float* z_out, float* t1, float* r, float* s1, int B, hipStream_t s) {
+    const lg_config& c = pl->cfg;
+    const int planes = B * c.C, H = c.H, W = c.W;
+    DwArgs a;
+    memset(&a, 0, sizeof(a));
+    a.C = c.C; a.planes = planes;
+    int rc;
+    // D: x0.5, dw3, x0.5, dw3  (unlg_former.py:29-30) ; then "- ms" (unlg_former.py:58)
+    a.in = z_in; a.out = t1; a.w9 = P + pl->shared(S_D1W); a.bias = P + pl->shared(S_D1B);
+    a.hi = H; a.wi = W; a.ho = H / 2; a.wo = W / 2;
+    if ((rc = launch_resample_dw(0, 0, a, s))) return rc;
+    a.in = t1; a.out = r; a.w9 = P + pl->shared(S_D3W); a.bias = P + pl->shared(S_D3B); a.sub = ms;
+    a.hi = H / 2; a.wi = W / 2; a.ho = H / 4; a.wo = W / 4;
+    if ((rc = launch_resample_dw(0, 1, a, s))) return rc;
+    // DT: x2, dw3, x2, dw3 (unlg_former.py:32-33)
+    a.in = r; a.out = s1; a.w9 = P + pl->shared(S_DT1W); a.bias = P + pl->shared(S_DT1B); a.sub = nullptr;
+    a.hi = H / 4; a.wi = W / 4; a.ho = H / 2; a.wo = W / 2;
+    if ((rc = launch_resample_dw(1, 0, a, s))) return rc;
+    // last DT stage fused with pan term and the update (unlg_former.py:59-61)
+    a.in = s1; a.out = z_out; a.w9 = P + pl->shared(S_DT3W); a.bias = P + pl->shared(S_DT3B);
+    a.z = z_in; a.pan = pan; a.rw = P + pl->shared(S_RW); a.rb = P + pl->shared(S_RB);
+    a.rtw = P + pl->shared(S_RTW); a.rtb = P + pl->shared(S_RTB); a.eta = P + pl->eta(stage);
+    a.hi = H / 2; a.wi = W / 2; a.ho = H; a.wo = W;
+    return launch_resample_dw(1, 2, a, s);
+}
+
+static uint64_t mix_seed(uint64_t seed, int stage, int blk) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(stage * 8 + blk + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+static int block_mixer_fwd(const lg_plan* pl, const float* P, int stage, int j, const BlockBufs& bb, const float* posT, int B,
+                           int flags, uint64_t seed, hipStream_t s) {
+    int rc;
+    FftArgs f;
+    f.g = bb.g; f.o = bb.o2;
+    f.amp = (flags & LG_FLAG_SAVE) ? bb.amp : nullptr;
+    f.pha = (flags & LG_FLAG_SAVE) ? bb.pha : nullptr;
+    f.ampw = P + pl->blk(stage, j, B_AMPW); f.ampb = P + pl->blk(stage, j, B_AMPB);
+    f.phaw = P + pl->blk(stage, j, B_PHAW); f.phab = P + pl->blk(stage, j, B_PHAB);
+    f.ch = bb.e / 2; f.planes = B * f.ch; f.n = bb.h;
+    if ((rc = launch_fftmix(f, s))) return rc;
+    AttnArgs t;
+    t.x = bb.xin; t.o2 = bb.o2; t.y = bb.xmid; t.posT = posT;
+    t.ln1g = P + pl->blk(stage, j, B_LN1G); t.ln1b = P + pl->blk(stage, j, B_LN1B);
+    t.qkvw = P + pl->blk(stage, j, B_QKVW); t.qkvb = P + pl->blk(stage, j, B_QKVB);
+    t.projw = P + pl->blk(stage, j, B_PROJW); t.projb = P + pl->blk(stage, j, B_PROJB);
+    t.B = B; t.h = bb.h; t.w = bb.w;
+    t.dropout = (flags & LG_FLAG_DROPOUT) ? 1 : 0;
+    t.seed = mix_seed(seed, stage, j);
+    return launch_attn(bb.e, t, s);
+}
+
+static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, const BlockBufs& bb, float* g_next, int next_blk,
+                         int B, int flags, hipStream_t s) {
+    int rc;
+    Ffn1Args a1;
+    a1.x = bb.xmid; a1.h1 = (flags & LG_FLAG_SAVE) ? bb.h1 : nullptr; a1.h2 = bb.h2;
+    a1.ln2g = P + pl->blk(stage, j, B_LN2G); a1.ln2b = P + pl->blk(stage, j, B_LN2B);
+    a1.w1 = P + pl->blk(stage, j, B_W1); a1.b1 = P + pl->blk(stage, j, B_B1);
+    a1.w2 = P + pl->blk(stage, j, B_W2); a1.b2 = P + pl->blk(stage, j, B_B2);
+    a1.P = (long)B * bb.h * bb.w;
+    if ((rc = launch_ffn1(bb.e, a1, s))) return rc;
+    Ffn2Args a2;
+    a2.h2 = bb.h2; a2.x = bb.xmid; a2.h3 = (flags & LG_FLAG_SAVE) ? bb.h3 : nullptr; a2.y = bb.xout;
+    a2.g = g_next;
+    a2.dww = P + pl->blk(stage, j, B_DWW); a2.dwb = P + pl->blk(stage, j, B_DWB);
+    a2.w3 = P + pl->blk(stage, j, B_W3); a2.b3 = P + pl->blk(stage, j, B_B3);
+    a2.n1g = g_next ? P + pl->blk(stage, next_blk, B_LN1G) : nullptr;
+    a2.n1b = g_next ? P + pl->blk(stage, next_blk, B_LN1B) : nullptr;
+    a2.B = B; a2.h = bb.h; a2.w = bb.w;
+    return launch_ffn2(bb.e, a2, s);
+}
+
+static int pos_transpose_stage(const lg_plan* pl, const float* P, int stage, float* posT_stage, hipStream_t s) {
+    for (int j = 0; j < 5; ++j) {
+        int rc = launch_pos_transpose(P + pl->blk(stage, j, B_POS), posT_stage + (size_t)j * 2 * 64 * 64, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// LGT.forward (LGT.py:314-344) on z -> out with the buffers of `nb`
+static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z, float* out, NetBufs& nb, int B, int flags,
+                   uint64_t seed, hipStream_t s) {
+    const lg_config& c = pl->cfg;
+    const int E = 4 * c.C;
+    int rc;
+    float* posT = nb.posT + (size_t)stage * 5 * 2 * 64 * 64;
+    if ((rc = pos_transpose_stage(pl, P, stage, posT, s))) return rc;
+    EmbedArgs ea;
+    ea.z = z; ea.x = nb.x0; ea.g = nb.blk[0].g;
+    ea.dww = P + pl->lgt(stage, L_PE_DWW); ea.dwb = P + pl->lgt(stage, L_PE_DWB);
+    ea.w = P + pl->lgt(stage, L_PE_W); ea.b = P + pl->lgt(stage, L_PE_B);
+    ea.lng = P + pl->lgt(stage, L_PE_LNG); ea.lnb = P + pl->lgt(stage, L_PE_LNB);
+    ea.n1g = P + pl->blk(stage, 0, B_LN1G); ea.n1b = P + pl->blk(stage, 0, B_LN1B);
+    ea.HW = c.H * c.W; ea.total = (long)B * c.H * c.W;
+    if ((rc = launch_embed(c.C, ea, s))) return rc;
+    // encoder LGB (2 blocks)
+    if ((rc = block_mixer_fwd(pl, P, stage, 0, nb.blk[0], posT + 0 * 8192, B, flags, seed, s))) return rc;
+    if ((rc = block_ffn_fwd(pl, P, stage, 0, nb.blk[0], nb.blk[1].g, 1, B, flags, s))) return rc;
+    if ((rc = block_mixer_fwd(pl, P, stage, 1, nb.blk[1], posT + 1 * 8192, B, flags, seed, s))) return rc;
+    if ((rc = block_ffn_fwd(pl, P, stage, 1, nb.blk[1], nullptr, 0, B, flags, s))) return rc;
+    // down
+    DownArgs da;
+    da.x = nb.blk[1].xout; da.y = nb.blk[2].xin; da.g = nb.blk[2].g;
+    da.w = P + pl->lgt(stage, L_DOWNW); da.b = P + pl->lgt(stage, L_DOWNB);
+    da.n1g = P + pl->blk(stage, 2, B_LN1G); da.n1b = P + pl->blk(stage, 2, B_LN1B);
+    da.B = B; da.H = c.H; da.W = c.W;
+    if ((rc = launch_down(E, da, s))) return rc;
+    // bottleneck
+    if ((rc = block_mixer_fwd(pl, P, stage, 2, nb.blk[2], posT + 2 * 8192, B, flags, seed, s))) return rc;
+    if ((rc = block_ffn_fwd(pl, P, stage, 2, nb.blk[2], nullptr, 0, B, flags, s))) return rc;
+    // up + fusion
+    UpFuseArgs ua;
+    ua.xb = nb.blk[2].xout; ua.skip = nb.blk[1].xout; ua.y = nb.blk[3].xin; ua.g = nb.blk[3].g;
+    ua.upw = P + pl->lgt(stage, L_UPW); ua.upb = P + pl->lgt(stage, L_UPB);
+    ua.fw = P + pl->lgt(stage, L_FUSEW); ua.fb = P + pl->lgt(stage, L_FUSEB);
+    ua.n1g = P + pl->blk(stage, 3, B_LN1G); ua.n1b = P + pl->blk(stage, 3, B_LN1B);
+    ua.B = B; ua.H = c.H; ua.W = c.W;
+    if ((rc = launch_upfuse(E, ua, s))) return rc;
+    // decoder LGB (2 blocks)
+    if ((rc = block_mixer_fwd(pl, P, stage, 3, nb.blk[3], posT + 3 * 8192, B, flags, seed, s))) return rc;
+    if ((rc = block_ffn_fwd(pl, P, stage, 3, nb.blk[3], nb.blk[4].g, 4, B, flags, s))) return rc;
+    if ((rc = block_mixer_fwd(pl, P, stage, 4, nb.blk[4], posT + 4 * 8192, B, flags, seed, s))) return rc;
+    if ((rc = block_ffn_fwd(pl, P, stage, 4, nb.blk[4], nullptr, 0, B, flags, s))) return rc;
+    // tail
+    TailArgs ta;
+    ta.x = nb.blk[4].xout; ta.z = z; ta.out = out;
+    ta.w = P + pl->lgt(stage, L_TAILW); ta.b = P + pl->lgt(stage, L_TAILB);
+    ta.HW = c.H * c.W; ta.total = (long)B * c.H * c.W;
+    return launch_tail(c.C, ta, s);
+}
+
+extern "C" int lgteun_forward(const lg_plan* plan, const float* params, const float* ms, const float* pan, float* out,
+                              void* workspace, size_t workspace_bytes, int32_t B, int32_t flags, uint64_t seed, void* stream) {
+    if (!plan || !params || !ms || !pan || !out || !workspace || B <= 0) { lg_set_error("forward: null/invalid argument"); return -1; }
+    const int train = (flags & LG_FLAG_SAVE) ? 1 : 0;
+    if (workspace_bytes < lg_workspace_bytes(plan, B, train)) {
+        lg_set_error("forward: workspace too small (%zu < %zu)", workspace_bytes, lg_workspace_bytes(plan, B, train));
+        return -3;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const lg_config& c = plan->cfg;
+    NetBufs nb;
+    carve(plan, B, train, workspace, nb);
+    int rc;
+    // Z0 = bicubic x4 (unlg_former.py:53)
+    if ((rc = launch_resample(2, ms, nb.Z[0], B * c.C, c.H / 4, c.W / 4, s))) return rc;
+    for (int i = 0; i < c.K; ++i) {
+        if ((rc = data_step_fwd(plan, params, i, nb.Z[i], ms, pan, nb.Z[i + 1], nb.t1[i], nb.r[i], nb.s1[i], B, s))) return rc;
+        const bool last = (i == c.K - 1);
+        if (last) {
+            if ((rc = lgt_fwd(plan, params, i, nb.Z[i + 1], out, nb, B, flags, seed, s))) return rc;
+        } else if (flags & LG_FLAG_FAITHFUL) {
+            // the reference executes these LGTs and discards their result (unlg_former.py:63-67)
+            if ((rc = lgt_fwd(plan, params, i, nb.Z[i + 1], nb.deadout, nb, B, flags & ~LG_FLAG_SAVE, seed, s))) return rc;
+        }
+    }
+    return 0;
+}
+
+extern "C" int lgteun_backward(const lg_plan* plan, const float* params, float* grads, const float* ms, const float* pan,
+                               const float* dout, void* workspace, size_t workspace_bytes, int32_t B, int32_t flags, uint64_t seed,
+                               void* stream) {
+    if (!plan || !params || !grads || !ms || !pan || !dout || !workspace || B <= 0) { lg_set_error("backward: null/invalid argument"); return -1; }
+    if (workspace_bytes < lg_workspace_bytes(plan, B, 1)) { lg_set_error("backward: workspace too small"); return -3; }
+    NetBufs nb;
+    carve(plan, B, 1, workspace, nb);
+    return net_backward(plan, params, grads, ms, pan, dout, nb, (char*)workspace + nb.bytes, B, flags, seed, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-op entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int lg_op_resample(const float* x, float* y, int32_t planes, int32_t hi, int32_t wi, int32_t mode, void* stream) {
+    if (!x || !y || planes <= 0 || hi <= 0 || wi <= 0 || mode < 0 || mode > 2) { lg_set_error("op_resample: invalid argument"); return -1; }
+    if (mode == 0 && ((hi & 1) || (wi & 1))) { lg_set_error("op_resample: x0.5 needs even sizes"); return -2; }
+    return launch_resample(mode, x, y, planes, hi, wi, (hipStream_t)stream);
+}
+
+extern "C" int lg_op_data_step(const lg_plan* plan, const float* params, int32_t stage, const float* z_in, const float* ms,
+                               const float* pan, float* z_out, float* tmp, int32_t B, void* stream) {
+    if (!plan || !params || !z_in || !ms || !pan || !z_out || !tmp || stage < 0 || stage >= plan->cfg.K) { lg_set_error("op_data_step: invalid argument"); return -1; }
+    const lg_config& c = plan->cfg;
+    size_t q = (size_t)B * c.C * c.H * c.W / 4;
+    return data_step_fwd(plan, params, stage, z_in, ms, pan, z_out, tmp, tmp + q, tmp + 2 * q, B, (hipStream_t)stream);
+}
+
+extern "C" int lg_op_lgt(const lg_plan* plan, const float* params, int32_t stage, const float* z, float* out, void* workspace,
+                         size_t workspace_bytes, int32_t B, int32_t flags, uint64_t seed, void* stream) {
+    if (!plan || !params || !z || !out || !workspace || stage < 0 || stage >= plan->cfg.K) { lg_set_error("op_lgt: invalid argument"); return -1; }
+    const int train = (flags & LG_FLAG_SAVE) ? 1 : 0;
+    if (workspace_bytes < lg_workspace_bytes(plan, B, train)) { lg_set_error("op_lgt: workspace too small"); return -3; }
+    NetBufs nb;
+    carve(plan, B, train, workspace, nb);
+    return lgt_fwd(plan, params, stage, z, out, nb, B, flags, seed, (hipStream_t)stream);
+}
+
+extern "C" int lg_op_block(const lg_plan* plan, const float* params, int32_t stage, int32_t blk, int32_t which, const float* x,
+                           float* y, void* workspace, size_t workspace_bytes, int32_t B, void* stream) {
+    if (!plan || !params || !x || !y || !workspace || stage < 0 || stage >= plan->cfg.K || blk < 0 || blk > 4 || which < 0 || which > 2) {
+        lg_set_error("op_block: invalid argument");
+        return -1;
+    }
+    if (workspace_bytes < lg_workspace_bytes(plan, B, 0)) { lg_set_error("op_block: workspace too small"); return -3; }
+    hipStream_t s = (hipStream_t)stream;
+    NetBufs nb;
+    carve(plan, B, 0, workspace, nb);
+    BlockBufs bb = nb.blk[blk];
+    int rc;
+    const size_t npix = (size_t)B * bb.h * bb.w;
+    if (which == 0 || which == 1) {
+        // LN1 + planar split of the global half (normally emitted by the producing kernel's epilogue)
+        if ((rc = launch_ln_split(bb.e, x, params + plan->blk(stage, blk, B_LN1G), params + plan->blk(stage, blk, B_LN1B), bb.g, B,
+                                  bb.h * bb.w, s)))
+            return rc;
+    }
+    if (which == 0) {
+        FftArgs f;
+        f.g = bb.g; f.o = y; f.amp = nullptr; f.pha = nullptr;
+        f.ampw = params + plan->blk(stage, blk, B_AMPW); f.ampb = params + plan->blk(stage, blk, B_AMPB);
+        f.phaw = params + plan->blk(stage, blk, B_PHAW); f.phab = params + plan->blk(stage, blk, B_PHAB);
+        f.ch = bb.e / 2; f.planes = B * f.ch; f.n = bb.h;
+        return launch_fftmix(f, s);
+    }
+    if (which == 1) {
+        float* posT = nb.posT;
+        if ((rc = launch_pos_transpose(params + plan->blk(stage, blk, B_POS), posT, s))) return rc;
+        bb.xin = const_cast<float*>(x);
+        bb.xmid = y;
+        return block_mixer_fwd(plan, params, stage, blk, bb, posT, B, 0, 0, s);
+    }
+    bb.xmid = const_cast<float*>(x);
+    bb.xout = y;
+    (void)npix;
+    return block_ffn_fwd(plan, params, stage, blk, bb, nullptr, 0, B, 0, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// L1 loss (mean) forward + backward -- models/base/losses.py:19-40, unlg_former.py:99-104
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_l1(const float* __restrict__ out, const float* __restrict__ gt, float* __restrict__ dout,
+                                            float* loss_accum, long n, float inv_n, float gscale) {
+    float part = 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        float d = out[i] - gt[i];
+        part += fabsf(d);
+        dout[i] = (d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_accum, (sm[0] + sm[1] + sm[2] + sm[3]) * inv_n);
+}
+
+extern "C" int lg_l1_loss(const float* out, const float* gt, float* dout, float* loss_accum, int64_t n_local, int64_t n_global,
+                          float scale, void* stream) {
+    if (!out || !gt || !dout || !loss_accum || n_local <= 0 || n_global <= 0) { lg_set_error("l1_loss: invalid argument"); return -1; }
+    int grid = (int)((n_local + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    k_l1<<<grid, 256, 0, (hipStream_t)stream>>>(out, gt, dout, loss_accum, n_local, 1.0f / (float)n_global, scale / (float)n_global);
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam single-tensor semantics) over ranges of the flat buffers
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, const int64_t* __restrict__ ranges, float step_size, float b1,
+                                              float b2, float inv_bc2_sqrt, float eps, float gscale) {
+    const int64_t lo = ranges[2 * blockIdx.y], hi = ranges[2 * blockIdx.y + 1];
+    for (int64_t i = lo + blockIdx.x * 256L + threadIdx.x; i < hi; i += (int64_t)gridDim.x * 256L) {
+        float gi = g[i] * gscale;
+        float mi = b1 * m[i] + (1.0f - b1) * gi;
+        float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+extern "C" int lg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* ranges,
+                            int32_t n_ranges, int64_t max_range, int32_t step, float lr, float beta1, float beta2, float eps,
+                            float grad_scale, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !ranges || n_ranges <= 0 || step < 1) { lg_set_error("adam_step: invalid argument"); return -1; }
+    double bc1 = 1.0 - pow((double)beta1, (double)step);
+    double bc2 = 1.0 - pow((double)beta2, (double)step);
+    int gx = (int)((max_range + 255) / 256);
+    if (gx < 1) gx = 1;
+    if (gx > 512) gx = 512;
+    dim3 grid(gx, n_ranges);
+    k_adam<<<grid, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, ranges, (float)(lr / bc1), beta1, beta2,
+                                                   (float)(1.0 / sqrt(bc2)), eps, grad_scale);
+    LG_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,8 @@
+// Backward orchestration (autograd of Pansharpening.forward, reference models/unlg_former.py:50-67).
+#pragma once
+#include "common.h"
+#include "workspace.h"
+
+size_t bwd_workspace_bytes(const lg_plan* plan, int B);
+int net_backward(const lg_plan* plan, const float* params, float* grads, const float* ms, const float* pan, const float* dout,
+                 NetBufs& nb, void* bwd_ws, int B, int flags, uint64_t seed, hipStream_t s);

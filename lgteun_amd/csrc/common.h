@@ -1,0 +1,133 @@
+// Shared host/device definitions for the gfx950 LGTEUN kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/lgteun_hip.h"
+
+// ----------------------------------------------------------------------------------------------
+// parameter slots, in Pansharpening.state_dict() order (reference models/unlg_former.py:22-48,
+// models/common/LGT.py:252-303; key list in SURVEY.md section 8b)
+// ----------------------------------------------------------------------------------------------
+enum SharedSlot { S_D1W, S_D1B, S_D3W, S_D3B, S_DT1W, S_DT1B, S_DT3W, S_DT3B, S_RW, S_RB, S_RTW, S_RTB, S_NSHARED };
+
+// one LGB block = 21 tensors: LGMixer (11) then feed_forward (10)
+enum BlockSlot {
+    B_POS, B_QKVW, B_QKVB, B_AMPW, B_AMPB, B_PHAW, B_PHAB, B_PROJW, B_PROJB, B_LN1G, B_LN1B,
+    B_W1, B_B1, B_W2, B_B2, B_DWW, B_DWB, B_W3, B_B3, B_LN2G, B_LN2B, B_NSLOT
+};
+// LGT-level layout: patch_embed(6) enc0(21) enc1(21) down(2) bott(21) up(2) fuse(2) dec0(21) dec1(21) tail(2)
+enum LgtSlot {
+    L_PE_DWW = 0, L_PE_DWB, L_PE_W, L_PE_B, L_PE_LNG, L_PE_LNB,
+    L_ENC0 = 6, L_ENC1 = 27, L_DOWNW = 48, L_DOWNB, L_BOTT = 50, L_UPW = 71, L_UPB, L_FUSEW, L_FUSEB,
+    L_DEC0 = 75, L_DEC1 = 96, L_TAILW = 117, L_TAILB, L_NSLOT = 119
+};
+static inline int block_base(int blk) {
+    const int b[5] = {L_ENC0, L_ENC1, L_BOTT, L_DEC0, L_DEC1};
+    return b[blk];
+}
+
+struct lg_plan {
+    lg_config cfg;
+    int n_offsets;
+    int64_t* off;  // host copy of offsets
+    int64_t shared(int s) const { return off[s]; }
+    int64_t eta(int i) const { return off[S_NSHARED + i]; }
+    int64_t lgt(int stage, int slot) const { return off[S_NSHARED + cfg.K + stage * L_NSLOT + slot]; }
+    int64_t blk(int stage, int b, int slot) const { return lgt(stage, block_base(b) + slot); }
+};
+
+void lg_set_error(const char* fmt, ...);
+
+#define LG_CHECK_LAUNCH()                                                              \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess) {                                                       \
+            lg_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+            return (int)e__;                                                           \
+        }                                                                              \
+    } while (0)
+
+#define LG_EPS 1e-5f
+
+#ifdef __HIPCC__
+// ----------------------------------------------------------------------------------------------
+// device helpers
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// d gelu / dx = Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// cubic-convolution weights, A = -0.75 (torch upsample_bicubic2d); taps at i0-1 .. i0+2.
+// All t used here are dyadic, so these are exact in fp32.
+__device__ __forceinline__ void cubic_w(float t, float w[4]) {
+    const float A = -0.75f;
+    float x;
+    x = t + 1.0f; w[0] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+    x = t;        w[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    x = 1.0f - t; w[2] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    x = 2.0f - t; w[3] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+}
+// 1-D resampling plan for output index o (F.interpolate bicubic, align_corners=False,
+// scale given): MODE 0: x0.5, 1: x2, 2: x4.  i0 = floor(src), t = src - i0.
+template <int MODE>
+__device__ __forceinline__ void resample_plan(int o, int& i0, float w[4]) {
+    if (MODE == 0) { i0 = 2 * o; cubic_w(0.5f, w); }
+    else if (MODE == 1) {
+        int m = o >> 1;
+        if (o & 1) { i0 = m; cubic_w(0.25f, w); } else { i0 = m - 1; cubic_w(0.75f, w); }
+    } else {
+        int m = o >> 2, r = o & 3;
+        if (r == 0) { i0 = m - 1; cubic_w(0.625f, w); }
+        else if (r == 1) { i0 = m - 1; cubic_w(0.875f, w); }
+        else if (r == 2) { i0 = m; cubic_w(0.125f, w); }
+        else { i0 = m; cubic_w(0.375f, w); }
+    }
+}
+// resampled value at output (oy,ox) of a plane [hi][wi]
+template <int MODE>
+__device__ __forceinline__ float resample_at(const float* __restrict__ p, int hi, int wi, int oy, int ox) {
+    int iy0, ix0;
+    float wy[4], wx[4];
+    resample_plan<MODE>(oy, iy0, wy);
+    resample_plan<MODE>(ox, ix0, wx);
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        int yy = clampi(iy0 - 1 + a, 0, hi - 1);
+        float r = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) r += wx[b] * p[yy * wi + clampi(ix0 - 1 + b, 0, wi - 1)];
+        acc += wy[a] * r;
+    }
+    return acc;
+}
+
+template <int E>
+__device__ __forceinline__ void ln_stats(const float (&x)[E], float& mu, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < E; ++i) s += x[i];
+    mu = s * (1.0f / E);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < E; ++i) { float d = x[i] - mu; v += d * d; }
+    rstd = 1.0f / sqrtf(v * (1.0f / E) + LG_EPS);
+}
+
+// counter-hash RNG for dropout: keep-mask of element idx under seed (keep prob 0.9)
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    // 24 random bits -> uniform [0,1)
+    float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+    return u < 0.1f ? 0.0f : (1.0f / 0.9f);
+}
+#endif  // __HIPCC__

@@ -1,0 +1,167 @@
+// Local (window) mixer + LGMixer projection + residual for gfx950.
+// Reference: models/common/LGT.py:112-146 (local_mixer), 183-219 (LGMixer), 45-61,231-248 (pre_norm/residual).
+//
+// One wavefront = one 8x8 window: lane i is token i (64 tokens = 64 lanes, the CDNA wave width).  Each lane
+// LayerNorms its own pixel, makes its q/k/v (1x1 conv = per-pixel matvec with wave-uniform weights), parks k/v
+// in LDS, then walks the 64 keys: scores, softmax and the A.V sum stay in the lane's registers (no score
+// tensor ever reaches memory; the reference materialises B*nW*2*64*64 floats per block).  The same lane then
+// concatenates the global-mixer output of its pixel, applies proj (+dropout) and the residual.
+// A workgroup is 4 waves = 4 horizontally adjacent windows and loops over window quads (pos_emb^T stays in LDS).
+#include "kernels.h"
+
+template <int HC>
+__global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) {
+    constexpr int E = 2 * HC, D = HC / 2;
+    extern __shared__ float smem[];
+    float* sPos = smem;                       // [2][64][64]  posT[h][j][i]
+    float* sK = smem + 2 * 64 * 64;           // [4][64][HC]
+    float* sV = sK + 4 * 64 * HC;             // [4][64][HC]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 2 * 64 * 64; i += 256) sPos[i] = a.posT[i];
+    const int nwx = a.w >> 3, nwy = a.h >> 3;
+    const float scale = (float)(1.0 / sqrt((double)D));
+    float* myK = sK + wave * 64 * HC;
+    float* myV = sV + wave * 64 * HC;
+    for (int quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
+        const int win = quad * 4 + wave;
+        const bool active = win < nwin;
+        long p = 0, b = 0;
+        int y = 0, x = 0;
+        float q[HC];
+        __syncthreads();  // previous iteration's readers of sK/sV are done; sPos is loaded
+        if (active) {
+            int wx = win % nwx;
+            int r = win / nwx;
+            int wy = r % nwy;
+            b = r / nwy;
+            y = wy * 8 + (lane >> 3);
+            x = wx * 8 + (lane & 7);
+            p = (b * a.h + y) * (long)a.w + x;
+            float xv[E];
+            const float4* src = reinterpret_cast<const float4*>(a.x + p * E);
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) {
+                float4 v = src[k];
+                xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
+            }
+            float mu, rstd;
+            ln_stats<E>(xv, mu, rstd);
+            float y1[HC];
+#pragma unroll
+            for (int c = 0; c < HC; ++c) y1[c] = (xv[c] - mu) * rstd * a.ln1g[c] + a.ln1b[c];
+            // to_qkv: rows [0,HC) q, [HC,2HC) k, [2HC,3HC) v   (LGT.py:136 chunk order)
+#pragma unroll
+            for (int c = 0; c < HC; ++c) {
+                float vq = 0.f, vk = 0.f, vv = 0.f;
+#pragma unroll
+                for (int k = 0; k < HC; ++k) {
+                    vq += a.qkvw[c * HC + k] * y1[k];
+                    vk += a.qkvw[(HC + c) * HC + k] * y1[k];
+                    vv += a.qkvw[(2 * HC + c) * HC + k] * y1[k];
+                }
+                q[c] = (vq + a.qkvb[c]) * scale;
+                myK[lane * HC + c] = vk + a.qkvb[HC + c];
+                myV[lane * HC + c] = vv + a.qkvb[2 * HC + c];
+            }
+        }
+        __syncthreads();
+        if (active) {
+            float o1[HC];
+#pragma unroll
+            for (int hd = 0; hd < 2; ++hd) {
+                float sc[64];
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int j = 0; j < 64; ++j) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) s += q[hd * D + c] * myK[j * HC + hd * D + c];
+                    s += sPos[(hd * 64 + j) * 64 + lane];
+                    sc[j] = s;
+                    mx = fmaxf(mx, s);
+                }
+                float l = 0.f;
+                float acc[D];
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc[c] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 64; ++j) {
+                    float pj = expf(sc[j] - mx);
+                    l += pj;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) acc[c] += pj * myV[j * HC + hd * D + c];
+                }
+                float inv = 1.0f / l;
+#pragma unroll
+                for (int c = 0; c < D; ++c) o1[hd * D + c] = acc[c] * inv;
+            }
+            // global-mixer half of the concat (planar)
+            float o2[HC];
+            const long hw = (long)a.h * a.w;
+            const long s = (long)y * a.w + x;
+#pragma unroll
+            for (int c = 0; c < HC; ++c) o2[c] = a.o2[(b * HC + c) * hw + s];
+            // proj (E x E), dropout, residual -- in chunks of 4 outputs
+            const float4* xs = reinterpret_cast<const float4*>(a.x + p * E);
+            float4* yo = reinterpret_cast<float4*>(a.y + p * E);
+#pragma unroll
+            for (int n4 = 0; n4 < E / 4; ++n4) {
+                float o[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int n = n4 * 4 + u;
+                    float v = 0.f;
+#pragma unroll
+                    for (int k = 0; k < HC; ++k) v += a.projw[n * E + k] * o1[k];
+#pragma unroll
+                    for (int k = 0; k < HC; ++k) v += a.projw[n * E + HC + k] * o2[k];
+                    v += a.projb[n];
+                    if (a.dropout) v *= dropout_scale(a.seed, (uint64_t)(p * E + n));
+                    o[u] = v;
+                }
+                float4 xr = xs[n4];
+                yo[n4] = make_float4(xr.x + o[0], xr.y + o[1], xr.z + o[2], xr.w + o[3]);
+            }
+        }
+    }
+}
+
+__global__ void k_pos_transpose(const float* __restrict__ pos, float* __restrict__ posT) {
+    // pos [2][64][64] (h,i,j) -> posT [2][64][64] (h,j,i)
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 2 * 64 * 64) {
+        int h = i >> 12, r = (i >> 6) & 63, c = i & 63;
+        posT[(h * 64 + c) * 64 + r] = pos[i];
+    }
+}
+int launch_pos_transpose(const float* pos, float* posT, hipStream_t s) {
+    k_pos_transpose<<<32, 256, 0, s>>>(pos, posT);
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int HC>
+static int launch_attn_t(const AttnArgs& a, hipStream_t s) {
+    int nwin = a.B * (a.h / 8) * (a.w / 8);
+    int nquads = (nwin + 3) / 4;
+    size_t lds = (2 * 64 * 64 + 2 * 4 * 64 * HC) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn<HC>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) { lg_set_error("attn: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    int grid = nquads < 2048 ? nquads : 2048;
+    k_attn<HC><<<grid, 256, lds, s>>>(a, nwin, nquads);
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_attn(int e, const AttnArgs& a, hipStream_t s) {
+    if ((a.h & 7) || (a.w & 7)) { lg_set_error("attn: h,w must be multiples of 8"); return -2; }
+    if (e == 16) return launch_attn_t<8>(a, s);
+    if (e == 32) return launch_attn_t<16>(a, s);
+    if (e == 64) return launch_attn_t<32>(a, s);
+    lg_set_error("attn: e=%d unsupported", e);
+    return -1;
+}

@@ -1,0 +1,132 @@
+// Global (FFT amplitude/phase) mixer for gfx950 -- reference models/common/LGT.py:149-180.
+//
+// One workgroup owns one (sample, channel) plane n x n and keeps it in LDS as a complex n x n image
+// (n = 128: 128 KiB of the CU's 160 KiB).  rfft2 is restated as fft_H(rfft_W(x)) and irfft2 as
+// irfft_W(ifft_H(X)): forward radix-2 DIF leaves bins in bit-reversed positions, the
+// amplitude/phase edit is pointwise so it does not care, and the inverse radix-2 DIT consumes bit-reversed
+// input -- no reordering pass.  Only columns kx <= n/2 go through the column transforms (half spectrum);
+// rows are Hermitian-extended before the last (row) inverse, with Im of the kx = 0 and kx = n/2 columns
+// dropped exactly as a c2r transform does.  The four purely-real bins get +0.0 imaginary parts so that
+// angle() takes the same branch as pocketfft's r2c (+pi for negative DC).  fp32 throughout.
+#include "kernels.h"
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+__device__ __forceinline__ float2 cmulc(float2 a, float2 w) { return make_float2(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y); }
+
+// batched in-place radix-2 butterflies over LDS.  `lines` transforms of length n; element i of line l is at
+// buf[l * ls + i * es].  Lines for which skip(l) is true are left untouched.
+template <bool INVERSE, bool COLS>
+__device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int n, int lg) {
+    const int half = n >> 1;
+    const int items = n * half;
+    for (int st = 0; st < lg; ++st) {
+        const int m = INVERSE ? (1 << st) : (half >> st);
+        const int twstep = half / m;  // n / (2m)
+        for (int it = threadIdx.x; it < items; it += blockDim.x) {
+            int line, t;
+            if (COLS) { t = it / n; line = it - t * n; } else { line = it / half; t = it - line * half; }
+            if (COLS) {
+                int kx = (int)(__brev((unsigned)line) >> (32 - lg));
+                if (kx > half) continue;
+            }
+            int blk = t / m, j = t - blk * m;
+            int i0 = blk * 2 * m + j, i1 = i0 + m;
+            int a0 = COLS ? (i0 * n + line) : (line * n + i0);
+            int a1 = COLS ? (i1 * n + line) : (line * n + i1);
+            float2 w = tw[j * twstep];
+            float2 a = buf[a0], b = buf[a1];
+            if (!INVERSE) {
+                float2 d = make_float2(a.x - b.x, a.y - b.y);
+                buf[a0] = make_float2(a.x + b.x, a.y + b.y);
+                buf[a1] = cmul(d, w);
+            } else {
+                float2 bw = cmulc(b, w);
+                buf[a0] = make_float2(a.x + bw.x, a.y + bw.y);
+                buf[a1] = make_float2(a.x - bw.x, a.y - bw.y);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_fftmix(FftArgs a, int lg) {
+    extern __shared__ float2 smem2[];
+    const int n = a.n, half = n >> 1;
+    float2* buf = smem2;          // [n][n]
+    float2* tw = smem2 + n * n;   // [n/2]  exp(-2 pi i k / n)
+    const int plane = blockIdx.x;
+    const int ch = plane % a.ch;
+    const float* g = a.g + (size_t)plane * n * n;
+    for (int k = threadIdx.x; k < half; k += blockDim.x) {
+        float ang = 2.0f * (float)k / (float)n;
+        tw[k] = make_float2(cospif(ang), 0.0f - sinpif(ang));
+    }
+    for (int i = threadIdx.x; i < n * n; i += blockDim.x) buf[i] = make_float2(g[i], 0.0f);
+    __syncthreads();
+    // ---- rfft2: rows then columns
+    fft_pass<false, false>(buf, tw, n, lg);
+    for (int y = threadIdx.x; y < n; y += blockDim.x) { buf[y * n + 0].y = 0.0f; buf[y * n + 1].y = 0.0f; }  // kx = 0, n/2 are real
+    __syncthreads();
+    fft_pass<false, true>(buf, tw, n, lg);
+    if (threadIdx.x < 4) buf[(threadIdx.x >> 1) * n + (threadIdx.x & 1)].y = 0.0f;  // the four purely-real bins
+    __syncthreads();
+    // ---- amplitude / phase edit (LGT.py:168-177)
+    const float aw = a.ampw[ch], ab = a.ampb[ch], pw = a.phaw[ch], pb = a.phab[ch];
+    for (int it = threadIdx.x; it < n * n; it += blockDim.x) {
+        int q = it / n, p = it - q * n;
+        int kx = (int)(__brev((unsigned)p) >> (32 - lg));
+        if (kx > half) continue;
+        float2 f = buf[it];
+        float amp = hypotf(f.x, f.y);
+        float pha = atan2f(f.y, f.x);
+        if (a.amp) {
+            int ky = (int)(__brev((unsigned)q) >> (32 - lg));
+            size_t o = ((size_t)plane * n + ky) * (half + 1) + kx;
+            a.amp[o] = amp;
+            a.pha[o] = pha;
+        }
+        float am = aw * amp + ab;
+        float ph = pw * pha + pb;
+        float sn, cs;
+        sincosf(ph, &sn, &cs);
+        float re = (am * cs + 1e-8f) + 1e-8f;
+        float im = am * sn + 1e-8f;
+        buf[it] = make_float2(re, im);
+    }
+    __syncthreads();
+    // ---- irfft2: columns (complex), Hermitian extension, rows
+    fft_pass<true, true>(buf, tw, n, lg);
+    for (int it = threadIdx.x; it < n * (half + 1); it += blockDim.x) {
+        int y = it / (half + 1), kx = it - y * (half + 1);
+        int p = (int)(__brev((unsigned)kx) >> (32 - lg));
+        if (kx == 0 || kx == half) {
+            buf[y * n + p].y = 0.0f;
+        } else {
+            int pm = (int)(__brev((unsigned)(n - kx)) >> (32 - lg));
+            float2 v = buf[y * n + p];
+            buf[y * n + pm] = make_float2(v.x, -v.y);
+        }
+    }
+    __syncthreads();
+    fft_pass<true, false>(buf, tw, n, lg);
+    const float sc = 1.0f / ((float)n * (float)n);
+    float* o = a.o + (size_t)plane * n * n;
+    for (int i = threadIdx.x; i < n * n; i += blockDim.x) o[i] = fabsf(buf[i].x * sc);
+}
+
+int launch_fftmix(const FftArgs& a, hipStream_t s) {
+    int n = a.n, lg = 0;
+    while ((1 << lg) < n) ++lg;
+    if ((1 << lg) != n || n < 8 || n > 128) { lg_set_error("fftmix: plane size %d unsupported (power of two, 8..128)", n); return -2; }
+    size_t lds = ((size_t)n * n + n / 2) * sizeof(float2);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_fftmix, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        if (e != hipSuccess) { lg_set_error("fftmix: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    int threads = n >= 128 ? 1024 : (n >= 64 ? 512 : 256);
+    k_fftmix<<<a.planes, threads, lds, s>>>(a, lg);
+    LG_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,346 @@
+// Pixelwise / resampling kernels of the LGTEUN hot path for gfx950.
+//  - data module D / DT / R / RT and the proximal-gradient update (reference models/unlg_former.py:29-37,58-61)
+//  - LGT patch_embed, down, up+fusion, tail (reference models/common/LGT.py:64-88,280-281,294-295,302-303,337-342)
+// Activations inside an LGT are NHWC (one pixel = one contiguous channel vector); the data module works on
+// NCHW fp32 planes (C is 4 or 8).  One thread per pixel; weights are wave-uniform (scalar loads).
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// plain bicubic resample of planes (bmu.sampling_, basic_module_unformer_v2.py:21-23)
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_resample(const float* __restrict__ x, float* __restrict__ y, int planes, int hi,
+                                                  int wi, int ho, int wo) {
+    long total = (long)planes * ho * wo;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        int ox = (int)(i % wo);
+        long r = i / wo;
+        int oy = (int)(r % ho);
+        long p = r / ho;
+        y[i] = resample_at<MODE>(x + p * hi * wi, hi, wi, oy, ox);
+    }
+}
+
+int launch_resample(int mode, const float* x, float* y, int planes, int hi, int wi, hipStream_t s) {
+    int ho, wo;
+    if (mode == 0) { ho = hi / 2; wo = wi / 2; } else if (mode == 1) { ho = hi * 2; wo = wi * 2; } else { ho = hi * 4; wo = wi * 4; }
+    long total = (long)planes * ho * wo;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (mode == 0) k_resample<0><<<grid, 256, 0, s>>>(x, y, planes, hi, wi, ho, wo);
+    else if (mode == 1) k_resample<1><<<grid, 256, 0, s>>>(x, y, planes, hi, wi, ho, wo);
+    else k_resample<2><<<grid, 256, 0, s>>>(x, y, planes, hi, wi, ho, wo);
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bicubic resample followed by depthwise 3x3 (zero padding) -- one stage of D or DT, LDS-tiled:
+// a 32x32 output tile needs the 34x34 resampled halo tile (zero outside the image).
+// ------------------------------------------------------------------------------------------------
+template <int MODE, int EPI>
+__global__ __launch_bounds__(256) void k_resample_dw(DwArgs a) {
+    __shared__ float U[34][35];
+    const int plane = blockIdx.z;
+    const int c = plane % a.C;
+    const int b = plane / a.C;
+    const int ty0 = blockIdx.y * 32, tx0 = blockIdx.x * 32;
+    const float* in = a.in + (size_t)plane * a.hi * a.wi;
+    for (int i = threadIdx.x; i < 34 * 34; i += 256) {
+        int uy = i / 34, ux = i - uy * 34;
+        int oy = ty0 + uy - 1, ox = tx0 + ux - 1;
+        float v = 0.f;
+        if (oy >= 0 && oy < a.ho && ox >= 0 && ox < a.wo) v = resample_at<MODE>(in, a.hi, a.wi, oy, ox);
+        U[uy][ux] = v;
+    }
+    __syncthreads();
+    float w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = a.w9[c * 9 + k];
+    const float bias = a.bias[c];
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        int ly = i >> 5, lx = i & 31;
+        int oy = ty0 + ly, ox = tx0 + lx;
+        if (oy < a.ho && ox < a.wo) {
+            float v = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) v += w[dy * 3 + dx] * U[ly + dy][lx + dx];
+            v += bias;
+            size_t o = ((size_t)plane * a.ho + oy) * a.wo + ox;
+            if (EPI == 1) v -= a.sub[o];
+            if (EPI == 2) {
+                // Z <- Z - eta * (ms_term + RT(R(Z) - pan))      unlg_former.py:59-61
+                size_t hw = (size_t)a.ho * a.wo;
+                size_t pix = (size_t)oy * a.wo + ox;
+                float rz = a.rb[0];
+                for (int cc = 0; cc < a.C; ++cc) rz += a.rw[cc] * a.z[((size_t)b * a.C + cc) * hw + pix];
+                float pan_term = a.rtw[c] * (rz - a.pan[(size_t)b * hw + pix]) + a.rtb[c];
+                v = a.z[o] - a.eta[0] * (v + pan_term);
+            }
+            a.out[o] = v;
+        }
+    }
+}
+
+int launch_resample_dw(int mode, int epi, const DwArgs& a, hipStream_t s) {
+    dim3 grid((a.wo + 31) / 32, (a.ho + 31) / 32, a.planes);
+#define LG_RDW(M, E) k_resample_dw<M, E><<<grid, 256, 0, s>>>(a)
+    if (mode == 0 && epi == 0) LG_RDW(0, 0);
+    else if (mode == 0 && epi == 1) LG_RDW(0, 1);
+    else if (mode == 1 && epi == 0) LG_RDW(1, 0);
+    else if (mode == 1 && epi == 2) LG_RDW(1, 2);
+    else { lg_set_error("resample_dw: unsupported mode/epi %d/%d", mode, epi); return -1; }
+#undef LG_RDW
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// helper: emit the LayerNorm-ed global half of a pixel vector as planar [B,E/2,H,W]
+// (input of the next block's FFT mixer; LN over all E channels, LGT.py:58,203-206)
+// ------------------------------------------------------------------------------------------------
+template <int E>
+__device__ __forceinline__ void emit_g(const float (&x)[E], const float* __restrict__ n1g, const float* __restrict__ n1b,
+                                       float* __restrict__ g, long b, long s, long HW) {
+    float mu, rstd;
+    ln_stats<E>(x, mu, rstd);
+#pragma unroll
+    for (int n = E / 2; n < E; ++n) g[(b * (E / 2) + (n - E / 2)) * HW + s] = (x[n] - mu) * rstd * n1g[n] + n1b[n];
+}
+
+// ------------------------------------------------------------------------------------------------
+// patch_embedding (patch_size 1): dw1x1 -> 1x1 C->E -> LayerNorm(E)        LGT.py:64-88
+// ------------------------------------------------------------------------------------------------
+template <int C, int E>
+__global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
+    long p = blockIdx.x * 256L + threadIdx.x;
+    if (p >= a.total) return;
+    long b = p / a.HW, s = p - b * a.HW;
+    float t[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) t[c] = a.z[(b * C + c) * a.HW + s] * a.dww[c] + a.dwb[c];
+    float e[E];
+#pragma unroll
+    for (int n = 0; n < E; ++n) {
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) v += a.w[n * C + c] * t[c];
+        e[n] = v + a.b[n];
+    }
+    float mu, rstd;
+    ln_stats<E>(e, mu, rstd);
+#pragma unroll
+    for (int n = 0; n < E; ++n) e[n] = (e[n] - mu) * rstd * a.lng[n] + a.lnb[n];
+    float4* xo = reinterpret_cast<float4*>(a.x + p * E);
+#pragma unroll
+    for (int n = 0; n < E / 4; ++n) xo[n] = make_float4(e[4 * n], e[4 * n + 1], e[4 * n + 2], e[4 * n + 3]);
+    if (a.g) emit_g<E>(e, a.n1g, a.n1b, a.g, b, s, a.HW);
+}
+
+int launch_embed(int C, const EmbedArgs& a, hipStream_t s) {
+    int grid = (int)((a.total + 255) / 256);
+    if (C == 4) k_embed<4, 16><<<grid, 256, 0, s>>>(a);
+    else if (C == 8) k_embed<8, 32><<<grid, 256, 0, s>>>(a);
+    else { lg_set_error("embed: C=%d unsupported", C); return -1; }
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder down-sampling: bicubic x0.5 (per channel) then 1x1 E->2E          LGT.py:280-281,325-326
+// ------------------------------------------------------------------------------------------------
+template <int E>
+__global__ __launch_bounds__(256) void k_down(DownArgs a) {
+    const int ho = a.H / 2, wo = a.W / 2;
+    long total = (long)a.B * ho * wo;
+    long p = blockIdx.x * 256L + threadIdx.x;
+    if (p >= total) return;
+    int ox = (int)(p % wo);
+    long r = p / wo;
+    int oy = (int)(r % ho);
+    long b = r / ho;
+    int iy0, ix0;
+    float wy[4], wx[4];
+    resample_plan<0>(oy, iy0, wy);
+    resample_plan<0>(ox, ix0, wx);
+    float u[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) u[k] = 0.f;
+    for (int ta = 0; ta < 4; ++ta) {
+        int yy = clampi(iy0 - 1 + ta, 0, a.H - 1);
+        for (int tb = 0; tb < 4; ++tb) {
+            int xx = clampi(ix0 - 1 + tb, 0, a.W - 1);
+            float wgt = wy[ta] * wx[tb];
+            const float4* src = reinterpret_cast<const float4*>(a.x + ((b * a.H + yy) * (long)a.W + xx) * E);
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) {
+                float4 v = src[k];
+                u[4 * k] += wgt * v.x; u[4 * k + 1] += wgt * v.y; u[4 * k + 2] += wgt * v.z; u[4 * k + 3] += wgt * v.w;
+            }
+        }
+    }
+    float o[2 * E];
+#pragma unroll
+    for (int n = 0; n < 2 * E; ++n) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < E; ++k) v += a.w[n * E + k] * u[k];
+        o[n] = v + a.b[n];
+    }
+    float4* yo = reinterpret_cast<float4*>(a.y + p * (2 * E));
+#pragma unroll
+    for (int n = 0; n < 2 * E / 4; ++n) yo[n] = make_float4(o[4 * n], o[4 * n + 1], o[4 * n + 2], o[4 * n + 3]);
+    if (a.g) emit_g<2 * E>(o, a.n1g, a.n1b, a.g, b, (long)oy * wo + ox, (long)ho * wo);
+}
+
+int launch_down(int E, const DownArgs& a, hipStream_t s) {
+    long total = (long)a.B * (a.H / 2) * (a.W / 2);
+    int grid = (int)((total + 255) / 256);
+    if (E == 16) k_down<16><<<grid, 256, 0, s>>>(a);
+    else if (E == 32) k_down<32><<<grid, 256, 0, s>>>(a);
+    else { lg_set_error("down: E=%d unsupported", E); return -1; }
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder: bicubic x2 then 1x1 2E->E ; cat with skip ; fusion 1x1 2E->E    LGT.py:294-295,336-338
+// ------------------------------------------------------------------------------------------------
+template <int E>
+__global__ __launch_bounds__(256) void k_upfuse(UpFuseArgs a) {
+    const int hi = a.H / 2, wi = a.W / 2;
+    long total = (long)a.B * a.H * a.W;
+    long p = blockIdx.x * 256L + threadIdx.x;
+    if (p >= total) return;
+    int ox = (int)(p % a.W);
+    long r = p / a.W;
+    int oy = (int)(r % a.H);
+    long b = r / a.H;
+    int iy0, ix0;
+    float wy[4], wx[4];
+    resample_plan<1>(oy, iy0, wy);
+    resample_plan<1>(ox, ix0, wx);
+    float u[2 * E];
+#pragma unroll
+    for (int k = 0; k < 2 * E; ++k) u[k] = 0.f;
+    for (int ta = 0; ta < 4; ++ta) {
+        int yy = clampi(iy0 - 1 + ta, 0, hi - 1);
+        for (int tb = 0; tb < 4; ++tb) {
+            int xx = clampi(ix0 - 1 + tb, 0, wi - 1);
+            float wgt = wy[ta] * wx[tb];
+            const float4* src = reinterpret_cast<const float4*>(a.xb + ((b * hi + yy) * (long)wi + xx) * (2 * E));
+#pragma unroll
+            for (int k = 0; k < 2 * E / 4; ++k) {
+                float4 v = src[k];
+                u[4 * k] += wgt * v.x; u[4 * k + 1] += wgt * v.y; u[4 * k + 2] += wgt * v.z; u[4 * k + 3] += wgt * v.w;
+            }
+        }
+    }
+    float t[E];
+#pragma unroll
+    for (int n = 0; n < E; ++n) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2 * E; ++k) v += a.upw[n * 2 * E + k] * u[k];
+        t[n] = v + a.upb[n];
+    }
+    float sk[E];
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.skip + p * E);
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k) {
+            float4 v = src[k];
+            sk[4 * k] = v.x; sk[4 * k + 1] = v.y; sk[4 * k + 2] = v.z; sk[4 * k + 3] = v.w;
+        }
+    }
+    float o[E];
+#pragma unroll
+    for (int n = 0; n < E; ++n) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < E; ++k) v += a.fw[n * 2 * E + k] * t[k];
+#pragma unroll
+        for (int k = 0; k < E; ++k) v += a.fw[n * 2 * E + E + k] * sk[k];
+        o[n] = v + a.fb[n];
+    }
+    float4* yo = reinterpret_cast<float4*>(a.y + p * E);
+#pragma unroll
+    for (int n = 0; n < E / 4; ++n) yo[n] = make_float4(o[4 * n], o[4 * n + 1], o[4 * n + 2], o[4 * n + 3]);
+    if (a.g) emit_g<E>(o, a.n1g, a.n1b, a.g, b, (long)oy * a.W + ox, (long)a.H * a.W);
+}
+
+int launch_upfuse(int E, const UpFuseArgs& a, hipStream_t s) {
+    long total = (long)a.B * a.H * a.W;
+    int grid = (int)((total + 255) / 256);
+    if (E == 16) k_upfuse<16><<<grid, 256, 0, s>>>(a);
+    else if (E == 32) k_upfuse<32><<<grid, 256, 0, s>>>(a);
+    else { lg_set_error("upfuse: E=%d unsupported", E); return -1; }
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reconstruction tail: (identity resample) 1x1 E->C, + x                    LGT.py:302-303,342
+// ------------------------------------------------------------------------------------------------
+template <int C, int E>
+__global__ __launch_bounds__(256) void k_tail(TailArgs a) {
+    long p = blockIdx.x * 256L + threadIdx.x;
+    if (p >= a.total) return;
+    long b = p / a.HW, s = p - b * a.HW;
+    float x[E];
+    const float4* src = reinterpret_cast<const float4*>(a.x + p * E);
+#pragma unroll
+    for (int k = 0; k < E / 4; ++k) {
+        float4 v = src[k];
+        x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < E; ++k) v += a.w[c * E + k] * x[k];
+        long o = (b * C + c) * a.HW + s;
+        a.out[o] = v + a.b[c] + a.z[o];
+    }
+}
+
+int launch_tail(int C, const TailArgs& a, hipStream_t s) {
+    int grid = (int)((a.total + 255) / 256);
+    if (C == 4) k_tail<4, 16><<<grid, 256, 0, s>>>(a);
+    else if (C == 8) k_tail<8, 32><<<grid, 256, 0, s>>>(a);
+    else { lg_set_error("tail: C=%d unsupported", C); return -1; }
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone LN1 + planar split (per-op test entry only; in the net it is an epilogue of the producer)
+// ------------------------------------------------------------------------------------------------
+template <int E>
+__global__ __launch_bounds__(256) void k_ln_split(const float* __restrict__ x, const float* __restrict__ n1g,
+                                                  const float* __restrict__ n1b, float* __restrict__ g, long HW, long total) {
+    long p = blockIdx.x * 256L + threadIdx.x;
+    if (p >= total) return;
+    long b = p / HW, s = p - b * HW;
+    float v[E];
+    const float4* src = reinterpret_cast<const float4*>(x + p * E);
+#pragma unroll
+    for (int k = 0; k < E / 4; ++k) {
+        float4 t = src[k];
+        v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+    }
+    emit_g<E>(v, n1g, n1b, g, b, s, HW);
+}
+
+int launch_ln_split(int e, const float* x, const float* n1g, const float* n1b, float* g, int B, int HW, hipStream_t s) {
+    long total = (long)B * HW;
+    int grid = (int)((total + 255) / 256);
+    if (e == 16) k_ln_split<16><<<grid, 256, 0, s>>>(x, n1g, n1b, g, HW, total);
+    else if (e == 32) k_ln_split<32><<<grid, 256, 0, s>>>(x, n1g, n1b, g, HW, total);
+    else if (e == 64) k_ln_split<64><<<grid, 256, 0, s>>>(x, n1g, n1b, g, HW, total);
+    else { lg_set_error("ln_split: e=%d unsupported", e); return -1; }
+    LG_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,113 @@
+// Internal launcher declarations (one per fused kernel).  All pointers are device pointers.
+#pragma once
+#include "common.h"
+
+// ---------------- data module (reference models/unlg_former.py:29-37,58-61) ----------------
+struct DwArgs {
+    const float* in;    // [planes, hi, wi]
+    float* out;         // [planes, ho, wo]
+    const float* w9;    // [C,1,3,3]
+    const float* bias;  // [C]
+    const float* sub;   // EPI 1: subtract [planes, ho, wo]
+    // EPI 2 (data-step update): out = z - eta * (val + RT(R(z) - pan))
+    const float* z;     // [B, C, ho, wo]
+    const float* pan;   // [B, 1, ho, wo]
+    const float* rw;    // [1,C,1,1]
+    const float* rb;    // [1]
+    const float* rtw;   // [C,1,1,1]
+    const float* rtb;   // [C]
+    const float* eta;   // scalar
+    int C, planes, hi, wi, ho, wo;
+};
+// MODE 0: x0.5, 1: x2 ; EPI 0: none, 1: minus sub, 2: data-step update
+int launch_resample_dw(int mode, int epi, const DwArgs& a, hipStream_t s);
+int launch_resample(int mode, const float* x, float* y, int planes, int hi, int wi, hipStream_t s);
+
+// ---------------- LGT pixelwise pieces (reference models/common/LGT.py) ----------------
+struct EmbedArgs {
+    const float* z;  // [B,C,H,W]
+    float* x;        // [B,H,W,E]
+    float* g;        // [B,E/2,H,W] LN1(next block)(x)[..., E/2:]  (nullable)
+    const float *dww, *dwb, *w, *b, *lng, *lnb, *n1g, *n1b;
+    int HW;
+    long total;  // B*H*W
+};
+int launch_embed(int C, const EmbedArgs& a, hipStream_t s);
+
+struct DownArgs {
+    const float* x;  // [B,H,W,E]
+    float* y;        // [B,H/2,W/2,2E]
+    float* g;        // [B,E,H/2,W/2]
+    const float *w, *b, *n1g, *n1b;
+    int B, H, W;  // input size
+};
+int launch_down(int E, const DownArgs& a, hipStream_t s);
+
+struct UpFuseArgs {
+    const float* xb;    // [B,H/2,W/2,2E]
+    const float* skip;  // [B,H,W,E]
+    float* y;           // [B,H,W,E]
+    float* g;           // [B,E/2,H,W]
+    const float *upw, *upb, *fw, *fb, *n1g, *n1b;
+    int B, H, W;  // output size
+};
+int launch_upfuse(int E, const UpFuseArgs& a, hipStream_t s);
+
+struct TailArgs {
+    const float* x;  // [B,H,W,E]
+    const float* z;  // [B,C,H,W]
+    float* out;      // [B,C,H,W]
+    const float *w, *b;
+    int HW;
+    long total;
+};
+int launch_tail(int C, const TailArgs& a, hipStream_t s);
+
+// ---------------- global (FFT) mixer, LGT.py:149-180 ----------------
+struct FftArgs {
+    const float* g;   // [B,ch,n,n] planar, LayerNorm-ed global half
+    float* o;         // [B,ch,n,n] planar: abs(irfft2(...))
+    float* amp;       // optional save [B,ch,n,n/2+1]
+    float* pha;       // optional save
+    const float *ampw, *ampb, *phaw, *phab;  // [ch]
+    int planes, ch, n;
+};
+int launch_fftmix(const FftArgs& a, hipStream_t s);
+
+// ---------------- local mixer + proj + residual, LGT.py:112-146,183-219,231-248 ----------------
+struct AttnArgs {
+    const float* x;     // [B,h,w,e]
+    const float* o2;    // [B,e/2,h,w] planar global-mixer output
+    float* y;           // [B,h,w,e] = x + dropout(proj(cat(attn, o2)))
+    const float* posT;  // [2,64,64] transposed pos_emb: posT[h][j][i] = pos[h][i][j]
+    const float *ln1g, *ln1b, *qkvw, *qkvb, *projw, *projb;
+    int B, h, w;
+    int dropout;
+    uint64_t seed;
+};
+int launch_attn(int e, const AttnArgs& a, hipStream_t s);
+// posT[blk] for nblk blocks: src pointers via offsets into params
+int launch_pos_transpose(const float* pos, float* posT, hipStream_t s);
+
+// ---------------- feed_forward, LGT.py:91-109 ----------------
+struct Ffn1Args {
+    const float* x;  // [P, e]   (P = B*h*w)
+    float* h1;       // optional save, pre-GELU [P,4e]
+    float* h2;       // [P,4e] = W2 gelu(W1 LN(x) + b1) + b2
+    const float *ln2g, *ln2b, *w1, *b1, *w2, *b2;
+    long P;
+};
+int launch_ffn1(int e, const Ffn1Args& a, hipStream_t s);
+struct Ffn2Args {
+    const float* h2;  // [B,h,w,4e]
+    const float* x;   // [B,h,w,e] residual input
+    float* h3;        // optional save, pre-GELU [B,h,w,4e]
+    float* y;         // [B,h,w,e]
+    float* g;         // optional [B,e/2,h,w] LN1(next block)(y) global half
+    const float *dww, *dwb, *w3, *b3, *n1g, *n1b;
+    int B, h, w;
+};
+int launch_ffn2(int e, const Ffn2Args& a, hipStream_t s);
+
+// test helper: g[B,e/2,HW] = LayerNorm(x)[..., e/2:] (the epilogue the producing kernels fuse)
+int launch_ln_split(int e, const float* x, const float* n1g, const float* n1b, float* g, int B, int HW, hipStream_t s);

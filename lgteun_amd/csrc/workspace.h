@@ -1,0 +1,80 @@
+// Workspace carving shared by forward and backward orchestrators.  The caller owns one flat buffer; this
+// maps named activation tensors onto it deterministically from (plan, B, train).
+#pragma once
+#include "common.h"
+
+struct Carver {
+    char* base;
+    size_t off;
+    float* take(size_t nfloats) {
+        size_t o = off;
+        off += (nfloats * sizeof(float) + 255) & ~(size_t)255;
+        return base ? reinterpret_cast<float*>(base + o) : nullptr;
+    }
+};
+
+#define LG_MAX_K 16
+
+struct BlockBufs {
+    int e, h, w;       // channels / spatial size of this block
+    float *xin, *xmid, *xout;
+    float *g, *o2;     // planar [B,e/2,h,w]
+    float *amp, *pha;  // saved spectrum [B,e/2,h,w/2+1] (train)
+    float *h1, *h2, *h3;  // [B,h,w,4e]
+};
+
+struct NetBufs {
+    float* Z[LG_MAX_K + 1];                          // Z_0 .. Z_K  [B,C,H,W]
+    float *t1[LG_MAX_K], *r[LG_MAX_K], *s1[LG_MAX_K];  // data-step intermediates per stage
+    float* posT;                                     // [K][5][2*64*64]
+    BlockBufs blk[5];
+    float* x0;        // embed output = blk[0].xin
+    float* deadout;   // output of dead-stage LGTs (faithful mode)
+    size_t bytes;
+};
+
+static inline void carve(const lg_plan* plan, int B, int train, void* base, NetBufs& nb) {
+    const lg_config& c = plan->cfg;
+    Carver cv{reinterpret_cast<char*>(base), 0};
+    const size_t P0 = (size_t)c.H * c.W, P1 = P0 / 4, E = 4 * (size_t)c.C;
+    for (int i = 0; i <= c.K; ++i) nb.Z[i] = cv.take(B * c.C * P0);
+    for (int i = 0; i < c.K; ++i) {
+        nb.t1[i] = cv.take(B * c.C * P1);
+        nb.r[i] = cv.take(B * c.C * P1 / 4);
+        nb.s1[i] = cv.take(B * c.C * P1);
+    }
+    nb.posT = cv.take((size_t)c.K * 5 * 2 * 64 * 64);
+    nb.deadout = cv.take(B * c.C * P0);
+    float* shared_h2 = nullptr;
+    if (!train) shared_h2 = cv.take(B * P0 * 4 * E);  // largest (level-0) hidden tensor, reused by every block
+    for (int j = 0; j < 5; ++j) {
+        BlockBufs& bb = nb.blk[j];
+        const bool l1 = (j == 2);
+        bb.e = (int)(l1 ? 2 * E : E);
+        bb.h = l1 ? c.H / 2 : c.H;
+        bb.w = l1 ? c.W / 2 : c.W;
+        const size_t P = l1 ? P1 : P0, e = bb.e;
+        bb.xin = nullptr;  // wired below
+        bb.xmid = cv.take(B * P * e);
+        bb.xout = cv.take(B * P * e);
+        bb.g = cv.take(B * P * e / 2);
+        bb.o2 = cv.take(B * P * e / 2);
+        if (train) {
+            bb.amp = cv.take(B * (e / 2) * bb.h * (bb.w / 2 + 1));
+            bb.pha = cv.take(B * (e / 2) * bb.h * (bb.w / 2 + 1));
+            bb.h1 = cv.take(B * P * 4 * e);
+            bb.h2 = cv.take(B * P * 4 * e);
+            bb.h3 = cv.take(B * P * 4 * e);
+        } else {
+            bb.amp = bb.pha = bb.h1 = bb.h3 = nullptr;
+            bb.h2 = shared_h2;
+        }
+    }
+    nb.x0 = cv.take(B * P0 * E);
+    nb.blk[0].xin = nb.x0;
+    nb.blk[1].xin = nb.blk[0].xout;
+    nb.blk[2].xin = cv.take(B * P1 * 2 * E);  // down output
+    nb.blk[3].xin = cv.take(B * P0 * E);      // up+fusion output
+    nb.blk[4].xin = nb.blk[3].xout;
+    nb.bytes = cv.off;
+}

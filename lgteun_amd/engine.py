@@ -1,0 +1,275 @@
+"""Host-side engine: flat parameter storage, plans, workspaces and the calls into the HIP library.
+
+Layout decisions (MI355X-first):
+  * all parameters of the net live in ONE flat fp32 device buffer in canonical state_dict order
+    (each tensor 16-byte aligned); the nn.Parameters are views into it, so `state_dict()` /
+    `load_state_dict()` / `.parameters()` keep working while kernels get base pointer + offsets,
+    Adam is a single launch over two contiguous live ranges and the DDP bucket is the same two ranges.
+  * gradients use an identical flat buffer; only live tensors (shared data module, eta, last stage's LGT)
+    are ever written -- dead-stage parameters keep `grad is None` exactly like the reference.
+  * one workspace tensor per (B, train) holds every activation; the library allocates nothing.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import LG_FLAG_DROPOUT, LG_FLAG_FAITHFUL, LG_FLAG_SAVE, LgConfig, check
+
+
+def _block_names(pre):
+    m = pre + '0.fn.'
+    f = pre + '1.fn.'
+    return [m + 'fn.local_mixer.pos_emb', m + 'fn.local_mixer.to_qkv.weight', m + 'fn.local_mixer.to_qkv.bias',
+            m + 'fn.global_mixer.conv_amp.0.weight', m + 'fn.global_mixer.conv_amp.0.bias',
+            m + 'fn.global_mixer.conv_pha.0.weight', m + 'fn.global_mixer.conv_pha.0.bias',
+            m + 'fn.proj.weight', m + 'fn.proj.bias', m + 'norm.weight', m + 'norm.bias',
+            f + 'fn.net.0.weight', f + 'fn.net.0.bias', f + 'fn.net.2.point_conv.weight', f + 'fn.net.2.point_conv.bias',
+            f + 'fn.net.2.depth_conv.weight', f + 'fn.net.2.depth_conv.bias', f + 'fn.net.4.weight', f + 'fn.net.4.bias',
+            f + 'norm.weight', f + 'norm.bias']
+
+
+def canonical_names(C, K):
+    """Pansharpening.state_dict() key order of the reference (models/unlg_former.py:22-48): 12 shared tensors,
+    K eta, then 119 per stage.  This order defines the offsets table handed to lg_plan_create."""
+    names = []
+    for n in ('D.1', 'D.3', 'DT.1', 'DT.3'):
+        names += [n + '.weight', n + '.bias']
+    names += ['R.weight', 'R.bias', 'RT.weight', 'RT.bias']
+    names += [f'eta.{i}' for i in range(K)]
+    for i in range(K):
+        p = f'prior_module.{i}.'
+        names += [p + 'patch_embed.proj.0.weight', p + 'patch_embed.proj.0.bias', p + 'patch_embed.proj.1.weight',
+                  p + 'patch_embed.proj.1.bias', p + 'patch_embed.norm.weight', p + 'patch_embed.norm.bias']
+        names += _block_names(p + 'encoder_layers.0.0.blocks.0.')
+        names += _block_names(p + 'encoder_layers.0.0.blocks.1.')
+        names += [p + 'encoder_layers.0.1.1.weight', p + 'encoder_layers.0.1.1.bias']
+        names += _block_names(p + 'bottleneck.blocks.0.')
+        names += [p + 'decoder_layers.0.0.1.weight', p + 'decoder_layers.0.0.1.bias',
+                  p + 'decoder_layers.0.1.weight', p + 'decoder_layers.0.1.bias']
+        names += _block_names(p + 'decoder_layers.0.2.blocks.0.')
+        names += _block_names(p + 'decoder_layers.0.2.blocks.1.')
+        names += [p + 'tail.1.weight', p + 'tail.1.bias']
+    return names
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class Engine:
+    def __init__(self, module):
+        self.lib = _lib.lib()          # raises if the HIP library is not built -- no fallback
+        self.C = int(module.in_channels)
+        self.K = int(module.stage)
+        self.module_mode = lambda: module.mode
+        names = canonical_names(self.C, self.K)
+        params = dict(module.named_parameters())
+        if set(names) != set(params):
+            raise RuntimeError('parameter surface does not match the canonical LGTEUN state_dict')
+        dev = params[names[0]].device
+        if dev.type != 'cuda':
+            raise RuntimeError('lgteun_amd: parameters must live on an MI355X (cuda) device')
+        for n in names:
+            if params[n].device != dev or params[n].dtype != torch.float32:
+                raise RuntimeError(f'parameter {n}: expected float32 on {dev}')
+        self.device = dev
+        self.names = names
+        offs, total = [], 0
+        for n in names:
+            offs.append(total)
+            total += (max(params[n].numel(), 1) + 3) // 4 * 4
+        self.offsets = offs
+        self.total = total
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.params = [params[n] for n in names]
+        for n, o in zip(names, offs):
+            p = params[n]
+            view = self.flat[o:o + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+        self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        # live set: shared + eta, and the last stage's LGT -> two contiguous ranges of the flat buffers
+        n_head = 12 + self.K
+        first_last = 12 + self.K + 119 * (self.K - 1)
+        self.live_idx = list(range(n_head)) + list(range(first_last, len(names)))
+        self.live_ranges = [(0, offs[n_head] if n_head < len(offs) else total), (offs[first_last], total)]
+        self.ranges_dev = torch.tensor([v for r in self.live_ranges for v in r], dtype=torch.int64, device=dev)
+        self.max_range = max(b - a for a, b in self.live_ranges)
+        self._first_ptr = self.params[0].data_ptr()
+        self._last_ptr = self.params[-1].data_ptr()
+        self._plans = {}
+        self._ws = {}
+        self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._seed_ctr = 0
+        self.world = 1
+        self.process_group = None
+
+    # ------------------------------------------------------------------------------------------
+    def valid(self):
+        return (self.params[0].data_ptr() == self._first_ptr and self.params[-1].data_ptr() == self._last_ptr)
+
+    def __del__(self):
+        try:
+            for pl in self._plans.values():
+                self.lib.lg_plan_destroy(pl)
+        except Exception:  # noqa: BLE001
+            pass
+
+    def plan(self, H, W):
+        key = (H, W)
+        if key not in self._plans:
+            cfg = LgConfig(self.C, self.K, H, W, 0)
+            arr = (ctypes.c_int64 * len(self.offsets))(*self.offsets)
+            out = ctypes.c_void_p()
+            check(self.lib.lg_plan_create(ctypes.byref(cfg), arr, len(self.offsets), ctypes.byref(out)), 'lg_plan_create')
+            self._plans[key] = out
+        return self._plans[key]
+
+    def workspace(self, plan, B, train):
+        need = self.lib.lg_workspace_bytes(plan, B, 1 if train else 0)
+        key = (plan.value, B, bool(train))
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def next_seed(self):
+        self._seed_ctr += 1
+        return (torch.initial_seed() * 0x9E3779B1 + self._seed_ctr) & 0xFFFFFFFFFFFFFFFF
+
+    def _check_inputs(self, ms, pan):
+        if ms.dim() != 4 or pan.dim() != 4 or ms.shape[1] != self.C or pan.shape[1] != 1:
+            raise ValueError(f'expected ms [B,{self.C},h,w] and pan [B,1,4h,4w], got {tuple(ms.shape)} / {tuple(pan.shape)}')
+        B, _, h, w = ms.shape
+        if pan.shape[0] != B or pan.shape[2] != 4 * h or pan.shape[3] != 4 * w:
+            raise ValueError('pan must be 4x the MS size')
+        if ms.dtype != torch.float32 or pan.dtype != torch.float32:
+            raise ValueError('inputs must be float32 (NCHW), like the reference')
+        if ms.device != self.device or pan.device != self.device:
+            raise ValueError(f'inputs must be on {self.device}')
+        return B, 4 * h, 4 * w
+
+    # ------------------------------------------------------------------------------------------
+    def forward_raw(self, ms, pan, flags, seed=0):
+        B, H, W = self._check_inputs(ms, pan)
+        ms = ms.contiguous()
+        pan = pan.contiguous()
+        plan = self.plan(H, W)
+        ws = self.workspace(plan, B, bool(flags & LG_FLAG_SAVE))
+        out = torch.empty(B, self.C, H, W, dtype=torch.float32, device=self.device)
+        check(self.lib.lgteun_forward(plan, _ptr(self.flat), _ptr(ms), _ptr(pan), _ptr(out), _ptr(ws), ws.numel(), B, flags,
+                                      seed, _stream_ptr()), 'lgteun_forward')
+        return out, (plan, ws, ms, pan, B)
+
+    def backward_raw(self, saved, dout, gflat, flags, seed=0):
+        plan, ws, ms, pan, B = saved
+        dout = dout.contiguous()
+        check(self.lib.lgteun_backward(plan, _ptr(self.flat), _ptr(gflat), _ptr(ms), _ptr(pan), _ptr(dout), _ptr(ws),
+                                       ws.numel(), B, flags, seed, _stream_ptr()), 'lgteun_backward')
+
+    def base_flags(self, training):
+        f = LG_FLAG_FAITHFUL if self.module_mode() == 'faithful' else 0
+        if training:
+            f |= LG_FLAG_DROPOUT
+        return f
+
+    def forward_autograd(self, ms, pan, training):
+        flags = self.base_flags(training)
+        need_grad = torch.is_grad_enabled() and any(self.params[i].requires_grad for i in self.live_idx)
+        if not need_grad:
+            out, _ = self.forward_raw(ms, pan, flags, self.next_seed() if training else 0)
+            return out
+        live = [self.params[i] for i in self.live_idx]
+        return _LgteunFn.apply(self, ms, pan, flags, *live)
+
+    # ------------------------------------------------------------------------------------------
+    def train_step(self, ms, pan, gt, optim, loss_weight=1.0):
+        """forward + L1(mean) + backward + Adam as library calls; returns the device loss scalar (this rank's share)."""
+        flags = self.base_flags(True) | LG_FLAG_SAVE
+        if not getattr(optim, 'dropout', True):
+            flags &= ~LG_FLAG_DROPOUT
+        seed = self.next_seed()
+        self.gflat.zero_()
+        self._loss.zero_()
+        out, saved = self.forward_raw(ms, pan, flags, seed)
+        gt = gt.contiguous()
+        dout = torch.empty_like(out)
+        n_local = out.numel()
+        check(self.lib.lg_l1_loss(_ptr(out), _ptr(gt), _ptr(dout), _ptr(self._loss), n_local, n_local * self.world,
+                                  float(loss_weight), _stream_ptr()), 'lg_l1_loss')
+        self.backward_raw(saved, dout, self.gflat, flags, seed)
+        if self.world > 1:
+            import torch.distributed as dist
+            for a, b in self.live_ranges:
+                dist.all_reduce(self.gflat[a:b], op=dist.ReduceOp.SUM, group=self.process_group)
+        optim.step_flat(self)
+        return self._loss
+
+    def adam(self, state, step, lr, betas, eps, grad_scale=1.0):
+        check(self.lib.lg_adam_step(_ptr(self.flat), _ptr(self.gflat), _ptr(state['exp_avg']), _ptr(state['exp_avg_sq']),
+                                    _ptr(self.ranges_dev), len(self.live_ranges), self.max_range, step, float(lr),
+                                    float(betas[0]), float(betas[1]), float(eps), float(grad_scale), _stream_ptr()),
+              'lg_adam_step')
+
+
+class _LgteunFn(torch.autograd.Function):
+    """autograd bridge for callers that use torch optimizers / losses on the module output."""
+
+    @staticmethod
+    def forward(ctx, engine, ms, pan, flags, *live):
+        seed = engine.next_seed() if (flags & LG_FLAG_DROPOUT) else 0
+        out, saved = engine.forward_raw(ms, pan, flags | LG_FLAG_SAVE, seed)
+        ctx.engine, ctx.saved, ctx.flags, ctx.seed = engine, saved, flags | LG_FLAG_SAVE, seed
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng = ctx.engine
+        g = torch.zeros(eng.total, dtype=torch.float32, device=eng.device)
+        eng.backward_raw(ctx.saved, dout, g, ctx.flags, ctx.seed)
+        grads = []
+        for i in eng.live_idx:
+            p = eng.params[i]
+            o = eng.offsets[i]
+            grads.append(g[o:o + p.numel()].view(p.shape))
+        return (None, None, None, None, *grads)
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (reference models/base/base_model.py:123-124) as one HIP launch over the flat
+    live ranges.  Subclasses Optimizer so lr_scheduler.StepLR (base_model.py:137-147) drives `param_groups[0]['lr']`."""
+    is_fused_lgteun = True
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps))
+        self._step = 0
+        self._state = None
+        self.dropout = True
+
+    def step_flat(self, engine):
+        if self._state is None or self._state['exp_avg'].numel() != engine.total:
+            self._state = dict(exp_avg=torch.zeros_like(engine.flat), exp_avg_sq=torch.zeros_like(engine.flat))
+        self._step += 1
+        g = self.param_groups[0]
+        engine.adam(self._state, self._step, g['lr'], g['betas'], g['eps'])
+
+    def step(self, closure=None):   # pragma: no cover - the fused path goes through Engine.train_step
+        raise RuntimeError('FusedAdam is stepped by Engine.train_step(); use torch.optim.Adam for the autograd path')
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd['lgteun'] = dict(step=self._step, state=self._state)
+        return sd
+
+    def load_state_dict(self, sd):
+        extra = sd.pop('lgteun', None)
+        super().load_state_dict(sd)
+        if extra is not None:
+            self._step, self._state = extra['step'], extra['state']

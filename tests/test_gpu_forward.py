@@ -1,0 +1,137 @@
+"""-m gpu: HIP forward path vs the oracle (same seeded inputs) and vs the reference-generated goldens.
+Every call goes through the C ABI (ctypes).  Tolerances: north_star asks 1e-3 relative fp32 for the net;
+the fp32 kernels are held far tighter per op."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_gold
+from helpers import det_params, rel_l2
+from oracle import detweights as dw
+from oracle import lgteun_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail('no GPU visible: -m gpu tests must run on the MI355X box')
+    return torch.device('cuda')
+
+
+def test_library_loads_on_gpu(gpu):
+    from lgteun_amd import _lib
+    assert b'gfx950' in _lib.lib().lg_version()
+
+
+@pytest.mark.parametrize('C', [4, 8])
+def test_resample_and_data_step(gpu, C):
+    from gpu_helpers import Ops, make_module
+    net = make_module(C, 2)
+    ops = Ops(net, 32, 32)
+    g = load_gold(f'ops_c{C}')
+    x_ms, z, pan = T(g['resample_in']).cuda(), T(g['z_in']).cuda(), T(g['pan_in']).cuda()
+    assert rel_l2(ops.resample(x_ms, 2).cpu(), g['resample_x4']) < 2e-6
+    assert rel_l2(ops.resample(x_ms, 1).cpu(), g['resample_x2']) < 2e-6
+    assert rel_l2(ops.resample(z, 0).cpu(), g['resample_half']) < 2e-6
+    P = det_params(C, 2)
+    for stage in (0, 1):
+        want = orc.data_step(P, z.cpu(), x_ms.cpu(), pan.cpu(), P[f'eta.{stage}'])
+        got = ops.data_step(stage, z, x_ms, pan).cpu()
+        assert rel_l2(got, want) < 2e-6
+    # stage 0 of a K=1 reference net uses the same shared weights + eta.0 -> golden from the reference itself
+    assert rel_l2(ops.data_step(0, z, x_ms, pan).cpu(), g['data_step']) < 2e-6
+
+
+@pytest.mark.parametrize('C', [4, 8])
+def test_block_pieces(gpu, C):
+    """global mixer / mixer half-block / ffn half-block of every block kind vs oracle, on the golden features."""
+    from gpu_helpers import Ops, make_module
+    net = make_module(C, 1)
+    ops = Ops(net, 32, 32)
+    g = load_gold(f'ops_c{C}')
+    P = det_params(C, 1)
+    E = 4 * C
+    feat = T(g['feat_in'])                               # [2,32,32,E], sample 1 has negative-DC global planes
+    pre = 'prior_module.0.'
+    bp = pre + 'encoder_layers.0.0.blocks.0.'
+    y = orc.layer_norm(feat, P[bp + '0.fn.norm.weight'], P[bp + '0.fn.norm.bias'])
+    want_g = orc.global_mixer(P, bp + '0.fn.fn.global_mixer.', y[..., E // 2:]).permute(0, 3, 1, 2)
+    got_g = ops.block(0, 0, 0, feat.cuda()).cpu()
+    assert rel_l2(got_g, want_g) < 2e-4
+    want_m = feat + orc.lg_mixer(P, bp + '0.fn.fn.', y)
+    got_m = ops.block(0, 0, 1, feat.cuda()).cpu()
+    assert rel_l2(got_m, want_m) < 1e-4
+    y2 = orc.layer_norm(feat, P[bp + '1.fn.norm.weight'], P[bp + '1.fn.norm.bias'])
+    want_f = feat + orc.feed_forward(P, bp + '1.fn.fn.', y2)
+    got_f = ops.block(0, 0, 2, feat.cuda()).cpu()
+    assert rel_l2(got_f, want_f) < 5e-6
+    # bottleneck block (level 1: 16x16, 2E channels) on synthetic features
+    rng = np.random.default_rng(5)
+    f1 = T(rng.standard_normal((2, 16, 16, 2 * E)).astype(np.float32))
+    bb = pre + 'bottleneck.blocks.0.'
+    y = orc.layer_norm(f1, P[bb + '0.fn.norm.weight'], P[bb + '0.fn.norm.bias'])
+    assert rel_l2(ops.block(0, 2, 1, f1.cuda()).cpu(), f1 + orc.lg_mixer(P, bb + '0.fn.fn.', y)) < 1e-4
+    y2 = orc.layer_norm(f1, P[bb + '1.fn.norm.weight'], P[bb + '1.fn.norm.bias'])
+    assert rel_l2(ops.block(0, 2, 2, f1.cuda()).cpu(), f1 + orc.feed_forward(P, bb + '1.fn.fn.', y2)) < 5e-6
+
+
+@pytest.mark.parametrize('C', [4, 8])
+def test_lgt(gpu, C):
+    from gpu_helpers import Ops, make_module
+    net = make_module(C, 1)
+    ops = Ops(net, 32, 32)
+    g = load_gold(f'ops_c{C}')
+    got = ops.lgt(0, T(g['z_in']).cuda()).cpu()
+    assert rel_l2(got, g['lgt']) < 1e-4                  # vs the reference itself
+
+
+@pytest.mark.parametrize('name', ['net_c4_k2_p32', 'net_c8_k2_p32', 'net_c4_k4_p64', 'net_c4_k4_p128', 'net_c8_k4_p128'])
+@pytest.mark.parametrize('mode', ['faithful', 'live'])
+def test_whole_net_vs_reference_golden(gpu, manifest, name, mode):
+    from gpu_helpers import make_module
+    m = manifest[name]
+    g = load_gold(name)
+    ms, pan, gt = dw.make_inputs(m['B'], m['C'], m['h'], m['h'], seed=m['seed'], kind=m['kind'])
+    net = make_module(m['C'], m['K'])
+    net.mode = mode
+    with torch.no_grad():
+        y = net(T(ms).cuda(), T(pan).cuda()).cpu()
+    assert y.shape == g['out_fp32'].shape and y.dtype == torch.float32
+    # north_star: within 1e-3 relative of the reference PyTorch-CPU fp32 forward
+    assert rel_l2(y, g['out_fp32']) < 1e-3
+    assert rel_l2(y, g['out_fp64']) < 1e-3
+    # PSNR / SAM equal to 3 d.p.
+    o = np.transpose(y[0].numpy(), (1, 2, 0)).astype(np.float64) * 2047.5
+    t = np.transpose(gt[0], (1, 2, 0)).astype(np.float64) * 2047.5
+    met = np.array([orc.psnr(o, t), orc.sam(o, t)])
+    assert np.allclose(met, g['metrics'][:2], atol=5e-4), (met, g['metrics'])
+
+
+def test_batch_independence_and_determinism(gpu):
+    """samples are independent (pure data parallelism) and the path is run-to-run bit-stable"""
+    from gpu_helpers import make_module
+    net = make_module(4, 2)
+    ms, pan, _ = dw.make_inputs(4, 4, 8, 8, seed=3, kind='dn')
+    ms, pan = T(ms).cuda(), T(pan).cuda()
+    with torch.no_grad():
+        y = net(ms, pan)
+        y2 = net(ms, pan)
+        y_half = net(ms[2:], pan[2:])
+    assert torch.equal(y, y2)
+    assert torch.equal(y[2:], y_half)
+
+
+def test_bad_inputs_raise(gpu):
+    from gpu_helpers import make_module
+    from lgteun_amd._lib import LgteunHipError
+    net = make_module(4, 1)
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 3, 8, 8, device='cuda'), torch.zeros(1, 1, 32, 32, device='cuda'))
+    with pytest.raises(LgteunHipError):      # PAN 24x24: not a multiple of 16
+        net(torch.zeros(1, 4, 6, 6, device='cuda'), torch.zeros(1, 1, 24, 24, device='cuda'))
+    with pytest.raises(RuntimeError):        # no CPU path
+        make_module(4, 1, device='cpu')(torch.zeros(1, 4, 8, 8), torch.zeros(1, 1, 32, 32))
