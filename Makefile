@@ -2,14 +2,14 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := lgteun_amd/csrc
-SRCS  := $(CSRC)/api.hip $(CSRC)/k_pixel.hip $(CSRC)/k_fft.hip $(CSRC)/k_attn.hip $(CSRC)/k_ffn.hip $(CSRC)/k_bwd.hip
+SRCS  := $(CSRC)/api.hip $(CSRC)/k_pixel.hip $(CSRC)/k_fft.hip $(CSRC)/k_attn.hip $(CSRC)/k_ffn.hip $(CSRC)/k_bwd.hip $(CSRC)/k_bwd_pixel.hip $(CSRC)/k_wgrad.hip $(CSRC)/k_ffn_bwd.hip $(CSRC)/k_attn_bwd.hip
 OBJS  := $(SRCS:.hip=.o)
 LIB   := lgteun_amd/_lgteun_hip.so
 FLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
 
 all: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/workspace.h $(CSRC)/backward.h include/lgteun_hip.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/workspace.h $(CSRC)/backward.h $(CSRC)/bwd_kernels.h $(CSRC)/mfma.h include/lgteun_hip.h
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

@@ -96,6 +96,14 @@ int lg_op_lgt(const lg_plan* plan, const float* params, int32_t stage, const flo
 int lg_op_block(const lg_plan* plan, const float* params, int32_t stage, int32_t blk, int32_t which, const float* x,
                 float* y, void* workspace, size_t workspace_bytes, int32_t B, void* stream);
 
+/* backward of the same pieces (autograd of the lines cited at lg_op_block): runs the half-block forward on x with
+ * everything saved, then its backward for upstream gradient dy.  which = 0: dy, dx planar [B,e/2,h,w] (gradient wrt the
+ * LayerNorm-ed global half); 1, 2: dy, dx NHWC [B,h,w,e].  Parameter gradients accumulate (+=) into grads.
+ * workspace: lg_workspace_bytes(plan, B, 1). */
+int lg_op_block_bwd(const lg_plan* plan, const float* params, float* grads, int32_t stage, int32_t blk, int32_t which,
+                    const float* x, const float* dy, float* dx, void* workspace, size_t workspace_bytes, int32_t B,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,8 @@ SIGNATURES = {
                             c_void_p]),
     'lg_op_block': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_int32,
                               c_void_p]),
+    'lg_op_block_bwd': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_size_t, c_int32, c_void_p]),
 }
 
 

@@ -88,13 +88,6 @@ static int data_step_fwd(const lg_plan* pl, const float* P, int stage, const flo
     return launch_resample_dw(1, 2, a, s);
 }
 
-static uint64_t mix_seed(uint64_t seed, int stage, int blk) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(stage * 8 + blk + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
 static int block_mixer_fwd(const lg_plan* pl, const float* P, int stage, int j, const BlockBufs& bb, const float* posT, int B,
                            int flags, uint64_t seed, hipStream_t s) {
     int rc;
@@ -102,6 +95,7 @@ static int block_mixer_fwd(const lg_plan* pl, const float* P, int stage, int j, 
     f.g = bb.g; f.o = bb.o2;
     f.amp = (flags & LG_FLAG_SAVE) ? bb.amp : nullptr;
     f.pha = (flags & LG_FLAG_SAVE) ? bb.pha : nullptr;
+    f.sgn = (flags & LG_FLAG_SAVE) ? bb.sgn : nullptr;
     f.ampw = P + pl->blk(stage, j, B_AMPW); f.ampb = P + pl->blk(stage, j, B_AMPB);
     f.phaw = P + pl->blk(stage, j, B_PHAW); f.phab = P + pl->blk(stage, j, B_PHAB);
     f.ch = bb.e / 2; f.planes = B * f.ch; f.n = bb.h;
@@ -170,6 +164,7 @@ static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z,
     // down
     DownArgs da;
     da.x = nb.blk[1].xout; da.y = nb.blk[2].xin; da.g = nb.blk[2].g;
+    da.u_save = (flags & LG_FLAG_SAVE) ? nb.u_down : nullptr;
     da.w = P + pl->lgt(stage, L_DOWNW); da.b = P + pl->lgt(stage, L_DOWNB);
     da.n1g = P + pl->blk(stage, 2, B_LN1G); da.n1b = P + pl->blk(stage, 2, B_LN1B);
     da.B = B; da.H = c.H; da.W = c.W;
@@ -180,6 +175,7 @@ static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z,
     // up + fusion
     UpFuseArgs ua;
     ua.xb = nb.blk[2].xout; ua.skip = nb.blk[1].xout; ua.y = nb.blk[3].xin; ua.g = nb.blk[3].g;
+    ua.t_save = (flags & LG_FLAG_SAVE) ? nb.t_up : nullptr;
     ua.upw = P + pl->lgt(stage, L_UPW); ua.upb = P + pl->lgt(stage, L_UPB);
     ua.fw = P + pl->lgt(stage, L_FUSEW); ua.fb = P + pl->lgt(stage, L_FUSEB);
     ua.n1g = P + pl->blk(stage, 3, B_LN1G); ua.n1b = P + pl->blk(stage, 3, B_LN1B);
@@ -284,7 +280,7 @@ extern "C" int lg_op_block(const lg_plan* plan, const float* params, int32_t sta
     }
     if (which == 0) {
         FftArgs f;
-        f.g = bb.g; f.o = y; f.amp = nullptr; f.pha = nullptr;
+        f.g = bb.g; f.o = y; f.amp = nullptr; f.pha = nullptr; f.sgn = nullptr;
         f.ampw = params + plan->blk(stage, blk, B_AMPW); f.ampb = params + plan->blk(stage, blk, B_AMPB);
         f.phaw = params + plan->blk(stage, blk, B_PHAW); f.phab = params + plan->blk(stage, blk, B_PHAB);
         f.ch = bb.e / 2; f.planes = B * f.ch; f.n = bb.h;
@@ -301,6 +297,35 @@ extern "C" int lg_op_block(const lg_plan* plan, const float* params, int32_t sta
     bb.xout = y;
     (void)npix;
     return block_ffn_fwd(plan, params, stage, blk, bb, nullptr, 0, B, 0, s);
+}
+
+extern "C" int lg_op_block_bwd(const lg_plan* plan, const float* params, float* grads, int32_t stage, int32_t blk, int32_t which,
+                               const float* x, const float* dy, float* dx, void* workspace, size_t workspace_bytes, int32_t B,
+                               void* stream) {
+    if (!plan || !params || !grads || !x || !dy || !dx || !workspace || stage < 0 || stage >= plan->cfg.K || blk < 0 || blk > 4 ||
+        which < 0 || which > 2) {
+        lg_set_error("op_block_bwd: invalid argument");
+        return -1;
+    }
+    if (workspace_bytes < lg_workspace_bytes(plan, B, 1)) { lg_set_error("op_block_bwd: workspace too small"); return -3; }
+    hipStream_t s = (hipStream_t)stream;
+    NetBufs nb;
+    carve(plan, B, 1, workspace, nb);
+    BlockBufs& bb = nb.blk[blk];
+    int rc;
+    // forward of the half-block with everything saved
+    if (which == 0 || which == 1) {
+        if ((rc = launch_ln_split(bb.e, x, params + plan->blk(stage, blk, B_LN1G), params + plan->blk(stage, blk, B_LN1B), bb.g, B,
+                                  bb.h * bb.w, s)))
+            return rc;
+        if ((rc = launch_pos_transpose(params + plan->blk(stage, blk, B_POS), nb.posT, s))) return rc;
+        bb.xin = const_cast<float*>(x);
+        if ((rc = block_mixer_fwd(plan, params, stage, blk, bb, nb.posT, B, LG_FLAG_SAVE, 0, s))) return rc;
+    } else {
+        bb.xmid = const_cast<float*>(x);
+        if ((rc = block_ffn_fwd(plan, params, stage, blk, bb, nullptr, 0, B, LG_FLAG_SAVE, s))) return rc;
+    }
+    return op_block_bwd(plan, params, grads, stage, blk, which, dy, dx, nb, (char*)workspace + nb.bytes, B, s);
 }
 
 // ------------------------------------------------------------------------------------------------

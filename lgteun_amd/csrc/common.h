@@ -39,6 +39,15 @@ struct lg_plan {
 
 void lg_set_error(const char* fmt, ...);
 
+// per-(stage, block) dropout seed, shared by forward and backward
+static inline uint64_t mix_seed(uint64_t seed, int stage, int blk) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(stage * 8 + blk + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+
 #define LG_CHECK_LAUNCH()                                                              \
     do {                                                                               \
         hipError_t e__ = hipGetLastError();                                            \

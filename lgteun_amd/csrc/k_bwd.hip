@@ -1,8 +1,237 @@
+// Backward orchestration: autograd of Pansharpening.forward (reference models/unlg_former.py:50-67) over the live
+// graph only -- the last stage's LGT and the K shared data steps (dead-stage LGTs never get a gradient).
+#include <string.h>
+
 #include "kernels.h"
+#include "bwd_kernels.h"
 #include "backward.h"
-size_t bwd_workspace_bytes(const lg_plan*, int) { return 0; }
-int net_backward(const lg_plan*, const float*, float*, const float*, const float*, const float*, NetBufs&, void*, int, int, uint64_t,
-                 hipStream_t) {
-    lg_set_error("backward: not implemented yet");
-    return -100;
+
+struct BwdBufs {
+    float *dzA, *dzB, *gu3, *gs1, *gu1, *gr, *gd3, *gt1, *gd1;
+    float *dx[3];
+    float *doutp, *de, *tp, *dh3, *dh2, *dh1, *y2, *do2, *dg, *dym, *cat, *y1, *dqkv, *dpos_slab;
+    float *w3t, *w2t, *w1t, *slab, *dt, *dskip, *v, *du;
+    size_t bytes;
+};
+
+static void carve_bwd(const lg_plan* plan, int B, void* base, BwdBufs& bb) {
+    const lg_config& c = plan->cfg;
+    Carver cv{reinterpret_cast<char*>(base), 0};
+    const size_t P0 = (size_t)c.H * c.W * B, P1 = P0 / 4, E = 4 * (size_t)c.C, C = c.C;
+    bb.dzA = cv.take(C * P0); bb.dzB = cv.take(C * P0); bb.gu3 = cv.take(C * P0);
+    bb.gs1 = cv.take(C * P1); bb.gu1 = cv.take(C * P1); bb.gt1 = cv.take(C * P1); bb.gd1 = cv.take(C * P1);
+    bb.gr = cv.take(C * P1 / 4); bb.gd3 = cv.take(C * P1 / 4);
+    for (int i = 0; i < 3; ++i) bb.dx[i] = cv.take(P0 * E);
+    bb.doutp = cv.take(P0 * 16); bb.de = cv.take(P0 * E); bb.tp = cv.take(P0 * 16);
+    bb.dh3 = cv.take(P0 * 4 * E); bb.dh2 = cv.take(P0 * 4 * E); bb.dh1 = cv.take(P0 * 4 * E);
+    bb.y2 = cv.take(P0 * E); bb.do2 = cv.take(P0 * E / 2); bb.dg = cv.take(P0 * E / 2);
+    bb.dym = cv.take(P0 * E); bb.cat = cv.take(P0 * E); bb.y1 = cv.take(P0 * 16 > P0 * E / 2 ? P0 * 16 : P0 * E / 2);
+    bb.dqkv = cv.take(P0 * 2 * E);
+    bb.dpos_slab = cv.take((size_t)512 * 2 * 64 * 64);
+    bb.w3t = cv.take(8 * E * 2 * E); bb.w2t = cv.take(8 * E * 8 * E); bb.w1t = cv.take(8 * E * 2 * E);
+    size_t sl = wgrad_slab_floats((int)(8 * E), (int)(8 * E), (long)P0);
+    size_t sl2 = wgrad_slab_floats(64, 64, (long)P0);
+    bb.slab = cv.take(sl > sl2 ? sl : sl2);
+    bb.dt = cv.take(P0 * E); bb.dskip = cv.take(P0 * E); bb.v = cv.take(P1 * E); bb.du = cv.take(P1 * E);
+    bb.bytes = cv.off;
+}
+
+size_t bwd_workspace_bytes(const lg_plan* plan, int B) {
+    BwdBufs bb;
+    carve_bwd(plan, B, nullptr, bb);
+    return bb.bytes;
+}
+
+#define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+static int wgrad(const float* Y, int ldy, const float* X, int ldx, float* dW, int ldw, float* db, long P, int N, int K, int nv, int kv,
+                 int xf, float* slab, hipStream_t s) {
+    WgradArgs a;
+    a.Y = Y; a.X = X; a.dW = dW; a.db = db; a.P = P; a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.N = N; a.K = K;
+    a.n_valid = nv; a.k_valid = kv; a.xf = xf;
+    return launch_wgrad(a, slab, s);
+}
+
+// feed_forward half-block backward: dy (grad wrt block output) -> tmp (grad wrt the mid activation)
+static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int j, const BlockBufs& fb, BwdBufs& bb, const float* dy,
+                        float* tmp, int B, hipStream_t s) {
+    const int e = fb.e, n1 = 4 * e;
+    const long Pn = (long)B * fb.h * fb.w;
+    RC(launch_transpose(P + pl->blk(st, j, B_W3), bb.w3t, e, n1, s));
+    RC(launch_transpose(P + pl->blk(st, j, B_W2), bb.w2t, n1, n1, s));
+    RC(launch_transpose(P + pl->blk(st, j, B_W1), bb.w1t, n1, e, s));
+    Ffn2BwdArgs f2;
+    f2.dy = dy; f2.h3 = fb.h3; f2.dh3 = bb.dh3; f2.w3t = bb.w3t; f2.P = Pn;
+    RC(launch_ffn2_bwd(e, f2, s));
+    RC(wgrad(dy, e, fb.h3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 1, bb.slab, s));
+    Ffn1BwdArgs f1;
+    f1.dh3 = bb.dh3; f1.h2 = fb.h2; f1.h1 = fb.h1; f1.x = fb.xmid; f1.dy = dy;
+    f1.dh2 = bb.dh2; f1.dh1 = bb.dh1; f1.y2 = bb.y2; f1.dx = tmp;
+    f1.dww = P + pl->blk(st, j, B_DWW); f1.w2t = bb.w2t; f1.w1t = bb.w1t;
+    f1.ln2g = P + pl->blk(st, j, B_LN2G); f1.ln2b = P + pl->blk(st, j, B_LN2B);
+    f1.d_dww = G + pl->blk(st, j, B_DWW); f1.d_dwb = G + pl->blk(st, j, B_DWB);
+    f1.d_ln2g = G + pl->blk(st, j, B_LN2G); f1.d_ln2b = G + pl->blk(st, j, B_LN2B);
+    f1.B = B; f1.h = fb.h; f1.w = fb.w;
+    RC(launch_ffn1_bwd(e, f1, s));
+    RC(wgrad(bb.dh2, n1, fb.h1, n1, G + pl->blk(st, j, B_W2), n1, G + pl->blk(st, j, B_B2), Pn, n1, n1, n1, n1, 1, bb.slab, s));
+    RC(wgrad(bb.dh1, n1, bb.y2, e, G + pl->blk(st, j, B_W1), e, G + pl->blk(st, j, B_B1), Pn, n1, e, n1, e, 0, bb.slab, s));
+    return 0;
+}
+
+static int fft_bwd_call(const lg_plan* pl, const float* P, float* G, int st, int j, const BlockBufs& fb, const float* do2, float* dg,
+                        int B, hipStream_t s) {
+    const int hc = fb.e / 2;
+    FftBwdArgs fa;
+    fa.do2 = do2; fa.sgn = fb.sgn; fa.amp = fb.amp; fa.pha = fb.pha; fa.dg = dg;
+    fa.ampw = P + pl->blk(st, j, B_AMPW); fa.ampb = P + pl->blk(st, j, B_AMPB);
+    fa.phaw = P + pl->blk(st, j, B_PHAW); fa.phab = P + pl->blk(st, j, B_PHAB);
+    fa.d_ampw = G + pl->blk(st, j, B_AMPW); fa.d_ampb = G + pl->blk(st, j, B_AMPB);
+    fa.d_phaw = G + pl->blk(st, j, B_PHAW); fa.d_phab = G + pl->blk(st, j, B_PHAB);
+    fa.ch = hc; fa.planes = B * hc; fa.n = fb.h;
+    return launch_fftmix_bwd(fa, s);
+}
+
+// mixer half-block backward: tmp (grad wrt the mid activation) -> dx_out (grad wrt block input)
+static int mixer_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int j, const BlockBufs& fb, BwdBufs& bb, const float* posT,
+                          const float* tmp, float* dx_out, int B, int flags, uint64_t seed, hipStream_t s) {
+    const int e = fb.e, hc = e / 2;
+    const long Pn = (long)B * fb.h * fb.w;
+    const int drop = (flags & LG_FLAG_DROPOUT) ? 1 : 0;
+    ProjO2BwdArgs po;
+    po.dy = tmp; po.do2 = bb.do2; po.dym = drop ? bb.dym : nullptr; po.projw = P + pl->blk(st, j, B_PROJW);
+    po.HW = fb.h * fb.w; po.total = Pn; po.dropout = drop; po.seed = mix_seed(seed, st, j);
+    RC(launch_proj_o2_bwd(e, po, s));
+    const float* dym = drop ? bb.dym : tmp;
+    RC(fft_bwd_call(pl, P, G, st, j, fb, bb.do2, bb.dg, B, s));
+    AttnBwdArgs at;
+    at.x = fb.xin; at.dy = tmp; at.dym = dym; at.o2 = fb.o2; at.dg = bb.dg; at.dx = dx_out;
+    at.cat = bb.cat; at.y1 = bb.y1; at.dqkv = bb.dqkv;
+    at.pos = P + pl->blk(st, j, B_POS); at.posT = posT; at.dpos_slab = bb.dpos_slab;
+    at.ln1g = P + pl->blk(st, j, B_LN1G); at.ln1b = P + pl->blk(st, j, B_LN1B);
+    at.qkvw = P + pl->blk(st, j, B_QKVW); at.qkvb = P + pl->blk(st, j, B_QKVB); at.projw = P + pl->blk(st, j, B_PROJW);
+    at.d_ln1g = G + pl->blk(st, j, B_LN1G); at.d_ln1b = G + pl->blk(st, j, B_LN1B);
+    at.B = B; at.h = fb.h; at.w = fb.w;
+    RC(launch_attn_bwd(e, at, s));
+    const int grid = attn_bwd_grid(e, B, fb.h, fb.w);
+    RC(launch_reduce_slab(bb.dpos_slab, grid, 1, 2 * 64 * 64, G + pl->blk(st, j, B_POS), 2 * 64 * 64, 1, 2 * 64 * 64, s));
+    RC(wgrad(dym, e, bb.cat, e, G + pl->blk(st, j, B_PROJW), e, G + pl->blk(st, j, B_PROJB), Pn, e, e, e, e, 0, bb.slab, s));
+    const int y1ld = (hc + 15) / 16 * 16, dqld = (3 * hc + 15) / 16 * 16;
+    RC(wgrad(bb.dqkv, dqld, bb.y1, y1ld, G + pl->blk(st, j, B_QKVW), hc, G + pl->blk(st, j, B_QKVB), Pn, dqld, y1ld, 3 * hc, hc, 0,
+             bb.slab, s));
+    return 0;
+}
+
+static int block_bwd(const lg_plan* pl, const float* P, float* G, int st, int j, const BlockBufs& fb, BwdBufs& bb, const float* posT,
+                     const float* dy, float* tmp, float* dx_out, int B, int flags, uint64_t seed, hipStream_t s) {
+    RC(ffn_half_bwd(pl, P, G, st, j, fb, bb, dy, tmp, B, s));
+    return mixer_half_bwd(pl, P, G, st, j, fb, bb, posT, tmp, dx_out, B, flags, seed, s);
+}
+
+// per-op backward entry (tests): which 0: global mixer (dy, dx planar), 1: mixer half-block, 2: ffn half-block
+int op_block_bwd(const lg_plan* pl, const float* P, float* G, int st, int j, int which, const float* dy, float* dx, NetBufs& nb,
+                 void* bwd_ws, int B, hipStream_t s) {
+    BwdBufs bb;
+    carve_bwd(pl, B, bwd_ws, bb);
+    const BlockBufs& fb = nb.blk[j];
+    if (which == 0) return fft_bwd_call(pl, P, G, st, j, fb, dy, dx, B, s);
+    if (which == 1) return mixer_half_bwd(pl, P, G, st, j, fb, bb, nb.posT, dy, dx, B, 0, 0, s);
+    return ffn_half_bwd(pl, P, G, st, j, fb, bb, dy, dx, B, s);
+}
+
+static int data_step_bwd(const lg_plan* pl, const float* P, float* G, int st, const NetBufs& nb, BwdBufs& bb, const float* pan,
+                         const float* g, float* dz, int B, hipStream_t s) {
+    const lg_config& c = pl->cfg;
+    const int planes = B * c.C, H = c.H, W = c.W;
+    DstepTopArgs t;
+    t.g = g; t.s1 = nb.s1[st]; t.z = nb.Z[st]; t.pan = pan; t.gu = bb.gu3; t.dz = dz;
+    t.w9 = P + pl->shared(S_DT3W); t.b9 = P + pl->shared(S_DT3B);
+    t.rw = P + pl->shared(S_RW); t.rb = P + pl->shared(S_RB); t.rtw = P + pl->shared(S_RTW); t.rtb = P + pl->shared(S_RTB);
+    t.eta = P + pl->eta(st);
+    t.dw9 = G + pl->shared(S_DT3W); t.dbias = G + pl->shared(S_DT3B);
+    t.drw = G + pl->shared(S_RW); t.drb = G + pl->shared(S_RB); t.drtw = G + pl->shared(S_RTW); t.drtb = G + pl->shared(S_RTB);
+    t.deta = G + pl->eta(st);
+    t.C = c.C; t.B = B; t.H = H; t.W = W;
+    RC(launch_dstep_top_bwd(t, s));
+    // s1 = dw(up(r)): grad wrt s1, then through the DT.1 conv
+    RC(launch_resample_adj(1, bb.gu3, bb.gs1, planes, H / 2, W / 2, 0, s));
+    DwBwdArgs d;
+    d.C = c.C; d.planes = planes;
+    d.gout = bb.gs1; d.in = nb.r[st]; d.gin = bb.gu1; d.w9 = P + pl->shared(S_DT1W);
+    d.dw9 = G + pl->shared(S_DT1W); d.dbias = G + pl->shared(S_DT1B);
+    d.hi = H / 4; d.wi = W / 4; d.n_h = H / 2; d.n_w = W / 2;
+    RC(launch_dw_bwd(1, d, s));
+    RC(launch_resample_adj(1, bb.gu1, bb.gr, planes, H / 4, W / 4, 0, s));
+    // r = dw(down(t1)) - ms
+    d.gout = bb.gr; d.in = nb.t1[st]; d.gin = bb.gd3; d.w9 = P + pl->shared(S_D3W);
+    d.dw9 = G + pl->shared(S_D3W); d.dbias = G + pl->shared(S_D3B);
+    d.hi = H / 2; d.wi = W / 2; d.n_h = H / 4; d.n_w = W / 4;
+    RC(launch_dw_bwd(0, d, s));
+    RC(launch_resample_adj(0, bb.gd3, bb.gt1, planes, H / 2, W / 2, 0, s));
+    // t1 = dw(down(Z))
+    d.gout = bb.gt1; d.in = nb.Z[st]; d.gin = bb.gd1; d.w9 = P + pl->shared(S_D1W);
+    d.dw9 = G + pl->shared(S_D1W); d.dbias = G + pl->shared(S_D1B);
+    d.hi = H; d.wi = W; d.n_h = H / 2; d.n_w = W / 2;
+    RC(launch_dw_bwd(0, d, s));
+    RC(launch_resample_adj(0, bb.gd1, dz, planes, H, W, 1, s));
+    return 0;
+}
+
+int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, const float* pan, const float* dout, NetBufs& nb,
+                 void* bwd_ws, int B, int flags, uint64_t seed, hipStream_t s) {
+    (void)ms;
+    const lg_config& c = pl->cfg;
+    const int E = 4 * c.C, st = c.K - 1;
+    BwdBufs bb;
+    carve_bwd(pl, B, bwd_ws, bb);
+    const long P0 = (long)B * c.H * c.W, P1 = P0 / 4;
+    const float* posT = nb.posT + (size_t)st * 5 * 2 * 64 * 64;
+    float *A = bb.dx[0], *Bf = bb.dx[1], *Cf = bb.dx[2];
+    // ---------------- LGT of the last stage (LGT.py:314-344, reversed)
+    TailBwdArgs tb;
+    tb.dout = dout; tb.dx = A; tb.doutp = bb.doutp; tb.dz = bb.dzA; tb.w = P + pl->lgt(st, L_TAILW);
+    tb.HW = c.H * c.W; tb.total = P0;
+    RC(launch_tail_bwd(c.C, tb, s));
+    RC(wgrad(bb.doutp, 16, nb.blk[4].xout, E, G + pl->lgt(st, L_TAILW), E, G + pl->lgt(st, L_TAILB), P0, 16, E, c.C, E, 0, bb.slab, s));
+    RC(block_bwd(pl, P, G, st, 4, nb.blk[4], bb, posT + 4 * 8192, A, Bf, Cf, B, flags, seed, s));
+    RC(block_bwd(pl, P, G, st, 3, nb.blk[3], bb, posT + 3 * 8192, Cf, Bf, A, B, flags, seed, s));
+    // up + fusion
+    UpFuseBwdArgs ub;
+    ub.dy = A; ub.dt = bb.dt; ub.dskip = bb.dskip; ub.v = bb.v; ub.dxb = Bf;
+    ub.fw = P + pl->lgt(st, L_FUSEW); ub.upw = P + pl->lgt(st, L_UPW);
+    ub.B = B; ub.H = c.H; ub.W = c.W;
+    RC(launch_upfuse_bwd_a(E, ub, s));
+    RC(wgrad(A, E, nb.t_up, E, G + pl->lgt(st, L_FUSEW), 2 * E, G + pl->lgt(st, L_FUSEB), P0, E, E, E, E, 0, bb.slab, s));
+    RC(wgrad(A, E, nb.blk[1].xout, E, G + pl->lgt(st, L_FUSEW) + E, 2 * E, nullptr, P0, E, E, E, E, 0, bb.slab, s));
+    RC(launch_upfuse_bwd_b(E, ub, s));
+    RC(wgrad(bb.v, E, nb.blk[2].xout, 2 * E, G + pl->lgt(st, L_UPW), 2 * E, G + pl->lgt(st, L_UPB), P1, E, 2 * E, E, 2 * E, 0, bb.slab, s));
+    // bottleneck
+    RC(block_bwd(pl, P, G, st, 2, nb.blk[2], bb, posT + 2 * 8192, Bf, Cf, A, B, flags, seed, s));
+    // down
+    DownBwdArgs db;
+    db.dy = A; db.du = bb.du; db.dskip = bb.dskip; db.dx = Bf; db.w = P + pl->lgt(st, L_DOWNW);
+    db.B = B; db.H = c.H; db.W = c.W;
+    RC(launch_down_bwd_a(E, db, s));
+    RC(wgrad(A, 2 * E, nb.u_down, E, G + pl->lgt(st, L_DOWNW), E, G + pl->lgt(st, L_DOWNB), P1, 2 * E, E, 2 * E, E, 0, bb.slab, s));
+    RC(launch_down_bwd_b(E, db, s));
+    // encoder
+    RC(block_bwd(pl, P, G, st, 1, nb.blk[1], bb, posT + 1 * 8192, Bf, Cf, A, B, flags, seed, s));
+    RC(block_bwd(pl, P, G, st, 0, nb.blk[0], bb, posT + 0 * 8192, A, Bf, Cf, B, flags, seed, s));
+    // patch embed
+    EmbedBwdArgs eb;
+    eb.dx = Cf; eb.z = nb.Z[c.K]; eb.dz = bb.dzA; eb.de = bb.de; eb.tp = bb.tp;
+    eb.dww = P + pl->lgt(st, L_PE_DWW); eb.dwb = P + pl->lgt(st, L_PE_DWB); eb.w = P + pl->lgt(st, L_PE_W); eb.b = P + pl->lgt(st, L_PE_B);
+    eb.lng = P + pl->lgt(st, L_PE_LNG);
+    eb.d_dww = G + pl->lgt(st, L_PE_DWW); eb.d_dwb = G + pl->lgt(st, L_PE_DWB);
+    eb.d_lng = G + pl->lgt(st, L_PE_LNG); eb.d_lnb = G + pl->lgt(st, L_PE_LNB);
+    eb.HW = c.H * c.W; eb.total = P0;
+    RC(launch_embed_bwd(c.C, eb, s));
+    RC(wgrad(bb.de, E, bb.tp, 16, G + pl->lgt(st, L_PE_W), c.C, G + pl->lgt(st, L_PE_B), P0, E, 16, E, c.C, 0, bb.slab, s));
+    // ---------------- K shared data steps, last to first (unlg_former.py:56-61)
+    float* g = bb.dzA;
+    float* dz = bb.dzB;
+    for (int i = c.K - 1; i >= 0; --i) {
+        RC(data_step_bwd(pl, P, G, i, nb, bb, pan, g, dz, B, s));
+        float* t = g; g = dz; dz = t;
+    }
+    return 0;
 }

@@ -1,0 +1,562 @@
+// Backward of the pixelwise / resampling kernels (k_pixel.hip) for gfx950: data module (D, DT, R, RT, eta),
+// LGT tail / patch_embed / down / up+fusion.  Autograd of reference models/unlg_former.py:29-37,58-61 and
+// models/common/LGT.py:64-88,280-281,294-295,302-303.  Small parameter gradients (a few floats per tensor) are
+// reduced per workgroup and added with float atomics; all 1x1-conv weight gradients go through k_wgrad.hip.
+#include "kernels.h"
+#include "bwd_kernels.h"
+
+// sum v[0..N) over the 256 threads of the block; result valid in threads 0..N-1 (returned value for index tid)
+template <int N>
+__device__ __forceinline__ float block_sum(float (&v)[N], float* sm /* [4*N] */) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float s = v[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) sm[wave * N + i] = s;
+    }
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x < N) r = sm[threadIdx.x] + sm[N + threadIdx.x] + sm[2 * N + threadIdx.x] + sm[3 * N + threadIdx.x];
+    __syncthreads();
+    return r;
+}
+
+// adjoint coefficients of the 1-D resampler: input index i (size n_in) receives coef[a] * gout[base + a]
+template <int MODE>
+struct AdjPlan {
+    static constexpr int NC = (MODE == 0) ? 3 : 10;
+    int base;
+    float coef[NC];
+    __device__ __forceinline__ void make(int i, int n_in, int n_out) {
+        base = (MODE == 0) ? (i / 2 - 1) : (2 * i - 4);
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            const int o = base + a;
+            float c = 0.f;
+            if (o >= 0 && o < n_out) {
+                int i0;
+                float w[4];
+                resample_plan<MODE>(o, i0, w);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (clampi(i0 - 1 + t, 0, n_in - 1) == i) c += w[t];
+            }
+            coef[a] = c;
+        }
+    }
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_resample_adj(const float* __restrict__ gout, float* __restrict__ gin, int planes, int hi, int wi,
+                                                      int ho, int wo, int accumulate) {
+    long total = (long)planes * hi * wi;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        int ix = (int)(idx % wi);
+        long r = idx / wi;
+        int iy = (int)(r % hi);
+        long p = r / hi;
+        AdjPlan<MODE> py, px;
+        py.make(iy, hi, ho);
+        px.make(ix, wi, wo);
+        const float* g = gout + p * ho * wo;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < AdjPlan<MODE>::NC; ++a) {
+            if (py.coef[a] == 0.f) continue;
+            float rs = 0.f;
+#pragma unroll
+            for (int b = 0; b < AdjPlan<MODE>::NC; ++b)
+                if (px.coef[b] != 0.f) rs += px.coef[b] * g[(py.base + a) * wo + px.base + b];
+            acc += py.coef[a] * rs;
+        }
+        if (accumulate) gin[idx] += acc; else gin[idx] = acc;
+    }
+}
+
+int launch_resample_adj(int mode, const float* gout, float* gin, int planes, int hi, int wi, int accumulate, hipStream_t s) {
+    int ho = mode == 0 ? hi / 2 : hi * 2, wo = mode == 0 ? wi / 2 : wi * 2;
+    long total = (long)planes * hi * wi;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (mode == 0) k_resample_adj<0><<<grid, 256, 0, s>>>(gout, gin, planes, hi, wi, ho, wo, accumulate);
+    else k_resample_adj<1><<<grid, 256, 0, s>>>(gout, gin, planes, hi, wi, ho, wo, accumulate);
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of "resample -> depthwise 3x3": gin = dw^T gout ; dW, dbias
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_dw_bwd(DwBwdArgs a) {
+    __shared__ float Gt[34][35];
+    __shared__ float Ut[34][35];
+    __shared__ float red[4 * 10];
+    const int plane = blockIdx.z;
+    const int c = plane % a.C;
+    const int ty0 = blockIdx.y * 32, tx0 = blockIdx.x * 32;
+    const float* in = a.in + (size_t)plane * a.hi * a.wi;
+    const float* go = a.gout + (size_t)plane * a.n_h * a.n_w;
+    for (int i = threadIdx.x; i < 34 * 34; i += 256) {
+        int uy = i / 34, ux = i - uy * 34;
+        int oy = ty0 + uy - 1, ox = tx0 + ux - 1;
+        float u = 0.f, g = 0.f;
+        if (oy >= 0 && oy < a.n_h && ox >= 0 && ox < a.n_w) {
+            u = resample_at<MODE>(in, a.hi, a.wi, oy, ox);
+            g = go[oy * a.n_w + ox];
+        }
+        Ut[uy][ux] = u;
+        Gt[uy][ux] = g;
+    }
+    __syncthreads();
+    float w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = a.w9[c * 9 + k];
+    float part[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) part[k] = 0.f;
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        int ly = i >> 5, lx = i & 31;
+        int oy = ty0 + ly, ox = tx0 + lx;
+        if (oy < a.n_h && ox < a.n_w) {
+            float gi = 0.f;
+            const float gc = Gt[ly + 1][lx + 1];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    gi += w[dy * 3 + dx] * Gt[ly + 2 - dy][lx + 2 - dx];
+                    part[dy * 3 + dx] += gc * Ut[ly + dy][lx + dx];
+                }
+            part[9] += gc;
+            a.gin[((size_t)plane * a.n_h + oy) * a.n_w + ox] = gi;
+        }
+    }
+    float r = block_sum<10>(part, red);
+    if (threadIdx.x < 9) atomicAdd(a.dw9 + c * 9 + threadIdx.x, r);
+    else if (threadIdx.x == 9) atomicAdd(a.dbias + c, r);
+}
+
+int launch_dw_bwd(int mode, const DwBwdArgs& a, hipStream_t s) {
+    dim3 grid((a.n_w + 31) / 32, (a.n_h + 31) / 32, a.planes);
+    if (mode == 0) k_dw_bwd<0><<<grid, 256, 0, s>>>(a);
+    else k_dw_bwd<1><<<grid, 256, 0, s>>>(a);
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// top of the data-step backward: through Z' = Z - eta*(dw(up(s1)) + RT(R(Z)-pan))   (unlg_former.py:59-61)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dstep_top_bwd(DstepTopArgs a) {
+    __shared__ float Gm[34][35];
+    __shared__ float Ut[34][35];
+    __shared__ float red[4 * 14];
+    const int plane = blockIdx.z;
+    const int c = plane % a.C;
+    const int b = plane / a.C;
+    const int ty0 = blockIdx.y * 32, tx0 = blockIdx.x * 32;
+    const size_t hw = (size_t)a.H * a.W;
+    const float* s1 = a.s1 + (size_t)plane * (a.H / 2) * (a.W / 2);
+    const float* g = a.g + (size_t)plane * hw;
+    const float eta = a.eta[0];
+    for (int i = threadIdx.x; i < 34 * 34; i += 256) {
+        int uy = i / 34, ux = i - uy * 34;
+        int oy = ty0 + uy - 1, ox = tx0 + ux - 1;
+        float u = 0.f, gm = 0.f;
+        if (oy >= 0 && oy < a.H && ox >= 0 && ox < a.W) {
+            u = resample_at<1>(s1, a.H / 2, a.W / 2, oy, ox);
+            gm = -eta * g[(size_t)oy * a.W + ox];
+        }
+        Ut[uy][ux] = u;
+        Gm[uy][ux] = gm;
+    }
+    __syncthreads();
+    float w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = a.w9[c * 9 + k];
+    const float bias3 = a.b9[c];
+    float part[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) part[k] = 0.f;
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        int ly = i >> 5, lx = i & 31;
+        int oy = ty0 + ly, ox = tx0 + lx;
+        if (oy < a.H && ox < a.W) {
+            const size_t pix = (size_t)oy * a.W + ox;
+            const float gm = Gm[ly + 1][lx + 1];
+            const float gv = g[pix];
+            float mt = bias3, gu = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float u = Ut[ly + dy][lx + dx];
+                    mt += w[dy * 3 + dx] * u;
+                    gu += w[dy * 3 + dx] * Gm[ly + 2 - dy][lx + 2 - dx];
+                    part[dy * 3 + dx] += gm * u;
+                }
+            float rz = a.rb[0], dpr = 0.f;
+            for (int cc = 0; cc < a.C; ++cc) {
+                rz += a.rw[cc] * a.z[((size_t)b * a.C + cc) * hw + pix];
+                dpr += a.rtw[cc] * a.g[((size_t)b * a.C + cc) * hw + pix];
+            }
+            dpr *= -eta;
+            const float pr = rz - a.pan[(size_t)b * hw + pix];
+            const float pt = a.rtw[c] * pr + a.rtb[c];
+            part[9] += gm;                                   // d bias(DT.3) and d RT.bias
+            part[10] += -gv * (mt + pt);                     // d eta
+            part[11] += gm * pr;                             // d RT.weight[c]
+            part[12] += dpr * a.z[((size_t)b * a.C + c) * hw + pix];  // d R.weight[c]
+            part[13] += (c == 0) ? dpr : 0.f;                // d R.bias
+            a.gu[(size_t)plane * hw + pix] = gu;
+            a.dz[(size_t)plane * hw + pix] = gv + a.rw[c] * dpr;
+        }
+    }
+    float r = block_sum<14>(part, red);
+    if (threadIdx.x < 9) atomicAdd(a.dw9 + c * 9 + threadIdx.x, r);
+    else if (threadIdx.x == 9) { atomicAdd(a.dbias + c, r); atomicAdd(a.drtb + c, r); }
+    else if (threadIdx.x == 10) atomicAdd(a.deta, r);
+    else if (threadIdx.x == 11) atomicAdd(a.drtw + c, r);
+    else if (threadIdx.x == 12) atomicAdd(a.drw + c, r);
+    else if (threadIdx.x == 13) atomicAdd(a.drb, r);
+}
+
+int launch_dstep_top_bwd(const DstepTopArgs& a, hipStream_t s) {
+    dim3 grid((a.W + 31) / 32, (a.H + 31) / 32, a.B * a.C);
+    k_dstep_top_bwd<<<grid, 256, 0, s>>>(a);
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tail backward: out = Wt x + bt + z
+// ------------------------------------------------------------------------------------------------
+template <int C, int E>
+__global__ __launch_bounds__(256) void k_tail_bwd(TailBwdArgs a) {
+    long p = blockIdx.x * 256L + threadIdx.x;
+    if (p >= a.total) return;
+    long b = p / a.HW, s = p - b * a.HW;
+    float d[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        long o = (b * C + c) * a.HW + s;
+        d[c] = a.dout[o];
+        a.dz[o] = d[c];
+    }
+    float4* dxo = reinterpret_cast<float4*>(a.dx + p * E);
+#pragma unroll
+    for (int k4 = 0; k4 < E / 4; ++k4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc += a.w[c * E + k4 * 4 + u] * d[c];
+            v[u] = acc;
+        }
+        dxo[k4] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    float4* dp = reinterpret_cast<float4*>(a.doutp + p * 16);
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (k4 * 4 + u < C) ? d[(k4 * 4 + u) % C] : 0.f;
+        dp[k4] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+int launch_tail_bwd(int C, const TailBwdArgs& a, hipStream_t s) {
+    int grid = (int)((a.total + 255) / 256);
+    if (C == 4) k_tail_bwd<4, 16><<<grid, 256, 0, s>>>(a);
+    else if (C == 8) k_tail_bwd<8, 32><<<grid, 256, 0, s>>>(a);
+    else { lg_set_error("tail_bwd: C=%d unsupported", C); return -1; }
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// patch_embed backward: x = LN(W (z*dww + dwb) + b)
+// ------------------------------------------------------------------------------------------------
+template <int C, int E>
+__global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
+    __shared__ float red[4 * 2 * E];
+    __shared__ float red2[4 * 2 * C];
+    long p = blockIdx.x * 256L + threadIdx.x;
+    const bool valid = p < a.total;
+    float pl[2 * E], pc[2 * C];
+#pragma unroll
+    for (int i = 0; i < 2 * E; ++i) pl[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * C; ++i) pc[i] = 0.f;
+    if (valid) {
+        long b = p / a.HW, s = p - b * a.HW;
+        float zc[C], t[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { zc[c] = a.z[(b * C + c) * a.HW + s]; t[c] = zc[c] * a.dww[c] + a.dwb[c]; }
+        float e[E];
+#pragma unroll
+        for (int n = 0; n < E; ++n) {
+            float v = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) v += a.w[n * C + c] * t[c];
+            e[n] = v + a.b[n];
+        }
+        float mu, rstd;
+        ln_stats<E>(e, mu, rstd);
+        float dxh[E];
+        float m1 = 0.f, m2 = 0.f;
+        const float4* dxs = reinterpret_cast<const float4*>(a.dx + p * E);
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k) {
+            float4 v = dxs[k];
+            dxh[4 * k] = v.x; dxh[4 * k + 1] = v.y; dxh[4 * k + 2] = v.z; dxh[4 * k + 3] = v.w;
+        }
+#pragma unroll
+        for (int n = 0; n < E; ++n) {
+            const float xh = (e[n] - mu) * rstd;
+            pl[n] = dxh[n] * xh;      // d gamma
+            pl[E + n] = dxh[n];       // d beta
+            dxh[n] *= a.lng[n];
+            m1 += dxh[n];
+            m2 += dxh[n] * xh;
+            e[n] = xh;
+        }
+        m1 *= (1.0f / E);
+        m2 *= (1.0f / E);
+        float de[E];
+#pragma unroll
+        for (int n = 0; n < E; ++n) de[n] = rstd * (dxh[n] - m1 - e[n] * m2);
+        float4* deo = reinterpret_cast<float4*>(a.de + p * E);
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k) deo[k] = make_float4(de[4 * k], de[4 * k + 1], de[4 * k + 2], de[4 * k + 3]);
+        float4* tpo = reinterpret_cast<float4*>(a.tp + p * 16);
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (k4 * 4 + u < C) ? t[(k4 * 4 + u) % C] : 0.f;
+            tpo[k4] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float dt = 0.f;
+#pragma unroll
+            for (int n = 0; n < E; ++n) dt += a.w[n * C + c] * de[n];
+            pc[c] = dt * zc[c];   // d dww
+            pc[C + c] = dt;       // d dwb
+            a.dz[(b * C + c) * a.HW + s] += dt * a.dww[c];
+        }
+    }
+    float r = block_sum<2 * E>(pl, red);
+    if (threadIdx.x < E) atomicAdd(a.d_lng + threadIdx.x, r);
+    else if (threadIdx.x < 2 * E) atomicAdd(a.d_lnb + threadIdx.x - E, r);
+    float r2 = block_sum<2 * C>(pc, red2);
+    if (threadIdx.x < C) atomicAdd(a.d_dww + threadIdx.x, r2);
+    else if (threadIdx.x < 2 * C) atomicAdd(a.d_dwb + threadIdx.x - C, r2);
+}
+
+int launch_embed_bwd(int C, const EmbedBwdArgs& a, hipStream_t s) {
+    int grid = (int)((a.total + 255) / 256);
+    if (C == 4) k_embed_bwd<4, 16><<<grid, 256, 0, s>>>(a);
+    else if (C == 8) k_embed_bwd<8, 32><<<grid, 256, 0, s>>>(a);
+    else { lg_set_error("embed_bwd: C=%d unsupported", C); return -1; }
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// down backward: y = Wd * down2(x) + bd
+// ------------------------------------------------------------------------------------------------
+template <int E>
+__global__ __launch_bounds__(256) void k_down_bwd_a(DownBwdArgs a) {
+    long total = (long)a.B * (a.H / 2) * (a.W / 2);
+    long p = blockIdx.x * 256L + threadIdx.x;
+    if (p >= total) return;
+    float dy[2 * E];
+    const float4* src = reinterpret_cast<const float4*>(a.dy + p * 2 * E);
+#pragma unroll
+    for (int k = 0; k < 2 * E / 4; ++k) {
+        float4 v = src[k];
+        dy[4 * k] = v.x; dy[4 * k + 1] = v.y; dy[4 * k + 2] = v.z; dy[4 * k + 3] = v.w;
+    }
+    float4* duo = reinterpret_cast<float4*>(a.du + p * E);
+#pragma unroll
+    for (int k4 = 0; k4 < E / 4; ++k4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float acc = 0.f;
+#pragma unroll
+            for (int n = 0; n < 2 * E; ++n) acc += a.w[n * E + k4 * 4 + u] * dy[n];
+            v[u] = acc;
+        }
+        duo[k4] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void k_down_bwd_b(DownBwdArgs a) {
+    long total = (long)a.B * a.H * a.W;
+    long p = blockIdx.x * 256L + threadIdx.x;
+    if (p >= total) return;
+    int ix = (int)(p % a.W);
+    long r = p / a.W;
+    int iy = (int)(r % a.H);
+    long b = r / a.H;
+    const int ho = a.H / 2, wo = a.W / 2;
+    AdjPlan<0> py, px;
+    py.make(iy, a.H, ho);
+    px.make(ix, a.W, wo);
+    float acc[E];
+    const float4* sk = reinterpret_cast<const float4*>(a.dskip + p * E);
+#pragma unroll
+    for (int k = 0; k < E / 4; ++k) {
+        float4 v = sk[k];
+        acc[4 * k] = v.x; acc[4 * k + 1] = v.y; acc[4 * k + 2] = v.z; acc[4 * k + 3] = v.w;
+    }
+#pragma unroll
+    for (int ya = 0; ya < 3; ++ya) {
+        if (py.coef[ya] == 0.f) continue;
+#pragma unroll
+        for (int xb = 0; xb < 3; ++xb) {
+            if (px.coef[xb] == 0.f) continue;
+            const float wgt = py.coef[ya] * px.coef[xb];
+            const float4* src = reinterpret_cast<const float4*>(a.du + ((b * ho + py.base + ya) * (long)wo + px.base + xb) * E);
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) {
+                float4 v = src[k];
+                acc[4 * k] += wgt * v.x; acc[4 * k + 1] += wgt * v.y; acc[4 * k + 2] += wgt * v.z; acc[4 * k + 3] += wgt * v.w;
+            }
+        }
+    }
+    float4* dxo = reinterpret_cast<float4*>(a.dx + p * E);
+#pragma unroll
+    for (int k = 0; k < E / 4; ++k) dxo[k] = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+}
+
+int launch_down_bwd_a(int E, const DownBwdArgs& a, hipStream_t s) {
+    long total = (long)a.B * (a.H / 2) * (a.W / 2);
+    int grid = (int)((total + 255) / 256);
+    if (E == 16) k_down_bwd_a<16><<<grid, 256, 0, s>>>(a);
+    else if (E == 32) k_down_bwd_a<32><<<grid, 256, 0, s>>>(a);
+    else { lg_set_error("down_bwd: E=%d unsupported", E); return -1; }
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+int launch_down_bwd_b(int E, const DownBwdArgs& a, hipStream_t s) {
+    long total = (long)a.B * a.H * a.W;
+    int grid = (int)((total + 255) / 256);
+    if (E == 16) k_down_bwd_b<16><<<grid, 256, 0, s>>>(a);
+    else if (E == 32) k_down_bwd_b<32><<<grid, 256, 0, s>>>(a);
+    else { lg_set_error("down_bwd: E=%d unsupported", E); return -1; }
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// up + fusion backward: y = Wf [t ; skip] + bf,  t = Wu up2(xb) + bu  (1x1 conv and resampler commute)
+// ------------------------------------------------------------------------------------------------
+template <int E>
+__global__ __launch_bounds__(256) void k_upfuse_bwd_a(UpFuseBwdArgs a) {
+    long total = (long)a.B * a.H * a.W;
+    long p = blockIdx.x * 256L + threadIdx.x;
+    if (p >= total) return;
+    float dy[E];
+    const float4* src = reinterpret_cast<const float4*>(a.dy + p * E);
+#pragma unroll
+    for (int k = 0; k < E / 4; ++k) {
+        float4 v = src[k];
+        dy[4 * k] = v.x; dy[4 * k + 1] = v.y; dy[4 * k + 2] = v.z; dy[4 * k + 3] = v.w;
+    }
+    float4* dto = reinterpret_cast<float4*>(a.dt + p * E);
+    float4* dso = reinterpret_cast<float4*>(a.dskip + p * E);
+#pragma unroll
+    for (int k4 = 0; k4 < E / 4; ++k4) {
+        float v[4], q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float acc = 0.f, acc2 = 0.f;
+#pragma unroll
+            for (int n = 0; n < E; ++n) {
+                acc += a.fw[n * 2 * E + k4 * 4 + u] * dy[n];
+                acc2 += a.fw[n * 2 * E + E + k4 * 4 + u] * dy[n];
+            }
+            v[u] = acc;
+            q[u] = acc2;
+        }
+        dto[k4] = make_float4(v[0], v[1], v[2], v[3]);
+        dso[k4] = make_float4(q[0], q[1], q[2], q[3]);
+    }
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void k_upfuse_bwd_b(UpFuseBwdArgs a) {
+    const int hi = a.H / 2, wi = a.W / 2;
+    long total = (long)a.B * hi * wi;
+    long p = blockIdx.x * 256L + threadIdx.x;
+    if (p >= total) return;
+    int ix = (int)(p % wi);
+    long r = p / wi;
+    int iy = (int)(r % hi);
+    long b = r / hi;
+    AdjPlan<1> py, px;
+    py.make(iy, hi, a.H);
+    px.make(ix, wi, a.W);
+    float v[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) v[k] = 0.f;
+    for (int ya = 0; ya < 10; ++ya) {
+        const float cy = py.coef[ya];
+        if (cy == 0.f) continue;
+        for (int xb = 0; xb < 10; ++xb) {
+            const float cx = px.coef[xb];
+            if (cx == 0.f) continue;
+            const float wgt = cy * cx;
+            const float4* src = reinterpret_cast<const float4*>(a.dt + ((b * a.H + py.base + ya) * (long)a.W + px.base + xb) * E);
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) {
+                float4 t = src[k];
+                v[4 * k] += wgt * t.x; v[4 * k + 1] += wgt * t.y; v[4 * k + 2] += wgt * t.z; v[4 * k + 3] += wgt * t.w;
+            }
+        }
+    }
+    float4* vo = reinterpret_cast<float4*>(a.v + p * E);
+#pragma unroll
+    for (int k = 0; k < E / 4; ++k) vo[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    float4* dxo = reinterpret_cast<float4*>(a.dxb + p * 2 * E);
+#pragma unroll
+    for (int k4 = 0; k4 < 2 * E / 4; ++k4) {
+        float q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float acc = 0.f;
+#pragma unroll
+            for (int n = 0; n < E; ++n) acc += a.upw[n * 2 * E + k4 * 4 + u] * v[n];
+            q[u] = acc;
+        }
+        dxo[k4] = make_float4(q[0], q[1], q[2], q[3]);
+    }
+}
+
+int launch_upfuse_bwd_a(int E, const UpFuseBwdArgs& a, hipStream_t s) {
+    long total = (long)a.B * a.H * a.W;
+    int grid = (int)((total + 255) / 256);
+    if (E == 16) k_upfuse_bwd_a<16><<<grid, 256, 0, s>>>(a);
+    else if (E == 32) k_upfuse_bwd_a<32><<<grid, 256, 0, s>>>(a);
+    else { lg_set_error("upfuse_bwd: E=%d unsupported", E); return -1; }
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+int launch_upfuse_bwd_b(int E, const UpFuseBwdArgs& a, hipStream_t s) {
+    long total = (long)a.B * (a.H / 2) * (a.W / 2);
+    int grid = (int)((total + 255) / 256);
+    if (E == 16) k_upfuse_bwd_b<16><<<grid, 256, 0, s>>>(a);
+    else if (E == 32) k_upfuse_bwd_b<32><<<grid, 256, 0, s>>>(a);
+    else { lg_set_error("upfuse_bwd: E=%d unsupported", E); return -1; }
+    LG_CHECK_LAUNCH();
+    return 0;
+}

@@ -11,30 +11,7 @@
 // 16-deep block is permuted identically for A and B, which a dot product does not care about.
 #include "kernels.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// acc[mt][nt] += A[mt*16.., :K] * W[nt*16.., :K]^T ; A in LDS (row stride lda), W in global ([N][K] row-major)
-template <int MT, int NT, int K>
-__device__ __forceinline__ void wave_gemm(f32x4 (&acc)[MT][NT], const float* A, int lda, const float* __restrict__ Wg) {
-    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-#pragma unroll 2
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        float4 av[MT], bv[NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const float4*>(A + (mt * 16 + r) * lda + k0 + 4 * g);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float4*>(Wg + (size_t)(nt * 16 + r) * K + k0 + 4 * g);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, bv[nt].x, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].y, bv[nt].y, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].z, bv[nt].z, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].w, bv[nt].w, acc[mt][nt], 0, 0, 0);
-            }
-    }
-}
+#include "mfma.h"
 
 // ------------------------------------------------------------------------------------------------
 // k_ffn1: each wave owns MW = 16*MT pixels end to end (no inter-wave dependency)

@@ -181,6 +181,11 @@ __global__ __launch_bounds__(256) void k_down(DownArgs a) {
             }
         }
     }
+    if (a.u_save) {
+        float4* uo = reinterpret_cast<float4*>(a.u_save + p * E);
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k) uo[k] = make_float4(u[4 * k], u[4 * k + 1], u[4 * k + 2], u[4 * k + 3]);
+    }
     float o[2 * E];
 #pragma unroll
     for (int n = 0; n < 2 * E; ++n) {
@@ -245,6 +250,11 @@ __global__ __launch_bounds__(256) void k_upfuse(UpFuseArgs a) {
 #pragma unroll
         for (int k = 0; k < 2 * E; ++k) v += a.upw[n * 2 * E + k] * u[k];
         t[n] = v + a.upb[n];
+    }
+    if (a.t_save) {
+        float4* to = reinterpret_cast<float4*>(a.t_save + p * E);
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k) to[k] = make_float4(t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
     }
     float sk[E];
     {

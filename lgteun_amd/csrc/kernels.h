@@ -38,6 +38,7 @@ struct DownArgs {
     const float* x;  // [B,H,W,E]
     float* y;        // [B,H/2,W/2,2E]
     float* g;        // [B,E,H/2,W/2]
+    float* u_save;   // optional [B,H/2,W/2,E]: the resampled conv input (for the weight gradient)
     const float *w, *b, *n1g, *n1b;
     int B, H, W;  // input size
 };
@@ -48,6 +49,7 @@ struct UpFuseArgs {
     const float* skip;  // [B,H,W,E]
     float* y;           // [B,H,W,E]
     float* g;           // [B,E/2,H,W]
+    float* t_save;      // optional [B,H,W,E]: up-path tensor after its 1x1 conv (for the weight gradient)
     const float *upw, *upb, *fw, *fb, *n1g, *n1b;
     int B, H, W;  // output size
 };
@@ -69,6 +71,7 @@ struct FftArgs {
     float* o;         // [B,ch,n,n] planar: abs(irfft2(...))
     float* amp;       // optional save [B,ch,n,n/2+1]
     float* pha;       // optional save
+    float* sgn;       // optional save: sign of the irfft2 output [B,ch,n,n]
     const float *ampw, *ampb, *phaw, *phab;  // [ch]
     int planes, ch, n;
 };

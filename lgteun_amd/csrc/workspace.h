@@ -20,6 +20,7 @@ struct BlockBufs {
     float *xin, *xmid, *xout;
     float *g, *o2;     // planar [B,e/2,h,w]
     float *amp, *pha;  // saved spectrum [B,e/2,h,w/2+1] (train)
+    float* sgn;        // saved sign of the irfft2 output [B,e/2,h,w] (train)
     float *h1, *h2, *h3;  // [B,h,w,4e]
 };
 
@@ -30,6 +31,8 @@ struct NetBufs {
     BlockBufs blk[5];
     float* x0;        // embed output = blk[0].xin
     float* deadout;   // output of dead-stage LGTs (faithful mode)
+    float* u_down;    // saved bicubic-downsampled encoder output [B,H/2,W/2,E] (train)
+    float* t_up;      // saved up-path tensor [B,H,W,E] (train)
     size_t bytes;
 };
 
@@ -62,11 +65,12 @@ static inline void carve(const lg_plan* plan, int B, int train, void* base, NetB
         if (train) {
             bb.amp = cv.take(B * (e / 2) * bb.h * (bb.w / 2 + 1));
             bb.pha = cv.take(B * (e / 2) * bb.h * (bb.w / 2 + 1));
+            bb.sgn = cv.take(B * P * e / 2);
             bb.h1 = cv.take(B * P * 4 * e);
             bb.h2 = cv.take(B * P * 4 * e);
             bb.h3 = cv.take(B * P * 4 * e);
         } else {
-            bb.amp = bb.pha = bb.h1 = bb.h3 = nullptr;
+            bb.amp = bb.pha = bb.sgn = bb.h1 = bb.h3 = nullptr;
             bb.h2 = shared_h2;
         }
     }
@@ -76,5 +80,7 @@ static inline void carve(const lg_plan* plan, int B, int train, void* base, NetB
     nb.blk[2].xin = cv.take(B * P1 * 2 * E);  // down output
     nb.blk[3].xin = cv.take(B * P0 * E);      // up+fusion output
     nb.blk[4].xin = nb.blk[3].xout;
+    nb.u_down = train ? cv.take(B * P1 * E) : nullptr;
+    nb.t_up = train ? cv.take(B * P0 * E) : nullptr;
     nb.bytes = cv.off;
 }

@@ -66,3 +66,18 @@ class Ops:
         _lib.check(self.lib.lg_op_block(self.plan, _ptr(self.eng.flat), stage, blk, which, _ptr(x), _ptr(y), _ptr(ws),
                                         ws.numel(), B, _stream_ptr()), 'lg_op_block')
         return y
+
+    def block_bwd(self, stage, blk, which, x, dy):
+        """returns (dx, flat_param_grads).  which 0: dy/dx planar [B,e/2,h,w]; 1,2: NHWC."""
+        B = x.shape[0]
+        dx = torch.empty_like(dy)
+        grads = torch.zeros_like(self.eng.flat)
+        ws = self.ws(B, train=True)
+        _lib.check(self.lib.lg_op_block_bwd(self.plan, _ptr(self.eng.flat), _ptr(grads), stage, blk, which, _ptr(x), _ptr(dy),
+                                            _ptr(dx), _ptr(ws), ws.numel(), B, _stream_ptr()), 'lg_op_block_bwd')
+        return dx, grads
+
+    def grad_of(self, flat_grads, name):
+        i = self.eng.names.index(name)
+        o, p = self.eng.offsets[i], self.eng.params[i]
+        return flat_grads[o:o + p.numel()].view(p.shape)
