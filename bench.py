@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- train image-pairs/sec of the LGTEUN unfolding hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = forward + L1 + backward + Adam (+ StepLR tick) over one synthetic batch already resident in HBM.
+Workload = BASELINE.json configs[1]: GF-2-shaped 4-band 32x32 MS / 128x128 PAN, K=4 stages, 32 pairs per GPU, executed in
+FAITHFUL mode (all K LGTs run forward like the reference; backward over the live graph).  Weak scaling: per-GPU batch fixed.
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline     -- the dominant kernel timed live with HIP events on its launch stream (lg_prof_*), against its roof
+  cpu_baseline -- the oracle's CPU train step (kind "port") on this host's cores, bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md): HBM3E 8 TB/s spec; fp32 matrix (v_mfma_f32_16x16x4_f32) 157.3 TF spec
+PEAK_HBM_GBS = 8000.0
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+C, K, H, B_PER_GPU = 4, 4, 128, 32
+E, P0 = 4 * C, H * H
+
+
+def synth_batch(B, rank, device):
+    """integer DN in [0,2047] / 2047.5 (reference dataset/utils.py:232-249, bit_depth 11); seed configs/unlg_former.py:66"""
+    g = torch.Generator().manual_seed(19971118 + rank)
+
+    def dn(*shape):
+        return (torch.randint(0, 2048, shape, generator=g).float() / 2047.5).to(device)
+    return dn(B, C, H // 4, H // 4), dn(B, 1, H, H), dn(B, C, H, H)
+
+
+def algorithmic_per_launch(kernel, B):
+    """ALGORITHMIC work of one average launch of `kernel` (SURVEY 8d per-unit figures):
+    bytes = what an ideally fused unit moves (reads its input once, writes its output once, fp32); flops = 2 x MAC.
+    Per LGT the kernel runs on 4 level-0 blocks (E ch, P0 px) and 1 level-1 block (2E ch, P0/4 px)."""
+    px = [(E, P0)] * 4 + [(2 * E, P0 // 4)]
+    if kernel in ('ffn1', 'ffn2', 'ffn1_bwd', 'ffn2_bwd'):
+        # the FFN half-block as one fused unit: read x (e), write y (e) per pixel
+        byts = sum(2 * e * p * 4 for e, p in px) / 5 * B
+        flops = {'ffn1': sum(2 * (e * 4 * e + 4 * e * 4 * e) * p for e, p in px),
+                 'ffn2': sum(2 * (9 * 4 * e + 4 * e * e) * p for e, p in px),
+                 'ffn1_bwd': sum(2 * (e * 4 * e + 4 * e * 4 * e + 9 * 4 * e * 2) * p for e, p in px),
+                 'ffn2_bwd': sum(2 * (4 * e * e) * p for e, p in px)}[kernel] / 5 * B
+        return byts, flops
+    if kernel in ('fft', 'attn', 'fft_bwd', 'attn_bwd'):
+        # mixer half-block unit: read x (e), write y (e); the two kernels split it by channel half
+        byts = sum(2 * e * p * 4 for e, p in px) / 5 * B / 2
+        return byts, 0.0
+    raise ValueError(kernel)
+
+
+def host_cores():
+    """cores this process may actually use: cgroup CPU quota if set, else the affinity mask; capped at 32"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(cores):
+    """oracle (CPU restatement, torch CPU fp32) train step: forward(faithful) + L1 + backward + Adam, bounded sample"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import det_params
+    from oracle import lgteun_oracle as orc
+    torch.set_num_threads(cores)
+    Bc = 4
+    P = det_params(C, K, requires_grad=True)
+    ms, pan, gt = synth_batch(Bc, 0, 'cpu')
+    mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in P.items()}
+
+    def step(it):
+        for v in P.values():
+            v.grad = None
+        loss = orc.l1_loss(orc.forward(P, ms, pan, K, mode='faithful'), gt)
+        loss.backward()
+        with torch.no_grad():
+            for k, v in P.items():
+                if v.grad is None:
+                    continue
+                p, m1, v1 = orc.adam_step(v, v.grad, mom[k][0], mom[k][1], it, 1.5e-3)
+                v.copy_(p)
+                mom[k] = (m1, v1)
+    step(1)                                   # warm-up
+    t0 = time.time()
+    n = 2
+    for it in range(n):
+        step(it + 2)
+    dt = (time.time() - t0) / n
+    return dict(value=round(Bc / dt, 3), unit='train image-pairs/sec', cores=cores, kind='port',
+                sample=f'{n} timed train steps (fwd faithful + L1 + bwd + Adam), batch {Bc}, fp32 torch-CPU oracle, after 1 warm-up')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--prof-kernel', default='ffn2', help='kernel timed live for the roofline object')
+    ap.add_argument('--mode', default='faithful', choices=['faithful', 'live'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from lgteun_amd import ddp
+    rank, world, local_rank = ddp.env_world()
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run', file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        ddp.init_from_env('nccl')
+    import torch.distributed as dist
+
+    import lgteun_amd
+    from lgteun_amd import _lib
+    from lgteun_amd.compat import Config
+
+    torch.manual_seed(19971118)
+    net = lgteun_amd.Pansharpening(Config(ms_chans=C), None, stage=K).to(device)
+    net.mode = args.mode
+    net.train()
+    eng = net.engine()
+    if world > 1:
+        eng.attach_ddp()
+    opt = lgteun_amd.FusedAdam(net.parameters(), lr=1.5e-3, betas=(0.9, 0.999))          # configs/unlg_former.py:82-84
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=25900, gamma=0.85)              # :86, stepped every iteration
+    ms, pan, gt = synth_batch(B_PER_GPU, rank, device)
+
+    def step():
+        eng.train_step(ms, pan, gt, opt)
+        sched.step()
+
+    import warnings
+    warnings.filterwarnings('ignore', message='Detected call of')
+    L = _lib.lib()
+    kid = _lib.KERNEL_IDS[args.prof_kernel]
+    _lib.check(L.lg_prof_enable(kid, 64 * (args.steps + 1)), 'lg_prof_enable')
+    for _ in range(args.warmup):
+        step()
+    L.lg_prof_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tot_ms, n_l = ctypes.c_double(), ctypes.c_int64()
+    _lib.check(L.lg_prof_read(ctypes.byref(tot_ms), ctypes.byref(n_l)), 'lg_prof_read')
+    L.lg_prof_disable()
+    loss = float(eng._loss.item()) * world if world == 1 else None
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = B_PER_GPU * world * args.steps / elapsed
+        byts, flops = algorithmic_per_launch(args.prof_kernel, B_PER_GPU)
+        avg_us = tot_ms.value / max(n_l.value, 1) * 1e3
+        ach_gbs = byts / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+        roof = dict(bound='hbm', achieved=round(ach_gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach_gbs / PEAK_HBM_GBS, 4),
+                    traffic=None, kernel=L.lg_kernel_name(kid).decode(), launches=int(n_l.value), avg_launch_us=round(avg_us, 2),
+                    algorithmic_bytes_per_launch=int(byts), algorithmic_flops_per_launch=int(flops),
+                    mfma_frac_fp32=round(flops / (avg_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if avg_us > 0 else None)
+        out = dict(metric='train image-pairs/sec, GF-2 4-band 128x128, K=4, bs=32/GPU', value=round(value, 2), unit='image-pairs/sec',
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
+                   scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload='BASELINE configs[1]: C=4, MS 32x32, PAN 128x128, K=4, 32 pairs/GPU, train step = fwd + L1 + '
+                                        'bwd + Adam + StepLR tick', mode=args.mode, global_batch=B_PER_GPU * world, parallelism=f'dp{world}',
+                               dropout=True),
+                   roofline=roof)
+        if loss is not None:
+            out['final_loss'] = round(loss, 6)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(host_cores())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

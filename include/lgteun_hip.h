@@ -39,6 +39,17 @@ extern "C" {
 #define LG_FLAG_SAVE 2     /* keep what lgteun_backward needs in the workspace */
 #define LG_FLAG_DROPOUT 4  /* training-mode Dropout(0.1) after LGMixer.proj (LGT.py:198,215), counter-hash RNG */
 
+/* flags for lgteun_backward: run only a part (lets the caller start the gradient all-reduce of the LGT bucket
+ * while the data-step backward still runs).  Neither bit set = both parts. */
+#define LG_FLAG_BWD_LGT 8
+#define LG_FLAG_BWD_DATA 16
+
+/* kernel ids for the live HIP-event timing facility (lg_prof_*) */
+enum lg_kernel_id {
+    LG_K_NONE = 0, LG_K_FFN1, LG_K_FFN2, LG_K_FFT, LG_K_ATTN, LG_K_UPFUSE, LG_K_DOWN, LG_K_EMBED, LG_K_TAIL, LG_K_DATASTEP,
+    LG_K_FFN1_BWD, LG_K_FFN2_BWD, LG_K_FFT_BWD, LG_K_ATTN_BWD, LG_K_WGRAD, LG_K_COUNT
+};
+
 typedef struct lg_config {
     int32_t C;       /* MS bands: 4 or 8                      (cfg.ms_chans, unlg_former.py:24) */
     int32_t K;       /* unfolding stages                      (stage kwarg, unlg_former.py:22)  */
@@ -78,6 +89,16 @@ int lg_l1_loss(const float* out, const float* gt, float* dout, float* loss_accum
 int lg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* ranges,
                  int32_t n_ranges, int64_t max_range, int32_t step, float lr, float beta1, float beta2, float eps,
                  float grad_scale, void* stream);
+
+/* Live per-kernel timing: when enabled for `kernel_id`, every launch of that kernel is bracketed by hipEvents recorded on
+ * the stream it is launched on.  lg_prof_read synchronises on the recorded events and returns the summed device time (ms)
+ * and the number of launches since lg_prof_enable / lg_prof_reset.  Host-side event objects are the only thing the library
+ * ever creates; lg_prof_disable destroys them. */
+int lg_prof_enable(int32_t kernel_id, int32_t max_launches);
+int lg_prof_reset(void);
+int lg_prof_read(double* total_ms, int64_t* launches);
+void lg_prof_disable(void);
+const char* lg_kernel_name(int32_t kernel_id);
 
 /* ---- per-op entry points (unit-tested against the oracle; same kernels the orchestrators launch) ---- */
 /* bmu.sampling_ bicubic (basic_module_unformer_v2.py:21-23): mode 0: x0.5, 1: x2, 2: x4.  x [planes,hi,wi]. */

@@ -14,6 +14,10 @@ LIB_PATH = os.path.join(_HERE, '_lgteun_hip.so')
 LG_FLAG_FAITHFUL = 1
 LG_FLAG_SAVE = 2
 LG_FLAG_DROPOUT = 4
+LG_FLAG_BWD_LGT = 8
+LG_FLAG_BWD_DATA = 16
+KERNEL_IDS = {n: i for i, n in enumerate(['none', 'ffn1', 'ffn2', 'fft', 'attn', 'upfuse', 'down', 'embed', 'tail', 'datastep', 'ffn1_bwd',
+                                           'ffn2_bwd', 'fft_bwd', 'attn_bwd', 'wgrad'])}
 
 
 class LgConfig(ctypes.Structure):
@@ -47,6 +51,11 @@ SIGNATURES = {
                             c_void_p]),
     'lg_op_block': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_int32,
                               c_void_p]),
+    'lg_prof_enable': (c_int32, [c_int32, c_int32]),
+    'lg_prof_reset': (c_int32, []),
+    'lg_prof_read': (c_int32, [POINTER(ctypes.c_double), POINTER(c_int64)]),
+    'lg_prof_disable': (None, []),
+    'lg_kernel_name': (c_char_p, [c_int32]),
     'lg_op_block_bwd': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_int32, c_void_p]),
 }

@@ -18,6 +18,63 @@ void lg_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ------------------------------------------------------------------------------------------------
+// live per-kernel timing
+// ------------------------------------------------------------------------------------------------
+static struct {
+    int kid = 0;
+    int cap = 0, n = 0;
+    hipEvent_t* ev = nullptr;  // 2 per launch
+} g_prof;
+
+void lg_prof_begin(int kid, hipStream_t s) {
+    if (kid != g_prof.kid || g_prof.n >= g_prof.cap) return;
+    hipEventRecord(g_prof.ev[2 * g_prof.n], s);
+}
+void lg_prof_end(int kid, hipStream_t s) {
+    if (kid != g_prof.kid || g_prof.n >= g_prof.cap) return;
+    hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
+    g_prof.n++;
+}
+extern "C" void lg_prof_disable(void) {
+    for (int i = 0; i < 2 * g_prof.cap; ++i) hipEventDestroy(g_prof.ev[i]);
+    free(g_prof.ev);
+    g_prof.ev = nullptr;
+    g_prof.cap = g_prof.n = g_prof.kid = 0;
+}
+extern "C" int lg_prof_enable(int32_t kernel_id, int32_t max_launches) {
+    if (kernel_id <= 0 || kernel_id >= LG_K_COUNT || max_launches <= 0) { lg_set_error("prof_enable: invalid argument"); return -1; }
+    lg_prof_disable();
+    g_prof.ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * max_launches);
+    for (int i = 0; i < 2 * max_launches; ++i) {
+        hipError_t e = hipEventCreate(&g_prof.ev[i]);
+        if (e != hipSuccess) { lg_set_error("prof_enable: hipEventCreate: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    g_prof.cap = max_launches;
+    g_prof.kid = kernel_id;
+    return 0;
+}
+extern "C" int lg_prof_reset(void) { g_prof.n = 0; return 0; }
+extern "C" int lg_prof_read(double* total_ms, int64_t* launches) {
+    if (!total_ms || !launches) { lg_set_error("prof_read: null argument"); return -1; }
+    double tot = 0.0;
+    for (int i = 0; i < g_prof.n; ++i) {
+        hipError_t e = hipEventSynchronize(g_prof.ev[2 * i + 1]);
+        if (e != hipSuccess) { lg_set_error("prof_read: %s", hipGetErrorString(e)); return (int)e; }
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = g_prof.n;
+    return 0;
+}
+extern "C" const char* lg_kernel_name(int32_t k) {
+    static const char* names[LG_K_COUNT] = {"none", "k_ffn1", "k_ffn2", "k_fftmix", "k_attn", "k_upfuse", "k_down", "k_embed", "k_tail",
+                                            "k_resample_dw", "k_ffn1_bwd", "k_ffn2_bwd", "k_fftmix_bwd", "k_attn_bwd", "k_wgrad"};
+    return (k >= 0 && k < LG_K_COUNT) ? names[k] : "?";
+}
+
 extern "C" const char* lg_version(void) { return "lgteun_hip 0.1 (gfx950)"; }
 extern "C" const char* lg_last_error(void) { return g_err; }
 

@@ -59,6 +59,16 @@ static inline uint64_t mix_seed(uint64_t seed, int stage, int blk) {
 
 #define LG_EPS 1e-5f
 
+// live per-kernel timing (api.hip): RAII scope used at the top of a launcher
+void lg_prof_begin(int kid, hipStream_t s);
+void lg_prof_end(int kid, hipStream_t s);
+struct ProfScope {
+    int kid;
+    hipStream_t s;
+    ProfScope(int k, hipStream_t st) : kid(k), s(st) { lg_prof_begin(kid, s); }
+    ~ProfScope() { lg_prof_end(kid, s); }
+};
+
 #ifdef __HIPCC__
 // ----------------------------------------------------------------------------------------------
 // device helpers

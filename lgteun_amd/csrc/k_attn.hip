@@ -142,6 +142,7 @@ int launch_pos_transpose(const float* pos, float* posT, hipStream_t s) {
 
 template <int HC>
 static int launch_attn_t(const AttnArgs& a, hipStream_t s) {
+    ProfScope prof__(LG_K_ATTN, s);
     int nwin = a.B * (a.h / 8) * (a.w / 8);
     int nquads = (nwin + 3) / 4;
     size_t lds = (2 * 64 * 64 + 2 * 4 * 64 * HC) * sizeof(float);

@@ -186,6 +186,9 @@ int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, c
     const long P0 = (long)B * c.H * c.W, P1 = P0 / 4;
     const float* posT = nb.posT + (size_t)st * 5 * 2 * 64 * 64;
     float *A = bb.dx[0], *Bf = bb.dx[1], *Cf = bb.dx[2];
+    const bool do_lgt = !(flags & (LG_FLAG_BWD_LGT | LG_FLAG_BWD_DATA)) || (flags & LG_FLAG_BWD_LGT);
+    const bool do_data = !(flags & (LG_FLAG_BWD_LGT | LG_FLAG_BWD_DATA)) || (flags & LG_FLAG_BWD_DATA);
+    if (do_lgt) {
     // ---------------- LGT of the last stage (LGT.py:314-344, reversed)
     TailBwdArgs tb;
     tb.dout = dout; tb.dx = A; tb.doutp = bb.doutp; tb.dz = bb.dzA; tb.w = P + pl->lgt(st, L_TAILW);
@@ -226,7 +229,9 @@ int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, c
     eb.HW = c.H * c.W; eb.total = P0;
     RC(launch_embed_bwd(c.C, eb, s));
     RC(wgrad(bb.de, E, bb.tp, 16, G + pl->lgt(st, L_PE_W), c.C, G + pl->lgt(st, L_PE_B), P0, E, 16, E, c.C, 0, bb.slab, s));
-    // ---------------- K shared data steps, last to first (unlg_former.py:56-61)
+    }
+    if (!do_data) return 0;
+    // ---------------- K shared data steps, last to first (unlg_former.py:56-61); input gradient: bb.dzA
     float* g = bb.dzA;
     float* dz = bb.dzB;
     for (int i = c.K - 1; i >= 0; --i) {

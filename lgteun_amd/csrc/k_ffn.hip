@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void k_ffn1(Ffn1Args a) {
 
 template <int E, int MT>
 static int launch_ffn1_t(const Ffn1Args& a, hipStream_t s) {
+    ProfScope prof__(LG_K_FFN1, s);
     constexpr int N1 = 4 * E, MW = 16 * MT;
     size_t lds = (size_t)4 * MW * ((E + 4) + (N1 + 4)) * sizeof(float);
     static bool attr_done = false;
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(256) void k_ffn2(Ffn2Args a, int tiles_x, int tiles
 
 template <int E, int MT, int TY, int TX>
 static int launch_ffn2_t(const Ffn2Args& a, hipStream_t s) {
+    ProfScope prof__(LG_K_FFN2, s);
     constexpr int N1 = 4 * E, M = TY * TX;
     size_t lds = (size_t)(M * (N1 + 4) + M * (E + 1)) * sizeof(float);
     static bool attr_done = false;

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void k_ffn2_bwd(Ffn2BwdArgs a) {
 
 template <int E, int MT>
 static int launch_ffn2_bwd_t(const Ffn2BwdArgs& a, hipStream_t s) {
+    ProfScope prof__(LG_K_FFN2_BWD, s);
     constexpr int MW = 16 * MT;
     size_t lds = (size_t)4 * MW * (E + 4) * sizeof(float);
     long per_wg = 4L * MW;
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a, int tiles_x, in
 
 template <int E, int MT, int TY, int TX>
 static int launch_ffn1_bwd_t(const Ffn1BwdArgs& a, hipStream_t s) {
+    ProfScope prof__(LG_K_FFN1_BWD, s);
     constexpr int N1 = 4 * E, M = TY * TX;
     size_t lds = (size_t)(2 * M * (N1 + 4) + M * (E + 1) + N1 * 10) * sizeof(float);
     static bool attr_done = false;

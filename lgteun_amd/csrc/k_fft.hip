@@ -126,6 +126,7 @@ __global__ void k_fftmix(FftArgs a, int lg) {
 }
 
 int launch_fftmix(const FftArgs& a, hipStream_t s) {
+    ProfScope prof__(LG_K_FFT, s);
     int n = a.n, lg = 0;
     while ((1 << lg) < n) ++lg;
     if ((1 << lg) != n || n < 8 || n > 128) { lg_set_error("fftmix: plane size %d unsupported (power of two, 8..128)", n); return -2; }
@@ -221,6 +222,7 @@ __global__ void k_fftmix_bwd(FftBwdArgs a, int lg) {
 }
 
 int launch_fftmix_bwd(const FftBwdArgs& a, hipStream_t s) {
+    ProfScope prof__(LG_K_FFT_BWD, s);
     int n = a.n, lg = 0;
     while ((1 << lg) < n) ++lg;
     if ((1 << lg) != n || n < 8 || n > 128) { lg_set_error("fftmix_bwd: plane size %d unsupported", n); return -2; }

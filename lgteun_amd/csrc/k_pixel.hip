@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void k_resample_dw(DwArgs a) {
 }
 
 int launch_resample_dw(int mode, int epi, const DwArgs& a, hipStream_t s) {
+    ProfScope prof__(LG_K_DATASTEP, s);
     dim3 grid((a.wo + 31) / 32, (a.ho + 31) / 32, a.planes);
 #define LG_RDW(M, E) k_resample_dw<M, E><<<grid, 256, 0, s>>>(a)
     if (mode == 0 && epi == 0) LG_RDW(0, 0);
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
 }
 
 int launch_embed(int C, const EmbedArgs& a, hipStream_t s) {
+    ProfScope prof__(LG_K_EMBED, s);
     int grid = (int)((a.total + 255) / 256);
     if (C == 4) k_embed<4, 16><<<grid, 256, 0, s>>>(a);
     else if (C == 8) k_embed<8, 32><<<grid, 256, 0, s>>>(a);
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(256) void k_down(DownArgs a) {
 }
 
 int launch_down(int E, const DownArgs& a, hipStream_t s) {
+    ProfScope prof__(LG_K_DOWN, s);
     long total = (long)a.B * (a.H / 2) * (a.W / 2);
     int grid = (int)((total + 255) / 256);
     if (E == 16) k_down<16><<<grid, 256, 0, s>>>(a);
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(256) void k_upfuse(UpFuseArgs a) {
 }
 
 int launch_upfuse(int E, const UpFuseArgs& a, hipStream_t s) {
+    ProfScope prof__(LG_K_UPFUSE, s);
     long total = (long)a.B * a.H * a.W;
     int grid = (int)((total + 255) / 256);
     if (E == 16) k_upfuse<16><<<grid, 256, 0, s>>>(a);
@@ -317,6 +321,7 @@ __global__ __launch_bounds__(256) void k_tail(TailArgs a) {
 }
 
 int launch_tail(int C, const TailArgs& a, hipStream_t s) {
+    ProfScope prof__(LG_K_TAIL, s);
     int grid = (int)((a.total + 255) / 256);
     if (C == 4) k_tail<4, 16><<<grid, 256, 0, s>>>(a);
     else if (C == 8) k_tail<8, 32><<<grid, 256, 0, s>>>(a);

@@ -3,8 +3,8 @@
 // The reduction runs over PIXELS (up to B*H*W = 524 288 at bs=32), the output is tiny (16..256 squared), so the
 // pixel axis is the MFMA K dimension: v_mfma_f32_16x16x4_f32 with lane (r,g) feeding A[i=r][k=g] = Y[p+g][n0+r] and
 // B[k=g][j=r] = X[p+g][k0+r] -- both operands are read in their natural [pixel][channel] layout, 64-byte segments,
-// no transposes.  Every wave owns a 64x64 block of dW over a slice of the pixels and writes its partial to a slab;
-// a second kernel sums the slab in a fixed order (bitwise reproducible, no float atomics).
+// no transposes.  Every wave owns a 64x64 block of dW over a slice of the pixels; the 4 waves of a workgroup are summed in
+// LDS and the workgroup's partial goes to a slab that a second kernel sums in a fixed slice order.
 #include "kernels.h"
 #include "bwd_kernels.h"
 
@@ -48,47 +48,71 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a, int k_blocks, long p
                 if (i < NT && j < KT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     }
-    // partial -> slab[slice][N][K]
-    const long nslices = (long)gridDim.x * 4;
-    (void)nslices;
-    float* my = slab + slice * ((long)a.N * a.K);
+    // the 4 waves of the workgroup hold partials of the same 64x64 block: sum them in LDS, one slab slice per workgroup
+    __shared__ float red[64 * 64 + 64];
+    for (int i = threadIdx.x; i < 64 * 64 + 64; i += 256) red[i] = 0.f;
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {   // waves take turns: fixed order, no float atomics -> bitwise reproducible
+        if (wave == w) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i < NT && j < KT) {
+                for (int j = 0; j < 4; ++j)
+                    if (i < NT && j < KT) {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) my[(long)(n0 + i * 16 + 4 * g + v) * a.K + k0 + j * 16 + r] = acc[i][j][v];
+                        for (int v = 0; v < 4; ++v) red[(i * 16 + 4 * g + v) * 64 + j * 16 + r] += acc[i][j][v];
+                    }
+            if (a.db && kb == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float s = bsum[i];
+                    s += __shfl_xor(s, 16);
+                    s += __shfl_xor(s, 32);
+                    if (g == 0 && i < NT) red[64 * 64 + i * 16 + r] += s;
+                }
             }
-    if (a.db && kb == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float s = bsum[i];
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if (g == 0 && i < NT) bslab[slice * a.N + n0 + i * 16 + r] = s;
         }
+        __syncthreads();
     }
+    float* my = slab + (long)blockIdx.x * ((long)a.N * a.K);
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int rr = i >> 6, cc = i & 63;
+        if (rr < NT * 16 && cc < KT * 16) my[(long)(n0 + rr) * a.K + k0 + cc] = red[i];
+    }
+    if (a.db && kb == 0 && threadIdx.x < NT * 16) bslab[(long)blockIdx.x * a.N + n0 + threadIdx.x] = red[64 * 64 + threadIdx.x];
 }
 
 // dst[row*ld + col] += sum_s slab[s][row*cols + col]   for row < rows_valid, col < cols_valid
+// block = 64 consecutive outputs x 4 slice phases (fixed summation order: bitwise reproducible)
 __global__ __launch_bounds__(256) void k_reduce_slab(const float* __restrict__ slab, long nslices, int rows, int cols, float* dst,
                                                      int ld, int rows_valid, int cols_valid) {
+    __shared__ float part[4][64];
     const long n = (long)rows * cols;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+    const int o = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const long i = blockIdx.x * 64L + o;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        long k = ph;
+        for (; k + 12 < nslices; k += 16) {
+            s0 += slab[k * n + i];
+            s1 += slab[(k + 4) * n + i];
+            s2 += slab[(k + 8) * n + i];
+            s3 += slab[(k + 12) * n + i];
+        }
+        for (; k < nslices; k += 4) s0 += slab[k * n + i];
+    }
+    part[ph][o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ph == 0 && i < n) {
         const int row = (int)(i / cols), col = (int)(i - (long)row * cols);
-        if (row >= rows_valid || col >= cols_valid) continue;
-        float s = 0.f;
-        for (long k = 0; k < nslices; ++k) s += slab[k * n + i];
-        dst[(long)row * ld + col] += s;
+        if (row < rows_valid && col < cols_valid) dst[(long)row * ld + col] += (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
     }
 }
 
 int launch_reduce_slab(const float* slab, long nslices, int rows, int cols, float* dst, int ld, int rows_valid, int cols_valid,
                        hipStream_t s) {
     long n = (long)rows * cols;
-    int grid = (int)((n + 255) / 256);
-    if (grid > 1024) grid = 1024;
+    int grid = (int)((n + 63) / 64);
     k_reduce_slab<<<grid, 256, 0, s>>>(slab, nslices, rows, cols, dst, ld, rows_valid, cols_valid);
     LG_CHECK_LAUNCH();
     return 0;
@@ -99,10 +123,11 @@ size_t wgrad_slab_floats(int N, int K, long P) {
     const int blocks = ((N + 63) / 64) * ((K + 63) / 64);
     long splits = 512 / blocks;
     if (splits < 1) splits = 1;
-    return (size_t)(splits * 4) * ((size_t)N * K + N);
+    return (size_t)splits * ((size_t)N * K + N);
 }
 
 int launch_wgrad(const WgradArgs& a, float* slab, hipStream_t s) {
+    ProfScope prof__(LG_K_WGRAD, s);
     if ((a.N & 15) || (a.K & 15) || a.N <= 0 || a.K <= 0 || a.P <= 0) { lg_set_error("wgrad: N,K must be positive multiples of 16"); return -2; }
     const int n_blocks = (a.N + 63) / 64, k_blocks = (a.K + 63) / 64;
     const int blocks = n_blocks * k_blocks;
@@ -116,13 +141,13 @@ int launch_wgrad(const WgradArgs& a, float* slab, hipStream_t s) {
     nslices = (a.P + px - 1) / px;
     splits = (nslices + 3) / 4;
     nslices = splits * 4;
-    float* bslab = slab + nslices * (long)a.N * a.K;
+    float* bslab = slab + splits * (long)a.N * a.K;
     dim3 grid((unsigned)splits, (unsigned)blocks);
     if (a.xf == 1) k_wgrad<1><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);
     else k_wgrad<0><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);
     LG_CHECK_LAUNCH();
-    int rc = launch_reduce_slab(slab, nslices, a.N, a.K, a.dW, a.ldw, a.n_valid, a.k_valid, s);
+    int rc = launch_reduce_slab(slab, splits, a.N, a.K, a.dW, a.ldw, a.n_valid, a.k_valid, s);
     if (rc) return rc;
-    if (a.db) rc = launch_reduce_slab(bslab, nslices, 1, a.N, a.db, a.N, 1, a.n_valid, s);
+    if (a.db) rc = launch_reduce_slab(bslab, splits, 1, a.N, a.db, a.N, 1, a.n_valid, s);
     return rc;
 }

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import LG_FLAG_DROPOUT, LG_FLAG_FAITHFUL, LG_FLAG_SAVE, LgConfig, check
+from ._lib import (LG_FLAG_BWD_DATA, LG_FLAG_BWD_LGT, LG_FLAG_DROPOUT, LG_FLAG_FAITHFUL, LG_FLAG_SAVE, LgConfig, check)
 
 
 def _block_names(pre):
@@ -109,6 +109,18 @@ class Engine:
         self._seed_ctr = 0
         self.world = 1
         self.process_group = None
+        self.buckets = None
+
+    def attach_ddp(self, group=None):
+        """join a torch.distributed group: broadcast rank-0 weights, reduce the live gradient ranges every step"""
+        import torch.distributed as dist
+        from .ddp import GradBuckets, broadcast_flat
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.process_group = group
+        if self.world > 1:
+            broadcast_flat(self.flat, 0, group)
+            self.buckets = GradBuckets(self.live_ranges, group)
+        return self
 
     # ------------------------------------------------------------------------------------------
     def valid(self):
@@ -204,11 +216,15 @@ class Engine:
         n_local = out.numel()
         check(self.lib.lg_l1_loss(_ptr(out), _ptr(gt), _ptr(dout), _ptr(self._loss), n_local, n_local * self.world,
                                   float(loss_weight), _stream_ptr()), 'lg_l1_loss')
-        self.backward_raw(saved, dout, self.gflat, flags, seed)
         if self.world > 1:
-            import torch.distributed as dist
-            for a, b in self.live_ranges:
-                dist.all_reduce(self.gflat[a:b], op=dist.ReduceOp.SUM, group=self.process_group)
+            # bucket 1 (last stage's LGT) is reduced over RCCL while the K data-step backwards still run
+            self.backward_raw(saved, dout, self.gflat, flags | LG_FLAG_BWD_LGT, seed)
+            self.buckets.start(self.gflat, 1)
+            self.backward_raw(saved, dout, self.gflat, flags | LG_FLAG_BWD_DATA, seed)
+            self.buckets.start(self.gflat, 0)
+            self.buckets.finish()
+        else:
+            self.backward_raw(saved, dout, self.gflat, flags, seed)
         optim.step_flat(self)
         return self._loss
 
