@@ -54,6 +54,20 @@ def canonical_names(C, K):
     return names
 
 
+def flat_layout(names, numels, K):
+    """offsets (floats, each tensor 16-byte aligned) of the canonical tensors in the flat buffers, total size, indices of
+    the live tensors and the two contiguous live ranges [(shared + eta), (last stage's LGT)]  (SURVEY D3)."""
+    offs, total = [], 0
+    for n in numels:
+        offs.append(total)
+        total += (max(n, 1) + 3) // 4 * 4
+    n_head = 12 + K
+    first_last = 12 + K + 119 * (K - 1)
+    live_idx = list(range(n_head)) + list(range(first_last, len(names)))
+    live_ranges = [(0, offs[n_head] if n_head < len(offs) else total), (offs[first_last], total)]
+    return offs, total, live_idx, live_ranges
+
+
 def _stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -80,10 +94,7 @@ class Engine:
                 raise RuntimeError(f'parameter {n}: expected float32 on {dev}')
         self.device = dev
         self.names = names
-        offs, total = [], 0
-        for n in names:
-            offs.append(total)
-            total += (max(params[n].numel(), 1) + 3) // 4 * 4
+        offs, total, self.live_idx, self.live_ranges = flat_layout(names, [params[n].numel() for n in names], self.K)
         self.offsets = offs
         self.total = total
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -94,11 +105,6 @@ class Engine:
             view.copy_(p.data)
             p.data = view
         self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
-        # live set: shared + eta, and the last stage's LGT -> two contiguous ranges of the flat buffers
-        n_head = 12 + self.K
-        first_last = 12 + self.K + 119 * (self.K - 1)
-        self.live_idx = list(range(n_head)) + list(range(first_last, len(names)))
-        self.live_ranges = [(0, offs[n_head] if n_head < len(offs) else total), (offs[first_last], total)]
         self.ranges_dev = torch.tensor([v for r in self.live_ranges for v in r], dtype=torch.int64, device=dev)
         self.max_range = max(b - a for a, b in self.live_ranges)
         self._first_ptr = self.params[0].data_ptr()

@@ -1,0 +1,94 @@
+"""CPU (no GPU) checks of the drop-in boundary: registry / config / module surface / C-ABI symbol table."""
+import ctypes
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import state_shapes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_registry_and_module_surface():
+    import lgteun_amd
+    from lgteun_amd.compat import Config
+    assert 'UnlgFormer' in lgteun_amd.MODELS and lgteun_amd.MODELS.get('UnlgFormer') is lgteun_amd.UnlgFormer
+    with pytest.raises(KeyError):
+        lgteun_amd.build_model('NoSuchModel')
+    for C, K in ((4, 2), (8, 1)):
+        net = lgteun_amd.Pansharpening(Config(ms_chans=C), None, stage=K)
+        sd = net.state_dict()
+        assert list(sd.keys()) == lgteun_amd.canonical_names(C, K)          # same keys, same ORDER as the reference
+        assert {k: tuple(v.shape) for k, v in sd.items()} == state_shapes(C, K)
+        assert all(float(sd[f'eta.{i}']) == pytest.approx(0.1) for i in range(K))   # unlg_former.py:40
+        blob = pickle.dumps(net)                                              # reference pickles whole modules (base_model.py:362)
+        net2 = pickle.loads(blob)
+        assert list(net2.state_dict().keys()) == list(sd.keys())
+        with pytest.raises(RuntimeError):                                     # no CPU compute path
+            net(torch.zeros(1, C, 8, 8), torch.zeros(1, 1, 32, 32))
+
+
+def test_runner_from_config_file(tmp_path):
+    """configs/unlg_former.py-style entry -> Config.fromfile -> build_model(cfg.model_type, ...) (main.py:61-122)"""
+    import logging
+    import lgteun_amd
+    from lgteun_amd.compat import Config
+    cfg_file = tmp_path / 'unlg_former.py'
+    cfg_file.write_text(
+        "name = 'LGTEUN'\nms_chans = 4\nmodel_type = 'UnlgFormer'\ndatas = 'GF-2'\n"
+        f"work_dir = r'{tmp_path}/out'\ncuda = True\nbit_depth = 11\nmax_iter = 10\nseed = 19971118\n"
+        "optim_cfg = {'core_module': dict(type='Adam', betas=(0.9, 0.999), lr=1.5e-3)}\n"
+        "sched_cfg = dict(step_size=25900, gamma=0.85)\nloss_cfg = {'rec_loss': dict(type='l1', w=1.)}\n"
+        "model_cfg = {'core_module': dict(stage=2)}\n")
+    cfg = Config.fromfile(str(cfg_file))
+    assert cfg.model_type == 'UnlgFormer' and cfg.loss_cfg['rec_loss'].w == 1.0 and cfg.model_cfg['core_module']['stage'] == 2
+    runner = lgteun_amd.build_model(cfg.model_type, cfg, logging.getLogger('t'), None, None, None)
+    core = runner.module_dict['core_module']
+    assert core.stage == 2 and core.in_channels == 4
+    assert 'rec_loss' in runner.loss_module and runner.loss_module['rec_loss'].get_type() == 'l1'
+    runner.set_optim()
+    runner.set_sched()
+    assert runner.optim_dict['core_module'].is_fused_lgteun
+    lrs = []
+    for _ in range(3):
+        lrs.append(runner.optim_dict['core_module'].param_groups[0]['lr'])
+        runner.sched_dict['core_module'].step()
+    assert lrs == [1.5e-3] * 3
+    bad = Config(dict(cfg, loss_cfg={'rec_loss': dict(type='huber', w=1.)}))
+    with pytest.raises(SystemExit):                                          # losses.py:33-34 behaviour
+        lgteun_amd.build_model('UnlgFormer', bad, None, None, None, None)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from lgteun_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'lgteun_hip.h')).read()
+    declared = set(re.findall(r'\b(lg_[a-z0-9_]+|lgteun_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'lg_config', 'lg_plan'}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('HIP library not built in this environment')
+    L = ctypes.CDLL(_lib.LIB_PATH)          # load only: no compute calls without a GPU
+    for name in declared:
+        assert hasattr(L, name), name
+    L.lg_version.restype = ctypes.c_char_p
+    assert b'gfx950' in L.lg_version()
+    # argument validation works without a device
+    L.lg_plan_create.restype = ctypes.c_int32
+    cfg = _lib.LgConfig(5, 2, 32, 32, 0)
+    offs = (ctypes.c_int64 * 4)(0, 4, 8, 12)
+    out = ctypes.c_void_p()
+    assert L.lg_plan_create(ctypes.byref(cfg), offs, 4, ctypes.byref(out)) < 0
+    L.lg_last_error.restype = ctypes.c_char_p
+    assert b'C must be 4 or 8' in L.lg_last_error()
+
+
+def test_metrics_match_oracle():
+    from lgteun_amd import metrics as mtc
+    from oracle import lgteun_oracle as orc
+    rng = np.random.default_rng(0)
+    a, b = rng.uniform(0, 2047, (16, 16, 4)), rng.uniform(0, 2047, (16, 16, 4))
+    assert mtc.psnr(a, b) == orc.psnr(a, b) and mtc.sam(a, b) == orc.sam(a, b) and mtc.ergas(a, b) == orc.ergas(a, b)

@@ -1,0 +1,101 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the DDP bucket logic (lgteun_amd.ddp + the flat live-range layout).
+Each rank computes ITS SHARE of the global-mean L1 gradient with the oracle on its batch shard, scatters it into the flat
+gradient buffer at the engine's offsets and SUM-all-reduces the two live ranges; the result must equal the single-process
+gradient on the concatenated batch (SURVEY 8e equivalence test), and dead-stage slots must stay untouched."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import det_params, state_shapes
+from oracle import detweights as dw
+from oracle import lgteun_oracle as orc
+
+C, K, H, B = 4, 2, 8, 4
+
+
+def _flat_grads(P, ms, pan, gt, n_global):
+    from lgteun_amd.engine import canonical_names, flat_layout
+    names = canonical_names(C, K)
+    shapes = state_shapes(C, K)
+    numels = [int(np.prod(shapes[n])) if len(shapes[n]) else 1 for n in names]
+    offs, total, live_idx, live_ranges = flat_layout(names, numels, K)
+    out = orc.forward(P, ms, pan, K)
+    loss = (out - gt).abs().sum() / n_global          # this rank's share of the global mean
+    loss.backward()
+    flat = torch.zeros(total)
+    for i in live_idx:
+        g = P[names[i]].grad
+        flat[offs[i]:offs[i] + g.numel()] = g.reshape(-1)
+    return flat, live_ranges, float(loss)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from lgteun_amd import ddp
+    r, w, _ = ddp.init_from_env('gloo')
+    assert (r, w) == (rank, world)
+    ms, pan, gt = dw.make_inputs(B, C, H, H, seed=21, kind='smooth')
+    a, b = ddp.shard_bounds(B, rank, world)
+    T = torch.from_numpy
+    P = det_params(C, K, requires_grad=True)
+    n_global = B * C * 4 * H * 4 * H
+    flat, ranges, loss = _flat_grads(P, T(ms[a:b]), T(pan[a:b]), T(gt[a:b]), n_global)
+    # weights broadcast from rank 0 must leave identical buffers identical
+    wflat = torch.cat([v.detach().reshape(-1) for v in P.values()])
+    before = wflat.clone()
+    ddp.broadcast_flat(wflat, 0)
+    assert torch.equal(wflat, before)
+    buckets = ddp.GradBuckets(ranges)
+    buckets.start(flat, 1)       # LGT bucket first (overlaps the data-step backward on the GPU path)
+    buckets.start(flat, 0)
+    buckets.finish()
+    lt = torch.tensor([loss], dtype=torch.float64)
+    dist.all_reduce(lt)
+    if rank == 0:
+        q.put((flat.numpy(), float(lt.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_equal_single_process():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, loss2 = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ms, pan, gt = dw.make_inputs(B, C, H, H, seed=21, kind='smooth')
+    T = torch.from_numpy
+    P = det_params(C, K, requires_grad=True)
+    want, ranges, loss1 = _flat_grads(P, T(ms), T(pan), T(gt), B * C * 4 * H * 4 * H)
+    assert abs(loss1 - loss2) < 1e-6
+    want = want.numpy()
+    assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1.0) + 1e-7
+    (a0, b0), (a1, b1) = ranges
+    assert np.all(got[b0:a1] == 0.0)                 # dead-stage slots never receive a gradient
+    assert np.abs(got[a1:b1]).max() > 0 and np.abs(got[a0:b0]).max() > 0
+
+
+def test_shard_bounds_and_layout():
+    from lgteun_amd import ddp
+    from lgteun_amd.engine import canonical_names, flat_layout
+    assert [ddp.shard_bounds(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 256)]
+    with pytest.raises(ValueError):
+        ddp.shard_bounds(10, 0, 4)
+    names = canonical_names(4, 4)
+    shapes = state_shapes(4, 4)
+    offs, total, live_idx, ranges = flat_layout(names, [int(np.prod(shapes[n])) if len(shapes[n]) else 1 for n in names], 4)
+    assert all(o % 4 == 0 for o in offs) and len(live_idx) == 12 + 4 + 119
+    assert ranges[0][0] == 0 and ranges[1][1] == total and ranges[0][1] <= ranges[1][0]
