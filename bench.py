@@ -122,10 +122,12 @@ def main():
         if args.gpus != 1 or world != 1:
             print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run', file=sys.stderr)
             sys.exit(2)
+    if local_rank >= torch.cuda.device_count():   # rehearsal of N ranks on fewer GPUs (gloo): share devices
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
-        ddp.init_from_env('nccl')
+        ddp.init_from_env(os.environ.get('LGTEUN_DDP_BACKEND', 'nccl'))   # nccl = RCCL over xGMI; gloo only for rehearsal
     import torch.distributed as dist
 
     import lgteun_amd

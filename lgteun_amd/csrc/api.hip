@@ -172,20 +172,24 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
                          int B, int flags, hipStream_t s) {
     int rc;
     Ffn1Args a1;
-    a1.x = bb.xmid; a1.h1 = (flags & LG_FLAG_SAVE) ? bb.h1 : nullptr; a1.h2 = bb.h2;
+    a1.x = bb.xmid; a1.a1s = (flags & LG_FLAG_SAVE) ? bb.a1 : nullptr; a1.g1s = (flags & LG_FLAG_SAVE) ? bb.g1 : nullptr; a1.h2 = bb.h2;
     a1.ln2g = P + pl->blk(stage, j, B_LN2G); a1.ln2b = P + pl->blk(stage, j, B_LN2B);
     a1.w1 = P + pl->blk(stage, j, B_W1); a1.b1 = P + pl->blk(stage, j, B_B1);
     a1.w2 = P + pl->blk(stage, j, B_W2); a1.b2 = P + pl->blk(stage, j, B_B2);
     a1.P = (long)B * bb.h * bb.w;
-    if ((rc = launch_ffn1(bb.e, a1, s))) return rc;
     Ffn2Args a2;
-    a2.h2 = bb.h2; a2.x = bb.xmid; a2.h3 = (flags & LG_FLAG_SAVE) ? bb.h3 : nullptr; a2.y = bb.xout;
+    a2.h2 = bb.h2; a2.x = bb.xmid; a2.a3s = (flags & LG_FLAG_SAVE) ? bb.a3 : nullptr; a2.g3s = (flags & LG_FLAG_SAVE) ? bb.g3 : nullptr; a2.y = bb.xout;
     a2.g = g_next;
     a2.dww = P + pl->blk(stage, j, B_DWW); a2.dwb = P + pl->blk(stage, j, B_DWB);
     a2.w3 = P + pl->blk(stage, j, B_W3); a2.b3 = P + pl->blk(stage, j, B_B3);
     a2.n1g = g_next ? P + pl->blk(stage, next_blk, B_LN1G) : nullptr;
     a2.n1b = g_next ? P + pl->blk(stage, next_blk, B_LN1B) : nullptr;
     a2.B = B; a2.h = bb.h; a2.w = bb.w;
+    a1.h2 = (flags & LG_FLAG_SAVE) ? bb.h2 : nullptr;   // fused path: h2 only leaves the chip when the backward needs it
+    rc = launch_ffn_fused(bb.e, a1, a2, s);
+    if (rc != 1) return rc;
+    a1.h2 = bb.h2;
+    if ((rc = launch_ffn1(bb.e, a1, s))) return rc;
     return launch_ffn2(bb.e, a2, s);
 }
 

@@ -94,27 +94,30 @@ int launch_upfuse_bwd_a(int E, const UpFuseBwdArgs& a, hipStream_t s);
 int launch_upfuse_bwd_b(int E, const UpFuseBwdArgs& a, hipStream_t s);
 
 // ---------------- feed_forward backward ----------------
-struct Ffn2BwdArgs {
-    const float* dy;   // [P,e] grad wrt block output
-    const float* h3;   // [P,4e] saved pre-GELU
-    float* dh3;        // [P,4e]
-    const float* w3t;  // [4e][e] transposed W3
-    long P;
+struct FfnDwBwdArgs {
+    const float* dy;   // [B,h,w,e]  grad wrt block output
+    const float* g3;   // [B,h,w,4e] saved gelu'(h3)
+    const float* h2;   // [B,h,w,4e] saved
+    float* dh2;        // [B,h,w,4e] out: dw3x3^T ((dy W3) * g3)
+    const float *w3t;  // [4e][e] transposed W3
+    const float* dww;  // [4e,1,3,3]
+    float *slab_w, *slab_b;  // [tiles][4e*9], [tiles][4e] partials
+    float *d_dww, *d_dwb;
+    int B, h, w;
 };
-int launch_ffn2_bwd(int e, const Ffn2BwdArgs& a, hipStream_t s);
+size_t ffn_dw_bwd_slab_floats(int e, int B, int h, int w);
+int launch_ffn_dw_bwd(int e, const FfnDwBwdArgs& a, hipStream_t s);
 struct Ffn1BwdArgs {
-    const float* dh3;  // [B,h,w,4e]
-    const float* h2;   // saved
-    const float* h1;   // saved pre-GELU
-    const float* x;    // [B,h,w,e] block mid activation (LN2 input)
-    const float* dy;   // [B,h,w,e] grad wrt block output (residual path)
-    float* dh2;        // [P,4e] (wgrad operand)
+    const float* dh2;  // [P,4e]
+    const float* g1;   // [P,4e] saved gelu'(h1)
+    const float* x;    // [P,e] block mid activation (LN2 input)
+    const float* dy;   // [P,e] grad wrt block output (residual path)
     float* dh1;        // [P,4e] (wgrad operand)
     float* y2;         // [P,e] LN2(x) (wgrad operand)
     float* dx;         // [P,e] grad wrt x
-    const float *dww, *w2t, *w1t, *ln2g, *ln2b;
-    float *d_dww, *d_dwb, *d_ln2g, *d_ln2b;
-    int B, h, w;
+    const float *w2t, *w1t, *ln2g, *ln2b;
+    float *d_ln2g, *d_ln2b;
+    long P;
 };
 int launch_ffn1_bwd(int e, const Ffn1BwdArgs& a, hipStream_t s);
 int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[cols][rows]

@@ -73,11 +73,38 @@ struct ProfScope {
 // ----------------------------------------------------------------------------------------------
 // device helpers
 // ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf(|z|) by Abramowitz & Stegun 7.1.26 (max abs error 1.5e-7, i.e. fp32 rounding level), branch-free:
+// 1 rcp + 1 exp + 6 fma instead of the piecewise libm erff.  Returns 1 - erf(|z|) as `tail` too (keeps the far
+// negative GELU tail from cancelling against 1).
+__device__ __forceinline__ float erfc_abs_f(float az) {
+    const float t = __frcp_rn(1.0f + 0.3275911f * az);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    return poly * __expf(-az * az);
+}
+// GELU(x) = x * Phi(x), Phi(x) = 0.5*erfc(-x/sqrt2)   (nn.GELU() exact/erf form, LGT.py:97,99)
+__device__ __forceinline__ float gelu_f(float x) {
+    const float z = x * 0.70710678118654752440f;
+    const float e = 0.5f * erfc_abs_f(fabsf(z));      // 0.5*erfc(|z|)
+    const float phi = z >= 0.f ? 1.0f - e : e;         // Phi(x)
+    return x * phi;
+}
+// gelu and its derivative together (they share erfc and the exp): a = x*Phi(x), g = Phi(x) + x*phi(x)
+__device__ __forceinline__ void gelu_both_f(float x, float& a, float& g) {
+    const float az = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * az);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float ex = __expf(-az * az);            // exp(-x^2/2)
+    const float e = 0.5f * poly * ex;
+    const float cdf = x >= 0.f ? 1.0f - e : e;
+    a = x * cdf;
+    g = cdf + x * (0.39894228040143267794f * ex);
+}
 // d gelu / dx = Phi(x) + x * phi(x)
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    const float z = x * 0.70710678118654752440f;
+    const float e = 0.5f * erfc_abs_f(fabsf(z));
+    const float cdf = z >= 0.f ? 1.0f - e : e;
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

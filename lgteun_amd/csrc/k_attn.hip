@@ -152,7 +152,7 @@ static int launch_attn_t(const AttnArgs& a, hipStream_t s) {
         if (e != hipSuccess) { lg_set_error("attn: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
-    int grid = nquads < 2048 ? nquads : 2048;
+    int grid = nquads < 768 ? nquads : 768;   // 3 resident workgroups per CU; each walks its window quads with pos_emb^T in LDS
     k_attn<HC><<<grid, 256, lds, s>>>(a, nwin, nquads);
     LG_CHECK_LAUNCH();
     return 0;

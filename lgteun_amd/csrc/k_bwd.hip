@@ -9,7 +9,7 @@
 struct BwdBufs {
     float *dzA, *dzB, *gu3, *gs1, *gu1, *gr, *gd3, *gt1, *gd1;
     float *dx[3];
-    float *doutp, *de, *tp, *dh3, *dh2, *dh1, *y2, *do2, *dg, *dym, *cat, *y1, *dqkv, *dpos_slab;
+    float *doutp, *de, *tp, *dh2, *dh1, *y2, *do2, *dg, *dym, *cat, *y1, *dqkv, *dpos_slab;
     float *w3t, *w2t, *w1t, *slab, *dt, *dskip, *v, *du;
     size_t bytes;
 };
@@ -23,7 +23,7 @@ static void carve_bwd(const lg_plan* plan, int B, void* base, BwdBufs& bb) {
     bb.gr = cv.take(C * P1 / 4); bb.gd3 = cv.take(C * P1 / 4);
     for (int i = 0; i < 3; ++i) bb.dx[i] = cv.take(P0 * E);
     bb.doutp = cv.take(P0 * 16); bb.de = cv.take(P0 * E); bb.tp = cv.take(P0 * 16);
-    bb.dh3 = cv.take(P0 * 4 * E); bb.dh2 = cv.take(P0 * 4 * E); bb.dh1 = cv.take(P0 * 4 * E);
+    bb.dh2 = cv.take(P0 * 4 * E); bb.dh1 = cv.take(P0 * 4 * E);
     bb.y2 = cv.take(P0 * E); bb.do2 = cv.take(P0 * E / 2); bb.dg = cv.take(P0 * E / 2);
     bb.dym = cv.take(P0 * E); bb.cat = cv.take(P0 * E); bb.y1 = cv.take(P0 * 16 > P0 * E / 2 ? P0 * 16 : P0 * E / 2);
     bb.dqkv = cv.take(P0 * 2 * E);
@@ -31,7 +31,9 @@ static void carve_bwd(const lg_plan* plan, int B, void* base, BwdBufs& bb) {
     bb.w3t = cv.take(8 * E * 2 * E); bb.w2t = cv.take(8 * E * 8 * E); bb.w1t = cv.take(8 * E * 2 * E);
     size_t sl = wgrad_slab_floats((int)(8 * E), (int)(8 * E), (long)P0);
     size_t sl2 = wgrad_slab_floats(64, 64, (long)P0);
-    bb.slab = cv.take(sl > sl2 ? sl : sl2);
+    size_t sl3 = ffn_dw_bwd_slab_floats((int)E, B, c.H, c.W);
+    if (sl2 > sl) sl = sl2;
+    bb.slab = cv.take(sl > sl3 ? sl : sl3);
     bb.dt = cv.take(P0 * E); bb.dskip = cv.take(P0 * E); bb.v = cv.take(P1 * E); bb.du = cv.take(P1 * E);
     bb.bytes = cv.off;
 }
@@ -60,20 +62,21 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
     RC(launch_transpose(P + pl->blk(st, j, B_W3), bb.w3t, e, n1, s));
     RC(launch_transpose(P + pl->blk(st, j, B_W2), bb.w2t, n1, n1, s));
     RC(launch_transpose(P + pl->blk(st, j, B_W1), bb.w1t, n1, e, s));
-    Ffn2BwdArgs f2;
-    f2.dy = dy; f2.h3 = fb.h3; f2.dh3 = bb.dh3; f2.w3t = bb.w3t; f2.P = Pn;
-    RC(launch_ffn2_bwd(e, f2, s));
-    RC(wgrad(dy, e, fb.h3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 1, bb.slab, s));
+    FfnDwBwdArgs fd;
+    fd.dy = dy; fd.g3 = fb.g3; fd.h2 = fb.h2; fd.dh2 = bb.dh2; fd.w3t = bb.w3t; fd.dww = P + pl->blk(st, j, B_DWW);
+    fd.slab_w = bb.slab; fd.slab_b = bb.slab + ffn_dw_bwd_slab_floats(e, B, fb.h, fb.w) / 10 * 9;
+    fd.d_dww = G + pl->blk(st, j, B_DWW); fd.d_dwb = G + pl->blk(st, j, B_DWB);
+    fd.B = B; fd.h = fb.h; fd.w = fb.w;
+    RC(launch_ffn_dw_bwd(e, fd, s));
+    RC(wgrad(dy, e, fb.a3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 0, bb.slab, s));
     Ffn1BwdArgs f1;
-    f1.dh3 = bb.dh3; f1.h2 = fb.h2; f1.h1 = fb.h1; f1.x = fb.xmid; f1.dy = dy;
-    f1.dh2 = bb.dh2; f1.dh1 = bb.dh1; f1.y2 = bb.y2; f1.dx = tmp;
-    f1.dww = P + pl->blk(st, j, B_DWW); f1.w2t = bb.w2t; f1.w1t = bb.w1t;
+    f1.dh2 = bb.dh2; f1.g1 = fb.g1; f1.x = fb.xmid; f1.dy = dy; f1.dh1 = bb.dh1; f1.y2 = bb.y2; f1.dx = tmp;
+    f1.w2t = bb.w2t; f1.w1t = bb.w1t;
     f1.ln2g = P + pl->blk(st, j, B_LN2G); f1.ln2b = P + pl->blk(st, j, B_LN2B);
-    f1.d_dww = G + pl->blk(st, j, B_DWW); f1.d_dwb = G + pl->blk(st, j, B_DWB);
     f1.d_ln2g = G + pl->blk(st, j, B_LN2G); f1.d_ln2b = G + pl->blk(st, j, B_LN2B);
-    f1.B = B; f1.h = fb.h; f1.w = fb.w;
+    f1.P = Pn;
     RC(launch_ffn1_bwd(e, f1, s));
-    RC(wgrad(bb.dh2, n1, fb.h1, n1, G + pl->blk(st, j, B_W2), n1, G + pl->blk(st, j, B_B2), Pn, n1, n1, n1, n1, 1, bb.slab, s));
+    RC(wgrad(bb.dh2, n1, fb.a1, n1, G + pl->blk(st, j, B_W2), n1, G + pl->blk(st, j, B_B2), Pn, n1, n1, n1, n1, 0, bb.slab, s));
     RC(wgrad(bb.dh1, n1, bb.y2, e, G + pl->blk(st, j, B_W1), e, G + pl->blk(st, j, B_B1), Pn, n1, e, n1, e, 0, bb.slab, s));
     return 0;
 }

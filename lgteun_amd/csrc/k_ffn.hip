@@ -75,8 +75,14 @@ __global__ __launch_bounds__(256) void k_ffn1(Ffn1Args a) {
                 for (int v = 0; v < 4; ++v) {
                     const int row = mt * 16 + 4 * g + v;
                     float h = acc[mt][nt][v] + bias;
-                    if (a.h1 && p0 + row < a.P) a.h1[(p0 + row) * N1 + col] = h;
-                    bufH[row * LDH + col] = gelu_f(h);
+                    if (a.a1s) {
+                        float av, gv;
+                        gelu_both_f(h, av, gv);
+                        if (p0 + row < a.P) { a.a1s[(p0 + row) * N1 + col] = av; a.g1s[(p0 + row) * N1 + col] = gv; }
+                        bufH[row * LDH + col] = av;
+                    } else {
+                        bufH[row * LDH + col] = gelu_f(h);
+                    }
                 }
             }
     }
@@ -178,8 +184,17 @@ __global__ __launch_bounds__(256) void k_ffn2(Ffn2Args a, int tiles_x, int tiles
                     }
                 }
                 acc.x += bq[0]; acc.y += bq[1]; acc.z += bq[2]; acc.w += bq[3];
-                if (a.h3) *reinterpret_cast<float4*>(a.h3 + ((b * a.h + y) * (long)a.w + x) * N1 + 4 * q) = acc;
-                acc = make_float4(gelu_f(acc.x), gelu_f(acc.y), gelu_f(acc.z), gelu_f(acc.w));
+                if (a.a3s) {
+                    float4 av, gv;
+                    gelu_both_f(acc.x, av.x, gv.x); gelu_both_f(acc.y, av.y, gv.y);
+                    gelu_both_f(acc.z, av.z, gv.z); gelu_both_f(acc.w, av.w, gv.w);
+                    const long o = ((b * a.h + y) * (long)a.w + x) * N1 + 4 * q;
+                    *reinterpret_cast<float4*>(a.a3s + o) = av;
+                    *reinterpret_cast<float4*>(a.g3s + o) = gv;
+                    acc = av;
+                } else {
+                    acc = make_float4(gelu_f(acc.x), gelu_f(acc.y), gelu_f(acc.z), gelu_f(acc.w));
+                }
             }
             *reinterpret_cast<float4*>(bufH + m * LDH + 4 * q) = acc;
         }
@@ -255,4 +270,248 @@ int launch_ffn2(int e, const Ffn2Args& a, hipStream_t s) {
     if (e == 64) return launch_ffn2_t<64, 1, 8, 8>(a, s);
     lg_set_error("ffn2: e=%d unsupported", e);
     return -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_ffn_fused: the whole feed_forward half-block in one kernel.  A workgroup owns an 8x16 pixel tile; the two
+// channel-mixing GEMMs are recomputed on the 10x18 halo tile (x1.41 of their flops) so that h2 -- the only tensor with
+// spatial coupling (depthwise 3x3) -- never leaves LDS.  HBM traffic drops from {x, h2 write, h2 read x taps, x, y}
+// to the algorithmic {x (+halo), y}.  LDS: LN(x) halo tile [192][e+4], h2 halo tile [180][4e+4], one [16][4e+4]
+// scratch per wave (a1 chunk, later gelu(dw(h2)) chunk): 81.7 KB at e=16 -> two workgroups per CU.
+// Optionally saves h1/h2/h3 of the inner pixels for the backward (live stage).
+// ------------------------------------------------------------------------------------------------
+struct FfnFusedArgs {
+    Ffn1Args a1;
+    Ffn2Args a2;
+};
+
+template <int E>
+__global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int tiles_x, int tiles_y) {
+    constexpr int N1 = 4 * E, TY = 8, TX = 16, HX = TX + 2, HY = TY + 2, NH = HX * HY /*180*/, MH = 192, M = TY * TX;
+    constexpr int LDA = E + 4, LDH = N1 + 4, LDO = E + 1, CQ = N1 / 4, NT3 = E / 16;
+    static_assert(CQ <= 64 && 64 % CQ == 0, "quad mapping");
+    extern __shared__ float smem[];
+    float* bufA = smem;                       // [MH][LDA]   LN2(x) on the halo tile; later [M][LDO] output tile
+    float* bufH2 = smem + MH * LDA;           // [NH][LDH]   h2 on the halo tile (0 outside the image)
+    float* scr = bufH2 + NH * LDH;            // [4][16][LDH] per-wave chunk
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    float* my = scr + wave * 16 * LDH;
+    int t = blockIdx.x;
+    const int tx_i = t % tiles_x;
+    t /= tiles_x;
+    const int ty_i = t % tiles_y;
+    const long b = t / tiles_y;
+    const int y0 = ty_i * TY, x0 = tx_i * TX;
+    const int h = a2.h, w = a2.w;
+    // ---- P0: halo tile load + LayerNorm (one pixel per thread, 192 rows; rows >= 180 and out-of-image pixels are zero)
+    if (threadIdx.x < MH) {
+        const int m = threadIdx.x;
+        const int hy = m / HX, hx = m - hy * HX;
+        const int y = y0 + hy - 1, x = x0 + hx - 1;
+        float xv[E];
+        const bool in = (m < NH) && y >= 0 && y < h && x >= 0 && x < w;
+        if (in) {
+            const float4* src = reinterpret_cast<const float4*>(a1.x + ((b * h + y) * (long)w + x) * E);
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) {
+                float4 v = src[k];
+                xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
+            }
+            float mu, rstd;
+            ln_stats<E>(xv, mu, rstd);
+#pragma unroll
+            for (int c = 0; c < E; ++c) xv[c] = (xv[c] - mu) * rstd * a1.ln2g[c] + a1.ln2b[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < E; ++c) xv[c] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k)
+            *reinterpret_cast<float4*>(bufA + m * LDA + 4 * k) = make_float4(xv[4 * k], xv[4 * k + 1], xv[4 * k + 2], xv[4 * k + 3]);
+    }
+    __syncthreads();
+    // weights as MFMA B fragments, resident in registers for the whole tile when they fit (e = 16: 16 + 64 + 16 VGPRs);
+    // otherwise every row chunk re-reads them through L1 (the vector-memory path, not the GEMM, then sets the pace)
+    constexpr bool RB = (E == 16);
+    float4 w1f[RB ? 4 : 1][1], w2f[RB ? 4 : 1][RB ? 4 : 1];
+    if (RB) {
+        load_bfrag<4, 1>(reinterpret_cast<float4(&)[4][1]>(w1f), a1.w1, E);
+        load_bfrag<4, 4>(reinterpret_cast<float4(&)[4][4]>(w2f), a1.w2, N1);
+    }
+    // ---- P1: per wave, 3 chunks of 16 halo pixels: GEMM1 -> GELU -> GEMM2 -> h2 tile
+    for (int ch = 0; ch < 3; ++ch) {
+        const int row0 = (wave * 3 + ch) * 16;
+        // validity / global pixel index of the 4 rows this lane owns in the C layout
+        long prow[4];
+        bool inner[4], inimg[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int m = row0 + 4 * g + v;
+            const int hy = m / HX, hx = m - hy * HX;
+            const int y = y0 + hy - 1, x = x0 + hx - 1;
+            inimg[v] = (m < NH) && y >= 0 && y < h && x >= 0 && x < w;
+            inner[v] = inimg[v] && hy >= 1 && hy <= TY && hx >= 1 && hx <= TX;
+            prow[v] = (b * h + y) * (long)w + x;
+        }
+        for (int nc = 0; nc < N1; nc += 64) {
+            f32x4 acc[1][4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (RB) wave_gemm_rb<1, 4, 1>(acc, bufA + row0 * LDA, LDA, reinterpret_cast<const float4(&)[4][1]>(w1f));
+            else wave_gemm<1, 4, E>(acc, bufA + row0 * LDA, LDA, a1.w1 + (size_t)nc * E);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int col = nc + nt * 16 + r;
+                const float bias = a1.b1[col];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float hh = acc[0][nt][v] + bias;
+                    if (a1.a1s) {
+                        float av, gv;
+                        gelu_both_f(hh, av, gv);
+                        if (inner[v]) { a1.a1s[prow[v] * N1 + col] = av; a1.g1s[prow[v] * N1 + col] = gv; }
+                        my[(4 * g + v) * LDH + col] = av;
+                    } else {
+                        my[(4 * g + v) * LDH + col] = gelu_f(hh);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int nc = 0; nc < N1; nc += 64) {
+            f32x4 acc[1][4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (RB) wave_gemm_rb<1, 4, 4>(acc, my, LDH, reinterpret_cast<const float4(&)[4][4]>(w2f));
+            else wave_gemm<1, 4, N1>(acc, my, LDH, a1.w2 + (size_t)nc * N1);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int col = nc + nt * 16 + r;
+                const float bias = a1.b2[col];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int m = row0 + 4 * g + v;
+                    const float hh = inimg[v] ? acc[0][nt][v] + bias : 0.f;   // dep_conv zero-pads h2 (basic_module_unformer_v2.py:18)
+                    if (a1.h2 && inner[v]) a1.h2[prow[v] * N1 + col] = hh;
+                    if (m < NH) bufH2[m * LDH + col] = hh;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // ---- P2: per wave, 2 chunks of 16 inner pixels: dw3x3 + GELU -> scratch -> GEMM3 -> output tile (in bufA's space)
+    float* bufO = bufA;
+    {
+        const int q = lane % CQ;
+        float wq[4][9], bq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wq[u][k] = a2.dww[(4 * q + u) * 9 + k];
+            bq[u] = a2.dwb[4 * q + u];
+        }
+        float4 w3f[RB ? 1 : 1][RB ? 4 : 1];
+        if (RB) load_bfrag<1, 4>(reinterpret_cast<float4(&)[1][4]>(w3f), a2.w3, N1);
+        for (int ch = 0; ch < 2; ++ch) {
+            const int m0 = (wave * 2 + ch) * 16;
+            for (int mm = lane / CQ; mm < 16; mm += 64 / CQ) {
+                const int m = m0 + mm;
+                const int ty = m / TX, tx = m - ty * TX;
+                float4 acc = make_float4(bq[0], bq[1], bq[2], bq[3]);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float4 v = *reinterpret_cast<const float4*>(bufH2 + ((ty + dy) * HX + tx + dx) * LDH + 4 * q);
+                        acc.x += wq[0][dy * 3 + dx] * v.x; acc.y += wq[1][dy * 3 + dx] * v.y;
+                        acc.z += wq[2][dy * 3 + dx] * v.z; acc.w += wq[3][dy * 3 + dx] * v.w;
+                    }
+                const int y = y0 + ty, x = x0 + tx;
+                float4 av;
+                if (a2.a3s) {
+                    float4 gv;
+                    gelu_both_f(acc.x, av.x, gv.x); gelu_both_f(acc.y, av.y, gv.y);
+                    gelu_both_f(acc.z, av.z, gv.z); gelu_both_f(acc.w, av.w, gv.w);
+                    if (y < h && x < w) {
+                        const long o = ((b * h + y) * (long)w + x) * N1 + 4 * q;
+                        *reinterpret_cast<float4*>(a2.a3s + o) = av;
+                        *reinterpret_cast<float4*>(a2.g3s + o) = gv;
+                    }
+                } else {
+                    av = make_float4(gelu_f(acc.x), gelu_f(acc.y), gelu_f(acc.z), gelu_f(acc.w));
+                }
+                *reinterpret_cast<float4*>(my + mm * LDH + 4 * q) = av;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            f32x4 acc3[1][NT3];
+#pragma unroll
+            for (int nt = 0; nt < NT3; ++nt) acc3[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (RB) wave_gemm_rb<1, 1, 4>(reinterpret_cast<f32x4(&)[1][1]>(acc3), my, LDH, reinterpret_cast<const float4(&)[1][4]>(w3f));
+            else wave_gemm<1, NT3, N1>(acc3, my, LDH, a2.w3);
+#pragma unroll
+            for (int nt = 0; nt < NT3; ++nt) {
+                const int col = nt * 16 + r;
+                const float bias = a2.b3[col];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) bufO[(m0 + 4 * g + v) * LDO + col] = acc3[0][nt][v] + bias;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    // ---- P3: residual, store, planar LN1 half for the next block
+    if (threadIdx.x < M) {
+        const int m = threadIdx.x;
+        const int y = y0 + m / TX, x = x0 + m % TX;
+        if (y < h && x < w) {
+            const long p = (b * h + y) * (long)w + x;
+            float o[E];
+            const float4* xs = reinterpret_cast<const float4*>(a2.x + p * E);
+            float4* yo = reinterpret_cast<float4*>(a2.y + p * E);
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) {
+                float4 xr = xs[k];
+                o[4 * k] = xr.x + bufO[m * LDO + 4 * k];
+                o[4 * k + 1] = xr.y + bufO[m * LDO + 4 * k + 1];
+                o[4 * k + 2] = xr.z + bufO[m * LDO + 4 * k + 2];
+                o[4 * k + 3] = xr.w + bufO[m * LDO + 4 * k + 3];
+                yo[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+            }
+            if (a2.g) {
+                float mu, rstd;
+                ln_stats<E>(o, mu, rstd);
+                const long hw = (long)h * w, s = (long)y * w + x;
+#pragma unroll
+                for (int n = E / 2; n < E; ++n) a2.g[(b * (E / 2) + (n - E / 2)) * hw + s] = (o[n] - mu) * rstd * a2.n1g[n] + a2.n1b[n];
+            }
+        }
+    }
+}
+
+template <int E>
+static int launch_ffn_fused_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
+    ProfScope prof__(LG_K_FFN2, s);
+    constexpr int N1 = 4 * E;
+    size_t lds = (size_t)(192 * (E + 4) + 180 * (N1 + 4) + 4 * 16 * (N1 + 4)) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_fused<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { lg_set_error("ffn_fused: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    int tiles_x = (a2.w + 15) / 16, tiles_y = (a2.h + 7) / 8;
+    int grid = a2.B * tiles_x * tiles_y;
+    k_ffn_fused<E><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y);
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+// returns 1 if the fused kernel does not cover this size (caller falls back to k_ffn1 + k_ffn2)
+int launch_ffn_fused(int e, const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
+    if (e == 16) return launch_ffn_fused_t<16>(a1, a2, s);
+    if (e == 32) return launch_ffn_fused_t<32>(a1, a2, s);
+    return 1;
 }

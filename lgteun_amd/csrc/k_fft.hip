@@ -21,27 +21,29 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int n, i
     const int half = n >> 1;
     const int items = n * half;
     for (int st = 0; st < lg; ++st) {
-        const int m = INVERSE ? (1 << st) : (half >> st);
-        const int twstep = half / m;  // n / (2m)
+        // butterfly half-span m = 2^ms; twiddle stride n/(2m) = 2^(lg-1-ms).  All index math is shifts and masks.
+        const int ms = INVERSE ? st : (lg - 1 - st);
+        const int m = 1 << ms;
+        const int twshift = lg - 1 - ms;
         for (int it = threadIdx.x; it < items; it += blockDim.x) {
             int line, t;
-            if (COLS) { t = it / n; line = it - t * n; } else { line = it / half; t = it - line * half; }
+            if (COLS) { t = it >> lg; line = it & (n - 1); } else { line = it >> (lg - 1); t = it & (half - 1); }
             if (COLS) {
                 int kx = (int)(__brev((unsigned)line) >> (32 - lg));
                 if (kx > half) continue;
             }
-            int blk = t / m, j = t - blk * m;
-            int i0 = blk * 2 * m + j, i1 = i0 + m;
-            int a0 = COLS ? (i0 * n + line) : (line * n + i0);
-            int a1 = COLS ? (i1 * n + line) : (line * n + i1);
-            float2 w = tw[j * twstep];
-            float2 a = buf[a0], b = buf[a1];
+            const int j = t & (m - 1);
+            const int i0 = ((t >> ms) << (ms + 1)) + j, i1 = i0 + m;
+            const int a0 = COLS ? ((i0 << lg) + line) : ((line << lg) + i0);
+            const int a1 = COLS ? ((i1 << lg) + line) : ((line << lg) + i1);
+            const float2 w = tw[j << twshift];
+            const float2 a = buf[a0], b = buf[a1];
             if (!INVERSE) {
-                float2 d = make_float2(a.x - b.x, a.y - b.y);
+                const float2 d = make_float2(a.x - b.x, a.y - b.y);
                 buf[a0] = make_float2(a.x + b.x, a.y + b.y);
                 buf[a1] = cmul(d, w);
             } else {
-                float2 bw = cmulc(b, w);
+                const float2 bw = cmulc(b, w);
                 buf[a0] = make_float2(a.x + bw.x, a.y + bw.y);
                 buf[a1] = make_float2(a.x - bw.x, a.y - bw.y);
             }
@@ -91,7 +93,7 @@ __global__ void k_fftmix(FftArgs a, int lg) {
     // ---- amplitude / phase edit (LGT.py:168-177)
     const float aw = a.ampw[ch], ab = a.ampb[ch], pw = a.phaw[ch], pb = a.phab[ch];
     for (int it = threadIdx.x; it < n * n; it += blockDim.x) {
-        int q = it / n, p = it - q * n;
+        int q = it >> lg, p = it & (n - 1);
         int kx = (int)(__brev((unsigned)p) >> (32 - lg));
         if (kx > half) continue;
         float2 f = buf[it];
@@ -170,7 +172,7 @@ __global__ void k_fftmix_bwd(FftBwdArgs a, int lg) {
     const float nn = (float)n * (float)n;
     float s_aw = 0.f, s_ab = 0.f, s_pw = 0.f, s_pb = 0.f;
     for (int it = threadIdx.x; it < n * n; it += blockDim.x) {
-        int q = it / n, p = it - q * n;
+        int q = it >> lg, p = it & (n - 1);
         int kx = (int)(__brev((unsigned)p) >> (32 - lg));
         if (kx > half) continue;
         int ky = (int)(__brev((unsigned)q) >> (32 - lg));

@@ -95,7 +95,8 @@ int launch_pos_transpose(const float* pos, float* posT, hipStream_t s);
 // ---------------- feed_forward, LGT.py:91-109 ----------------
 struct Ffn1Args {
     const float* x;  // [P, e]   (P = B*h*w)
-    float* h1;       // optional save, pre-GELU [P,4e]
+    float* a1s;      // optional save [P,4e]: gelu(h1)        (conv input of W2 for its weight gradient)
+    float* g1s;      // optional save [P,4e]: gelu'(h1)       (backward never re-evaluates GELU)
     float* h2;       // [P,4e] = W2 gelu(W1 LN(x) + b1) + b2
     const float *ln2g, *ln2b, *w1, *b1, *w2, *b2;
     long P;
@@ -104,13 +105,16 @@ int launch_ffn1(int e, const Ffn1Args& a, hipStream_t s);
 struct Ffn2Args {
     const float* h2;  // [B,h,w,4e]
     const float* x;   // [B,h,w,e] residual input
-    float* h3;        // optional save, pre-GELU [B,h,w,4e]
+    float* a3s;       // optional save [B,h,w,4e]: gelu(h3)
+    float* g3s;       // optional save [B,h,w,4e]: gelu'(h3)
     float* y;         // [B,h,w,e]
     float* g;         // optional [B,e/2,h,w] LN1(next block)(y) global half
     const float *dww, *dwb, *w3, *b3, *n1g, *n1b;
     int B, h, w;
 };
 int launch_ffn2(int e, const Ffn2Args& a, hipStream_t s);
+// fused feed_forward half-block (h2 stays in LDS); returns 1 when e is not covered -> use launch_ffn1 + launch_ffn2
+int launch_ffn_fused(int e, const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s);
 
 // test helper: g[B,e/2,HW] = LayerNorm(x)[..., e/2:] (the epilogue the producing kernels fuse)
 int launch_ln_split(int e, const float* x, const float* n1g, const float* n1b, float* g, int B, int HW, hipStream_t s);

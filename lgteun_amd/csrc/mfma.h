@@ -27,3 +27,32 @@ __device__ __forceinline__ void wave_gemm(f32x4 (&acc)[MT][NT], const float* A, 
     }
 }
 
+
+// ---- register-resident weights: B fragments of a [N][K] row-major weight, loaded once and reused for every row chunk
+template <int NT, int KB>
+__device__ __forceinline__ void load_bfrag(float4 (&bf)[NT][KB], const float* __restrict__ Wg, int K) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) bf[nt][kb] = *reinterpret_cast<const float4*>(Wg + (size_t)(nt * 16 + r) * K + kb * 16 + 4 * g);
+}
+template <int MT, int NT, int KB>
+__device__ __forceinline__ void wave_gemm_rb(f32x4 (&acc)[MT][NT], const float* A, int lda, const float4 (&bf)[NT][KB]) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        float4 av[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const float4*>(A + (mt * 16 + r) * lda + kb * 16 + 4 * g);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, bf[nt][kb].x, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].y, bf[nt][kb].y, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].z, bf[nt][kb].z, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].w, bf[nt][kb].w, acc[mt][nt], 0, 0, 0);
+            }
+    }
+}

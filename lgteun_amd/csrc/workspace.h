@@ -21,7 +21,7 @@ struct BlockBufs {
     float *g, *o2;     // planar [B,e/2,h,w]
     float *amp, *pha;  // saved spectrum [B,e/2,h,w/2+1] (train)
     float* sgn;        // saved sign of the irfft2 output [B,e/2,h,w] (train)
-    float *h1, *h2, *h3;  // [B,h,w,4e]
+    float *a1, *g1, *h2, *a3, *g3;  // [B,h,w,4e]: gelu(h1), gelu'(h1), h2, gelu(h3), gelu'(h3)  (a*, g* train only)
 };
 
 struct NetBufs {
@@ -66,11 +66,13 @@ static inline void carve(const lg_plan* plan, int B, int train, void* base, NetB
             bb.amp = cv.take(B * (e / 2) * bb.h * (bb.w / 2 + 1));
             bb.pha = cv.take(B * (e / 2) * bb.h * (bb.w / 2 + 1));
             bb.sgn = cv.take(B * P * e / 2);
-            bb.h1 = cv.take(B * P * 4 * e);
+            bb.a1 = cv.take(B * P * 4 * e);
+            bb.g1 = cv.take(B * P * 4 * e);
             bb.h2 = cv.take(B * P * 4 * e);
-            bb.h3 = cv.take(B * P * 4 * e);
+            bb.a3 = cv.take(B * P * 4 * e);
+            bb.g3 = cv.take(B * P * 4 * e);
         } else {
-            bb.amp = bb.pha = bb.sgn = bb.h1 = bb.h3 = nullptr;
+            bb.amp = bb.pha = bb.sgn = bb.a1 = bb.g1 = bb.a3 = bb.g3 = nullptr;
             bb.h2 = shared_h2;
         }
     }
