@@ -77,7 +77,7 @@ struct ProfScope {
 // 1 rcp + 1 exp + 6 fma instead of the piecewise libm erff.  Returns 1 - erf(|z|) as `tail` too (keeps the far
 // negative GELU tail from cancelling against 1).
 __device__ __forceinline__ float erfc_abs_f(float az) {
-    const float t = __frcp_rn(1.0f + 0.3275911f * az);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);
     const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
     return poly * __expf(-az * az);
 }
@@ -91,7 +91,7 @@ __device__ __forceinline__ float gelu_f(float x) {
 // gelu and its derivative together (they share erfc and the exp): a = x*Phi(x), g = Phi(x) + x*phi(x)
 __device__ __forceinline__ void gelu_both_f(float x, float& a, float& g) {
     const float az = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * az);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);
     const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
     const float ex = __expf(-az * az);            // exp(-x^2/2)
     const float e = 0.5f * poly * ex;
@@ -163,7 +163,7 @@ __device__ __forceinline__ void ln_stats(const float (&x)[E], float& mu, float& 
     float v = 0.f;
 #pragma unroll
     for (int i = 0; i < E; ++i) { float d = x[i] - mu; v += d * d; }
-    rstd = 1.0f / sqrtf(v * (1.0f / E) + LG_EPS);
+    rstd = __builtin_amdgcn_rsqf(v * (1.0f / E) + LG_EPS);   // v_rsq_f32 (1 ulp) instead of the IEEE sqrt + divide sequence
 }
 
 // counter-hash RNG for dropout: keep-mask of element idx under seed (keep prob 0.9)

@@ -12,7 +12,7 @@
 template <int HC>
 __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) {
     constexpr int E = 2 * HC, D = HC / 2;
-    extern __shared__ float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sPos = smem;                       // [2][64][64]  posT[h][j][i]
     float* sK = smem + 2 * 64 * 64;           // [4][64][HC]
     float* sV = sK + 4 * 64 * HC;             // [4][64][HC]
@@ -69,14 +69,20 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
             float o1[HC];
 #pragma unroll
             for (int hd = 0; hd < 2; ++hd) {
+                // K_j / V_j rows of this head as 16-byte LDS broadcasts (ds_read_b128, immediate offsets)
+                const float4* kh = reinterpret_cast<const float4*>(myK + hd * D);
+                const float4* vh = reinterpret_cast<const float4*>(myV + hd * D);
+                const float* ph = sPos + hd * 64 * 64 + lane;
                 float sc[64];
                 float mx = -3.0e38f;
 #pragma unroll
                 for (int j = 0; j < 64; ++j) {
-                    float s = 0.f;
+                    float s = ph[j * 64];
 #pragma unroll
-                    for (int c = 0; c < D; ++c) s += q[hd * D + c] * myK[j * HC + hd * D + c];
-                    s += sPos[(hd * 64 + j) * 64 + lane];
+                    for (int c4 = 0; c4 < D / 4; ++c4) {
+                        const float4 kv = kh[j * (HC / 4) + c4];
+                        s += q[hd * D + 4 * c4] * kv.x + q[hd * D + 4 * c4 + 1] * kv.y + q[hd * D + 4 * c4 + 2] * kv.z + q[hd * D + 4 * c4 + 3] * kv.w;
+                    }
                     sc[j] = s;
                     mx = fmaxf(mx, s);
                 }
@@ -86,12 +92,15 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
                 for (int c = 0; c < D; ++c) acc[c] = 0.f;
 #pragma unroll
                 for (int j = 0; j < 64; ++j) {
-                    float pj = expf(sc[j] - mx);
+                    const float pj = __expf(sc[j] - mx);
                     l += pj;
 #pragma unroll
-                    for (int c = 0; c < D; ++c) acc[c] += pj * myV[j * HC + hd * D + c];
+                    for (int c4 = 0; c4 < D / 4; ++c4) {
+                        const float4 vv = vh[j * (HC / 4) + c4];
+                        acc[4 * c4] += pj * vv.x; acc[4 * c4 + 1] += pj * vv.y; acc[4 * c4 + 2] += pj * vv.z; acc[4 * c4 + 3] += pj * vv.w;
+                    }
                 }
-                float inv = 1.0f / l;
+                const float inv = __builtin_amdgcn_rcpf(l);
 #pragma unroll
                 for (int c = 0; c < D; ++c) o1[hd * D + c] = acc[c] * inv;
             }

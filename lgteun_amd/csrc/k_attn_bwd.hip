@@ -19,7 +19,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
     constexpr int Y1LD = (HC + 15) / 16 * 16, DQLD = (3 * HC + 15) / 16 * 16;  // wgrad operands are padded to 16 columns
     constexpr int PW = 4 * 64 * HC + 2 * 64 * 3;  // floats of LDS per wave
     constexpr int PLD = 65;                       // padded pos_emb row: conflict-free for lane = query AND lane = key
-    extern __shared__ float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sPos = smem;                    // [2][64 i][65]  pos_emb[h][i][j]
     float* sDpos = smem + 2 * 64 * PLD;    // [2][64 i][65]  accumulated dS
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -114,15 +114,18 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                 for (int c = 0; c < D; ++c) { q[c] = sQ[lane * HC + hd * D + c]; dOi[c] = sDO[lane * HC + hd * D + c]; }
                 const float* prow = sPos + (hd * 64 + lane) * PLD;
                 float* drow = sDpos + (hd * 64 + lane) * PLD;
-                const float* kh = sK + hd * D;
-                const float* vh = sV + hd * D;
+                const float4* kh = reinterpret_cast<const float4*>(sK + hd * D);   // rows as 16-byte LDS broadcasts
+                const float4* vh = reinterpret_cast<const float4*>(sV + hd * D);
                 float sc[64];
                 float mx = -3.0e38f;
 #pragma unroll
                 for (int j = 0; j < 64; ++j) {
                     float t = prow[j];
 #pragma unroll
-                    for (int c = 0; c < D; ++c) t += q[c] * kh[j * HC + c];
+                    for (int c4 = 0; c4 < D / 4; ++c4) {
+                        const float4 kv = kh[j * (HC / 4) + c4];
+                        t += q[4 * c4] * kv.x + q[4 * c4 + 1] * kv.y + q[4 * c4 + 2] * kv.z + q[4 * c4 + 3] * kv.w;
+                    }
                     sc[j] = t;
                     mx = fmaxf(mx, t);
                     if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
@@ -130,8 +133,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                 asm volatile("" ::: "memory");
                 float l = 0.f;
 #pragma unroll
-                for (int j = 0; j < 64; ++j) { sc[j] = expf(sc[j] - mx); l += sc[j]; }
-                const float inv = 1.0f / l;
+                for (int j = 0; j < 64; ++j) { sc[j] = __expf(sc[j] - mx); l += sc[j]; }
+                const float inv = __builtin_amdgcn_rcpf(l);
                 float O[D];
 #pragma unroll
                 for (int c = 0; c < D; ++c) O[c] = 0.f;
@@ -142,7 +145,11 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                     sc[j] *= inv;
                     float dP = 0.f;
 #pragma unroll
-                    for (int c = 0; c < D; ++c) { const float vv = vh[j * HC + c]; O[c] += sc[j] * vv; dP += dOi[c] * vv; }
+                    for (int c4 = 0; c4 < D / 4; ++c4) {
+                        const float4 vv = vh[j * (HC / 4) + c4];
+                        O[4 * c4] += sc[j] * vv.x; O[4 * c4 + 1] += sc[j] * vv.y; O[4 * c4 + 2] += sc[j] * vv.z; O[4 * c4 + 3] += sc[j] * vv.w;
+                        dP += dOi[4 * c4] * vv.x + dOi[4 * c4 + 1] * vv.y + dOi[4 * c4 + 2] * vv.z + dOi[4 * c4 + 3] * vv.w;
+                    }
                     Dv += sc[j] * dP;
                     if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
                 }
@@ -153,11 +160,18 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
 #pragma unroll
                 for (int j = 0; j < 64; ++j) {
                     float dP = 0.f;
+                    float4 kv[D / 4];
 #pragma unroll
-                    for (int c = 0; c < D; ++c) dP += dOi[c] * vh[j * HC + c];
+                    for (int c4 = 0; c4 < D / 4; ++c4) {
+                        const float4 vv = vh[j * (HC / 4) + c4];
+                        kv[c4] = kh[j * (HC / 4) + c4];
+                        dP += dOi[4 * c4] * vv.x + dOi[4 * c4 + 1] * vv.y + dOi[4 * c4 + 2] * vv.z + dOi[4 * c4 + 3] * vv.w;
+                    }
                     const float dS = sc[j] * (dP - Dv);
 #pragma unroll
-                    for (int c = 0; c < D; ++c) dqh[c] += dS * kh[j * HC + c];
+                    for (int c4 = 0; c4 < D / 4; ++c4) {
+                        dqh[4 * c4] += dS * kv[c4].x; dqh[4 * c4 + 1] += dS * kv[c4].y; dqh[4 * c4 + 2] += dS * kv[c4].z; dqh[4 * c4 + 3] += dS * kv[c4].w;
+                    }
                     __hip_atomic_fetch_add(&drow[j], dS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
                 }
@@ -179,21 +193,27 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
 #pragma unroll
                 for (int c = 0; c < D; ++c) { kj[c] = sK[lane * HC + hd * D + c]; vj[c] = sV[lane * HC + hd * D + c]; dkh[c] = 0.f; dvh[c] = 0.f; }
                 const float* pcol = sPos + hd * 64 * PLD + lane;
-#pragma unroll 4
+                const float4* qh = reinterpret_cast<const float4*>(sQ + hd * D);
+                const float4* doh = reinterpret_cast<const float4*>(sDO + hd * D);
+                const float* st = sSt + hd * 64 * 3;
+#pragma unroll 8
                 for (int i = 0; i < 64; ++i) {
                     float t = pcol[i * PLD], dP = 0.f;
-                    float qi[D], doi[D];
+                    float4 qi[D / 4], doi[D / 4];
 #pragma unroll
-                    for (int c = 0; c < D; ++c) {
-                        qi[c] = sQ[i * HC + hd * D + c];
-                        doi[c] = sDO[i * HC + hd * D + c];
-                        t += qi[c] * kj[c];
-                        dP += doi[c] * vj[c];
+                    for (int c4 = 0; c4 < D / 4; ++c4) {
+                        qi[c4] = qh[i * (HC / 4) + c4];
+                        doi[c4] = doh[i * (HC / 4) + c4];
+                        t += qi[c4].x * kj[4 * c4] + qi[c4].y * kj[4 * c4 + 1] + qi[c4].z * kj[4 * c4 + 2] + qi[c4].w * kj[4 * c4 + 3];
+                        dP += doi[c4].x * vj[4 * c4] + doi[c4].y * vj[4 * c4 + 1] + doi[c4].z * vj[4 * c4 + 2] + doi[c4].w * vj[4 * c4 + 3];
                     }
-                    const float P = expf(t - sSt[(hd * 64 + i) * 3 + 0]) * sSt[(hd * 64 + i) * 3 + 1];
-                    const float dS = P * (dP - sSt[(hd * 64 + i) * 3 + 2]);
+                    const float P = __expf(t - st[i * 3 + 0]) * st[i * 3 + 1];
+                    const float dS = P * (dP - st[i * 3 + 2]);
 #pragma unroll
-                    for (int c = 0; c < D; ++c) { dvh[c] += P * doi[c]; dkh[c] += dS * qi[c]; }
+                    for (int c4 = 0; c4 < D / 4; ++c4) {
+                        dvh[4 * c4] += P * doi[c4].x; dvh[4 * c4 + 1] += P * doi[c4].y; dvh[4 * c4 + 2] += P * doi[c4].z; dvh[4 * c4 + 3] += P * doi[c4].w;
+                        dkh[4 * c4] += dS * qi[c4].x; dkh[4 * c4 + 1] += dS * qi[c4].y; dkh[4 * c4 + 2] += dS * qi[c4].z; dkh[4 * c4 + 3] += dS * qi[c4].w;
+                    }
                 }
                 float* dk_o = a.dqkv + p * DQLD + HC + hd * D;
                 float* dv_o = a.dqkv + p * DQLD + 2 * HC + hd * D;

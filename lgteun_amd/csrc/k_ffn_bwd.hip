@@ -91,18 +91,24 @@ __global__ __launch_bounds__(256) void k_ffn_dw_bwd(FfnDwBwdArgs a, int tiles_x,
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int m = wave * 48 + mt * 16 + 4 * g + v;
-                const int hy = m / HX, hx = m - hy * HX;
-                const int y = y0 + hy - 1, x = x0 + hx - 1;
-                const bool in = (m < NH) && y >= 0 && y < h && x >= 0 && x < w;
-                const long p = (b * h + y) * (long)w + x;
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int col = nt * 16 + r;
-                    float d = 0.f;
-                    if (in) d = acc[mt][nt][v] * a.g3[p * N1 + c0 + col];
-                    if (m < NH) bufG[m * LDG + col] = d;
-                }
+                for (int nt = 0; nt < 2; ++nt)
+                    if (m < NH) bufG[m * LDG + nt * 16 + r] = acc[mt][nt][v];
             }
+    }
+    __syncthreads();
+    // dh3 *= g3 (0 outside the image): coalesced 16-byte loads of the saved gelu'(h3)
+    for (int i = threadIdx.x; i < NH * CQ; i += 256) {
+        const int m = i / CQ, qq = i - m * CQ;
+        const int hy = m / HX, hx = m - hy * HX;
+        const int y = y0 + hy - 1, x = x0 + hx - 1;
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y >= 0 && y < h && x >= 0 && x < w) {
+            const float4 gv = *reinterpret_cast<const float4*>(a.g3 + ((b * h + y) * (long)w + x) * N1 + c0 + 4 * qq);
+            const float4 t = *reinterpret_cast<const float4*>(bufG + m * LDG + 4 * qq);
+            d = make_float4(t.x * gv.x, t.y * gv.y, t.z * gv.z, t.w * gv.w);
+        }
+        *reinterpret_cast<float4*>(bufG + m * LDG + 4 * qq) = d;
     }
     __syncthreads();
     // ---- P2: dh2 = dw^T dh3 and the depthwise weight/bias gradient partials; thread <-> (pixel, channel quad)
@@ -213,16 +219,21 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a) {
             for (int nt = 0; nt < 4; ++nt) {
                 const int col = nc + nt * 16 + r;
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int m = mt * 16 + 4 * g + v;
-                    float d = 0.f;
-                    if (p0 + m < a.P) {
-                        d = acc[mt][nt][v] * a.g1[(p0 + m) * N1 + col];
-                        a.dh1[(p0 + m) * N1 + col] = d;
-                    }
-                    bufD1[m * LDH + col] = d;
-                }
+                for (int v = 0; v < 4; ++v) bufD1[(mt * 16 + 4 * g + v) * LDH + col] = acc[mt][nt][v];
             }
+    }
+    __syncthreads();
+    // dh1 = (dh2 W2) * g1 : coalesced 16-byte pass over the wave's rows (g1 in, dh1 out), result kept in LDS for the next GEMM
+    for (int i = lane; i < MW * (N1 / 4); i += 64) {
+        const int m = i / (N1 / 4), k4 = i - m * (N1 / 4);
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p0 + m < a.P) {
+            const float4 gv = *reinterpret_cast<const float4*>(a.g1 + (p0 + m) * N1 + 4 * k4);
+            const float4 t = *reinterpret_cast<const float4*>(bufD1 + m * LDH + 4 * k4);
+            d = make_float4(t.x * gv.x, t.y * gv.y, t.z * gv.z, t.w * gv.w);
+            *reinterpret_cast<float4*>(a.dh1 + (p0 + m) * N1 + 4 * k4) = d;
+        }
+        *reinterpret_cast<float4*>(bufD1 + m * LDH + 4 * k4) = d;
     }
     __syncthreads();
     // ---- d(LN2 out) = dh1 W1
@@ -321,7 +332,7 @@ static int launch_ffn1_bwd_t(const Ffn1BwdArgs& a, hipStream_t s) {
     return 0;
 }
 int launch_ffn1_bwd(int e, const Ffn1BwdArgs& a, hipStream_t s) {
-    if (e == 16) return launch_ffn1_bwd_t<16, 2>(a, s);
+    if (e == 16) return launch_ffn1_bwd_t<16, 1>(a, s);
     if (e == 32) return launch_ffn1_bwd_t<32, 2>(a, s);
     if (e == 64) return launch_ffn1_bwd_t<64, 1>(a, s);
     lg_set_error("ffn1_bwd: e=%d unsupported", e);
