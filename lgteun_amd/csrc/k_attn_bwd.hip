@@ -15,27 +15,35 @@
 
 template <int HC, int NW>
 __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nwin, int ngroups) {
+    // blockIdx.y = head: the two heads of a window are independent, so each workgroup keeps only one head's pos_emb /
+    // dpos / K,V,Q,dO tiles in LDS -> half the LDS, twice the waves per CU.
     constexpr int E = 2 * HC, D = HC / 2;
     constexpr int Y1LD = (HC + 15) / 16 * 16, DQLD = (3 * HC + 15) / 16 * 16;  // wgrad operands are padded to 16 columns
-    constexpr int PW = 4 * 64 * HC + 2 * 64 * 3;  // floats of LDS per wave
+    constexpr int PW = 4 * 64 * D + 64 * 4;       // floats of LDS per wave
     constexpr int PLD = 65;                       // padded pos_emb row: conflict-free for lane = query AND lane = key
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sPos = smem;                    // [2][64 i][65]  pos_emb[h][i][j]
-    float* sDpos = smem + 2 * 64 * PLD;    // [2][64 i][65]  accumulated dS
+    const int hd = blockIdx.y;
+    float* sPos = smem;                    // [64 i][65]  pos_emb[hd][i][j]
+    float* sDpos = smem + 64 * PLD;        // [64 i][65]  accumulated dS
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* sK = smem + 4 * 64 * PLD + wave * PW;
-    float* sV = sK + 64 * HC;
-    float* sQ = sV + 64 * HC;
-    float* sDO = sQ + 64 * HC;
-    float* sSt = sDO + 64 * HC;  // [2][64][3]  row max, 1/row sum, D_i
-    for (int i = threadIdx.x; i < 2 * 64 * 64; i += NW * 64) {
-        const int hi = i >> 6, j = i & 63;
-        sPos[hi * PLD + j] = a.pos[i];
-        sDpos[hi * PLD + j] = 0.f;
+    float* sK = smem + 2 * 64 * PLD + wave * PW;   // [64][D]
+    float* sV = sK + 64 * D;
+    float* sQ = sV + 64 * D;
+    float* sDO = sQ + 64 * D;
+    float* sSt = sDO + 64 * D;             // [64][4]  row max, 1/row sum, D_i
+    for (int i = threadIdx.x; i < 64 * 64; i += NW * 64) {
+        const int ii = i >> 6, j = i & 63;
+        sPos[ii * PLD + j] = a.pos[hd * 64 * 64 + i];
+        sDpos[ii * PLD + j] = 0.f;
     }
     const int nwx = a.w >> 3, nwy = a.h >> 3;
     const long hw = (long)a.h * a.w;
     const float scale = (float)(1.0 / sqrt((double)D));
+    // pos_emb gradient: in pass 2 lane j owns column j of dS, so dpos[hd][i][j] accumulates in 64 registers across all the
+    // windows of this wave (LDS float atomics here cost more than the rest of the kernel)
+    float dpacc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) dpacc[i] = 0.f;
 
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int win = grp * NW + wave;
@@ -63,27 +71,31 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                 float y1[HC];
 #pragma unroll
                 for (int c = 0; c < HC; ++c) y1[c] = (xv[c] - mu) * rstd * a.ln1g[c] + a.ln1b[c];
-                float4* y1o = reinterpret_cast<float4*>(a.y1 + p * Y1LD);
+                if (hd == 0) {
+                    float4* y1o = reinterpret_cast<float4*>(a.y1 + p * Y1LD);
 #pragma unroll
-                for (int k = 0; k < Y1LD / 4; ++k)
-                    y1o[k] = (4 * k < HC) ? make_float4(y1[(4 * k) % HC], y1[(4 * k + 1) % HC], y1[(4 * k + 2) % HC], y1[(4 * k + 3) % HC])
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int k = 0; k < Y1LD / 4; ++k)
+                        y1o[k] = (4 * k < HC) ? make_float4(y1[(4 * k) % HC], y1[(4 * k + 1) % HC], y1[(4 * k + 2) % HC], y1[(4 * k + 3) % HC])
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                // this head's q, k, v channels: rows hd*D + c of each third of to_qkv
+                const float* wq = a.qkvw + (size_t)(hd * D) * HC;
 #pragma unroll
-                for (int c = 0; c < HC; ++c) {
+                for (int c = 0; c < D; ++c) {
                     float vq = 0.f, vk = 0.f, vv = 0.f;
 #pragma unroll
                     for (int k = 0; k < HC; ++k) {
-                        vq += a.qkvw[c * HC + k] * y1[k];
-                        vk += a.qkvw[(HC + c) * HC + k] * y1[k];
-                        vv += a.qkvw[(2 * HC + c) * HC + k] * y1[k];
+                        vq += wq[c * HC + k] * y1[k];
+                        vk += wq[(HC + c) * HC + k] * y1[k];
+                        vv += wq[(2 * HC + c) * HC + k] * y1[k];
                     }
-                    sQ[lane * HC + c] = (vq + a.qkvb[c]) * scale;
-                    sK[lane * HC + c] = vk + a.qkvb[HC + c];
-                    sV[lane * HC + c] = vv + a.qkvb[2 * HC + c];
+                    sQ[lane * D + c] = (vq + a.qkvb[hd * D + c]) * scale;
+                    sK[lane * D + c] = vk + a.qkvb[HC + hd * D + c];
+                    sV[lane * D + c] = vv + a.qkvb[2 * HC + hd * D + c];
                 }
             }
             {
-                // dO = grad wrt the attention output = (proj^T dym)[:HC]
+                // dO = grad wrt this head's attention output channels = (proj^T dym)[hd*D : hd*D + D]
                 float dym[E];
                 const float4* ds = reinterpret_cast<const float4*>(a.dym + p * E);
 #pragma unroll
@@ -92,145 +104,148 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                     dym[4 * k] = v.x; dym[4 * k + 1] = v.y; dym[4 * k + 2] = v.z; dym[4 * k + 3] = v.w;
                 }
 #pragma unroll
-                for (int k = 0; k < HC; ++k) {
+                for (int k = 0; k < D; ++k) {
                     float acc = 0.f;
 #pragma unroll
-                    for (int n = 0; n < E; ++n) acc += a.projw[n * E + k] * dym[n];
-                    sDO[lane * HC + k] = acc;
+                    for (int n = 0; n < E; ++n) acc += a.projw[n * E + hd * D + k] * dym[n];
+                    sDO[lane * D + k] = acc;
                 }
-                // global-mixer half of the proj input
-                float* co = a.cat + p * E;
+                if (hd == 0) {   // global-mixer half of the proj input, and the zero padding of the dqkv rows
+                    float* co = a.cat + p * E;
 #pragma unroll
-                for (int c = 0; c < HC; ++c) co[HC + c] = a.o2[(b * HC + c) * hw + s];
+                    for (int c = 0; c < HC; ++c) co[HC + c] = a.o2[(b * HC + c) * hw + s];
+                    if (DQLD > 3 * HC) {
+                        float* pad = a.dqkv + p * DQLD + 3 * HC;
+#pragma unroll
+                        for (int c = 0; c < DQLD - 3 * HC; ++c) pad[c] = 0.f;
+                    }
+                }
             }
         }
         __syncthreads();
         if (active) {
             // ---------------- pass 1: lane = query i
-#pragma unroll 1
-            for (int hd = 0; hd < 2; ++hd) {
-                float q[D], dOi[D];
+            float q[D], dOi[D];
 #pragma unroll
-                for (int c = 0; c < D; ++c) { q[c] = sQ[lane * HC + hd * D + c]; dOi[c] = sDO[lane * HC + hd * D + c]; }
-                const float* prow = sPos + (hd * 64 + lane) * PLD;
-                float* drow = sDpos + (hd * 64 + lane) * PLD;
-                const float4* kh = reinterpret_cast<const float4*>(sK + hd * D);   // rows as 16-byte LDS broadcasts
-                const float4* vh = reinterpret_cast<const float4*>(sV + hd * D);
-                float sc[64];
-                float mx = -3.0e38f;
+            for (int c = 0; c < D; ++c) { q[c] = sQ[lane * D + c]; dOi[c] = sDO[lane * D + c]; }
+            const float* prow = sPos + lane * PLD;
+            const float4* kh = reinterpret_cast<const float4*>(sK);   // rows as 16-byte LDS broadcasts
+            const float4* vh = reinterpret_cast<const float4*>(sV);
+            float sc[64];
+            float mx = -3.0e38f;
 #pragma unroll
-                for (int j = 0; j < 64; ++j) {
-                    float t = prow[j];
+            for (int j = 0; j < 64; ++j) {
+                float t = prow[j];
 #pragma unroll
-                    for (int c4 = 0; c4 < D / 4; ++c4) {
-                        const float4 kv = kh[j * (HC / 4) + c4];
-                        t += q[4 * c4] * kv.x + q[4 * c4 + 1] * kv.y + q[4 * c4 + 2] * kv.z + q[4 * c4 + 3] * kv.w;
-                    }
-                    sc[j] = t;
-                    mx = fmaxf(mx, t);
-                    if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+                for (int c4 = 0; c4 < D / 4; ++c4) {
+                    const float4 kv = kh[j * (D / 4) + c4];
+                    t += q[4 * c4] * kv.x + q[4 * c4 + 1] * kv.y + q[4 * c4 + 2] * kv.z + q[4 * c4 + 3] * kv.w;
                 }
-                asm volatile("" ::: "memory");
-                float l = 0.f;
-#pragma unroll
-                for (int j = 0; j < 64; ++j) { sc[j] = __expf(sc[j] - mx); l += sc[j]; }
-                const float inv = __builtin_amdgcn_rcpf(l);
-                float O[D];
-#pragma unroll
-                for (int c = 0; c < D; ++c) O[c] = 0.f;
-                // D_i = sum_j P_ij dP_ij, summed the way softmax-backward does
-                float Dv = 0.f;
-#pragma unroll
-                for (int j = 0; j < 64; ++j) {
-                    sc[j] *= inv;
-                    float dP = 0.f;
-#pragma unroll
-                    for (int c4 = 0; c4 < D / 4; ++c4) {
-                        const float4 vv = vh[j * (HC / 4) + c4];
-                        O[4 * c4] += sc[j] * vv.x; O[4 * c4 + 1] += sc[j] * vv.y; O[4 * c4 + 2] += sc[j] * vv.z; O[4 * c4 + 3] += sc[j] * vv.w;
-                        dP += dOi[4 * c4] * vv.x + dOi[4 * c4 + 1] * vv.y + dOi[4 * c4 + 2] * vv.z + dOi[4 * c4 + 3] * vv.w;
-                    }
-                    Dv += sc[j] * dP;
-                    if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
-                }
-                asm volatile("" ::: "memory");   // re-read K_j / V_j from LDS below instead of keeping 64 x 2D values live
-                float dqh[D];
-#pragma unroll
-                for (int c = 0; c < D; ++c) dqh[c] = 0.f;
-#pragma unroll
-                for (int j = 0; j < 64; ++j) {
-                    float dP = 0.f;
-                    float4 kv[D / 4];
-#pragma unroll
-                    for (int c4 = 0; c4 < D / 4; ++c4) {
-                        const float4 vv = vh[j * (HC / 4) + c4];
-                        kv[c4] = kh[j * (HC / 4) + c4];
-                        dP += dOi[4 * c4] * vv.x + dOi[4 * c4 + 1] * vv.y + dOi[4 * c4 + 2] * vv.z + dOi[4 * c4 + 3] * vv.w;
-                    }
-                    const float dS = sc[j] * (dP - Dv);
-#pragma unroll
-                    for (int c4 = 0; c4 < D / 4; ++c4) {
-                        dqh[4 * c4] += dS * kv[c4].x; dqh[4 * c4 + 1] += dS * kv[c4].y; dqh[4 * c4 + 2] += dS * kv[c4].z; dqh[4 * c4 + 3] += dS * kv[c4].w;
-                    }
-                    __hip_atomic_fetch_add(&drow[j], dS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
-                }
-                float* co = a.cat + p * E + hd * D;
-                float* dq_o = a.dqkv + p * DQLD + hd * D;
-#pragma unroll
-                for (int c = 0; c < D; ++c) { co[c] = O[c]; dq_o[c] = dqh[c] * scale; }
-                sSt[(hd * 64 + lane) * 3 + 0] = mx;
-                sSt[(hd * 64 + lane) * 3 + 1] = inv;
-                sSt[(hd * 64 + lane) * 3 + 2] = Dv;
+                sc[j] = t;
+                mx = fmaxf(mx, t);
+                if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
             }
+            asm volatile("" ::: "memory");
+            float l = 0.f;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) { sc[j] = __expf(sc[j] - mx); l += sc[j]; }
+            const float inv = __builtin_amdgcn_rcpf(l);
+            float O[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) O[c] = 0.f;
+            // D_i = sum_j P_ij dP_ij, summed the way softmax-backward does
+            float Dv = 0.f;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                sc[j] *= inv;
+                float dP = 0.f;
+#pragma unroll
+                for (int c4 = 0; c4 < D / 4; ++c4) {
+                    const float4 vv = vh[j * (D / 4) + c4];
+                    O[4 * c4] += sc[j] * vv.x; O[4 * c4 + 1] += sc[j] * vv.y; O[4 * c4 + 2] += sc[j] * vv.z; O[4 * c4 + 3] += sc[j] * vv.w;
+                    dP += dOi[4 * c4] * vv.x + dOi[4 * c4 + 1] * vv.y + dOi[4 * c4 + 2] * vv.z + dOi[4 * c4 + 3] * vv.w;
+                }
+                Dv += sc[j] * dP;
+                if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("" ::: "memory");   // re-read K_j / V_j from LDS below instead of keeping 64 x 2D values live
+            float dqh[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) dqh[c] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                float dP = 0.f;
+                float4 kv[D / 4];
+#pragma unroll
+                for (int c4 = 0; c4 < D / 4; ++c4) {
+                    const float4 vv = vh[j * (D / 4) + c4];
+                    kv[c4] = kh[j * (D / 4) + c4];
+                    dP += dOi[4 * c4] * vv.x + dOi[4 * c4 + 1] * vv.y + dOi[4 * c4 + 2] * vv.z + dOi[4 * c4 + 3] * vv.w;
+                }
+                const float dS = sc[j] * (dP - Dv);
+#pragma unroll
+                for (int c4 = 0; c4 < D / 4; ++c4) {
+                    dqh[4 * c4] += dS * kv[c4].x; dqh[4 * c4 + 1] += dS * kv[c4].y; dqh[4 * c4 + 2] += dS * kv[c4].z; dqh[4 * c4 + 3] += dS * kv[c4].w;
+                }
+                if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+            }
+            float* co = a.cat + p * E + hd * D;
+            float* dq_o = a.dqkv + p * DQLD + hd * D;
+#pragma unroll
+            for (int c = 0; c < D; ++c) { co[c] = O[c]; dq_o[c] = dqh[c] * scale; }
+            sSt[lane * 4 + 0] = mx;
+            sSt[lane * 4 + 1] = inv;
+            sSt[lane * 4 + 2] = Dv;
         }
         __syncthreads();
         if (active) {
             // ---------------- pass 2: lane = key j
-#pragma unroll 1
-            for (int hd = 0; hd < 2; ++hd) {
-                float kj[D], vj[D], dkh[D], dvh[D];
+            float kj[D], vj[D], dkh[D], dvh[D];
 #pragma unroll
-                for (int c = 0; c < D; ++c) { kj[c] = sK[lane * HC + hd * D + c]; vj[c] = sV[lane * HC + hd * D + c]; dkh[c] = 0.f; dvh[c] = 0.f; }
-                const float* pcol = sPos + hd * 64 * PLD + lane;
-                const float4* qh = reinterpret_cast<const float4*>(sQ + hd * D);
-                const float4* doh = reinterpret_cast<const float4*>(sDO + hd * D);
-                const float* st = sSt + hd * 64 * 3;
-#pragma unroll 8
-                for (int i = 0; i < 64; ++i) {
-                    float t = pcol[i * PLD], dP = 0.f;
-                    float4 qi[D / 4], doi[D / 4];
+            for (int c = 0; c < D; ++c) { kj[c] = sK[lane * D + c]; vj[c] = sV[lane * D + c]; dkh[c] = 0.f; dvh[c] = 0.f; }
+            const float* pcol = sPos + lane;
+            const float4* qh = reinterpret_cast<const float4*>(sQ);
+            const float4* doh = reinterpret_cast<const float4*>(sDO);
+            const float4* st = reinterpret_cast<const float4*>(sSt);
 #pragma unroll
-                    for (int c4 = 0; c4 < D / 4; ++c4) {
-                        qi[c4] = qh[i * (HC / 4) + c4];
-                        doi[c4] = doh[i * (HC / 4) + c4];
-                        t += qi[c4].x * kj[4 * c4] + qi[c4].y * kj[4 * c4 + 1] + qi[c4].z * kj[4 * c4 + 2] + qi[c4].w * kj[4 * c4 + 3];
-                        dP += doi[c4].x * vj[4 * c4] + doi[c4].y * vj[4 * c4 + 1] + doi[c4].z * vj[4 * c4 + 2] + doi[c4].w * vj[4 * c4 + 3];
-                    }
-                    const float P = __expf(t - st[i * 3 + 0]) * st[i * 3 + 1];
-                    const float dS = P * (dP - st[i * 3 + 2]);
+            for (int i = 0; i < 64; ++i) {
+                float t = pcol[i * PLD], dP = 0.f;
+                float4 qi[D / 4], doi[D / 4];
 #pragma unroll
-                    for (int c4 = 0; c4 < D / 4; ++c4) {
-                        dvh[4 * c4] += P * doi[c4].x; dvh[4 * c4 + 1] += P * doi[c4].y; dvh[4 * c4 + 2] += P * doi[c4].z; dvh[4 * c4 + 3] += P * doi[c4].w;
-                        dkh[4 * c4] += dS * qi[c4].x; dkh[4 * c4 + 1] += dS * qi[c4].y; dkh[4 * c4 + 2] += dS * qi[c4].z; dkh[4 * c4 + 3] += dS * qi[c4].w;
-                    }
+                for (int c4 = 0; c4 < D / 4; ++c4) {
+                    qi[c4] = qh[i * (D / 4) + c4];
+                    doi[c4] = doh[i * (D / 4) + c4];
+                    t += qi[c4].x * kj[4 * c4] + qi[c4].y * kj[4 * c4 + 1] + qi[c4].z * kj[4 * c4 + 2] + qi[c4].w * kj[4 * c4 + 3];
+                    dP += doi[c4].x * vj[4 * c4] + doi[c4].y * vj[4 * c4 + 1] + doi[c4].z * vj[4 * c4 + 2] + doi[c4].w * vj[4 * c4 + 3];
                 }
-                float* dk_o = a.dqkv + p * DQLD + HC + hd * D;
-                float* dv_o = a.dqkv + p * DQLD + 2 * HC + hd * D;
+                const float4 sv = st[i];
+                const float P = __expf(t - sv.x) * sv.y;
+                const float dS = P * (dP - sv.z);
+                dpacc[i] += dS;
+                if ((i & 15) == 15) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int c = 0; c < D; ++c) { dk_o[c] = dkh[c]; dv_o[c] = dvh[c]; }
+                for (int c4 = 0; c4 < D / 4; ++c4) {
+                    dvh[4 * c4] += P * doi[c4].x; dvh[4 * c4 + 1] += P * doi[c4].y; dvh[4 * c4 + 2] += P * doi[c4].z; dvh[4 * c4 + 3] += P * doi[c4].w;
+                    dkh[4 * c4] += dS * qi[c4].x; dkh[4 * c4 + 1] += dS * qi[c4].y; dkh[4 * c4 + 2] += dS * qi[c4].z; dkh[4 * c4 + 3] += dS * qi[c4].w;
+                }
             }
-            if (DQLD > 3 * HC) {
-                float* pad = a.dqkv + p * DQLD + 3 * HC;
+            float* dk_o = a.dqkv + p * DQLD + HC + hd * D;
+            float* dv_o = a.dqkv + p * DQLD + 2 * HC + hd * D;
 #pragma unroll
-                for (int c = 0; c < DQLD - 3 * HC; ++c) pad[c] = 0.f;
-            }
+            for (int c = 0; c < D; ++c) { dk_o[c] = dkh[c]; dv_o[c] = dvh[c]; }
         }
     }
     __syncthreads();
-    // pos_emb partial of this workgroup -> slab[blockIdx.x][h][i][j]
-    float* slab = a.dpos_slab + (size_t)blockIdx.x * 2 * 64 * 64;
-    for (int idx = threadIdx.x; idx < 2 * 64 * 64; idx += NW * 64) slab[idx] = sDpos[(idx >> 6) * PLD + (idx & 63)];
+    for (int w = 0; w < NW; ++w) {   // waves take turns (fixed order): sDpos[i][j] += this wave's column sums
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) sDpos[i * PLD + lane] += dpacc[i];
+        }
+        __syncthreads();
+    }
+    // pos_emb partial of this workgroup -> slab[blockIdx.x][hd][i][j]
+    float* slab = a.dpos_slab + ((size_t)blockIdx.x * 2 + hd) * 64 * 64;
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += NW * 64) slab[idx] = sDpos[(idx >> 6) * PLD + (idx & 63)];
 }
 
 // per-pixel epilogue: dqkv -> to_qkv^T, join the FFT-mixer gradient, LayerNorm-1 backward + residual, LN1 param grads
@@ -315,12 +330,12 @@ template <int HC, int NW>
 static int grid_t(int B, int h, int w) {
     int nwin = B * (h / 8) * (w / 8);
     int ngroups = (nwin + NW - 1) / NW;
-    return ngroups < 256 ? ngroups : 256;
+    return ngroups < 512 ? ngroups : 512;
 }
 int attn_bwd_grid(int e, int B, int h, int w) {
     if (e == 16) return grid_t<8, 8>(B, h, w);
     if (e == 32) return grid_t<16, 4>(B, h, w);
-    return grid_t<32, 2>(B, h, w);
+    return grid_t<32, 4>(B, h, w);
 }
 
 template <int HC, int NW>
@@ -328,7 +343,7 @@ static int launch_attn_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
     ProfScope prof__(LG_K_ATTN_BWD, s);
     int nwin = a.B * (a.h / 8) * (a.w / 8);
     int ngroups = (nwin + NW - 1) / NW;
-    size_t lds = (size_t)(4 * 64 * 65 + NW * (4 * 64 * HC + 2 * 64 * 3)) * sizeof(float);
+    size_t lds = (size_t)(2 * 64 * 65 + NW * (4 * 64 * (HC / 2) + 64 * 4)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)k_attn_bwd_core<HC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
@@ -336,7 +351,7 @@ static int launch_attn_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
         attr_done = true;
     }
     int grid = grid_t<HC, NW>(a.B, a.h, a.w);
-    k_attn_bwd_core<HC, NW><<<grid, NW * 64, lds, s>>>(a, nwin, ngroups);
+    k_attn_bwd_core<HC, NW><<<dim3(grid, 2), NW * 64, lds, s>>>(a, nwin, ngroups);
     LG_CHECK_LAUNCH();
     const long total = (long)a.B * a.h * a.w;
     k_attn_bwd_epi<2 * HC><<<(int)((total + 255) / 256), 256, 0, s>>>(a, total);
@@ -348,7 +363,7 @@ int launch_attn_bwd(int e, const AttnBwdArgs& a, hipStream_t s) {
     if ((a.h & 7) || (a.w & 7)) { lg_set_error("attn_bwd: h,w must be multiples of 8"); return -2; }
     if (e == 16) return launch_attn_bwd_t<8, 8>(a, s);
     if (e == 32) return launch_attn_bwd_t<16, 4>(a, s);
-    if (e == 64) return launch_attn_bwd_t<32, 2>(a, s);
+    if (e == 64) return launch_attn_bwd_t<32, 4>(a, s);
     lg_set_error("attn_bwd: e=%d unsupported", e);
     return -1;
 }

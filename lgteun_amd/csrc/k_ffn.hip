@@ -285,7 +285,7 @@ struct FfnFusedArgs {
     Ffn2Args a2;
 };
 
-template <int E>
+template <int E, bool SAVE>
 __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int tiles_x, int tiles_y) {
     constexpr int N1 = 4 * E, TY = 8, TX = 16, HX = TX + 2, HY = TY + 2, NH = HX * HY /*180*/, MH = 192, M = TY * TX;
     constexpr int LDA = E + 4, LDH = N1 + 4, LDO = E + 1, CQ = N1 / 4, NT3 = E / 16;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const float hh = acc[0][nt][v] + bias;
-                    if (a1.a1s) {
+                    if (SAVE) {
                         float av, gv;
                         gelu_both_f(hh, av, gv);
                         if (inner[v]) { a1.a1s[prow[v] * N1 + col] = av; a1.g1s[prow[v] * N1 + col] = gv; }
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
                 for (int v = 0; v < 4; ++v) {
                     const int m = row0 + 4 * g + v;
                     const float hh = inimg[v] ? acc[0][nt][v] + bias : 0.f;   // dep_conv zero-pads h2 (basic_module_unformer_v2.py:18)
-                    if (a1.h2 && inner[v]) a1.h2[prow[v] * N1 + col] = hh;
+                    if (SAVE && inner[v]) a1.h2[prow[v] * N1 + col] = hh;
                     if (m < NH) bufH2[m * LDH + col] = hh;
                 }
             }
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
                     }
                 const int y = y0 + ty, x = x0 + tx;
                 float4 av;
-                if (a2.a3s) {
+                if (SAVE) {
                     float4 gv;
                     gelu_both_f(acc.x, av.x, gv.x); gelu_both_f(acc.y, av.y, gv.y);
                     gelu_both_f(acc.z, av.z, gv.z); gelu_both_f(acc.w, av.w, gv.w);
@@ -498,13 +498,16 @@ static int launch_ffn_fused_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_
     size_t lds = (size_t)(192 * (E + 4) + 180 * (N1 + 4) + 4 * 16 * (N1 + 4)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_fused<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_fused<E, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_fused<E, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn_fused: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
     int tiles_x = (a2.w + 15) / 16, tiles_y = (a2.h + 7) / 8;
     int grid = a2.B * tiles_x * tiles_y;
-    k_ffn_fused<E><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y);
+    const bool save = a1.a1s != nullptr;   // forward of the live stage: keep gelu / gelu' / h2 for the backward
+    if (save) k_ffn_fused<E, true><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y);
+    else k_ffn_fused<E, false><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y);
     LG_CHECK_LAUNCH();
     return 0;
 }
