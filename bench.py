@@ -57,7 +57,7 @@ def algorithmic_per_launch(kernel, B):
         # mixer half-block unit: read x (e), write y (e); the two kernels split it by channel half
         byts = sum(2 * e * p * 4 for e, p in px) / 5 * B / 2
         return byts, 0.0
-    raise ValueError(kernel)
+    return 0.0, 0.0   # kernels without a per-unit figure in SURVEY 8d: time only
 
 
 def host_cores():
