@@ -286,7 +286,7 @@ struct FfnFusedArgs {
 };
 
 template <int E, bool SAVE>
-__global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int tiles_x, int tiles_y, int ntiles) {
     constexpr int N1 = 4 * E, TY = 8, TX = 16, HX = TX + 2, HY = TY + 2, NH = HX * HY /*180*/, MH = 192, M = TY * TX;
     constexpr int LDA = E + 4, LDH = N1 + 4, LDO = E + 1, CQ = N1 / 4, NT3 = E / 16;
     static_assert(CQ <= 64 && 64 % CQ == 0, "quad mapping");
@@ -296,13 +296,24 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
     float* scr = bufH2 + NH * LDH;            // [4][16][LDH] per-wave chunk
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     float* my = scr + wave * 16 * LDH;
-    int t = blockIdx.x;
+    const int h = a2.h, w = a2.w;
+    // weights as MFMA B fragments, resident in registers for ALL tiles of this (persistent) workgroup when they fit
+    // (e = 16: 16 + 64 + 16 VGPRs); otherwise every row chunk re-reads them through L1
+    constexpr bool RB = (E == 16);
+    float4 w1f[RB ? 4 : 1][1], w2f[RB ? 4 : 1][RB ? 4 : 1];
+    if (RB) {
+        load_bfrag<4, 1>(reinterpret_cast<float4(&)[4][1]>(w1f), a1.w1, E);
+        load_bfrag<4, 4>(reinterpret_cast<float4(&)[4][4]>(w2f), a1.w2, N1);
+    }
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int t = tile;
     const int tx_i = t % tiles_x;
     t /= tiles_x;
     const int ty_i = t % tiles_y;
     const long b = t / tiles_y;
     const int y0 = ty_i * TY, x0 = tx_i * TX;
-    const int h = a2.h, w = a2.w;
+    __syncthreads();   // previous tile's readers of bufA (output tile) / bufH2 are done
     // ---- P0: halo tile load + LayerNorm (one pixel per thread, 192 rows; rows >= 180 and out-of-image pixels are zero)
     if (threadIdx.x < MH) {
         const int m = threadIdx.x;
@@ -330,14 +341,6 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
             *reinterpret_cast<float4*>(bufA + m * LDA + 4 * k) = make_float4(xv[4 * k], xv[4 * k + 1], xv[4 * k + 2], xv[4 * k + 3]);
     }
     __syncthreads();
-    // weights as MFMA B fragments, resident in registers for the whole tile when they fit (e = 16: 16 + 64 + 16 VGPRs);
-    // otherwise every row chunk re-reads them through L1 (the vector-memory path, not the GEMM, then sets the pace)
-    constexpr bool RB = (E == 16);
-    float4 w1f[RB ? 4 : 1][1], w2f[RB ? 4 : 1][RB ? 4 : 1];
-    if (RB) {
-        load_bfrag<4, 1>(reinterpret_cast<float4(&)[4][1]>(w1f), a1.w1, E);
-        load_bfrag<4, 4>(reinterpret_cast<float4(&)[4][4]>(w2f), a1.w2, N1);
-    }
     // ---- P1: per wave, 3 chunks of 16 halo pixels: GEMM1 -> GELU -> GEMM2 -> h2 tile
     for (int ch = 0; ch < 3; ++ch) {
         const int row0 = (wave * 3 + ch) * 16;
@@ -404,6 +407,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
     // ---- P2: per wave, 2 chunks of 16 inner pixels: dw3x3 + GELU -> scratch -> GEMM3 -> output tile (in bufA's space)
     float* bufO = bufA;
     {
+        // depthwise taps and the W3 fragments are (re)loaded per tile: keeping them live across P1 costs ~56 VGPRs
         const int q = lane % CQ;
         float wq[4][9], bq[4];
 #pragma unroll
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
             for (int k = 0; k < 9; ++k) wq[u][k] = a2.dww[(4 * q + u) * 9 + k];
             bq[u] = a2.dwb[4 * q + u];
         }
-        float4 w3f[RB ? 1 : 1][RB ? 4 : 1];
+        float4 w3f[1][RB ? 4 : 1];
         if (RB) load_bfrag<1, 4>(reinterpret_cast<float4(&)[1][4]>(w3f), a2.w3, N1);
         for (int ch = 0; ch < 2; ++ch) {
             const int m0 = (wave * 2 + ch) * 16;
@@ -489,6 +493,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
             }
         }
     }
+    }   // tiles of this workgroup
 }
 
 template <int E>
@@ -504,10 +509,11 @@ static int launch_ffn_fused_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_
         attr_done = true;
     }
     int tiles_x = (a2.w + 15) / 16, tiles_y = (a2.h + 7) / 8;
-    int grid = a2.B * tiles_x * tiles_y;
+    const int ntiles = a2.B * tiles_x * tiles_y;
+    const int grid = ntiles < 512 ? ntiles : 512;   // persistent: 2 resident workgroups per CU walk the tiles, weights stay in registers
     const bool save = a1.a1s != nullptr;   // forward of the live stage: keep gelu / gelu' / h2 for the backward
-    if (save) k_ffn_fused<E, true><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y);
-    else k_ffn_fused<E, false><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y);
+    if (save) k_ffn_fused<E, true><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y, ntiles);
+    else k_ffn_fused<E, false><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y, ntiles);
     LG_CHECK_LAUNCH();
     return 0;
 }

@@ -185,7 +185,7 @@ int launch_ffn_dw_bwd(int e, const FfnDwBwdArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------
 template <int E, int MT>
-__global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a) {
+__global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a, long nchunks) {
     constexpr int N1 = 4 * E, MW = 16 * MT, LDH = N1 + 4, LDO = E + 1, NTE = E / 16;
     constexpr bool RB = (E == 16);
     extern __shared__ float smem[];
@@ -194,7 +194,16 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a) {
     float* bufD = smem + wave * (MW * (2 * LDH + LDO));   // [MW][LDH] dh2 rows
     float* bufD1 = bufD + MW * LDH;                        // [MW][LDH] dh1 rows
     float* bufO = bufD1 + MW * LDH;                        // [MW][LDO] d(LN2 output)
-    const long p0 = ((long)blockIdx.x * 4 + wave) * MW;
+    float4 w2f[RB ? 4 : 1][RB ? 4 : 1];
+    if (RB) load_bfrag<4, 4>(reinterpret_cast<float4(&)[4][4]>(w2f), a.w2t, N1);
+    float pl[2 * E];
+#pragma unroll
+    for (int i = 0; i < 2 * E; ++i) pl[i] = 0.f;
+    // persistent: the workgroup walks row chunks (weights and LN-gradient partials stay in registers)
+#pragma unroll 1
+    for (long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const long p0 = (chunk * 4 + wave) * MW;
+    __syncthreads();
     for (int i = lane; i < MW * (N1 / 4); i += 64) {
         const int m = i / (N1 / 4), k4 = i - m * (N1 / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -203,8 +212,6 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a) {
     }
     __syncthreads();
     // ---- dh1 = (dh2 W2) * g1
-    float4 w2f[RB ? 4 : 1][RB ? 4 : 1];
-    if (RB) load_bfrag<4, 4>(reinterpret_cast<float4(&)[4][4]>(w2f), a.w2t, N1);
     for (int nc = 0; nc < N1; nc += 64) {
         f32x4 acc[MT][4];
 #pragma unroll
@@ -253,9 +260,6 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a) {
     }
     __syncthreads();
     // ---- LayerNorm backward + residual, LN2 parameter gradients (lane < MW: one pixel each)
-    float pl[2 * E];
-#pragma unroll
-    for (int i = 0; i < 2 * E; ++i) pl[i] = 0.f;
     if (lane < MW && p0 + lane < a.P) {
         const int m = lane;
         const long p = p0 + m;
@@ -274,8 +278,8 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a) {
         for (int c = 0; c < E; ++c) {
             const float xh = (xv[c] - mu) * rstd;
             const float dyl = bufO[m * LDO + c];
-            pl[c] = dyl * xh;
-            pl[E + c] = dyl;
+            pl[c] += dyl * xh;
+            pl[E + c] += dyl;
             dxh[c] = dyl * a.ln2g[c];
             m1 += dxh[c];
             m2 += dxh[c] * xh;
@@ -300,6 +304,7 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a) {
             y2o[k] = make_float4(yv[0], yv[1], yv[2], yv[3]);
         }
     }
+    }   // chunks of this workgroup
 #pragma unroll
     for (int i = 0; i < 2 * E; ++i) {
         float sv = pl[i];
@@ -326,8 +331,9 @@ static int launch_ffn1_bwd_t(const Ffn1BwdArgs& a, hipStream_t s) {
         attr_done = true;
     }
     long per_wg = 4L * MW;
-    int grid = (int)((a.P + per_wg - 1) / per_wg);
-    k_ffn1_bwd<E, MT><<<grid, 256, lds, s>>>(a);
+    const long nchunks = (a.P + per_wg - 1) / per_wg;
+    const int grid = (int)(nchunks < 1024 ? nchunks : 1024);   // persistent workgroups
+    k_ffn1_bwd<E, MT><<<grid, 256, lds, s>>>(a, nchunks);
     LG_CHECK_LAUNCH();
     return 0;
 }
