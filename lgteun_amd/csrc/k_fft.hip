@@ -16,40 +16,73 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 w) { return make_float2
 
 // batched in-place radix-2 butterflies over LDS.  `lines` transforms of length n; element i of line l is at
 // buf[l * ls + i * es].  Lines for which skip(l) is true are left untouched.
-template <bool INVERSE, bool COLS>
-__device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int n, int lg) {
+// S fused radix-2 stages in one LDS pass: a thread loads 2^S points, runs the S butterfly levels in registers and writes
+// them back (same data flow as S consecutive radix-2 passes -> same bit-reversed positions), so the plane crosses LDS
+// 3 times per 1-D transform (7 = 3 + 3 + 1 stages at n = 128) instead of 7.
+template <bool INVERSE, bool COLS, int S>
+__device__ __forceinline__ void fft_fused(float2* buf, const float2* tw, int n, int lg, int st) {
+    constexpr int R = 1 << S;
     const int half = n >> 1;
-    const int items = n * half;
-    for (int st = 0; st < lg; ++st) {
-        // butterfly half-span m = 2^ms; twiddle stride n/(2m) = 2^(lg-1-ms).  All index math is shifts and masks.
-        const int ms = INVERSE ? st : (lg - 1 - st);
-        const int m = 1 << ms;
-        const int twshift = lg - 1 - ms;
-        for (int it = threadIdx.x; it < items; it += blockDim.x) {
-            int line, t;
-            if (COLS) { t = it >> lg; line = it & (n - 1); } else { line = it >> (lg - 1); t = it & (half - 1); }
-            if (COLS) {
-                int kx = (int)(__brev((unsigned)line) >> (32 - lg));
-                if (kx > half) continue;
-            }
-            const int j = t & (m - 1);
-            const int i0 = ((t >> ms) << (ms + 1)) + j, i1 = i0 + m;
-            const int a0 = COLS ? ((i0 << lg) + line) : ((line << lg) + i0);
-            const int a1 = COLS ? ((i1 << lg) + line) : ((line << lg) + i1);
-            const float2 w = tw[j << twshift];
-            const float2 a = buf[a0], b = buf[a1];
-            if (!INVERSE) {
-                const float2 d = make_float2(a.x - b.x, a.y - b.y);
-                buf[a0] = make_float2(a.x + b.x, a.y + b.y);
-                buf[a1] = cmul(d, w);
-            } else {
-                const float2 bw = cmulc(b, w);
-                buf[a0] = make_float2(a.x + bw.x, a.y + bw.y);
-                buf[a1] = make_float2(a.x - bw.x, a.y - bw.y);
+    // spans of the fused levels: forward (DIF) largest first, inverse (DIT) smallest first; mL = smallest span
+    const int lgmL = INVERSE ? st : (lg - st - S);
+    const int mL = 1 << lgmL;
+    const int per_line = n >> S;                 // items per line
+    const int lgpl = lg - S;
+    const int items = n << lgpl;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        int line, t;
+        if (COLS) { t = it >> lg; line = it & (n - 1); } else { line = it >> lgpl; t = it & (per_line - 1); }
+        if (COLS) {
+            const int kx = (int)(__brev((unsigned)line) >> (32 - lg));
+            if (kx > half) continue;
+        }
+        const int lo = t & (mL - 1), hi = t >> lgmL;
+        const int i_base = (hi << (lgmL + S)) + lo;
+        float2 v[R];
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            const int i = i_base + (c << lgmL);
+            v[c] = buf[COLS ? ((i << lg) + line) : ((line << lg) + i)];
+        }
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            // level k pairs (c, c + d); span of this level m = mL * d
+            const int dsh = INVERSE ? k : (S - 1 - k);
+            const int d = 1 << dsh;
+            const int twshift = lg - 1 - (lgmL + dsh);
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                if (c & d) continue;
+                const int j = lo + ((c & (d - 1)) << lgmL);
+                const float2 w = tw[j << twshift];
+                const float2 a = v[c], b = v[c + d];
+                if (!INVERSE) {
+                    const float2 df = make_float2(a.x - b.x, a.y - b.y);
+                    v[c] = make_float2(a.x + b.x, a.y + b.y);
+                    v[c + d] = cmul(df, w);
+                } else {
+                    const float2 bw = cmulc(b, w);
+                    v[c] = make_float2(a.x + bw.x, a.y + bw.y);
+                    v[c + d] = make_float2(a.x - bw.x, a.y - bw.y);
+                }
             }
         }
-        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            const int i = i_base + (c << lgmL);
+            buf[COLS ? ((i << lg) + line) : ((line << lg) + i)] = v[c];
+        }
     }
+    __syncthreads();
+}
+
+// full 1-D transform of every line: stages grouped 3 + 3 + ... + remainder
+template <bool INVERSE, bool COLS>
+__device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int n, int lg) {
+    int st = 0;
+    while (lg - st >= 3) { fft_fused<INVERSE, COLS, 3>(buf, tw, n, lg, st); st += 3; }
+    if (lg - st == 2) fft_fused<INVERSE, COLS, 2>(buf, tw, n, lg, st);
+    else if (lg - st == 1) fft_fused<INVERSE, COLS, 1>(buf, tw, n, lg, st);
 }
 
 // rows: drop Im of the kx = 0 and kx = n/2 columns and Hermitian-extend (what a c2r transform assumes)
