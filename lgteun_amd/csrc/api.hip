@@ -83,8 +83,8 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
     if (cfg->C != 4 && cfg->C != 8) { lg_set_error("plan_create: C must be 4 or 8 (got %d)", cfg->C); return -2; }
     if (cfg->K < 1 || cfg->K > LG_MAX_K) { lg_set_error("plan_create: K out of range (%d)", cfg->K); return -2; }
     if (cfg->H % 16 || cfg->W % 16 || cfg->H <= 0 || cfg->W <= 0) { lg_set_error("plan_create: H,W must be positive multiples of 16"); return -2; }
-    if (cfg->H != cfg->W || (cfg->H & (cfg->H - 1)) || cfg->H > 128) {
-        lg_set_error("plan_create: FFT mixer supports square power-of-two PAN sizes <= 128 (got %dx%d)", cfg->H, cfg->W);
+    if (cfg->H != cfg->W || (cfg->H & (cfg->H - 1)) || cfg->H > 512) {
+        lg_set_error("plan_create: FFT mixer supports square power-of-two PAN sizes <= 512 (got %dx%d)", cfg->H, cfg->W);
         return -2;
     }
     const int expect = S_NSHARED + cfg->K + L_NSLOT * cfg->K;
@@ -146,13 +146,14 @@ static int data_step_fwd(const lg_plan* pl, const float* P, int stage, const flo
 }
 
 static int block_mixer_fwd(const lg_plan* pl, const float* P, int stage, int j, const BlockBufs& bb, const float* posT, int B,
-                           int flags, uint64_t seed, hipStream_t s) {
+                           int flags, uint64_t seed, hipStream_t s, float* fft_scratch = nullptr) {
     int rc;
     FftArgs f;
     f.g = bb.g; f.o = bb.o2;
     f.amp = (flags & LG_FLAG_SAVE) ? bb.amp : nullptr;
     f.pha = (flags & LG_FLAG_SAVE) ? bb.pha : nullptr;
     f.sgn = (flags & LG_FLAG_SAVE) ? bb.sgn : nullptr;
+    f.scratch = fft_scratch;
     f.ampw = P + pl->blk(stage, j, B_AMPW); f.ampb = P + pl->blk(stage, j, B_AMPB);
     f.phaw = P + pl->blk(stage, j, B_PHAW); f.phab = P + pl->blk(stage, j, B_PHAB);
     f.ch = bb.e / 2; f.planes = B * f.ch; f.n = bb.h;
@@ -218,9 +219,9 @@ static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z,
     ea.HW = c.H * c.W; ea.total = (long)B * c.H * c.W;
     if ((rc = launch_embed(c.C, ea, s))) return rc;
     // encoder LGB (2 blocks)
-    if ((rc = block_mixer_fwd(pl, P, stage, 0, nb.blk[0], posT + 0 * 8192, B, flags, seed, s))) return rc;
+    if ((rc = block_mixer_fwd(pl, P, stage, 0, nb.blk[0], posT + 0 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
     if ((rc = block_ffn_fwd(pl, P, stage, 0, nb.blk[0], nb.blk[1].g, 1, B, flags, s))) return rc;
-    if ((rc = block_mixer_fwd(pl, P, stage, 1, nb.blk[1], posT + 1 * 8192, B, flags, seed, s))) return rc;
+    if ((rc = block_mixer_fwd(pl, P, stage, 1, nb.blk[1], posT + 1 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
     if ((rc = block_ffn_fwd(pl, P, stage, 1, nb.blk[1], nullptr, 0, B, flags, s))) return rc;
     // down
     DownArgs da;
@@ -231,7 +232,7 @@ static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z,
     da.B = B; da.H = c.H; da.W = c.W;
     if ((rc = launch_down(E, da, s))) return rc;
     // bottleneck
-    if ((rc = block_mixer_fwd(pl, P, stage, 2, nb.blk[2], posT + 2 * 8192, B, flags, seed, s))) return rc;
+    if ((rc = block_mixer_fwd(pl, P, stage, 2, nb.blk[2], posT + 2 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
     if ((rc = block_ffn_fwd(pl, P, stage, 2, nb.blk[2], nullptr, 0, B, flags, s))) return rc;
     // up + fusion
     UpFuseArgs ua;
@@ -243,9 +244,9 @@ static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z,
     ua.B = B; ua.H = c.H; ua.W = c.W;
     if ((rc = launch_upfuse(E, ua, s))) return rc;
     // decoder LGB (2 blocks)
-    if ((rc = block_mixer_fwd(pl, P, stage, 3, nb.blk[3], posT + 3 * 8192, B, flags, seed, s))) return rc;
+    if ((rc = block_mixer_fwd(pl, P, stage, 3, nb.blk[3], posT + 3 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
     if ((rc = block_ffn_fwd(pl, P, stage, 3, nb.blk[3], nb.blk[4].g, 4, B, flags, s))) return rc;
-    if ((rc = block_mixer_fwd(pl, P, stage, 4, nb.blk[4], posT + 4 * 8192, B, flags, seed, s))) return rc;
+    if ((rc = block_mixer_fwd(pl, P, stage, 4, nb.blk[4], posT + 4 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
     if ((rc = block_ffn_fwd(pl, P, stage, 4, nb.blk[4], nullptr, 0, B, flags, s))) return rc;
     // tail
     TailArgs ta;
@@ -341,7 +342,7 @@ extern "C" int lg_op_block(const lg_plan* plan, const float* params, int32_t sta
     }
     if (which == 0) {
         FftArgs f;
-        f.g = bb.g; f.o = y; f.amp = nullptr; f.pha = nullptr; f.sgn = nullptr;
+        f.g = bb.g; f.o = y; f.amp = nullptr; f.pha = nullptr; f.sgn = nullptr; f.scratch = nb.fft_scratch;
         f.ampw = params + plan->blk(stage, blk, B_AMPW); f.ampb = params + plan->blk(stage, blk, B_AMPB);
         f.phaw = params + plan->blk(stage, blk, B_PHAW); f.phab = params + plan->blk(stage, blk, B_PHAB);
         f.ch = bb.e / 2; f.planes = B * f.ch; f.n = bb.h;
@@ -352,7 +353,7 @@ extern "C" int lg_op_block(const lg_plan* plan, const float* params, int32_t sta
         if ((rc = launch_pos_transpose(params + plan->blk(stage, blk, B_POS), posT, s))) return rc;
         bb.xin = const_cast<float*>(x);
         bb.xmid = y;
-        return block_mixer_fwd(plan, params, stage, blk, bb, posT, B, 0, 0, s);
+        return block_mixer_fwd(plan, params, stage, blk, bb, posT, B, 0, 0, s, nb.fft_scratch);
     }
     bb.xmid = const_cast<float*>(x);
     bb.xout = y;
@@ -381,7 +382,7 @@ extern "C" int lg_op_block_bwd(const lg_plan* plan, const float* params, float* 
             return rc;
         if ((rc = launch_pos_transpose(params + plan->blk(stage, blk, B_POS), nb.posT, s))) return rc;
         bb.xin = const_cast<float*>(x);
-        if ((rc = block_mixer_fwd(plan, params, stage, blk, bb, nb.posT, B, LG_FLAG_SAVE, 0, s))) return rc;
+        if ((rc = block_mixer_fwd(plan, params, stage, blk, bb, nb.posT, B, LG_FLAG_SAVE, 0, s, nb.fft_scratch))) return rc;
     } else {
         bb.xmid = const_cast<float*>(x);
         if ((rc = block_ffn_fwd(plan, params, stage, blk, bb, nullptr, 0, B, LG_FLAG_SAVE, s))) return rc;

@@ -141,6 +141,7 @@ struct FftBwdArgs {
     const float* amp;  // [planes,n,n/2+1]
     const float* pha;
     float* dg;         // [planes,n,n]
+    float* scratch;    // n > 128 only: half-spectrum scratch
     const float *ampw, *ampb, *phaw, *phab;
     float *d_ampw, *d_ampb, *d_phaw, *d_phab;
     int planes, ch, n;

@@ -10,7 +10,7 @@ struct BwdBufs {
     float *dzA, *dzB, *gu3, *gs1, *gu1, *gr, *gd3, *gt1, *gd1;
     float *dx[3];
     float *doutp, *de, *tp, *dh2, *dh1, *y2, *do2, *dg, *dym, *cat, *y1, *dqkv, *dpos_slab;
-    float *w3t, *w2t, *w1t, *slab, *dt, *dskip, *v, *du;
+    float *w3t, *w2t, *w1t, *slab, *dt, *dskip, *v, *du, *fft_scratch;
     size_t bytes;
 };
 
@@ -82,10 +82,10 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
 }
 
 static int fft_bwd_call(const lg_plan* pl, const float* P, float* G, int st, int j, const BlockBufs& fb, const float* do2, float* dg,
-                        int B, hipStream_t s) {
+                        int B, hipStream_t s, float* fft_scratch) {
     const int hc = fb.e / 2;
     FftBwdArgs fa;
-    fa.do2 = do2; fa.sgn = fb.sgn; fa.amp = fb.amp; fa.pha = fb.pha; fa.dg = dg;
+    fa.do2 = do2; fa.sgn = fb.sgn; fa.amp = fb.amp; fa.pha = fb.pha; fa.dg = dg; fa.scratch = fft_scratch;
     fa.ampw = P + pl->blk(st, j, B_AMPW); fa.ampb = P + pl->blk(st, j, B_AMPB);
     fa.phaw = P + pl->blk(st, j, B_PHAW); fa.phab = P + pl->blk(st, j, B_PHAB);
     fa.d_ampw = G + pl->blk(st, j, B_AMPW); fa.d_ampb = G + pl->blk(st, j, B_AMPB);
@@ -105,7 +105,7 @@ static int mixer_half_bwd(const lg_plan* pl, const float* P, float* G, int st, i
     po.HW = fb.h * fb.w; po.total = Pn; po.dropout = drop; po.seed = mix_seed(seed, st, j);
     RC(launch_proj_o2_bwd(e, po, s));
     const float* dym = drop ? bb.dym : tmp;
-    RC(fft_bwd_call(pl, P, G, st, j, fb, bb.do2, bb.dg, B, s));
+    RC(fft_bwd_call(pl, P, G, st, j, fb, bb.do2, bb.dg, B, s, bb.fft_scratch));
     AttnBwdArgs at;
     at.x = fb.xin; at.dy = tmp; at.dym = dym; at.o2 = fb.o2; at.dg = bb.dg; at.dx = dx_out;
     at.cat = bb.cat; at.y1 = bb.y1; at.dqkv = bb.dqkv;
@@ -135,8 +135,9 @@ int op_block_bwd(const lg_plan* pl, const float* P, float* G, int st, int j, int
                  void* bwd_ws, int B, hipStream_t s) {
     BwdBufs bb;
     carve_bwd(pl, B, bwd_ws, bb);
+    bb.fft_scratch = nb.fft_scratch;
     const BlockBufs& fb = nb.blk[j];
-    if (which == 0) return fft_bwd_call(pl, P, G, st, j, fb, dy, dx, B, s);
+    if (which == 0) return fft_bwd_call(pl, P, G, st, j, fb, dy, dx, B, s, nb.fft_scratch);
     if (which == 1) return mixer_half_bwd(pl, P, G, st, j, fb, bb, nb.posT, dy, dx, B, 0, 0, s);
     return ffn_half_bwd(pl, P, G, st, j, fb, bb, dy, dx, B, s);
 }
@@ -186,6 +187,7 @@ int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, c
     const int E = 4 * c.C, st = c.K - 1;
     BwdBufs bb;
     carve_bwd(pl, B, bwd_ws, bb);
+    bb.fft_scratch = nb.fft_scratch;
     const long P0 = (long)B * c.H * c.W, P1 = P0 / 4;
     const float* posT = nb.posT + (size_t)st * 5 * 2 * 64 * 64;
     float *A = bb.dx[0], *Bf = bb.dx[1], *Cf = bb.dx[2];

@@ -8,6 +8,8 @@
 // rows are Hermitian-extended before the last (row) inverse, with Im of the kx = 0 and kx = n/2 columns
 // dropped exactly as a c2r transform does.  The four purely-real bins get +0.0 imaginary parts so that
 // angle() takes the same branch as pocketfft's r2c (+pi for negative DC).  fp32 throughout.
+#include <string.h>
+
 #include "kernels.h"
 #include "bwd_kernels.h"
 
@@ -19,31 +21,32 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 w) { return make_float2
 // S fused radix-2 stages in one LDS pass: a thread loads 2^S points, runs the S butterfly levels in registers and writes
 // them back (same data flow as S consecutive radix-2 passes -> same bit-reversed positions), so the plane crosses LDS
 // 3 times per 1-D transform (7 = 3 + 3 + 1 stages at n = 128) instead of 7.
-template <bool INVERSE, bool COLS, int S>
-__device__ __forceinline__ void fft_fused(float2* buf, const float2* tw, int n, int lg, int st) {
+// Lines: `nlines` transforms of length n = 2^lg; element i of line l sits at buf[l * ls + i * es].
+// SKIP (square in-LDS planes only): lines are columns in bit-reversed kx order; columns with kx > n/2 are not needed.
+template <bool INVERSE, bool SKIP, int S>
+__device__ __forceinline__ void fft_fused(float2* buf, const float2* tw, int lg, int lgnl, int ls, int es, int st) {
+    const int nlines = 1 << lgnl;
     constexpr int R = 1 << S;
-    const int half = n >> 1;
+    const int n = 1 << lg, half = n >> 1;
     // spans of the fused levels: forward (DIF) largest first, inverse (DIT) smallest first; mL = smallest span
     const int lgmL = INVERSE ? st : (lg - st - S);
     const int mL = 1 << lgmL;
-    const int per_line = n >> S;                 // items per line
-    const int lgpl = lg - S;
-    const int items = n << lgpl;
+    const int lgpl = lg - S;                     // log2(items per line)
+    const int items = nlines << lgpl;
     for (int it = threadIdx.x; it < items; it += blockDim.x) {
         int line, t;
-        if (COLS) { t = it >> lg; line = it & (n - 1); } else { line = it >> lgpl; t = it & (per_line - 1); }
-        if (COLS) {
+        if (es != 1) { t = it >> lgnl; line = it & (nlines - 1); }         // column transforms: consecutive threads -> consecutive lines
+        else { line = it >> lgpl; t = it & ((1 << lgpl) - 1); }             // row transforms: consecutive threads -> consecutive items
+        if (SKIP) {
             const int kx = (int)(__brev((unsigned)line) >> (32 - lg));
             if (kx > half) continue;
         }
         const int lo = t & (mL - 1), hi = t >> lgmL;
         const int i_base = (hi << (lgmL + S)) + lo;
+        float2* base = buf + line * ls;
         float2 v[R];
 #pragma unroll
-        for (int c = 0; c < R; ++c) {
-            const int i = i_base + (c << lgmL);
-            v[c] = buf[COLS ? ((i << lg) + line) : ((line << lg) + i)];
-        }
+        for (int c = 0; c < R; ++c) v[c] = base[(i_base + (c << lgmL)) * es];
 #pragma unroll
         for (int k = 0; k < S; ++k) {
             // level k pairs (c, c + d); span of this level m = mL * d
@@ -68,21 +71,56 @@ __device__ __forceinline__ void fft_fused(float2* buf, const float2* tw, int n, 
             }
         }
 #pragma unroll
-        for (int c = 0; c < R; ++c) {
-            const int i = i_base + (c << lgmL);
-            buf[COLS ? ((i << lg) + line) : ((line << lg) + i)] = v[c];
-        }
+        for (int c = 0; c < R; ++c) base[(i_base + (c << lgmL)) * es] = v[c];
     }
     __syncthreads();
 }
 
 // full 1-D transform of every line: stages grouped 3 + 3 + ... + remainder
+template <bool INVERSE, bool SKIP>
+__device__ __forceinline__ void fft_lines(float2* buf, const float2* tw, int lg, int lgnl, int ls, int es) {
+    int st = 0;
+    while (lg - st >= 3) { fft_fused<INVERSE, SKIP, 3>(buf, tw, lg, lgnl, ls, es, st); st += 3; }
+    if (lg - st == 2) fft_fused<INVERSE, SKIP, 2>(buf, tw, lg, lgnl, ls, es, st);
+    else if (lg - st == 1) fft_fused<INVERSE, SKIP, 1>(buf, tw, lg, lgnl, ls, es, st);
+}
+// square n x n plane resident in LDS (row-major): rows, or the kx <= n/2 columns
 template <bool INVERSE, bool COLS>
 __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int n, int lg) {
-    int st = 0;
-    while (lg - st >= 3) { fft_fused<INVERSE, COLS, 3>(buf, tw, n, lg, st); st += 3; }
-    if (lg - st == 2) fft_fused<INVERSE, COLS, 2>(buf, tw, n, lg, st);
-    else if (lg - st == 1) fft_fused<INVERSE, COLS, 1>(buf, tw, n, lg, st);
+    if (COLS) fft_lines<INVERSE, true>(buf, tw, lg, lg, 1, n);
+    else fft_lines<INVERSE, false>(buf, tw, lg, lg, n, 1);
+}
+
+// amplitude / phase edit of one bin (LGT.py:168-177) and its backward, shared by the in-LDS and the split (256^2) paths
+__device__ __forceinline__ float2 bin_edit_fwd(float2 f, float aw, float ab, float pw, float pb, float& amp, float& pha) {
+    amp = hypotf(f.x, f.y);
+    pha = atan2f(f.y, f.x);
+    const float am = aw * amp + ab, ph = pw * pha + pb;
+    float sn, cs;
+    sincosf(ph, &sn, &cs);
+    return make_float2((am * cs + 1e-8f) + 1e-8f, am * sn + 1e-8f);
+}
+// f = c/n^2 * rfft2(dt) bin; returns dF * n^2 / c and accumulates the four parameter-gradient partials
+__device__ __forceinline__ float2 bin_edit_bwd(float2 f, float c, float nn, float A, float PH, float aw, float ab, float pw, float pb,
+                                               float& s_aw, float& s_ab, float& s_pw, float& s_pb) {
+    const float dR = f.x * (c / nn), dI = f.y * (c / nn);
+    const float Am = aw * A + ab, Ph = pw * PH + pb;
+    float sn, cs;
+    sincosf(Ph, &sn, &cs);
+    const float dAm = dR * cs + dI * sn;
+    const float dPh = Am * (dI * cs - dR * sn);
+    s_aw += dAm * A; s_ab += dAm; s_pw += dPh * PH; s_pb += dPh;
+    const float dA = aw * dAm, dPH = pw * dPh;
+    float sn0, cs0;
+    sincosf(PH, &sn0, &cs0);
+    float dFr = 0.f, dFi = 0.f;
+    if (A > 0.f) {
+        const float ia = 1.0f / A;
+        dFr = dA * cs0 - dPH * sn0 * ia;
+        dFi = dA * sn0 + dPH * cs0 * ia;
+    }
+    const float k2 = nn / c;
+    return make_float2(dFr * k2, dFi * k2);
 }
 
 // rows: drop Im of the kx = 0 and kx = n/2 columns and Hermitian-extend (what a c2r transform assumes)
@@ -129,22 +167,15 @@ __global__ void k_fftmix(FftArgs a, int lg) {
         int q = it >> lg, p = it & (n - 1);
         int kx = (int)(__brev((unsigned)p) >> (32 - lg));
         if (kx > half) continue;
-        float2 f = buf[it];
-        float amp = hypotf(f.x, f.y);
-        float pha = atan2f(f.y, f.x);
+        float amp, pha;
+        const float2 ed = bin_edit_fwd(buf[it], aw, ab, pw, pb, amp, pha);
         if (a.amp) {
             int ky = (int)(__brev((unsigned)q) >> (32 - lg));
             size_t o = ((size_t)plane * n + ky) * (half + 1) + kx;
             a.amp[o] = amp;
             a.pha[o] = pha;
         }
-        float am = aw * amp + ab;
-        float ph = pw * pha + pb;
-        float sn, cs;
-        sincosf(ph, &sn, &cs);
-        float re = (am * cs + 1e-8f) + 1e-8f;
-        float im = am * sn + 1e-8f;
-        buf[it] = make_float2(re, im);
+        buf[it] = ed;
     }
     __syncthreads();
     // ---- irfft2: columns (complex), Hermitian extension, rows
@@ -160,11 +191,211 @@ __global__ void k_fftmix(FftArgs a, int lg) {
     }
 }
 
+
+// ================================================================================================
+// Split path for planes that do not fit LDS (n = 256, 512): rows -> global half spectrum S[plane][n][n/2+1] -> columns
+// (+ amplitude/phase edit, in place) -> rows.  Same arithmetic as the in-LDS kernels; three launches per direction.
+// ================================================================================================
+#define FFT_ROWS_PER_WG(n) (16384 / (n))   // 128 KiB complex tile
+#define FFT_COLS_PER_WG(n) (8192 / (n))    // 64 KiB complex tile
+
+__device__ __forceinline__ void make_twiddles(float2* tw, int n) {
+    for (int k = threadIdx.x; k < (n >> 1); k += blockDim.x) {
+        float ang = 2.0f * (float)k / (float)n;
+        tw[k] = make_float2(cospif(ang), 0.0f - sinpif(ang));
+    }
+}
+
+// real rows -> half spectrum (natural kx order).  mul: optional elementwise factor (backward: sign of the forward output)
+__global__ void k_fft_rows_fwd(const float* __restrict__ in, const float* __restrict__ mul, float2* __restrict__ S, int n, int lg, int force_real) {
+    extern __shared__ float2 smem2[];
+    const int R = FFT_ROWS_PER_WG(n), half = n >> 1;
+    int lgR = 0;
+    while ((1 << lgR) < R) ++lgR;
+    float2* buf = smem2;
+    float2* tw = smem2 + R * n;
+    const size_t plane = blockIdx.x;
+    const int row0 = blockIdx.y * R;
+    make_twiddles(tw, n);
+    const size_t base = (plane * n + row0) * n;
+    for (int i = threadIdx.x; i < R * n; i += blockDim.x) {
+        float v = in[base + i];
+        if (mul) v *= mul[base + i];
+        buf[i] = make_float2(v, 0.0f);
+    }
+    __syncthreads();
+    fft_lines<false, false>(buf, tw, lg, lgR, n, 1);
+    for (int i = threadIdx.x; i < R * (half + 1); i += blockDim.x) {
+        const int r = i / (half + 1), kx = i - r * (half + 1);
+        float2 v = buf[r * n + (int)(__brev((unsigned)kx) >> (32 - lg))];
+        if (force_real && (kx == 0 || kx == half)) v.y = 0.0f;
+        S[(plane * n + row0 + r) * (half + 1) + kx] = v;
+    }
+}
+
+// columns of the half spectrum, in place: forward column FFT, bin edit (forward or backward), inverse column FFT
+template <bool BWD>
+__global__ void k_fft_cols(FftArgs fa, FftBwdArgs ba, float2* __restrict__ S, int n, int lg) {
+    extern __shared__ float2 smem2[];
+    const int CB = FFT_COLS_PER_WG(n), half = n >> 1;
+    int lgCB = 0;
+    while ((1 << lgCB) < CB) ++lgCB;
+    float2* buf = smem2;            // [n rows][CB cols]
+    float2* tw = smem2 + n * CB;
+    float* red = reinterpret_cast<float*>(tw + half);
+    const size_t plane = blockIdx.x;
+    const int chn = BWD ? ba.ch : fa.ch;
+    const int ch = (int)(plane % chn);
+    const int kx0 = blockIdx.y * CB;
+    const int ncols = min(CB, half + 1 - kx0);
+    make_twiddles(tw, n);
+    for (int i = threadIdx.x; i < n * CB; i += blockDim.x) {
+        const int y = i >> lgCB, c = i & (CB - 1);
+        buf[i] = (c < ncols) ? S[(plane * n + y) * (half + 1) + kx0 + c] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    fft_lines<false, false>(buf, tw, lg, lgCB, 1, CB);
+    if (!BWD) {   // the four purely-real bins: ky in {0, n/2} (positions 0, 1) x kx in {0, n/2}
+        if (threadIdx.x < 2 * CB) {
+            const int q = threadIdx.x / CB, c = threadIdx.x - q * CB;
+            if (c < ncols && (kx0 + c == 0 || kx0 + c == half)) buf[q * CB + c].y = 0.0f;
+        }
+        __syncthreads();
+    }
+    const float aw = (BWD ? ba.ampw : fa.ampw)[ch], ab = (BWD ? ba.ampb : fa.ampb)[ch];
+    const float pw = (BWD ? ba.phaw : fa.phaw)[ch], pb = (BWD ? ba.phab : fa.phab)[ch];
+    const float nn = (float)n * (float)n;
+    float s_aw = 0.f, s_ab = 0.f, s_pw = 0.f, s_pb = 0.f;
+    for (int i = threadIdx.x; i < n * CB; i += blockDim.x) {
+        const int q = i >> lgCB, c = i & (CB - 1);
+        if (c >= ncols) continue;
+        const int ky = (int)(__brev((unsigned)q) >> (32 - lg)), kx = kx0 + c;
+        const size_t o = (plane * n + ky) * (half + 1) + kx;
+        if (!BWD) {
+            float amp, pha;
+            buf[i] = bin_edit_fwd(buf[i], aw, ab, pw, pb, amp, pha);
+            if (fa.amp) { fa.amp[o] = amp; fa.pha[o] = pha; }
+        } else {
+            const float cw = (kx == 0 || kx == half) ? 1.0f : 2.0f;
+            buf[i] = bin_edit_bwd(buf[i], cw, nn, ba.amp[o], ba.pha[o], aw, ab, pw, pb, s_aw, s_ab, s_pw, s_pb);
+        }
+    }
+    __syncthreads();
+    fft_lines<true, false>(buf, tw, lg, lgCB, 1, CB);
+    for (int i = threadIdx.x; i < n * CB; i += blockDim.x) {
+        const int y = i >> lgCB, c = i & (CB - 1);
+        if (c < ncols) S[(plane * n + y) * (half + 1) + kx0 + c] = buf[i];
+    }
+    if (BWD) {
+        float v[4] = {s_aw, s_ab, s_pw, s_pb};
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
+            if (lane == 0) red[wave * 4 + i] = v[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            float sum = 0.f;
+            for (int w = 0; w < nw; ++w) sum += red[w * 4 + threadIdx.x];
+            float* dst = threadIdx.x == 0 ? ba.d_ampw : (threadIdx.x == 1 ? ba.d_ampb : (threadIdx.x == 2 ? ba.d_phaw : ba.d_phab));
+            atomicAdd(dst + ch, sum);
+        }
+    }
+}
+
+// half spectrum rows -> real rows (c2r): out = |x| (+ sign save) when absout, else the signed value
+__global__ void k_fft_rows_inv(const float2* __restrict__ S, float* __restrict__ out, float* __restrict__ sgn, int n, int lg, int absout) {
+    extern __shared__ float2 smem2[];
+    const int R = FFT_ROWS_PER_WG(n), half = n >> 1;
+    int lgR = 0;
+    while ((1 << lgR) < R) ++lgR;
+    float2* buf = smem2;
+    float2* tw = smem2 + R * n;
+    const size_t plane = blockIdx.x;
+    const int row0 = blockIdx.y * R;
+    make_twiddles(tw, n);
+    for (int i = threadIdx.x; i < R * (half + 1); i += blockDim.x) {
+        const int r = i / (half + 1), kx = i - r * (half + 1);
+        float2 v = S[(plane * n + row0 + r) * (half + 1) + kx];
+        const int p = (int)(__brev((unsigned)kx) >> (32 - lg));
+        if (kx == 0 || kx == half) {
+            buf[r * n + p] = make_float2(v.x, 0.0f);           // c2r drops these imaginary parts
+        } else {
+            buf[r * n + p] = v;
+            buf[r * n + (int)(__brev((unsigned)(n - kx)) >> (32 - lg))] = make_float2(v.x, -v.y);
+        }
+    }
+    __syncthreads();
+    fft_lines<true, false>(buf, tw, lg, lgR, n, 1);
+    const float sc = 1.0f / ((float)n * (float)n);
+    const size_t base = (plane * n + row0) * n;
+    for (int i = threadIdx.x; i < R * n; i += blockDim.x) {
+        const float v = buf[i].x * sc;
+        if (absout) {
+            out[base + i] = fabsf(v);
+            if (sgn) sgn[base + i] = (v > 0.f) ? 1.0f : ((v < 0.f) ? -1.0f : 0.0f);
+        } else {
+            out[base + i] = v;
+        }
+    }
+}
+
+size_t fft_scratch_floats(int planes, int n) { return n > 128 ? (size_t)planes * n * (n / 2 + 1) * 2 : 0; }
+
+static int split_attrs() {
+    static bool done = false;
+    if (done) return 0;
+    const void* fns[4] = {(const void*)k_fft_rows_fwd, (const void*)k_fft_cols<false>, (const void*)k_fft_cols<true>, (const void*)k_fft_rows_inv};
+    for (int i = 0; i < 4; ++i) {
+        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        if (e != hipSuccess) { lg_set_error("fft split: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    done = true;
+    return 0;
+}
+
+static int launch_fft_split(const FftArgs* fa, const FftBwdArgs* ba, hipStream_t s) {
+    const int n = fa ? fa->n : ba->n, planes = fa ? fa->planes : ba->planes;
+    float2* S = reinterpret_cast<float2*>(fa ? fa->scratch : ba->scratch);
+    if (!S) { lg_set_error("fftmix: plane size %d needs the split path but no scratch buffer was given", n); return -2; }
+    int lg = 0;
+    while ((1 << lg) < n) ++lg;
+    int rc = split_attrs();
+    if (rc) return rc;
+    const int R = FFT_ROWS_PER_WG(n), CB = FFT_COLS_PER_WG(n), half = n / 2;
+    const size_t lds_rows = ((size_t)R * n + half) * sizeof(float2);
+    const size_t lds_cols = ((size_t)n * CB + half) * sizeof(float2) + 64 * sizeof(float);
+    dim3 grows(planes, n / R), gcols(planes, (half + 1 + CB - 1) / CB);
+    if (fa) {
+        k_fft_rows_fwd<<<grows, 1024, lds_rows, s>>>(fa->g, nullptr, S, n, lg, 1);
+        LG_CHECK_LAUNCH();
+        FftBwdArgs dummy;
+        memset(&dummy, 0, sizeof(dummy));
+        k_fft_cols<false><<<gcols, 512, lds_cols, s>>>(*fa, dummy, S, n, lg);
+        LG_CHECK_LAUNCH();
+        k_fft_rows_inv<<<grows, 1024, lds_rows, s>>>(S, fa->o, fa->sgn, n, lg, 1);
+        LG_CHECK_LAUNCH();
+    } else {
+        k_fft_rows_fwd<<<grows, 1024, lds_rows, s>>>(ba->do2, ba->sgn, S, n, lg, 0);
+        LG_CHECK_LAUNCH();
+        FftArgs dummy;
+        memset(&dummy, 0, sizeof(dummy));
+        k_fft_cols<true><<<gcols, 512, lds_cols, s>>>(dummy, *ba, S, n, lg);
+        LG_CHECK_LAUNCH();
+        k_fft_rows_inv<<<grows, 1024, lds_rows, s>>>(S, ba->dg, nullptr, n, lg, 0);
+        LG_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
 int launch_fftmix(const FftArgs& a, hipStream_t s) {
     ProfScope prof__(LG_K_FFT, s);
     int n = a.n, lg = 0;
     while ((1 << lg) < n) ++lg;
-    if ((1 << lg) != n || n < 8 || n > 128) { lg_set_error("fftmix: plane size %d unsupported (power of two, 8..128)", n); return -2; }
+    if ((1 << lg) != n || n < 8 || n > 512) { lg_set_error("fftmix: plane size %d unsupported (power of two, 8..512)", n); return -2; }
+    if (n > 128) return launch_fft_split(&a, nullptr, s);
     size_t lds = ((size_t)n * n + n / 2) * sizeof(float2);
     static bool attr_done = false;
     if (!attr_done) {
@@ -210,27 +441,8 @@ __global__ void k_fftmix_bwd(FftBwdArgs a, int lg) {
         if (kx > half) continue;
         int ky = (int)(__brev((unsigned)q) >> (32 - lg));
         const float c = (kx == 0 || kx == half) ? 1.0f : 2.0f;
-        const float2 f = buf[it];
-        const float dR = f.x * (c / nn), dI = f.y * (c / nn);
         const size_t o = ((size_t)plane * n + ky) * (half + 1) + kx;
-        const float A = a.amp[o], PH = a.pha[o];
-        const float Am = aw * A + ab, Ph = pw * PH + pb;
-        float sn, cs;
-        sincosf(Ph, &sn, &cs);
-        const float dAm = dR * cs + dI * sn;
-        const float dPh = Am * (dI * cs - dR * sn);
-        s_aw += dAm * A; s_ab += dAm; s_pw += dPh * PH; s_pb += dPh;
-        const float dA = aw * dAm, dPH = pw * dPh;
-        float sn0, cs0;
-        sincosf(PH, &sn0, &cs0);
-        float dFr = 0.f, dFi = 0.f;
-        if (A > 0.f) {
-            const float ia = 1.0f / A;
-            dFr = dA * cs0 - dPH * sn0 * ia;
-            dFi = dA * sn0 + dPH * cs0 * ia;
-        }
-        const float k2 = nn / c;
-        buf[it] = make_float2(dFr * k2, dFi * k2);
+        buf[it] = bin_edit_bwd(buf[it], c, nn, a.amp[o], a.pha[o], aw, ab, pw, pb, s_aw, s_ab, s_pw, s_pb);
     }
     __syncthreads();
     fft_pass<true, true>(buf, tw, n, lg);
@@ -260,7 +472,8 @@ int launch_fftmix_bwd(const FftBwdArgs& a, hipStream_t s) {
     ProfScope prof__(LG_K_FFT_BWD, s);
     int n = a.n, lg = 0;
     while ((1 << lg) < n) ++lg;
-    if ((1 << lg) != n || n < 8 || n > 128) { lg_set_error("fftmix_bwd: plane size %d unsupported", n); return -2; }
+    if ((1 << lg) != n || n < 8 || n > 512) { lg_set_error("fftmix_bwd: plane size %d unsupported", n); return -2; }
+    if (n > 128) return launch_fft_split(nullptr, &a, s);
     size_t lds = ((size_t)n * n + n / 2) * sizeof(float2) + 64 * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {

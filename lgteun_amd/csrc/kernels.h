@@ -72,10 +72,12 @@ struct FftArgs {
     float* amp;       // optional save [B,ch,n,n/2+1]
     float* pha;       // optional save
     float* sgn;       // optional save: sign of the irfft2 output [B,ch,n,n]
+    float* scratch;   // n > 128 only: half-spectrum scratch [planes][n][n/2+1] complex
     const float *ampw, *ampb, *phaw, *phab;  // [ch]
     int planes, ch, n;
 };
 int launch_fftmix(const FftArgs& a, hipStream_t s);
+size_t fft_scratch_floats(int planes, int n);
 
 // ---------------- local mixer + proj + residual, LGT.py:112-146,183-219,231-248 ----------------
 struct AttnArgs {

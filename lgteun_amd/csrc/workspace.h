@@ -33,6 +33,7 @@ struct NetBufs {
     float* deadout;   // output of dead-stage LGTs (faithful mode)
     float* u_down;    // saved bicubic-downsampled encoder output [B,H/2,W/2,E] (train)
     float* t_up;      // saved up-path tensor [B,H,W,E] (train)
+    float* fft_scratch;  // PAN > 128 only: half-spectrum scratch of the split FFT path
     size_t bytes;
 };
 
@@ -84,5 +85,10 @@ static inline void carve(const lg_plan* plan, int B, int train, void* base, NetB
     nb.blk[4].xin = nb.blk[3].xout;
     nb.u_down = train ? cv.take(B * P1 * E) : nullptr;
     nb.t_up = train ? cv.take(B * P0 * E) : nullptr;
+    {
+        const size_t planes = (size_t)B * (E / 2);
+        const size_t fl = c.H > 128 ? planes * c.H * (c.H / 2 + 1) * 2 : 0;
+        nb.fft_scratch = fl ? cv.take(fl) : nullptr;
+    }
     nb.bytes = cv.off;
 }

@@ -168,3 +168,25 @@ def test_half_block_backward_vs_oracle(C, blk, which):
         worst.append((float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)), k))
     worst.sort(reverse=True)
     assert worst[0][0] < 2e-3, worst[:5]
+
+
+@pytest.mark.parametrize('which', [0, 1])
+def test_half_block_backward_256_split_fft(which):
+    """level-0 mixer half-block at 256x256 (plane too large for LDS: three-kernel FFT path), fp64 oracle"""
+    from gpu_helpers import Ops, make_module
+    C = 4
+    net = make_module(C, 1)
+    ops = Ops(net, 256, 256)
+    e, hw = 16, 256
+    rng = np.random.default_rng(77 + which)
+    x = T(rng.standard_normal((1, hw, hw, e)).astype(np.float32))
+    dy_shape = (1, e // 2, hw, hw) if which == 0 else (1, hw, hw, e)
+    dy = T(rng.standard_normal(dy_shape).astype(np.float32))
+    P64 = det_params(C, 1, dtype=torch.float64, requires_grad=True)
+    want_dx, want_g = _oracle_block(P64, C, 0, which, x.double(), dy.double())
+    got_dx, flat = ops.block_bwd(0, 0, which, x.cuda(), dy.cuda())
+    assert rel_l2(got_dx.cpu(), want_dx) < 5e-4, rel_l2(got_dx.cpu(), want_dx)
+    for k, g in want_g.items():
+        got = ops.grad_of(flat, k).cpu().numpy()
+        ref = g.numpy()
+        assert float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)) < 5e-3, k

@@ -89,7 +89,8 @@ def test_lgt(gpu, C):
     assert rel_l2(got, g['lgt']) < 1e-4                  # vs the reference itself
 
 
-@pytest.mark.parametrize('name', ['net_c4_k2_p32', 'net_c8_k2_p32', 'net_c4_k4_p64', 'net_c4_k4_p128', 'net_c8_k4_p128'])
+@pytest.mark.parametrize('name', ['net_c4_k2_p32', 'net_c8_k2_p32', 'net_c4_k4_p64', 'net_c4_k4_p128', 'net_c8_k4_p128',
+                                  'net_c4_k2_p256'])
 @pytest.mark.parametrize('mode', ['faithful', 'live'])
 def test_whole_net_vs_reference_golden(gpu, manifest, name, mode):
     from gpu_helpers import make_module
@@ -109,6 +110,18 @@ def test_whole_net_vs_reference_golden(gpu, manifest, name, mode):
     t = np.transpose(gt[0], (1, 2, 0)).astype(np.float64) * 2047.5
     met = np.array([orc.psnr(o, t), orc.sam(o, t)])
     assert np.allclose(met, g['metrics'][:2], atol=5e-4), (met, g['metrics'])
+
+
+def test_config5_shape_c8_k8_p256_vs_oracle(gpu):
+    """BASELINE configs[4] shape: 8 bands, 256x256 PAN / 64x64 MS, K=8 (split-FFT path at level 0) vs the oracle"""
+    from gpu_helpers import make_module
+    C, K = 8, 8
+    ms, pan, _ = dw.make_inputs(1, C, 64, 64, seed=5, kind='smooth')
+    net = make_module(C, K)
+    with torch.no_grad():
+        y = net(T(ms).cuda(), T(pan).cuda()).cpu()
+        want = orc.forward(det_params(C, K), T(ms), T(pan), K, mode='live')
+    assert rel_l2(y, want) < 1e-3
 
 
 def test_batch_independence_and_determinism(gpu):
@@ -133,5 +146,7 @@ def test_bad_inputs_raise(gpu):
         net(torch.zeros(1, 3, 8, 8, device='cuda'), torch.zeros(1, 1, 32, 32, device='cuda'))
     with pytest.raises(LgteunHipError):      # PAN 24x24: not a multiple of 16
         net(torch.zeros(1, 4, 6, 6, device='cuda'), torch.zeros(1, 1, 24, 24, device='cuda'))
+    with pytest.raises(LgteunHipError):      # PAN 96x96: not a power of two (FFT mixer)
+        net(torch.zeros(1, 4, 24, 24, device='cuda'), torch.zeros(1, 1, 96, 96, device='cuda'))
     with pytest.raises(RuntimeError):        # no CPU path
         make_module(4, 1, device='cpu')(torch.zeros(1, 4, 8, 8), torch.zeros(1, 1, 32, 32))

@@ -51,7 +51,7 @@ def test_ops_vs_reference(C):
 
 
 @pytest.mark.parametrize('name', ['net_c4_k2_p32', 'net_c8_k2_p32', 'net_c4_k4_p64', 'net_c4_k4_p128',
-                                  'net_c8_k4_p128'])
+                                  'net_c8_k4_p128', 'net_c4_k2_p256'])
 def test_whole_net_vs_reference(name, manifest):
     m = manifest[name]
     g = load_gold(name)

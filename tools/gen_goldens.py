@@ -97,6 +97,7 @@ def main():
         dict(name='net_c4_k4_p64', C=4, K=4, B=1, h=16, kind='smooth'),
         dict(name='net_c4_k4_p128', C=4, K=4, B=1, h=32, kind='dn'),
         dict(name='net_c8_k4_p128', C=8, K=4, B=1, h=32, kind='dn'),
+        dict(name='net_c4_k2_p256', C=4, K=2, B=1, h=64, kind='smooth'),   # 256x256 PAN: split-FFT path (BASELINE config 5 size)
     ]
     for cs in cases:
         C, K, B, h = cs['C'], cs['K'], cs['B'], cs['h']
