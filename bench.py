@@ -27,6 +27,9 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0
 PEAK_F32_MFMA_TFLOPS = 157.3
 
+# HBM bytes per launch from the PMC counters (profiles/, FETCH_SIZE x2 corrected + WRITE_SIZE; separate --pmc passes), per kernel
+TRAFFIC_BYTES = {'ffn': 233361138}   # k_ffn_fused, all launches of a step averaged (profiles/r01_bench_bs32_pmc_hbm.csv)
+
 C, K, H, B_PER_GPU = 4, 4, 128, 32
 E, P0 = 4 * C, H * H
 
@@ -42,21 +45,20 @@ def synth_batch(B, rank, device):
 
 def algorithmic_per_launch(kernel, B):
     """ALGORITHMIC work of one average launch of `kernel` (SURVEY 8d per-unit figures):
-    bytes = what an ideally fused unit moves (reads its input once, writes its output once, fp32); flops = 2 x MAC.
-    Per LGT the kernel runs on 4 level-0 blocks (E ch, P0 px) and 1 level-1 block (2E ch, P0/4 px)."""
+    bytes = what the ideally fused unit moves (reads its input once, writes its output once, fp32); flops = 2 x MAC of
+    its convs.  Per LGT a block kernel runs on 4 level-0 blocks (E ch, P0 px) and 1 level-1 block (2E ch, P0/4 px);
+    figures are averaged over those 5 launches."""
     px = [(E, P0)] * 4 + [(2 * E, P0 // 4)]
-    if kernel in ('ffn1', 'ffn2', 'ffn1_bwd', 'ffn2_bwd'):
-        # the FFN half-block as one fused unit: read x (e), write y (e) per pixel
-        byts = sum(2 * e * p * 4 for e, p in px) / 5 * B
-        flops = {'ffn1': sum(2 * (e * 4 * e + 4 * e * 4 * e) * p for e, p in px),
-                 'ffn2': sum(2 * (9 * 4 * e + 4 * e * e) * p for e, p in px),
-                 'ffn1_bwd': sum(2 * (e * 4 * e + 4 * e * 4 * e + 9 * 4 * e * 2) * p for e, p in px),
-                 'ffn2_bwd': sum(2 * (4 * e * e) * p for e, p in px)}[kernel] / 5 * B
+    if kernel == 'ffn':
+        # k_ffn_fused = the whole feed_forward half-block: x in, y out (+ planar LN half for the next mixer: e/2)
+        byts = sum((2 * e + e // 2) * p * 4 for e, p in px) / 5 * B
+        flops = sum((2 * (e * 4 * e + 4 * e * 4 * e + 4 * e * e) + 18 * 4 * e) * p for e, p in px) / 5 * B
         return byts, flops
     if kernel in ('fft', 'attn', 'fft_bwd', 'attn_bwd'):
         # mixer half-block unit: read x (e), write y (e); the two kernels split it by channel half
         byts = sum(2 * e * p * 4 for e, p in px) / 5 * B / 2
-        return byts, 0.0
+        flops = sum((2 * (3 * (e // 2) ** 2 + e * e) + 2 * 2 * 64 * (e // 2)) * p for e, p in px) / 5 * B if kernel == 'attn' else 0.0
+        return byts, flops
     return 0.0, 0.0   # kernels without a per-unit figure in SURVEY 8d: time only
 
 
@@ -111,7 +113,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--prof-kernel', default='ffn2', help='kernel timed live for the roofline object')
+    ap.add_argument('--prof-kernel', default='ffn', help='kernel timed live for the roofline object (default: the dominant one)')
     ap.add_argument('--mode', default='faithful', choices=['faithful', 'live'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -182,10 +184,17 @@ def main():
         byts, flops = algorithmic_per_launch(args.prof_kernel, B_PER_GPU)
         avg_us = tot_ms.value / max(n_l.value, 1) * 1e3
         ach_gbs = byts / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
-        roof = dict(bound='hbm', achieved=round(ach_gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach_gbs / PEAK_HBM_GBS, 4),
-                    traffic=None, kernel=L.lg_kernel_name(kid).decode(), launches=int(n_l.value), avg_launch_us=round(avg_us, 2),
-                    algorithmic_bytes_per_launch=int(byts), algorithmic_flops_per_launch=int(flops),
-                    mfma_frac_fp32=round(flops / (avg_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if avg_us > 0 else None)
+        ach_tf = flops / (avg_us * 1e-6) / 1e12 if avg_us > 0 else 0.0
+        f_hbm, f_mfma = ach_gbs / PEAK_HBM_GBS, ach_tf / PEAK_F32_MFMA_TFLOPS
+        # the binding roof is the one the kernel sits closer to: fp32 GEMM-bearing units are matrix-core bound
+        if f_mfma >= f_hbm:
+            roof = dict(bound='mfma', achieved=round(ach_tf, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=round(f_mfma, 4))
+        else:
+            roof = dict(bound='hbm', achieved=round(ach_gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(f_hbm, 4))
+        roof.update(traffic=TRAFFIC_BYTES.get(args.prof_kernel), kernel=L.lg_kernel_name(kid).decode(), launches=int(n_l.value),
+                    avg_launch_us=round(avg_us, 2), algorithmic_bytes_per_launch=int(byts), algorithmic_flops_per_launch=int(flops),
+                    hbm_frac=round(f_hbm, 4), mfma_frac_fp32=round(f_mfma, 4), peak_hbm_GBs=PEAK_HBM_GBS,
+                    peak_fp32_mfma_TFLOPs=PEAK_F32_MFMA_TFLOPS)
         out = dict(metric='train image-pairs/sec, GF-2 4-band 128x128, K=4, bs=32/GPU', value=round(value, 2), unit='image-pairs/sec',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
