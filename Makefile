@@ -5,7 +5,7 @@ CSRC  := lgteun_amd/csrc
 SRCS  := $(CSRC)/api.hip $(CSRC)/k_pixel.hip $(CSRC)/k_fft.hip $(CSRC)/k_attn.hip $(CSRC)/k_ffn.hip $(CSRC)/k_bwd.hip $(CSRC)/k_bwd_pixel.hip $(CSRC)/k_wgrad.hip $(CSRC)/k_ffn_bwd.hip $(CSRC)/k_attn_bwd.hip
 OBJS  := $(SRCS:.hip=.o)
 LIB   := lgteun_amd/_lgteun_hip.so
-FLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+FLAGS := -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=$(ARCH) -Wall -Wno-unused-function -Wno-unused-value
 
 all: $(LIB)
 

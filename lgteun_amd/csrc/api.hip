@@ -5,6 +5,11 @@
 #include <string.h>
 #include <math.h>
 
+// only the C ABI of include/lgteun_hip.h is exported from the shared object (everything else: -fvisibility=hidden)
+#pragma GCC visibility push(default)
+#include "../../include/lgteun_hip.h"
+#pragma GCC visibility pop
+
 #include "kernels.h"
 #include "workspace.h"
 #include "backward.h"

@@ -92,3 +92,26 @@ def test_metrics_match_oracle():
     rng = np.random.default_rng(0)
     a, b = rng.uniform(0, 2047, (16, 16, 4)), rng.uniform(0, 2047, (16, 16, 4))
     assert mtc.psnr(a, b) == orc.psnr(a, b) and mtc.sam(a, b) == orc.sam(a, b) and mtc.ergas(a, b) == orc.ergas(a, b)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='needs the reference tree (build container only)')
+def test_reference_checkpoint_converter(tmp_path):
+    """a checkpoint written the reference's way (pickled module objects, base_model.py:354-369) converts to a plain
+    state_dict that the product module loads bit-exactly"""
+    import subprocess
+    import sys
+    import lgteun_amd
+    from lgteun_amd.compat import Config
+    src, dst = tmp_path / 'model_iter_7.pth', tmp_path / 'model_iter_7.state.pth'
+    gen = (
+        "import sys, torch; sys.path.insert(0, r'%s/tools'); from _ref_import import import_reference; R = import_reference();"
+        "torch.manual_seed(3); net = R.Pansharpening(R.Config(ms_chans=4), None, stage=2);"
+        "torch.save({'core_module': net, 'iter_num': 7}, r'%s')" % (ROOT, src))
+    subprocess.run([sys.executable, '-W', 'ignore', '-c', gen], check=True)
+    subprocess.run([sys.executable, '-W', 'ignore', os.path.join(ROOT, 'tools', 'convert_checkpoint.py'), str(src), str(dst)], check=True)
+    ck = torch.load(dst, weights_only=True)              # reference-free: plain tensors only
+    assert ck['iter_num'] == 7
+    net = lgteun_amd.Pansharpening(Config(ms_chans=4), None, stage=2)
+    net.load_state_dict(ck['core_module'])
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, ck['core_module'][k]), k

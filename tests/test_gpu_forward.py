@@ -150,3 +150,15 @@ def test_bad_inputs_raise(gpu):
         net(torch.zeros(1, 4, 24, 24, device='cuda'), torch.zeros(1, 1, 96, 96, device='cuda'))
     with pytest.raises(RuntimeError):        # no CPU path
         make_module(4, 1, device='cpu')(torch.zeros(1, 4, 8, 8), torch.zeros(1, 1, 32, 32))
+
+
+@pytest.mark.parametrize('C,K,B,h', [(4, 1, 3, 4), (8, 3, 5, 8), (4, 5, 1, 16)])
+def test_edge_shapes_vs_oracle(gpu, C, K, B, h):
+    """smallest legal PAN (16x16: one 8x8 window per level-1 plane), odd batch sizes, K = 1 / 3 / 5 (class default)"""
+    from gpu_helpers import make_module
+    ms, pan, _ = dw.make_inputs(B, C, h, h, seed=40 + B, kind='smooth')
+    net = make_module(C, K)
+    with torch.no_grad():
+        y = net(T(ms).cuda(), T(pan).cuda()).cpu()
+        want = orc.forward(det_params(C, K), T(ms), T(pan), K)
+    assert rel_l2(y, want) < 1e-4
