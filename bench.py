@@ -116,6 +116,8 @@ def main():
     ap.add_argument('--prof-kernel', default='ffn', help='kernel timed live for the roofline object (default: the dominant one)')
     ap.add_argument('--mode', default='faithful', choices=['faithful', 'live'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
+                    help="fp32: parity mode (default).  bf16: saved/hidden FFN activations of the backward stored as bf16")
     args = ap.parse_args()
 
     from lgteun_amd import ddp
@@ -139,6 +141,7 @@ def main():
     torch.manual_seed(19971118)
     net = lgteun_amd.Pansharpening(Config(ms_chans=C), None, stage=K).to(device)
     net.mode = args.mode
+    net.precision = args.precision
     net.train()
     eng = net.engine()
     if world > 1:
@@ -197,7 +200,7 @@ def main():
                     peak_fp32_mfma_TFLOPs=PEAK_F32_MFMA_TFLOPS)
         out = dict(metric='train image-pairs/sec, GF-2 4-band 128x128, K=4, bs=32/GPU', value=round(value, 2), unit='image-pairs/sec',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
-                   scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   scaling='weak', vs_baseline=None, dtype='f32' if args.precision == 'fp32' else 'f32 compute, bf16 saved activations', data='synthetic',
                    config=dict(workload='BASELINE configs[1]: C=4, MS 32x32, PAN 128x128, K=4, 32 pairs/GPU, train step = fwd + L1 + '
                                         'bwd + Adam + StepLR tick', mode=args.mode, global_batch=B_PER_GPU * world, parallelism=f'dp{world}',
                                dropout=True),

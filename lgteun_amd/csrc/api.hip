@@ -86,6 +86,7 @@ extern "C" const char* lg_last_error(void) { return g_err; }
 extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int32_t n_offsets, lg_plan** out) {
     if (!cfg || !offsets || !out) { lg_set_error("plan_create: null argument"); return -1; }
     if (cfg->C != 4 && cfg->C != 8) { lg_set_error("plan_create: C must be 4 or 8 (got %d)", cfg->C); return -2; }
+    if (cfg->precision != 0 && cfg->precision != 1) { lg_set_error("plan_create: precision must be 0 (fp32) or 1 (bf16 hidden storage)"); return -2; }
     if (cfg->K < 1 || cfg->K > LG_MAX_K) { lg_set_error("plan_create: K out of range (%d)", cfg->K); return -2; }
     if (cfg->H % 16 || cfg->W % 16 || cfg->H <= 0 || cfg->W <= 0) { lg_set_error("plan_create: H,W must be positive multiples of 16"); return -2; }
     if (cfg->H != cfg->W || (cfg->H & (cfg->H - 1)) || cfg->H > 512) {
@@ -183,6 +184,7 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     a1.w1 = P + pl->blk(stage, j, B_W1); a1.b1 = P + pl->blk(stage, j, B_B1);
     a1.w2 = P + pl->blk(stage, j, B_W2); a1.b2 = P + pl->blk(stage, j, B_B2);
     a1.P = (long)B * bb.h * bb.w;
+    a1.hbf = pl->cfg.precision == 1 ? 1 : 0;
     Ffn2Args a2;
     a2.h2 = bb.h2; a2.x = bb.xmid; a2.a3s = (flags & LG_FLAG_SAVE) ? bb.a3 : nullptr; a2.g3s = (flags & LG_FLAG_SAVE) ? bb.g3 : nullptr; a2.y = bb.xout;
     a2.g = g_next;
@@ -190,7 +192,7 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     a2.w3 = P + pl->blk(stage, j, B_W3); a2.b3 = P + pl->blk(stage, j, B_B3);
     a2.n1g = g_next ? P + pl->blk(stage, next_blk, B_LN1G) : nullptr;
     a2.n1b = g_next ? P + pl->blk(stage, next_blk, B_LN1B) : nullptr;
-    a2.B = B; a2.h = bb.h; a2.w = bb.w;
+    a2.B = B; a2.h = bb.h; a2.w = bb.w; a2.hbf = a1.hbf;
     a1.h2 = (flags & LG_FLAG_SAVE) ? bb.h2 : nullptr;   // fused path: h2 only leaves the chip when the backward needs it
     rc = launch_ffn_fused(bb.e, a1, a2, s);
     if (rc != 1) return rc;

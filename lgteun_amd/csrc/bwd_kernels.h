@@ -4,15 +4,15 @@
 
 // ---------------- generic 1x1-conv weight gradient ----------------
 struct WgradArgs {
-    const float* Y;  // [P, ldy]  gradient of the conv output
-    const float* X;  // [P, ldx]  conv input (optionally transformed on load)
+    const void* Y;   // [P, ldy]  gradient of the conv output (fp32, or bf16 hidden storage when ybf)
+    const void* X;   // [P, ldx]  conv input (fp32, or bf16 hidden storage when xbf)
     float* dW;       // [N][ldw] accumulated (+=)
     float* db;       // [N] accumulated (+=), nullable
     long P;
     int ldy, ldx, ldw;
     int N, K;              // multiples of 16 (padded)
     int n_valid, k_valid;  // rows / cols of dW that exist
-    int xf;                // 0: none, 1: gelu(X)
+    int ybf, xbf;          // operand storage: 0 fp32, 1 bf16 (hstore.h)
 };
 size_t wgrad_slab_floats(int N, int K, long P);
 int launch_wgrad(const WgradArgs& a, float* slab, hipStream_t s);
@@ -96,9 +96,10 @@ int launch_upfuse_bwd_b(int E, const UpFuseBwdArgs& a, hipStream_t s);
 // ---------------- feed_forward backward ----------------
 struct FfnDwBwdArgs {
     const float* dy;   // [B,h,w,e]  grad wrt block output
-    const float* g3;   // [B,h,w,4e] saved gelu'(h3)
-    const float* h2;   // [B,h,w,4e] saved
-    float* dh2;        // [B,h,w,4e] out: dw3x3^T ((dy W3) * g3)
+    const void* g3;    // [B,h,w,4e] saved gelu'(h3)   (hidden storage)
+    const void* h2;    // [B,h,w,4e] saved              (hidden storage)
+    void* dh2;         // [B,h,w,4e] out: dw3x3^T ((dy W3) * g3)   (hidden storage)
+    int hbf;           // hidden storage: 0 fp32, 1 bf16
     const float *w3t;  // [4e][e] transposed W3
     const float* dww;  // [4e,1,3,3]
     float *slab_w, *slab_b;  // [tiles][4e*9], [tiles][4e] partials
@@ -108,16 +109,17 @@ struct FfnDwBwdArgs {
 size_t ffn_dw_bwd_slab_floats(int e, int B, int h, int w);
 int launch_ffn_dw_bwd(int e, const FfnDwBwdArgs& a, hipStream_t s);
 struct Ffn1BwdArgs {
-    const float* dh2;  // [P,4e]
-    const float* g1;   // [P,4e] saved gelu'(h1)
+    const void* dh2;   // [P,4e]  (hidden storage)
+    const void* g1;    // [P,4e] saved gelu'(h1)  (hidden storage)
     const float* x;    // [P,e] block mid activation (LN2 input)
     const float* dy;   // [P,e] grad wrt block output (residual path)
-    float* dh1;        // [P,4e] (wgrad operand)
+    void* dh1;         // [P,4e] (wgrad operand, hidden storage)
     float* y2;         // [P,e] LN2(x) (wgrad operand)
     float* dx;         // [P,e] grad wrt x
     const float *w2t, *w1t, *ln2g, *ln2b;
     float *d_ln2g, *d_ln2b;
     long P;
+    int hbf;           // hidden storage: 0 fp32, 1 bf16
 };
 int launch_ffn1_bwd(int e, const Ffn1BwdArgs& a, hipStream_t s);
 int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[cols][rows]

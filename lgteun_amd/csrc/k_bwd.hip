@@ -46,11 +46,11 @@ size_t bwd_workspace_bytes(const lg_plan* plan, int B) {
 
 #define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
-static int wgrad(const float* Y, int ldy, const float* X, int ldx, float* dW, int ldw, float* db, long P, int N, int K, int nv, int kv,
-                 int xf, float* slab, hipStream_t s) {
+static int wgrad(const void* Y, int ldy, const void* X, int ldx, float* dW, int ldw, float* db, long P, int N, int K, int nv, int kv,
+                 int ybf, int xbf, float* slab, hipStream_t s) {
     WgradArgs a;
     a.Y = Y; a.X = X; a.dW = dW; a.db = db; a.P = P; a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.N = N; a.K = K;
-    a.n_valid = nv; a.k_valid = kv; a.xf = xf;
+    a.n_valid = nv; a.k_valid = kv; a.ybf = ybf; a.xbf = xbf;
     return launch_wgrad(a, slab, s);
 }
 
@@ -58,6 +58,7 @@ static int wgrad(const float* Y, int ldy, const float* X, int ldx, float* dW, in
 static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int j, const BlockBufs& fb, BwdBufs& bb, const float* dy,
                         float* tmp, int B, hipStream_t s) {
     const int e = fb.e, n1 = 4 * e;
+    const int hbf = pl->cfg.precision == 1 ? 1 : 0;   // bf16 storage of the hidden / saved FFN tensors
     const long Pn = (long)B * fb.h * fb.w;
     RC(launch_transpose(P + pl->blk(st, j, B_W3), bb.w3t, e, n1, s));
     RC(launch_transpose(P + pl->blk(st, j, B_W2), bb.w2t, n1, n1, s));
@@ -66,18 +67,18 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
     fd.dy = dy; fd.g3 = fb.g3; fd.h2 = fb.h2; fd.dh2 = bb.dh2; fd.w3t = bb.w3t; fd.dww = P + pl->blk(st, j, B_DWW);
     fd.slab_w = bb.slab; fd.slab_b = bb.slab + ffn_dw_bwd_slab_floats(e, B, fb.h, fb.w) / 10 * 9;
     fd.d_dww = G + pl->blk(st, j, B_DWW); fd.d_dwb = G + pl->blk(st, j, B_DWB);
-    fd.B = B; fd.h = fb.h; fd.w = fb.w;
+    fd.B = B; fd.h = fb.h; fd.w = fb.w; fd.hbf = hbf;
     RC(launch_ffn_dw_bwd(e, fd, s));
-    RC(wgrad(dy, e, fb.a3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 0, bb.slab, s));
+    RC(wgrad(dy, e, fb.a3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 0, hbf, bb.slab, s));
     Ffn1BwdArgs f1;
     f1.dh2 = bb.dh2; f1.g1 = fb.g1; f1.x = fb.xmid; f1.dy = dy; f1.dh1 = bb.dh1; f1.y2 = bb.y2; f1.dx = tmp;
     f1.w2t = bb.w2t; f1.w1t = bb.w1t;
     f1.ln2g = P + pl->blk(st, j, B_LN2G); f1.ln2b = P + pl->blk(st, j, B_LN2B);
     f1.d_ln2g = G + pl->blk(st, j, B_LN2G); f1.d_ln2b = G + pl->blk(st, j, B_LN2B);
-    f1.P = Pn;
+    f1.P = Pn; f1.hbf = hbf;
     RC(launch_ffn1_bwd(e, f1, s));
-    RC(wgrad(bb.dh2, n1, fb.a1, n1, G + pl->blk(st, j, B_W2), n1, G + pl->blk(st, j, B_B2), Pn, n1, n1, n1, n1, 0, bb.slab, s));
-    RC(wgrad(bb.dh1, n1, bb.y2, e, G + pl->blk(st, j, B_W1), e, G + pl->blk(st, j, B_B1), Pn, n1, e, n1, e, 0, bb.slab, s));
+    RC(wgrad(bb.dh2, n1, fb.a1, n1, G + pl->blk(st, j, B_W2), n1, G + pl->blk(st, j, B_B2), Pn, n1, n1, n1, n1, hbf, hbf, bb.slab, s));
+    RC(wgrad(bb.dh1, n1, bb.y2, e, G + pl->blk(st, j, B_W1), e, G + pl->blk(st, j, B_B1), Pn, n1, e, n1, e, hbf, 0, bb.slab, s));
     return 0;
 }
 
@@ -117,9 +118,9 @@ static int mixer_half_bwd(const lg_plan* pl, const float* P, float* G, int st, i
     RC(launch_attn_bwd(e, at, s));
     const int grid = attn_bwd_grid(e, B, fb.h, fb.w);
     RC(launch_reduce_slab(bb.dpos_slab, grid, 1, 2 * 64 * 64, G + pl->blk(st, j, B_POS), 2 * 64 * 64, 1, 2 * 64 * 64, s));
-    RC(wgrad(dym, e, bb.cat, e, G + pl->blk(st, j, B_PROJW), e, G + pl->blk(st, j, B_PROJB), Pn, e, e, e, e, 0, bb.slab, s));
+    RC(wgrad(dym, e, bb.cat, e, G + pl->blk(st, j, B_PROJW), e, G + pl->blk(st, j, B_PROJB), Pn, e, e, e, e, 0, 0, bb.slab, s));
     const int y1ld = (hc + 15) / 16 * 16, dqld = (3 * hc + 15) / 16 * 16;
-    RC(wgrad(bb.dqkv, dqld, bb.y1, y1ld, G + pl->blk(st, j, B_QKVW), hc, G + pl->blk(st, j, B_QKVB), Pn, dqld, y1ld, 3 * hc, hc, 0,
+    RC(wgrad(bb.dqkv, dqld, bb.y1, y1ld, G + pl->blk(st, j, B_QKVW), hc, G + pl->blk(st, j, B_QKVB), Pn, dqld, y1ld, 3 * hc, hc, 0, 0,
              bb.slab, s));
     return 0;
 }
@@ -199,7 +200,7 @@ int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, c
     tb.dout = dout; tb.dx = A; tb.doutp = bb.doutp; tb.dz = bb.dzA; tb.w = P + pl->lgt(st, L_TAILW);
     tb.HW = c.H * c.W; tb.total = P0;
     RC(launch_tail_bwd(c.C, tb, s));
-    RC(wgrad(bb.doutp, 16, nb.blk[4].xout, E, G + pl->lgt(st, L_TAILW), E, G + pl->lgt(st, L_TAILB), P0, 16, E, c.C, E, 0, bb.slab, s));
+    RC(wgrad(bb.doutp, 16, nb.blk[4].xout, E, G + pl->lgt(st, L_TAILW), E, G + pl->lgt(st, L_TAILB), P0, 16, E, c.C, E, 0, 0, bb.slab, s));
     RC(block_bwd(pl, P, G, st, 4, nb.blk[4], bb, posT + 4 * 8192, A, Bf, Cf, B, flags, seed, s));
     RC(block_bwd(pl, P, G, st, 3, nb.blk[3], bb, posT + 3 * 8192, Cf, Bf, A, B, flags, seed, s));
     // up + fusion
@@ -208,10 +209,10 @@ int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, c
     ub.fw = P + pl->lgt(st, L_FUSEW); ub.upw = P + pl->lgt(st, L_UPW);
     ub.B = B; ub.H = c.H; ub.W = c.W;
     RC(launch_upfuse_bwd_a(E, ub, s));
-    RC(wgrad(A, E, nb.t_up, E, G + pl->lgt(st, L_FUSEW), 2 * E, G + pl->lgt(st, L_FUSEB), P0, E, E, E, E, 0, bb.slab, s));
-    RC(wgrad(A, E, nb.blk[1].xout, E, G + pl->lgt(st, L_FUSEW) + E, 2 * E, nullptr, P0, E, E, E, E, 0, bb.slab, s));
+    RC(wgrad(A, E, nb.t_up, E, G + pl->lgt(st, L_FUSEW), 2 * E, G + pl->lgt(st, L_FUSEB), P0, E, E, E, E, 0, 0, bb.slab, s));
+    RC(wgrad(A, E, nb.blk[1].xout, E, G + pl->lgt(st, L_FUSEW) + E, 2 * E, nullptr, P0, E, E, E, E, 0, 0, bb.slab, s));
     RC(launch_upfuse_bwd_b(E, ub, s));
-    RC(wgrad(bb.v, E, nb.blk[2].xout, 2 * E, G + pl->lgt(st, L_UPW), 2 * E, G + pl->lgt(st, L_UPB), P1, E, 2 * E, E, 2 * E, 0, bb.slab, s));
+    RC(wgrad(bb.v, E, nb.blk[2].xout, 2 * E, G + pl->lgt(st, L_UPW), 2 * E, G + pl->lgt(st, L_UPB), P1, E, 2 * E, E, 2 * E, 0, 0, bb.slab, s));
     // bottleneck
     RC(block_bwd(pl, P, G, st, 2, nb.blk[2], bb, posT + 2 * 8192, Bf, Cf, A, B, flags, seed, s));
     // down
@@ -219,7 +220,7 @@ int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, c
     db.dy = A; db.du = bb.du; db.dskip = bb.dskip; db.dx = Bf; db.w = P + pl->lgt(st, L_DOWNW);
     db.B = B; db.H = c.H; db.W = c.W;
     RC(launch_down_bwd_a(E, db, s));
-    RC(wgrad(A, 2 * E, nb.u_down, E, G + pl->lgt(st, L_DOWNW), E, G + pl->lgt(st, L_DOWNB), P1, 2 * E, E, 2 * E, E, 0, bb.slab, s));
+    RC(wgrad(A, 2 * E, nb.u_down, E, G + pl->lgt(st, L_DOWNW), E, G + pl->lgt(st, L_DOWNB), P1, 2 * E, E, 2 * E, E, 0, 0, bb.slab, s));
     RC(launch_down_bwd_b(E, db, s));
     // encoder
     RC(block_bwd(pl, P, G, st, 1, nb.blk[1], bb, posT + 1 * 8192, Bf, Cf, A, B, flags, seed, s));
@@ -233,7 +234,7 @@ int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, c
     eb.d_lng = G + pl->lgt(st, L_PE_LNG); eb.d_lnb = G + pl->lgt(st, L_PE_LNB);
     eb.HW = c.H * c.W; eb.total = P0;
     RC(launch_embed_bwd(c.C, eb, s));
-    RC(wgrad(bb.de, E, bb.tp, 16, G + pl->lgt(st, L_PE_W), c.C, G + pl->lgt(st, L_PE_B), P0, E, 16, E, c.C, 0, bb.slab, s));
+    RC(wgrad(bb.de, E, bb.tp, 16, G + pl->lgt(st, L_PE_W), c.C, G + pl->lgt(st, L_PE_B), P0, E, 16, E, c.C, 0, 0, bb.slab, s));
     }
     if (!do_data) return 0;
     // ---------------- K shared data steps, last to first (unlg_former.py:56-61); input gradient: bb.dzA

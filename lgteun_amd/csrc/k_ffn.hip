@@ -12,11 +12,12 @@
 #include "kernels.h"
 
 #include "mfma.h"
+#include "hstore.h"
 
 // ------------------------------------------------------------------------------------------------
 // k_ffn1: each wave owns MW = 16*MT pixels end to end (no inter-wave dependency)
 // ------------------------------------------------------------------------------------------------
-template <int E, int MT>
+template <int E, int MT, bool BF>
 __global__ __launch_bounds__(256) void k_ffn1(Ffn1Args a) {
     constexpr int N1 = 4 * E, MW = 16 * MT, LDA = E + 4, LDH = N1 + 4;
     constexpr int LPP = 64 / MW;       // lanes per pixel in the load/LN phase (2 or 4)
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void k_ffn1(Ffn1Args a) {
                     if (a.a1s) {
                         float av, gv;
                         gelu_both_f(h, av, gv);
-                        if (p0 + row < a.P) { a.a1s[(p0 + row) * N1 + col] = av; a.g1s[(p0 + row) * N1 + col] = gv; }
+                        if (p0 + row < a.P) { HS<BF>::st1(a.a1s, (p0 + row) * N1 + col, av); HS<BF>::st1(a.g1s, (p0 + row) * N1 + col, gv); }
                         bufH[row * LDH + col] = av;
                     } else {
                         bufH[row * LDH + col] = gelu_f(h);
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void k_ffn1(Ffn1Args a) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int row = mt * 16 + 4 * g + v;
-                    if (p0 + row < a.P) a.h2[(p0 + row) * N1 + col] = acc[mt][nt][v] + bias;
+                    if (p0 + row < a.P) HS<BF>::st1(a.h2, (p0 + row) * N1 + col, acc[mt][nt][v] + bias);
                 }
             }
     }
@@ -117,13 +118,15 @@ static int launch_ffn1_t(const Ffn1Args& a, hipStream_t s) {
     size_t lds = (size_t)4 * MW * ((E + 4) + (N1 + 4)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn1<E, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn1<E, MT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1<E, MT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn1: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
     long per_wg = 4L * MW;
     int grid = (int)((a.P + per_wg - 1) / per_wg);
-    k_ffn1<E, MT><<<grid, 256, lds, s>>>(a);
+    if (a.hbf) k_ffn1<E, MT, true><<<grid, 256, lds, s>>>(a);
+    else k_ffn1<E, MT, false><<<grid, 256, lds, s>>>(a);
     LG_CHECK_LAUNCH();
     return 0;
 }
@@ -139,7 +142,7 @@ int launch_ffn1(int e, const Ffn1Args& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // k_ffn2: workgroup = TY x TX pixel tile (M = TY*TX = 64*MT)
 // ------------------------------------------------------------------------------------------------
-template <int E, int MT, int TY, int TX>
+template <int E, int MT, int TY, int TX, bool BF>
 __global__ __launch_bounds__(256) void k_ffn2(Ffn2Args a, int tiles_x, int tiles_y) {
     constexpr int N1 = 4 * E, M = TY * TX, LDH = N1 + 4, LDO = E + 1, CQ = N1 / 4, NT3 = E / 16;
     static_assert(M == 64 * MT, "tile");
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void k_ffn2(Ffn2Args a, int tiles_x, int tiles
                     for (int dx = 0; dx < 3; ++dx) {
                         const int xx = x + dx - 1;
                         if (xx < 0 || xx >= a.w) continue;
-                        const float4 v = *reinterpret_cast<const float4*>(a.h2 + ((b * a.h + yy) * (long)a.w + xx) * N1 + 4 * q);
+                        const float4 v = HS<BF>::ld4(a.h2, ((b * a.h + yy) * (long)a.w + xx) * N1 + 4 * q);
                         acc.x += wq[0][dy * 3 + dx] * v.x;
                         acc.y += wq[1][dy * 3 + dx] * v.y;
                         acc.z += wq[2][dy * 3 + dx] * v.z;
@@ -189,8 +192,8 @@ __global__ __launch_bounds__(256) void k_ffn2(Ffn2Args a, int tiles_x, int tiles
                     gelu_both_f(acc.x, av.x, gv.x); gelu_both_f(acc.y, av.y, gv.y);
                     gelu_both_f(acc.z, av.z, gv.z); gelu_both_f(acc.w, av.w, gv.w);
                     const long o = ((b * a.h + y) * (long)a.w + x) * N1 + 4 * q;
-                    *reinterpret_cast<float4*>(a.a3s + o) = av;
-                    *reinterpret_cast<float4*>(a.g3s + o) = gv;
+                    HS<BF>::st4(a.a3s, o, av);
+                    HS<BF>::st4(a.g3s, o, gv);
                     acc = av;
                 } else {
                     acc = make_float4(gelu_f(acc.x), gelu_f(acc.y), gelu_f(acc.z), gelu_f(acc.w));
@@ -253,13 +256,15 @@ static int launch_ffn2_t(const Ffn2Args& a, hipStream_t s) {
     size_t lds = (size_t)(M * (N1 + 4) + M * (E + 1)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn2<E, MT, TY, TX>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn2<E, MT, TY, TX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn2<E, MT, TY, TX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn2: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
     int tiles_x = (a.w + TX - 1) / TX, tiles_y = (a.h + TY - 1) / TY;
     int grid = a.B * tiles_x * tiles_y;
-    k_ffn2<E, MT, TY, TX><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
+    if (a.hbf) k_ffn2<E, MT, TY, TX, true><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
+    else k_ffn2<E, MT, TY, TX, false><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
     LG_CHECK_LAUNCH();
     return 0;
 }
@@ -285,7 +290,7 @@ struct FfnFusedArgs {
     Ffn2Args a2;
 };
 
-template <int E, bool SAVE>
+template <int E, bool SAVE, bool BF>
 __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int tiles_x, int tiles_y, int ntiles) {
     constexpr int N1 = 4 * E, TY = 8, TX = 16, HX = TX + 2, HY = TY + 2, NH = HX * HY /*180*/, MH = 192, M = TY * TX;
     constexpr int LDA = E + 4, LDH = N1 + 4, LDO = E + 1, CQ = N1 / 4, NT3 = E / 16;
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
                     if (SAVE) {
                         float av, gv;
                         gelu_both_f(hh, av, gv);
-                        if (inner[v]) { a1.a1s[prow[v] * N1 + col] = av; a1.g1s[prow[v] * N1 + col] = gv; }
+                        if (inner[v]) { HS<BF>::st1(a1.a1s, prow[v] * N1 + col, av); HS<BF>::st1(a1.g1s, prow[v] * N1 + col, gv); }
                         my[(4 * g + v) * LDH + col] = av;
                     } else {
                         my[(4 * g + v) * LDH + col] = gelu_f(hh);
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
                 for (int v = 0; v < 4; ++v) {
                     const int m = row0 + 4 * g + v;
                     const float hh = inimg[v] ? acc[0][nt][v] + bias : 0.f;   // dep_conv zero-pads h2 (basic_module_unformer_v2.py:18)
-                    if (SAVE && inner[v]) a1.h2[prow[v] * N1 + col] = hh;
+                    if (SAVE && inner[v]) HS<BF>::st1(a1.h2, prow[v] * N1 + col, hh);
                     if (m < NH) bufH2[m * LDH + col] = hh;
                 }
             }
@@ -440,8 +445,8 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
                     gelu_both_f(acc.z, av.z, gv.z); gelu_both_f(acc.w, av.w, gv.w);
                     if (y < h && x < w) {
                         const long o = ((b * h + y) * (long)w + x) * N1 + 4 * q;
-                        *reinterpret_cast<float4*>(a2.a3s + o) = av;
-                        *reinterpret_cast<float4*>(a2.g3s + o) = gv;
+                        HS<BF>::st4(a2.a3s, o, av);
+                        HS<BF>::st4(a2.g3s, o, gv);
                     }
                 } else {
                     av = make_float4(gelu_f(acc.x), gelu_f(acc.y), gelu_f(acc.z), gelu_f(acc.w));
@@ -503,8 +508,9 @@ static int launch_ffn_fused_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_
     size_t lds = (size_t)(192 * (E + 4) + 180 * (N1 + 4) + 4 * 16 * (N1 + 4)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_fused<E, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_fused<E, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_fused<E, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_fused<E, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_fused<E, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn_fused: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
@@ -512,8 +518,9 @@ static int launch_ffn_fused_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_
     const int ntiles = a2.B * tiles_x * tiles_y;
     const int grid = ntiles < 512 ? ntiles : 512;   // persistent: 2 resident workgroups per CU walk the tiles, weights stay in registers
     const bool save = a1.a1s != nullptr;   // forward of the live stage: keep gelu / gelu' / h2 for the backward
-    if (save) k_ffn_fused<E, true><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y, ntiles);
-    else k_ffn_fused<E, false><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y, ntiles);
+    if (save && a1.hbf) k_ffn_fused<E, true, true><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y, ntiles);
+    else if (save) k_ffn_fused<E, true, false><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y, ntiles);
+    else k_ffn_fused<E, false, false><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y, ntiles);   // nothing stored: storage type irrelevant
     LG_CHECK_LAUNCH();
     return 0;
 }

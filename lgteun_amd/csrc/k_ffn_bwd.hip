@@ -9,6 +9,7 @@
 #include "kernels.h"
 #include "bwd_kernels.h"
 #include "mfma.h"
+#include "hstore.h"
 
 __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
     long n = (long)rows * cols;
@@ -28,7 +29,7 @@ int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream
 
 // ------------------------------------------------------------------------------------------------
 #define DW_TPW 8   // tiles walked by one workgroup (weight-gradient partials stay in registers across them)
-template <int E>
+template <int E, bool BF>
 __global__ __launch_bounds__(256) void k_ffn_dw_bwd(FfnDwBwdArgs a, int tiles_x, int tiles_y) {
     constexpr int N1 = 4 * E, TY = 8, TX = 16, HX = TX + 2, HY = TY + 2, NH = HX * HY, MH = 192, CG = 32, CQ = CG / 4;
     constexpr int LDY = E + 4, LDG = CG + 4;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void k_ffn_dw_bwd(FfnDwBwdArgs a, int tiles_x,
         const int hy = m / HX, hx = m - hy * HX;
         const int y = y0 + hy - 1, x = x0 + hx - 1;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y >= 0 && y < h && x >= 0 && x < w) v = *reinterpret_cast<const float4*>(a.h2 + ((b * h + y) * (long)w + x) * N1 + c0 + 4 * q);
+        if (y >= 0 && y < h && x >= 0 && x < w) v = HS<BF>::ld4(a.h2, ((b * h + y) * (long)w + x) * N1 + c0 + 4 * q);
         *reinterpret_cast<float4*>(bufH + m * LDG + 4 * q) = v;
     }
     __syncthreads();
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void k_ffn_dw_bwd(FfnDwBwdArgs a, int tiles_x,
         const int y = y0 + hy - 1, x = x0 + hx - 1;
         float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
         if (y >= 0 && y < h && x >= 0 && x < w) {
-            const float4 gv = *reinterpret_cast<const float4*>(a.g3 + ((b * h + y) * (long)w + x) * N1 + c0 + 4 * qq);
+            const float4 gv = HS<BF>::ld4(a.g3, ((b * h + y) * (long)w + x) * N1 + c0 + 4 * qq);
             const float4 t = *reinterpret_cast<const float4*>(bufG + m * LDG + 4 * qq);
             d = make_float4(t.x * gv.x, t.y * gv.y, t.z * gv.z, t.w * gv.w);
         }
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void k_ffn_dw_bwd(FfnDwBwdArgs a, int tiles_x,
                 pw[0][dy * 3 + dx] += gc.x * hv.x; pw[1][dy * 3 + dx] += gc.y * hv.y;
                 pw[2][dy * 3 + dx] += gc.z * hv.z; pw[3][dy * 3 + dx] += gc.w * hv.w;
             }
-        *reinterpret_cast<float4*>(a.dh2 + ((b * h + y) * (long)w + x) * N1 + c0 + 4 * q) = acc;
+        HS<BF>::st4(a.dh2, ((b * h + y) * (long)w + x) * N1 + c0 + 4 * q, acc);
     }
     }   // tiles of this workgroup
     const int tile_id = blockIdx.x;
@@ -164,11 +165,13 @@ static int launch_ffn_dw_bwd_t(const FfnDwBwdArgs& a, hipStream_t s) {
     const size_t lds = (size_t)(192 * (E + 4) + 2 * 180 * 36 + 4 * 8 * 40) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn_dw_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
-    k_ffn_dw_bwd<E><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
+    if (a.hbf) k_ffn_dw_bwd<E, true><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
+    else k_ffn_dw_bwd<E, false><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
     LG_CHECK_LAUNCH();
     int rc = launch_reduce_slab(a.slab_w, nwg, 4 * E, 9, a.d_dww, 9, 4 * E, 9, s);
     if (rc) return rc;
@@ -184,7 +187,7 @@ int launch_ffn_dw_bwd(int e, const FfnDwBwdArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int E, int MT>
+template <int E, int MT, bool BF>
 __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a, long nchunks) {
     constexpr int N1 = 4 * E, MW = 16 * MT, LDH = N1 + 4, LDO = E + 1, NTE = E / 16;
     constexpr bool RB = (E == 16);
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a, long nchunks) {
     for (int i = lane; i < MW * (N1 / 4); i += 64) {
         const int m = i / (N1 / 4), k4 = i - m * (N1 / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p0 + m < a.P) v = *reinterpret_cast<const float4*>(a.dh2 + (p0 + m) * N1 + 4 * k4);
+        if (p0 + m < a.P) v = HS<BF>::ld4(a.dh2, (p0 + m) * N1 + 4 * k4);
         *reinterpret_cast<float4*>(bufD + m * LDH + 4 * k4) = v;
     }
     __syncthreads();
@@ -235,10 +238,10 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a, long nchunks) {
         const int m = i / (N1 / 4), k4 = i - m * (N1 / 4);
         float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p0 + m < a.P) {
-            const float4 gv = *reinterpret_cast<const float4*>(a.g1 + (p0 + m) * N1 + 4 * k4);
+            const float4 gv = HS<BF>::ld4(a.g1, (p0 + m) * N1 + 4 * k4);
             const float4 t = *reinterpret_cast<const float4*>(bufD1 + m * LDH + 4 * k4);
             d = make_float4(t.x * gv.x, t.y * gv.y, t.z * gv.z, t.w * gv.w);
-            *reinterpret_cast<float4*>(a.dh1 + (p0 + m) * N1 + 4 * k4) = d;
+            HS<BF>::st4(a.dh1, (p0 + m) * N1 + 4 * k4, d);
         }
         *reinterpret_cast<float4*>(bufD1 + m * LDH + 4 * k4) = d;
     }
@@ -326,14 +329,16 @@ static int launch_ffn1_bwd_t(const Ffn1BwdArgs& a, hipStream_t s) {
     size_t lds = (size_t)4 * MW * (2 * (N1 + 4) + E + 1) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn1_bwd<E, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn1_bwd<E, MT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1_bwd<E, MT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn1_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
     long per_wg = 4L * MW;
     const long nchunks = (a.P + per_wg - 1) / per_wg;
     const int grid = (int)(nchunks < 1024 ? nchunks : 1024);   // persistent workgroups
-    k_ffn1_bwd<E, MT><<<grid, 256, lds, s>>>(a, nchunks);
+    if (a.hbf) k_ffn1_bwd<E, MT, true><<<grid, 256, lds, s>>>(a, nchunks);
+    else k_ffn1_bwd<E, MT, false><<<grid, 256, lds, s>>>(a, nchunks);
     LG_CHECK_LAUNCH();
     return 0;
 }

@@ -7,13 +7,12 @@
 // LDS and the workgroup's partial goes to a slab that a second kernel sums in a fixed slice order.
 #include "kernels.h"
 #include "bwd_kernels.h"
+#include "hstore.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int XF>
-__device__ __forceinline__ float xform(float v) { return XF == 1 ? gelu_f(v) : v; }
 
-template <int XF>
+template <bool YBF, bool XBF>
 __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a, int k_blocks, long px_per_wave, float* slab, float* bslab) {
     // Operand fetch: lane (r,g) loads ONE float4 of Y and ONE of X per 4-pixel step: Y[p+g][n0 + 4r .. 4r+3], X[p+g][k0 + 4r ..].
     // Element t of the float4 feeds MFMA tile t, so tile t owns the strided channel set {4r + t}: a 64-channel row is one
@@ -39,10 +38,9 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a, int k_blocks, long p
         const long row = p + g;
         const bool valid = row < p_end;
         float4 af = make_float4(0.f, 0.f, 0.f, 0.f), bf = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid && yok) af = *reinterpret_cast<const float4*>(a.Y + row * a.ldy + n0 + 4 * r);
+        if (valid && yok) af = HS<YBF>::ld4(a.Y, row * a.ldy + n0 + 4 * r);
         if (valid && xok) {
-            bf = *reinterpret_cast<const float4*>(a.X + row * a.ldx + k0 + 4 * r);
-            if (XF == 1) bf = make_float4(gelu_f(bf.x), gelu_f(bf.y), gelu_f(bf.z), gelu_f(bf.w));
+            bf = HS<XBF>::ld4(a.X, row * a.ldx + k0 + 4 * r);
         }
         bsum.x += af.x; bsum.y += af.y; bsum.z += af.z; bsum.w += af.w;
         const float av[4] = {af.x, af.y, af.z, af.w}, bv[4] = {bf.x, bf.y, bf.z, bf.w};
@@ -82,7 +80,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a, int k_blocks, long p
 }
 
 // narrow shapes (N or K < 64): scalar operand loads, only the needed 16x16 tiles are issued
-template <int XF>
+template <bool YBF, bool XBF>
 __global__ __launch_bounds__(256) void k_wgrad_narrow(WgradArgs a, int k_blocks, long px_per_wave, float* slab, float* bslab) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int nb = blockIdx.y / k_blocks, kb = blockIdx.y - nb * k_blocks;
@@ -106,8 +104,8 @@ __global__ __launch_bounds__(256) void k_wgrad_narrow(WgradArgs a, int k_blocks,
         float af[4], bf[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            af[t] = (valid && t < NT) ? a.Y[row * a.ldy + n0 + t * 16 + r] : 0.f;
-            bf[t] = (valid && t < KT) ? xform<XF>(a.X[row * a.ldx + k0 + t * 16 + r]) : 0.f;
+            af[t] = (valid && t < NT) ? HS<YBF>::ld1(a.Y, row * a.ldy + n0 + t * 16 + r) : 0.f;
+            bf[t] = (valid && t < KT) ? HS<XBF>::ld1(a.X, row * a.ldx + k0 + t * 16 + r) : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -221,13 +219,15 @@ int launch_wgrad(const WgradArgs& a, float* slab, hipStream_t s) {
     float* bslab = slab + splits * (long)a.N * a.K;
     dim3 grid((unsigned)splits, (unsigned)blocks);
     const bool wide = (a.N % 64 == 0) && (a.K % 64 == 0);
-    if (wide) {
-        if (a.xf == 1) k_wgrad<1><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);
-        else k_wgrad<0><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);
-    } else {
-        if (a.xf == 1) k_wgrad_narrow<1><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);
-        else k_wgrad_narrow<0><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);
-    }
+#define LG_WG(KERN)                                                                                            \
+    do {                                                                                                       \
+        if (a.ybf && a.xbf) KERN<true, true><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);               \
+        else if (a.ybf) KERN<true, false><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);                  \
+        else if (a.xbf) KERN<false, true><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);                  \
+        else KERN<false, false><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);                            \
+    } while (0)
+    if (wide) LG_WG(k_wgrad); else LG_WG(k_wgrad_narrow);
+#undef LG_WG
     LG_CHECK_LAUNCH();
     return launch_reduce_slab2(slab, splits, a.N, a.K, a.dW, a.ldw, a.n_valid, a.k_valid, a.db ? bslab : nullptr, a.N, a.db, a.n_valid, s);
 }

@@ -97,18 +97,20 @@ int launch_pos_transpose(const float* pos, float* posT, hipStream_t s);
 // ---------------- feed_forward, LGT.py:91-109 ----------------
 struct Ffn1Args {
     const float* x;  // [P, e]   (P = B*h*w)
-    float* a1s;      // optional save [P,4e]: gelu(h1)        (conv input of W2 for its weight gradient)
-    float* g1s;      // optional save [P,4e]: gelu'(h1)       (backward never re-evaluates GELU)
-    float* h2;       // [P,4e] = W2 gelu(W1 LN(x) + b1) + b2
+    void* a1s;       // optional save [P,4e]: gelu(h1)        (conv input of W2 for its weight gradient)
+    void* g1s;       // optional save [P,4e]: gelu'(h1)       (backward never re-evaluates GELU)
+    void* h2;        // [P,4e] = W2 gelu(W1 LN(x) + b1) + b2
+    int hbf;         // hidden storage: 0 fp32, 1 bf16 (hstore.h)
     const float *ln2g, *ln2b, *w1, *b1, *w2, *b2;
     long P;
 };
 int launch_ffn1(int e, const Ffn1Args& a, hipStream_t s);
 struct Ffn2Args {
-    const float* h2;  // [B,h,w,4e]
+    const void* h2;   // [B,h,w,4e]
     const float* x;   // [B,h,w,e] residual input
-    float* a3s;       // optional save [B,h,w,4e]: gelu(h3)
-    float* g3s;       // optional save [B,h,w,4e]: gelu'(h3)
+    void* a3s;        // optional save [B,h,w,4e]: gelu(h3)
+    void* g3s;        // optional save [B,h,w,4e]: gelu'(h3)
+    int hbf;          // hidden storage: 0 fp32, 1 bf16
     float* y;         // [B,h,w,e]
     float* g;         // optional [B,e/2,h,w] LN1(next block)(y) global half
     const float *dww, *dwb, *w3, *b3, *n1g, *n1b;

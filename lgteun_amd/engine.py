@@ -82,6 +82,7 @@ class Engine:
         self.C = int(module.in_channels)
         self.K = int(module.stage)
         self.module_mode = lambda: module.mode
+        self.module_precision = lambda: getattr(module, 'precision', 'fp32')
         names = canonical_names(self.C, self.K)
         params = dict(module.named_parameters())
         if set(names) != set(params):
@@ -140,9 +141,10 @@ class Engine:
             pass
 
     def plan(self, H, W):
-        key = (H, W)
+        prec = {'fp32': 0, 'bf16': 1}[self.module_precision()]
+        key = (H, W, prec)
         if key not in self._plans:
-            cfg = LgConfig(self.C, self.K, H, W, 0)
+            cfg = LgConfig(self.C, self.K, H, W, prec)
             arr = (ctypes.c_int64 * len(self.offsets))(*self.offsets)
             out = ctypes.c_void_p()
             check(self.lib.lg_plan_create(ctypes.byref(cfg), arr, len(self.offsets), ctypes.byref(out)), 'lg_plan_create')

@@ -97,6 +97,7 @@ class Pansharpening(nn.Module):
         self.prior_module = nn.ModuleList([_lgt(C, C * 4) for _ in range(stage)])
         # execution options (not part of the reference surface)
         self.mode = 'faithful'     # 'faithful': run all K LGTs like the reference; 'live': skip the dead ones
+        self.precision = 'fp32'    # 'fp32': parity mode; 'bf16': saved / hidden FFN activations of the backward stored as bf16
         self._engine = None
 
     # ---- engine plumbing ----------------------------------------------------------------------

@@ -28,7 +28,7 @@ class Ops:
         self.net = net
         self.eng = net.engine()
         self.lib = self.eng.lib
-        self.plan = self.eng.plan(H, W)
+        self.plan = self.eng.plan(H, W)   # precision follows net.precision
         self.H, self.W = H, W
 
     def ws(self, B, train=False):

@@ -190,3 +190,34 @@ def test_half_block_backward_256_split_fft(which):
         got = ops.grad_of(flat, k).cpu().numpy()
         ref = g.numpy()
         assert float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)) < 5e-3, k
+
+
+def test_bf16_saved_activations_mode(manifest):
+    """precision='bf16': the 4e-wide saved / hidden FFN tensors of the backward are stored as bf16 (fp32 arithmetic).
+    The forward is untouched (bitwise equal to fp32 mode); gradients carry bf16 rounding of those activations: global
+    relative L2 vs the reference's fp32 gradients < 1e-2, loss identical."""
+    from gpu_helpers import make_module
+    from lgteun_amd import FusedAdam
+    m = manifest['grad_c4_k2_p32']
+    g = load_gold('grad_c4_k2_p32')
+    ms, pan, gt = (T(a).cuda() for a in dw.make_inputs(m['B'], m['C'], m['h'], m['h'], seed=m['seed'], kind=m['kind']))
+    net = make_module(m['C'], m['K'])
+    with torch.no_grad():
+        y32 = net(ms, pan)
+    net.precision = 'bf16'
+    with torch.no_grad():
+        y16 = net(ms, pan)
+    assert torch.equal(y32, y16)
+    opt = FusedAdam(net.parameters(), lr=0.0)
+    opt.dropout = False
+    eng = net.engine()
+    loss = float(eng.train_step(ms, pan, gt, opt).item())
+    assert abs(loss - float(g['loss'])) < 2e-5
+    num = den = 0.0
+    for i in eng.live_idx:
+        n, o, p = eng.names[i], eng.offsets[i], eng.params[i]
+        got = eng.gflat[o:o + p.numel()].view(p.shape).cpu().numpy()
+        ref = g[n.replace('.', '/')]
+        num += float(((got - ref) ** 2).sum())
+        den += float((ref ** 2).sum())
+    assert (num / den) ** 0.5 < 1e-2, (num / den) ** 0.5
