@@ -28,10 +28,11 @@ int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream
 }
 
 // ------------------------------------------------------------------------------------------------
+#define DW_CG 32   // channels per workgroup (depthwise work is per channel); 16 (3 workgroups per CU) measured no faster
 #define DW_TPW 8   // tiles walked by one workgroup (weight-gradient partials stay in registers across them)
-template <int E, bool BF>
+template <int E, bool BF, int CG>
 __global__ __launch_bounds__(256) void k_ffn_dw_bwd(FfnDwBwdArgs a, int tiles_x, int tiles_y) {
-    constexpr int N1 = 4 * E, TY = 8, TX = 16, HX = TX + 2, HY = TY + 2, NH = HX * HY, MH = 192, CG = 32, CQ = CG / 4;
+    constexpr int N1 = 4 * E, TY = 8, TX = 16, HX = TX + 2, HY = TY + 2, NH = HX * HY, MH = 192, CQ = CG / 4, NTG = CG / 16;
     constexpr int LDY = E + 4, LDG = CG + 4;
     extern __shared__ float smem[];
     float* bufY = smem;                  // [MH][LDY] dy on the halo tile
@@ -70,46 +71,56 @@ __global__ __launch_bounds__(256) void k_ffn_dw_bwd(FfnDwBwdArgs a, int tiles_x,
         if (m < NH && y >= 0 && y < h && x >= 0 && x < w) v = *reinterpret_cast<const float4*>(a.dy + ((b * h + y) * (long)w + x) * E + 4 * k4);
         *reinterpret_cast<float4*>(bufY + m * LDY + 4 * k4) = v;
     }
-    for (int i = threadIdx.x; i < NH * CQ; i += 256) {
-        const int m = i / CQ, q = i - m * CQ;
-        const int hy = m / HX, hx = m - hy * HX;
-        const int y = y0 + hy - 1, x = x0 + hx - 1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y >= 0 && y < h && x >= 0 && x < w) v = HS<BF>::ld4(a.h2, ((b * h + y) * (long)w + x) * N1 + c0 + 4 * q);
-        *reinterpret_cast<float4*>(bufH + m * LDG + 4 * q) = v;
+    // h2 and g3 of the halo tile are requested together (one exposed HBM round trip per tile instead of two);
+    // g3 waits in registers until the GEMM result is in LDS
+    constexpr int NG3 = (NH * CQ + 255) / 256;
+    float4 g3r[NG3];
+#pragma unroll
+    for (int it = 0; it < NG3; ++it) {
+        const int i = threadIdx.x + it * 256;
+        g3r[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < NH * CQ) {
+            const int m = i / CQ, qq = i - m * CQ;
+            const int hy = m / HX, hx = m - hy * HX;
+            const int y = y0 + hy - 1, x = x0 + hx - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < h && x >= 0 && x < w) {
+                const long o = ((b * h + y) * (long)w + x) * N1 + c0 + 4 * qq;
+                v = HS<BF>::ld4(a.h2, o);
+                g3r[it] = HS<BF>::ld4(a.g3, o);
+            }
+            *reinterpret_cast<float4*>(bufH + m * LDG + 4 * qq) = v;
+        }
     }
     __syncthreads();
     // ---- P1: dh3 = (dy W3)[:, c0:c0+32] * g3 on the halo tile; wave owns 48 rows (3 m-tiles) x 2 n-tiles
     {
-        f32x4 acc[3][2];
+        f32x4 acc[3][NTG];
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        wave_gemm<3, 2, E>(acc, bufY + wave * 48 * LDY, LDY, a.w3t + (size_t)c0 * E);
+            for (int nt = 0; nt < NTG; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        wave_gemm<3, NTG, E>(acc, bufY + wave * 48 * LDY, LDY, a.w3t + (size_t)c0 * E);
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int m = wave * 48 + mt * 16 + 4 * g + v;
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < NTG; ++nt)
                     if (m < NH) bufG[m * LDG + nt * 16 + r] = acc[mt][nt][v];
             }
     }
     __syncthreads();
-    // dh3 *= g3 (0 outside the image): coalesced 16-byte loads of the saved gelu'(h3)
-    for (int i = threadIdx.x; i < NH * CQ; i += 256) {
-        const int m = i / CQ, qq = i - m * CQ;
-        const int hy = m / HX, hx = m - hy * HX;
-        const int y = y0 + hy - 1, x = x0 + hx - 1;
-        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y >= 0 && y < h && x >= 0 && x < w) {
-            const float4 gv = HS<BF>::ld4(a.g3, ((b * h + y) * (long)w + x) * N1 + c0 + 4 * qq);
+    // dh3 *= g3 (g3 is 0 outside the image)
+#pragma unroll
+    for (int it = 0; it < NG3; ++it) {
+        const int i = threadIdx.x + it * 256;
+        if (i < NH * CQ) {
+            const int m = i / CQ, qq = i - m * CQ;
             const float4 t = *reinterpret_cast<const float4*>(bufG + m * LDG + 4 * qq);
-            d = make_float4(t.x * gv.x, t.y * gv.y, t.z * gv.z, t.w * gv.w);
+            *reinterpret_cast<float4*>(bufG + m * LDG + 4 * qq) = make_float4(t.x * g3r[it].x, t.y * g3r[it].y, t.z * g3r[it].z, t.w * g3r[it].w);
         }
-        *reinterpret_cast<float4*>(bufG + m * LDG + 4 * qq) = d;
     }
     __syncthreads();
     // ---- P2: dh2 = dw^T dh3 and the depthwise weight/bias gradient partials; thread <-> (pixel, channel quad)
@@ -161,17 +172,18 @@ static int launch_ffn_dw_bwd_t(const FfnDwBwdArgs& a, hipStream_t s) {
     ProfScope prof__(LG_K_FFN2_BWD, s);
     int tiles_x = (a.w + 15) / 16, tiles_y = (a.h + 7) / 8;
     const long nwg = ((long)a.B * tiles_x * tiles_y + DW_TPW - 1) / DW_TPW;
-    dim3 grid((unsigned)nwg, 4 * E / 32);
-    const size_t lds = (size_t)(192 * (E + 4) + 2 * 180 * 36 + 4 * 8 * 40) * sizeof(float);
+    dim3 grid((unsigned)nwg, 4 * E / DW_CG);
+    constexpr int CG = DW_CG;
+    const size_t lds = (size_t)(192 * (E + 4) + 2 * 180 * (CG + 4) + 4 * (CG / 4) * 40) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, false, CG>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, true, CG>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn_dw_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
-    if (a.hbf) k_ffn_dw_bwd<E, true><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
-    else k_ffn_dw_bwd<E, false><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
+    if (a.hbf) k_ffn_dw_bwd<E, true, CG><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
+    else k_ffn_dw_bwd<E, false, CG><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
     LG_CHECK_LAUNCH();
     int rc = launch_reduce_slab(a.slab_w, nwg, 4 * E, 9, a.d_dww, 9, 4 * E, 9, s);
     if (rc) return rc;
@@ -207,11 +219,30 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a, long nchunks) {
     for (long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const long p0 = (chunk * 4 + wave) * MW;
     __syncthreads();
-    for (int i = lane; i < MW * (N1 / 4); i += 64) {
+    // all global operands of the chunk are requested up front (one exposed HBM round trip per chunk): dh2 -> LDS,
+    // g1 and the LayerNorm-phase rows (x, dy of pixel `lane`) wait in registers
+    constexpr int NR = MW * (N1 / 4) / 64;
+    float4 g1r[NR];
+#pragma unroll
+    for (int it = 0; it < NR; ++it) {
+        const int i = lane + it * 64;
         const int m = i / (N1 / 4), k4 = i - m * (N1 / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p0 + m < a.P) v = HS<BF>::ld4(a.dh2, (p0 + m) * N1 + 4 * k4);
+        g1r[it] = v;
+        if (p0 + m < a.P) {
+            v = HS<BF>::ld4(a.dh2, (p0 + m) * N1 + 4 * k4);
+            g1r[it] = HS<BF>::ld4(a.g1, (p0 + m) * N1 + 4 * k4);
+        }
         *reinterpret_cast<float4*>(bufD + m * LDH + 4 * k4) = v;
+    }
+    float4 xr[E / 4], dyr[E / 4];
+    {
+        const bool pv = lane < MW && p0 + lane < a.P;
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k) {
+            xr[k] = pv ? reinterpret_cast<const float4*>(a.x + (p0 + lane) * E)[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            dyr[k] = pv ? reinterpret_cast<const float4*>(a.dy + (p0 + lane) * E)[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     __syncthreads();
     // ---- dh1 = (dh2 W2) * g1
@@ -233,16 +264,14 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a, long nchunks) {
             }
     }
     __syncthreads();
-    // dh1 = (dh2 W2) * g1 : coalesced 16-byte pass over the wave's rows (g1 in, dh1 out), result kept in LDS for the next GEMM
-    for (int i = lane; i < MW * (N1 / 4); i += 64) {
+    // dh1 = (dh2 W2) * g1 : coalesced 16-byte pass over the wave's rows (dh1 out), result kept in LDS for the next GEMM
+#pragma unroll
+    for (int it = 0; it < NR; ++it) {
+        const int i = lane + it * 64;
         const int m = i / (N1 / 4), k4 = i - m * (N1 / 4);
-        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p0 + m < a.P) {
-            const float4 gv = HS<BF>::ld4(a.g1, (p0 + m) * N1 + 4 * k4);
-            const float4 t = *reinterpret_cast<const float4*>(bufD1 + m * LDH + 4 * k4);
-            d = make_float4(t.x * gv.x, t.y * gv.y, t.z * gv.z, t.w * gv.w);
-            HS<BF>::st4(a.dh1, (p0 + m) * N1 + 4 * k4, d);
-        }
+        const float4 t = *reinterpret_cast<const float4*>(bufD1 + m * LDH + 4 * k4);
+        const float4 d = make_float4(t.x * g1r[it].x, t.y * g1r[it].y, t.z * g1r[it].z, t.w * g1r[it].w);
+        if (p0 + m < a.P) HS<BF>::st4(a.dh1, (p0 + m) * N1 + 4 * k4, d);
         *reinterpret_cast<float4*>(bufD1 + m * LDH + 4 * k4) = d;
     }
     __syncthreads();
@@ -267,12 +296,8 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a, long nchunks) {
         const int m = lane;
         const long p = p0 + m;
         float xv[E];
-        const float4* xs = reinterpret_cast<const float4*>(a.x + p * E);
 #pragma unroll
-        for (int k = 0; k < E / 4; ++k) {
-            float4 v = xs[k];
-            xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
-        }
+        for (int k = 0; k < E / 4; ++k) { xv[4 * k] = xr[k].x; xv[4 * k + 1] = xr[k].y; xv[4 * k + 2] = xr[k].z; xv[4 * k + 3] = xr[k].w; }
         float mu, rstd;
         ln_stats<E>(xv, mu, rstd);
         float m1 = 0.f, m2 = 0.f;
@@ -290,12 +315,11 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a, long nchunks) {
         }
         m1 *= (1.0f / E);
         m2 *= (1.0f / E);
-        const float4* dys = reinterpret_cast<const float4*>(a.dy + p * E);
         float4* dxo = reinterpret_cast<float4*>(a.dx + p * E);
         float4* y2o = reinterpret_cast<float4*>(a.y2 + p * E);
 #pragma unroll
         for (int k = 0; k < E / 4; ++k) {
-            float4 dv = dys[k];
+            const float4 dv = dyr[k];
             float o[4], yv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {

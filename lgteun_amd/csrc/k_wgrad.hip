@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void k_wgrad_narrow(WgradArgs a, int k_blocks,
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll 4
     for (long p = p_begin; p < p_end; p += 4) {
         const long row = p + g;
         const bool valid = row < p_end;
