@@ -66,6 +66,15 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
         }
         __syncthreads();
         if (active) {
+            // operands of the epilogue (FFT-mixer half, residual x) are requested now so their HBM latency hides under the softmax
+            float o2[HC];
+            const long hw = (long)a.h * a.w;
+            const long s = (long)y * a.w + x;
+#pragma unroll
+            for (int c = 0; c < HC; ++c) o2[c] = a.o2[(b * HC + c) * hw + s];
+            float4 xres[E / 4];
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) xres[k] = reinterpret_cast<const float4*>(a.x + p * E)[k];
             float o1[HC];
 #pragma unroll
             for (int hd = 0; hd < 2; ++hd) {
@@ -104,14 +113,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
 #pragma unroll
                 for (int c = 0; c < D; ++c) o1[hd * D + c] = acc[c] * inv;
             }
-            // global-mixer half of the concat (planar)
-            float o2[HC];
-            const long hw = (long)a.h * a.w;
-            const long s = (long)y * a.w + x;
-#pragma unroll
-            for (int c = 0; c < HC; ++c) o2[c] = a.o2[(b * HC + c) * hw + s];
             // proj (E x E), dropout, residual -- in chunks of 4 outputs
-            const float4* xs = reinterpret_cast<const float4*>(a.x + p * E);
             float4* yo = reinterpret_cast<float4*>(a.y + p * E);
 #pragma unroll
             for (int n4 = 0; n4 < E / 4; ++n4) {
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
                     if (a.dropout) v *= dropout_scale(a.seed, (uint64_t)(p * E + n));
                     o[u] = v;
                 }
-                float4 xr = xs[n4];
+                const float4 xr = xres[n4];
                 yo[n4] = make_float4(xr.x + o[0], xr.y + o[1], xr.z + o[2], xr.w + o[3]);
             }
         }
