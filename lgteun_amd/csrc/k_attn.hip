@@ -22,6 +22,27 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
     const float scale = (float)(1.0 / sqrt((double)D));
     float* myK = sK + wave * 64 * HC;
     float* myV = sV + wave * 64 * HC;
+    // pixel of this lane in window `win` (row-major windows, row-major tokens)
+    auto pixel_of = [&](int win, long& b, int& y, int& x) -> long {
+        const int wx = win % nwx;
+        const int r = win / nwx;
+        const int wy = r % nwy;
+        b = r / nwy;
+        y = wy * 8 + (lane >> 3);
+        x = wx * 8 + (lane & 7);
+        return (b * a.h + y) * (long)a.w + x;
+    };
+    // software prefetch: the x row of the NEXT quad's window is requested while the current window is processed
+    float4 xpre[E / 4];
+    {
+        const int win0 = blockIdx.x * 4 + wave;
+        if (blockIdx.x < nquads && win0 < nwin) {
+            long b0; int y0, x0;
+            const long p0 = pixel_of(win0, b0, y0, x0);
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) xpre[k] = reinterpret_cast<const float4*>(a.x + p0 * E)[k];
+        }
+    }
     for (int quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
         const int win = quad * 4 + wave;
         const bool active = win < nwin;
@@ -30,19 +51,18 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
         float q[HC];
         __syncthreads();  // previous iteration's readers of sK/sV are done; sPos is loaded
         if (active) {
-            int wx = win % nwx;
-            int r = win / nwx;
-            int wy = r % nwy;
-            b = r / nwy;
-            y = wy * 8 + (lane >> 3);
-            x = wx * 8 + (lane & 7);
-            p = (b * a.h + y) * (long)a.w + x;
+            p = pixel_of(win, b, y, x);
             float xv[E];
-            const float4* src = reinterpret_cast<const float4*>(a.x + p * E);
 #pragma unroll
-            for (int k = 0; k < E / 4; ++k) {
-                float4 v = src[k];
-                xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
+            for (int k = 0; k < E / 4; ++k) { xv[4 * k] = xpre[k].x; xv[4 * k + 1] = xpre[k].y; xv[4 * k + 2] = xpre[k].z; xv[4 * k + 3] = xpre[k].w; }
+            {
+                const int wnext = (quad + (int)gridDim.x) * 4 + wave;
+                if (quad + (int)gridDim.x < nquads && wnext < nwin) {
+                    long bn; int yn, xn;
+                    const long pn = pixel_of(wnext, bn, yn, xn);
+#pragma unroll
+                    for (int k = 0; k < E / 4; ++k) xpre[k] = reinterpret_cast<const float4*>(a.x + pn * E)[k];
+                }
             }
             float mu, rstd;
             ln_stats<E>(xv, mu, rstd);
