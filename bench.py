@@ -179,6 +179,22 @@ def main():
     tot_ms, n_l = ctypes.c_double(), ctypes.c_int64()
     _lib.check(L.lg_prof_read(ctypes.byref(tot_ms), ctypes.byref(n_l)), 'lg_prof_read')
     L.lg_prof_disable()
+    # side measurement (NOT `value`): the same train step with the K-1 dead LGT forwards skipped -- bit-identical outputs,
+    # gradients and weights (tests/test_gpu_fullsize.py), i.e. what a user of this framework can run instead
+    live = None
+    if args.mode == 'faithful' and world == 1:
+        net.mode = 'live'
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_live = max(5, args.steps // 2)
+        for _ in range(n_live):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / n_live
+        live = dict(value=round(B_PER_GPU / dt, 2), ms_per_step=round(dt * 1e3, 3), note='dead-stage LGT forwards skipped; identical results')
+        net.mode = args.mode
     loss = float(eng._loss.item()) * world if world == 1 else None
 
     if rank == 0:
@@ -207,6 +223,8 @@ def main():
                    roofline=roof)
         if loss is not None:
             out['final_loss'] = round(loss, 6)
+        if live is not None:
+            out['live_mode'] = live
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(host_cores())
         print(json.dumps(out), flush=True)

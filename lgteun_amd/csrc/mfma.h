@@ -15,15 +15,18 @@ __device__ __forceinline__ void wave_gemm(f32x4 (&acc)[MT][NT], const float* A, 
         for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const float4*>(A + (mt * 16 + r) * lda + k0 + 4 * g);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float4*>(Wg + (size_t)(nt * 16 + r) * K + k0 + 4 * g);
+        // k sub-step outermost: consecutive MFMAs hit different accumulators (the 16x16x4 f32 MFMA has a 40-cycle dependent
+        // latency against a 32-cycle issue interval)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, bv[nt].x, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].y, bv[nt].y, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].z, bv[nt].z, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].w, bv[nt].w, acc[mt][nt], 0, 0, 0);
-            }
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float a_ = ks == 0 ? av[mt].x : (ks == 1 ? av[mt].y : (ks == 2 ? av[mt].z : av[mt].w));
+                    const float b_ = ks == 0 ? bv[nt].x : (ks == 1 ? bv[nt].y : (ks == 2 ? bv[nt].z : bv[nt].w));
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, acc[mt][nt], 0, 0, 0);
+                }
     }
 }
 
@@ -46,13 +49,14 @@ __device__ __forceinline__ void wave_gemm_rb(f32x4 (&acc)[MT][NT], const float* 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const float4*>(A + (mt * 16 + r) * lda + kb * 16 + 4 * g);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, bf[nt][kb].x, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].y, bf[nt][kb].y, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].z, bf[nt][kb].z, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].w, bf[nt][kb].w, acc[mt][nt], 0, 0, 0);
-            }
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float a_ = ks == 0 ? av[mt].x : (ks == 1 ? av[mt].y : (ks == 2 ? av[mt].z : av[mt].w));
+                    const float b_ = ks == 0 ? bf[nt][kb].x : (ks == 1 ? bf[nt][kb].y : (ks == 2 ? bf[nt][kb].z : bf[nt][kb].w));
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, acc[mt][nt], 0, 0, 0);
+                }
     }
 }
