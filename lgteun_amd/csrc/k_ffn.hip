@@ -525,8 +525,269 @@ static int launch_ffn_fused_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_ffn_fused_bf: throughput-mode variant of k_ffn_fused (lg_config.precision = 1): the three 1x1-conv GEMMs run on the
+// bf16 matrix cores (v_mfma_f32_16x16x32_bf16 / 16x16x16 for K = 16) with fp32 accumulation; their LDS operand tiles
+// (LN(x), gelu(h1) chunk, gelu(dw(h2)) chunk) are bf16; LayerNorm, bias, GELU, the h2 tile, the depthwise 3x3, the
+// residual and everything the backward saves are computed in fp32.  Weights stay fp32 in HBM and are converted to bf16
+// B fragments once per (persistent) workgroup.  Same tiling / phases as the fp32 kernel.
+// ------------------------------------------------------------------------------------------------
+template <int E, bool SAVE, bool BF>
+__global__ __launch_bounds__(256) void k_ffn_fused_bf(Ffn1Args a1, Ffn2Args a2, int tiles_x, int tiles_y, int ntiles) {
+    constexpr int N1 = 4 * E, TY = 8, TX = 16, HX = TX + 2, HY = TY + 2, NH = HX * HY /*180*/, MH = 192, M = TY * TX;
+    constexpr int LDA = E + 8, LDS16 = N1 + 8 /* halves */, LDH = N1 + 4, LDO = E + 1, CQ = N1 / 4, NT3 = E / 16;
+    constexpr int KB2 = N1 / 32;   // 32-deep k blocks of GEMM2 / GEMM3
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* bufH2 = smem;                                   // [NH][LDH] fp32  h2 on the halo tile (0 outside the image)
+    float* bufO = bufH2 + NH * LDH;                        // [M][LDO]  fp32  output tile
+    __bf16* bufA = reinterpret_cast<__bf16*>(bufO + M * LDO + 3);   // [MH][LDA] bf16 LN2(x) on the halo tile (16-byte aligned below)
+    bufA = reinterpret_cast<__bf16*>((reinterpret_cast<uintptr_t>(bufA) + 15) & ~(uintptr_t)15);
+    __bf16* scr = bufA + MH * LDA;                         // [4][16][LDS16] bf16 per-wave chunk
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    __bf16* my = scr + wave * 16 * LDS16;
+    const int h = a2.h, w = a2.w;
+    // B fragments (bf16) for the whole life of the workgroup
+    s16x4 w1k16[4];
+    bf16x8 w2f[4][KB2], w3f[NT3][KB2];
+    if constexpr (E == 16) {
+        load_bfrag_bf16_k16<4>(w1k16, a1.w1);
+        load_bfrag_bf16<4, KB2>(w2f, a1.w2, N1);
+        load_bfrag_bf16<NT3, KB2>(w3f, a2.w3, N1);
+    }
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int tx_i = t % tiles_x;
+    t /= tiles_x;
+    const int ty_i = t % tiles_y;
+    const long b = t / tiles_y;
+    const int y0 = ty_i * TY, x0 = tx_i * TX;
+    __syncthreads();
+    // ---- P0: halo tile load + LayerNorm (fp32) -> bf16 rows
+    if (threadIdx.x < MH) {
+        const int m = threadIdx.x;
+        const int hy = m / HX, hx = m - hy * HX;
+        const int y = y0 + hy - 1, x = x0 + hx - 1;
+        float xv[E];
+        const bool in = (m < NH) && y >= 0 && y < h && x >= 0 && x < w;
+        if (in) {
+            const float4* src = reinterpret_cast<const float4*>(a1.x + ((b * h + y) * (long)w + x) * E);
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) {
+                float4 v = src[k];
+                xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
+            }
+            float mu, rstd;
+            ln_stats<E>(xv, mu, rstd);
+#pragma unroll
+            for (int c = 0; c < E; ++c) xv[c] = (xv[c] - mu) * rstd * a1.ln2g[c] + a1.ln2b[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < E; ++c) xv[c] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k) {
+            const bf16x4 hv = (bf16x4){(__bf16)xv[4 * k], (__bf16)xv[4 * k + 1], (__bf16)xv[4 * k + 2], (__bf16)xv[4 * k + 3]};
+            *reinterpret_cast<bf16x4*>(bufA + m * LDA + 4 * k) = hv;
+        }
+    }
+    __syncthreads();
+    // ---- P1: per wave, 3 chunks of 16 halo pixels: GEMM1 -> GELU -> GEMM2 -> h2 tile
+    for (int ch = 0; ch < 3; ++ch) {
+        const int row0 = (wave * 3 + ch) * 16;
+        long prow[4];
+        bool inner[4], inimg[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int m = row0 + 4 * g + v;
+            const int hy = m / HX, hx = m - hy * HX;
+            const int y = y0 + hy - 1, x = x0 + hx - 1;
+            inimg[v] = (m < NH) && y >= 0 && y < h && x >= 0 && x < w;
+            inner[v] = inimg[v] && hy >= 1 && hy <= TY && hx >= 1 && hx <= TX;
+            prow[v] = (b * h + y) * (long)w + x;
+        }
+        for (int nc = 0; nc < N1; nc += 64) {
+            f32x4 acc[1][4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (E == 16) {
+                wave_gemm_bf_k16<1, 4>(acc, bufA + row0 * LDA, LDA, w1k16);
+            } else {
+                constexpr int KB1 = E / 32;
+                bf16x8 wf[4][KB1];
+                load_bfrag_bf16<4, KB1>(wf, a1.w1 + (size_t)nc * E, E);
+                wave_gemm_bf<1, 4, KB1>(acc, bufA + row0 * LDA, LDA, wf);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int col = nc + nt * 16 + r;
+                const float bias = a1.b1[col];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float hh = acc[0][nt][v] + bias;
+                    float av;
+                    if (SAVE) {
+                        float gv;
+                        gelu_both_f(hh, av, gv);
+                        if (inner[v]) { HS<BF>::st1(a1.a1s, prow[v] * N1 + col, av); HS<BF>::st1(a1.g1s, prow[v] * N1 + col, gv); }
+                    } else {
+                        av = gelu_f(hh);
+                    }
+                    my[(4 * g + v) * LDS16 + col] = (__bf16)av;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int nc = 0; nc < N1; nc += 64) {
+            f32x4 acc[1][4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (E == 16) {
+                wave_gemm_bf<1, 4, KB2>(acc, my, LDS16, w2f);
+            } else {
+                bf16x8 wf[4][KB2];
+                load_bfrag_bf16<4, KB2>(wf, a1.w2 + (size_t)nc * N1, N1);
+                wave_gemm_bf<1, 4, KB2>(acc, my, LDS16, wf);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int col = nc + nt * 16 + r;
+                const float bias = a1.b2[col];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int m = row0 + 4 * g + v;
+                    const float hh = inimg[v] ? acc[0][nt][v] + bias : 0.f;   // dep_conv zero-pads h2 (basic_module_unformer_v2.py:18)
+                    if (SAVE && inner[v]) HS<BF>::st1(a1.h2, prow[v] * N1 + col, hh);
+                    if (m < NH) bufH2[m * LDH + col] = hh;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // ---- P2: per wave, 2 chunks of 16 inner pixels: dw3x3 + GELU (fp32) -> bf16 scratch -> GEMM3 -> output tile
+    {
+        const int q = lane % CQ;
+        float wq[4][9], bq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wq[u][k] = a2.dww[(4 * q + u) * 9 + k];
+            bq[u] = a2.dwb[4 * q + u];
+        }
+        for (int ch = 0; ch < 2; ++ch) {
+            const int m0 = (wave * 2 + ch) * 16;
+            for (int mm = lane / CQ; mm < 16; mm += 64 / CQ) {
+                const int m = m0 + mm;
+                const int ty = m / TX, tx = m - ty * TX;
+                float4 acc = make_float4(bq[0], bq[1], bq[2], bq[3]);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float4 v = *reinterpret_cast<const float4*>(bufH2 + ((ty + dy) * HX + tx + dx) * LDH + 4 * q);
+                        acc.x += wq[0][dy * 3 + dx] * v.x; acc.y += wq[1][dy * 3 + dx] * v.y;
+                        acc.z += wq[2][dy * 3 + dx] * v.z; acc.w += wq[3][dy * 3 + dx] * v.w;
+                    }
+                const int y = y0 + ty, x = x0 + tx;
+                float4 av;
+                if (SAVE) {
+                    float4 gv;
+                    gelu_both_f(acc.x, av.x, gv.x); gelu_both_f(acc.y, av.y, gv.y);
+                    gelu_both_f(acc.z, av.z, gv.z); gelu_both_f(acc.w, av.w, gv.w);
+                    if (y < h && x < w) {
+                        const long o = ((b * h + y) * (long)w + x) * N1 + 4 * q;
+                        HS<BF>::st4(a2.a3s, o, av);
+                        HS<BF>::st4(a2.g3s, o, gv);
+                    }
+                } else {
+                    av = make_float4(gelu_f(acc.x), gelu_f(acc.y), gelu_f(acc.z), gelu_f(acc.w));
+                }
+                *reinterpret_cast<bf16x4*>(my + mm * LDS16 + 4 * q) = (bf16x4){(__bf16)av.x, (__bf16)av.y, (__bf16)av.z, (__bf16)av.w};
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            f32x4 acc3[1][NT3];
+#pragma unroll
+            for (int nt = 0; nt < NT3; ++nt) acc3[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (E == 16) {
+                wave_gemm_bf<1, NT3, KB2>(acc3, my, LDS16, w3f);
+            } else {
+                bf16x8 wf[NT3][KB2];
+                load_bfrag_bf16<NT3, KB2>(wf, a2.w3, N1);
+                wave_gemm_bf<1, NT3, KB2>(acc3, my, LDS16, wf);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT3; ++nt) {
+                const int col = nt * 16 + r;
+                const float bias = a2.b3[col];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) bufO[(m0 + 4 * g + v) * LDO + col] = acc3[0][nt][v] + bias;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    // ---- P3: residual, store, planar LN1 half for the next block (fp32)
+    if (threadIdx.x < M) {
+        const int m = threadIdx.x;
+        const int y = y0 + m / TX, x = x0 + m % TX;
+        if (y < h && x < w) {
+            const long p = (b * h + y) * (long)w + x;
+            float o[E];
+            const float4* xs = reinterpret_cast<const float4*>(a2.x + p * E);
+            float4* yo = reinterpret_cast<float4*>(a2.y + p * E);
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) {
+                float4 xr = xs[k];
+                o[4 * k] = xr.x + bufO[m * LDO + 4 * k];
+                o[4 * k + 1] = xr.y + bufO[m * LDO + 4 * k + 1];
+                o[4 * k + 2] = xr.z + bufO[m * LDO + 4 * k + 2];
+                o[4 * k + 3] = xr.w + bufO[m * LDO + 4 * k + 3];
+                yo[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+            }
+            if (a2.g) {
+                float mu, rstd;
+                ln_stats<E>(o, mu, rstd);
+                const long hw = (long)h * w, s = (long)y * w + x;
+#pragma unroll
+                for (int n = E / 2; n < E; ++n) a2.g[(b * (E / 2) + (n - E / 2)) * hw + s] = (o[n] - mu) * rstd * a2.n1g[n] + a2.n1b[n];
+            }
+        }
+    }
+    }   // tiles of this workgroup
+}
+
+template <int E>
+static int launch_ffn_fused_bf_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
+    ProfScope prof__(LG_K_FFN2, s);
+    constexpr int N1 = 4 * E;
+    const size_t lds = (size_t)(180 * (N1 + 4) + 128 * (E + 1) + 8) * sizeof(float) + (size_t)(192 * (E + 8) + 4 * 16 * (N1 + 8)) * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_fused_bf<E, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_fused_bf<E, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { lg_set_error("ffn_fused_bf: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    int tiles_x = (a2.w + 15) / 16, tiles_y = (a2.h + 7) / 8;
+    const int ntiles = a2.B * tiles_x * tiles_y;
+    const int grid = ntiles < 512 ? ntiles : 512;
+    if (a1.a1s != nullptr) k_ffn_fused_bf<E, true, true><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y, ntiles);
+    else k_ffn_fused_bf<E, false, true><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y, ntiles);
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
 // returns 1 if the fused kernel does not cover this size (caller falls back to k_ffn1 + k_ffn2)
 int launch_ffn_fused(int e, const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
+    if (a1.hbf) {   // throughput mode: bf16 matrix cores for the three GEMMs
+        if (e == 16) return launch_ffn_fused_bf_t<16>(a1, a2, s);
+        if (e == 32) return launch_ffn_fused_bf_t<32>(a1, a2, s);
+        return 1;
+    }
     if (e == 16) return launch_ffn_fused_t<16>(a1, a2, s);
     if (e == 32) return launch_ffn_fused_t<32>(a1, a2, s);
     return 1;

@@ -193,9 +193,10 @@ def test_half_block_backward_256_split_fft(which):
 
 
 def test_bf16_saved_activations_mode(manifest):
-    """precision='bf16': the 4e-wide saved / hidden FFN tensors of the backward are stored as bf16 (fp32 arithmetic).
-    The forward is untouched (bitwise equal to fp32 mode); gradients carry bf16 rounding of those activations: global
-    relative L2 vs the reference's fp32 gradients < 1e-2, loss identical."""
+    """precision='bf16' (throughput mode, opt-in): the FFN's three 1x1-conv GEMMs take bf16 operands on the matrix cores
+    (fp32 accumulate) and the 4e-wide tensors saved for the backward are stored as bf16; everything else is fp32.
+    Gates: forward within 5e-3 relative L2 and >= 50 dB PSNR of the fp32 mode, loss within 1e-3 relative of the
+    reference's, gradients within 2e-2 global relative L2 of the reference's fp32 gradients."""
     from gpu_helpers import make_module
     from lgteun_amd import FusedAdam
     m = manifest['grad_c4_k2_p32']
@@ -207,12 +208,16 @@ def test_bf16_saved_activations_mode(manifest):
     net.precision = 'bf16'
     with torch.no_grad():
         y16 = net(ms, pan)
-    assert torch.equal(y32, y16)
+    fwd_rel = rel_l2(y16.cpu(), y32.cpu())
+    mse = float(((y16 - y32) ** 2).mean())
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-30))
+    print(f'bf16 mode: forward rel_l2 {fwd_rel:.3e}  PSNR vs fp32 mode {psnr:.1f} dB')
+    assert fwd_rel < 5e-3 and psnr >= 50.0, (fwd_rel, psnr)
     opt = FusedAdam(net.parameters(), lr=0.0)
     opt.dropout = False
     eng = net.engine()
     loss = float(eng.train_step(ms, pan, gt, opt).item())
-    assert abs(loss - float(g['loss'])) < 2e-5
+    assert abs(loss - float(g['loss'])) < 1e-3 * abs(float(g['loss'])), (loss, float(g['loss']))
     num = den = 0.0
     for i in eng.live_idx:
         n, o, p = eng.names[i], eng.offsets[i], eng.params[i]
@@ -220,7 +225,8 @@ def test_bf16_saved_activations_mode(manifest):
         ref = g[n.replace('.', '/')]
         num += float(((got - ref) ** 2).sum())
         den += float((ref ** 2).sum())
-    assert (num / den) ** 0.5 < 1e-2, (num / den) ** 0.5
+    print(f'bf16 mode: grad rel_l2 {(num / den) ** 0.5:.3e}')
+    assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
 
 
 def test_runner_train_eval_save_load_roundtrip(tmp_path):
