@@ -202,11 +202,10 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
 }
 
 static int pos_transpose_stage(const lg_plan* pl, const float* P, int stage, float* posT_stage, hipStream_t s) {
-    for (int j = 0; j < 5; ++j) {
-        int rc = launch_pos_transpose(P + pl->blk(stage, j, B_POS), posT_stage + (size_t)j * 2 * 64 * 64, s);
-        if (rc) return rc;
-    }
-    return 0;
+    const float* src[5];
+    float* dst[5];
+    for (int j = 0; j < 5; ++j) { src[j] = P + pl->blk(stage, j, B_POS); dst[j] = posT_stage + (size_t)j * 2 * 64 * 64; }
+    return launch_pos_transpose_n(5, src, dst, s);
 }
 
 // LGT.forward (LGT.py:314-344) on z -> out with the buffers of `nb`

@@ -123,6 +123,7 @@ struct Ffn1BwdArgs {
 };
 int launch_ffn1_bwd(int e, const Ffn1BwdArgs& a, hipStream_t s);
 int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[cols][rows]
+int launch_transpose3(const float* const* src, float* const* dst, const int* rows, const int* cols, int njobs, hipStream_t s);
 
 // ---------------- mixer backward ----------------
 struct ProjO2BwdArgs {

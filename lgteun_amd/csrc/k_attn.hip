@@ -157,19 +157,26 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
     }
 }
 
-__global__ void k_pos_transpose(const float* __restrict__ pos, float* __restrict__ posT) {
-    // pos [2][64][64] (h,i,j) -> posT [2][64][64] (h,j,i)
+struct PosTArgs { const float* src[5]; float* dst[5]; };
+__global__ void k_pos_transpose(PosTArgs a) {
+    // pos [2][64][64] (h,i,j) -> posT [2][64][64] (h,j,i); blockIdx.y = block of the stage
+    const float* __restrict__ pos = a.src[blockIdx.y];
+    float* __restrict__ posT = a.dst[blockIdx.y];
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i < 2 * 64 * 64) {
         int h = i >> 12, r = (i >> 6) & 63, c = i & 63;
         posT[(h * 64 + c) * 64 + r] = pos[i];
     }
 }
-int launch_pos_transpose(const float* pos, float* posT, hipStream_t s) {
-    k_pos_transpose<<<32, 256, 0, s>>>(pos, posT);
+int launch_pos_transpose_n(int n, const float* const* pos, float* const* posT, hipStream_t s) {
+    if (n < 1 || n > 5) { lg_set_error("pos_transpose: n=%d", n); return -2; }
+    PosTArgs a;
+    for (int j = 0; j < 5; ++j) { a.src[j] = pos[j < n ? j : 0]; a.dst[j] = posT[j < n ? j : 0]; }
+    k_pos_transpose<<<dim3(32, n), 256, 0, s>>>(a);
     LG_CHECK_LAUNCH();
     return 0;
 }
+int launch_pos_transpose(const float* pos, float* posT, hipStream_t s) { return launch_pos_transpose_n(1, &pos, &posT, s); }
 
 template <int HC>
 static int launch_attn_t(const AttnArgs& a, hipStream_t s) {

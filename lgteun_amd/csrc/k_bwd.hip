@@ -60,9 +60,12 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
     const int e = fb.e, n1 = 4 * e;
     const int hbf = pl->cfg.precision == 1 ? 1 : 0;   // bf16 storage of the hidden / saved FFN tensors
     const long Pn = (long)B * fb.h * fb.w;
-    RC(launch_transpose(P + pl->blk(st, j, B_W3), bb.w3t, e, n1, s));
-    RC(launch_transpose(P + pl->blk(st, j, B_W2), bb.w2t, n1, n1, s));
-    RC(launch_transpose(P + pl->blk(st, j, B_W1), bb.w1t, n1, e, s));
+    {
+        const float* tsrc[3] = {P + pl->blk(st, j, B_W3), P + pl->blk(st, j, B_W2), P + pl->blk(st, j, B_W1)};
+        float* tdst[3] = {bb.w3t, bb.w2t, bb.w1t};
+        const int trows[3] = {e, n1, n1}, tcols[3] = {n1, n1, e};
+        RC(launch_transpose3(tsrc, tdst, trows, tcols, 3, s));
+    }
     FfnDwBwdArgs fd;
     fd.dy = dy; fd.g3 = fb.g3; fd.h2 = fb.h2; fd.dh2 = bb.dh2; fd.w3t = bb.w3t; fd.dww = P + pl->blk(st, j, B_DWW);
     fd.slab_w = bb.slab; fd.slab_b = bb.slab + ffn_dw_bwd_slab_floats(e, B, fb.h, fb.w) / 10 * 9;

@@ -11,21 +11,34 @@
 #include "mfma.h"
 #include "hstore.h"
 
-__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+struct TransposeJobs { const float* src[3]; float* dst[3]; int rows[3], cols[3]; };
+__global__ __launch_bounds__(256) void k_transpose(TransposeJobs t) {
+    const int q = blockIdx.y;
+    const float* __restrict__ src = t.src[q];
+    float* __restrict__ dst = t.dst[q];
+    const int rows = t.rows[q], cols = t.cols[q];
     long n = (long)rows * cols;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
         int r = (int)(i / cols), c = (int)(i - (long)r * cols);
         dst[(long)c * rows + r] = src[i];
     }
 }
-int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s) {
-    long n = (long)rows * cols;
-    int grid = (int)((n + 255) / 256);
+int launch_transpose3(const float* const* src, float* const* dst, const int* rows, const int* cols, int njobs, hipStream_t s) {
+    if (njobs < 1 || njobs > 3) { lg_set_error("transpose: njobs=%d", njobs); return -2; }
+    TransposeJobs t;
+    long nmax = 0;
+    for (int q = 0; q < 3; ++q) {
+        const int u = q < njobs ? q : 0;
+        t.src[q] = src[u]; t.dst[q] = dst[u]; t.rows[q] = rows[u]; t.cols[q] = cols[u];
+        if ((long)rows[u] * cols[u] > nmax) nmax = (long)rows[u] * cols[u];
+    }
+    int grid = (int)((nmax + 255) / 256);
     if (grid > 1024) grid = 1024;
-    k_transpose<<<grid, 256, 0, s>>>(src, dst, rows, cols);
+    k_transpose<<<dim3(grid, njobs), 256, 0, s>>>(t);
     LG_CHECK_LAUNCH();
     return 0;
 }
+int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s) { return launch_transpose3(&src, &dst, &rows, &cols, 1, s); }
 
 // ------------------------------------------------------------------------------------------------
 #define DW_CG 32   // channels per workgroup (depthwise work is per channel); 16 (3 workgroups per CU) measured no faster

@@ -156,35 +156,42 @@ __global__ __launch_bounds__(256) void k_wgrad_narrow(WgradArgs a, int k_blocks,
 __global__ __launch_bounds__(256) void k_reduce_slab(const float* __restrict__ slab, long nslices, int rows, int cols, float* dst,
                                                      int ld, int rows_valid, int cols_valid, const float* __restrict__ slab2, int n2,
                                                      float* dst2, int n2_valid) {
-    __shared__ float part[4][64];
+    // 16 outputs x 16 slice phases per workgroup: every thread has 8 independent loads in flight (the old 64 x 4 shape walked 128
+    // slices per thread and was pure load latency, ~12 us per call); fixed summation order -> deterministic.
+    __shared__ float part[16][17];
     // job 0 (blockIdx.y == 0): the [rows][cols] slab; job 1: an optional [n2] vector slab (bias) in the same launch
     if (blockIdx.y == 1) { slab = slab2; rows = 1; cols = n2; dst = dst2; ld = n2; rows_valid = 1; cols_valid = n2_valid; }
     const long n = (long)rows * cols;
-    const int o = threadIdx.x & 63, ph = threadIdx.x >> 6;
-    const long i = blockIdx.x * 64L + o;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int o = threadIdx.x & 15, ph = threadIdx.x >> 4;
+    const long i = blockIdx.x * 16L + o;
+    float sv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sv[u] = 0.f;
     if (i < n) {
         long k = ph;
-        for (; k + 12 < nslices; k += 16) {
-            s0 += slab[k * n + i];
-            s1 += slab[(k + 4) * n + i];
-            s2 += slab[(k + 8) * n + i];
-            s3 += slab[(k + 12) * n + i];
+        for (; k + 16 * 7 < nslices; k += 16 * 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sv[u] += slab[(k + 16 * u) * n + i];
         }
-        for (; k < nslices; k += 4) s0 += slab[k * n + i];
+        for (; k < nslices; k += 16) sv[0] += slab[k * n + i];
     }
-    part[ph][o] = (s0 + s1) + (s2 + s3);
+    part[ph][o] = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
     __syncthreads();
     if (ph == 0 && i < n) {
         const int row = (int)(i / cols), col = (int)(i - (long)row * cols);
-        if (row < rows_valid && col < cols_valid) dst[(long)row * ld + col] += (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+        if (row < rows_valid && col < cols_valid) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += part[q][o];
+            dst[(long)row * ld + col] += t;
+        }
     }
 }
 
 static int launch_reduce_slab2(const float* slab, long nslices, int rows, int cols, float* dst, int ld, int rows_valid, int cols_valid,
                                const float* slab2, int n2, float* dst2, int n2_valid, hipStream_t s) {
     long n = (long)rows * cols;
-    dim3 grid((unsigned)((n + 63) / 64), slab2 ? 2 : 1);
+    dim3 grid((unsigned)((n + 15) / 16), slab2 ? 2 : 1);
     k_reduce_slab<<<grid, 256, 0, s>>>(slab, nslices, rows, cols, dst, ld, rows_valid, cols_valid, slab2, n2, dst2, n2_valid);
     LG_CHECK_LAUNCH();
     return 0;
