@@ -12,142 +12,132 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
-template <bool YBF, bool XBF>
-__global__ __launch_bounds__(256) void k_wgrad(WgradArgs a, int k_blocks, long px_per_wave, float* slab, float* bslab) {
-    // Operand fetch: lane (r,g) loads ONE float4 of Y and ONE of X per 4-pixel step: Y[p+g][n0 + 4r .. 4r+3], X[p+g][k0 + 4r ..].
-    // Element t of the float4 feeds MFMA tile t, so tile t owns the strided channel set {4r + t}: a 64-channel row is one
-    // fully coalesced 256-byte segment per 16 lanes, and 2 loads feed 16 MFMAs.  Output row of acc[i][j][v] (MFMA row 4g+v,
-    // col r) is therefore dW[n0 + 4(4g+v) + i][k0 + 4r + j].
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-    const int nb = blockIdx.y / k_blocks, kb = blockIdx.y - nb * k_blocks;
-    const int n0 = nb * 64, k0 = kb * 64;
-    const int NW = min(64, a.N - n0), KW = min(64, a.K - k0);   // valid widths of this block (multiples of 16)
-    const bool yok = 4 * r < NW, xok = 4 * r < KW;
-    const long slice = (long)blockIdx.x * 4 + wave;
-    const long p_begin = slice * px_per_wave;
-    long p_end = p_begin + px_per_wave;
-    if (p_end > a.P) p_end = a.P;
-    f32x4 acc[4][4];
-    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (long p = p_begin; p < p_end; p += 4) {
-        const long row = p + g;
-        const bool valid = row < p_end;
-        float4 af = make_float4(0.f, 0.f, 0.f, 0.f), bf = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid && yok) af = HS<YBF>::ld4(a.Y, row * a.ldy + n0 + 4 * r);
-        if (valid && xok) {
-            bf = HS<XBF>::ld4(a.X, row * a.ldx + k0 + 4 * r);
-        }
-        bsum.x += af.x; bsum.y += af.y; bsum.z += af.z; bsum.w += af.w;
-        const float av[4] = {af.x, af.y, af.z, af.w}, bv[4] = {bf.x, bf.y, bf.z, bf.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-    }
-    // the 4 waves of the workgroup hold partials of the same 64x64 block: sum them in LDS, one slab slice per workgroup
-    __shared__ float red[64 * 64 + 64];
-    for (int i = threadIdx.x; i < 64 * 64 + 64; i += 256) red[i] = 0.f;
-    __syncthreads();
-    for (int w = 0; w < 4; ++w) {   // waves take turns: fixed order, no float atomics -> bitwise reproducible
-        if (wave == w) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) red[(4 * (4 * g + v) + i) * 64 + 4 * r + j] += acc[i][j][v];
-            // bias: lanes with equal r hold the same 4 channels for different pixels
-            float4 b = bsum;
-            b.x += __shfl_xor(b.x, 16); b.y += __shfl_xor(b.y, 16); b.z += __shfl_xor(b.z, 16); b.w += __shfl_xor(b.w, 16);
-            b.x += __shfl_xor(b.x, 32); b.y += __shfl_xor(b.y, 32); b.z += __shfl_xor(b.z, 32); b.w += __shfl_xor(b.w, 32);
-            if (g == 0) {
-                red[64 * 64 + 4 * r] += b.x; red[64 * 64 + 4 * r + 1] += b.y; red[64 * 64 + 4 * r + 2] += b.z; red[64 * 64 + 4 * r + 3] += b.w;
-            }
-        }
-        __syncthreads();
-    }
-    float* my = slab + (long)blockIdx.x * ((long)a.N * a.K);
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int rr = i >> 6, cc = i & 63;
-        if (rr < NW && cc < KW) my[(long)(n0 + rr) * a.K + k0 + cc] = red[i];
-    }
-    if (a.db && kb == 0 && threadIdx.x < NW) bslab[(long)blockIdx.x * a.N + n0 + threadIdx.x] = red[64 * 64 + threadIdx.x];
-}
+// Block shape: NT x KT tiles of 16 (compile time, so the pixel loop is branch-free and software-pipelined: the operands of
+// the next 16 pixels are in flight while the MFMAs of the current 16 issue).  VEC (64x64 blocks only): lane (r,g) loads ONE
+// float4 of Y and ONE of X per 4-pixel step, Y[p+g][n0 + 4r .. 4r+3] / X[p+g][k0 + 4r ..]; element t of the float4 feeds MFMA
+// tile t, so tile t owns the strided channel set {4r + t}: a 64-channel row is one fully coalesced 256-byte segment per 16
+// lanes and 2 loads feed 16 MFMAs.  Output acc[i][j][v] (MFMA row 4g+v, col r) is then dW[n0 + 4(4g+v) + i][k0 + 4r + j].
+// Non-VEC: scalar loads in the natural tile order (tile t = channels 16t .. 16t+15), columns >= n_valid / k_valid read as 0.
+// 4-pixel MFMA steps per batch: narrow blocks have few MFMAs per pixel, so they keep more pixels in flight
+__host__ __device__ constexpr int wgrad_batch(int nt, int kt, bool vec) { return vec ? 4 : (nt + kt <= 2 ? 16 : (nt + kt <= 4 ? 8 : 4)); }
 
-// narrow shapes (N or K < 64): scalar operand loads, only the needed 16x16 tiles are issued
-template <bool YBF, bool XBF>
-__global__ __launch_bounds__(256) void k_wgrad_narrow(WgradArgs a, int k_blocks, long px_per_wave, float* slab, float* bslab) {
+template <int NT, int KT, bool VEC, bool YBF, bool XBF>
+__global__ __launch_bounds__(256) void k_wgrad_t(WgradArgs a, int k_blocks, long px_per_wave, float* slab, float* bslab) {
+    constexpr int U = wgrad_batch(NT, KT, VEC);
+    constexpr int NB = 16 * NT, KB = 16 * KT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int nb = blockIdx.y / k_blocks, kb = blockIdx.y - nb * k_blocks;
-    const int n0 = nb * 64, k0 = kb * 64;
-    const int NT = min(4, (a.N - n0) / 16), KT = min(4, (a.K - k0) / 16);
+    const int n0 = nb * NB, k0 = kb * KB;
     const long slice = (long)blockIdx.x * 4 + wave;
     const long p_begin = slice * px_per_wave;
     long p_end = p_begin + px_per_wave;
     if (p_end > a.P) p_end = a.P;
-    f32x4 acc[4][4];
-    float bsum[4];
+    f32x4 acc[NT][KT];
+    float bsum[NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NT; ++i) {
         bsum[i] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < KT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll 4
-    for (long p = p_begin; p < p_end; p += 4) {
-        const long row = p + g;
-        const bool valid = row < p_end;
-        float af[4], bf[4];
+    // column offsets / masks of this lane (non-VEC)
+    int ycol[NT], xcol[KT];
+    bool yok[NT], xok[KT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            af[t] = (valid && t < NT) ? HS<YBF>::ld1(a.Y, row * a.ldy + n0 + t * 16 + r) : 0.f;
-            bf[t] = (valid && t < KT) ? HS<XBF>::ld1(a.X, row * a.ldx + k0 + t * 16 + r) : 0.f;
+    for (int t = 0; t < NT; ++t) { const int c = n0 + t * 16 + r; yok[t] = c < a.n_valid; ycol[t] = yok[t] ? c : 0; }
+#pragma unroll
+    for (int t = 0; t < KT; ++t) { const int c = k0 + t * 16 + r; xok[t] = c < a.k_valid; xcol[t] = xok[t] ? c : 0; }
+    // masks are applied by multiplication (operands are finite tensors): a select would let the compiler sink the loads into
+    // branches with a full wait each, which is what made the first version of this kernel pure load latency
+    float ym[NT], xm[KT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ym[t] = yok[t] ? 1.f : 0.f;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) xm[t] = xok[t] ? 1.f : 0.f;
+    auto fetch = [&](long p, float (&y)[U][NT], float (&x)[U][KT]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long row = p + 4 * u + g;
+            const long rc = row < p_end ? row : p_begin;   // a row that exists; masked in `consume`
+            if (VEC) {
+                const float4 yv = HS<YBF>::ld4(a.Y, rc * a.ldy + n0 + 4 * r);
+                const float4 xv = HS<XBF>::ld4(a.X, rc * a.ldx + k0 + 4 * r);
+                const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int t = 0; t < NT; ++t) y[u][t] = yy[t & 3];
+#pragma unroll
+                for (int t = 0; t < KT; ++t) x[u][t] = xx[t & 3];
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) y[u][t] = HS<YBF>::ld1(a.Y, rc * a.ldy + ycol[t]);
+#pragma unroll
+                for (int t = 0; t < KT; ++t) x[u][t] = HS<XBF>::ld1(a.X, rc * a.ldx + xcol[t]);
+            }
         }
+    };
+    if (p_begin < p_end) {
+        float yc[U][NT], xc[U][KT];
+        fetch(p_begin, yc, xc);
+#pragma unroll 1
+        for (long p = p_begin; p < p_end; p += 4 * U) {
+            float yn[U][NT], xn[U][KT];
+            fetch(p + 4 * U, yn, xn);   // next batch in flight under this batch's MFMAs (past the slice end: cached, unused)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bsum[i] += af[i];
+            for (int u = 0; u < U; ++u) {
+                const float rm = (p + 4 * u + g) < p_end ? 1.f : 0.f;
+                float yv[NT], xv[KT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (i < NT && j < KT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < NT; ++i) { yv[i] = yc[u][i] * (VEC ? rm : rm * ym[i]); bsum[i] += yv[i]; }
+#pragma unroll
+                for (int j = 0; j < KT; ++j) xv[j] = VEC ? xc[u][j] : xc[u][j] * xm[j];
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < KT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[i], xv[j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i) yc[u][i] = yn[u][i];
+#pragma unroll
+                for (int j = 0; j < KT; ++j) xc[u][j] = xn[u][j];
+            }
         }
     }
-    // the 4 waves of the workgroup hold partials of the same 64x64 block: sum them in LDS, one slab slice per workgroup
-    __shared__ float red[64 * 64 + 64];
-    for (int i = threadIdx.x; i < 64 * 64 + 64; i += 256) red[i] = 0.f;
-    __syncthreads();
-    for (int w = 0; w < 4; ++w) {   // waves take turns: fixed order, no float atomics -> bitwise reproducible
+    // the 4 waves of the workgroup hold partials of the same block: summed in LDS in a fixed order (no float atomics ->
+    // bitwise reproducible), one slab slice per workgroup
+    __shared__ float red[NB * KB + NB];
+    for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (i < NT && j < KT) {
+                for (int j = 0; j < KT; ++j)
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) red[(i * 16 + 4 * g + v) * 64 + j * 16 + r] += acc[i][j][v];
+                    for (int v = 0; v < 4; ++v) {
+                        const int idx = VEC ? (4 * (4 * g + v) + i) * KB + 4 * r + j : (i * 16 + 4 * g + v) * KB + j * 16 + r;
+                        red[idx] = (w == 0 ? 0.f : red[idx]) + acc[i][j][v];
                     }
-            if (a.db && kb == 0) {
+            // bias: lanes with equal r hold the same channels for different pixels
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float s = bsum[i];
-                    s += __shfl_xor(s, 16);
-                    s += __shfl_xor(s, 32);
-                    if (g == 0 && i < NT) red[64 * 64 + i * 16 + r] += s;
-                }
+            for (int i = 0; i < NT; ++i) {
+                float sv = bsum[i];
+                sv += __shfl_xor(sv, 16);
+                sv += __shfl_xor(sv, 32);
+                const int idx = NB * KB + (VEC ? 4 * r + i : i * 16 + r);
+                if (g == 0) red[idx] = (w == 0 ? 0.f : red[idx]) + sv;
             }
         }
         __syncthreads();
     }
     float* my = slab + (long)blockIdx.x * ((long)a.N * a.K);
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int rr = i >> 6, cc = i & 63;
-        if (rr < NT * 16 && cc < KT * 16) my[(long)(n0 + rr) * a.K + k0 + cc] = red[i];
+    for (int i = threadIdx.x; i < NB * KB; i += 256) {
+        const int rr = i / KB, cc = i - rr * KB;
+        my[(long)(n0 + rr) * a.K + k0 + cc] = red[i];
     }
-    if (a.db && kb == 0 && threadIdx.x < NT * 16) bslab[(long)blockIdx.x * a.N + n0 + threadIdx.x] = red[64 * 64 + threadIdx.x];
+    if (a.db && kb == 0 && threadIdx.x < NB) bslab[(long)blockIdx.x * a.N + n0 + threadIdx.x] = red[NB * KB + threadIdx.x];
 }
 
 // dst[row*ld + col] += sum_s slab[s][row*cols + col]   for row < rows_valid, col < cols_valid
@@ -201,41 +191,63 @@ int launch_reduce_slab(const float* slab, long nslices, int rows, int cols, floa
     return launch_reduce_slab2(slab, nslices, rows, cols, dst, ld, rows_valid, cols_valid, nullptr, 0, nullptr, 0, s);
 }
 
+static int tiles_per_block(int n16) {   // largest of 4,3,2,1 dividing the tile count
+    for (int t = 4; t > 1; --t) if (n16 % t == 0) return t;
+    return 1;
+}
+static long wgrad_splits(int N, int K) {
+    const int blocks = (N / 16 / tiles_per_block(N / 16)) * (K / 16 / tiles_per_block(K / 16));
+    long splits = 512 / blocks;   // two waves per SIMD
+    return splits < 1 ? 1 : splits;
+}
 size_t wgrad_slab_floats(int N, int K, long P) {
     // sized for the launch geometry below (upper bound)
-    const int blocks = ((N + 63) / 64) * ((K + 63) / 64);
-    long splits = 512 / blocks;
-    if (splits < 1) splits = 1;
-    return (size_t)splits * ((size_t)N * K + N);
+    (void)P;
+    return (size_t)wgrad_splits(N, K) * ((size_t)N * K + N);
+}
+
+template <int NT, int KT, bool VEC>
+static void wgrad_dispatch_bf(const WgradArgs& a, dim3 grid, int k_blocks, long px, float* slab, float* bslab, hipStream_t s) {
+    if (a.ybf && a.xbf) k_wgrad_t<NT, KT, VEC, true, true><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);
+    else if (a.ybf) k_wgrad_t<NT, KT, VEC, true, false><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);
+    else if (a.xbf) k_wgrad_t<NT, KT, VEC, false, true><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);
+    else k_wgrad_t<NT, KT, VEC, false, false><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);
+}
+template <int NT>
+static void wgrad_dispatch_kt(int KT, const WgradArgs& a, dim3 grid, int k_blocks, long px, float* slab, float* bslab, hipStream_t s) {
+    switch (KT) {
+        case 1: wgrad_dispatch_bf<NT, 1, false>(a, grid, k_blocks, px, slab, bslab, s); break;
+        case 2: wgrad_dispatch_bf<NT, 2, false>(a, grid, k_blocks, px, slab, bslab, s); break;
+        case 3: wgrad_dispatch_bf<NT, 3, false>(a, grid, k_blocks, px, slab, bslab, s); break;
+        default: wgrad_dispatch_bf<NT, 4, false>(a, grid, k_blocks, px, slab, bslab, s); break;
+    }
 }
 
 int launch_wgrad(const WgradArgs& a, float* slab, hipStream_t s) {
     ProfScope prof__(LG_K_WGRAD, s);
     if ((a.N & 15) || (a.K & 15) || a.N <= 0 || a.K <= 0 || a.P <= 0) { lg_set_error("wgrad: N,K must be positive multiples of 16"); return -2; }
-    const int n_blocks = (a.N + 63) / 64, k_blocks = (a.K + 63) / 64;
+    if (a.n_valid > a.N || a.k_valid > a.K || a.n_valid > a.ldy || a.k_valid > a.ldx) { lg_set_error("wgrad: valid extents exceed the operands"); return -2; }
+    const int NT = tiles_per_block(a.N / 16), KT = tiles_per_block(a.K / 16);
+    const int n_blocks = a.N / (16 * NT), k_blocks = a.K / (16 * KT);
     const int blocks = n_blocks * k_blocks;
-    long splits = 512 / blocks;   // two waves per SIMD: the load -> MFMA chain needs another wave to hide HBM latency
-    if (splits < 1) splits = 1;
+    long splits = wgrad_splits(a.N, a.K);
     long nslices = splits * 4;
     long px = (a.P + nslices - 1) / nslices;
-    px = (px + 3) & ~3L;
-    if (px < 4) px = 4;
+    const bool vec = NT == 4 && KT == 4 && a.n_valid == a.N && a.k_valid == a.K && (a.ldy & 3) == 0 && (a.ldx & 3) == 0;
+    const long batch = 4L * wgrad_batch(NT, KT, vec);
+    px = (px + batch - 1) / batch * batch;   // whole batches
     // shrink the slice count if the tensor is small
     nslices = (a.P + px - 1) / px;
     splits = (nslices + 3) / 4;
-    nslices = splits * 4;
     float* bslab = slab + splits * (long)a.N * a.K;
     dim3 grid((unsigned)splits, (unsigned)blocks);
-    const bool wide = (a.N % 64 == 0) && (a.K % 64 == 0);
-#define LG_WG(KERN)                                                                                            \
-    do {                                                                                                       \
-        if (a.ybf && a.xbf) KERN<true, true><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);               \
-        else if (a.ybf) KERN<true, false><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);                  \
-        else if (a.xbf) KERN<false, true><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);                  \
-        else KERN<false, false><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);                            \
-    } while (0)
-    if (wide) LG_WG(k_wgrad); else LG_WG(k_wgrad_narrow);
-#undef LG_WG
+    if (vec) wgrad_dispatch_bf<4, 4, true>(a, grid, k_blocks, px, slab, bslab, s);
+    else switch (NT) {
+        case 1: wgrad_dispatch_kt<1>(KT, a, grid, k_blocks, px, slab, bslab, s); break;
+        case 2: wgrad_dispatch_kt<2>(KT, a, grid, k_blocks, px, slab, bslab, s); break;
+        case 3: wgrad_dispatch_kt<3>(KT, a, grid, k_blocks, px, slab, bslab, s); break;
+        default: wgrad_dispatch_kt<4>(KT, a, grid, k_blocks, px, slab, bslab, s); break;
+    }
     LG_CHECK_LAUNCH();
     return launch_reduce_slab2(slab, splits, a.N, a.K, a.dW, a.ldw, a.n_valid, a.k_valid, a.db ? bslab : nullptr, a.N, a.db, a.n_valid, s);
 }
