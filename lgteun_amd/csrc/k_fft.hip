@@ -32,15 +32,16 @@ __device__ __forceinline__ void fft_fused(float2* buf, const float2* tw, int lg,
     const int lgmL = INVERSE ? st : (lg - st - S);
     const int mL = 1 << lgmL;
     const int lgpl = lg - S;                     // log2(items per line)
-    const int items = nlines << lgpl;
+    // SKIP: only the half + 1 needed columns are enumerated (bit-reversed positions: kx < n/2 <-> even p, kx = n/2 <-> p = 1),
+    // so every lane of a wave works (skipping by predicate left half of each wave idle)
+    const int items = SKIP ? ((half + 1) << lgpl) : (nlines << lgpl);
     for (int it = threadIdx.x; it < items; it += blockDim.x) {
         int line, t;
-        if (es != 1) { t = it >> lgnl; line = it & (nlines - 1); }         // column transforms: consecutive threads -> consecutive lines
-        else { line = it >> lgpl; t = it & ((1 << lgpl) - 1); }             // row transforms: consecutive threads -> consecutive items
         if (SKIP) {
-            const int kx = (int)(__brev((unsigned)line) >> (32 - lg));
-            if (kx > half) continue;
-        }
+            if (it < (half << lgpl)) { t = it >> (lgnl - 1); line = 2 * (it & (half - 1)); }
+            else { t = it - (half << lgpl); line = 1; }
+        } else if (es != 1) { t = it >> lgnl; line = it & (nlines - 1); }   // column transforms: consecutive threads -> consecutive lines
+        else { line = it >> lgpl; t = it & ((1 << lgpl) - 1); }             // row transforms: consecutive threads -> consecutive items
         const int lo = t & (mL - 1), hi = t >> lgmL;
         const int i_base = (hi << (lgmL + S)) + lo;
         float2* base = buf + line * ls;
@@ -127,7 +128,9 @@ __device__ __forceinline__ float2 bin_edit_bwd(float2 f, float c, float nn, floa
 __device__ __forceinline__ void hermitian_extend(float2* buf, int n, int lg) {
     const int half = n >> 1;
     for (int it = threadIdx.x; it < n * (half + 1); it += blockDim.x) {
-        int y = it / (half + 1), kx = it - y * (half + 1);
+        int y, kx;
+        if (it < n * half) { y = it >> (lg - 1); kx = it & (half - 1); }
+        else { y = it - n * half; kx = half; }
         int p = (int)(__brev((unsigned)kx) >> (32 - lg));
         if (kx == 0 || kx == half) {
             buf[y * n + p].y = 0.0f;
@@ -138,6 +141,15 @@ __device__ __forceinline__ void hermitian_extend(float2* buf, int n, int lg) {
         }
     }
     __syncthreads();
+}
+
+// enumeration of the half-spectrum bins of an in-LDS plane (bit-reversed layout): item it in [0, n (n/2 + 1)) -> row q, LDS
+// column p, compact column c (c < n/2: p = 2c, kx = brev(c); c = n/2: p = 1, kx = n/2).  amp / pha are stored at [q][c]
+// (coalesced; the backward of the same plane size reads them back with the same map)
+__device__ __forceinline__ void half_bin(int it, int n, int lg, int& q, int& p, int& c) {
+    const int half = n >> 1;
+    if (it < n * half) { q = it >> (lg - 1); c = it & (half - 1); p = 2 * c; }
+    else { q = it - n * half; c = half; p = 1; }
 }
 
 __global__ void k_fftmix(FftArgs a, int lg) {
@@ -163,19 +175,17 @@ __global__ void k_fftmix(FftArgs a, int lg) {
     __syncthreads();
     // ---- amplitude / phase edit (LGT.py:168-177)
     const float aw = a.ampw[ch], ab = a.ampb[ch], pw = a.phaw[ch], pb = a.phab[ch];
-    for (int it = threadIdx.x; it < n * n; it += blockDim.x) {
-        int q = it >> lg, p = it & (n - 1);
-        int kx = (int)(__brev((unsigned)p) >> (32 - lg));
-        if (kx > half) continue;
+    for (int it = threadIdx.x; it < n * (half + 1); it += blockDim.x) {
+        int q, p, c;
+        half_bin(it, n, lg, q, p, c);
         float amp, pha;
-        const float2 ed = bin_edit_fwd(buf[it], aw, ab, pw, pb, amp, pha);
+        const float2 ed = bin_edit_fwd(buf[q * n + p], aw, ab, pw, pb, amp, pha);
         if (a.amp) {
-            int ky = (int)(__brev((unsigned)q) >> (32 - lg));
-            size_t o = ((size_t)plane * n + ky) * (half + 1) + kx;
+            size_t o = ((size_t)plane * n + q) * (half + 1) + c;
             a.amp[o] = amp;
             a.pha[o] = pha;
         }
-        buf[it] = ed;
+        buf[q * n + p] = ed;
     }
     __syncthreads();
     // ---- irfft2: columns (complex), Hermitian extension, rows
@@ -435,14 +445,12 @@ __global__ void k_fftmix_bwd(FftBwdArgs a, int lg) {
     const float aw = a.ampw[ch], ab = a.ampb[ch], pw = a.phaw[ch], pb = a.phab[ch];
     const float nn = (float)n * (float)n;
     float s_aw = 0.f, s_ab = 0.f, s_pw = 0.f, s_pb = 0.f;
-    for (int it = threadIdx.x; it < n * n; it += blockDim.x) {
-        int q = it >> lg, p = it & (n - 1);
-        int kx = (int)(__brev((unsigned)p) >> (32 - lg));
-        if (kx > half) continue;
-        int ky = (int)(__brev((unsigned)q) >> (32 - lg));
-        const float c = (kx == 0 || kx == half) ? 1.0f : 2.0f;
-        const size_t o = ((size_t)plane * n + ky) * (half + 1) + kx;
-        buf[it] = bin_edit_bwd(buf[it], c, nn, a.amp[o], a.pha[o], aw, ab, pw, pb, s_aw, s_ab, s_pw, s_pb);
+    for (int it = threadIdx.x; it < n * (half + 1); it += blockDim.x) {
+        int q, p, c;
+        half_bin(it, n, lg, q, p, c);
+        const float cf = (c == 0 || c == half) ? 1.0f : 2.0f;
+        const size_t o = ((size_t)plane * n + q) * (half + 1) + c;
+        buf[q * n + p] = bin_edit_bwd(buf[q * n + p], cf, nn, a.amp[o], a.pha[o], aw, ab, pw, pb, s_aw, s_ab, s_pw, s_pb);
     }
     __syncthreads();
     fft_pass<true, true>(buf, tw, n, lg);
