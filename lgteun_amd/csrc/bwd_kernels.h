@@ -15,6 +15,51 @@ struct WgradArgs {
     int ybf, xbf;          // operand storage: 0 fp32, 1 bf16 (hstore.h)
 };
 size_t wgrad_slab_floats(int N, int K, long P);
+// Parameter-gradient partial sums: every workgroup writes its partial to its own row of a scratch slab and a second tiny
+// kernel sums the rows in a fixed order.  (Float atomics onto the handful of parameter addresses serialise in L2 at
+// ~40 ns each: 2048 workgroups x one address was an 80 us tail on a 20 us kernel -- and the result was order-dependent.)
+#define PIXEL_PART_WGS 2048   // grid cap of the per-pixel backward kernels that emit partial rows
+size_t chan_partial_floats(int C, int B, int H, int W);   // k_dw_bwd / k_dstep_top_bwd scratch (upper bound)
+// dst_k[c * stride_k] (+)= sum over slices of part[(slice * C + c) * NK + k]; k in allc_mask: summed over c as well (dst_k[0])
+struct ChanReduce {
+    float* dst[14];
+    float* dst2[14];   // optional second destination of the same sum
+    int stride[14];
+    int NK, C, nslices;
+    unsigned allc_mask;
+};
+int launch_reduce_chan(const float* part, const ChanReduce& m, hipStream_t s);
+int launch_reduce_slab_pair(const float* slab_a, const float* slab_b, long nslices, int n, float* dst_a, float* dst_b, hipStream_t s);
+
+// Deferred reductions: while a ReduceQueue is active on the calling thread (reduce_queue_begin), launch_reduce_slab* /
+// launch_reduce_chan only RECORD their job; flush() sums all recorded slabs in ONE launch (blockIdx.y = job).  A backward
+// pass has ~60 of these tiny reductions (5 us of pure latency each).  Slabs must then stay untouched until the flush, so
+// producers take them from the queue's arena (take() flushes by itself when the arena or the job table is full).
+struct ReduceJob {
+    const float* slab;   // element (slice s, row r, col c) at slab[s * slice_stride + r * row_stride + c]
+    float* dst;          // dst[r * ld + c] += sum_s ...   for r < rows_valid, c < cols_valid
+    float* dst2;         // optional second destination
+    long nslices, slice_stride;
+    int rows, cols, row_stride, ld, rows_valid, cols_valid;
+};
+#define LG_MAX_REDUCE_JOBS 56
+struct ReduceJobTable {
+    ReduceJob j[LG_MAX_REDUCE_JOBS];
+    int n;
+};
+struct ReduceQueue {
+    float* arena;
+    size_t cap, off;   // floats
+    hipStream_t stream;
+    ReduceJobTable tab;
+    void init(float* base, size_t cap_floats, hipStream_t s) { arena = base; cap = cap_floats; off = 0; stream = s; tab.n = 0; }
+    float* take(size_t nfloats);   // nullptr (error set) when nfloats > cap
+    int push(const ReduceJob& j);
+    int flush();
+};
+bool reduce_chan_enqueue(const float* part, const ChanReduce& m, int* rc);
+void reduce_queue_begin(ReduceQueue* q);
+int reduce_queue_end();   // flushes and deactivates
 int launch_wgrad(const WgradArgs& a, float* slab, hipStream_t s);
 int launch_reduce_slab(const float* slab, long nslices, int rows, int cols, float* dst, int ld, int rows_valid, int cols_valid,
                        hipStream_t s);
@@ -25,8 +70,9 @@ struct DwBwdArgs {
     const float* in;    // conv input before resampling: [planes, hi, wi]; conv input = resample<MODE>(in)
     float* gin;         // [planes, n, n] gradient wrt the resampled conv input (dw^T gout)
     const float* w9;    // [C,1,3,3]
-    float* dw9;         // grads (+= atomics)
+    float* dw9;         // grads (+=)
     float* dbias;
+    float* part;        // scratch [workgroups][10] per-workgroup partial sums (chan_partial_floats)
     int C, planes, hi, wi, n_h, n_w;  // n_h x n_w = conv resolution
 };
 int launch_dw_bwd(int mode, const DwBwdArgs& a, hipStream_t s);
@@ -39,6 +85,7 @@ struct DstepTopArgs {
     float* dz;         // out: direct part of dZ_i = g + Rw[c]*dpr
     const float *w9, *b9, *rw, *rb, *rtw, *rtb, *eta;
     float *dw9, *dbias, *drw, *drb, *drtw, *drtb, *deta;
+    float* part;       // scratch [workgroups][14] per-workgroup partial sums (chan_partial_floats)
     int C, B, H, W;
 };
 int launch_dstep_top_bwd(const DstepTopArgs& a, hipStream_t s);
@@ -65,6 +112,7 @@ struct EmbedBwdArgs {
     float* tp;        // [P,16] padded conv input (wgrad operand)
     const float *dww, *dwb, *w, *b, *lng;
     float *d_dww, *d_dwb, *d_lng, *d_lnb;
+    float* part;      // scratch: per-workgroup partial sums, PIXEL_PART_WGS * (2E + 2C) floats
     int HW;
     long total;
 };
@@ -118,6 +166,7 @@ struct Ffn1BwdArgs {
     float* dx;         // [P,e] grad wrt x
     const float *w2t, *w1t, *ln2g, *ln2b;
     float *d_ln2g, *d_ln2b;
+    float* part;        // scratch: per-workgroup LN2 partial sums, PIXEL_PART_WGS * 2e floats
     long P;
     int hbf;           // hidden storage: 0 fp32, 1 bf16
 };
@@ -166,6 +215,7 @@ struct AttnBwdArgs {
     float* dpos_slab;   // [grid][2*64*64] partial pos_emb grads
     const float *ln1g, *ln1b, *qkvw, *qkvb, *projw;
     float *d_ln1g, *d_ln1b;
+    float* part;        // scratch: per-workgroup LN1 partial sums, PIXEL_PART_WGS * 2e floats
     int B, h, w;
 };
 int attn_bwd_grid(int e, int B, int h, int w);

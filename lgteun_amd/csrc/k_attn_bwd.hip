@@ -253,11 +253,10 @@ template <int E>
 __global__ __launch_bounds__(256) void k_attn_bwd_epi(AttnBwdArgs a, long total) {
     constexpr int HC = E / 2, DQLD = (3 * HC + 15) / 16 * 16;
     __shared__ float red[4 * 2 * E];
-    const long p = blockIdx.x * 256L + threadIdx.x;
     float pl[2 * E];
 #pragma unroll
     for (int i = 0; i < 2 * E; ++i) pl[i] = 0.f;
-    if (p < total) {
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < total; p += (long)gridDim.x * 256L) {
         const long hw = (long)a.h * a.w;
         const long b = p / hw, s = p - b * hw;
         float dqkv[3 * HC];
@@ -290,8 +289,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_epi(AttnBwdArgs a, long total)
 #pragma unroll
         for (int c = 0; c < E; ++c) {
             const float xh = (xv[c] - mu) * rstd;
-            pl[c] = dyf[c] * xh;
-            pl[E + c] = dyf[c];
+            pl[c] += dyf[c] * xh;
+            pl[E + c] += dyf[c];
             dyf[c] *= a.ln1g[c];
             m1 += dyf[c];
             m2 += dyf[c] * xh;
@@ -322,7 +321,9 @@ __global__ __launch_bounds__(256) void k_attn_bwd_epi(AttnBwdArgs a, long total)
     __syncthreads();
     if (threadIdx.x < 2 * E) {
         const float v = red[threadIdx.x] + red[2 * E + threadIdx.x] + red[4 * E + threadIdx.x] + red[6 * E + threadIdx.x];
-        if (threadIdx.x < E) atomicAdd(a.d_ln1g + threadIdx.x, v); else atomicAdd(a.d_ln1b + threadIdx.x - E, v);
+        // partial rows [grid][E] d gamma | [grid][E] d beta, summed by launch_reduce_slab_pair
+        if (threadIdx.x < E) a.part[blockIdx.x * (size_t)E + threadIdx.x] = v;
+        else a.part[(size_t)gridDim.x * E + blockIdx.x * (size_t)E + threadIdx.x - E] = v;
     }
 }
 
@@ -354,9 +355,12 @@ static int launch_attn_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
     k_attn_bwd_core<HC, NW><<<dim3(grid, 2), NW * 64, lds, s>>>(a, nwin, ngroups);
     LG_CHECK_LAUNCH();
     const long total = (long)a.B * a.h * a.w;
-    k_attn_bwd_epi<2 * HC><<<(int)((total + 255) / 256), 256, 0, s>>>(a, total);
+    if (!a.part) { lg_set_error("attn_bwd: partial-sum scratch missing"); return -2; }
+    const long nb = (total + 255) / 256;
+    const int egrid = (int)(nb < PIXEL_PART_WGS ? nb : PIXEL_PART_WGS);
+    k_attn_bwd_epi<2 * HC><<<egrid, 256, 0, s>>>(a, total);
     LG_CHECK_LAUNCH();
-    return 0;
+    return launch_reduce_slab_pair(a.part, a.part + (size_t)egrid * 2 * HC, egrid, 2 * HC, a.d_ln1g, a.d_ln1b, s);
 }
 
 int launch_attn_bwd(int e, const AttnBwdArgs& a, hipStream_t s) {

@@ -10,7 +10,10 @@ struct BwdBufs {
     float *dzA, *dzB, *gu3, *gs1, *gu1, *gr, *gd3, *gt1, *gd1;
     float *dx[3];
     float *doutp, *de, *tp, *dh2, *dh1, *y2, *do2, *dg, *dym, *cat, *y1, *dqkv, *dpos_slab;
-    float *w3t, *w2t, *w1t, *slab, *dt, *dskip, *v, *du, *fft_scratch;
+    float *w3t, *w2t, *w1t, *dt, *dskip, *v, *du, *fft_scratch;
+    float* slab_arena;    // scratch of the deferred parameter-gradient reductions (ReduceQueue, bwd_kernels.h)
+    size_t slab_cap;      // floats
+    ReduceQueue rq;
     size_t bytes;
 };
 
@@ -33,7 +36,16 @@ static void carve_bwd(const lg_plan* plan, int B, void* base, BwdBufs& bb) {
     size_t sl2 = wgrad_slab_floats(64, 64, (long)P0);
     size_t sl3 = ffn_dw_bwd_slab_floats((int)E, B, c.H, c.W);
     if (sl2 > sl) sl = sl2;
-    bb.slab = cv.take(sl > sl3 ? sl : sl3);
+    // per-workgroup partial-sum rows of the parameter-gradient reductions (bwd_kernels.h)
+    size_t sl4 = chan_partial_floats(c.C, B, c.H, c.W);
+    const size_t sl5 = (size_t)PIXEL_PART_WGS * (2 * 8 * c.C + 2 * c.C);
+    if (sl5 > sl4) sl4 = sl5;
+    if (sl4 > sl) sl = sl4;
+    // arena: one block's worth of slabs (dw-conv partials + the three FFN weight gradients + the small ones) between flushes;
+    // take() flushes by itself if a configuration needs more
+    if (sl3 > sl) sl = sl3;
+    bb.slab_cap = 4 * sl;
+    bb.slab_arena = cv.take(bb.slab_cap);
     bb.dt = cv.take(P0 * E); bb.dskip = cv.take(P0 * E); bb.v = cv.take(P1 * E); bb.du = cv.take(P1 * E);
     bb.bytes = cv.off;
 }
@@ -46,8 +58,19 @@ size_t bwd_workspace_bytes(const lg_plan* plan, int B) {
 
 #define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
+// deactivates the calling thread's reduce queue on every exit path (error returns included)
+struct ReduceQueueScope {
+    explicit ReduceQueueScope(BwdBufs& bb, hipStream_t s) {
+        bb.rq.init(bb.slab_arena, bb.slab_cap, s);
+        reduce_queue_begin(&bb.rq);
+    }
+    ~ReduceQueueScope() { (void)reduce_queue_end(); }
+};
+
 static int wgrad(const void* Y, int ldy, const void* X, int ldx, float* dW, int ldw, float* db, long P, int N, int K, int nv, int kv,
-                 int ybf, int xbf, float* slab, hipStream_t s) {
+                 int ybf, int xbf, BwdBufs& bb, hipStream_t s) {
+    float* slab = bb.rq.take(wgrad_slab_floats(N, K, P));
+    if (!slab) return -3;
     WgradArgs a;
     a.Y = Y; a.X = X; a.dW = dW; a.db = db; a.P = P; a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.N = N; a.K = K;
     a.n_valid = nv; a.k_valid = kv; a.ybf = ybf; a.xbf = xbf;
@@ -68,20 +91,23 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
     }
     FfnDwBwdArgs fd;
     fd.dy = dy; fd.g3 = fb.g3; fd.h2 = fb.h2; fd.dh2 = bb.dh2; fd.w3t = bb.w3t; fd.dww = P + pl->blk(st, j, B_DWW);
-    fd.slab_w = bb.slab; fd.slab_b = bb.slab + ffn_dw_bwd_slab_floats(e, B, fb.h, fb.w) / 10 * 9;
+    fd.slab_w = bb.rq.take(ffn_dw_bwd_slab_floats(e, B, fb.h, fb.w));
+    if (!fd.slab_w) return -3;
+    fd.slab_b = fd.slab_w + ffn_dw_bwd_slab_floats(e, B, fb.h, fb.w) / 10 * 9;
     fd.d_dww = G + pl->blk(st, j, B_DWW); fd.d_dwb = G + pl->blk(st, j, B_DWB);
     fd.B = B; fd.h = fb.h; fd.w = fb.w; fd.hbf = hbf;
     RC(launch_ffn_dw_bwd(e, fd, s));
-    RC(wgrad(dy, e, fb.a3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 0, hbf, bb.slab, s));
+    RC(wgrad(dy, e, fb.a3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 0, hbf, bb, s));
     Ffn1BwdArgs f1;
     f1.dh2 = bb.dh2; f1.g1 = fb.g1; f1.x = fb.xmid; f1.dy = dy; f1.dh1 = bb.dh1; f1.y2 = bb.y2; f1.dx = tmp;
     f1.w2t = bb.w2t; f1.w1t = bb.w1t;
     f1.ln2g = P + pl->blk(st, j, B_LN2G); f1.ln2b = P + pl->blk(st, j, B_LN2B);
-    f1.d_ln2g = G + pl->blk(st, j, B_LN2G); f1.d_ln2b = G + pl->blk(st, j, B_LN2B);
+    f1.d_ln2g = G + pl->blk(st, j, B_LN2G); f1.d_ln2b = G + pl->blk(st, j, B_LN2B); f1.part = bb.rq.take((size_t)PIXEL_PART_WGS * 2 * e);
+    if (!f1.part) return -3;
     f1.P = Pn; f1.hbf = hbf;
     RC(launch_ffn1_bwd(e, f1, s));
-    RC(wgrad(bb.dh2, n1, fb.a1, n1, G + pl->blk(st, j, B_W2), n1, G + pl->blk(st, j, B_B2), Pn, n1, n1, n1, n1, hbf, hbf, bb.slab, s));
-    RC(wgrad(bb.dh1, n1, bb.y2, e, G + pl->blk(st, j, B_W1), e, G + pl->blk(st, j, B_B1), Pn, n1, e, n1, e, hbf, 0, bb.slab, s));
+    RC(wgrad(bb.dh2, n1, fb.a1, n1, G + pl->blk(st, j, B_W2), n1, G + pl->blk(st, j, B_B2), Pn, n1, n1, n1, n1, hbf, hbf, bb, s));
+    RC(wgrad(bb.dh1, n1, bb.y2, e, G + pl->blk(st, j, B_W1), e, G + pl->blk(st, j, B_B1), Pn, n1, e, n1, e, hbf, 0, bb, s));
     return 0;
 }
 
@@ -116,22 +142,24 @@ static int mixer_half_bwd(const lg_plan* pl, const float* P, float* G, int st, i
     at.pos = P + pl->blk(st, j, B_POS); at.posT = posT; at.dpos_slab = bb.dpos_slab;
     at.ln1g = P + pl->blk(st, j, B_LN1G); at.ln1b = P + pl->blk(st, j, B_LN1B);
     at.qkvw = P + pl->blk(st, j, B_QKVW); at.qkvb = P + pl->blk(st, j, B_QKVB); at.projw = P + pl->blk(st, j, B_PROJW);
-    at.d_ln1g = G + pl->blk(st, j, B_LN1G); at.d_ln1b = G + pl->blk(st, j, B_LN1B);
+    at.d_ln1g = G + pl->blk(st, j, B_LN1G); at.d_ln1b = G + pl->blk(st, j, B_LN1B); at.part = bb.rq.take((size_t)PIXEL_PART_WGS * 2 * e);
+    if (!at.part) return -3;
     at.B = B; at.h = fb.h; at.w = fb.w;
     RC(launch_attn_bwd(e, at, s));
     const int grid = attn_bwd_grid(e, B, fb.h, fb.w);
     RC(launch_reduce_slab(bb.dpos_slab, grid, 1, 2 * 64 * 64, G + pl->blk(st, j, B_POS), 2 * 64 * 64, 1, 2 * 64 * 64, s));
-    RC(wgrad(dym, e, bb.cat, e, G + pl->blk(st, j, B_PROJW), e, G + pl->blk(st, j, B_PROJB), Pn, e, e, e, e, 0, 0, bb.slab, s));
+    RC(wgrad(dym, e, bb.cat, e, G + pl->blk(st, j, B_PROJW), e, G + pl->blk(st, j, B_PROJB), Pn, e, e, e, e, 0, 0, bb, s));
     const int y1ld = (hc + 15) / 16 * 16, dqld = (3 * hc + 15) / 16 * 16;
     RC(wgrad(bb.dqkv, dqld, bb.y1, y1ld, G + pl->blk(st, j, B_QKVW), hc, G + pl->blk(st, j, B_QKVB), Pn, dqld, y1ld, 3 * hc, hc, 0, 0,
-             bb.slab, s));
+             bb, s));
     return 0;
 }
 
 static int block_bwd(const lg_plan* pl, const float* P, float* G, int st, int j, const BlockBufs& fb, BwdBufs& bb, const float* posT,
                      const float* dy, float* tmp, float* dx_out, int B, int flags, uint64_t seed, hipStream_t s) {
     RC(ffn_half_bwd(pl, P, G, st, j, fb, bb, dy, tmp, B, s));
-    return mixer_half_bwd(pl, P, G, st, j, fb, bb, posT, tmp, dx_out, B, flags, seed, s);
+    RC(mixer_half_bwd(pl, P, G, st, j, fb, bb, posT, tmp, dx_out, B, flags, seed, s));
+    return bb.rq.flush();   // dpos_slab and the arena are reused by the next block
 }
 
 // per-op backward entry (tests): which 0: global mixer (dy, dx planar), 1: mixer half-block, 2: ffn half-block
@@ -142,8 +170,11 @@ int op_block_bwd(const lg_plan* pl, const float* P, float* G, int st, int j, int
     bb.fft_scratch = nb.fft_scratch;
     const BlockBufs& fb = nb.blk[j];
     if (which == 0) return fft_bwd_call(pl, P, G, st, j, fb, dy, dx, B, s, nb.fft_scratch);
-    if (which == 1) return mixer_half_bwd(pl, P, G, st, j, fb, bb, nb.posT, dy, dx, B, 0, 0, s);
-    return ffn_half_bwd(pl, P, G, st, j, fb, bb, dy, dx, B, s);
+    ReduceQueueScope rqs(bb, s);
+    const int rc = which == 1 ? mixer_half_bwd(pl, P, G, st, j, fb, bb, nb.posT, dy, dx, B, 0, 0, s)
+                              : ffn_half_bwd(pl, P, G, st, j, fb, bb, dy, dx, B, s);
+    const int rc2 = reduce_queue_end();
+    return rc ? rc : rc2;
 }
 
 static int data_step_bwd(const lg_plan* pl, const float* P, float* G, int st, const NetBufs& nb, BwdBufs& bb, const float* pan,
@@ -158,7 +189,8 @@ static int data_step_bwd(const lg_plan* pl, const float* P, float* G, int st, co
     t.dw9 = G + pl->shared(S_DT3W); t.dbias = G + pl->shared(S_DT3B);
     t.drw = G + pl->shared(S_RW); t.drb = G + pl->shared(S_RB); t.drtw = G + pl->shared(S_RTW); t.drtb = G + pl->shared(S_RTB);
     t.deta = G + pl->eta(st);
-    t.C = c.C; t.B = B; t.H = H; t.W = W;
+    t.C = c.C; t.B = B; t.H = H; t.W = W; t.part = bb.rq.take(chan_partial_floats(c.C, B, H, W));
+    if (!t.part) return -3;
     RC(launch_dstep_top_bwd(t, s));
     // s1 = dw(up(r)): grad wrt s1, then through the DT.1 conv
     RC(launch_resample_adj(1, bb.gu3, bb.gs1, planes, H / 2, W / 2, 0, s));
@@ -167,21 +199,27 @@ static int data_step_bwd(const lg_plan* pl, const float* P, float* G, int st, co
     d.gout = bb.gs1; d.in = nb.r[st]; d.gin = bb.gu1; d.w9 = P + pl->shared(S_DT1W);
     d.dw9 = G + pl->shared(S_DT1W); d.dbias = G + pl->shared(S_DT1B);
     d.hi = H / 4; d.wi = W / 4; d.n_h = H / 2; d.n_w = W / 2;
+    d.part = bb.rq.take(chan_partial_floats(c.C, B, H, W));
+    if (!d.part) return -3;
     RC(launch_dw_bwd(1, d, s));
     RC(launch_resample_adj(1, bb.gu1, bb.gr, planes, H / 4, W / 4, 0, s));
     // r = dw(down(t1)) - ms
     d.gout = bb.gr; d.in = nb.t1[st]; d.gin = bb.gd3; d.w9 = P + pl->shared(S_D3W);
     d.dw9 = G + pl->shared(S_D3W); d.dbias = G + pl->shared(S_D3B);
     d.hi = H / 2; d.wi = W / 2; d.n_h = H / 4; d.n_w = W / 4;
+    d.part = bb.rq.take(chan_partial_floats(c.C, B, H, W));
+    if (!d.part) return -3;
     RC(launch_dw_bwd(0, d, s));
     RC(launch_resample_adj(0, bb.gd3, bb.gt1, planes, H / 2, W / 2, 0, s));
     // t1 = dw(down(Z))
     d.gout = bb.gt1; d.in = nb.Z[st]; d.gin = bb.gd1; d.w9 = P + pl->shared(S_D1W);
     d.dw9 = G + pl->shared(S_D1W); d.dbias = G + pl->shared(S_D1B);
     d.hi = H; d.wi = W; d.n_h = H / 2; d.n_w = W / 2;
+    d.part = bb.rq.take(chan_partial_floats(c.C, B, H, W));
+    if (!d.part) return -3;
     RC(launch_dw_bwd(0, d, s));
     RC(launch_resample_adj(0, bb.gd1, dz, planes, H, W, 1, s));
-    return 0;
+    return bb.rq.flush();   // the K stages share these parameters: two stages' jobs must not meet in one reduce launch
 }
 
 int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, const float* pan, const float* dout, NetBufs& nb,
@@ -192,6 +230,7 @@ int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, c
     BwdBufs bb;
     carve_bwd(pl, B, bwd_ws, bb);
     bb.fft_scratch = nb.fft_scratch;
+    ReduceQueueScope rqs(bb, s);
     const long P0 = (long)B * c.H * c.W, P1 = P0 / 4;
     const float* posT = nb.posT + (size_t)st * 5 * 2 * 64 * 64;
     float *A = bb.dx[0], *Bf = bb.dx[1], *Cf = bb.dx[2];
@@ -203,7 +242,7 @@ int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, c
     tb.dout = dout; tb.dx = A; tb.doutp = bb.doutp; tb.dz = bb.dzA; tb.w = P + pl->lgt(st, L_TAILW);
     tb.HW = c.H * c.W; tb.total = P0;
     RC(launch_tail_bwd(c.C, tb, s));
-    RC(wgrad(bb.doutp, 16, nb.blk[4].xout, E, G + pl->lgt(st, L_TAILW), E, G + pl->lgt(st, L_TAILB), P0, 16, E, c.C, E, 0, 0, bb.slab, s));
+    RC(wgrad(bb.doutp, 16, nb.blk[4].xout, E, G + pl->lgt(st, L_TAILW), E, G + pl->lgt(st, L_TAILB), P0, 16, E, c.C, E, 0, 0, bb, s));
     RC(block_bwd(pl, P, G, st, 4, nb.blk[4], bb, posT + 4 * 8192, A, Bf, Cf, B, flags, seed, s));
     RC(block_bwd(pl, P, G, st, 3, nb.blk[3], bb, posT + 3 * 8192, Cf, Bf, A, B, flags, seed, s));
     // up + fusion
@@ -212,10 +251,10 @@ int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, c
     ub.fw = P + pl->lgt(st, L_FUSEW); ub.upw = P + pl->lgt(st, L_UPW);
     ub.B = B; ub.H = c.H; ub.W = c.W;
     RC(launch_upfuse_bwd_a(E, ub, s));
-    RC(wgrad(A, E, nb.t_up, E, G + pl->lgt(st, L_FUSEW), 2 * E, G + pl->lgt(st, L_FUSEB), P0, E, E, E, E, 0, 0, bb.slab, s));
-    RC(wgrad(A, E, nb.blk[1].xout, E, G + pl->lgt(st, L_FUSEW) + E, 2 * E, nullptr, P0, E, E, E, E, 0, 0, bb.slab, s));
+    RC(wgrad(A, E, nb.t_up, E, G + pl->lgt(st, L_FUSEW), 2 * E, G + pl->lgt(st, L_FUSEB), P0, E, E, E, E, 0, 0, bb, s));
+    RC(wgrad(A, E, nb.blk[1].xout, E, G + pl->lgt(st, L_FUSEW) + E, 2 * E, nullptr, P0, E, E, E, E, 0, 0, bb, s));
     RC(launch_upfuse_bwd_b(E, ub, s));
-    RC(wgrad(bb.v, E, nb.blk[2].xout, 2 * E, G + pl->lgt(st, L_UPW), 2 * E, G + pl->lgt(st, L_UPB), P1, E, 2 * E, E, 2 * E, 0, 0, bb.slab, s));
+    RC(wgrad(bb.v, E, nb.blk[2].xout, 2 * E, G + pl->lgt(st, L_UPW), 2 * E, G + pl->lgt(st, L_UPB), P1, E, 2 * E, E, 2 * E, 0, 0, bb, s));
     // bottleneck
     RC(block_bwd(pl, P, G, st, 2, nb.blk[2], bb, posT + 2 * 8192, Bf, Cf, A, B, flags, seed, s));
     // down
@@ -223,7 +262,7 @@ int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, c
     db.dy = A; db.du = bb.du; db.dskip = bb.dskip; db.dx = Bf; db.w = P + pl->lgt(st, L_DOWNW);
     db.B = B; db.H = c.H; db.W = c.W;
     RC(launch_down_bwd_a(E, db, s));
-    RC(wgrad(A, 2 * E, nb.u_down, E, G + pl->lgt(st, L_DOWNW), E, G + pl->lgt(st, L_DOWNB), P1, 2 * E, E, 2 * E, E, 0, 0, bb.slab, s));
+    RC(wgrad(A, 2 * E, nb.u_down, E, G + pl->lgt(st, L_DOWNW), E, G + pl->lgt(st, L_DOWNB), P1, 2 * E, E, 2 * E, E, 0, 0, bb, s));
     RC(launch_down_bwd_b(E, db, s));
     // encoder
     RC(block_bwd(pl, P, G, st, 1, nb.blk[1], bb, posT + 1 * 8192, Bf, Cf, A, B, flags, seed, s));
@@ -235,11 +274,12 @@ int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, c
     eb.lng = P + pl->lgt(st, L_PE_LNG);
     eb.d_dww = G + pl->lgt(st, L_PE_DWW); eb.d_dwb = G + pl->lgt(st, L_PE_DWB);
     eb.d_lng = G + pl->lgt(st, L_PE_LNG); eb.d_lnb = G + pl->lgt(st, L_PE_LNB);
-    eb.HW = c.H * c.W; eb.total = P0;
+    eb.HW = c.H * c.W; eb.total = P0; eb.part = bb.rq.take((size_t)PIXEL_PART_WGS * (2 * E + 2 * c.C));
+    if (!eb.part) return -3;
     RC(launch_embed_bwd(c.C, eb, s));
-    RC(wgrad(bb.de, E, bb.tp, 16, G + pl->lgt(st, L_PE_W), c.C, G + pl->lgt(st, L_PE_B), P0, E, 16, E, c.C, 0, 0, bb.slab, s));
+    RC(wgrad(bb.de, E, bb.tp, 16, G + pl->lgt(st, L_PE_W), c.C, G + pl->lgt(st, L_PE_B), P0, E, 16, E, c.C, 0, 0, bb, s));
     }
-    if (!do_data) return 0;
+    if (!do_data) return reduce_queue_end();
     // ---------------- K shared data steps, last to first (unlg_former.py:56-61); input gradient: bb.dzA
     float* g = bb.dzA;
     float* dz = bb.dzB;
@@ -247,5 +287,5 @@ int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, c
         RC(data_step_bwd(pl, P, G, i, nb, bb, pan, g, dz, B, s));
         float* t = g; g = dz; dz = t;
     }
-    return 0;
+    return reduce_queue_end();
 }

@@ -2,6 +2,8 @@
 // LGT tail / patch_embed / down / up+fusion.  Autograd of reference models/unlg_former.py:29-37,58-61 and
 // models/common/LGT.py:64-88,280-281,294-295,302-303.  Small parameter gradients (a few floats per tensor) are
 // reduced per workgroup and added with float atomics; all 1x1-conv weight gradients go through k_wgrad.hip.
+#include <string.h>
+
 #include "kernels.h"
 #include "bwd_kernels.h"
 
@@ -135,16 +137,58 @@ __global__ __launch_bounds__(256) void k_dw_bwd(DwBwdArgs a) {
         }
     }
     float r = block_sum<10>(part, red);
-    if (threadIdx.x < 9) atomicAdd(a.dw9 + c * 9 + threadIdx.x, r);
-    else if (threadIdx.x == 9) atomicAdd(a.dbias + c, r);
+    // partial row of this workgroup: slice = (sample, tile), then channel
+    const int tiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+    const size_t slice = (size_t)(plane / a.C) * tiles + tile;
+    if (threadIdx.x < 10) a.part[(slice * a.C + c) * 10 + threadIdx.x] = r;
 }
 
+// one wave per (channel, k): fixed summation order
+__global__ __launch_bounds__(64) void k_reduce_chan(const float* __restrict__ part, ChanReduce m) {
+    const int c = blockIdx.x / m.NK, k = blockIdx.x - c * m.NK, lane = threadIdx.x;
+    const bool allc = (m.allc_mask >> k) & 1u;
+    if (allc && c != 0) return;
+    const int c_end = allc ? m.C : c + 1;
+    float sv[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int cc = c; cc < c_end; ++cc) {
+        int i = lane;
+        for (; i + 192 < m.nslices; i += 256) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sv[u] += part[((size_t)(i + 64 * u) * m.C + cc) * m.NK + k];
+        }
+        for (; i < m.nslices; i += 64) sv[0] += part[((size_t)i * m.C + cc) * m.NK + k];
+    }
+    float t = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+    if (lane == 0) {
+        const int o = allc ? 0 : c * m.stride[k];
+        m.dst[k][o] += t;
+        if (m.dst2[k]) m.dst2[k][o] += t;
+    }
+}
+int launch_reduce_chan(const float* part, const ChanReduce& m, hipStream_t s) {
+    if (m.NK < 1 || m.NK > 14 || m.C < 1 || m.nslices < 1) { lg_set_error("reduce_chan: bad shape"); return -2; }
+    int qrc = 0;
+    if (reduce_chan_enqueue(part, m, &qrc)) return qrc;
+    k_reduce_chan<<<m.C * m.NK, 64, 0, s>>>(part, m);
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+size_t chan_partial_floats(int C, int B, int H, int W) { return (size_t)((H + 31) / 32) * ((W + 31) / 32) * B * C * 14; }
+
 int launch_dw_bwd(int mode, const DwBwdArgs& a, hipStream_t s) {
+    if (!a.part) { lg_set_error("dw_bwd: partial-sum scratch missing"); return -2; }
     dim3 grid((a.n_w + 31) / 32, (a.n_h + 31) / 32, a.planes);
     if (mode == 0) k_dw_bwd<0><<<grid, 256, 0, s>>>(a);
     else k_dw_bwd<1><<<grid, 256, 0, s>>>(a);
     LG_CHECK_LAUNCH();
-    return 0;
+    ChanReduce m;
+    memset(&m, 0, sizeof(m));
+    for (int k = 0; k < 9; ++k) { m.dst[k] = a.dw9 + k; m.stride[k] = 9; }
+    m.dst[9] = a.dbias; m.stride[9] = 1;
+    m.NK = 10; m.C = a.C; m.nslices = (int)(grid.x * grid.y) * (a.planes / a.C); m.allc_mask = 0;
+    return launch_reduce_chan(a.part, m, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -216,19 +260,26 @@ __global__ __launch_bounds__(256) void k_dstep_top_bwd(DstepTopArgs a) {
         }
     }
     float r = block_sum<14>(part, red);
-    if (threadIdx.x < 9) atomicAdd(a.dw9 + c * 9 + threadIdx.x, r);
-    else if (threadIdx.x == 9) { atomicAdd(a.dbias + c, r); atomicAdd(a.drtb + c, r); }
-    else if (threadIdx.x == 10) atomicAdd(a.deta, r);
-    else if (threadIdx.x == 11) atomicAdd(a.drtw + c, r);
-    else if (threadIdx.x == 12) atomicAdd(a.drw + c, r);
-    else if (threadIdx.x == 13) atomicAdd(a.drb, r);
+    const int tiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+    const size_t slice = (size_t)b * tiles + tile;
+    if (threadIdx.x < 14) a.part[(slice * a.C + c) * 14 + threadIdx.x] = r;
 }
 
 int launch_dstep_top_bwd(const DstepTopArgs& a, hipStream_t s) {
+    if (!a.part) { lg_set_error("dstep_top_bwd: partial-sum scratch missing"); return -2; }
     dim3 grid((a.W + 31) / 32, (a.H + 31) / 32, a.B * a.C);
     k_dstep_top_bwd<<<grid, 256, 0, s>>>(a);
     LG_CHECK_LAUNCH();
-    return 0;
+    ChanReduce m;
+    memset(&m, 0, sizeof(m));
+    for (int k = 0; k < 9; ++k) { m.dst[k] = a.dw9 + k; m.stride[k] = 9; }
+    m.dst[9] = a.dbias; m.dst2[9] = a.drtb; m.stride[9] = 1;   // d bias(DT.3) and d RT.bias
+    m.dst[10] = a.deta; m.stride[10] = 0;                        // summed over channels
+    m.dst[11] = a.drtw; m.stride[11] = 1;
+    m.dst[12] = a.drw; m.stride[12] = 1;
+    m.dst[13] = a.drb; m.stride[13] = 0;                         // summed over channels
+    m.NK = 14; m.C = a.C; m.nslices = (int)(grid.x * grid.y) * a.B; m.allc_mask = (1u << 10) | (1u << 13);
+    return launch_reduce_chan(a.part, m, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -285,14 +336,12 @@ template <int C, int E>
 __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
     __shared__ float red[4 * 2 * E];
     __shared__ float red2[4 * 2 * C];
-    long p = blockIdx.x * 256L + threadIdx.x;
-    const bool valid = p < a.total;
     float pl[2 * E], pc[2 * C];
 #pragma unroll
     for (int i = 0; i < 2 * E; ++i) pl[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < 2 * C; ++i) pc[i] = 0.f;
-    if (valid) {
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < a.total; p += (long)gridDim.x * 256L) {
         long b = p / a.HW, s = p - b * a.HW;
         float zc[C], t[C];
 #pragma unroll
@@ -318,8 +367,8 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
 #pragma unroll
         for (int n = 0; n < E; ++n) {
             const float xh = (e[n] - mu) * rstd;
-            pl[n] = dxh[n] * xh;      // d gamma
-            pl[E + n] = dxh[n];       // d beta
+            pl[n] += dxh[n] * xh;     // d gamma
+            pl[E + n] += dxh[n];      // d beta
             dxh[n] *= a.lng[n];
             m1 += dxh[n];
             m2 += dxh[n] * xh;
@@ -346,26 +395,34 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
             float dt = 0.f;
 #pragma unroll
             for (int n = 0; n < E; ++n) dt += a.w[n * C + c] * de[n];
-            pc[c] = dt * zc[c];   // d dww
-            pc[C + c] = dt;       // d dwb
+            pc[c] += dt * zc[c];   // d dww
+            pc[C + c] += dt;       // d dwb
             a.dz[(b * C + c) * a.HW + s] += dt * a.dww[c];
         }
     }
+    // partial rows: [grid][E] d gamma | [grid][E] d beta | [grid][C] d dww | [grid][C] d dwb
+    const size_t nwg = gridDim.x;
     float r = block_sum<2 * E>(pl, red);
-    if (threadIdx.x < E) atomicAdd(a.d_lng + threadIdx.x, r);
-    else if (threadIdx.x < 2 * E) atomicAdd(a.d_lnb + threadIdx.x - E, r);
+    if (threadIdx.x < E) a.part[blockIdx.x * (size_t)E + threadIdx.x] = r;
+    else if (threadIdx.x < 2 * E) a.part[nwg * E + blockIdx.x * (size_t)E + threadIdx.x - E] = r;
     float r2 = block_sum<2 * C>(pc, red2);
-    if (threadIdx.x < C) atomicAdd(a.d_dww + threadIdx.x, r2);
-    else if (threadIdx.x < 2 * C) atomicAdd(a.d_dwb + threadIdx.x - C, r2);
+    if (threadIdx.x < C) a.part[2 * nwg * E + blockIdx.x * (size_t)C + threadIdx.x] = r2;
+    else if (threadIdx.x < 2 * C) a.part[2 * nwg * E + nwg * C + blockIdx.x * (size_t)C + threadIdx.x - C] = r2;
 }
 
 int launch_embed_bwd(int C, const EmbedBwdArgs& a, hipStream_t s) {
-    int grid = (int)((a.total + 255) / 256);
+    if (!a.part) { lg_set_error("embed_bwd: partial-sum scratch missing"); return -2; }
+    long nb = (a.total + 255) / 256;
+    const int grid = (int)(nb < PIXEL_PART_WGS ? nb : PIXEL_PART_WGS);
+    const int E = 4 * C;
     if (C == 4) k_embed_bwd<4, 16><<<grid, 256, 0, s>>>(a);
     else if (C == 8) k_embed_bwd<8, 32><<<grid, 256, 0, s>>>(a);
     else { lg_set_error("embed_bwd: C=%d unsupported", C); return -1; }
     LG_CHECK_LAUNCH();
-    return 0;
+    const size_t g = (size_t)grid;
+    int rc = launch_reduce_slab_pair(a.part, a.part + g * E, grid, E, a.d_lng, a.d_lnb, s);
+    if (rc) return rc;
+    return launch_reduce_slab_pair(a.part + 2 * g * E, a.part + 2 * g * E + g * C, grid, C, a.d_dww, a.d_dwb, s);
 }
 
 // ------------------------------------------------------------------------------------------------

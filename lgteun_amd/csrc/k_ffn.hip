@@ -293,7 +293,9 @@ struct FfnFusedArgs {
 template <int E, bool SAVE, bool BF>
 __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int tiles_x, int tiles_y, int ntiles) {
     constexpr int N1 = 4 * E, TY = 8, TX = 16, HX = TX + 2, HY = TY + 2, NH = HX * HY /*180*/, MH = 192, M = TY * TX;
-    constexpr int LDA = E + 4, LDH = N1 + 4, LDO = E + 1, CQ = N1 / 4, NT3 = E / 16;
+    // LDA: at E = 16 the unpadded 64-byte row makes the A-fragment float4 reads one contiguous 1 KB (conflict-free) AND brings
+    // the workgroup under 80 KB of LDS, so two workgroups share a CU and one's MFMA phases overlap the other's GELU/LDS phases
+    constexpr int LDA = (E == 16 ? E : E + 4), LDH = N1 + 4, LDO = E + 1, CQ = N1 / 4, NT3 = E / 16;
     static_assert(CQ <= 64 && 64 % CQ == 0, "quad mapping");
     extern __shared__ float smem[];
     float* bufA = smem;                       // [MH][LDA]   LN2(x) on the halo tile; later [M][LDO] output tile
@@ -505,7 +507,7 @@ template <int E>
 static int launch_ffn_fused_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     ProfScope prof__(LG_K_FFN2, s);
     constexpr int N1 = 4 * E;
-    size_t lds = (size_t)(192 * (E + 4) + 180 * (N1 + 4) + 4 * 16 * (N1 + 4)) * sizeof(float);
+    size_t lds = (size_t)(192 * (E == 16 ? E : E + 4) + 180 * (N1 + 4) + 4 * 16 * (N1 + 4)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ffn_fused<E, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

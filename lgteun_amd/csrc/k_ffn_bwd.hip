@@ -355,7 +355,9 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a, long nchunks) {
     __syncthreads();
     if (threadIdx.x < 2 * E) {
         const float sv = red[threadIdx.x] + red[2 * E + threadIdx.x] + red[4 * E + threadIdx.x] + red[6 * E + threadIdx.x];
-        if (threadIdx.x < E) atomicAdd(a.d_ln2g + threadIdx.x, sv); else atomicAdd(a.d_ln2b + threadIdx.x - E, sv);
+        // partial rows [grid][E] d gamma | [grid][E] d beta, summed by launch_reduce_slab_pair
+        if (threadIdx.x < E) a.part[blockIdx.x * (size_t)E + threadIdx.x] = sv;
+        else a.part[(size_t)gridDim.x * E + blockIdx.x * (size_t)E + threadIdx.x - E] = sv;
     }
 }
 
@@ -374,10 +376,11 @@ static int launch_ffn1_bwd_t(const Ffn1BwdArgs& a, hipStream_t s) {
     long per_wg = 4L * MW;
     const long nchunks = (a.P + per_wg - 1) / per_wg;
     const int grid = (int)(nchunks < 1024 ? nchunks : 1024);   // persistent workgroups
+    if (!a.part) { lg_set_error("ffn1_bwd: partial-sum scratch missing"); return -2; }
     if (a.hbf) k_ffn1_bwd<E, MT, true><<<grid, 256, lds, s>>>(a, nchunks);
     else k_ffn1_bwd<E, MT, false><<<grid, 256, lds, s>>>(a, nchunks);
     LG_CHECK_LAUNCH();
-    return 0;
+    return launch_reduce_slab_pair(a.part, a.part + (size_t)grid * E, grid, E, a.d_ln2g, a.d_ln2b, s);
 }
 int launch_ffn1_bwd(int e, const Ffn1BwdArgs& a, hipStream_t s) {
     if (e == 16) return launch_ffn1_bwd_t<16, 1>(a, s);

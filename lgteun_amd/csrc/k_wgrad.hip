@@ -178,13 +178,117 @@ __global__ __launch_bounds__(256) void k_reduce_slab(const float* __restrict__ s
     }
 }
 
+// all queued jobs in one launch: blockIdx.y = job, same 16 outputs x 16 slice phases shape as k_reduce_slab
+__global__ __launch_bounds__(256) void k_reduce_jobs(ReduceJobTable t) {
+    __shared__ float part[16][17];
+    const ReduceJob& jb = t.j[blockIdx.y];
+    const long n = (long)jb.rows * jb.cols;
+    if (blockIdx.x * 16L >= n) return;
+    const int o = threadIdx.x & 15, ph = threadIdx.x >> 4;
+    const long i = blockIdx.x * 16L + o;
+    const int row = (int)(i / jb.cols), col = (int)(i - (long)row * jb.cols);
+    float sv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sv[u] = 0.f;
+    if (i < n) {
+        const float* __restrict__ src = jb.slab + (long)row * jb.row_stride + col;
+        const long ss = jb.slice_stride, ns = jb.nslices;
+        long k = ph;
+        for (; k + 16 * 7 < ns; k += 16 * 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sv[u] += src[(k + 16 * u) * ss];
+        }
+        for (; k < ns; k += 16) sv[0] += src[k * ss];
+    }
+    part[ph][o] = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
+    __syncthreads();
+    if (ph == 0 && i < n && row < jb.rows_valid && col < jb.cols_valid) {
+        float tsum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tsum += part[q][o];
+        jb.dst[(long)row * jb.ld + col] += tsum;
+        if (jb.dst2) jb.dst2[(long)row * jb.ld + col] += tsum;
+    }
+}
+
+static thread_local ReduceQueue* tl_rq = nullptr;
+void reduce_queue_begin(ReduceQueue* q) { tl_rq = q; }
+int reduce_queue_end() {
+    ReduceQueue* q = tl_rq;
+    tl_rq = nullptr;
+    return q ? q->flush() : 0;
+}
+int ReduceQueue::flush() {
+    off = 0;
+    if (tab.n == 0) return 0;
+    long nmax = 0;
+    for (int k = 0; k < tab.n; ++k) {
+        const long n = (long)tab.j[k].rows * tab.j[k].cols;
+        if (n > nmax) nmax = n;
+    }
+    dim3 grid((unsigned)((nmax + 15) / 16), (unsigned)tab.n);
+    k_reduce_jobs<<<grid, 256, 0, stream>>>(tab);
+    tab.n = 0;
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+int ReduceQueue::push(const ReduceJob& j) {
+    if (tab.n == LG_MAX_REDUCE_JOBS) {
+        // the slabs already handed out stay valid: only the table is drained (off is restored)
+        const size_t keep = off;
+        int rc = flush();
+        off = keep;
+        if (rc) return rc;
+    }
+    tab.j[tab.n++] = j;
+    return 0;
+}
+float* ReduceQueue::take(size_t nfloats) {
+    nfloats = (nfloats + 63) & ~(size_t)63;
+    if (nfloats > cap) { lg_set_error("reduce queue: slab of %zu floats exceeds the arena (%zu)", nfloats, cap); return nullptr; }
+    if (off + nfloats > cap && flush()) return nullptr;
+    float* p = arena + off;
+    off += nfloats;
+    return p;
+}
+
 static int launch_reduce_slab2(const float* slab, long nslices, int rows, int cols, float* dst, int ld, int rows_valid, int cols_valid,
                                const float* slab2, int n2, float* dst2, int n2_valid, hipStream_t s) {
+    if (tl_rq) {
+        ReduceJob j;
+        j.slab = slab; j.dst = dst; j.dst2 = nullptr; j.nslices = nslices; j.slice_stride = (long)rows * cols;
+        j.rows = rows; j.cols = cols; j.row_stride = cols; j.ld = ld; j.rows_valid = rows_valid; j.cols_valid = cols_valid;
+        int rc = tl_rq->push(j);
+        if (rc || !slab2) return rc;
+        j.slab = slab2; j.dst = dst2; j.slice_stride = n2; j.rows = 1; j.cols = n2; j.row_stride = n2; j.ld = n2; j.rows_valid = 1;
+        j.cols_valid = n2_valid;
+        return tl_rq->push(j);
+    }
     long n = (long)rows * cols;
     dim3 grid((unsigned)((n + 15) / 16), slab2 ? 2 : 1);
     k_reduce_slab<<<grid, 256, 0, s>>>(slab, nslices, rows, cols, dst, ld, rows_valid, cols_valid, slab2, n2, dst2, n2_valid);
     LG_CHECK_LAUNCH();
     return 0;
+}
+// per-channel partial rows (k_dw_bwd / k_dstep_top_bwd) as queue jobs; false when no queue is active
+bool reduce_chan_enqueue(const float* part, const ChanReduce& m, int* rc) {
+    if (!tl_rq) return false;
+    *rc = 0;
+    for (int k = 0; k < m.NK && !*rc; ++k) {
+        ReduceJob j;
+        j.slab = part + k; j.dst = m.dst[k]; j.dst2 = m.dst2[k]; j.cols = 1; j.cols_valid = 1;
+        if ((m.allc_mask >> k) & 1u) {
+            j.nslices = (long)m.nslices * m.C; j.slice_stride = m.NK; j.rows = 1; j.row_stride = 0; j.ld = 1; j.rows_valid = 1;
+        } else {
+            j.nslices = m.nslices; j.slice_stride = (long)m.C * m.NK; j.rows = m.C; j.row_stride = m.NK; j.ld = m.stride[k]; j.rows_valid = m.C;
+        }
+        *rc = tl_rq->push(j);
+    }
+    return true;
+}
+// two [nslices][n] vector slabs -> dst_a[n], dst_b[n] (+=) in one launch
+int launch_reduce_slab_pair(const float* slab_a, const float* slab_b, long nslices, int n, float* dst_a, float* dst_b, hipStream_t s) {
+    return launch_reduce_slab2(slab_a, nslices, 1, n, dst_a, n, 1, n, slab_b, n, dst_b, n, s);
 }
 int launch_reduce_slab(const float* slab, long nslices, int rows, int cols, float* dst, int ld, int rows_valid, int cols_valid,
                        hipStream_t s) {
