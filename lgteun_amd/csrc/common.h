@@ -99,6 +99,33 @@ __device__ __forceinline__ void gelu_both_f(float x, float& a, float& g) {
     a = x * cdf;
     g = cdf + x * (0.39894228040143267794f * ex);
 }
+// Two GELUs per instruction stream: the polynomial / scaling work on float2 ext-vectors compiles to v_pk_fma_f32 / v_pk_mul_f32
+// (gfx950 packed fp32), so a pair costs ~13 packed VALU slots + 4 transcendentals instead of 2 x (16 + 2).  Same formula and
+// constants as gelu_f (A&S 7.1.26 erfc), with the branch-free identity  x * Phi(x) = 0.5 x + |x| (0.5 - 0.5 erfc(|z|)).
+typedef float lg_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lg_v2f gelu2_core(lg_v2f x, lg_v2f& absx, lg_v2f& ex) {
+    absx = (lg_v2f){fabsf(x.x), fabsf(x.y)};
+    const lg_v2f az = absx * 0.70710678118654752440f;
+    const lg_v2f d = az * 0.3275911f + 1.0f;
+    const lg_v2f t = (lg_v2f){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const lg_v2f poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const lg_v2f m = az * az * -1.44269504088896340736f;   // -az^2 * log2(e)
+    ex = (lg_v2f){__builtin_amdgcn_exp2f(m.x), __builtin_amdgcn_exp2f(m.y)};   // exp(-x^2 / 2)
+    return poly * ex * -0.5f + 0.5f;                       // 0.5 - 0.5 erfc(|z|) = Phi(|x|) - 0.5
+}
+__device__ __forceinline__ lg_v2f gelu2_f(lg_v2f x) {
+    lg_v2f absx, ex;
+    const lg_v2f sv = gelu2_core(x, absx, ex);
+    return absx * sv + x * 0.5f;
+}
+// a = gelu(x), g = gelu'(x) = Phi(x) + x phi(x),  Phi(x) = 0.5 + copysign(Phi(|x|) - 0.5, x)
+__device__ __forceinline__ void gelu2_both_f(lg_v2f x, lg_v2f& a, lg_v2f& g) {
+    lg_v2f absx, ex;
+    const lg_v2f sv = gelu2_core(x, absx, ex);
+    a = absx * sv + x * 0.5f;
+    const lg_v2f cs = (lg_v2f){copysignf(sv.x, x.x), copysignf(sv.y, x.y)};
+    g = x * (ex * 0.39894228040143267794f) + (cs + 0.5f);
+}
 // d gelu / dx = Phi(x) + x * phi(x)
 __device__ __forceinline__ float gelu_grad_f(float x) {
     const float z = x * 0.70710678118654752440f;

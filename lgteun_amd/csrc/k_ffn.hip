@@ -374,16 +374,19 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
                 const int col = nc + nt * 16 + r;
                 const float bias = a1.b1[col];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float hh = acc[0][nt][v] + bias;
+                for (int v = 0; v < 4; v += 2) {   // packed pairs (v_pk_fma_f32)
+                    const lg_v2f hh = (lg_v2f){acc[0][nt][v] + bias, acc[0][nt][v + 1] + bias};
+                    lg_v2f av;
                     if (SAVE) {
-                        float av, gv;
-                        gelu_both_f(hh, av, gv);
-                        if (inner[v]) { HS<BF>::st1(a1.a1s, prow[v] * N1 + col, av); HS<BF>::st1(a1.g1s, prow[v] * N1 + col, gv); }
-                        my[(4 * g + v) * LDH + col] = av;
+                        lg_v2f gv;
+                        gelu2_both_f(hh, av, gv);
+                        if (inner[v]) { HS<BF>::st1(a1.a1s, prow[v] * N1 + col, av.x); HS<BF>::st1(a1.g1s, prow[v] * N1 + col, gv.x); }
+                        if (inner[v + 1]) { HS<BF>::st1(a1.a1s, prow[v + 1] * N1 + col, av.y); HS<BF>::st1(a1.g1s, prow[v + 1] * N1 + col, gv.y); }
                     } else {
-                        my[(4 * g + v) * LDH + col] = gelu_f(hh);
+                        av = gelu2_f(hh);
                     }
+                    my[(4 * g + v) * LDH + col] = av.x;
+                    my[(4 * g + v + 1) * LDH + col] = av.y;
                 }
             }
         }
@@ -442,16 +445,18 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
                 const int y = y0 + ty, x = x0 + tx;
                 float4 av;
                 if (SAVE) {
-                    float4 gv;
-                    gelu_both_f(acc.x, av.x, gv.x); gelu_both_f(acc.y, av.y, gv.y);
-                    gelu_both_f(acc.z, av.z, gv.z); gelu_both_f(acc.w, av.w, gv.w);
+                    lg_v2f a01, a23, g01, g23;
+                    gelu2_both_f((lg_v2f){acc.x, acc.y}, a01, g01);
+                    gelu2_both_f((lg_v2f){acc.z, acc.w}, a23, g23);
+                    av = make_float4(a01.x, a01.y, a23.x, a23.y);
                     if (y < h && x < w) {
                         const long o = ((b * h + y) * (long)w + x) * N1 + 4 * q;
                         HS<BF>::st4(a2.a3s, o, av);
-                        HS<BF>::st4(a2.g3s, o, gv);
+                        HS<BF>::st4(a2.g3s, o, make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
                 } else {
-                    av = make_float4(gelu_f(acc.x), gelu_f(acc.y), gelu_f(acc.z), gelu_f(acc.w));
+                    const lg_v2f a01 = gelu2_f((lg_v2f){acc.x, acc.y}), a23 = gelu2_f((lg_v2f){acc.z, acc.w});
+                    av = make_float4(a01.x, a01.y, a23.x, a23.y);
                 }
                 *reinterpret_cast<float4*>(my + mm * LDH + 4 * q) = av;
             }
@@ -626,17 +631,19 @@ __global__ __launch_bounds__(256) void k_ffn_fused_bf(Ffn1Args a1, Ffn2Args a2, 
                 const int col = nc + nt * 16 + r;
                 const float bias = a1.b1[col];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float hh = acc[0][nt][v] + bias;
-                    float av;
+                for (int v = 0; v < 4; v += 2) {   // packed pairs (v_pk_fma_f32)
+                    const lg_v2f hh = (lg_v2f){acc[0][nt][v] + bias, acc[0][nt][v + 1] + bias};
+                    lg_v2f av;
                     if (SAVE) {
-                        float gv;
-                        gelu_both_f(hh, av, gv);
-                        if (inner[v]) { HS<BF>::st1(a1.a1s, prow[v] * N1 + col, av); HS<BF>::st1(a1.g1s, prow[v] * N1 + col, gv); }
+                        lg_v2f gv;
+                        gelu2_both_f(hh, av, gv);
+                        if (inner[v]) { HS<BF>::st1(a1.a1s, prow[v] * N1 + col, av.x); HS<BF>::st1(a1.g1s, prow[v] * N1 + col, gv.x); }
+                        if (inner[v + 1]) { HS<BF>::st1(a1.a1s, prow[v + 1] * N1 + col, av.y); HS<BF>::st1(a1.g1s, prow[v + 1] * N1 + col, gv.y); }
                     } else {
-                        av = gelu_f(hh);
+                        av = gelu2_f(hh);
                     }
-                    my[(4 * g + v) * LDS16 + col] = (__bf16)av;
+                    my[(4 * g + v) * LDS16 + col] = (__bf16)av.x;
+                    my[(4 * g + v + 1) * LDS16 + col] = (__bf16)av.y;
                 }
             }
         }
@@ -696,16 +703,18 @@ __global__ __launch_bounds__(256) void k_ffn_fused_bf(Ffn1Args a1, Ffn2Args a2, 
                 const int y = y0 + ty, x = x0 + tx;
                 float4 av;
                 if (SAVE) {
-                    float4 gv;
-                    gelu_both_f(acc.x, av.x, gv.x); gelu_both_f(acc.y, av.y, gv.y);
-                    gelu_both_f(acc.z, av.z, gv.z); gelu_both_f(acc.w, av.w, gv.w);
+                    lg_v2f a01, a23, g01, g23;
+                    gelu2_both_f((lg_v2f){acc.x, acc.y}, a01, g01);
+                    gelu2_both_f((lg_v2f){acc.z, acc.w}, a23, g23);
+                    av = make_float4(a01.x, a01.y, a23.x, a23.y);
                     if (y < h && x < w) {
                         const long o = ((b * h + y) * (long)w + x) * N1 + 4 * q;
                         HS<BF>::st4(a2.a3s, o, av);
-                        HS<BF>::st4(a2.g3s, o, gv);
+                        HS<BF>::st4(a2.g3s, o, make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
                 } else {
-                    av = make_float4(gelu_f(acc.x), gelu_f(acc.y), gelu_f(acc.z), gelu_f(acc.w));
+                    const lg_v2f a01 = gelu2_f((lg_v2f){acc.x, acc.y}), a23 = gelu2_f((lg_v2f){acc.z, acc.w});
+                    av = make_float4(a01.x, a01.y, a23.x, a23.y);
                 }
                 *reinterpret_cast<bf16x4*>(my + mm * LDS16 + 4 * q) = (bf16x4){(__bf16)av.x, (__bf16)av.y, (__bf16)av.z, (__bf16)av.w};
             }
