@@ -28,7 +28,7 @@ PEAK_HBM_GBS = 8000.0
 PEAK_F32_MFMA_TFLOPS = 157.3
 
 # HBM bytes per launch from the PMC counters (profiles/, FETCH_SIZE x2 corrected + WRITE_SIZE; separate --pmc passes), per kernel
-TRAFFIC_BYTES = {'ffn': 233361138}   # k_ffn_fused, all launches of a step averaged (profiles/r01_bench_bs32_pmc_hbm.csv)
+TRAFFIC_BYTES = {'ffn': 233277537}   # k_ffn_fused, all launches of a step averaged (profiles/r01_bench_bs32_pmc_hbm.csv)
 
 C, K, H, B_PER_GPU = 4, 4, 128, 32
 E, P0 = 4 * C, H * H
@@ -116,6 +116,7 @@ def main():
     ap.add_argument('--prof-kernel', default='ffn', help='kernel timed live for the roofline object (default: the dominant one)')
     ap.add_argument('--mode', default='faithful', choices=['faithful', 'live'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-live', action='store_true', help='skip the live-mode side measurement (profiling runs)')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                     help="fp32: parity mode (default).  bf16: saved/hidden FFN activations of the backward stored as bf16")
     args = ap.parse_args()
@@ -182,7 +183,7 @@ def main():
     # side measurement (NOT `value`): the same train step with the K-1 dead LGT forwards skipped -- bit-identical outputs,
     # gradients and weights (tests/test_gpu_fullsize.py), i.e. what a user of this framework can run instead
     live = None
-    if args.mode == 'faithful' and world == 1:
+    if args.mode == 'faithful' and world == 1 and not args.no_live:
         net.mode = 'live'
         for _ in range(2):
             step()
