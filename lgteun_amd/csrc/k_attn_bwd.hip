@@ -45,25 +45,29 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
 #pragma unroll
     for (int i = 0; i < 64; ++i) dpacc[i] = 0.f;
 
+    // pixel of this lane in window `win` (row-major windows, row-major tokens)
+    auto pixel_of = [&](int win, long& b, long& s) -> long {
+        const int wx = win % nwx;
+        const int rr = win / nwx;
+        const int wy = rr % nwy;
+        b = rr / nwy;
+        const int y = wy * 8 + (lane >> 3), x = wx * 8 + (lane & 7);
+        s = (long)y * a.w + x;
+        return b * hw + s;
+    };
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int win = grp * NW + wave;
         const bool active = win < nwin;
         long p = 0;
         __syncthreads();
         if (active) {
-            const int wx = win % nwx;
-            const int rr = win / nwx;
-            const int wy = rr % nwy;
-            const long b = rr / nwy;
-            const int y = wy * 8 + (lane >> 3), x = wx * 8 + (lane & 7);
-            const long s = (long)y * a.w + x;
-            p = b * hw + s;
+            long b, s;
+            p = pixel_of(win, b, s);
             {
                 float xv[E];
-                const float4* src = reinterpret_cast<const float4*>(a.x + p * E);
 #pragma unroll
                 for (int k = 0; k < E / 4; ++k) {
-                    float4 v = src[k];
+                    const float4 v = reinterpret_cast<const float4*>(a.x + p * E)[k];
                     xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
                 }
                 float mu, rstd;
@@ -97,10 +101,9 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
             {
                 // dO = grad wrt this head's attention output channels = (proj^T dym)[hd*D : hd*D + D]
                 float dym[E];
-                const float4* ds = reinterpret_cast<const float4*>(a.dym + p * E);
 #pragma unroll
                 for (int k = 0; k < E / 4; ++k) {
-                    float4 v = ds[k];
+                    const float4 v = reinterpret_cast<const float4*>(a.dym + p * E)[k];
                     dym[4 * k] = v.x; dym[4 * k + 1] = v.y; dym[4 * k + 2] = v.z; dym[4 * k + 3] = v.w;
                 }
 #pragma unroll
@@ -153,21 +156,20 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
             float O[D];
 #pragma unroll
             for (int c = 0; c < D; ++c) O[c] = 0.f;
-            // D_i = sum_j P_ij dP_ij, summed the way softmax-backward does
-            float Dv = 0.f;
+            // D_i = sum_j P_ij dP_ij = dO_i . O_i  (dP_ij = dO_i . v_j): no second pass over V for it
 #pragma unroll
             for (int j = 0; j < 64; ++j) {
                 sc[j] *= inv;
-                float dP = 0.f;
 #pragma unroll
                 for (int c4 = 0; c4 < D / 4; ++c4) {
                     const float4 vv = vh[j * (D / 4) + c4];
                     O[4 * c4] += sc[j] * vv.x; O[4 * c4 + 1] += sc[j] * vv.y; O[4 * c4 + 2] += sc[j] * vv.z; O[4 * c4 + 3] += sc[j] * vv.w;
-                    dP += dOi[4 * c4] * vv.x + dOi[4 * c4 + 1] * vv.y + dOi[4 * c4 + 2] * vv.z + dOi[4 * c4 + 3] * vv.w;
                 }
-                Dv += sc[j] * dP;
                 if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
             }
+            float Dv = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) Dv += dOi[c] * O[c];
             asm volatile("" ::: "memory");   // re-read K_j / V_j from LDS below instead of keeping 64 x 2D values live
             float dqh[D];
 #pragma unroll
