@@ -57,6 +57,7 @@ struct ReduceQueue {
     int push(const ReduceJob& j);
     int flush();
 };
+int launch_reduce_slab_wb(const float* wslab, const float* bslab, long nslices, int rows, int cols, float* dW, int ld, float* db, hipStream_t s);
 bool reduce_chan_enqueue(const float* part, const ChanReduce& m, int* rc);
 void reduce_queue_begin(ReduceQueue* q);
 int reduce_queue_end();   // flushes and deactivates
@@ -167,9 +168,14 @@ struct Ffn1BwdArgs {
     const float *w2t, *w1t, *ln2g, *ln2b;
     float *d_ln2g, *d_ln2b;
     float* part;        // scratch: per-workgroup LN2 partial sums, PIXEL_PART_WGS * 2e floats
+    // e <= 32: the first conv's weight / bias gradient (dW1 = sum_p dh1 (x) LN2(x), db1 = sum_p dh1) is accumulated in this
+    // kernel (dh1 and LN2(x) are already on chip), so dh1 / y2 never go to HBM: w1slab = FFN1_BWD_WGS * (4e*e + 4e) floats
+    float *w1slab, *d_w1, *d_b1;
     long P;
     int hbf;           // hidden storage: 0 fp32, 1 bf16
 };
+#define FFN1_BWD_WGS 1024   // persistent grid cap of k_ffn1_bwd
+inline bool ffn1_bwd_fuses_w1(int e) { return e <= 32; }
 int launch_ffn1_bwd(int e, const Ffn1BwdArgs& a, hipStream_t s);
 int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[cols][rows]
 int launch_transpose3(const float* const* src, float* const* dst, const int* rows, const int* cols, int njobs, hipStream_t s);

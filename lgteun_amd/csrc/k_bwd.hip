@@ -105,9 +105,16 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
     f1.d_ln2g = G + pl->blk(st, j, B_LN2G); f1.d_ln2b = G + pl->blk(st, j, B_LN2B); f1.part = bb.rq.take((size_t)PIXEL_PART_WGS * 2 * e);
     if (!f1.part) return -3;
     f1.P = Pn; f1.hbf = hbf;
+    f1.w1slab = nullptr; f1.d_w1 = nullptr; f1.d_b1 = nullptr;
+    if (ffn1_bwd_fuses_w1(e)) {   // dW1 / db1 come out of k_ffn1_bwd itself
+        f1.w1slab = bb.rq.take((size_t)FFN1_BWD_WGS * ((size_t)n1 * e + n1));
+        if (!f1.w1slab) return -3;
+        f1.d_w1 = G + pl->blk(st, j, B_W1); f1.d_b1 = G + pl->blk(st, j, B_B1);
+    }
     RC(launch_ffn1_bwd(e, f1, s));
     RC(wgrad(bb.dh2, n1, fb.a1, n1, G + pl->blk(st, j, B_W2), n1, G + pl->blk(st, j, B_B2), Pn, n1, n1, n1, n1, hbf, hbf, bb, s));
-    RC(wgrad(bb.dh1, n1, bb.y2, e, G + pl->blk(st, j, B_W1), e, G + pl->blk(st, j, B_B1), Pn, n1, e, n1, e, hbf, 0, bb, s));
+    if (!ffn1_bwd_fuses_w1(e))
+        RC(wgrad(bb.dh1, n1, bb.y2, e, G + pl->blk(st, j, B_W1), e, G + pl->blk(st, j, B_B1), Pn, n1, e, n1, e, hbf, 0, bb, s));
     return 0;
 }
 

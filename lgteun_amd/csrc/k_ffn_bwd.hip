@@ -213,15 +213,26 @@ int launch_ffn_dw_bwd(int e, const FfnDwBwdArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------
 template <int E, int MT, bool BF>
-__global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a, long nchunks) {
-    constexpr int N1 = 4 * E, MW = 16 * MT, LDH = N1 + 4, LDO = E + 1, NTE = E / 16;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2 : 1))) void k_ffn1_bwd(Ffn1BwdArgs a, long nchunks) {
+    constexpr int N1 = 4 * E, MW = 16 * MT, LDH = N1 + 4, LDO = E + 1, NTE = E / 16, LDY = LDO;
     constexpr bool RB = (E == 16);
-    extern __shared__ float smem[];
+    constexpr bool FW1 = (E <= 32);   // dW1 / db1 accumulated here (bwd_kernels.h: ffn1_bwd_fuses_w1)
+    constexpr int NB1 = N1 / 64;      // 64-wide blocks of dh1 columns: element t of a float4 at column 4r feeds tile 4*nb + t
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float red[4 * 2 * E];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     float* bufD = smem + wave * (MW * (2 * LDH + LDO));   // [MW][LDH] dh2 rows
     float* bufD1 = bufD + MW * LDH;                        // [MW][LDH] dh1 rows
     float* bufO = bufD1 + MW * LDH;                        // [MW][LDO] d(LN2 output)
+    float* bufY = bufO;                                    // [MW][LDY] LN2(x), B operand of the dW1 tiles: dead before bufO is written
+    f32x4 acc1[FW1 ? 4 * NB1 : 1][FW1 ? NTE : 1];
+    float4 bs1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FW1) {
+#pragma unroll
+        for (int i = 0; i < 4 * NB1; ++i)
+#pragma unroll
+            for (int j = 0; j < NTE; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     float4 w2f[RB ? 4 : 1][RB ? 4 : 1];
     if (RB) load_bfrag<4, 4>(reinterpret_cast<float4(&)[4][4]>(w2f), a.w2t, N1);
     float pl[2 * E];
@@ -257,6 +268,16 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a, long nchunks) {
             dyr[k] = pv ? reinterpret_cast<const float4*>(a.dy + (p0 + lane) * E)[k] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    if (FW1 && lane < MW) {   // LN2(x) of this lane's pixel -> bufY (rows of pixels past the end are zero)
+        const bool pv = p0 + lane < a.P;
+        float xv[E];
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k) { xv[4 * k] = xr[k].x; xv[4 * k + 1] = xr[k].y; xv[4 * k + 2] = xr[k].z; xv[4 * k + 3] = xr[k].w; }
+        float mu, rstd;
+        ln_stats<E>(xv, mu, rstd);
+#pragma unroll
+        for (int c = 0; c < E; ++c) bufY[lane * LDY + c] = pv ? (xv[c] - mu) * rstd * a.ln2g[c] + a.ln2b[c] : 0.f;
+    }
     __syncthreads();
     // ---- dh1 = (dh2 W2) * g1
     for (int nc = 0; nc < N1; nc += 64) {
@@ -284,10 +305,31 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a, long nchunks) {
         const int m = i / (N1 / 4), k4 = i - m * (N1 / 4);
         const float4 t = *reinterpret_cast<const float4*>(bufD1 + m * LDH + 4 * k4);
         const float4 d = make_float4(t.x * g1r[it].x, t.y * g1r[it].y, t.z * g1r[it].z, t.w * g1r[it].w);
-        if (p0 + m < a.P) HS<BF>::st4(a.dh1, (p0 + m) * N1 + 4 * k4, d);
+        if (FW1) { bs1.x += d.x; bs1.y += d.y; bs1.z += d.z; bs1.w += d.w; }   // k4 = lane % (N1/4) is the same for every `it`
+        else if (p0 + m < a.P) HS<BF>::st4(a.dh1, (p0 + m) * N1 + 4 * k4, d);
         *reinterpret_cast<float4*>(bufD1 + m * LDH + 4 * k4) = d;
     }
     __syncthreads();
+    if (FW1) {
+        // ---- dW1[n][k] += sum_pixels dh1[p][n] * LN2(x)[p][k]: pixels are the MFMA K dimension (4 per step)
+#pragma unroll
+        for (int ks = 0; ks < MW / 4; ++ks) {
+            float4 af[NB1];
+            float bv[NTE];
+#pragma unroll
+            for (int nb = 0; nb < NB1; ++nb) af[nb] = *reinterpret_cast<const float4*>(bufD1 + (4 * ks + g) * LDH + nb * 64 + 4 * r);
+#pragma unroll
+            for (int kt = 0; kt < NTE; ++kt) bv[kt] = bufY[(4 * ks + g) * LDY + kt * 16 + r];
+#pragma unroll
+            for (int nb = 0; nb < NB1; ++nb) {
+                const float av[4] = {af[nb].x, af[nb].y, af[nb].z, af[nb].w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int kt = 0; kt < NTE; ++kt) acc1[4 * nb + t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[kt], acc1[4 * nb + t][kt], 0, 0, 0);
+            }
+        }
+    }
     // ---- d(LN2 out) = dh1 W1
     {
         f32x4 acc[MT][NTE];
@@ -341,7 +383,7 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a, long nchunks) {
                 yv[u] = xv[c] * a.ln2g[c] + a.ln2b[c];
             }
             dxo[k] = make_float4(dv.x + o[0], dv.y + o[1], dv.z + o[2], dv.w + o[3]);
-            y2o[k] = make_float4(yv[0], yv[1], yv[2], yv[3]);
+            if (!FW1) y2o[k] = make_float4(yv[0], yv[1], yv[2], yv[3]);
         }
     }
     }   // chunks of this workgroup
@@ -359,6 +401,40 @@ __global__ __launch_bounds__(256) void k_ffn1_bwd(Ffn1BwdArgs a, long nchunks) {
         if (threadIdx.x < E) a.part[blockIdx.x * (size_t)E + threadIdx.x] = sv;
         else a.part[(size_t)gridDim.x * E + blockIdx.x * (size_t)E + threadIdx.x - E] = sv;
     }
+    if (FW1) {
+        // the 4 waves' dW1 / db1 partials, summed in LDS in a fixed order -> one slab row per workgroup
+        float* rw = smem;   // [N1][E] + [N1]
+        __syncthreads();
+        // db1: lanes with equal lane % (N1/4) hold the same 4 columns
+        float4 b4 = bs1;
+#pragma unroll
+        for (int off = N1 / 4; off < 64; off <<= 1) {
+            b4.x += __shfl_xor(b4.x, off); b4.y += __shfl_xor(b4.y, off); b4.z += __shfl_xor(b4.z, off); b4.w += __shfl_xor(b4.w, off);
+        }
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int i = 0; i < 4 * NB1; ++i)
+#pragma unroll
+                    for (int kt = 0; kt < NTE; ++kt)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int n = (i >> 2) * 64 + 4 * (4 * g + v) + (i & 3), k = kt * 16 + r;
+                            rw[n * E + k] = (w == 0 ? 0.f : rw[n * E + k]) + acc1[i][kt][v];
+                        }
+                if (lane < N1 / 4) {
+                    float* rb = rw + N1 * E + 4 * lane;
+                    rb[0] = (w == 0 ? 0.f : rb[0]) + b4.x; rb[1] = (w == 0 ? 0.f : rb[1]) + b4.y;
+                    rb[2] = (w == 0 ? 0.f : rb[2]) + b4.z; rb[3] = (w == 0 ? 0.f : rb[3]) + b4.w;
+                }
+            }
+            __syncthreads();
+        }
+        float* wrow = a.w1slab + (size_t)blockIdx.x * (N1 * E);
+        for (int i = threadIdx.x; i < N1 * E; i += 256) wrow[i] = rw[i];
+        float* brow = a.w1slab + (size_t)gridDim.x * (N1 * E) + (size_t)blockIdx.x * N1;
+        for (int i = threadIdx.x; i < N1; i += 256) brow[i] = rw[N1 * E + i];
+    }
 }
 
 template <int E, int MT>
@@ -375,12 +451,16 @@ static int launch_ffn1_bwd_t(const Ffn1BwdArgs& a, hipStream_t s) {
     }
     long per_wg = 4L * MW;
     const long nchunks = (a.P + per_wg - 1) / per_wg;
-    const int grid = (int)(nchunks < 1024 ? nchunks : 1024);   // persistent workgroups
+    const int grid = (int)(nchunks < FFN1_BWD_WGS ? nchunks : FFN1_BWD_WGS);   // persistent workgroups
     if (!a.part) { lg_set_error("ffn1_bwd: partial-sum scratch missing"); return -2; }
+    if (ffn1_bwd_fuses_w1(E) && (!a.w1slab || !a.d_w1 || !a.d_b1)) { lg_set_error("ffn1_bwd: dW1 slab / destinations missing"); return -2; }
+    if (!ffn1_bwd_fuses_w1(E) && (!a.dh1 || !a.y2)) { lg_set_error("ffn1_bwd: dh1 / y2 outputs missing"); return -2; }
     if (a.hbf) k_ffn1_bwd<E, MT, true><<<grid, 256, lds, s>>>(a, nchunks);
     else k_ffn1_bwd<E, MT, false><<<grid, 256, lds, s>>>(a, nchunks);
     LG_CHECK_LAUNCH();
-    return launch_reduce_slab_pair(a.part, a.part + (size_t)grid * E, grid, E, a.d_ln2g, a.d_ln2b, s);
+    int rc = launch_reduce_slab_pair(a.part, a.part + (size_t)grid * E, grid, E, a.d_ln2g, a.d_ln2b, s);
+    if (rc || !ffn1_bwd_fuses_w1(E)) return rc;
+    return launch_reduce_slab_wb(a.w1slab, a.w1slab + (size_t)grid * N1 * E, grid, N1, E, a.d_w1, E, a.d_b1, s);
 }
 int launch_ffn1_bwd(int e, const Ffn1BwdArgs& a, hipStream_t s) {
     if (e == 16) return launch_ffn1_bwd_t<16, 1>(a, s);

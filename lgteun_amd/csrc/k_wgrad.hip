@@ -286,6 +286,10 @@ bool reduce_chan_enqueue(const float* part, const ChanReduce& m, int* rc) {
     }
     return true;
 }
+// [nslices][rows*cols] matrix slab + [nslices][rows] bias slab -> dW[rows][ld] , db[rows] (+=)
+int launch_reduce_slab_wb(const float* wslab, const float* bslab, long nslices, int rows, int cols, float* dW, int ld, float* db, hipStream_t s) {
+    return launch_reduce_slab2(wslab, nslices, rows, cols, dW, ld, rows, cols, bslab, rows, db, rows, s);
+}
 // two [nslices][n] vector slabs -> dst_a[n], dst_b[n] (+=) in one launch
 int launch_reduce_slab_pair(const float* slab_a, const float* slab_b, long nslices, int n, float* dst_a, float* dst_b, hipStream_t s) {
     return launch_reduce_slab2(slab_a, nslices, 1, n, dst_a, n, 1, n, slab_b, n, dst_b, n, s);
