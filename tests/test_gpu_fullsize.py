@@ -75,3 +75,44 @@ def test_dropout_training_mode_statistics():
     assert not torch.equal(ys[0], ys[1])
     rel = float((ys.mean(0) - y_eval).norm() / y_eval.norm())
     assert rel < 0.2, rel
+
+
+@pytest.mark.parametrize('drop', [False, True])
+def test_dropout_mask_is_a_function_of_seed_and_consistent_in_backward(drop):
+    """The counter-hash dropout mask depends only on (seed, stage, block, element): the same seed reproduces the forward bit
+    for bit, another seed changes it, and the backward applies the SAME mask.  The last check is a central-difference
+    directional derivative of sum(out * r) with the seed held fixed, along the proj bias of the LAST block: that bias enters
+    right behind the mask and everything downstream of it (FFN half-block, tail) is smooth, whereas a direction through any
+    FFT mixer is not differentiable numerically (torch.angle's branch cut makes the network piecewise continuous)."""
+    from gpu_helpers import make_module
+    from lgteun_amd.engine import LG_FLAG_DROPOUT, LG_FLAG_SAVE, LG_FLAG_FAITHFUL
+    net = make_module(4, 2)
+    eng = net.engine()
+    ms, pan, _ = (T(a).cuda() for a in dw.make_inputs(2, 4, 8, 8, seed=21, kind='smooth'))
+    flags = (LG_FLAG_DROPOUT if drop else 0) | LG_FLAG_SAVE | LG_FLAG_FAITHFUL
+    y1, saved = eng.forward_raw(ms, pan, flags, seed=1234)
+    y1 = y1.clone()
+    y2, _ = eng.forward_raw(ms, pan, flags, seed=1234)
+    assert torch.equal(y1, y2)
+    y3, _ = eng.forward_raw(ms, pan, flags, seed=1235)
+    assert torch.equal(y1, y3) != drop
+    gen = torch.Generator(device='cpu').manual_seed(5)
+    r = torch.randn(y1.shape, generator=gen).cuda()
+    _, saved = eng.forward_raw(ms, pan, flags, seed=1234)
+    g = torch.zeros_like(eng.flat)
+    eng.backward_raw(saved, r, g, flags, seed=1234)
+    i = [k for k in eng.live_idx if eng.names[k].endswith('fn.fn.proj.bias')][-1]   # last block of the last stage
+    o, n = eng.offsets[i], eng.params[i].numel()
+    d = torch.zeros_like(eng.flat)
+    d[o:o + n] = torch.randn(n, generator=gen).cuda()
+    base = eng.flat.clone()
+    eps = 1e-2
+    vals = []
+    for sgn in (+1.0, -1.0):
+        eng.flat.copy_(base + sgn * eps * d)
+        y, _ = eng.forward_raw(ms, pan, flags, seed=1234)
+        vals.append(float((y.double() * r.double()).sum()))
+    eng.flat.copy_(base)
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    an = float((g.double() * d.double()).sum())
+    assert abs(fd - an) <= 1e-2 * max(abs(fd), abs(an), 1e-6), (fd, an)
