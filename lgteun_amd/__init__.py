@@ -4,3 +4,4 @@ reference's MODELS-registry / nn.Module surface.  Compute = hand-written HIP ker
 from .builder import MODELS, build_model  # noqa: F401
 from .unlg_former import Pansharpening, UnlgFormer  # noqa: F401
 from .engine import Engine, FusedAdam, canonical_names  # noqa: F401
+from .dataset import DATASETS, PSDataset, PrefetchLoader, ShardedSampler, build_dataset, build_loader  # noqa: F401

@@ -155,29 +155,42 @@ class Base_model:
 
     @torch.no_grad()
     def test(self, iter_id, save=False, ref=True):
-        """reduced-resolution evaluation (base_model.py:267-352): PSNR / SAM / ERGAS mean +- std."""
+        """evaluation (base_model.py:267-352): ref=True -> reduced resolution, PSNR / SSIM / Q / SAM / ERGAS against the target;
+        ref=False -> full resolution, no-reference D_lambda / D_s / QNR against the LR MS and the PAN.  Stores
+        `<metric>_mean` / `<metric>_std` lists in self.eval_results like the reference and returns the latest values."""
         loader = self.test_data_loader1 if ref else self.test_data_loader0
         for module in self.module_dict.values():
             module.eval()
         dev = next(iter(self.module_dict.values())).parameters().__next__().device
+        names = ['PSNR', 'SSIM', 'Q', 'SAM', 'ERGAS'] if ref else ['D_lambda', 'D_s', 'QNR']
+        norm = self.cfg.get('norm_input', True)
+
+        def to_np(t):   # [b c h w] -> [b h w c] (PAN: [b h w])
+            t = data_denormalize(t, self.cfg.bit_depth) if norm else t
+            a = t.permute(0, 2, 3, 1).cpu().numpy()
+            return a[..., 0] if a.shape[-1] == 1 else a
         res = []
-        for input_batch in loader:
+        for input_batch in (loader or []):
             input_batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in input_batch.items()}
-            if self.cfg.get('norm_input', True):
+            if norm:
                 input_batch = data_normalize(input_batch, self.cfg.bit_depth)
-            out = self.get_model_output(input_batch)
-            out = data_denormalize(out, self.cfg.bit_depth).permute(0, 2, 3, 1).cpu().numpy()
+            out = to_np(self.get_model_output(input_batch))
             if ref:
-                gt = data_denormalize(input_batch['target'], self.cfg.bit_depth).permute(0, 2, 3, 1).cpu().numpy()
-                for i in range(out.shape[0]):
-                    res.append(mtc.ref_evaluate(out[i], gt[i]))
+                gt = to_np(input_batch['target'])
+                res.extend(mtc.ref_evaluate(out[i], gt[i]) for i in range(out.shape[0]))
+            else:
+                pan, lr = to_np(input_batch['input_pan']), to_np(input_batch['input_lr'])
+                res.extend(mtc.no_ref_evaluate(out[i], pan[i], lr[i]) for i in range(out.shape[0]))
+        latest = {}
         if res:
             res = np.array(res)
-            self.eval_results = dict(PSNR=(res[:, 0].mean(), res[:, 0].std()), SAM=(res[:, 1].mean(), res[:, 1].std()),
-                                     ERGAS=(res[:, 2].mean(), res[:, 2].std()))
+            for k, name in enumerate(names):
+                self.eval_results.setdefault(f'{name}_mean', []).append(round(float(res[:, k].mean()), 4))
+                self.eval_results.setdefault(f'{name}_std', []).append(round(float(res[:, k].std()), 4))
+                latest[name] = (float(res[:, k].mean()), float(res[:, k].std()))
             if self.logger is not None:
-                self.logger.info(f'iter {iter_id} eval: {self.eval_results}')
-        return self.eval_results
+                self.logger.info(f'iter {iter_id} {"low" if ref else "full"}-resolution eval: {latest}')
+        return latest
 
     def save(self, iter_id):
         """reference pickles whole module objects + iter_num (base_model.py:354-369); additionally stores the

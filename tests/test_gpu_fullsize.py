@@ -116,3 +116,30 @@ def test_dropout_mask_is_a_function_of_seed_and_consistent_in_backward(drop):
     fd = (vals[0] - vals[1]) / (2 * eps)
     an = float((g.double() * d.double()).sum())
     assert abs(fd - an) <= 1e-2 * max(abs(fd), abs(an), 1e-6), (fd, an)
+
+
+def test_prefetch_loader_stages_batches_on_the_device(tmp_path):
+    """lgteun_amd.dataset.PrefetchLoader: batches arrive on the GPU (copied from pinned memory on a side stream, `depth` ahead),
+    in order and bit-identical to the host batches; a forward pass consumes them directly"""
+    from gpu_helpers import make_module
+    from lgteun_amd import dataset as ds
+    rng = np.random.default_rng(0)
+    root = tmp_path / 'set'
+    root.mkdir()
+    for i in range(5):
+        ds.write_tiff(str(root / f'{i}_lr.tif'), rng.integers(0, 2048, (8, 8, 4)).astype(np.uint16))
+        ds.write_tiff(str(root / f'{i}_pan.tif'), rng.integers(0, 2048, (32, 32)).astype(np.uint16))
+        ds.write_tiff(str(root / f'{i}_mul.tif'), rng.integers(0, 2048, (32, 32, 4)).astype(np.uint16))
+    cfg = dict(dataset=dict(type='PSDataset', image_dirs=[str(root)], bit_depth=11, norm_input=True), batch_size=2, num_workers=0, shuffle=False)
+    host, _ = ds.build_loader(cfg)
+    dev, _ = ds.build_loader(cfg, device='cuda:0', prefetch_depth=2)
+    net = make_module(4, 2)
+    n = 0
+    for hb, db in zip(host, dev):
+        assert db['input_lr'].is_cuda and db['input_pan'].is_cuda and db['target'].is_cuda and db['image_id'] == hb['image_id']
+        assert torch.equal(db['input_lr'].cpu(), hb['input_lr']) and torch.equal(db['input_pan'].cpu(), hb['input_pan'])
+        with torch.no_grad():
+            y = net(db['input_lr'], db['input_pan'])
+        assert y.shape == db['target'].shape and torch.isfinite(y).all()
+        n += 1
+    assert n == 3
