@@ -13,6 +13,7 @@
 #include "kernels.h"
 #include "bwd_kernels.h"
 
+#define FFT_LD(n) ((n) + 1)   // row pitch (complex values) of a plane held in LDS, see fft_pass
 __device__ __forceinline__ float2 cmul(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
 __device__ __forceinline__ float2 cmulc(float2 a, float2 w) { return make_float2(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y); }
 
@@ -23,7 +24,7 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 w) { return make_float2
 // 3 times per 1-D transform (7 = 3 + 3 + 1 stages at n = 128) instead of 7.
 // Lines: `nlines` transforms of length n = 2^lg; element i of line l sits at buf[l * ls + i * es].
 // SKIP (square in-LDS planes only): lines are columns in bit-reversed kx order; columns with kx > n/2 are not needed.
-template <bool INVERSE, bool SKIP, int S>
+template <bool INVERSE, bool SKIP, int S, bool LINESFAST = false>
 __device__ __forceinline__ void fft_fused(float2* buf, const float2* tw, int lg, int lgnl, int ls, int es, int st) {
     const int nlines = 1 << lgnl;
     constexpr int R = 1 << S;
@@ -40,7 +41,7 @@ __device__ __forceinline__ void fft_fused(float2* buf, const float2* tw, int lg,
         if (SKIP) {
             if (it < (half << lgpl)) { t = it >> (lgnl - 1); line = 2 * (it & (half - 1)); }
             else { t = it - (half << lgpl); line = 1; }
-        } else if (es != 1) { t = it >> lgnl; line = it & (nlines - 1); }   // column transforms: consecutive threads -> consecutive lines
+        } else if (es != 1 || LINESFAST) { t = it >> lgnl; line = it & (nlines - 1); }   // consecutive threads -> consecutive lines
         else { line = it >> lgpl; t = it & ((1 << lgpl) - 1); }             // row transforms: consecutive threads -> consecutive items
         const int lo = t & (mL - 1), hi = t >> lgmL;
         const int i_base = (hi << (lgmL + S)) + lo;
@@ -78,18 +79,21 @@ __device__ __forceinline__ void fft_fused(float2* buf, const float2* tw, int lg,
 }
 
 // full 1-D transform of every line: stages grouped 3 + 3 + ... + remainder
-template <bool INVERSE, bool SKIP>
+template <bool INVERSE, bool SKIP, bool LINESFAST = false>
 __device__ __forceinline__ void fft_lines(float2* buf, const float2* tw, int lg, int lgnl, int ls, int es) {
     int st = 0;
-    while (lg - st >= 3) { fft_fused<INVERSE, SKIP, 3>(buf, tw, lg, lgnl, ls, es, st); st += 3; }
-    if (lg - st == 2) fft_fused<INVERSE, SKIP, 2>(buf, tw, lg, lgnl, ls, es, st);
-    else if (lg - st == 1) fft_fused<INVERSE, SKIP, 1>(buf, tw, lg, lgnl, ls, es, st);
+    while (lg - st >= 3) { fft_fused<INVERSE, SKIP, 3, LINESFAST>(buf, tw, lg, lgnl, ls, es, st); st += 3; }
+    if (lg - st == 2) fft_fused<INVERSE, SKIP, 2, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
+    else if (lg - st == 1) fft_fused<INVERSE, SKIP, 1, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
 }
-// square n x n plane resident in LDS (row-major): rows, or the kx <= n/2 columns
+// square n x n plane resident in LDS, row pitch ld = n + 1 complex values: rows, or the kx <= n/2 columns.  In BOTH directions
+// consecutive lanes take consecutive lines: for columns that is adjacent float2s, for rows a stride of n + 1 float2 = 2n + 2
+// dwords (= 2 mod 64) -- conflict-free ds_read_b64 / ds_write_b64.  (With pitch n and lanes walking along a row, the
+// radix-2 spans put 4..16 lanes on the same banks in every row pass.)
 template <bool INVERSE, bool COLS>
 __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int n, int lg) {
-    if (COLS) fft_lines<INVERSE, true>(buf, tw, lg, lg, 1, n);
-    else fft_lines<INVERSE, false>(buf, tw, lg, lg, n, 1);
+    if (COLS) fft_lines<INVERSE, true>(buf, tw, lg, lg, 1, FFT_LD(n));
+    else fft_lines<INVERSE, false, true>(buf, tw, lg, lg, FFT_LD(n), 1);
 }
 
 // amplitude / phase edit of one bin (LGT.py:168-177) and its backward, shared by the in-LDS and the split (256^2) paths
@@ -133,11 +137,11 @@ __device__ __forceinline__ void hermitian_extend(float2* buf, int n, int lg) {
         else { y = it - n * half; kx = half; }
         int p = (int)(__brev((unsigned)kx) >> (32 - lg));
         if (kx == 0 || kx == half) {
-            buf[y * n + p].y = 0.0f;
+            buf[y * FFT_LD(n) + p].y = 0.0f;
         } else {
             int pm = (int)(__brev((unsigned)(n - kx)) >> (32 - lg));
-            float2 v = buf[y * n + p];
-            buf[y * n + pm] = make_float2(v.x, -v.y);
+            float2 v = buf[y * FFT_LD(n) + p];
+            buf[y * FFT_LD(n) + pm] = make_float2(v.x, -v.y);
         }
     }
     __syncthreads();
@@ -152,11 +156,15 @@ __device__ __forceinline__ void half_bin(int it, int n, int lg, int& q, int& p, 
     else { q = it - n * half; c = half; p = 1; }
 }
 
-__global__ void k_fftmix(FftArgs a, int lg) {
+// LG = log2(n) is a template parameter: every shift / mask / stride of the (force-inlined) passes becomes an immediate and the
+// stage loops unroll -- about a third of the butterfly loops' instructions were runtime index arithmetic
+template <int LG>
+__global__ void k_fftmix(FftArgs a) {
     extern __shared__ float2 smem2[];
-    const int n = a.n, half = n >> 1;
-    float2* buf = smem2;          // [n][n]
-    float2* tw = smem2 + n * n;   // [n/2]  exp(-2 pi i k / n)
+    constexpr int lg = LG, n = 1 << LG, half = n >> 1;
+    constexpr int LD = FFT_LD(n);
+    float2* buf = smem2;          // [n][LD]
+    float2* tw = smem2 + n * LD;   // [n/2]  exp(-2 pi i k / n)
     const int plane = blockIdx.x;
     const int ch = plane % a.ch;
     const float* g = a.g + (size_t)plane * n * n;
@@ -164,14 +172,14 @@ __global__ void k_fftmix(FftArgs a, int lg) {
         float ang = 2.0f * (float)k / (float)n;
         tw[k] = make_float2(cospif(ang), 0.0f - sinpif(ang));
     }
-    for (int i = threadIdx.x; i < n * n; i += blockDim.x) buf[i] = make_float2(g[i], 0.0f);
+    for (int i = threadIdx.x; i < n * n; i += blockDim.x) buf[(i >> lg) * LD + (i & (n - 1))] = make_float2(g[i], 0.0f);
     __syncthreads();
     // ---- rfft2: rows then columns
     fft_pass<false, false>(buf, tw, n, lg);
-    for (int y = threadIdx.x; y < n; y += blockDim.x) { buf[y * n + 0].y = 0.0f; buf[y * n + 1].y = 0.0f; }  // kx = 0, n/2 are real
+    for (int y = threadIdx.x; y < n; y += blockDim.x) { buf[y * LD + 0].y = 0.0f; buf[y * LD + 1].y = 0.0f; }  // kx = 0, n/2 are real
     __syncthreads();
     fft_pass<false, true>(buf, tw, n, lg);
-    if (threadIdx.x < 4) buf[(threadIdx.x >> 1) * n + (threadIdx.x & 1)].y = 0.0f;  // the four purely-real bins
+    if (threadIdx.x < 4) buf[(threadIdx.x >> 1) * LD + (threadIdx.x & 1)].y = 0.0f;  // the four purely-real bins
     __syncthreads();
     // ---- amplitude / phase edit (LGT.py:168-177)
     const float aw = a.ampw[ch], ab = a.ampb[ch], pw = a.phaw[ch], pb = a.phab[ch];
@@ -179,13 +187,13 @@ __global__ void k_fftmix(FftArgs a, int lg) {
         int q, p, c;
         half_bin(it, n, lg, q, p, c);
         float amp, pha;
-        const float2 ed = bin_edit_fwd(buf[q * n + p], aw, ab, pw, pb, amp, pha);
+        const float2 ed = bin_edit_fwd(buf[q * LD + p], aw, ab, pw, pb, amp, pha);
         if (a.amp) {
             size_t o = ((size_t)plane * n + q) * (half + 1) + c;
             a.amp[o] = amp;
             a.pha[o] = pha;
         }
-        buf[q * n + p] = ed;
+        buf[q * LD + p] = ed;
     }
     __syncthreads();
     // ---- irfft2: columns (complex), Hermitian extension, rows
@@ -195,7 +203,7 @@ __global__ void k_fftmix(FftArgs a, int lg) {
     const float sc = 1.0f / ((float)n * (float)n);
     float* o = a.o + (size_t)plane * n * n;
     for (int i = threadIdx.x; i < n * n; i += blockDim.x) {
-        const float v = buf[i].x * sc;
+        const float v = buf[(i >> lg) * LD + (i & (n - 1))].x * sc;
         o[i] = fabsf(v);
         if (a.sgn) a.sgn[(size_t)plane * n * n + i] = (v > 0.f) ? 1.0f : ((v < 0.f) ? -1.0f : 0.0f);
     }
@@ -406,15 +414,21 @@ int launch_fftmix(const FftArgs& a, hipStream_t s) {
     while ((1 << lg) < n) ++lg;
     if ((1 << lg) != n || n < 8 || n > 512) { lg_set_error("fftmix: plane size %d unsupported (power of two, 8..512)", n); return -2; }
     if (n > 128) return launch_fft_split(&a, nullptr, s);
-    size_t lds = ((size_t)n * n + n / 2) * sizeof(float2);
+    size_t lds = ((size_t)n * FFT_LD(n) + n / 2) * sizeof(float2);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_fftmix, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_fftmix<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         if (e != hipSuccess) { lg_set_error("fftmix: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
     int threads = n >= 128 ? 1024 : (n >= 64 ? 512 : 256);
-    k_fftmix<<<a.planes, threads, lds, s>>>(a, lg);
+    switch (lg) {
+        case 3: k_fftmix<3><<<a.planes, threads, lds, s>>>(a); break;
+        case 4: k_fftmix<4><<<a.planes, threads, lds, s>>>(a); break;
+        case 5: k_fftmix<5><<<a.planes, threads, lds, s>>>(a); break;
+        case 6: k_fftmix<6><<<a.planes, threads, lds, s>>>(a); break;
+        default: k_fftmix<7><<<a.planes, threads, lds, s>>>(a); break;
+    }
     LG_CHECK_LAUNCH();
     return 0;
 }
@@ -425,11 +439,13 @@ int launch_fftmix(const FftArgs& a, hipStream_t s) {
 // through amp = |F|, pha = angle(F);  dg = Re sum_{kx<=n/2} dF e^{+i theta}  [adjoint of the r2c rfft2], which is the
 // same c2r machinery applied to dF * n^2 / c_kx.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_fftmix_bwd(FftBwdArgs a, int lg) {
+template <int LG>
+__global__ void k_fftmix_bwd(FftBwdArgs a) {
     extern __shared__ float2 smem2[];
-    const int n = a.n, half = n >> 1;
-    float2* buf = smem2;
-    float2* tw = smem2 + n * n;
+    constexpr int lg = LG, n = 1 << LG, half = n >> 1;
+    constexpr int LD = FFT_LD(n);
+    float2* buf = smem2;           // [n][LD]
+    float2* tw = smem2 + n * LD;
     float* red = reinterpret_cast<float*>(tw + half);  // [16][4]
     const int plane = blockIdx.x;
     const int ch = plane % a.ch;
@@ -438,7 +454,7 @@ __global__ void k_fftmix_bwd(FftBwdArgs a, int lg) {
         float ang = 2.0f * (float)k / (float)n;
         tw[k] = make_float2(cospif(ang), 0.0f - sinpif(ang));
     }
-    for (int i = threadIdx.x; i < n * n; i += blockDim.x) buf[i] = make_float2(a.do2[base + i] * a.sgn[base + i], 0.0f);
+    for (int i = threadIdx.x; i < n * n; i += blockDim.x) buf[(i >> lg) * LD + (i & (n - 1))] = make_float2(a.do2[base + i] * a.sgn[base + i], 0.0f);
     __syncthreads();
     fft_pass<false, false>(buf, tw, n, lg);
     fft_pass<false, true>(buf, tw, n, lg);
@@ -450,14 +466,14 @@ __global__ void k_fftmix_bwd(FftBwdArgs a, int lg) {
         half_bin(it, n, lg, q, p, c);
         const float cf = (c == 0 || c == half) ? 1.0f : 2.0f;
         const size_t o = ((size_t)plane * n + q) * (half + 1) + c;
-        buf[q * n + p] = bin_edit_bwd(buf[q * n + p], cf, nn, a.amp[o], a.pha[o], aw, ab, pw, pb, s_aw, s_ab, s_pw, s_pb);
+        buf[q * LD + p] = bin_edit_bwd(buf[q * LD + p], cf, nn, a.amp[o], a.pha[o], aw, ab, pw, pb, s_aw, s_ab, s_pw, s_pb);
     }
     __syncthreads();
     fft_pass<true, true>(buf, tw, n, lg);
     hermitian_extend(buf, n, lg);
     fft_pass<true, false>(buf, tw, n, lg);
     const float sc = 1.0f / nn;
-    for (int i = threadIdx.x; i < n * n; i += blockDim.x) a.dg[base + i] = buf[i].x * sc;
+    for (int i = threadIdx.x; i < n * n; i += blockDim.x) a.dg[base + i] = buf[(i >> lg) * LD + (i & (n - 1))].x * sc;
     // parameter gradient partials
     float v[4] = {s_aw, s_ab, s_pw, s_pb};
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
@@ -482,15 +498,21 @@ int launch_fftmix_bwd(const FftBwdArgs& a, hipStream_t s) {
     while ((1 << lg) < n) ++lg;
     if ((1 << lg) != n || n < 8 || n > 512) { lg_set_error("fftmix_bwd: plane size %d unsupported", n); return -2; }
     if (n > 128) return launch_fft_split(nullptr, &a, s);
-    size_t lds = ((size_t)n * n + n / 2) * sizeof(float2) + 64 * sizeof(float);
+    size_t lds = ((size_t)n * FFT_LD(n) + n / 2) * sizeof(float2) + 64 * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_fftmix_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_fftmix_bwd<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         if (e != hipSuccess) { lg_set_error("fftmix_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
     int threads = n >= 128 ? 1024 : (n >= 64 ? 512 : 256);
-    k_fftmix_bwd<<<a.planes, threads, lds, s>>>(a, lg);
+    switch (lg) {
+        case 3: k_fftmix_bwd<3><<<a.planes, threads, lds, s>>>(a); break;
+        case 4: k_fftmix_bwd<4><<<a.planes, threads, lds, s>>>(a); break;
+        case 5: k_fftmix_bwd<5><<<a.planes, threads, lds, s>>>(a); break;
+        case 6: k_fftmix_bwd<6><<<a.planes, threads, lds, s>>>(a); break;
+        default: k_fftmix_bwd<7><<<a.planes, threads, lds, s>>>(a); break;
+    }
     LG_CHECK_LAUNCH();
     return 0;
 }
