@@ -78,13 +78,21 @@ __device__ __forceinline__ void fft_fused(float2* buf, const float2* tw, int lg,
     __syncthreads();
 }
 
-// full 1-D transform of every line: stages grouped 3 + 3 + ... + remainder
+// full 1-D transform of every line in ceil(lg / 4) LDS passes of up to four fused radix-2 stages (16 points per thread in
+// registers): 7 = 4 + 3, 6 = 3 + 3, 8 = 4 + 4, 9 = 3 + 3 + 3.  Every pass costs one read and one write of the plane plus a
+// barrier, so at n = 128 a transform is 2 passes instead of the 3 of the (3, 3, 1) grouping.
 template <bool INVERSE, bool SKIP, bool LINESFAST = false>
 __device__ __forceinline__ void fft_lines(float2* buf, const float2* tw, int lg, int lgnl, int ls, int es) {
+    const int npass = (lg + 3) >> 2, base = lg / npass, extra = lg - base * npass;
     int st = 0;
-    while (lg - st >= 3) { fft_fused<INVERSE, SKIP, 3, LINESFAST>(buf, tw, lg, lgnl, ls, es, st); st += 3; }
-    if (lg - st == 2) fft_fused<INVERSE, SKIP, 2, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
-    else if (lg - st == 1) fft_fused<INVERSE, SKIP, 1, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
+    for (int ps = 0; ps < npass; ++ps) {
+        const int S = base + (ps < extra ? 1 : 0);
+        if (S == 4) fft_fused<INVERSE, SKIP, 4, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
+        else if (S == 3) fft_fused<INVERSE, SKIP, 3, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
+        else if (S == 2) fft_fused<INVERSE, SKIP, 2, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
+        else fft_fused<INVERSE, SKIP, 1, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
+        st += S;
+    }
 }
 // square n x n plane resident in LDS, row pitch ld = n + 1 complex values: rows, or the kx <= n/2 columns.  In BOTH directions
 // consecutive lanes take consecutive lines: for columns that is adjacent float2s, for rows a stride of n + 1 float2 = 2n + 2
