@@ -180,6 +180,7 @@ def main():
     tot_ms, n_l = ctypes.c_double(), ctypes.c_int64()
     _lib.check(L.lg_prof_read(ctypes.byref(tot_ms), ctypes.byref(n_l)), 'lg_prof_read')
     L.lg_prof_disable()
+    loss = float(eng._loss.item()) * world if world == 1 else None
     # side measurement (NOT `value`): the same train step with the K-1 dead LGT forwards skipped -- bit-identical outputs,
     # gradients and weights (tests/test_gpu_fullsize.py), i.e. what a user of this framework can run instead
     live = None
@@ -196,7 +197,25 @@ def main():
         dt = (time.perf_counter() - t1) / n_live
         live = dict(value=round(B_PER_GPU / dt, 2), ms_per_step=round(dt * 1e3, 3), note='dead-stage LGT forwards skipped; identical results')
         net.mode = args.mode
-    loss = float(eng._loss.item()) * world if world == 1 else None
+    # second side measurement (NOT `value`): BASELINE configs[1] names bf16 training.  The opt-in throughput mode (FFN GEMMs on
+    # the bf16 matrix cores with fp32 accumulation, bf16 storage of the tensors saved for the backward; everything else fp32)
+    # is gated against the fp32 mode in tests/test_gpu_backward.py (>= 50 dB PSNR, gradients within 2e-2); the headline stays
+    # the fp32 parity mode, which is what the 1e-3 output gate is stated for.
+    bf16 = None
+    if args.precision == 'fp32' and world == 1 and not args.no_live:
+        net.precision = 'bf16'
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_bf = max(5, args.steps // 2)
+        for _ in range(n_bf):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / n_bf
+        bf16 = dict(value=round(B_PER_GPU / dt, 2), ms_per_step=round(dt * 1e3, 3), mode=args.mode,
+                    note='precision="bf16" throughput mode: bf16 MFMA in the FFN forward + bf16 saved activations; PSNR vs fp32 mode >= 50 dB (tested)')
+        net.precision = 'fp32'
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -226,6 +245,8 @@ def main():
             out['final_loss'] = round(loss, 6)
         if live is not None:
             out['live_mode'] = live
+        if bf16 is not None:
+            out['bf16_mode'] = bf16
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(host_cores())
         print(json.dumps(out), flush=True)
