@@ -58,6 +58,8 @@ struct ReduceQueue {
     int flush();
 };
 int launch_reduce_slab_wb(const float* wslab, const float* bslab, long nslices, int rows, int cols, float* dW, int ld, float* db, hipStream_t s);
+// one job: recorded when a queue is active on this thread, otherwise summed right away on `s`
+int launch_reduce_job(const ReduceJob& j, hipStream_t s);
 bool reduce_chan_enqueue(const float* part, const ChanReduce& m, int* rc);
 void reduce_queue_begin(ReduceQueue* q);
 int reduce_queue_end();   // flushes and deactivates
@@ -202,8 +204,10 @@ struct FftBwdArgs {
     float* scratch;    // n > 128 only: half-spectrum scratch
     const float *ampw, *ampb, *phaw, *phab;
     float *d_ampw, *d_ampb, *d_phaw, *d_phab;
+    float* part;       // scratch: per-workgroup partial sums of the four parameter gradients, fft_bwd_part_floats()
     int planes, ch, n;
 };
+size_t fft_bwd_part_floats(int planes, int n);
 int launch_fftmix_bwd(const FftBwdArgs& a, hipStream_t s);
 
 struct AttnBwdArgs {

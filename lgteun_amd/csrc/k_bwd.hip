@@ -119,7 +119,7 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
 }
 
 static int fft_bwd_call(const lg_plan* pl, const float* P, float* G, int st, int j, const BlockBufs& fb, const float* do2, float* dg,
-                        int B, hipStream_t s, float* fft_scratch) {
+                        int B, hipStream_t s, float* fft_scratch, float* part) {
     const int hc = fb.e / 2;
     FftBwdArgs fa;
     fa.do2 = do2; fa.sgn = fb.sgn; fa.amp = fb.amp; fa.pha = fb.pha; fa.dg = dg; fa.scratch = fft_scratch;
@@ -127,7 +127,7 @@ static int fft_bwd_call(const lg_plan* pl, const float* P, float* G, int st, int
     fa.phaw = P + pl->blk(st, j, B_PHAW); fa.phab = P + pl->blk(st, j, B_PHAB);
     fa.d_ampw = G + pl->blk(st, j, B_AMPW); fa.d_ampb = G + pl->blk(st, j, B_AMPB);
     fa.d_phaw = G + pl->blk(st, j, B_PHAW); fa.d_phab = G + pl->blk(st, j, B_PHAB);
-    fa.ch = hc; fa.planes = B * hc; fa.n = fb.h;
+    fa.ch = hc; fa.planes = B * hc; fa.n = fb.h; fa.part = part;
     return launch_fftmix_bwd(fa, s);
 }
 
@@ -142,7 +142,9 @@ static int mixer_half_bwd(const lg_plan* pl, const float* P, float* G, int st, i
     po.HW = fb.h * fb.w; po.total = Pn; po.dropout = drop; po.seed = mix_seed(seed, st, j);
     RC(launch_proj_o2_bwd(e, po, s));
     const float* dym = drop ? bb.dym : tmp;
-    RC(fft_bwd_call(pl, P, G, st, j, fb, bb.do2, bb.dg, B, s, bb.fft_scratch));
+    float* fpart = bb.rq.take(fft_bwd_part_floats(B * hc, fb.h));
+    if (!fpart) return -3;
+    RC(fft_bwd_call(pl, P, G, st, j, fb, bb.do2, bb.dg, B, s, bb.fft_scratch, fpart));
     AttnBwdArgs at;
     at.x = fb.xin; at.dy = tmp; at.dym = dym; at.o2 = fb.o2; at.dg = bb.dg; at.dx = dx_out;
     at.cat = bb.cat; at.y1 = bb.y1; at.dqkv = bb.dqkv;
@@ -176,7 +178,7 @@ int op_block_bwd(const lg_plan* pl, const float* P, float* G, int st, int j, int
     carve_bwd(pl, B, bwd_ws, bb);
     bb.fft_scratch = nb.fft_scratch;
     const BlockBufs& fb = nb.blk[j];
-    if (which == 0) return fft_bwd_call(pl, P, G, st, j, fb, dy, dx, B, s, nb.fft_scratch);
+    if (which == 0) return fft_bwd_call(pl, P, G, st, j, fb, dy, dx, B, s, nb.fft_scratch, bb.slab_arena);   // no queue: summed at once
     ReduceQueueScope rqs(bb, s);
     const int rc = which == 1 ? mixer_half_bwd(pl, P, G, st, j, fb, bb, nb.posT, dy, dx, B, 0, 0, s)
                               : ffn_half_bwd(pl, P, G, st, j, fb, bb, dy, dx, B, s);

@@ -325,8 +325,8 @@ __global__ void k_fft_cols(FftArgs fa, FftBwdArgs ba, float2* __restrict__ S, in
         if (threadIdx.x < 4) {
             float sum = 0.f;
             for (int w = 0; w < nw; ++w) sum += red[w * 4 + threadIdx.x];
-            float* dst = threadIdx.x == 0 ? ba.d_ampw : (threadIdx.x == 1 ? ba.d_ampb : (threadIdx.x == 2 ? ba.d_phaw : ba.d_phab));
-            atomicAdd(dst + ch, sum);
+            // partial row [sample][column group][channel][4]: summed in a fixed order by launch_reduce_job (no float atomics)
+            ba.part[(((plane / chn) * gridDim.y + blockIdx.y) * chn + ch) * 4 + threadIdx.x] = sum;
         }
     }
 }
@@ -495,12 +495,32 @@ __global__ void k_fftmix_bwd(FftBwdArgs a) {
     if (threadIdx.x < 4) {
         float s = 0.f;
         for (int w = 0; w < nw; ++w) s += red[w * 4 + threadIdx.x];
-        float* dst = threadIdx.x == 0 ? a.d_ampw : (threadIdx.x == 1 ? a.d_ampb : (threadIdx.x == 2 ? a.d_phaw : a.d_phab));
-        atomicAdd(dst + ch, s);
+        a.part[(size_t)plane * 4 + threadIdx.x] = s;   // [sample][channel][4] partial row (plane = sample * ch + channel)
     }
 }
 
+static int fft_bwd_col_groups(int n) { return n > 128 ? (n / 2 + 1 + FFT_COLS_PER_WG(n) - 1) / FFT_COLS_PER_WG(n) : 1; }
+size_t fft_bwd_part_floats(int planes, int n) { return (size_t)planes * fft_bwd_col_groups(n) * 4; }
+// the four per-channel parameter gradients from the partial rows [sample][column group][channel][4]
+static int fft_bwd_reduce(const FftBwdArgs& a, hipStream_t s) {
+    float* dst[4] = {a.d_ampw, a.d_ampb, a.d_phaw, a.d_phab};
+    for (int k = 0; k < 4; ++k) {
+        ReduceJob j;
+        j.slab = a.part + k; j.dst = dst[k]; j.dst2 = nullptr;
+        j.nslices = (long)(a.planes / a.ch) * fft_bwd_col_groups(a.n); j.slice_stride = (long)a.ch * 4;
+        j.rows = a.ch; j.cols = 1; j.row_stride = 4; j.ld = 1; j.rows_valid = a.ch; j.cols_valid = 1;
+        int rc = launch_reduce_job(j, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+static int launch_fftmix_bwd_kernels(const FftBwdArgs& a, hipStream_t s);
 int launch_fftmix_bwd(const FftBwdArgs& a, hipStream_t s) {
+    if (!a.part) { lg_set_error("fftmix_bwd: partial-sum scratch missing"); return -2; }
+    int rc = launch_fftmix_bwd_kernels(a, s);
+    return rc ? rc : fft_bwd_reduce(a, s);
+}
+static int launch_fftmix_bwd_kernels(const FftBwdArgs& a, hipStream_t s) {
     ProfScope prof__(LG_K_FFT_BWD, s);
     int n = a.n, lg = 0;
     while ((1 << lg) < n) ++lg;

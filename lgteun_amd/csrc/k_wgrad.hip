@@ -270,6 +270,16 @@ static int launch_reduce_slab2(const float* slab, long nslices, int rows, int co
     LG_CHECK_LAUNCH();
     return 0;
 }
+int launch_reduce_job(const ReduceJob& j, hipStream_t s) {
+    if (tl_rq) return tl_rq->push(j);
+    ReduceJobTable t;
+    t.j[0] = j;
+    t.n = 1;
+    const long n = (long)j.rows * j.cols;
+    k_reduce_jobs<<<dim3((unsigned)((n + 15) / 16), 1), 256, 0, s>>>(t);
+    LG_CHECK_LAUNCH();
+    return 0;
+}
 // per-channel partial rows (k_dw_bwd / k_dstep_top_bwd) as queue jobs; false when no queue is active
 bool reduce_chan_enqueue(const float* part, const ChanReduce& m, int* rc) {
     if (!tl_rq) return false;
