@@ -312,6 +312,15 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
         load_bfrag<4, 1>(reinterpret_cast<float4(&)[4][1]>(w1f), a1.w1, E);
         load_bfrag<4, 4>(reinterpret_cast<float4(&)[4][4]>(w2f), a1.w2, N1);
     }
+    // e = 32: the weights do not fit one wave's registers (W2 alone is 64 KB), so P1 splits the OUTPUT COLUMNS across the four
+    // waves instead of the rows: wave w owns columns [32w, 32w + 32) of h1 and h2 for all 192 halo rows and keeps exactly its
+    // slices of W1 (16 VGPRs) and W2 (64 VGPRs) resident for the whole kernel -- no weight traffic in the tile loop
+    constexpr bool NS = (E == 32);
+    float4 w1p[NS ? 2 : 1][NS ? 2 : 1], w2p[NS ? 2 : 1][NS ? 8 : 1];
+    if (NS) {
+        load_bfrag<2, 2>(reinterpret_cast<float4(&)[2][2]>(w1p), a1.w1 + (size_t)(wave * 32) * E, E);
+        load_bfrag<2, 8>(reinterpret_cast<float4(&)[2][8]>(w2p), a1.w2 + (size_t)(wave * 32) * N1, N1);
+    }
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int t = tile;
@@ -349,6 +358,76 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
     }
     __syncthreads();
     // ---- P1: per wave, 3 chunks of 16 halo pixels: GEMM1 -> GELU -> GEMM2 -> h2 tile
+    if constexpr (NS) {
+        // four row blocks of 48 halo rows; per block: GEMM1 + GELU -> A2 (gelu(h1), shared by the waves) | barrier | GEMM2 -> h2 tile
+        float* A2 = scr;   // [48][LDH]
+        const int cw0 = wave * 32;
+        for (int rb = 0; rb < 4; ++rb) {
+            const int row0 = rb * 48;
+            long prow[3][4];
+            bool inner[3][4], inimg[3][4];
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int m = row0 + mt * 16 + 4 * g + v;
+                    const int hy = m / HX, hx = m - hy * HX;
+                    const int y = y0 + hy - 1, x = x0 + hx - 1;
+                    inimg[mt][v] = (m < NH) && y >= 0 && y < h && x >= 0 && x < w;
+                    inner[mt][v] = inimg[mt][v] && hy >= 1 && hy <= TY && hx >= 1 && hx <= TX;
+                    prow[mt][v] = (b * h + y) * (long)w + x;
+                }
+            f32x4 acc[3][2];
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            wave_gemm_rb<3, 2, 2>(acc, bufA + row0 * LDA, LDA, reinterpret_cast<const float4(&)[2][2]>(w1p));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int col = cw0 + nt * 16 + r;
+                const float bias = a1.b1[col];
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+                    for (int v = 0; v < 4; v += 2) {
+                        const lg_v2f hh = (lg_v2f){acc[mt][nt][v] + bias, acc[mt][nt][v + 1] + bias};
+                        lg_v2f av;
+                        if (SAVE) {
+                            lg_v2f gv;
+                            gelu2_both_f(hh, av, gv);
+                            if (inner[mt][v]) { HS<BF>::st1(a1.a1s, prow[mt][v] * N1 + col, av.x); HS<BF>::st1(a1.g1s, prow[mt][v] * N1 + col, gv.x); }
+                            if (inner[mt][v + 1]) { HS<BF>::st1(a1.a1s, prow[mt][v + 1] * N1 + col, av.y); HS<BF>::st1(a1.g1s, prow[mt][v + 1] * N1 + col, gv.y); }
+                        } else {
+                            av = gelu2_f(hh);
+                        }
+                        A2[(mt * 16 + 4 * g + v) * LDH + col] = av.x;
+                        A2[(mt * 16 + 4 * g + v + 1) * LDH + col] = av.y;
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            wave_gemm_rb<3, 2, 8>(acc, A2, LDH, reinterpret_cast<const float4(&)[2][8]>(w2p));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int col = cw0 + nt * 16 + r;
+                const float bias = a1.b2[col];
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int m = row0 + mt * 16 + 4 * g + v;
+                        const float hh = inimg[mt][v] ? acc[mt][nt][v] + bias : 0.f;   // dep_conv zero-pads h2
+                        if (SAVE && inner[mt][v]) HS<BF>::st1(a1.h2, prow[mt][v] * N1 + col, hh);
+                        if (m < NH) bufH2[m * LDH + col] = hh;
+                    }
+            }
+            __syncthreads();   // A2 is rewritten by the next row block
+        }
+    } else {
     for (int ch = 0; ch < 3; ++ch) {
         const int row0 = (wave * 3 + ch) * 16;
         // validity / global pixel index of the 4 rows this lane owns in the C layout
@@ -412,6 +491,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
     }
     __syncthreads();
     // ---- P2: per wave, 2 chunks of 16 inner pixels: dw3x3 + GELU -> scratch -> GEMM3 -> output tile (in bufA's space)
