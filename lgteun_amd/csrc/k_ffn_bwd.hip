@@ -185,8 +185,10 @@ static int launch_ffn_dw_bwd_t(const FfnDwBwdArgs& a, hipStream_t s) {
     ProfScope prof__(LG_K_FFN2_BWD, s);
     int tiles_x = (a.w + 15) / 16, tiles_y = (a.h + 7) / 8;
     const long nwg = ((long)a.B * tiles_x * tiles_y + DW_TPW - 1) / DW_TPW;
-    dim3 grid((unsigned)nwg, 4 * E / DW_CG);
-    constexpr int CG = DW_CG;
+    // channel group per workgroup: 32 at e = 16 (two groups); 64 from e = 32 up, where every extra group re-reads the dy halo tile
+    // and repeats the dy x W3 GEMM rows
+    constexpr int CG = (E >= 32 ? 64 : DW_CG);
+    dim3 grid((unsigned)nwg, 4 * E / CG);
     const size_t lds = (size_t)(192 * (E + 4) + 2 * 180 * (CG + 4) + 4 * (CG / 4) * 40) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {

@@ -16,12 +16,15 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--only', default='', help='substring of the configuration name (e.g. c3)')
     args = ap.parse_args()
     import lgteun_amd
     from gpu_helpers import make_module
     from lgteun_amd import FusedAdam
     cfgs = [('c2', 4, 128, 4, 32), ('c3', 8, 128, 4, 32), ('c5 (C=8)', 8, 256, 8, 16), ('c5 with C=4', 4, 256, 8, 16), ('512^2 PAN', 4, 512, 4, 4)]
     for name, C, H, K, B in cfgs:
+        if args.only and args.only not in name:
+            continue
         for mode in ('faithful', 'live'):
             net = make_module(C, K)
             net.mode = mode
