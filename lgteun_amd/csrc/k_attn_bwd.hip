@@ -146,7 +146,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                 }
                 sc[j] = t;
                 mx = fmaxf(mx, t);
-                if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+                if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("" ::: "memory");
             float l = 0.f;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                     const float4 vv = vh[j * (D / 4) + c4];
                     O[4 * c4] += sc[j] * vv.x; O[4 * c4 + 1] += sc[j] * vv.y; O[4 * c4 + 2] += sc[j] * vv.z; O[4 * c4 + 3] += sc[j] * vv.w;
                 }
-                if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+                if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
             float Dv = 0.f;
 #pragma unroll
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                 for (int c4 = 0; c4 < D / 4; ++c4) {
                     dqh[4 * c4] += dS * kv[c4].x; dqh[4 * c4 + 1] += dS * kv[c4].y; dqh[4 * c4 + 2] += dS * kv[c4].z; dqh[4 * c4 + 3] += dS * kv[c4].w;
                 }
-                if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+                if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
             float* co = a.cat + p * E + hd * D;
             float* dq_o = a.dqkv + p * DQLD + hd * D;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                 const float P = __expf(t - sv.x) * sv.y;
                 const float dS = P * (dP - sv.z);
                 dpacc[i] += dS;
-                if ((i & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int c4 = 0; c4 < D / 4; ++c4) {
                     dvh[4 * c4] += P * doi[c4].x; dvh[4 * c4 + 1] += P * doi[c4].y; dvh[4 * c4 + 2] += P * doi[c4].z; dvh[4 * c4 + 3] += P * doi[c4].w;
