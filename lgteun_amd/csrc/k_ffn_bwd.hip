@@ -44,7 +44,7 @@ int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream
 #define DW_CG 32   // channels per workgroup (depthwise work is per channel); 16 (3 workgroups per CU) measured no faster
 #define DW_TPW 8   // tiles walked by one workgroup (weight-gradient partials stay in registers across them)
 template <int E, bool BF, int CG>
-__global__ __launch_bounds__(256) void k_ffn_dw_bwd(FfnDwBwdArgs a, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2 : 1))) void k_ffn_dw_bwd(FfnDwBwdArgs a, int tiles_x, int tiles_y) {
     constexpr int N1 = 4 * E, TY = 8, TX = 16, HX = TX + 2, HY = TY + 2, NH = HX * HY, MH = 192, CQ = CG / 4, NTG = CG / 16;
     constexpr int LDY = E + 4, LDG = CG + 4;
     extern __shared__ float smem[];
@@ -67,7 +67,54 @@ __global__ __launch_bounds__(256) void k_ffn_dw_bwd(FfnDwBwdArgs a, int tiles_x,
 #pragma unroll
         for (int k = 0; k < 10; ++k) pw[u][k] = 0.f;
     const int ntiles = a.B * tiles_x * tiles_y;
-    for (int tile = blockIdx.x * DW_TPW; tile < (blockIdx.x + 1) * DW_TPW && tile < ntiles; ++tile) {
+    constexpr int NDY = MH * (E / 4) / 256;             // dy halo tile: float4 items per thread
+    constexpr int NG3 = (NH * CQ + 255) / 256;          // h2 / g3 halo tile: float4 items per thread
+    static_assert(MH * (E / 4) % 256 == 0, "dy tile items");
+    // PF (e = 16): the halo-tile loads were 60 % of a tile's time with nothing else in flight (in-kernel clock stamps), so the
+    // NEXT tile's dy / h2 / g3 are requested into registers right after the current tile's copies went to LDS, and land under
+    // the GEMM + depthwise phases.  The W3 fragments are register-resident for that: a weight load in the compute phases
+    // would make its s_waitcnt (one in-order counter) wait for the prefetch as well.
+    constexpr bool PF = (E == 16);
+    float4 w3r[PF ? NTG : 1][1];
+    if (PF) load_bfrag<NTG, 1>(reinterpret_cast<float4(&)[NTG][1]>(w3r), a.w3t + (size_t)c0 * E, E);
+    float4 dyr[NDY], h2r[NG3], g3n[NG3];
+    auto issue = [&](int tile_) {
+        int t_ = tile_;
+        const int tx_ = t_ % tiles_x;
+        t_ /= tiles_x;
+        const int ty_ = t_ % tiles_y;
+        const long b_ = t_ / tiles_y;
+        const int yb = ty_ * TY, xb = tx_ * TX;
+#pragma unroll
+        for (int it = 0; it < NDY; ++it) {
+            const int i = threadIdx.x + it * 256;
+            const int m = i / (E / 4), k4 = i - m * (E / 4);
+            const int hy = m / HX, hx = m - hy * HX;
+            const int y = yb + hy - 1, x = xb + hx - 1;
+            dyr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < NH && y >= 0 && y < h && x >= 0 && x < w) dyr[it] = *reinterpret_cast<const float4*>(a.dy + ((b_ * h + y) * (long)w + x) * E + 4 * k4);
+        }
+#pragma unroll
+        for (int it = 0; it < NG3; ++it) {
+            const int i = threadIdx.x + it * 256;
+            h2r[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            g3n[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < NH * CQ) {
+                const int m = i / CQ, qq = i - m * CQ;
+                const int hy = m / HX, hx = m - hy * HX;
+                const int y = yb + hy - 1, x = xb + hx - 1;
+                if (y >= 0 && y < h && x >= 0 && x < w) {
+                    const long o = ((b_ * h + y) * (long)w + x) * N1 + c0 + 4 * qq;
+                    h2r[it] = HS<BF>::ld4(a.h2, o);
+                    g3n[it] = HS<BF>::ld4(a.g3, o);
+                }
+            }
+        }
+    };
+    const int tile_first = blockIdx.x * DW_TPW;
+    const int tile_end = min((int)(blockIdx.x + 1) * DW_TPW, ntiles);
+    if (PF && tile_first < tile_end) issue(tile_first);
+    for (int tile = tile_first; tile < tile_end; ++tile) {
     int t = tile;
     const int tx_i = t % tiles_x;
     t /= tiles_x;
@@ -75,36 +122,26 @@ __global__ __launch_bounds__(256) void k_ffn_dw_bwd(FfnDwBwdArgs a, int tiles_x,
     const long b = t / tiles_y;
     const int y0 = ty_i * TY, x0 = tx_i * TX;
     __syncthreads();
-    // ---- P0: dy halo tile (all e channels) and h2 halo tile (this channel group)
-    for (int i = threadIdx.x; i < MH * (E / 4); i += 256) {
-        const int m = i / (E / 4), k4 = i - m * (E / 4);
-        const int hy = m / HX, hx = m - hy * HX;
-        const int y = y0 + hy - 1, x = x0 + hx - 1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < NH && y >= 0 && y < h && x >= 0 && x < w) v = *reinterpret_cast<const float4*>(a.dy + ((b * h + y) * (long)w + x) * E + 4 * k4);
-        *reinterpret_cast<float4*>(bufY + m * LDY + 4 * k4) = v;
-    }
-    // h2 and g3 of the halo tile are requested together (one exposed HBM round trip per tile instead of two);
-    // g3 waits in registers until the GEMM result is in LDS
-    constexpr int NG3 = (NH * CQ + 255) / 256;
+    // ---- P0: dy halo tile (all e channels) and h2 halo tile (this channel group) -> LDS; g3 stays in registers until the GEMM
+    // result is in LDS
+    if (!PF) issue(tile);
     float4 g3r[NG3];
+#pragma unroll
+    for (int it = 0; it < NDY; ++it) {
+        const int i = threadIdx.x + it * 256;
+        const int m = i / (E / 4), k4 = i - m * (E / 4);
+        *reinterpret_cast<float4*>(bufY + m * LDY + 4 * k4) = dyr[it];
+    }
 #pragma unroll
     for (int it = 0; it < NG3; ++it) {
         const int i = threadIdx.x + it * 256;
-        g3r[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        g3r[it] = g3n[it];
         if (i < NH * CQ) {
             const int m = i / CQ, qq = i - m * CQ;
-            const int hy = m / HX, hx = m - hy * HX;
-            const int y = y0 + hy - 1, x = x0 + hx - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (y >= 0 && y < h && x >= 0 && x < w) {
-                const long o = ((b * h + y) * (long)w + x) * N1 + c0 + 4 * qq;
-                v = HS<BF>::ld4(a.h2, o);
-                g3r[it] = HS<BF>::ld4(a.g3, o);
-            }
-            *reinterpret_cast<float4*>(bufH + m * LDG + 4 * qq) = v;
+            *reinterpret_cast<float4*>(bufH + m * LDG + 4 * qq) = h2r[it];
         }
     }
+    if (PF && tile + 1 < tile_end) issue(tile + 1);
     __syncthreads();
     // ---- P1: dh3 = (dy W3)[:, c0:c0+32] * g3 on the halo tile; wave owns 48 rows (3 m-tiles) x 2 n-tiles
     {
@@ -113,7 +150,8 @@ __global__ __launch_bounds__(256) void k_ffn_dw_bwd(FfnDwBwdArgs a, int tiles_x,
         for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTG; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        wave_gemm<3, NTG, E>(acc, bufY + wave * 48 * LDY, LDY, a.w3t + (size_t)c0 * E);
+        if (PF) wave_gemm_rb<3, NTG, 1>(acc, bufY + wave * 48 * LDY, LDY, reinterpret_cast<const float4(&)[NTG][1]>(w3r));
+        else wave_gemm<3, NTG, E>(acc, bufY + wave * 48 * LDY, LDY, a.w3t + (size_t)c0 * E);
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
