@@ -260,6 +260,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
     constexpr int NB1 = N1 / 64;      // 64-wide blocks of dh1 columns: element t of a float4 at column 4r feeds tile 4*nb + t
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float red[4 * 2 * E];
+    __shared__ float lnp[2 * E];   // LN2 gamma | beta: read from LDS in the loop (a global load there would stall on the prefetch)
+    if (threadIdx.x < E) { lnp[threadIdx.x] = a.ln2g[threadIdx.x]; lnp[E + threadIdx.x] = a.ln2b[threadIdx.x]; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     float* bufD = smem + wave * (MW * (2 * LDH + LDO));   // [MW][LDH] dh2 rows
     float* bufD1 = bufD + MW * LDH;                        // [MW][LDH] dh1 rows
@@ -273,41 +275,97 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
 #pragma unroll
             for (int j = 0; j < NTE; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    float4 w2f[RB ? 4 : 1][RB ? 4 : 1];
-    if (RB) load_bfrag<4, 4>(reinterpret_cast<float4(&)[4][4]>(w2f), a.w2t, N1);
-    float pl[2 * E];
+    // PF (e = 16): the chunk's loads (dh2, g1, x, dy) were ~58 % of a chunk's time with nothing else in flight (in-kernel
+    // clock stamps), so the NEXT chunk's operands are requested into registers as soon as the current ones are committed.
+    // For that no other vector-memory load may sit in the compute phases (one in-order s_waitcnt counter): W2^T lives in LDS
+    // (it would take 64 VGPRs as fragments, the prefetch needs them) and the W1^T fragments in 16 registers.
+    constexpr bool PF = RB;
+    float* w2l = smem + 4 * (MW * (2 * LDH + LDO));   // [N1][LDH] W2^T rows (PF)
+    if (PF) {
+        for (int i2 = threadIdx.x; i2 < N1 * (N1 / 4); i2 += 256) {
+            const int row = i2 / (N1 / 4), k4 = i2 - row * (N1 / 4);
+            *reinterpret_cast<float4*>(w2l + row * LDH + 4 * k4) = *reinterpret_cast<const float4*>(a.w2t + (size_t)row * N1 + 4 * k4);
+        }
+    }
+    float4 w1r[PF ? NTE : 1][PF ? N1 / 16 : 1];
+    if (PF) load_bfrag<NTE, N1 / 16>(reinterpret_cast<float4(&)[NTE][N1 / 16]>(w1r), a.w1t, N1);
+    // LN-gradient partials: PF: this lane's channel quarter (4 gamma + 4 beta); otherwise all 2E of the lane's pixel
+    constexpr int NPL = (E == 16) ? 8 : 2 * E;
+    float pl[NPL];
 #pragma unroll
-    for (int i = 0; i < 2 * E; ++i) pl[i] = 0.f;
-    // persistent: the workgroup walks row chunks (weights and LN-gradient partials stay in registers)
+    for (int i = 0; i < NPL; ++i) pl[i] = 0.f;
+    constexpr int NR = MW * (N1 / 4) / 64;
+    // PF: x / dy of the wave's 16 pixels are spread over all 64 lanes (lane = 4 * pixel + channel quarter: one float4 each,
+    // one coalesced 1 KB row per load) and the LayerNorm phases work 4 lanes per pixel; otherwise lane < MW owns a whole pixel
+    constexpr int NX = PF ? 1 : E / 4;
+    float4 dh2n[NR], g1n[NR], xn[NX], dyn[NX];
+    auto issue = [&](long chunk_) {
+        const long q0 = (chunk_ * 4 + wave) * MW;
+#pragma unroll
+        for (int it = 0; it < NR; ++it) {
+            const int i = lane + it * 64;
+            const int m = i / (N1 / 4), k4 = i - m * (N1 / 4);
+            dh2n[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            g1n[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q0 + m < a.P) {
+                dh2n[it] = HS<BF>::ld4(a.dh2, (q0 + m) * N1 + 4 * k4);
+                g1n[it] = HS<BF>::ld4(a.g1, (q0 + m) * N1 + 4 * k4);
+            }
+        }
+        if (PF) {
+            const bool pv = q0 + (lane >> 2) < a.P;
+            xn[0] = pv ? reinterpret_cast<const float4*>(a.x + (q0 + (lane >> 2)) * E)[lane & 3] : make_float4(0.f, 0.f, 0.f, 0.f);
+            dyn[0] = pv ? reinterpret_cast<const float4*>(a.dy + (q0 + (lane >> 2)) * E)[lane & 3] : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            const bool pv = lane < MW && q0 + lane < a.P;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                xn[k] = pv ? reinterpret_cast<const float4*>(a.x + (q0 + lane) * E)[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                dyn[k] = pv ? reinterpret_cast<const float4*>(a.dy + (q0 + lane) * E)[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    if (PF && (long)blockIdx.x < nchunks) issue(blockIdx.x);
+    // persistent: the workgroup walks row chunks (weights and LN-gradient partials stay in registers / LDS)
 #pragma unroll 1
     for (long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const long p0 = (chunk * 4 + wave) * MW;
     __syncthreads();
-    // all global operands of the chunk are requested up front (one exposed HBM round trip per chunk): dh2 -> LDS,
-    // g1 and the LayerNorm-phase rows (x, dy of pixel `lane`) wait in registers
-    constexpr int NR = MW * (N1 / 4) / 64;
+    // operands of the chunk: dh2 -> LDS, g1 and the LayerNorm-phase rows (x, dy of pixel `lane`) wait in registers
+    if (!PF) issue(chunk);
     float4 g1r[NR];
 #pragma unroll
     for (int it = 0; it < NR; ++it) {
         const int i = lane + it * 64;
         const int m = i / (N1 / 4), k4 = i - m * (N1 / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        g1r[it] = v;
-        if (p0 + m < a.P) {
-            v = HS<BF>::ld4(a.dh2, (p0 + m) * N1 + 4 * k4);
-            g1r[it] = HS<BF>::ld4(a.g1, (p0 + m) * N1 + 4 * k4);
-        }
-        *reinterpret_cast<float4*>(bufD + m * LDH + 4 * k4) = v;
+        g1r[it] = g1n[it];
+        *reinterpret_cast<float4*>(bufD + m * LDH + 4 * k4) = dh2n[it];
     }
-    float4 xr[E / 4], dyr[E / 4];
-    {
-        const bool pv = lane < MW && p0 + lane < a.P;
+    float4 xr[NX], dyr[NX];
 #pragma unroll
-        for (int k = 0; k < E / 4; ++k) {
-            xr[k] = pv ? reinterpret_cast<const float4*>(a.x + (p0 + lane) * E)[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-            dyr[k] = pv ? reinterpret_cast<const float4*>(a.dy + (p0 + lane) * E)[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
+    for (int k = 0; k < NX; ++k) { xr[k] = xn[k]; dyr[k] = dyn[k]; }
+    if (PF && chunk + (long)gridDim.x < nchunks) issue(chunk + (long)gridDim.x);
+    float mu_q = 0.f, rstd_q = 0.f;   // PF: LayerNorm statistics of this lane's pixel (kept for the backward phase)
+    if constexpr (PF) {
+        // 4 lanes per pixel: quarter sums joined by two xor-shuffles
+        const int px = lane >> 2, qd = lane & 3;
+        const bool pv = p0 + px < a.P;
+        const float4 xq = xr[0];
+        float sm = (xq.x + xq.y) + (xq.z + xq.w);
+        sm += __shfl_xor(sm, 1);
+        sm += __shfl_xor(sm, 2);
+        mu_q = sm * (1.0f / E);
+        const float d0 = xq.x - mu_q, d1 = xq.y - mu_q, d2 = xq.z - mu_q, d3 = xq.w - mu_q;
+        float vs = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        vs += __shfl_xor(vs, 1);
+        vs += __shfl_xor(vs, 2);
+        rstd_q = __builtin_amdgcn_rsqf(vs * (1.0f / E) + LG_EPS);
+        float* yrow = bufY + px * LDY + 4 * qd;
+        yrow[0] = pv ? d0 * rstd_q * lnp[4 * qd] + lnp[E + 4 * qd] : 0.f;
+        yrow[1] = pv ? d1 * rstd_q * lnp[4 * qd + 1] + lnp[E + 4 * qd + 1] : 0.f;
+        yrow[2] = pv ? d2 * rstd_q * lnp[4 * qd + 2] + lnp[E + 4 * qd + 2] : 0.f;
+        yrow[3] = pv ? d3 * rstd_q * lnp[4 * qd + 3] + lnp[E + 4 * qd + 3] : 0.f;
+    } else
     if (FW1 && lane < MW) {   // LN2(x) of this lane's pixel -> bufY (rows of pixels past the end are zero)
         const bool pv = p0 + lane < a.P;
         float xv[E];
@@ -316,7 +374,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
         float mu, rstd;
         ln_stats<E>(xv, mu, rstd);
 #pragma unroll
-        for (int c = 0; c < E; ++c) bufY[lane * LDY + c] = pv ? (xv[c] - mu) * rstd * a.ln2g[c] + a.ln2b[c] : 0.f;
+        for (int c = 0; c < E; ++c) bufY[lane * LDY + c] = pv ? (xv[c] - mu) * rstd * lnp[c] + lnp[E + c] : 0.f;
     }
     __syncthreads();
     // ---- dh1 = (dh2 W2) * g1
@@ -326,7 +384,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (RB) wave_gemm_rb<MT, 4, 4>(acc, bufD, LDH, reinterpret_cast<const float4(&)[4][4]>(w2f));
+        if (PF) wave_gemm_ld<MT, 4, N1>(acc, bufD, LDH, w2l + nc * LDH, LDH);
         else wave_gemm<MT, 4, N1>(acc, bufD, LDH, a.w2t + (size_t)nc * N1);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -377,7 +435,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTE; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        wave_gemm<MT, NTE, N1>(acc, bufD1, LDH, a.w1t);
+        if (PF) wave_gemm_rb<MT, NTE, N1 / 16>(acc, bufD1, LDH, reinterpret_cast<const float4(&)[NTE][N1 / 16]>(w1r));
+        else wave_gemm<MT, NTE, N1>(acc, bufD1, LDH, a.w1t);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -386,7 +445,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
                 for (int v = 0; v < 4; ++v) bufO[(mt * 16 + 4 * g + v) * LDO + nt * 16 + r] = acc[mt][nt][v];
     }
     __syncthreads();
-    // ---- LayerNorm backward + residual, LN2 parameter gradients (lane < MW: one pixel each)
+    // ---- LayerNorm backward + residual, LN2 parameter gradients
+    if constexpr (PF) {
+        const int px = lane >> 2, qd = lane & 3;
+        const bool pv = p0 + px < a.P;
+        const float4 xq = xr[0];
+        const float xh[4] = {(xq.x - mu_q) * rstd_q, (xq.y - mu_q) * rstd_q, (xq.z - mu_q) * rstd_q, (xq.w - mu_q) * rstd_q};
+        float dxh[4], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float dyl = pv ? bufO[px * LDO + 4 * qd + u] : 0.f;
+            pl[u] += dyl * xh[u];
+            pl[4 + u] += dyl;
+            dxh[u] = dyl * lnp[4 * qd + u];
+            m1 += dxh[u];
+            m2 += dxh[u] * xh[u];
+        }
+        m1 += __shfl_xor(m1, 1); m1 += __shfl_xor(m1, 2);
+        m2 += __shfl_xor(m2, 1); m2 += __shfl_xor(m2, 2);
+        m1 *= (1.0f / E);
+        m2 *= (1.0f / E);
+        if (pv) {
+            const float4 dv = dyr[0];
+            reinterpret_cast<float4*>(a.dx + (p0 + px) * E)[qd] =
+                make_float4(dv.x + rstd_q * (dxh[0] - m1 - xh[0] * m2), dv.y + rstd_q * (dxh[1] - m1 - xh[1] * m2),
+                            dv.z + rstd_q * (dxh[2] - m1 - xh[2] * m2), dv.w + rstd_q * (dxh[3] - m1 - xh[3] * m2));
+        }
+    } else
     if (lane < MW && p0 + lane < a.P) {
         const int m = lane;
         const long p = p0 + m;
@@ -403,7 +488,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
             const float dyl = bufO[m * LDO + c];
             pl[c] += dyl * xh;
             pl[E + c] += dyl;
-            dxh[c] = dyl * a.ln2g[c];
+            dxh[c] = dyl * lnp[c];
             m1 += dxh[c];
             m2 += dxh[c] * xh;
             xv[c] = xh;
@@ -420,19 +505,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
             for (int u = 0; u < 4; ++u) {
                 const int c = 4 * k + u;
                 o[u] = rstd * (dxh[c] - m1 - xv[c] * m2);
-                yv[u] = xv[c] * a.ln2g[c] + a.ln2b[c];
+                yv[u] = xv[c] * lnp[c] + lnp[E + c];
             }
             dxo[k] = make_float4(dv.x + o[0], dv.y + o[1], dv.z + o[2], dv.w + o[3]);
             if (!FW1) y2o[k] = make_float4(yv[0], yv[1], yv[2], yv[3]);
         }
     }
     }   // chunks of this workgroup
+    if constexpr (PF) {
 #pragma unroll
-    for (int i = 0; i < 2 * E; ++i) {
-        float sv = pl[i];
+        for (int i = 0; i < 8; ++i) {   // lanes with the same channel quarter (lane & 3) hold the same channels
+            float sv = pl[i];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sv += __shfl_xor(sv, off);
-        if (lane == 0) red[wave * 2 * E + i] = sv;
+            for (int off = 32; off >= 4; off >>= 1) sv += __shfl_xor(sv, off);
+            if (lane < 4) red[wave * 2 * E + (i >> 2) * E + 4 * lane + (i & 3)] = sv;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            float sv = pl[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sv += __shfl_xor(sv, off);
+            if (lane == 0) red[wave * 2 * E + i] = sv;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 2 * E) {
@@ -481,7 +576,7 @@ template <int E, int MT>
 static int launch_ffn1_bwd_t(const Ffn1BwdArgs& a, hipStream_t s) {
     ProfScope prof__(LG_K_FFN1_BWD, s);
     constexpr int N1 = 4 * E, MW = 16 * MT;
-    size_t lds = (size_t)4 * MW * (2 * (N1 + 4) + E + 1) * sizeof(float);
+    size_t lds = (size_t)(4 * MW * (2 * (N1 + 4) + E + 1) + (E == 16 ? N1 * (N1 + 4) : 0)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ffn1_bwd<E, MT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);

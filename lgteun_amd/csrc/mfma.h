@@ -31,6 +31,30 @@ __device__ __forceinline__ void wave_gemm(f32x4 (&acc)[MT][NT], const float* A, 
 }
 
 
+// same tile with the weight rows in LDS ([N][ldb], ldb = K + 4 keeps the 16-byte fragment reads conflict-free)
+template <int MT, int NT, int K>
+__device__ __forceinline__ void wave_gemm_ld(f32x4 (&acc)[MT][NT], const float* A, int lda, const float* Bl, int ldb) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+#pragma unroll 2
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        float4 av[MT], bv[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const float4*>(A + (mt * 16 + r) * lda + k0 + 4 * g);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float4*>(Bl + (nt * 16 + r) * ldb + k0 + 4 * g);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float a_ = ks == 0 ? av[mt].x : (ks == 1 ? av[mt].y : (ks == 2 ? av[mt].z : av[mt].w));
+                    const float b_ = ks == 0 ? bv[nt].x : (ks == 1 ? bv[nt].y : (ks == 2 ? bv[nt].z : bv[nt].w));
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, acc[mt][nt], 0, 0, 0);
+                }
+    }
+}
+
 // ---- register-resident weights: B fragments of a [N][K] row-major weight, loaded once and reused for every row chunk
 template <int NT, int KB>
 __device__ __forceinline__ void load_bfrag(float4 (&bf)[NT][KB], const float* __restrict__ Wg, int K) {
