@@ -36,6 +36,22 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
         sPos[ii * PLD + j] = a.pos[hd * 64 * 64 + i];
         sDpos[ii * PLD + j] = 0.f;
     }
+    // this head's slices of to_qkv (rows hd*D + c of each third) and of proj^T, once per workgroup: read as LDS broadcasts in the
+    // window prologue (as ~44 dependent vector loads per window they were most of the prologue, 44 % of the kernel)
+    __shared__ __attribute__((aligned(16))) float sWq[3 * D * HC];   // [q|k|v][c][k]
+    __shared__ __attribute__((aligned(16))) float sWp[D * E];        // [k][n] = projw[n][hd*D + k]
+    __shared__ float sBq[3 * D];
+    __shared__ float sLn[2 * HC];   // LN1 gamma | beta of the local half
+    if (threadIdx.x < HC) { sLn[threadIdx.x] = a.ln1g[threadIdx.x]; sLn[HC + threadIdx.x] = a.ln1b[threadIdx.x]; }
+    for (int i = threadIdx.x; i < 3 * D * HC; i += NW * 64) {
+        const int t3 = i / (D * HC), rem = i - t3 * (D * HC);
+        sWq[i] = a.qkvw[(size_t)(t3 * HC + hd * D) * HC + rem];
+    }
+    for (int i = threadIdx.x; i < D * E; i += NW * 64) {
+        const int k = i / E, n = i - k * E;
+        sWp[i] = a.projw[n * E + hd * D + k];
+    }
+    if (threadIdx.x < 3 * D) sBq[threadIdx.x] = a.qkvb[(threadIdx.x / D) * HC + hd * D + threadIdx.x % D];
     const int nwx = a.w >> 3, nwy = a.h >> 3;
     const long hw = (long)a.h * a.w;
     const float scale = (float)(1.0 / sqrt((double)D));
@@ -63,18 +79,31 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
         if (active) {
             long b, s;
             p = pixel_of(win, b, s);
+            // every global operand of the prologue is requested here, in one batch: x, dym and (head 0) the planar FFT-mixer half
+            // used to be three dependent HBM round trips
+            float4 xq4[E / 4], dq4[E / 4];
+            float o2v[HC];
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) {
+                xq4[k] = reinterpret_cast<const float4*>(a.x + p * E)[k];
+                dq4[k] = reinterpret_cast<const float4*>(a.dym + p * E)[k];
+            }
+            if (hd == 0) {
+#pragma unroll
+                for (int c = 0; c < HC; ++c) o2v[c] = a.o2[(b * HC + c) * hw + s];
+            }
             {
                 float xv[E];
 #pragma unroll
                 for (int k = 0; k < E / 4; ++k) {
-                    const float4 v = reinterpret_cast<const float4*>(a.x + p * E)[k];
+                    const float4 v = xq4[k];
                     xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
                 }
                 float mu, rstd;
                 ln_stats<E>(xv, mu, rstd);
                 float y1[HC];
 #pragma unroll
-                for (int c = 0; c < HC; ++c) y1[c] = (xv[c] - mu) * rstd * a.ln1g[c] + a.ln1b[c];
+                for (int c = 0; c < HC; ++c) y1[c] = (xv[c] - mu) * rstd * sLn[c] + sLn[HC + c];
                 if (hd == 0) {
                     float4* y1o = reinterpret_cast<float4*>(a.y1 + p * Y1LD);
 #pragma unroll
@@ -83,19 +112,18 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                                               : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 // this head's q, k, v channels: rows hd*D + c of each third of to_qkv
-                const float* wq = a.qkvw + (size_t)(hd * D) * HC;
 #pragma unroll
                 for (int c = 0; c < D; ++c) {
                     float vq = 0.f, vk = 0.f, vv = 0.f;
 #pragma unroll
                     for (int k = 0; k < HC; ++k) {
-                        vq += wq[c * HC + k] * y1[k];
-                        vk += wq[(HC + c) * HC + k] * y1[k];
-                        vv += wq[(2 * HC + c) * HC + k] * y1[k];
+                        vq += sWq[c * HC + k] * y1[k];
+                        vk += sWq[(D + c) * HC + k] * y1[k];
+                        vv += sWq[(2 * D + c) * HC + k] * y1[k];
                     }
-                    sQ[lane * D + c] = (vq + a.qkvb[hd * D + c]) * scale;
-                    sK[lane * D + c] = vk + a.qkvb[HC + hd * D + c];
-                    sV[lane * D + c] = vv + a.qkvb[2 * HC + hd * D + c];
+                    sQ[lane * D + c] = (vq + sBq[c]) * scale;
+                    sK[lane * D + c] = vk + sBq[D + c];
+                    sV[lane * D + c] = vv + sBq[2 * D + c];
                 }
             }
             {
@@ -103,20 +131,20 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                 float dym[E];
 #pragma unroll
                 for (int k = 0; k < E / 4; ++k) {
-                    const float4 v = reinterpret_cast<const float4*>(a.dym + p * E)[k];
+                    const float4 v = dq4[k];
                     dym[4 * k] = v.x; dym[4 * k + 1] = v.y; dym[4 * k + 2] = v.z; dym[4 * k + 3] = v.w;
                 }
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
                     float acc = 0.f;
 #pragma unroll
-                    for (int n = 0; n < E; ++n) acc += a.projw[n * E + hd * D + k] * dym[n];
+                    for (int n = 0; n < E; ++n) acc += sWp[k * E + n] * dym[n];
                     sDO[lane * D + k] = acc;
                 }
                 if (hd == 0) {   // global-mixer half of the proj input, and the zero padding of the dqkv rows
                     float* co = a.cat + p * E;
 #pragma unroll
-                    for (int c = 0; c < HC; ++c) co[HC + c] = a.o2[(b * HC + c) * hw + s];
+                    for (int c = 0; c < HC; ++c) co[HC + c] = o2v[c];
                     if (DQLD > 3 * HC) {
                         float* pad = a.dqkv + p * DQLD + 3 * HC;
 #pragma unroll
@@ -349,7 +377,7 @@ static int launch_attn_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
     size_t lds = (size_t)(2 * 64 * 65 + NW * (4 * 64 * (HC / 2) + 64 * 4)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_attn_bwd_core<HC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn_bwd_core<HC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
         if (e != hipSuccess) { lg_set_error("attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
