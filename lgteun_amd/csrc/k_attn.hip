@@ -18,6 +18,15 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
     float* sV = sK + 4 * 64 * HC;             // [4][64][HC]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 2 * 64 * 64; i += 256) sPos[i] = a.posT[i];
+    // weights of the block, once per (persistent) workgroup: read as LDS broadcasts in the window loop (as dependent vector
+    // loads they were ~60 load instructions with waits per window)
+    __shared__ __attribute__((aligned(16))) float sWqkv[3 * HC * HC];
+    __shared__ __attribute__((aligned(16))) float sWproj[E * E];
+    __shared__ float sBias[3 * HC + E + 2 * HC];   // qkv bias | proj bias | ln1 gamma, beta (local half)
+    for (int i = threadIdx.x; i < 3 * HC * HC; i += 256) sWqkv[i] = a.qkvw[i];
+    for (int i = threadIdx.x; i < E * E; i += 256) sWproj[i] = a.projw[i];
+    for (int i = threadIdx.x; i < 3 * HC + E + 2 * HC; i += 256)
+        sBias[i] = i < 3 * HC ? a.qkvb[i] : (i < 3 * HC + E ? a.projb[i - 3 * HC] : (i < 4 * HC + E ? a.ln1g[i - 3 * HC - E] : a.ln1b[i - 4 * HC - E]));
     const int nwx = a.w >> 3, nwy = a.h >> 3;
     const float scale = (float)(1.0 / sqrt((double)D));
     float* myK = sK + wave * 64 * HC;
@@ -68,20 +77,20 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
             ln_stats<E>(xv, mu, rstd);
             float y1[HC];
 #pragma unroll
-            for (int c = 0; c < HC; ++c) y1[c] = (xv[c] - mu) * rstd * a.ln1g[c] + a.ln1b[c];
+            for (int c = 0; c < HC; ++c) y1[c] = (xv[c] - mu) * rstd * sBias[3 * HC + E + c] + sBias[4 * HC + E + c];
             // to_qkv: rows [0,HC) q, [HC,2HC) k, [2HC,3HC) v   (LGT.py:136 chunk order)
 #pragma unroll
             for (int c = 0; c < HC; ++c) {
                 float vq = 0.f, vk = 0.f, vv = 0.f;
 #pragma unroll
                 for (int k = 0; k < HC; ++k) {
-                    vq += a.qkvw[c * HC + k] * y1[k];
-                    vk += a.qkvw[(HC + c) * HC + k] * y1[k];
-                    vv += a.qkvw[(2 * HC + c) * HC + k] * y1[k];
+                    vq += sWqkv[c * HC + k] * y1[k];
+                    vk += sWqkv[(HC + c) * HC + k] * y1[k];
+                    vv += sWqkv[(2 * HC + c) * HC + k] * y1[k];
                 }
-                q[c] = (vq + a.qkvb[c]) * scale;
-                myK[lane * HC + c] = vk + a.qkvb[HC + c];
-                myV[lane * HC + c] = vv + a.qkvb[2 * HC + c];
+                q[c] = (vq + sBias[c]) * scale;
+                myK[lane * HC + c] = vk + sBias[HC + c];
+                myV[lane * HC + c] = vv + sBias[2 * HC + c];
             }
         }
         __syncthreads();
@@ -143,10 +152,10 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
                     const int n = n4 * 4 + u;
                     float v = 0.f;
 #pragma unroll
-                    for (int k = 0; k < HC; ++k) v += a.projw[n * E + k] * o1[k];
+                    for (int k = 0; k < HC; ++k) v += sWproj[n * E + k] * o1[k];
 #pragma unroll
-                    for (int k = 0; k < HC; ++k) v += a.projw[n * E + HC + k] * o2[k];
-                    v += a.projb[n];
+                    for (int k = 0; k < HC; ++k) v += sWproj[n * E + HC + k] * o2[k];
+                    v += sBias[3 * HC + n];
                     if (a.dropout) v *= dropout_scale(a.seed, (uint64_t)(p * E + n));
                     o[u] = v;
                 }
