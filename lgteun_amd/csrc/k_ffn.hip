@@ -291,7 +291,7 @@ struct FfnFusedArgs {
 };
 
 template <int E, bool SAVE, bool BF>
-__global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int tiles_x, int tiles_y, int ntiles) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2 : 1))) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int tiles_x, int tiles_y, int ntiles) {
     constexpr int N1 = 4 * E, TY = 8, TX = 16, HX = TX + 2, HY = TY + 2, NH = HX * HY /*180*/, MH = 192, M = TY * TX;
     // LDA: at E = 16 the unpadded 64-byte row makes the A-fragment float4 reads one contiguous 1 KB (conflict-free) AND brings
     // the workgroup under 80 KB of LDS, so two workgroups share a CU and one's MFMA phases overlap the other's GELU/LDS phases
@@ -304,6 +304,27 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     float* my = scr + wave * 16 * LDH;
     const int h = a2.h, w = a2.w;
+    // small parameters of the half-block, staged once per (persistent) workgroup: as global loads inside the tile loop every one
+    // of them was a dependent L1/L2 round trip on the critical path (~100 per tile).  LN / depthwise / b3 go to LDS (broadcast
+    // reads), the two wide biases this lane needs in the MFMA epilogues to registers.
+    __shared__ __attribute__((aligned(16))) float sPar[5 * E + 10 * N1];
+    float* sLn2g = sPar;            float* sLn2b = sPar + E;
+    float* sN1g = sPar + 2 * E;     float* sN1b = sPar + 3 * E;
+    float* sB3 = sPar + 4 * E;      float* sDww = sPar + 5 * E;     // [N1][9]
+    float* sDwb = sDww + 9 * N1;                                    // [N1]
+    for (int i = threadIdx.x; i < E; i += 256) {
+        sLn2g[i] = a1.ln2g[i]; sLn2b[i] = a1.ln2b[i]; sB3[i] = a2.b3[i];
+        sN1g[i] = a2.g ? a2.n1g[i] : 0.f; sN1b[i] = a2.g ? a2.n1b[i] : 0.f;
+    }
+    for (int i = threadIdx.x; i < 9 * N1; i += 256) sDww[i] = a2.dww[i];
+    for (int i = threadIdx.x; i < N1; i += 256) sDwb[i] = a2.dwb[i];
+    float b1r[4], b2r[4];   // biases of the h1 / h2 columns this lane holds in the MFMA C layout
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = (E == 32 ? wave * 32 : 0) + nt * 16 + r;
+        b1r[nt] = (nt < (E == 32 ? 2 : 4)) ? a1.b1[col] : 0.f;
+        b2r[nt] = (nt < (E == 32 ? 2 : 4)) ? a1.b2[col] : 0.f;
+    }
     // weights as MFMA B fragments, resident in registers for ALL tiles of this (persistent) workgroup when they fit
     // (e = 16: 16 + 64 + 16 VGPRs); otherwise every row chunk re-reads them through L1
     constexpr bool RB = (E == 16);
@@ -347,7 +368,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
             float mu, rstd;
             ln_stats<E>(xv, mu, rstd);
 #pragma unroll
-            for (int c = 0; c < E; ++c) xv[c] = (xv[c] - mu) * rstd * a1.ln2g[c] + a1.ln2b[c];
+            for (int c = 0; c < E; ++c) xv[c] = (xv[c] - mu) * rstd * sLn2g[c] + sLn2b[c];
         } else {
 #pragma unroll
             for (int c = 0; c < E; ++c) xv[c] = 0.f;
@@ -386,7 +407,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int col = cw0 + nt * 16 + r;
-                const float bias = a1.b1[col];
+                const float bias = b1r[nt];
 #pragma unroll
                 for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
@@ -414,7 +435,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int col = cw0 + nt * 16 + r;
-                const float bias = a1.b2[col];
+                const float bias = b2r[nt];
 #pragma unroll
                 for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
@@ -428,6 +449,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
             __syncthreads();   // A2 is rewritten by the next row block
         }
     } else {
+    static_assert(NS || N1 == 64, "register-resident biases assume one 64-column block");
     for (int ch = 0; ch < 3; ++ch) {
         const int row0 = (wave * 3 + ch) * 16;
         // validity / global pixel index of the 4 rows this lane owns in the C layout
@@ -451,7 +473,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int col = nc + nt * 16 + r;
-                const float bias = a1.b1[col];
+                const float bias = b1r[nt];
 #pragma unroll
                 for (int v = 0; v < 4; v += 2) {   // packed pairs (v_pk_fma_f32)
                     const lg_v2f hh = (lg_v2f){acc[0][nt][v] + bias, acc[0][nt][v + 1] + bias};
@@ -480,7 +502,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int col = nc + nt * 16 + r;
-                const float bias = a1.b2[col];
+                const float bias = b2r[nt];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int m = row0 + 4 * g + v;
@@ -503,8 +525,8 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) wq[u][k] = a2.dww[(4 * q + u) * 9 + k];
-            bq[u] = a2.dwb[4 * q + u];
+            for (int k = 0; k < 9; ++k) wq[u][k] = sDww[(4 * q + u) * 9 + k];
+            bq[u] = sDwb[4 * q + u];
         }
         float4 w3f[1][RB ? 4 : 1];
         if (RB) load_bfrag<1, 4>(reinterpret_cast<float4(&)[1][4]>(w3f), a2.w3, N1);
@@ -550,7 +572,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
 #pragma unroll
             for (int nt = 0; nt < NT3; ++nt) {
                 const int col = nt * 16 + r;
-                const float bias = a2.b3[col];
+                const float bias = sB3[col];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) bufO[(m0 + 4 * g + v) * LDO + col] = acc3[0][nt][v] + bias;
             }
@@ -581,7 +603,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(Ffn1Args a1, Ffn2Args a2, int
                 ln_stats<E>(o, mu, rstd);
                 const long hw = (long)h * w, s = (long)y * w + x;
 #pragma unroll
-                for (int n = E / 2; n < E; ++n) a2.g[(b * (E / 2) + (n - E / 2)) * hw + s] = (o[n] - mu) * rstd * a2.n1g[n] + a2.n1b[n];
+                for (int n = E / 2; n < E; ++n) a2.g[(b * (E / 2) + (n - E / 2)) * hw + s] = (o[n] - mu) * rstd * sN1g[n] + sN1b[n];
             }
         }
     }
@@ -595,9 +617,9 @@ static int launch_ffn_fused_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_
     size_t lds = (size_t)(192 * (E == 16 ? E : E + 4) + 180 * (N1 + 4) + 4 * 16 * (N1 + 4)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_fused<E, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_fused<E, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_fused<E, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_fused<E, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_fused<E, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_fused<E, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn_fused: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
@@ -858,8 +880,8 @@ static int launch_ffn_fused_bf_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStre
     const size_t lds = (size_t)(180 * (N1 + 4) + 128 * (E + 1) + 8) * sizeof(float) + (size_t)(192 * (E + 8) + 4 * 16 * (N1 + 8)) * 2;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_fused_bf<E, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_fused_bf<E, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_fused_bf<E, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_fused_bf<E, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn_fused_bf: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
