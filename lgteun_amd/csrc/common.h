@@ -203,4 +203,10 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx) {
     float u = (float)(z >> 40) * (1.0f / 16777216.0f);
     return u < 0.1f ? 0.0f : (1.0f / 0.9f);
 }
+// Small parameter tensors (weights / biases of the per-pixel matvecs) are staged in LDS once per workgroup and read back as
+// broadcasts: indexed straight from global memory inside a per-pixel loop they compile to long chains of dependent vector
+// loads, one s_waitcnt each.  Call from ALL threads of the block; __syncthreads() before use.
+__device__ __forceinline__ void lds_stage(float* dst, const float* __restrict__ src, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
 #endif  // __HIPCC__

@@ -408,6 +408,9 @@ int launch_attn_bwd(int e, const AttnBwdArgs& a, hipStream_t s) {
 template <int E>
 __global__ __launch_bounds__(256) void k_proj_o2_bwd(ProjO2BwdArgs a) {
     constexpr int HC = E / 2;
+    __shared__ float sProj[E * HC];   // [n][c] = projw[n][HC + c]
+    for (int i = threadIdx.x; i < E * HC; i += 256) sProj[i] = a.projw[(i / HC) * E + HC + (i % HC)];
+    __syncthreads();
     long p = blockIdx.x * 256L + threadIdx.x;
     if (p >= a.total) return;
     long b = p / a.HW, s = p - b * a.HW;
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(256) void k_proj_o2_bwd(ProjO2BwdArgs a) {
     for (int c = 0; c < HC; ++c) {
         float acc = 0.f;
 #pragma unroll
-        for (int n = 0; n < E; ++n) acc += a.projw[n * E + HC + c] * dy[n];
+        for (int n = 0; n < E; ++n) acc += sProj[n * HC + c] * dy[n];
         a.do2[(b * HC + c) * a.HW + s] = acc;
     }
 }

@@ -287,6 +287,9 @@ int launch_dstep_top_bwd(const DstepTopArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 template <int C, int E>
 __global__ __launch_bounds__(256) void k_tail_bwd(TailBwdArgs a) {
+    __shared__ float sW[C * E];
+    lds_stage(sW, a.w, C * E);
+    __syncthreads();
     long p = blockIdx.x * 256L + threadIdx.x;
     if (p >= a.total) return;
     long b = p / a.HW, s = p - b * a.HW;
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256) void k_tail_bwd(TailBwdArgs a) {
         for (int u = 0; u < 4; ++u) {
             float acc = 0.f;
 #pragma unroll
-            for (int c = 0; c < C; ++c) acc += a.w[c * E + k4 * 4 + u] * d[c];
+            for (int c = 0; c < C; ++c) acc += sW[c * E + k4 * 4 + u] * d[c];
             v[u] = acc;
         }
         dxo[k4] = make_float4(v[0], v[1], v[2], v[3]);
@@ -430,6 +433,9 @@ int launch_embed_bwd(int C, const EmbedBwdArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 template <int E>
 __global__ __launch_bounds__(256) void k_down_bwd_a(DownBwdArgs a) {
+    __shared__ float sW[2 * E * E];
+    lds_stage(sW, a.w, 2 * E * E);
+    __syncthreads();
     long total = (long)a.B * (a.H / 2) * (a.W / 2);
     long p = blockIdx.x * 256L + threadIdx.x;
     if (p >= total) return;
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(256) void k_down_bwd_a(DownBwdArgs a) {
         for (int u = 0; u < 4; ++u) {
             float acc = 0.f;
 #pragma unroll
-            for (int n = 0; n < 2 * E; ++n) acc += a.w[n * E + k4 * 4 + u] * dy[n];
+            for (int n = 0; n < 2 * E; ++n) acc += sW[n * E + k4 * 4 + u] * dy[n];
             v[u] = acc;
         }
         duo[k4] = make_float4(v[0], v[1], v[2], v[3]);
@@ -519,6 +525,9 @@ int launch_down_bwd_b(int E, const DownBwdArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 template <int E>
 __global__ __launch_bounds__(256) void k_upfuse_bwd_a(UpFuseBwdArgs a) {
+    __shared__ float sFw[E * 2 * E];
+    lds_stage(sFw, a.fw, E * 2 * E);
+    __syncthreads();
     long total = (long)a.B * a.H * a.W;
     long p = blockIdx.x * 256L + threadIdx.x;
     if (p >= total) return;
@@ -539,8 +548,8 @@ __global__ __launch_bounds__(256) void k_upfuse_bwd_a(UpFuseBwdArgs a) {
             float acc = 0.f, acc2 = 0.f;
 #pragma unroll
             for (int n = 0; n < E; ++n) {
-                acc += a.fw[n * 2 * E + k4 * 4 + u] * dy[n];
-                acc2 += a.fw[n * 2 * E + E + k4 * 4 + u] * dy[n];
+                acc += sFw[n * 2 * E + k4 * 4 + u] * dy[n];
+                acc2 += sFw[n * 2 * E + E + k4 * 4 + u] * dy[n];
             }
             v[u] = acc;
             q[u] = acc2;
@@ -552,6 +561,9 @@ __global__ __launch_bounds__(256) void k_upfuse_bwd_a(UpFuseBwdArgs a) {
 
 template <int E>
 __global__ __launch_bounds__(256) void k_upfuse_bwd_b(UpFuseBwdArgs a) {
+    __shared__ float sUw[E * 2 * E];
+    lds_stage(sUw, a.upw, E * 2 * E);
+    __syncthreads();
     const int hi = a.H / 2, wi = a.W / 2;
     long total = (long)a.B * hi * wi;
     long p = blockIdx.x * 256L + threadIdx.x;
@@ -592,7 +604,7 @@ __global__ __launch_bounds__(256) void k_upfuse_bwd_b(UpFuseBwdArgs a) {
         for (int u = 0; u < 4; ++u) {
             float acc = 0.f;
 #pragma unroll
-            for (int n = 0; n < E; ++n) acc += a.upw[n * 2 * E + k4 * 4 + u] * v[n];
+            for (int n = 0; n < E; ++n) acc += sUw[n * 2 * E + k4 * 4 + u] * v[n];
             q[u] = acc;
         }
         dxo[k4] = make_float4(q[0], q[1], q[2], q[3]);

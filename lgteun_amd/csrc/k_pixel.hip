@@ -155,6 +155,10 @@ int launch_embed(int C, const EmbedArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 template <int E>
 __global__ __launch_bounds__(256) void k_down(DownArgs a) {
+    __shared__ float sW[2 * E * E], sB[2 * E];
+    lds_stage(sW, a.w, 2 * E * E);
+    lds_stage(sB, a.b, 2 * E);
+    __syncthreads();
     const int ho = a.H / 2, wo = a.W / 2;
     long total = (long)a.B * ho * wo;
     long p = blockIdx.x * 256L + threadIdx.x;
@@ -193,8 +197,8 @@ __global__ __launch_bounds__(256) void k_down(DownArgs a) {
     for (int n = 0; n < 2 * E; ++n) {
         float v = 0.f;
 #pragma unroll
-        for (int k = 0; k < E; ++k) v += a.w[n * E + k] * u[k];
-        o[n] = v + a.b[n];
+        for (int k = 0; k < E; ++k) v += sW[n * E + k] * u[k];
+        o[n] = v + sB[n];
     }
     float4* yo = reinterpret_cast<float4*>(a.y + p * (2 * E));
 #pragma unroll
@@ -226,6 +230,10 @@ __global__ __launch_bounds__(256) void k_upfuse(UpFuseArgs a, int tiles_x, int t
     constexpr int TY = 8, TX = 32, SY = TY / 2 + 4, SX = TX / 2 + 4, NS = SY * SX /*160*/, LDV = E + 4, Q = 2 * E / 4;
     __shared__ float4 srcb[NS * Q];                          // [NS][2E] level-1 pixels
     __shared__ __attribute__((aligned(16))) float vb[NS * LDV];   // [NS][E] up-conv of them (no bias)
+    __shared__ float sFw[E * 2 * E], sFb[2 * E];   // fusion weight | up bias, fusion bias (synchronised by the barriers below)
+    lds_stage(sFw, a.fw, E * 2 * E);
+    lds_stage(sFb, a.upb, E);
+    lds_stage(sFb + E, a.fb, E);
     const int hi = a.H / 2, wi = a.W / 2;
     int t = blockIdx.x;
     const int tx_i = t % tiles_x;
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(256) void k_upfuse(UpFuseArgs a, int tiles_x, int t
         }
     }
 #pragma unroll
-    for (int n = 0; n < E; ++n) tt[n] += a.upb[n];
+    for (int n = 0; n < E; ++n) tt[n] += sFb[n];
     if (a.t_save) {
         float4* to = reinterpret_cast<float4*>(a.t_save + p * E);
 #pragma unroll
@@ -305,10 +313,10 @@ __global__ __launch_bounds__(256) void k_upfuse(UpFuseArgs a, int tiles_x, int t
     for (int n = 0; n < E; ++n) {
         float v = 0.f;
 #pragma unroll
-        for (int k = 0; k < E; ++k) v += a.fw[n * 2 * E + k] * tt[k];
+        for (int k = 0; k < E; ++k) v += sFw[n * 2 * E + k] * tt[k];
 #pragma unroll
-        for (int k = 0; k < E; ++k) v += a.fw[n * 2 * E + E + k] * sk[k];
-        o[n] = v + a.fb[n];
+        for (int k = 0; k < E; ++k) v += sFw[n * 2 * E + E + k] * sk[k];
+        o[n] = v + sFb[E + n];
     }
     float4* yo = reinterpret_cast<float4*>(a.y + p * E);
 #pragma unroll
@@ -333,6 +341,10 @@ int launch_upfuse(int E, const UpFuseArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 template <int C, int E>
 __global__ __launch_bounds__(256) void k_tail(TailArgs a) {
+    __shared__ float sW[C * E], sB[C];
+    lds_stage(sW, a.w, C * E);
+    lds_stage(sB, a.b, C);
+    __syncthreads();
     long p = blockIdx.x * 256L + threadIdx.x;
     if (p >= a.total) return;
     long b = p / a.HW, s = p - b * a.HW;
@@ -347,9 +359,9 @@ __global__ __launch_bounds__(256) void k_tail(TailArgs a) {
     for (int c = 0; c < C; ++c) {
         float v = 0.f;
 #pragma unroll
-        for (int k = 0; k < E; ++k) v += a.w[c * E + k] * x[k];
+        for (int k = 0; k < E; ++k) v += sW[c * E + k] * x[k];
         long o = (b * C + c) * a.HW + s;
-        a.out[o] = v + a.b[c] + a.z[o];
+        a.out[o] = v + sB[c] + a.z[o];
     }
 }
 
