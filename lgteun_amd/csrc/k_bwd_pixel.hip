@@ -64,13 +64,21 @@ __global__ __launch_bounds__(256) void k_resample_adj(const float* __restrict__ 
         px.make(ix, wi, wo);
         const float* g = gout + p * ho * wo;
         float acc = 0.f;
+        // column offsets clamped into the row (their coefficient is 0 there): the NC loads of a row are unconditional, so they
+        // issue as one batch instead of NC load -> wait -> fma steps
+        int cx[AdjPlan<MODE>::NC];
+#pragma unroll
+        for (int b = 0; b < AdjPlan<MODE>::NC; ++b) cx[b] = clampi(px.base + b, 0, wo - 1);
 #pragma unroll
         for (int a = 0; a < AdjPlan<MODE>::NC; ++a) {
             if (py.coef[a] == 0.f) continue;
+            const float* grow = g + (long)(py.base + a) * wo;
+            float v[AdjPlan<MODE>::NC];
+#pragma unroll
+            for (int b = 0; b < AdjPlan<MODE>::NC; ++b) v[b] = grow[cx[b]];
             float rs = 0.f;
 #pragma unroll
-            for (int b = 0; b < AdjPlan<MODE>::NC; ++b)
-                if (px.coef[b] != 0.f) rs += px.coef[b] * g[(py.base + a) * wo + px.base + b];
+            for (int b = 0; b < AdjPlan<MODE>::NC; ++b) rs += px.coef[b] * v[b];
             acc += py.coef[a] * rs;
         }
         if (accumulate) gin[idx] += acc; else gin[idx] = acc;
