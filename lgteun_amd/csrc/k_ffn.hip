@@ -518,6 +518,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
     __syncthreads();
     // ---- P2: per wave, 2 chunks of 16 inner pixels: dw3x3 + GELU -> scratch -> GEMM3 -> output tile (in bufA's space)
     float* bufO = bufA;
+    // the residual rows of P3 are requested now: their HBM round trip hides under the depthwise phase (e = 16 only: registers)
+    constexpr bool XPRE = (E == 16);
+    float4 xres[XPRE ? E / 4 : 1];
+    if (XPRE && threadIdx.x < M) {
+        const int ym = y0 + threadIdx.x / TX, xm = x0 + threadIdx.x % TX;
+        if (ym < h && xm < w) {
+            const float4* xs0 = reinterpret_cast<const float4*>(a2.x + ((b * h + ym) * (long)w + xm) * E);
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) xres[k] = xs0[k];
+        }
+    }
     {
         // depthwise taps and the W3 fragments are (re)loaded per tile: keeping them live across P1 costs ~56 VGPRs
         const int q = lane % CQ;
@@ -591,7 +602,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
             float4* yo = reinterpret_cast<float4*>(a2.y + p * E);
 #pragma unroll
             for (int k = 0; k < E / 4; ++k) {
-                float4 xr = xs[k];
+                float4 xr = XPRE ? xres[XPRE ? k : 0] : xs[k];
                 o[4 * k] = xr.x + bufO[m * LDO + 4 * k];
                 o[4 * k + 1] = xr.y + bufO[m * LDO + 4 * k + 1];
                 o[4 * k + 2] = xr.z + bufO[m * LDO + 4 * k + 2];
