@@ -667,6 +667,18 @@ __global__ __launch_bounds__(256) void k_ffn_fused_bf(Ffn1Args a1, Ffn2Args a2, 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     __bf16* my = scr + wave * 16 * LDS16;
     const int h = a2.h, w = a2.w;
+    // small parameters staged once per workgroup (see k_ffn_fused); the wide biases stay global here (col varies per nc block)
+    __shared__ __attribute__((aligned(16))) float sPar[5 * E + 10 * N1 + 2 * N1];
+    float* sLn2g = sPar;            float* sLn2b = sPar + E;
+    float* sN1g = sPar + 2 * E;     float* sN1b = sPar + 3 * E;
+    float* sB3 = sPar + 4 * E;      float* sDww = sPar + 5 * E;     // [N1][9]
+    float* sDwb = sDww + 9 * N1;    float* sB1 = sDwb + N1;         float* sB2 = sB1 + N1;
+    for (int i = threadIdx.x; i < E; i += 256) {
+        sLn2g[i] = a1.ln2g[i]; sLn2b[i] = a1.ln2b[i]; sB3[i] = a2.b3[i];
+        sN1g[i] = a2.g ? a2.n1g[i] : 0.f; sN1b[i] = a2.g ? a2.n1b[i] : 0.f;
+    }
+    for (int i = threadIdx.x; i < 9 * N1; i += 256) sDww[i] = a2.dww[i];
+    for (int i = threadIdx.x; i < N1; i += 256) { sDwb[i] = a2.dwb[i]; sB1[i] = a1.b1[i]; sB2[i] = a1.b2[i]; }
     // B fragments (bf16) for the whole life of the workgroup
     s16x4 w1k16[4];
     bf16x8 w2f[4][KB2], w3f[NT3][KB2];
@@ -701,7 +713,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused_bf(Ffn1Args a1, Ffn2Args a2, 
             float mu, rstd;
             ln_stats<E>(xv, mu, rstd);
 #pragma unroll
-            for (int c = 0; c < E; ++c) xv[c] = (xv[c] - mu) * rstd * a1.ln2g[c] + a1.ln2b[c];
+            for (int c = 0; c < E; ++c) xv[c] = (xv[c] - mu) * rstd * sLn2g[c] + sLn2b[c];
         } else {
 #pragma unroll
             for (int c = 0; c < E; ++c) xv[c] = 0.f;
@@ -742,7 +754,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused_bf(Ffn1Args a1, Ffn2Args a2, 
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int col = nc + nt * 16 + r;
-                const float bias = a1.b1[col];
+                const float bias = sB1[col];
 #pragma unroll
                 for (int v = 0; v < 4; v += 2) {   // packed pairs (v_pk_fma_f32)
                     const lg_v2f hh = (lg_v2f){acc[0][nt][v] + bias, acc[0][nt][v + 1] + bias};
@@ -776,7 +788,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused_bf(Ffn1Args a1, Ffn2Args a2, 
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int col = nc + nt * 16 + r;
-                const float bias = a1.b2[col];
+                const float bias = sB2[col];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int m = row0 + 4 * g + v;
@@ -796,8 +808,8 @@ __global__ __launch_bounds__(256) void k_ffn_fused_bf(Ffn1Args a1, Ffn2Args a2, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) wq[u][k] = a2.dww[(4 * q + u) * 9 + k];
-            bq[u] = a2.dwb[4 * q + u];
+            for (int k = 0; k < 9; ++k) wq[u][k] = sDww[(4 * q + u) * 9 + k];
+            bq[u] = sDwb[4 * q + u];
         }
         for (int ch = 0; ch < 2; ++ch) {
             const int m0 = (wave * 2 + ch) * 16;
@@ -846,7 +858,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused_bf(Ffn1Args a1, Ffn2Args a2, 
 #pragma unroll
             for (int nt = 0; nt < NT3; ++nt) {
                 const int col = nt * 16 + r;
-                const float bias = a2.b3[col];
+                const float bias = sB3[col];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) bufO[(m0 + 4 * g + v) * LDO + col] = acc3[0][nt][v] + bias;
             }
@@ -877,7 +889,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused_bf(Ffn1Args a1, Ffn2Args a2, 
                 ln_stats<E>(o, mu, rstd);
                 const long hw = (long)h * w, s = (long)y * w + x;
 #pragma unroll
-                for (int n = E / 2; n < E; ++n) a2.g[(b * (E / 2) + (n - E / 2)) * hw + s] = (o[n] - mu) * rstd * a2.n1g[n] + a2.n1b[n];
+                for (int n = E / 2; n < E; ++n) a2.g[(b * (E / 2) + (n - E / 2)) * hw + s] = (o[n] - mu) * rstd * sN1g[n] + sN1b[n];
             }
         }
     }
