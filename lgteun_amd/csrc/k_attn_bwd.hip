@@ -361,7 +361,10 @@ template <int HC, int NW>
 static int grid_t(int B, int h, int w) {
     int nwin = B * (h / 8) * (w / 8);
     int ngroups = (nwin + NW - 1) / NW;
-    return ngroups < 512 ? ngroups : 512;
+    // one resident workgroup per (CU, head): 256 VGPRs allow 2 waves per SIMD = 8 waves per CU anyway, and every extra round of
+    // workgroups pays the pos_emb / weight staging and the dpos write-out again (grid 512 -> 128 at NW = 8: 250 -> 218 us)
+    constexpr int cap = 1024 / NW;
+    return ngroups < cap ? ngroups : cap;
 }
 int attn_bwd_grid(int e, int B, int h, int w) {
     if (e == 16) return grid_t<8, 8>(B, h, w);
