@@ -176,7 +176,7 @@ struct Ffn1BwdArgs {
     long P;
     int hbf;           // hidden storage: 0 fp32, 1 bf16
 };
-#define FFN1_BWD_WGS 1024   // persistent grid cap of k_ffn1_bwd
+#define FFN1_BWD_WGS 512   // persistent grid cap of k_ffn1_bwd
 inline bool ffn1_bwd_fuses_w1(int e) { return e <= 32; }
 int launch_ffn1_bwd(int e, const Ffn1BwdArgs& a, hipStream_t s);
 int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[cols][rows]
