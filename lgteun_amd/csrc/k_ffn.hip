@@ -636,7 +636,8 @@ static int launch_ffn_fused_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_
     }
     int tiles_x = (a2.w + 15) / 16, tiles_y = (a2.h + 7) / 8;
     const int ntiles = a2.B * tiles_x * tiles_y;
-    const int grid = ntiles < 512 ? ntiles : 512;   // persistent: 2 resident workgroups per CU walk the tiles, weights stay in registers
+    const int cap = (E == 32) ? 256 : 512;   // persistent: resident workgroups per CU (2 at e = 16, 1 at e = 32) walk the tiles, weights stay in registers
+    const int grid = ntiles < cap ? ntiles : cap;
     const bool save = a1.a1s != nullptr;   // forward of the live stage: keep gelu / gelu' / h2 for the backward
     if (save && a1.hbf) k_ffn_fused<E, true, true><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y, ntiles);
     else if (save) k_ffn_fused<E, true, false><<<grid, 256, lds, s>>>(a1, a2, tiles_x, tiles_y, ntiles);
