@@ -17,6 +17,35 @@
 __device__ __forceinline__ float2 cmul(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
 __device__ __forceinline__ float2 cmulc(float2 a, float2 w) { return make_float2(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y); }
 
+// the S butterfly levels of one fused pass on the 2^S points a thread holds
+template <bool INVERSE, int S>
+__device__ __forceinline__ void fft_butterflies(float2 (&v)[1 << S], const float2* tw, int lo, int lgmL, int lg) {
+    constexpr int R = 1 << S;
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        // level k pairs (c, c + d); span of this level m = mL * d
+        const int dsh = INVERSE ? k : (S - 1 - k);
+        const int d = 1 << dsh;
+        const int twshift = lg - 1 - (lgmL + dsh);
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            if (c & d) continue;
+            const int j = lo + ((c & (d - 1)) << lgmL);
+            const float2 w = tw[j << twshift];
+            const float2 a = v[c], b = v[c + d];
+            if (!INVERSE) {
+                const float2 df = make_float2(a.x - b.x, a.y - b.y);
+                v[c] = make_float2(a.x + b.x, a.y + b.y);
+                v[c + d] = cmul(df, w);
+            } else {
+                const float2 bw = cmulc(b, w);
+                v[c] = make_float2(a.x + bw.x, a.y + bw.y);
+                v[c + d] = make_float2(a.x - bw.x, a.y - bw.y);
+            }
+        }
+    }
+}
+
 // batched in-place radix-2 butterflies over LDS.  `lines` transforms of length n; element i of line l is at
 // buf[l * ls + i * es].  Lines for which skip(l) is true are left untouched.
 // S fused radix-2 stages in one LDS pass: a thread loads 2^S points, runs the S butterfly levels in registers and writes
@@ -49,31 +78,51 @@ __device__ __forceinline__ void fft_fused(float2* buf, const float2* tw, int lg,
         float2 v[R];
 #pragma unroll
         for (int c = 0; c < R; ++c) v[c] = base[(i_base + (c << lgmL)) * es];
-#pragma unroll
-        for (int k = 0; k < S; ++k) {
-            // level k pairs (c, c + d); span of this level m = mL * d
-            const int dsh = INVERSE ? k : (S - 1 - k);
-            const int d = 1 << dsh;
-            const int twshift = lg - 1 - (lgmL + dsh);
-#pragma unroll
-            for (int c = 0; c < R; ++c) {
-                if (c & d) continue;
-                const int j = lo + ((c & (d - 1)) << lgmL);
-                const float2 w = tw[j << twshift];
-                const float2 a = v[c], b = v[c + d];
-                if (!INVERSE) {
-                    const float2 df = make_float2(a.x - b.x, a.y - b.y);
-                    v[c] = make_float2(a.x + b.x, a.y + b.y);
-                    v[c + d] = cmul(df, w);
-                } else {
-                    const float2 bw = cmulc(b, w);
-                    v[c] = make_float2(a.x + bw.x, a.y + bw.y);
-                    v[c + d] = make_float2(a.x - bw.x, a.y - bw.y);
-                }
-            }
-        }
+        fft_butterflies<INVERSE, S>(v, tw, lo, lgmL, lg);
 #pragma unroll
         for (int c = 0; c < R; ++c) base[(i_base + (c << lgmL)) * es] = v[c];
+    }
+    __syncthreads();
+}
+
+// First pass of the inverse ROW transform of an in-LDS plane (stages 0 .. S-1, span 1: a thread owns 2^S consecutive bit-reversed
+// positions of its row) with the Hermitian extension folded into its loads: even positions (kx < n/2) and position 1 (kx = n/2)
+// hold the half spectrum the column passes produced; an odd position p > 1 is bin kx = brev(p) > n/2 = conj of bin n - kx, read
+// from the even position brev(n - kx) of the same row; Im of the kx = 0 and kx = n/2 bins is dropped (what a c2r transform
+// does).  All loads finish before any store (one thread per item, barrier in between), so the separate extension pass and
+// its barrier are gone.
+template <int S>
+__device__ __forceinline__ void fft_rows_inv_first(float2* buf, const float2* tw, int lg, int ld) {
+    constexpr int R = 1 << S;
+    const int n = 1 << lg;
+    const int items = n << (lg - S);           // rows x groups per row; <= blockDim for every plane size launched
+    const int it = threadIdx.x;
+    const bool act = it < items;
+    const int line = it & (n - 1), t = it >> lg;
+    float2* base = buf + line * ld;
+    float2 v[R];
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            const int pos = (t << S) + c;
+            if ((c & 1) == 0) {
+                v[c] = base[pos];
+                if (pos == 0) v[c].y = 0.0f;
+            } else if (pos == 1) {
+                v[c] = make_float2(base[1].x, 0.0f);
+            } else {
+                const int kx = (int)(__brev((unsigned)pos) >> (32 - lg));
+                const int pm = (int)(__brev((unsigned)(n - kx)) >> (32 - lg));
+                const float2 u = base[pm];
+                v[c] = make_float2(u.x, -u.y);
+            }
+        }
+    }
+    __syncthreads();
+    if (act) {
+        fft_butterflies<true, S>(v, tw, 0, 0, lg);
+#pragma unroll
+        for (int c = 0; c < R; ++c) base[(t << S) + c] = v[c];
     }
     __syncthreads();
 }
@@ -81,13 +130,18 @@ __device__ __forceinline__ void fft_fused(float2* buf, const float2* tw, int lg,
 // full 1-D transform of every line in ceil(lg / 4) LDS passes of up to four fused radix-2 stages (16 points per thread in
 // registers): 7 = 4 + 3, 6 = 3 + 3, 8 = 4 + 4, 9 = 3 + 3 + 3.  Every pass costs one read and one write of the plane plus a
 // barrier, so at n = 128 a transform is 2 passes instead of the 3 of the (3, 3, 1) grouping.
-template <bool INVERSE, bool SKIP, bool LINESFAST = false>
+template <bool INVERSE, bool SKIP, bool LINESFAST = false, bool HERMFIRST = false>
 __device__ __forceinline__ void fft_lines(float2* buf, const float2* tw, int lg, int lgnl, int ls, int es) {
     const int npass = (lg + 3) >> 2, base = lg / npass, extra = lg - base * npass;
     int st = 0;
     for (int ps = 0; ps < npass; ++ps) {
         const int S = base + (ps < extra ? 1 : 0);
-        if (S == 4) fft_fused<INVERSE, SKIP, 4, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
+        if (HERMFIRST && ps == 0) {   // inverse rows of a square in-LDS plane: Hermitian extension folded into the first pass
+            if (S == 4) fft_rows_inv_first<4>(buf, tw, lg, ls);
+            else if (S == 3) fft_rows_inv_first<3>(buf, tw, lg, ls);
+            else if (S == 2) fft_rows_inv_first<2>(buf, tw, lg, ls);
+            else fft_rows_inv_first<1>(buf, tw, lg, ls);
+        } else if (S == 4) fft_fused<INVERSE, SKIP, 4, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
         else if (S == 3) fft_fused<INVERSE, SKIP, 3, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
         else if (S == 2) fft_fused<INVERSE, SKIP, 2, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
         else fft_fused<INVERSE, SKIP, 1, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
@@ -101,7 +155,7 @@ __device__ __forceinline__ void fft_lines(float2* buf, const float2* tw, int lg,
 template <bool INVERSE, bool COLS>
 __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int n, int lg) {
     if (COLS) fft_lines<INVERSE, true>(buf, tw, lg, lg, 1, FFT_LD(n));
-    else fft_lines<INVERSE, false, true>(buf, tw, lg, lg, FFT_LD(n), 1);
+    else fft_lines<INVERSE, false, true, INVERSE>(buf, tw, lg, lg, FFT_LD(n), 1);   // inverse rows: Hermitian extension fused in
 }
 
 // amplitude / phase edit of one bin (LGT.py:168-177) and its backward, shared by the in-LDS and the split (256^2) paths
@@ -136,25 +190,6 @@ __device__ __forceinline__ float2 bin_edit_bwd(float2 f, float c, float nn, floa
     return make_float2(dFr * k2, dFi * k2);
 }
 
-// rows: drop Im of the kx = 0 and kx = n/2 columns and Hermitian-extend (what a c2r transform assumes)
-__device__ __forceinline__ void hermitian_extend(float2* buf, int n, int lg) {
-    const int half = n >> 1;
-    for (int it = threadIdx.x; it < n * (half + 1); it += blockDim.x) {
-        int y, kx;
-        if (it < n * half) { y = it >> (lg - 1); kx = it & (half - 1); }
-        else { y = it - n * half; kx = half; }
-        int p = (int)(__brev((unsigned)kx) >> (32 - lg));
-        if (kx == 0 || kx == half) {
-            buf[y * FFT_LD(n) + p].y = 0.0f;
-        } else {
-            int pm = (int)(__brev((unsigned)(n - kx)) >> (32 - lg));
-            float2 v = buf[y * FFT_LD(n) + p];
-            buf[y * FFT_LD(n) + pm] = make_float2(v.x, -v.y);
-        }
-    }
-    __syncthreads();
-}
-
 // enumeration of the half-spectrum bins of an in-LDS plane (bit-reversed layout): item it in [0, n (n/2 + 1)) -> row q, LDS
 // column p, compact column c (c < n/2: p = 2c, kx = brev(c); c = n/2: p = 1, kx = n/2).  amp / pha are stored at [q][c]
 // (coalesced; the backward of the same plane size reads them back with the same map)
@@ -180,7 +215,11 @@ __global__ void k_fftmix(FftArgs a) {
         float ang = 2.0f * (float)k / (float)n;
         tw[k] = make_float2(cospif(ang), 0.0f - sinpif(ang));
     }
-    for (int i = threadIdx.x; i < n * n; i += blockDim.x) buf[(i >> lg) * LD + (i & (n - 1))] = make_float2(g[i], 0.0f);
+    for (int i = threadIdx.x * 4; i < n * n; i += blockDim.x * 4) {   // 16-byte global loads (n >= 8: a quad never straddles rows)
+        const float4 v = *reinterpret_cast<const float4*>(g + i);
+        float2* d = buf + (i >> lg) * LD + (i & (n - 1));
+        d[0] = make_float2(v.x, 0.0f); d[1] = make_float2(v.y, 0.0f); d[2] = make_float2(v.z, 0.0f); d[3] = make_float2(v.w, 0.0f);
+    }
     __syncthreads();
     // ---- rfft2: rows then columns
     fft_pass<false, false>(buf, tw, n, lg);
@@ -206,14 +245,19 @@ __global__ void k_fftmix(FftArgs a) {
     __syncthreads();
     // ---- irfft2: columns (complex), Hermitian extension, rows
     fft_pass<true, true>(buf, tw, n, lg);
-    hermitian_extend(buf, n, lg);
     fft_pass<true, false>(buf, tw, n, lg);
     const float sc = 1.0f / ((float)n * (float)n);
     float* o = a.o + (size_t)plane * n * n;
-    for (int i = threadIdx.x; i < n * n; i += blockDim.x) {
-        const float v = buf[(i >> lg) * LD + (i & (n - 1))].x * sc;
-        o[i] = fabsf(v);
-        if (a.sgn) a.sgn[(size_t)plane * n * n + i] = (v > 0.f) ? 1.0f : ((v < 0.f) ? -1.0f : 0.0f);
+    for (int i = threadIdx.x * 4; i < n * n; i += blockDim.x * 4) {
+        const float2* r = buf + (i >> lg) * LD + (i & (n - 1));
+        const float v[4] = {r[0].x * sc, r[1].x * sc, r[2].x * sc, r[3].x * sc};
+        *reinterpret_cast<float4*>(o + i) = make_float4(fabsf(v[0]), fabsf(v[1]), fabsf(v[2]), fabsf(v[3]));
+        if (a.sgn) {
+            float sg[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sg[k] = (v[k] > 0.f) ? 1.0f : ((v[k] < 0.f) ? -1.0f : 0.0f);
+            *reinterpret_cast<float4*>(a.sgn + (size_t)plane * n * n + i) = make_float4(sg[0], sg[1], sg[2], sg[3]);
+        }
     }
 }
 
@@ -462,7 +506,13 @@ __global__ void k_fftmix_bwd(FftBwdArgs a) {
         float ang = 2.0f * (float)k / (float)n;
         tw[k] = make_float2(cospif(ang), 0.0f - sinpif(ang));
     }
-    for (int i = threadIdx.x; i < n * n; i += blockDim.x) buf[(i >> lg) * LD + (i & (n - 1))] = make_float2(a.do2[base + i] * a.sgn[base + i], 0.0f);
+    for (int i = threadIdx.x * 4; i < n * n; i += blockDim.x * 4) {
+        const float4 u = *reinterpret_cast<const float4*>(a.do2 + base + i);
+        const float4 sg = *reinterpret_cast<const float4*>(a.sgn + base + i);
+        float2* d = buf + (i >> lg) * LD + (i & (n - 1));
+        d[0] = make_float2(u.x * sg.x, 0.0f); d[1] = make_float2(u.y * sg.y, 0.0f);
+        d[2] = make_float2(u.z * sg.z, 0.0f); d[3] = make_float2(u.w * sg.w, 0.0f);
+    }
     __syncthreads();
     fft_pass<false, false>(buf, tw, n, lg);
     fft_pass<false, true>(buf, tw, n, lg);
@@ -478,10 +528,12 @@ __global__ void k_fftmix_bwd(FftBwdArgs a) {
     }
     __syncthreads();
     fft_pass<true, true>(buf, tw, n, lg);
-    hermitian_extend(buf, n, lg);
     fft_pass<true, false>(buf, tw, n, lg);
     const float sc = 1.0f / nn;
-    for (int i = threadIdx.x; i < n * n; i += blockDim.x) a.dg[base + i] = buf[(i >> lg) * LD + (i & (n - 1))].x * sc;
+    for (int i = threadIdx.x * 4; i < n * n; i += blockDim.x * 4) {
+        const float2* r = buf + (i >> lg) * LD + (i & (n - 1));
+        *reinterpret_cast<float4*>(a.dg + base + i) = make_float4(r[0].x * sc, r[1].x * sc, r[2].x * sc, r[3].x * sc);
+    }
     // parameter gradient partials
     float v[4] = {s_aw, s_ab, s_pw, s_pb};
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
