@@ -114,7 +114,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--prof-kernel', default='ffn', help='kernel timed live for the roofline object (default: the dominant one)')
-    ap.add_argument('--mode', default='faithful', choices=['faithful', 'live'])
+    ap.add_argument('--mode', default='faithful', choices=['faithful', 'live', 'chained'],
+                    help="'faithful' = the reference's graph (headline); 'live' / 'chained' are labelled non-headline variants")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-live', action='store_true', help='skip the live-mode side measurement (profiling runs)')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],

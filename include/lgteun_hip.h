@@ -44,6 +44,13 @@ extern "C" {
 #define LG_FLAG_BWD_LGT 8
 #define LG_FLAG_BWD_DATA 16
 
+/* forward + backward: the INTENDED unfolding, default off: stage i+1's data step consumes LGT_i's output
+ * instead of the data step's own output (the reference feeds `Z`, not `Z_`, forward: unlg_former.py:56-67), so every stage's
+ * LGT is live, every parameter gets a gradient, and training keeps one saved activation set per stage
+ * (lg_workspace_bytes(..., train = 2)).  Overrides LG_FLAG_FAITHFUL; LG_FLAG_BWD_LGT / _DATA do not apply (the K LGT and
+ * data-step backwards interleave) and are rejected. */
+#define LG_FLAG_CHAINED 32
+
 /* kernel ids for the live HIP-event timing facility (lg_prof_*) */
 enum lg_kernel_id {
     LG_K_NONE = 0, LG_K_FFN1, LG_K_FFN2, LG_K_FFT, LG_K_ATTN, LG_K_UPFUSE, LG_K_DOWN, LG_K_EMBED, LG_K_TAIL, LG_K_DATASTEP,
@@ -65,7 +72,8 @@ const char* lg_last_error(void); /* thread-local, host string */
 /* offsets: host array of n_offsets = 12 + K + 119*K int64 (float offsets into the flat parameter buffer). */
 int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int32_t n_offsets, lg_plan** out);
 void lg_plan_destroy(lg_plan* plan);
-/* bytes of workspace lgteun_forward/backward need for batch B (forward-only if !train). */
+/* bytes of workspace lgteun_forward/backward need for batch B: train = 0 forward only, 1 = forward with LG_FLAG_SAVE + backward,
+ * 2 = the same with LG_FLAG_CHAINED (K saved activation sets). */
 size_t lg_workspace_bytes(const lg_plan* plan, int32_t B, int32_t train);
 
 /* Pansharpening.forward (unlg_former.py:50-67).  seed: dropout counter seed (used with LG_FLAG_DROPOUT). */

@@ -16,6 +16,7 @@ LG_FLAG_SAVE = 2
 LG_FLAG_DROPOUT = 4
 LG_FLAG_BWD_LGT = 8
 LG_FLAG_BWD_DATA = 16
+LG_FLAG_CHAINED = 32
 KERNEL_IDS = {n: i for i, n in enumerate(['none', 'ffn1', 'ffn', 'fft', 'attn', 'upfuse', 'down', 'embed', 'tail', 'datastep', 'ffn1_bwd',
                                            'ffn2_bwd', 'fft_bwd', 'attn_bwd', 'wgrad'])}
 

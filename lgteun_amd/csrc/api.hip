@@ -113,7 +113,7 @@ extern "C" void lg_plan_destroy(lg_plan* plan) {
 }
 
 extern "C" size_t lg_workspace_bytes(const lg_plan* plan, int32_t B, int32_t train) {
-    if (!plan || B <= 0) return 0;
+    if (!plan || B <= 0 || train < 0 || train > 2) return 0;
     NetBufs nb;
     carve(plan, B, train, nullptr, nb);
     size_t fwd = nb.bytes;
@@ -265,7 +265,8 @@ static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z,
 extern "C" int lgteun_forward(const lg_plan* plan, const float* params, const float* ms, const float* pan, float* out,
                               void* workspace, size_t workspace_bytes, int32_t B, int32_t flags, uint64_t seed, void* stream) {
     if (!plan || !params || !ms || !pan || !out || !workspace || B <= 0) { lg_set_error("forward: null/invalid argument"); return -1; }
-    const int train = (flags & LG_FLAG_SAVE) ? 1 : 0;
+    const bool chained = (flags & LG_FLAG_CHAINED) != 0;
+    const int train = (flags & LG_FLAG_SAVE) ? (chained ? 2 : 1) : 0;
     if (workspace_bytes < lg_workspace_bytes(plan, B, train)) {
         lg_set_error("forward: workspace too small (%zu < %zu)", workspace_bytes, lg_workspace_bytes(plan, B, train));
         return -3;
@@ -277,6 +278,15 @@ extern "C" int lgteun_forward(const lg_plan* plan, const float* params, const fl
     int rc;
     // Z0 = bicubic x4 (unlg_former.py:53)
     if ((rc = launch_resample(2, ms, nb.Z[0], B * c.C, c.H / 4, c.W / 4, s))) return rc;
+    if (chained) {
+        // intended unfolding: X_{i+1} = LGT_i(data_step_i(X_i)); every stage saves into its own activation set when training
+        for (int i = 0; i < c.K; ++i) {
+            if ((rc = data_step_fwd(plan, params, i, nb.X[i], ms, pan, nb.Z[i + 1], nb.t1[i], nb.r[i], nb.s1[i], B, s))) return rc;
+            NetBufs sv = (train == 2) ? stage_view(nb, i) : nb;
+            if ((rc = lgt_fwd(plan, params, i, nb.Z[i + 1], i == c.K - 1 ? out : nb.X[i + 1], sv, B, flags, seed, s))) return rc;
+        }
+        return 0;
+    }
     for (int i = 0; i < c.K; ++i) {
         if ((rc = data_step_fwd(plan, params, i, nb.Z[i], ms, pan, nb.Z[i + 1], nb.t1[i], nb.r[i], nb.s1[i], B, s))) return rc;
         const bool last = (i == c.K - 1);
@@ -294,9 +304,14 @@ extern "C" int lgteun_backward(const lg_plan* plan, const float* params, float* 
                                const float* dout, void* workspace, size_t workspace_bytes, int32_t B, int32_t flags, uint64_t seed,
                                void* stream) {
     if (!plan || !params || !grads || !ms || !pan || !dout || !workspace || B <= 0) { lg_set_error("backward: null/invalid argument"); return -1; }
-    if (workspace_bytes < lg_workspace_bytes(plan, B, 1)) { lg_set_error("backward: workspace too small"); return -3; }
+    const int train = (flags & LG_FLAG_CHAINED) ? 2 : 1;
+    if ((flags & LG_FLAG_CHAINED) && (flags & (LG_FLAG_BWD_LGT | LG_FLAG_BWD_DATA))) {
+        lg_set_error("backward: LG_FLAG_BWD_LGT / LG_FLAG_BWD_DATA do not apply to LG_FLAG_CHAINED");
+        return -2;
+    }
+    if (workspace_bytes < lg_workspace_bytes(plan, B, train)) { lg_set_error("backward: workspace too small"); return -3; }
     NetBufs nb;
-    carve(plan, B, 1, workspace, nb);
+    carve(plan, B, train, workspace, nb);
     return net_backward(plan, params, grads, ms, pan, dout, nb, (char*)workspace + nb.bytes, B, flags, seed, (hipStream_t)stream);
 }
 

@@ -186,12 +186,13 @@ int op_block_bwd(const lg_plan* pl, const float* P, float* G, int st, int j, int
     return rc ? rc : rc2;
 }
 
-static int data_step_bwd(const lg_plan* pl, const float* P, float* G, int st, const NetBufs& nb, BwdBufs& bb, const float* pan,
-                         const float* g, float* dz, int B, hipStream_t s) {
+// zin: the tensor the forward data step of stage st consumed (nb.Z[st]; nb.X[st] in chained mode)
+static int data_step_bwd(const lg_plan* pl, const float* P, float* G, int st, const NetBufs& nb, BwdBufs& bb, const float* zin,
+                         const float* pan, const float* g, float* dz, int B, hipStream_t s) {
     const lg_config& c = pl->cfg;
     const int planes = B * c.C, H = c.H, W = c.W;
     DstepTopArgs t;
-    t.g = g; t.s1 = nb.s1[st]; t.z = nb.Z[st]; t.pan = pan; t.gu = bb.gu3; t.dz = dz;
+    t.g = g; t.s1 = nb.s1[st]; t.z = zin; t.pan = pan; t.gu = bb.gu3; t.dz = dz;
     t.w9 = P + pl->shared(S_DT3W); t.b9 = P + pl->shared(S_DT3B);
     t.rw = P + pl->shared(S_RW); t.rb = P + pl->shared(S_RB); t.rtw = P + pl->shared(S_RTW); t.rtb = P + pl->shared(S_RTB);
     t.eta = P + pl->eta(st);
@@ -221,7 +222,7 @@ static int data_step_bwd(const lg_plan* pl, const float* P, float* G, int st, co
     RC(launch_dw_bwd(0, d, s));
     RC(launch_resample_adj(0, bb.gd3, bb.gt1, planes, H / 2, W / 2, 0, s));
     // t1 = dw(down(Z))
-    d.gout = bb.gt1; d.in = nb.Z[st]; d.gin = bb.gd1; d.w9 = P + pl->shared(S_D1W);
+    d.gout = bb.gt1; d.in = zin; d.gin = bb.gd1; d.w9 = P + pl->shared(S_D1W);
     d.dw9 = G + pl->shared(S_D1W); d.dbias = G + pl->shared(S_D1B);
     d.hi = H; d.wi = W; d.n_h = H / 2; d.n_w = W / 2;
     d.part = bb.rq.take(chan_partial_floats(c.C, B, H, W));
@@ -231,22 +232,15 @@ static int data_step_bwd(const lg_plan* pl, const float* P, float* G, int st, co
     return bb.rq.flush();   // the K stages share these parameters: two stages' jobs must not meet in one reduce launch
 }
 
-int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, const float* pan, const float* dout, NetBufs& nb,
-                 void* bwd_ws, int B, int flags, uint64_t seed, hipStream_t s) {
-    (void)ms;
+// backward of stage st's LGT (LGT.py:314-344, reversed) from the activation set `nb` holds: dout = gradient wrt the LGT's
+// output, zin = the LGT's input; leaves the gradient wrt zin in bb.dzA
+static int lgt_bwd(const lg_plan* pl, const float* P, float* G, int st, const NetBufs& nb, BwdBufs& bb, const float* dout,
+                   const float* zin, int B, int flags, uint64_t seed, hipStream_t s) {
     const lg_config& c = pl->cfg;
-    const int E = 4 * c.C, st = c.K - 1;
-    BwdBufs bb;
-    carve_bwd(pl, B, bwd_ws, bb);
-    bb.fft_scratch = nb.fft_scratch;
-    ReduceQueueScope rqs(bb, s);
+    const int E = 4 * c.C;
     const long P0 = (long)B * c.H * c.W, P1 = P0 / 4;
     const float* posT = nb.posT + (size_t)st * 5 * 2 * 64 * 64;
     float *A = bb.dx[0], *Bf = bb.dx[1], *Cf = bb.dx[2];
-    const bool do_lgt = !(flags & (LG_FLAG_BWD_LGT | LG_FLAG_BWD_DATA)) || (flags & LG_FLAG_BWD_LGT);
-    const bool do_data = !(flags & (LG_FLAG_BWD_LGT | LG_FLAG_BWD_DATA)) || (flags & LG_FLAG_BWD_DATA);
-    if (do_lgt) {
-    // ---------------- LGT of the last stage (LGT.py:314-344, reversed)
     TailBwdArgs tb;
     tb.dout = dout; tb.dx = A; tb.doutp = bb.doutp; tb.dz = bb.dzA; tb.w = P + pl->lgt(st, L_TAILW);
     tb.HW = c.H * c.W; tb.total = P0;
@@ -278,7 +272,7 @@ int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, c
     RC(block_bwd(pl, P, G, st, 0, nb.blk[0], bb, posT + 0 * 8192, A, Bf, Cf, B, flags, seed, s));
     // patch embed
     EmbedBwdArgs eb;
-    eb.dx = Cf; eb.z = nb.Z[c.K]; eb.dz = bb.dzA; eb.de = bb.de; eb.tp = bb.tp;
+    eb.dx = Cf; eb.z = zin; eb.dz = bb.dzA; eb.de = bb.de; eb.tp = bb.tp;
     eb.dww = P + pl->lgt(st, L_PE_DWW); eb.dwb = P + pl->lgt(st, L_PE_DWB); eb.w = P + pl->lgt(st, L_PE_W); eb.b = P + pl->lgt(st, L_PE_B);
     eb.lng = P + pl->lgt(st, L_PE_LNG);
     eb.d_dww = G + pl->lgt(st, L_PE_DWW); eb.d_dwb = G + pl->lgt(st, L_PE_DWB);
@@ -287,13 +281,38 @@ int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, c
     if (!eb.part) return -3;
     RC(launch_embed_bwd(c.C, eb, s));
     RC(wgrad(bb.de, E, bb.tp, 16, G + pl->lgt(st, L_PE_W), c.C, G + pl->lgt(st, L_PE_B), P0, E, 16, E, c.C, 0, 0, bb, s));
+    return 0;
+}
+
+int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, const float* pan, const float* dout, NetBufs& nb,
+                 void* bwd_ws, int B, int flags, uint64_t seed, hipStream_t s) {
+    (void)ms;
+    const lg_config& c = pl->cfg;
+    BwdBufs bb;
+    carve_bwd(pl, B, bwd_ws, bb);
+    bb.fft_scratch = nb.fft_scratch;
+    ReduceQueueScope rqs(bb, s);
+    if (flags & LG_FLAG_CHAINED) {
+        // intended unfolding (every stage live): LGT_i then data step i, last stage first; each LGT reads its own activation set
+        const float* g = dout;
+        for (int i = c.K - 1; i >= 0; --i) {
+            const NetBufs sv = stage_view(nb, i);
+            RC(lgt_bwd(pl, P, G, i, sv, bb, g, nb.Z[i + 1], B, flags, seed, s));
+            RC(data_step_bwd(pl, P, G, i, nb, bb, nb.X[i], pan, bb.dzA, bb.dzB, B, s));
+            g = bb.dzB;
+        }
+        return reduce_queue_end();
     }
+    const bool do_lgt = !(flags & (LG_FLAG_BWD_LGT | LG_FLAG_BWD_DATA)) || (flags & LG_FLAG_BWD_LGT);
+    const bool do_data = !(flags & (LG_FLAG_BWD_LGT | LG_FLAG_BWD_DATA)) || (flags & LG_FLAG_BWD_DATA);
+    // ---------------- LGT of the last stage: the only live one
+    if (do_lgt) RC(lgt_bwd(pl, P, G, c.K - 1, nb, bb, dout, nb.Z[c.K], B, flags, seed, s));
     if (!do_data) return reduce_queue_end();
     // ---------------- K shared data steps, last to first (unlg_former.py:56-61); input gradient: bb.dzA
     float* g = bb.dzA;
     float* dz = bb.dzB;
     for (int i = c.K - 1; i >= 0; --i) {
-        RC(data_step_bwd(pl, P, G, i, nb, bb, pan, g, dz, B, s));
+        RC(data_step_bwd(pl, P, G, i, nb, bb, nb.Z[i], pan, g, dz, B, s));
         float* t = g; g = dz; dz = t;
     }
     return reduce_queue_end();

@@ -25,7 +25,8 @@ struct BlockBufs {
 };
 
 struct NetBufs {
-    float* Z[LG_MAX_K + 1];                          // Z_0 .. Z_K  [B,C,H,W]
+    float* Z[LG_MAX_K + 1];                          // Z_0 .. Z_K  [B,C,H,W]: Z[i] -> data step i -> Z[i+1] (= input of LGT i)
+    float* X[LG_MAX_K];                              // chained mode: input of data step i (X[0] = Z[0], X[i] = output of LGT i-1)
     float *t1[LG_MAX_K], *r[LG_MAX_K], *s1[LG_MAX_K];  // data-step intermediates per stage
     float* posT;                                     // [K][5][2*64*64]
     BlockBufs blk[5];
@@ -34,9 +35,26 @@ struct NetBufs {
     float* u_down;    // saved bicubic-downsampled encoder output [B,H/2,W/2,E] (train)
     float* t_up;      // saved up-path tensor [B,H,W,E] (train)
     float* fft_scratch;  // PAN > 128 only: half-spectrum scratch of the split FFT path
+    size_t set_off, set_bytes;  // the per-LGT activation set [set_off, set_off + set_bytes): train == 2 carves K of them back to back
     size_t bytes;
 };
 
+// NetBufs of stage `i` when every stage keeps its own activation set (chained training): same layout, shifted by i sets
+static inline NetBufs stage_view(const NetBufs& nb, int i) {
+    NetBufs v = nb;
+    const size_t sh = (size_t)i * nb.set_bytes;
+    auto mv = [sh](float*& p) { if (p) p = reinterpret_cast<float*>(reinterpret_cast<char*>(p) + sh); };
+    for (int j = 0; j < 5; ++j) {
+        BlockBufs& b = v.blk[j];
+        mv(b.xin); mv(b.xmid); mv(b.xout); mv(b.g); mv(b.o2); mv(b.amp); mv(b.pha); mv(b.sgn);
+        mv(b.a1); mv(b.g1); mv(b.h2); mv(b.a3); mv(b.g3);
+    }
+    mv(v.x0); mv(v.u_down); mv(v.t_up);
+    return v;
+}
+
+// train: 0 = inference, 1 = training (one saved activation set: only the last stage's LGT is live),
+// 2 = chained training (LG_FLAG_CHAINED: every stage's LGT is live and keeps its own set)
 static inline void carve(const lg_plan* plan, int B, int train, void* base, NetBufs& nb) {
     const lg_config& c = plan->cfg;
     Carver cv{reinterpret_cast<char*>(base), 0};
@@ -49,8 +67,11 @@ static inline void carve(const lg_plan* plan, int B, int train, void* base, NetB
     }
     nb.posT = cv.take((size_t)c.K * 5 * 2 * 64 * 64);
     nb.deadout = cv.take(B * c.C * P0);
+    nb.X[0] = nb.Z[0];
+    for (int i = 1; i < c.K; ++i) nb.X[i] = (train == 2) ? cv.take(B * c.C * P0) : nb.deadout;
     float* shared_h2 = nullptr;
     if (!train) shared_h2 = cv.take(B * P0 * 4 * E);  // largest (level-0) hidden tensor, reused by every block
+    nb.set_off = cv.off;
     for (int j = 0; j < 5; ++j) {
         BlockBufs& bb = nb.blk[j];
         const bool l1 = (j == 2);
@@ -85,6 +106,8 @@ static inline void carve(const lg_plan* plan, int B, int train, void* base, NetB
     nb.blk[4].xin = nb.blk[3].xout;
     nb.u_down = train ? cv.take(B * P1 * E) : nullptr;
     nb.t_up = train ? cv.take(B * P0 * E) : nullptr;
+    nb.set_bytes = cv.off - nb.set_off;
+    if (train == 2) cv.off += (size_t)(c.K - 1) * nb.set_bytes;
     {
         const size_t planes = (size_t)B * (E / 2);
         const size_t fl = c.H > 128 ? planes * c.H * (c.H / 2 + 1) * 2 : 0;

@@ -15,7 +15,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (LG_FLAG_BWD_DATA, LG_FLAG_BWD_LGT, LG_FLAG_DROPOUT, LG_FLAG_FAITHFUL, LG_FLAG_SAVE, LgConfig, check)
+from ._lib import (LG_FLAG_BWD_DATA, LG_FLAG_BWD_LGT, LG_FLAG_CHAINED, LG_FLAG_DROPOUT, LG_FLAG_FAITHFUL, LG_FLAG_SAVE, LgConfig,
+                   check)
 
 
 def _block_names(pre):
@@ -95,9 +96,11 @@ class Engine:
                 raise RuntimeError(f'parameter {n}: expected float32 on {dev}')
         self.device = dev
         self.names = names
-        offs, total, self.live_idx, self.live_ranges = flat_layout(names, [params[n].numel() for n in names], self.K)
+        offs, total, d3_idx, d3_ranges = flat_layout(names, [params[n].numel() for n in names], self.K)
         self.offsets = offs
         self.total = total
+        # which tensors get a gradient: the reference's graph (shared + eta + last LGT) or, in 'chained' mode, all
+        self._live = {False: (d3_idx, d3_ranges), True: (list(range(len(names))), [(0, total)])}
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.params = [params[n] for n in names]
         for n, o in zip(names, offs):
@@ -106,8 +109,8 @@ class Engine:
             view.copy_(p.data)
             p.data = view
         self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.ranges_dev = torch.tensor([v for r in self.live_ranges for v in r], dtype=torch.int64, device=dev)
-        self.max_range = max(b - a for a, b in self.live_ranges)
+        self._ranges_dev = {ch: torch.tensor([v for r in rg for v in r], dtype=torch.int64, device=dev)
+                            for ch, (_, rg) in self._live.items()}
         self._first_ptr = self.params[0].data_ptr()
         self._last_ptr = self.params[-1].data_ptr()
         self._plans = {}
@@ -118,6 +121,25 @@ class Engine:
         self.process_group = None
         self.buckets = None
 
+    def chained(self):
+        return self.module_mode() == 'chained'
+
+    @property
+    def live_idx(self):
+        return self._live[self.chained()][0]
+
+    @property
+    def live_ranges(self):
+        return self._live[self.chained()][1]
+
+    @property
+    def ranges_dev(self):
+        return self._ranges_dev[self.chained()]
+
+    @property
+    def max_range(self):
+        return max(b - a for a, b in self.live_ranges)
+
     def attach_ddp(self, group=None):
         """join a torch.distributed group: broadcast rank-0 weights, reduce the live gradient ranges every step"""
         import torch.distributed as dist
@@ -126,7 +148,7 @@ class Engine:
         self.process_group = group
         if self.world > 1:
             broadcast_flat(self.flat, 0, group)
-            self.buckets = GradBuckets(self.live_ranges, group)
+            self.buckets = {ch: GradBuckets(rg, group) for ch, (_, rg) in self._live.items()}
         return self
 
     # ------------------------------------------------------------------------------------------
@@ -152,8 +174,9 @@ class Engine:
         return self._plans[key]
 
     def workspace(self, plan, B, train):
-        need = self.lib.lg_workspace_bytes(plan, B, 1 if train else 0)
-        key = (plan.value, B, bool(train))
+        """train: 0 inference, 1 training, 2 chained training (K saved activation sets)"""
+        need = self.lib.lg_workspace_bytes(plan, B, int(train))
+        key = (plan.value, B, int(train))
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -182,7 +205,7 @@ class Engine:
         ms = ms.contiguous()
         pan = pan.contiguous()
         plan = self.plan(H, W)
-        ws = self.workspace(plan, B, bool(flags & LG_FLAG_SAVE))
+        ws = self.workspace(plan, B, (2 if flags & LG_FLAG_CHAINED else 1) if flags & LG_FLAG_SAVE else 0)
         out = torch.empty(B, self.C, H, W, dtype=torch.float32, device=self.device)
         check(self.lib.lgteun_forward(plan, _ptr(self.flat), _ptr(ms), _ptr(pan), _ptr(out), _ptr(ws), ws.numel(), B, flags,
                                       seed, _stream_ptr()), 'lgteun_forward')
@@ -195,7 +218,10 @@ class Engine:
                                        ws.numel(), B, flags, seed, _stream_ptr()), 'lgteun_backward')
 
     def base_flags(self, training):
-        f = LG_FLAG_FAITHFUL if self.module_mode() == 'faithful' else 0
+        mode = self.module_mode()
+        if mode not in ('faithful', 'live', 'chained'):
+            raise ValueError(f"mode must be 'faithful', 'live' or 'chained' (got {mode!r})")
+        f = {'faithful': LG_FLAG_FAITHFUL, 'live': 0, 'chained': LG_FLAG_CHAINED}[mode]
         if training:
             f |= LG_FLAG_DROPOUT
         return f
@@ -224,13 +250,18 @@ class Engine:
         n_local = out.numel()
         check(self.lib.lg_l1_loss(_ptr(out), _ptr(gt), _ptr(dout), _ptr(self._loss), n_local, n_local * self.world,
                                   float(loss_weight), _stream_ptr()), 'lg_l1_loss')
-        if self.world > 1:
+        if self.world > 1 and flags & LG_FLAG_CHAINED:
+            # every tensor is live and the LGT / data-step backwards interleave: one all-reduce of the whole flat buffer
+            self.backward_raw(saved, dout, self.gflat, flags, seed)
+            self.buckets[True].all_reduce(self.gflat)
+        elif self.world > 1:
             # bucket 1 (last stage's LGT) is reduced over RCCL while the K data-step backwards still run
+            bk = self.buckets[False]
             self.backward_raw(saved, dout, self.gflat, flags | LG_FLAG_BWD_LGT, seed)
-            self.buckets.start(self.gflat, 1)
+            bk.start(self.gflat, 1)
             self.backward_raw(saved, dout, self.gflat, flags | LG_FLAG_BWD_DATA, seed)
-            self.buckets.start(self.gflat, 0)
-            self.buckets.finish()
+            bk.start(self.gflat, 0)
+            bk.finish()
         else:
             self.backward_raw(saved, dout, self.gflat, flags, seed)
         optim.step_flat(self)
@@ -251,6 +282,7 @@ class _LgteunFn(torch.autograd.Function):
         seed = engine.next_seed() if (flags & LG_FLAG_DROPOUT) else 0
         out, saved = engine.forward_raw(ms, pan, flags | LG_FLAG_SAVE, seed)
         ctx.engine, ctx.saved, ctx.flags, ctx.seed = engine, saved, flags | LG_FLAG_SAVE, seed
+        ctx.live_idx = list(engine.live_idx)    # the mode may change before backward runs
         return out
 
     @staticmethod
@@ -259,7 +291,7 @@ class _LgteunFn(torch.autograd.Function):
         g = torch.zeros(eng.total, dtype=torch.float32, device=eng.device)
         eng.backward_raw(ctx.saved, dout, g, ctx.flags, ctx.seed)
         grads = []
-        for i in eng.live_idx:
+        for i in ctx.live_idx:
             p = eng.params[i]
             o = eng.offsets[i]
             grads.append(g[o:o + p.numel()].view(p.shape))

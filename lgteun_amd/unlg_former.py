@@ -96,7 +96,10 @@ class Pansharpening(nn.Module):
         self.eta = nn.ParameterList([nn.Parameter(torch.tensor(0.1)) for _ in range(stage)])
         self.prior_module = nn.ModuleList([_lgt(C, C * 4) for _ in range(stage)])
         # execution options (not part of the reference surface)
-        self.mode = 'faithful'     # 'faithful': run all K LGTs like the reference; 'live': skip the dead ones
+        # 'faithful': run all K LGTs like the reference; 'live': skip the dead ones (identical results);
+        # 'chained': the intended unfolding (stage i+1 consumes LGT_i's output; every parameter trains) -- NOT the reference's
+        # results, opt-in only
+        self.mode = 'faithful'
         self.precision = 'fp32'    # 'fp32': parity mode; 'bf16': saved / hidden FFN activations of the backward stored as bf16
         self._engine = None
 

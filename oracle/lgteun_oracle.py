@@ -229,13 +229,19 @@ def lgt(P, pre, x, num_block=(2, 1)):
 def forward(P, ms, pan, stage, mode='live'):
     """Pansharpening.forward.  mode='faithful' executes every stage's LGT like the reference
     (results of stages 0..K-2 are discarded: unlg_former.py:63 never feeds Z_ back, SURVEY D3);
-    mode='live' skips them.  Outputs are identical."""
+    mode='live' skips them.  Outputs are identical.
+    mode='chained' is NOT the reference: the intended unfolding, where the next stage's data step consumes the
+    LGT's output -- the same two functions composed the other way, so it is pinned only through them."""
+    if mode not in ('faithful', 'live', 'chained'):
+        raise ValueError(mode)
     z = resample(ms, 4)
     out = None
     for i in range(stage):
         z = data_step(P, z, ms, pan, P[f'eta.{i}'])
-        if mode == 'faithful' or i == stage - 1:
+        if mode != 'live' or i == stage - 1:
             out = lgt(P, f'prior_module.{i}.', z)
+        if mode == 'chained':
+            z = out
     return out
 
 

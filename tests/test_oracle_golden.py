@@ -128,3 +128,20 @@ def test_train3_vs_reference(manifest):
         if k.startswith('prior_module.0.'):
             continue
         assert rel_l2(v.detach(), g[k.replace('.', '/')]) < 5e-3, k
+
+
+def test_chained_mode_is_the_same_functions_composed_the_intended_way():
+    """mode='chained'  is not the reference, so no golden exists: it is pinned through the two functions it
+    composes (data_step, lgt -- both pinned above) by writing the composition out by hand."""
+    C, K, h = 4, 3, 8
+    ms, pan, _ = (T(a) for a in dw.make_inputs(2, C, h, h, seed=9, kind='smooth'))
+    P = det_params(C, K)
+    z = orc.resample(ms, 4)
+    for i in range(K):
+        z = orc.lgt(P, f'prior_module.{i}.', orc.data_step(P, z, ms, pan, P[f'eta.{i}']))
+    got = orc.forward(P, ms, pan, K, mode='chained')
+    assert torch.equal(got, z)
+    assert rel_l2(got, orc.forward(P, ms, pan, K, mode='faithful')) > 1e-3
+    assert torch.equal(orc.forward(P, ms, pan, 1, mode='chained'), orc.forward(P, ms, pan, 1, mode='faithful'))
+    with pytest.raises(ValueError):
+        orc.forward(P, ms, pan, K, mode='intended')

@@ -25,7 +25,7 @@ def main():
     for name, C, H, K, B in cfgs:
         if args.only and args.only not in name:
             continue
-        for mode in ('faithful', 'live'):
+        for mode in ('faithful', 'live', 'chained'):
             net = make_module(C, K)
             net.mode = mode
             net.train()
