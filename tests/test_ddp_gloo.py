@@ -18,13 +18,15 @@ from oracle import lgteun_oracle as orc
 C, K, H, B = 4, 2, 8, 4
 
 
-def _flat_grads(P, ms, pan, gt, n_global):
+def _flat_grads(P, ms, pan, gt, n_global, mode='faithful'):
     from lgteun_amd.engine import canonical_names, flat_layout
     names = canonical_names(C, K)
     shapes = state_shapes(C, K)
     numels = [int(np.prod(shapes[n])) if len(shapes[n]) else 1 for n in names]
     offs, total, live_idx, live_ranges = flat_layout(names, numels, K)
-    out = orc.forward(P, ms, pan, K)
+    if mode == 'chained':       # every tensor is live: one bucket = the whole flat buffer (Engine._live[True])
+        live_idx, live_ranges = list(range(len(names))), [(0, total)]
+    out = orc.forward(P, ms, pan, K, mode=mode)
     loss = (out - gt).abs().sum() / n_global          # this rank's share of the global mean
     loss.backward()
     flat = torch.zeros(total)
@@ -34,7 +36,7 @@ def _flat_grads(P, ms, pan, gt, n_global):
     return flat, live_ranges, float(loss)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
     from lgteun_amd import ddp
@@ -45,16 +47,19 @@ def _worker(rank, world, port, q):
     T = torch.from_numpy
     P = det_params(C, K, requires_grad=True)
     n_global = B * C * 4 * H * 4 * H
-    flat, ranges, loss = _flat_grads(P, T(ms[a:b]), T(pan[a:b]), T(gt[a:b]), n_global)
+    flat, ranges, loss = _flat_grads(P, T(ms[a:b]), T(pan[a:b]), T(gt[a:b]), n_global, mode)
     # weights broadcast from rank 0 must leave identical buffers identical
     wflat = torch.cat([v.detach().reshape(-1) for v in P.values()])
     before = wflat.clone()
     ddp.broadcast_flat(wflat, 0)
     assert torch.equal(wflat, before)
     buckets = ddp.GradBuckets(ranges)
-    buckets.start(flat, 1)       # LGT bucket first (overlaps the data-step backward on the GPU path)
-    buckets.start(flat, 0)
-    buckets.finish()
+    if mode == 'chained':
+        buckets.all_reduce(flat)
+    else:
+        buckets.start(flat, 1)       # LGT bucket first (overlaps the data-step backward on the GPU path)
+        buckets.start(flat, 0)
+        buckets.finish()
     lt = torch.tensor([loss], dtype=torch.float64)
     dist.all_reduce(lt)
     if rank == 0:
@@ -63,13 +68,14 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradients_equal_single_process():
+@pytest.mark.parametrize('mode', ['faithful', 'chained'])
+def test_two_rank_gradients_equal_single_process(mode):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     got, loss2 = q.get(timeout=300)
@@ -79,10 +85,17 @@ def test_two_rank_gradients_equal_single_process():
     ms, pan, gt = dw.make_inputs(B, C, H, H, seed=21, kind='smooth')
     T = torch.from_numpy
     P = det_params(C, K, requires_grad=True)
-    want, ranges, loss1 = _flat_grads(P, T(ms), T(pan), T(gt), B * C * 4 * H * 4 * H)
+    want, ranges, loss1 = _flat_grads(P, T(ms), T(pan), T(gt), B * C * 4 * H * 4 * H, mode)
     assert abs(loss1 - loss2) < 1e-6
     want = want.numpy()
     assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1.0) + 1e-7
+    if mode == 'chained':
+        from lgteun_amd.engine import canonical_names, flat_layout
+        shapes = state_shapes(C, K)
+        names = canonical_names(C, K)
+        _, _, _, d3 = flat_layout(names, [int(np.prod(shapes[n])) if len(shapes[n]) else 1 for n in names], K)
+        assert np.abs(got[d3[0][1]:d3[1][0]]).max() > 0      # the first stage's LGT now trains
+        return
     (a0, b0), (a1, b1) = ranges
     assert np.all(got[b0:a1] == 0.0)                 # dead-stage slots never receive a gradient
     assert np.abs(got[a1:b1]).max() > 0 and np.abs(got[a0:b0]).max() > 0
