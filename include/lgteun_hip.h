@@ -60,7 +60,9 @@ enum lg_kernel_id {
 typedef struct lg_config {
     int32_t C;       /* MS bands: 4 or 8                      (cfg.ms_chans, unlg_former.py:24) */
     int32_t K;       /* unfolding stages                      (stage kwarg, unlg_former.py:22)  */
-    int32_t H, W;    /* PAN size = 4 x MS size; H == W, power of two, 16..512 (FFT mixer: plane in LDS up to 128, split path above) */
+    int32_t H, W;    /* PAN size = 4 x MS size: multiples of 16, 16..1024 (LGT.py needs 8-px windows at both levels).  Square powers
+                      * of two up to 512 take the radix-2 FFT paths (plane in LDS up to 128, split above); everything else
+                      * (400x400 full-resolution scenes, rectangles) the Bluestein path -- same results, slower mixer */
     int32_t precision; /* 0 = fp32 storage/compute (parity mode); 1 = bf16 storage of FFN hidden tensors */
 } lg_config;
 

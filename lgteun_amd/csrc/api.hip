@@ -89,8 +89,8 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
     if (cfg->precision != 0 && cfg->precision != 1) { lg_set_error("plan_create: precision must be 0 (fp32) or 1 (bf16 hidden storage)"); return -2; }
     if (cfg->K < 1 || cfg->K > LG_MAX_K) { lg_set_error("plan_create: K out of range (%d)", cfg->K); return -2; }
     if (cfg->H % 16 || cfg->W % 16 || cfg->H <= 0 || cfg->W <= 0) { lg_set_error("plan_create: H,W must be positive multiples of 16"); return -2; }
-    if (cfg->H != cfg->W || (cfg->H & (cfg->H - 1)) || cfg->H > 512) {
-        lg_set_error("plan_create: FFT mixer supports square power-of-two PAN sizes <= 512 (got %dx%d)", cfg->H, cfg->W);
+    if (cfg->H > 1024 || cfg->W > 1024) {   // FFT mixer: Bluestein lines of up to 1024 points (square powers of two <= 512: radix-2 paths)
+        lg_set_error("plan_create: PAN sizes up to 1024x1024 are supported (got %dx%d)", cfg->H, cfg->W);
         return -2;
     }
     const int expect = S_NSHARED + cfg->K + L_NSLOT * cfg->K;
@@ -162,7 +162,7 @@ static int block_mixer_fwd(const lg_plan* pl, const float* P, int stage, int j, 
     f.scratch = fft_scratch;
     f.ampw = P + pl->blk(stage, j, B_AMPW); f.ampb = P + pl->blk(stage, j, B_AMPB);
     f.phaw = P + pl->blk(stage, j, B_PHAW); f.phab = P + pl->blk(stage, j, B_PHAB);
-    f.ch = bb.e / 2; f.planes = B * f.ch; f.n = bb.h;
+    f.ch = bb.e / 2; f.planes = B * f.ch; f.n = bb.h; f.h = bb.h; f.w = bb.w;
     if ((rc = launch_fftmix(f, s))) return rc;
     AttnArgs t;
     t.x = bb.xin; t.o2 = bb.o2; t.y = bb.xmid; t.posT = posT;
@@ -366,7 +366,7 @@ extern "C" int lg_op_block(const lg_plan* plan, const float* params, int32_t sta
         f.g = bb.g; f.o = y; f.amp = nullptr; f.pha = nullptr; f.sgn = nullptr; f.scratch = nb.fft_scratch;
         f.ampw = params + plan->blk(stage, blk, B_AMPW); f.ampb = params + plan->blk(stage, blk, B_AMPB);
         f.phaw = params + plan->blk(stage, blk, B_PHAW); f.phab = params + plan->blk(stage, blk, B_PHAB);
-        f.ch = bb.e / 2; f.planes = B * f.ch; f.n = bb.h;
+        f.ch = bb.e / 2; f.planes = B * f.ch; f.n = bb.h; f.h = bb.h; f.w = bb.w;
         return launch_fftmix(f, s);
     }
     if (which == 1) {

@@ -206,8 +206,9 @@ struct FftBwdArgs {
     float *d_ampw, *d_ampb, *d_phaw, *d_phab;
     float* part;       // scratch: per-workgroup partial sums of the four parameter gradients, fft_bwd_part_floats()
     int planes, ch, n;
+    int h, w;          // plane size (when non-zero; n = side of a square plane otherwise)
 };
-size_t fft_bwd_part_floats(int planes, int n);
+size_t fft_bwd_part_floats(int planes, int h, int w);
 int launch_fftmix_bwd(const FftBwdArgs& a, hipStream_t s);
 
 struct AttnBwdArgs {

@@ -127,7 +127,7 @@ static int fft_bwd_call(const lg_plan* pl, const float* P, float* G, int st, int
     fa.phaw = P + pl->blk(st, j, B_PHAW); fa.phab = P + pl->blk(st, j, B_PHAB);
     fa.d_ampw = G + pl->blk(st, j, B_AMPW); fa.d_ampb = G + pl->blk(st, j, B_AMPB);
     fa.d_phaw = G + pl->blk(st, j, B_PHAW); fa.d_phab = G + pl->blk(st, j, B_PHAB);
-    fa.ch = hc; fa.planes = B * hc; fa.n = fb.h; fa.part = part;
+    fa.ch = hc; fa.planes = B * hc; fa.n = fb.h; fa.h = fb.h; fa.w = fb.w; fa.part = part;
     return launch_fftmix_bwd(fa, s);
 }
 
@@ -142,7 +142,7 @@ static int mixer_half_bwd(const lg_plan* pl, const float* P, float* G, int st, i
     po.HW = fb.h * fb.w; po.total = Pn; po.dropout = drop; po.seed = mix_seed(seed, st, j);
     RC(launch_proj_o2_bwd(e, po, s));
     const float* dym = drop ? bb.dym : tmp;
-    float* fpart = bb.rq.take(fft_bwd_part_floats(B * hc, fb.h));
+    float* fpart = bb.rq.take(fft_bwd_part_floats(B * hc, fb.h, fb.w));
     if (!fpart) return -3;
     RC(fft_bwd_call(pl, P, G, st, j, fb, bb.do2, bb.dg, B, s, bb.fft_scratch, fpart));
     AttnBwdArgs at;

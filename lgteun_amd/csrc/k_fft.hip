@@ -413,6 +413,11 @@ __global__ void k_fft_rows_inv(const float2* __restrict__ S, float* __restrict__
 }
 
 size_t fft_scratch_floats(int planes, int n) { return n > 128 ? (size_t)planes * n * (n / 2 + 1) * 2 : 0; }
+bool fft_is_generic(int h, int w);
+// half-spectrum scratch of the paths that go through HBM (split: square powers of two above 128; generic: everything else)
+size_t fft_scratch_floats_hw(int planes, int h, int w) {
+    return (fft_is_generic(h, w) || h > 128) ? (size_t)planes * h * (w / 2 + 1) * 2 : 0;
+}
 
 static int split_attrs() {
     static bool done = false;
@@ -460,11 +465,267 @@ static int launch_fft_split(const FftArgs* fa, const FftBwdArgs* ba, hipStream_t
     return 0;
 }
 
+
+// ================================================================================================
+// Generic path: any plane h x w (sides multiples of 8 up to 1024: 400 x 400 full-resolution scenes, rectangular
+// crops, ...).  Same three-kernel structure as the split path (rows -> global half spectrum -> columns + edit -> rows), but every
+// line transform is a Bluestein chirp-z DFT evaluated with the power-of-two passes above:
+//     X_k = w_k * sum_j (x_j w_j) conj(w)_{k-j},   w_k = exp(-i pi k^2 / n)
+// i.e. one forward and one inverse FFT of length M >= 2n - 1 per line; the chirp filter's spectrum is computed once per
+// workgroup.  The DIF forward leaves bit-reversed order and the DIT inverse consumes it, so the pointwise product needs no
+// reordering.  Inverse transforms use IDFT(x) = conj(DFT(conj(x))).  Built for coverage, not speed: the square power-of-two
+// sizes (all BASELINE configs) never come here.
+// ================================================================================================
+struct GDft { int n, M, lgM, L, lgL; };   // line length, FFT length, lines per workgroup
+static GDft gdft_plan(int n) {
+    GDft d;
+    d.n = n; d.lgM = 0;
+    while ((1 << d.lgM) < 2 * n - 1) ++d.lgM;
+    d.M = 1 << d.lgM;
+    d.L = 8192 / d.M;          // 64 KiB of lines per workgroup
+    if (d.L > 16) d.L = 16;
+    d.lgL = 0;
+    while ((1 << d.lgL) < d.L) ++d.lgL;
+    return d;
+}
+static size_t gdft_lds_bytes(const GDft& d) { return ((size_t)d.L * d.M + d.M + d.n + d.M / 2) * sizeof(float2) + 64 * sizeof(float); }
+bool fft_is_generic(int h, int w) { return !(h == w && (h & (h - 1)) == 0 && h >= 8 && h <= 512); }
+
+struct GLds { float2 *lines, *bf, *wch, *tw; float* red; };
+__device__ __forceinline__ GLds gdft_carve(float2* smem, const GDft& d) {
+    GLds g;
+    g.lines = smem; g.bf = smem + ((size_t)d.L << d.lgM); g.wch = g.bf + d.M; g.tw = g.wch + d.n;
+    g.red = reinterpret_cast<float*>(g.tw + d.M / 2);
+    return g;
+}
+// twiddles of length M, chirp w_k (k < n, k^2 reduced mod 2n in integers so the angle keeps full precision) and the spectrum of
+// the chirp filter b_j = conj(w_j), |j| < n, wrapped to length M -- in the bit-reversed order the lines' spectra come out in
+__device__ __forceinline__ void gdft_setup(const GLds& g, const GDft& d) {
+    make_twiddles(g.tw, d.M);
+    for (int k = threadIdx.x; k < d.n; k += blockDim.x) {
+        const int k2 = (k * k) % (2 * d.n);
+        const float ang = (float)k2 / (float)d.n;
+        g.wch[k] = make_float2(cospif(ang), 0.0f - sinpif(ang));
+    }
+    for (int k = threadIdx.x; k < d.M; k += blockDim.x) g.bf[k] = make_float2(0.f, 0.f);
+    __syncthreads();
+    for (int k = threadIdx.x; k < d.n; k += blockDim.x) {
+        const float2 c = make_float2(g.wch[k].x, -g.wch[k].y);
+        g.bf[k] = c;
+        if (k) g.bf[d.M - k] = c;
+    }
+    __syncthreads();
+    fft_lines<false, false>(g.bf, g.tw, d.lgM, 0, d.M, 1);
+}
+// unnormalised forward DFT (length n) of the L lines [L][M] (entries k < n are the input; the rest is scratch), in place,
+// natural order on both sides.  Caller has synchronised after writing the input.
+__device__ __forceinline__ void gdft_lines(const GLds& g, const GDft& d) {
+    const int tot = d.L << d.lgM, msk = d.M - 1;
+    const float inv = 1.0f / (float)d.M;
+    for (int i = threadIdx.x; i < tot; i += blockDim.x) {
+        const int k = i & msk;
+        g.lines[i] = (k < d.n) ? cmul(g.lines[i], g.wch[k]) : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    fft_lines<false, false>(g.lines, g.tw, d.lgM, d.lgL, d.M, 1);
+    for (int i = threadIdx.x; i < tot; i += blockDim.x) g.lines[i] = cmul(g.lines[i], g.bf[i & msk]);
+    __syncthreads();
+    fft_lines<true, false>(g.lines, g.tw, d.lgM, d.lgL, d.M, 1);
+    for (int i = threadIdx.x; i < tot; i += blockDim.x) {
+        const int k = i & msk;
+        if (k < d.n) {
+            const float2 v = cmul(g.lines[i], g.wch[k]);
+            g.lines[i] = make_float2(v.x * inv, v.y * inv);
+        }
+    }
+    __syncthreads();
+}
+
+// real rows (length w) -> half spectrum S[plane][h][w/2+1]
+__global__ void k_gfft_rows_fwd(const float* __restrict__ in, const float* __restrict__ mul, float2* __restrict__ S, int h, int w, GDft d,
+                                int force_real) {
+    extern __shared__ float2 smem2[];
+    const GLds g = gdft_carve(smem2, d);
+    const size_t plane = blockIdx.x;
+    const int row0 = blockIdx.y * d.L, halfw = w >> 1;
+    gdft_setup(g, d);
+    for (int i = threadIdx.x; i < d.L * w; i += blockDim.x) {
+        const int l = i / w, x = i - l * w, row = row0 + l;
+        float v = 0.f;
+        if (row < h) {
+            const size_t o = (plane * h + row) * w + x;
+            v = in[o];
+            if (mul) v *= mul[o];
+        }
+        g.lines[(l << d.lgM) + x] = make_float2(v, 0.0f);
+    }
+    __syncthreads();
+    gdft_lines(g, d);
+    for (int i = threadIdx.x; i < d.L * (halfw + 1); i += blockDim.x) {
+        const int l = i / (halfw + 1), kx = i - l * (halfw + 1), row = row0 + l;
+        if (row >= h) continue;
+        float2 v = g.lines[(l << d.lgM) + kx];
+        if (force_real && (kx == 0 || kx == halfw)) v.y = 0.0f;
+        S[(plane * h + row) * (halfw + 1) + kx] = v;
+    }
+}
+
+// columns (length h) of the half spectrum, in place: forward DFT, bin edit (forward or backward), inverse DFT
+template <bool BWD>
+__global__ void k_gfft_cols(FftArgs fa, FftBwdArgs ba, float2* __restrict__ S, int h, int w, GDft d) {
+    extern __shared__ float2 smem2[];
+    const GLds g = gdft_carve(smem2, d);          // line c = column kx0 + c, element = row
+    const size_t plane = blockIdx.x;
+    const int chn = BWD ? ba.ch : fa.ch;
+    const int ch = (int)(plane % chn);
+    const int halfw = w >> 1, kx0 = blockIdx.y * d.L;
+    const int ncols = min(d.L, halfw + 1 - kx0);
+    gdft_setup(g, d);
+    for (int i = threadIdx.x; i < h * d.L; i += blockDim.x) {
+        const int y = i >> d.lgL, c = i & (d.L - 1);
+        g.lines[(c << d.lgM) + y] = (c < ncols) ? S[(plane * h + y) * (halfw + 1) + kx0 + c] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    gdft_lines(g, d);
+    if (!BWD) {   // the four purely-real bins: ky in {0, h/2} x kx in {0, w/2}
+        if (threadIdx.x < 2 * d.L) {
+            const int q = threadIdx.x >> d.lgL, c = threadIdx.x & (d.L - 1);
+            if (c < ncols && (kx0 + c == 0 || kx0 + c == halfw)) g.lines[(c << d.lgM) + (q ? (h >> 1) : 0)].y = 0.0f;
+        }
+        __syncthreads();
+    }
+    const float aw = (BWD ? ba.ampw : fa.ampw)[ch], ab = (BWD ? ba.ampb : fa.ampb)[ch];
+    const float pw = (BWD ? ba.phaw : fa.phaw)[ch], pb = (BWD ? ba.phab : fa.phab)[ch];
+    const float nn = (float)h * (float)w;
+    float s_aw = 0.f, s_ab = 0.f, s_pw = 0.f, s_pb = 0.f;
+    for (int i = threadIdx.x; i < d.L * h; i += blockDim.x) {
+        const int c = i / h, ky = i - c * h;
+        if (c >= ncols) continue;
+        const int kx = kx0 + c, idx = (c << d.lgM) + ky;
+        const size_t o = (plane * h + ky) * (halfw + 1) + kx;
+        float2 v;
+        if (!BWD) {
+            float amp, pha;
+            v = bin_edit_fwd(g.lines[idx], aw, ab, pw, pb, amp, pha);
+            if (fa.amp) { fa.amp[o] = amp; fa.pha[o] = pha; }
+        } else {
+            const float cw = (kx == 0 || kx == halfw) ? 1.0f : 2.0f;
+            v = bin_edit_bwd(g.lines[idx], cw, nn, ba.amp[o], ba.pha[o], aw, ab, pw, pb, s_aw, s_ab, s_pw, s_pb);
+        }
+        g.lines[idx] = make_float2(v.x, -v.y);    // conj: the inverse transform is conj(DFT(conj(.)))
+    }
+    __syncthreads();
+    gdft_lines(g, d);
+    for (int i = threadIdx.x; i < h * d.L; i += blockDim.x) {
+        const int y = i >> d.lgL, c = i & (d.L - 1);
+        if (c < ncols) {
+            const float2 v = g.lines[(c << d.lgM) + y];
+            S[(plane * h + y) * (halfw + 1) + kx0 + c] = make_float2(v.x, -v.y);
+        }
+    }
+    if (BWD) {
+        float v[4] = {s_aw, s_ab, s_pw, s_pb};
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
+            if (lane == 0) g.red[wave * 4 + i] = v[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            float sum = 0.f;
+            for (int k = 0; k < nw; ++k) sum += g.red[k * 4 + threadIdx.x];
+            ba.part[(((plane / chn) * gridDim.y + blockIdx.y) * chn + ch) * 4 + threadIdx.x] = sum;   // [sample][column group][channel][4]
+        }
+    }
+}
+
+// half spectrum rows -> real rows (c2r)
+__global__ void k_gfft_rows_inv(const float2* __restrict__ S, float* __restrict__ out, float* __restrict__ sgn, int h, int w, GDft d, int absout) {
+    extern __shared__ float2 smem2[];
+    const GLds g = gdft_carve(smem2, d);
+    const size_t plane = blockIdx.x;
+    const int row0 = blockIdx.y * d.L, halfw = w >> 1;
+    gdft_setup(g, d);
+    for (int i = threadIdx.x; i < d.L * (halfw + 1); i += blockDim.x) {
+        const int l = i / (halfw + 1), kx = i - l * (halfw + 1), row = row0 + l;
+        const float2 v = (row < h) ? S[(plane * h + row) * (halfw + 1) + kx] : make_float2(0.f, 0.f);
+        float2* ln = g.lines + (l << d.lgM);
+        if (kx == 0 || kx == halfw) {
+            ln[kx] = make_float2(v.x, 0.0f);                 // c2r drops these imaginary parts
+        } else {
+            ln[kx] = make_float2(v.x, -v.y);                 // conj(X_kx)
+            ln[w - kx] = v;                                  // conj(X_{w-kx}) = conj(conj(X_kx))
+        }
+    }
+    __syncthreads();
+    gdft_lines(g, d);
+    const float sc = 1.0f / ((float)h * (float)w);
+    for (int i = threadIdx.x; i < d.L * w; i += blockDim.x) {
+        const int l = i / w, x = i - l * w, row = row0 + l;
+        if (row >= h) continue;
+        const float v = g.lines[(l << d.lgM) + x].x * sc;
+        const size_t o = (plane * h + row) * w + x;
+        if (absout) {
+            out[o] = fabsf(v);
+            if (sgn) sgn[o] = (v > 0.f) ? 1.0f : ((v < 0.f) ? -1.0f : 0.0f);
+        } else {
+            out[o] = v;
+        }
+    }
+}
+
+static int fft_generic_col_groups(int h, int w) { const GDft dh = gdft_plan(h); return (w / 2 + 1 + dh.L - 1) / dh.L; }
+
+static int launch_fft_generic(const FftArgs* fa, const FftBwdArgs* ba, int h, int w, hipStream_t s) {
+    const int planes = fa ? fa->planes : ba->planes;
+    float2* S = reinterpret_cast<float2*>(fa ? fa->scratch : ba->scratch);
+    if (!S) { lg_set_error("fftmix: plane %dx%d needs the generic path but no scratch buffer was given", h, w); return -2; }
+    if (h < 8 || w < 8 || h > 1024 || w > 1024 || (h & 7) || (w & 7)) {
+        lg_set_error("fftmix: plane %dx%d unsupported (sides: multiples of 8, 8..1024)", h, w);
+        return -2;
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        const void* fns[4] = {(const void*)k_gfft_rows_fwd, (const void*)k_gfft_cols<false>, (const void*)k_gfft_cols<true>, (const void*)k_gfft_rows_inv};
+        for (int i = 0; i < 4; ++i) {
+            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+            if (e != hipSuccess) { lg_set_error("fft generic: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        }
+        attr_done = true;
+    }
+    const GDft dw = gdft_plan(w), dh = gdft_plan(h);
+    const size_t lds_r = gdft_lds_bytes(dw), lds_c = gdft_lds_bytes(dh);
+    dim3 grows(planes, (h + dw.L - 1) / dw.L), gcols(planes, fft_generic_col_groups(h, w));
+    if (fa) {
+        k_gfft_rows_fwd<<<grows, 1024, lds_r, s>>>(fa->g, nullptr, S, h, w, dw, 1);
+        LG_CHECK_LAUNCH();
+        FftBwdArgs dummy;
+        memset(&dummy, 0, sizeof(dummy));
+        k_gfft_cols<false><<<gcols, 1024, lds_c, s>>>(*fa, dummy, S, h, w, dh);
+        LG_CHECK_LAUNCH();
+        k_gfft_rows_inv<<<grows, 1024, lds_r, s>>>(S, fa->o, fa->sgn, h, w, dw, 1);
+        LG_CHECK_LAUNCH();
+    } else {
+        k_gfft_rows_fwd<<<grows, 1024, lds_r, s>>>(ba->do2, ba->sgn, S, h, w, dw, 0);
+        LG_CHECK_LAUNCH();
+        FftArgs dummy;
+        memset(&dummy, 0, sizeof(dummy));
+        k_gfft_cols<true><<<gcols, 1024, lds_c, s>>>(dummy, *ba, S, h, w, dh);
+        LG_CHECK_LAUNCH();
+        k_gfft_rows_inv<<<grows, 1024, lds_r, s>>>(S, ba->dg, nullptr, h, w, dw, 0);
+        LG_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
 int launch_fftmix(const FftArgs& a, hipStream_t s) {
     ProfScope prof__(LG_K_FFT, s);
-    int n = a.n, lg = 0;
+    const int ph = a.h ? a.h : a.n, pw = a.w ? a.w : a.n;
+    if (fft_is_generic(ph, pw)) return launch_fft_generic(&a, nullptr, ph, pw, s);
+    int n = ph, lg = 0;
     while ((1 << lg) < n) ++lg;
-    if ((1 << lg) != n || n < 8 || n > 512) { lg_set_error("fftmix: plane size %d unsupported (power of two, 8..512)", n); return -2; }
     if (n > 128) return launch_fft_split(&a, nullptr, s);
     size_t lds = ((size_t)n * FFT_LD(n) + n / 2) * sizeof(float2);
     static bool attr_done = false;
@@ -551,15 +812,18 @@ __global__ void k_fftmix_bwd(FftBwdArgs a) {
     }
 }
 
-static int fft_bwd_col_groups(int n) { return n > 128 ? (n / 2 + 1 + FFT_COLS_PER_WG(n) - 1) / FFT_COLS_PER_WG(n) : 1; }
-size_t fft_bwd_part_floats(int planes, int n) { return (size_t)planes * fft_bwd_col_groups(n) * 4; }
+static int fft_bwd_col_groups(int h, int w) {
+    if (fft_is_generic(h, w)) return fft_generic_col_groups(h, w);
+    return h > 128 ? (h / 2 + 1 + FFT_COLS_PER_WG(h) - 1) / FFT_COLS_PER_WG(h) : 1;
+}
+size_t fft_bwd_part_floats(int planes, int h, int w) { return (size_t)planes * fft_bwd_col_groups(h, w) * 4; }
 // the four per-channel parameter gradients from the partial rows [sample][column group][channel][4]
 static int fft_bwd_reduce(const FftBwdArgs& a, hipStream_t s) {
     float* dst[4] = {a.d_ampw, a.d_ampb, a.d_phaw, a.d_phab};
     for (int k = 0; k < 4; ++k) {
         ReduceJob j;
         j.slab = a.part + k; j.dst = dst[k]; j.dst2 = nullptr;
-        j.nslices = (long)(a.planes / a.ch) * fft_bwd_col_groups(a.n); j.slice_stride = (long)a.ch * 4;
+        j.nslices = (long)(a.planes / a.ch) * fft_bwd_col_groups(a.h ? a.h : a.n, a.w ? a.w : a.n); j.slice_stride = (long)a.ch * 4;
         j.rows = a.ch; j.cols = 1; j.row_stride = 4; j.ld = 1; j.rows_valid = a.ch; j.cols_valid = 1;
         int rc = launch_reduce_job(j, s);
         if (rc) return rc;
@@ -574,9 +838,10 @@ int launch_fftmix_bwd(const FftBwdArgs& a, hipStream_t s) {
 }
 static int launch_fftmix_bwd_kernels(const FftBwdArgs& a, hipStream_t s) {
     ProfScope prof__(LG_K_FFT_BWD, s);
-    int n = a.n, lg = 0;
+    const int ph = a.h ? a.h : a.n, pw = a.w ? a.w : a.n;
+    if (fft_is_generic(ph, pw)) return launch_fft_generic(nullptr, &a, ph, pw, s);
+    int n = ph, lg = 0;
     while ((1 << lg) < n) ++lg;
-    if ((1 << lg) != n || n < 8 || n > 512) { lg_set_error("fftmix_bwd: plane size %d unsupported", n); return -2; }
     if (n > 128) return launch_fft_split(nullptr, &a, s);
     size_t lds = ((size_t)n * FFT_LD(n) + n / 2) * sizeof(float2) + 64 * sizeof(float);
     static bool attr_done = false;

@@ -74,10 +74,13 @@ struct FftArgs {
     float* sgn;       // optional save: sign of the irfft2 output [B,ch,n,n]
     float* scratch;   // n > 128 only: half-spectrum scratch [planes][n][n/2+1] complex
     const float *ampw, *ampb, *phaw, *phab;  // [ch]
-    int planes, ch, n;
+    int planes, ch, n;   // n: side of a square plane (legacy callers); h, w (when non-zero) override it
+    int h, w;
 };
 int launch_fftmix(const FftArgs& a, hipStream_t s);
 size_t fft_scratch_floats(int planes, int n);
+size_t fft_scratch_floats_hw(int planes, int h, int w);
+bool fft_is_generic(int h, int w);   // true: Bluestein three-kernel path (anything but a square power of two 8..512)
 
 // ---------------- local mixer + proj + residual, LGT.py:112-146,183-219,231-248 ----------------
 struct AttnArgs {

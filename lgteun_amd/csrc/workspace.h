@@ -2,6 +2,7 @@
 // maps named activation tensors onto it deterministically from (plan, B, train).
 #pragma once
 #include "common.h"
+#include "kernels.h"
 
 struct Carver {
     char* base;
@@ -109,8 +110,9 @@ static inline void carve(const lg_plan* plan, int B, int train, void* base, NetB
     nb.set_bytes = cv.off - nb.set_off;
     if (train == 2) cv.off += (size_t)(c.K - 1) * nb.set_bytes;
     {
-        const size_t planes = (size_t)B * (E / 2);
-        const size_t fl = c.H > 128 ? planes * c.H * (c.H / 2 + 1) * 2 : 0;
+        // level 0: B * E/2 planes of H x W; level 1: B * E planes of H/2 x W/2 -- level 0's is the larger whenever both need one
+        const size_t f0 = fft_scratch_floats_hw((int)(B * (E / 2)), c.H, c.W), f1 = fft_scratch_floats_hw((int)(B * E), c.H / 2, c.W / 2);
+        const size_t fl = f0 > f1 ? f0 : f1;
         nb.fft_scratch = fl ? cv.take(fl) : nullptr;
     }
     nb.bytes = cv.off;

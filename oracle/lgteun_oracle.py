@@ -155,12 +155,27 @@ def local_mixer(P, pre, x, heads=2, win=8):
     return out.permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, c)
 
 
+# The four bins (ky in {0, H/2}) x (kx in {0, W/2}) of a real plane's spectrum are purely real; where their real part is
+# negative, angle() returns +pi or -pi by the SIGN OF THE ZERO the FFT library happened to leave in the imaginary part.  For
+# power-of-two sizes pocketfft leaves +0 on every host we ran; for other sizes (radix-3/5 passes) the sign depends on the host
+# CPU's code path (measured: +0 in the build container, -0 for the ky = H/2 bins on the GPU box's host, PAN 48x48).  The
+# reference's result is therefore machine-dependent there.  With this switch on, the oracle uses the +0 (= +pi) convention
+# for those four bins everywhere -- what the reference computes wherever its zero is positive.  Default off = verbatim.
+CANONICAL_REAL_BINS = False
+
+
 def global_mixer(P, pre, x):
     """LGT.py:149-180.  x: [B,H,W,c] -> [B,H,W,c]; FFT amplitude/phase mixer."""
     B, H, W, c = x.shape
     xc = x.permute(0, 3, 1, 2)
     fre = torch.fft.rfft2(xc, norm='backward')
     amp = torch.abs(fre)
+    if CANONICAL_REAL_BINS:
+        keep = torch.ones(H, W // 2 + 1, dtype=fre.real.dtype)
+        for ky in (0, H // 2):
+            for kx in (0, W // 2):
+                keep[ky, kx] = 0.0
+        fre = torch.complex(fre.real, fre.imag * keep + 0.0)     # x * 0 + 0 = +0 for either sign of zero
     pha = torch.angle(fre)
     amp = dep_conv(amp, P[pre + 'conv_amp.0.weight'], P[pre + 'conv_amp.0.bias'])
     pha = dep_conv(pha, P[pre + 'conv_pha.0.weight'], P[pre + 'conv_pha.0.bias'])

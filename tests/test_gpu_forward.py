@@ -146,8 +146,8 @@ def test_bad_inputs_raise(gpu):
         net(torch.zeros(1, 3, 8, 8, device='cuda'), torch.zeros(1, 1, 32, 32, device='cuda'))
     with pytest.raises(LgteunHipError):      # PAN 24x24: not a multiple of 16
         net(torch.zeros(1, 4, 6, 6, device='cuda'), torch.zeros(1, 1, 24, 24, device='cuda'))
-    with pytest.raises(LgteunHipError):      # PAN 96x96: not a power of two (FFT mixer)
-        net(torch.zeros(1, 4, 24, 24, device='cuda'), torch.zeros(1, 1, 96, 96, device='cuda'))
+    with pytest.raises(LgteunHipError):      # PAN 1040x16: beyond the 1024-point FFT lines
+        net(torch.zeros(1, 4, 260, 4, device='cuda'), torch.zeros(1, 1, 1040, 16, device='cuda'))
     with pytest.raises(RuntimeError):        # no CPU path
         make_module(4, 1, device='cpu')(torch.zeros(1, 4, 8, 8), torch.zeros(1, 1, 32, 32))
 

@@ -21,7 +21,7 @@ def main():
     import lgteun_amd
     from gpu_helpers import make_module
     from lgteun_amd import FusedAdam
-    cfgs = [('c2', 4, 128, 4, 32), ('c3', 8, 128, 4, 32), ('c5 (C=8)', 8, 256, 8, 16), ('c5 with C=4', 4, 256, 8, 16), ('512^2 PAN', 4, 512, 4, 4)]
+    cfgs = [('c2', 4, 128, 4, 32), ('c3', 8, 128, 4, 32), ('c5 (C=8)', 8, 256, 8, 16), ('c5 with C=4', 4, 256, 8, 16), ('512^2 PAN', 4, 512, 4, 4), ('400^2 PAN', 4, 400, 4, 4)]
     for name, C, H, K, B in cfgs:
         if args.only and args.only not in name:
             continue
