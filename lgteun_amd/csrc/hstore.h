@@ -9,8 +9,14 @@ typedef __bf16 bf16_t;
 template <bool BF>
 struct HS;
 
+// raw4 / ldraw / widen: a prefetch must keep the loaded bits untouched in its registers -- widening bf16 at load time makes the
+// conversion (and so an s_waitcnt for the load) sit right behind the issue, which serialises the prefetch it was meant to hide
 template <>
 struct HS<false> {
+    typedef float4 raw4;
+    static __device__ __forceinline__ raw4 ldraw(const void* base, long idx) { return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + idx); }
+    static __device__ __forceinline__ raw4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ float4 widen(raw4 u) { return u; }
     static __device__ __forceinline__ float4 ld4(const void* base, long idx) { return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + idx); }
     static __device__ __forceinline__ void st4(void* base, long idx, float4 v) { *reinterpret_cast<float4*>(static_cast<float*>(base) + idx) = v; }
     static __device__ __forceinline__ float ld1(const void* base, long idx) { return static_cast<const float*>(base)[idx]; }
@@ -19,6 +25,13 @@ struct HS<false> {
 
 template <>
 struct HS<true> {
+    typedef uint2 raw4;
+    static __device__ __forceinline__ raw4 ldraw(const void* base, long idx) { return *reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(base) + idx); }
+    static __device__ __forceinline__ raw4 zero() { return make_uint2(0u, 0u); }
+    static __device__ __forceinline__ float4 widen(raw4 u) {
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xffff0000u));
+    }
     static __device__ __forceinline__ float4 ld4(const void* base, long idx) {
         const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(base) + idx);
         return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),

@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
     constexpr bool PF = (E == 16);
     float4 w3r[PF ? NTG : 1][1];
     if (PF) load_bfrag<NTG, 1>(reinterpret_cast<float4(&)[NTG][1]>(w3r), a.w3t + (size_t)c0 * E, E);
-    float4 dyr[NDY], h2r[NG3], g3n[NG3];
+    float4 dyr[NDY];
+    typename HS<BF>::raw4 h2r[NG3], g3n[NG3];   // raw bits: widened when they leave the prefetch registers
     auto issue = [&](int tile_) {
         int t_ = tile_;
         const int tx_ = t_ % tiles_x;
@@ -97,16 +98,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
 #pragma unroll
         for (int it = 0; it < NG3; ++it) {
             const int i = threadIdx.x + it * 256;
-            h2r[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            g3n[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            h2r[it] = HS<BF>::zero();
+            g3n[it] = HS<BF>::zero();
             if (i < NH * CQ) {
                 const int m = i / CQ, qq = i - m * CQ;
                 const int hy = m / HX, hx = m - hy * HX;
                 const int y = yb + hy - 1, x = xb + hx - 1;
                 if (y >= 0 && y < h && x >= 0 && x < w) {
                     const long o = ((b_ * h + y) * (long)w + x) * N1 + c0 + 4 * qq;
-                    h2r[it] = HS<BF>::ld4(a.h2, o);
-                    g3n[it] = HS<BF>::ld4(a.g3, o);
+                    h2r[it] = HS<BF>::ldraw(a.h2, o);
+                    g3n[it] = HS<BF>::ldraw(a.g3, o);
                 }
             }
         }
@@ -135,10 +136,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
 #pragma unroll
     for (int it = 0; it < NG3; ++it) {
         const int i = threadIdx.x + it * 256;
-        g3r[it] = g3n[it];
+        g3r[it] = HS<BF>::widen(g3n[it]);
         if (i < NH * CQ) {
             const int m = i / CQ, qq = i - m * CQ;
-            *reinterpret_cast<float4*>(bufH + m * LDG + 4 * qq) = h2r[it];
+            *reinterpret_cast<float4*>(bufH + m * LDG + 4 * qq) = HS<BF>::widen(h2r[it]);
         }
     }
     if (PF && tile + 1 < tile_end) issue(tile + 1);
@@ -298,18 +299,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
     // PF: x / dy of the wave's 16 pixels are spread over all 64 lanes (lane = 4 * pixel + channel quarter: one float4 each,
     // one coalesced 1 KB row per load) and the LayerNorm phases work 4 lanes per pixel; otherwise lane < MW owns a whole pixel
     constexpr int NX = PF ? 1 : E / 4;
-    float4 dh2n[NR], g1n[NR], xn[NX], dyn[NX];
+    float4 xn[NX], dyn[NX];
+    typename HS<BF>::raw4 dh2n[NR], g1n[NR];    // raw bits: widened when they leave the prefetch registers
     auto issue = [&](long chunk_) {
         const long q0 = (chunk_ * 4 + wave) * MW;
 #pragma unroll
         for (int it = 0; it < NR; ++it) {
             const int i = lane + it * 64;
             const int m = i / (N1 / 4), k4 = i - m * (N1 / 4);
-            dh2n[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            g1n[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            dh2n[it] = HS<BF>::zero();
+            g1n[it] = HS<BF>::zero();
             if (q0 + m < a.P) {
-                dh2n[it] = HS<BF>::ld4(a.dh2, (q0 + m) * N1 + 4 * k4);
-                g1n[it] = HS<BF>::ld4(a.g1, (q0 + m) * N1 + 4 * k4);
+                dh2n[it] = HS<BF>::ldraw(a.dh2, (q0 + m) * N1 + 4 * k4);
+                g1n[it] = HS<BF>::ldraw(a.g1, (q0 + m) * N1 + 4 * k4);
             }
         }
         if (PF) {
@@ -338,8 +340,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
     for (int it = 0; it < NR; ++it) {
         const int i = lane + it * 64;
         const int m = i / (N1 / 4), k4 = i - m * (N1 / 4);
-        g1r[it] = g1n[it];
-        *reinterpret_cast<float4*>(bufD + m * LDH + 4 * k4) = dh2n[it];
+        g1r[it] = HS<BF>::widen(g1n[it]);
+        *reinterpret_cast<float4*>(bufD + m * LDH + 4 * k4) = HS<BF>::widen(dh2n[it]);
     }
     float4 xr[NX], dyr[NX];
 #pragma unroll
