@@ -28,7 +28,7 @@ PEAK_HBM_GBS = 8000.0
 PEAK_F32_MFMA_TFLOPS = 157.3
 
 # HBM bytes per launch from the PMC counters (profiles/, FETCH_SIZE x2 corrected + WRITE_SIZE; separate --pmc passes), per kernel
-TRAFFIC_BYTES = {'ffn': 234356066}   # k_ffn_fused, all launches of a step averaged (profiles/r01_bench_bs32_pmc_hbm.csv)
+TRAFFIC_BYTES = {'ffn': 234240860}   # k_ffn_fused, all launches of a step averaged (profiles/r01_bench_bs32_pmc_hbm.csv)
 
 C, K, H, B_PER_GPU = 4, 4, 128, 32
 E, P0 = 4 * C, H * H
