@@ -26,6 +26,7 @@ def main():
         if args.only and args.only not in name:
             continue
         for mode in ('faithful', 'live', 'chained'):
+            torch.cuda.reset_peak_memory_stats()
             net = make_module(C, K)
             net.mode = mode
             net.train()
