@@ -53,16 +53,17 @@ struct AdjPlan {
 template <int MODE>
 __global__ __launch_bounds__(256) void k_resample_adj(const float* __restrict__ gout, float* __restrict__ gin, int planes, int hi, int wi,
                                                       int ho, int wo, int accumulate) {
-    long total = (long)planes * hi * wi;
-    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
-        int ix = (int)(idx % wi);
-        long r = idx / wi;
-        int iy = (int)(r % hi);
-        long p = r / hi;
+    // blockIdx.y = plane, 32-bit pixel index inside it: the flat 64-bit index this kernel used to split with two 64-bit
+    // divisions per element cost more than its 16 gathers
+    const int hw = hi * wi;
+    const size_t pin = (size_t)blockIdx.y * hw;
+    const float* g = gout + (size_t)blockIdx.y * ho * wo;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+        const int iy = (int)((unsigned)i / (unsigned)wi);
+        const int ix = i - iy * wi;
         AdjPlan<MODE> py, px;
         py.make(iy, hi, ho);
         px.make(ix, wi, wo);
-        const float* g = gout + p * ho * wo;
         float acc = 0.f;
         // column offsets clamped into the row (their coefficient is 0 there): the NC loads of a row are unconditional, so they
         // issue as one batch instead of NC load -> wait -> fma steps
@@ -81,15 +82,16 @@ __global__ __launch_bounds__(256) void k_resample_adj(const float* __restrict__ 
             for (int b = 0; b < AdjPlan<MODE>::NC; ++b) rs += px.coef[b] * v[b];
             acc += py.coef[a] * rs;
         }
-        if (accumulate) gin[idx] += acc; else gin[idx] = acc;
+        if (accumulate) gin[pin + i] += acc; else gin[pin + i] = acc;
     }
 }
 
 int launch_resample_adj(int mode, const float* gout, float* gin, int planes, int hi, int wi, int accumulate, hipStream_t s) {
     int ho = mode == 0 ? hi / 2 : hi * 2, wo = mode == 0 ? wi / 2 : wi * 2;
-    long total = (long)planes * hi * wi;
-    int grid = (int)((total + 255) / 256);
-    if (grid > 4096) grid = 4096;
+    if (planes > 65535) { lg_set_error("resample_adj: %d planes exceed the grid limit", planes); return -2; }
+    int gx = (hi * wi + 255) / 256;
+    if (gx > 64) gx = 64;
+    dim3 grid(gx, planes);
     if (mode == 0) k_resample_adj<0><<<grid, 256, 0, s>>>(gout, gin, planes, hi, wi, ho, wo, accumulate);
     else k_resample_adj<1><<<grid, 256, 0, s>>>(gout, gin, planes, hi, wi, ho, wo, accumulate);
     LG_CHECK_LAUNCH();
