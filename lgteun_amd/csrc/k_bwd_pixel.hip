@@ -50,50 +50,83 @@ struct AdjPlan {
     }
 };
 
+// Adjoint of the separable clamped polyphase resampler, itself evaluated separably through LDS.  A workgroup owns RT input
+// rows of one plane: the gout rows they touch are staged once (G), contracted along x into T[gout row][ix] with the per-column
+// plans, then along y with the per-row plans -- 2 NC LDS reads per element instead of the NC x NC global gathers (100 for the
+// x2 adjoint) of the direct form, and the plans (a few hundred ALU ops each) are built once per workgroup, not per element.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_resample_adj(const float* __restrict__ gout, float* __restrict__ gin, int planes, int hi, int wi,
-                                                      int ho, int wo, int accumulate) {
-    // blockIdx.y = plane, 32-bit pixel index inside it: the flat 64-bit index this kernel used to split with two 64-bit
-    // divisions per element cost more than its 16 gathers
-    const int hw = hi * wi;
-    const size_t pin = (size_t)blockIdx.y * hw;
+__global__ __launch_bounds__(256) void k_resample_adj(const float* __restrict__ gout, float* __restrict__ gin, int hi, int wi, int ho, int wo,
+                                                      int accumulate, int rt, int grows) {
+    constexpr int NC = AdjPlan<MODE>::NC, PL = NC + 1;
+    extern __shared__ float sm[];
+    float* G = sm;                                  // [grows][wo]
+    float* T = G + (size_t)grows * wo;              // [grows][wi]
+    float* spx = T + (size_t)grows * wi;            // [wi][PL]: base (int bits), NC coefficients
+    float* spy = spx + (size_t)wi * PL;             // [rt][PL]
+    const int ry0 = blockIdx.x * rt;
+    const int nrow = min(rt, hi - ry0);
     const float* g = gout + (size_t)blockIdx.y * ho * wo;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
-        const int iy = (int)((unsigned)i / (unsigned)wi);
-        const int ix = i - iy * wi;
-        AdjPlan<MODE> py, px;
-        py.make(iy, hi, ho);
-        px.make(ix, wi, wo);
+    for (int i = threadIdx.x; i < wi + nrow; i += 256) {
+        AdjPlan<MODE> pl;
+        float* dst;
+        if (i < wi) { pl.make(i, wi, wo); dst = spx + i * PL; }
+        else { pl.make(ry0 + i - wi, hi, ho); dst = spy + (i - wi) * PL; }
+        dst[0] = __int_as_float(pl.base);
+#pragma unroll
+        for (int a = 0; a < NC; ++a) dst[1 + a] = pl.coef[a];
+    }
+    // gout rows [gy0, gy0 + grows): the windows of rows ry0 .. ry0 + nrow - 1 (rows outside the image are never weighted)
+    const int gy0 = (MODE == 0) ? (ry0 / 2 - 1) : (2 * ry0 - 4);
+    for (int i = threadIdx.x; i < grows * wo; i += 256) {
+        const int ly = (int)((unsigned)i / (unsigned)wo), x = i - ly * wo;
+        const int gy = gy0 + ly;
+        G[i] = (gy >= 0 && gy < ho) ? g[(size_t)gy * wo + x] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < grows * wi; i += 256) {
+        const int ly = (int)((unsigned)i / (unsigned)wi), ix = i - ly * wi;
+        const float* pp = spx + ix * PL;
+        const int bx = __float_as_int(pp[0]);
+        const float* grow = G + ly * wo;
         float acc = 0.f;
-        // column offsets clamped into the row (their coefficient is 0 there): the NC loads of a row are unconditional, so they
-        // issue as one batch instead of NC load -> wait -> fma steps
-        int cx[AdjPlan<MODE>::NC];
 #pragma unroll
-        for (int b = 0; b < AdjPlan<MODE>::NC; ++b) cx[b] = clampi(px.base + b, 0, wo - 1);
+        for (int b = 0; b < NC; ++b) acc += pp[1 + b] * grow[clampi(bx + b, 0, wo - 1)];   // clamped taps carry coefficient 0
+        T[i] = acc;
+    }
+    __syncthreads();
+    float* out = gin + (size_t)blockIdx.y * hi * wi + (size_t)ry0 * wi;
+    for (int i = threadIdx.x; i < nrow * wi; i += 256) {
+        const int ly = (int)((unsigned)i / (unsigned)wi), ix = i - ly * wi;
+        const float* pp = spy + ly * PL;
+        const int by = __float_as_int(pp[0]) - gy0;     // first T row of this input row's window
+        float acc = 0.f;
 #pragma unroll
-        for (int a = 0; a < AdjPlan<MODE>::NC; ++a) {
-            if (py.coef[a] == 0.f) continue;
-            const float* grow = g + (long)(py.base + a) * wo;
-            float v[AdjPlan<MODE>::NC];
-#pragma unroll
-            for (int b = 0; b < AdjPlan<MODE>::NC; ++b) v[b] = grow[cx[b]];
-            float rs = 0.f;
-#pragma unroll
-            for (int b = 0; b < AdjPlan<MODE>::NC; ++b) rs += px.coef[b] * v[b];
-            acc += py.coef[a] * rs;
-        }
-        if (accumulate) gin[pin + i] += acc; else gin[pin + i] = acc;
+        for (int a = 0; a < NC; ++a) acc += pp[1 + a] * T[clampi(by + a, 0, grows - 1) * wi + ix];
+        if (accumulate) out[i] += acc; else out[i] = acc;
     }
 }
 
 int launch_resample_adj(int mode, const float* gout, float* gin, int planes, int hi, int wi, int accumulate, hipStream_t s) {
-    int ho = mode == 0 ? hi / 2 : hi * 2, wo = mode == 0 ? wi / 2 : wi * 2;
+    const int ho = mode == 0 ? hi / 2 : hi * 2, wo = mode == 0 ? wi / 2 : wi * 2;
     if (planes > 65535) { lg_set_error("resample_adj: %d planes exceed the grid limit", planes); return -2; }
-    int gx = (hi * wi + 255) / 256;
-    if (gx > 64) gx = 64;
-    dim3 grid(gx, planes);
-    if (mode == 0) k_resample_adj<0><<<grid, 256, 0, s>>>(gout, gin, planes, hi, wi, ho, wo, accumulate);
-    else k_resample_adj<1><<<grid, 256, 0, s>>>(gout, gin, planes, hi, wi, ho, wo, accumulate);
+    const int NC = mode == 0 ? 3 : 10;
+    // rows per workgroup: as many as keep G + T under ~48 KB (three workgroups per CU), at least one
+    int rt = 16;
+    auto grows_of = [&](int r) { return mode == 0 ? ((r - 1) / 2 + 3) : (2 * r + 8); };
+    while (rt > 1 && (size_t)grows_of(rt) * (wo + wi) * sizeof(float) > 48 * 1024) rt >>= 1;
+    const int grows = grows_of(rt);
+    const size_t lds = ((size_t)grows * (wo + wi) + (size_t)(wi + rt) * (NC + 1)) * sizeof(float);
+    if (lds > 150 * 1024) { lg_set_error("resample_adj: plane width %d too large", wi); return -2; }
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_resample_adj<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_resample_adj<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) { lg_set_error("resample_adj: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    dim3 grid((hi + rt - 1) / rt, planes);
+    if (mode == 0) k_resample_adj<0><<<grid, 256, lds, s>>>(gout, gin, hi, wi, ho, wo, accumulate, rt, grows);
+    else k_resample_adj<1><<<grid, 256, lds, s>>>(gout, gin, hi, wi, ho, wo, accumulate, rt, grows);
     LG_CHECK_LAUNCH();
     return 0;
 }
