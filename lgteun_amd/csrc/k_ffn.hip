@@ -621,6 +621,277 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
     }   // tiles of this workgroup
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_ffn_strip (e = 16, fp32): the fused feed_forward half-block walking DOWN a 16-column strip.  k_ffn_fused recomputes h1 / h2
+// on the full 10x18 halo of every 8x16 tile (192 MFMA rows per 128 output pixels); here consecutive tiles of a strip share
+// their halo rows through a 10-row LDS ring of h2, so a step only computes the 8 NEW halo rows (8 x 18 = 144 pixels = exactly
+// 9 MFMA row blocks).  144 rows do not split evenly over 4 waves by rows, so the OUTPUT COLUMNS are split instead (as in the
+// e = 32 path): wave w owns columns [16 w, 16 w + 16) of h1 and h2 for all rows and keeps its W1 / W2 slices in 5 VGPR quads.
+// GEMM1/GEMM2 MFMAs per 128 pixels: 720 instead of 960; GELU-1 evaluations 9 216 instead of 12 288.
+// LDS: {LN(x) rows [144][16] + gelu(h1) chunk [48][68]} aliased with {per-wave chunk [4][16][68] + output tile [128][17]}
+// = 26 KB, h2 ring [10][18][68] = 49 KB -> 75 KB, two workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+template <bool SAVE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn_strip(Ffn1Args a1, Ffn2Args a2, int tiles_x, int strips_y, int nstrips,
+                                                                                          int SH) {
+    constexpr int E = 16, N1 = 64, TX = 16, HX = 18, TY = 8, RING = 10, LDA = 16, LDH = 68, LDO = 17, CQ = 16, M = 128;
+    constexpr int R1 = 4 * 16 * LDH + M * LDO;   // 6528 floats >= 144 * LDA + 48 * LDH
+    extern __shared__ float smem[];
+    float* bufA = smem;                  // [144][LDA]  LN2(x) of the new halo rows
+    float* A2 = smem + 144 * LDA;        // [48][LDH]   gelu(h1) chunk, shared by the waves
+    float* scr = smem;                   // P2: [4][16][LDH] per-wave gelu(dw(h2)) chunk
+    float* bufO = smem + 4 * 16 * LDH;   // P2/P3: [M][LDO] output tile
+    float* ring = smem + R1;             // [RING][HX][LDH] h2 rows y, slot (y - (Y0 - 1)) % RING
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    float* my = scr + wave * 16 * LDH;
+    const int h = a2.h, w = a2.w;
+    __shared__ __attribute__((aligned(16))) float sPar[5 * E];
+    float* sLn2g = sPar;            float* sLn2b = sPar + E;
+    float* sN1g = sPar + 2 * E;     float* sN1b = sPar + 3 * E;
+    float* sB3 = sPar + 4 * E;
+    for (int i = threadIdx.x; i < E; i += 256) {
+        sLn2g[i] = a1.ln2g[i]; sLn2b[i] = a1.ln2b[i]; sB3[i] = a2.b3[i];
+        sN1g[i] = a2.g ? a2.n1g[i] : 0.f; sN1b[i] = a2.g ? a2.n1b[i] : 0.f;
+    }
+    __shared__ __attribute__((aligned(16))) float sMask[144];   // 1 for halo pixels inside the image (h2 is zero-padded outside)
+    const int col = wave * 16 + r;                 // the h1 / h2 column this lane holds in the MFMA C layout
+    const float b1c = a1.b1[col], b2c = a1.b2[col];
+    float4 w1p[1][1], w2p[1][4];
+    load_bfrag<1, 1>(w1p, a1.w1 + (size_t)(wave * 16) * E, E);
+    load_bfrag<1, 4>(w2p, a1.w2 + (size_t)(wave * 16) * N1, N1);
+    // the column split leaves P1 with 20 weight registers (the row-split tile kernel holds 80), so the depthwise taps and the W3
+    // fragments stay resident too: no weight load -- LDS or global -- inside a step
+    const int q = lane % CQ;
+    float wq[4][9], bq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int kk = 0; kk < 9; ++kk) wq[u][kk] = a2.dww[(4 * q + u) * 9 + kk];
+        bq[u] = a2.dwb[4 * q + u];
+    }
+    float4 w3f[1][4];
+    load_bfrag<1, 4>(w3f, a2.w3, N1);
+#pragma unroll 1
+    for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+    int t = strip;
+    const int tx_i = t % tiles_x;
+    t /= tiles_x;
+    const int sy = t % strips_y;
+    const long b = t / strips_y;
+    const int x0 = tx_i * TX, Y0 = sy * SH, Yend = min(Y0 + SH, h);
+
+    // h2 of halo rows [ya, ya + nr) x columns [x0 - 1, x0 + 17) -> ring   (nr = 2: strip prologue, 8: one step)
+    auto compute_rows = [&](int ya, int nr) {
+        const int npx = nr * HX, nchunks = (npx + 47) / 48;
+        __syncthreads();   // readers of bufA / A2 space (previous step's output tile) are done
+        if (threadIdx.x < nchunks * 48) {
+            const int m = threadIdx.x;
+            const int hy = m / HX, hx = m - hy * HX;
+            const int y = ya + hy, x = x0 + hx - 1;
+            float xv[E];
+            const bool in = (m < npx) && y >= 0 && y < h && x >= 0 && x < w;
+            sMask[m] = in ? 1.0f : 0.0f;
+            if (in) {
+                const float4* src = reinterpret_cast<const float4*>(a1.x + ((b * h + y) * (long)w + x) * E);
+#pragma unroll
+                for (int k = 0; k < E / 4; ++k) {
+                    float4 v = src[k];
+                    xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
+                }
+                float mu, rstd;
+                ln_stats<E>(xv, mu, rstd);
+#pragma unroll
+                for (int c = 0; c < E; ++c) xv[c] = (xv[c] - mu) * rstd * sLn2g[c] + sLn2b[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < E; ++c) xv[c] = 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k)
+                *reinterpret_cast<float4*>(bufA + m * LDA + 4 * k) = make_float4(xv[4 * k], xv[4 * k + 1], xv[4 * k + 2], xv[4 * k + 3]);
+        }
+        __syncthreads();
+        // ring pixel of halo pixel m: ((s0 + hy) % RING) * HX + hx = (s0 * HX + m) mod (RING * HX) -- no division per pixel
+        const int ring0 = ((ya - Y0 + 1) % RING) * HX;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int row0 = ch * 48;
+            long prow[3][4];
+            int rslot[3][4];
+            bool inner[3][4];
+            float mk[3][4];
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) {
+                const float4 m4 = *reinterpret_cast<const float4*>(sMask + row0 + mt * 16 + 4 * g);
+                mk[mt][0] = m4.x; mk[mt][1] = m4.y; mk[mt][2] = m4.z; mk[mt][3] = m4.w;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int m = row0 + mt * 16 + 4 * g + v;
+                    int rs = ring0 + m;
+                    rs = rs >= RING * HX ? rs - RING * HX : rs;
+                    rslot[mt][v] = (m < npx) ? rs : -1;
+                    if (SAVE) {
+                        const int hy = m / HX, hx = m - hy * HX;
+                        const int y = ya + hy, x = x0 + hx - 1;
+                        inner[mt][v] = mk[mt][v] != 0.f && hx >= 1 && hx <= TX && y >= Y0 && y < Yend;
+                        prow[mt][v] = (b * h + y) * (long)w + x;
+                    }
+                }
+            }
+            f32x4 acc[3][1];
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            wave_gemm_rb<3, 1, 1>(acc, bufA + row0 * LDA, LDA, w1p);
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+                for (int v = 0; v < 4; v += 2) {
+                    const lg_v2f hh = (lg_v2f){acc[mt][0][v] + b1c, acc[mt][0][v + 1] + b1c};
+                    lg_v2f av;
+                    if (SAVE) {
+                        lg_v2f gv;
+                        gelu2_both_f(hh, av, gv);
+                        if (inner[mt][v]) { HS<false>::st1(a1.a1s, prow[mt][v] * N1 + col, av.x); HS<false>::st1(a1.g1s, prow[mt][v] * N1 + col, gv.x); }
+                        if (inner[mt][v + 1]) { HS<false>::st1(a1.a1s, prow[mt][v + 1] * N1 + col, av.y); HS<false>::st1(a1.g1s, prow[mt][v + 1] * N1 + col, gv.y); }
+                    } else {
+                        av = gelu2_f(hh);
+                    }
+                    A2[(mt * 16 + 4 * g + v) * LDH + col] = av.x;
+                    A2[(mt * 16 + 4 * g + v + 1) * LDH + col] = av.y;
+                }
+            __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            wave_gemm_rb<3, 1, 4>(acc, A2, LDH, w2p);
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float hh = (acc[mt][0][v] + b2c) * mk[mt][v];   // dep_conv zero-pads h2 (basic_module_unformer_v2.py:18)
+                    if (SAVE && inner[mt][v]) HS<false>::st1(a1.h2, prow[mt][v] * N1 + col, hh);
+                    if (rslot[mt][v] >= 0) ring[rslot[mt][v] * LDH + col] = hh;
+                }
+            __syncthreads();   // A2 is rewritten by the next chunk; the ring rows are complete after the last one
+        }
+    };
+
+    compute_rows(Y0 - 1, 2);
+#pragma unroll 1
+    for (int y0 = Y0; y0 < Yend; y0 += TY) {
+    // the residual rows of P3 are requested first: their HBM round trip hides under the whole step
+    float4 xres[E / 4];
+    if (threadIdx.x < M) {
+        const int ym = y0 + threadIdx.x / TX, xm = x0 + threadIdx.x % TX;
+        if (ym < h && xm < w) {
+            const float4* xs0 = reinterpret_cast<const float4*>(a2.x + ((b * h + ym) * (long)w + xm) * E);
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) xres[k] = xs0[k];
+        }
+    }
+    compute_rows(y0 + 1, TY);
+    // ---- P2: per wave, 2 chunks of 16 inner pixels: dw3x3 over the ring + GELU -> scratch -> GEMM3 -> output tile
+    {
+        const int sbase = (y0 - Y0) % RING;            // ring slot of row y0 - 1
+        for (int ch = 0; ch < 2; ++ch) {
+            const int m0 = (wave * 2 + ch) * 16;
+            for (int mm = lane / CQ; mm < 16; mm += 64 / CQ) {
+                const int m = m0 + mm;
+                const int ty = m / TX, tx = m - ty * TX;
+                float4 acc = make_float4(bq[0], bq[1], bq[2], bq[3]);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    int sl = sbase + ty + dy;
+                    sl = sl >= RING ? sl - RING : sl;
+                    sl = sl >= RING ? sl - RING : sl;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float4 v = *reinterpret_cast<const float4*>(ring + (sl * HX + tx + dx) * LDH + 4 * q);
+                        acc.x += wq[0][dy * 3 + dx] * v.x; acc.y += wq[1][dy * 3 + dx] * v.y;
+                        acc.z += wq[2][dy * 3 + dx] * v.z; acc.w += wq[3][dy * 3 + dx] * v.w;
+                    }
+                }
+                const int y = y0 + ty, x = x0 + tx;
+                float4 av;
+                if (SAVE) {
+                    lg_v2f a01, a23, g01, g23;
+                    gelu2_both_f((lg_v2f){acc.x, acc.y}, a01, g01);
+                    gelu2_both_f((lg_v2f){acc.z, acc.w}, a23, g23);
+                    av = make_float4(a01.x, a01.y, a23.x, a23.y);
+                    if (y < Yend && x < w) {
+                        const long o = ((b * h + y) * (long)w + x) * N1 + 4 * q;
+                        HS<false>::st4(a2.a3s, o, av);
+                        HS<false>::st4(a2.g3s, o, make_float4(g01.x, g01.y, g23.x, g23.y));
+                    }
+                } else {
+                    const lg_v2f a01 = gelu2_f((lg_v2f){acc.x, acc.y}), a23 = gelu2_f((lg_v2f){acc.z, acc.w});
+                    av = make_float4(a01.x, a01.y, a23.x, a23.y);
+                }
+                *reinterpret_cast<float4*>(my + mm * LDH + 4 * q) = av;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            f32x4 acc3[1][1];
+            acc3[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            wave_gemm_rb<1, 1, 4>(acc3, my, LDH, w3f);
+            const float bias = sB3[r];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) bufO[(m0 + 4 * g + v) * LDO + r] = acc3[0][0][v] + bias;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    // ---- P3: residual, store, planar LN1 half for the next block
+    if (threadIdx.x < M) {
+        const int m = threadIdx.x;
+        const int y = y0 + m / TX, x = x0 + m % TX;
+        if (y < Yend && x < w) {
+            const long p = (b * h + y) * (long)w + x;
+            float o[E];
+            float4* yo = reinterpret_cast<float4*>(a2.y + p * E);
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) {
+                const float4 xr = xres[k];
+                o[4 * k] = xr.x + bufO[m * LDO + 4 * k];
+                o[4 * k + 1] = xr.y + bufO[m * LDO + 4 * k + 1];
+                o[4 * k + 2] = xr.z + bufO[m * LDO + 4 * k + 2];
+                o[4 * k + 3] = xr.w + bufO[m * LDO + 4 * k + 3];
+                yo[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+            }
+            if (a2.g) {
+                float mu, rstd;
+                ln_stats<E>(o, mu, rstd);
+                const long hw = (long)h * w, sp = (long)y * w + x;
+#pragma unroll
+                for (int n = E / 2; n < E; ++n) a2.g[(b * (E / 2) + (n - E / 2)) * hw + sp] = (o[n] - mu) * rstd * sN1g[n] + sN1b[n];
+            }
+        }
+    }
+    }   // steps of the strip
+    }   // strips of this workgroup
+}
+
+static int launch_ffn_strip(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
+    ProfScope prof__(LG_K_FFN2, s);
+    const size_t lds = (size_t)(4 * 16 * 68 + 128 * 17 + 10 * 18 * 68) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_strip<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_strip<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e != hipSuccess) { lg_set_error("ffn_strip: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    const int tiles_x = (a2.w + 15) / 16;
+    // strip height: the tallest multiple of 8 rows that still yields >= 512 strips (two resident workgroups per CU), at least 16
+    int SH = (a2.h + 7) / 8 * 8;
+    while (SH > 16 && (long)a2.B * tiles_x * ((a2.h + SH - 1) / SH) < 512) SH = (SH / 2 + 7) / 8 * 8;
+    const int strips_y = (a2.h + SH - 1) / SH;
+    const int nstrips = a2.B * tiles_x * strips_y;
+    const int grid = nstrips < 512 ? nstrips : 512;
+    if (a1.a1s != nullptr) k_ffn_strip<true><<<grid, 256, lds, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    else k_ffn_strip<false><<<grid, 256, lds, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int E>
 static int launch_ffn_fused_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     ProfScope prof__(LG_K_FFN2, s);
@@ -925,7 +1196,8 @@ int launch_ffn_fused(int e, const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t 
         if (e == 32) return launch_ffn_fused_bf_t<32>(a1, a2, s);
         return 1;
     }
-    if (e == 16) return launch_ffn_fused_t<16>(a1, a2, s);
+    // e = 16: the strip kernel (halo rows shared through the LDS ring); LG_FFN_TILE=1 selects the per-tile kernel it replaced, for A/B runs
+    if (e == 16) return getenv("LG_FFN_TILE") ? launch_ffn_fused_t<16>(a1, a2, s) : launch_ffn_strip(a1, a2, s);
     if (e == 32) return launch_ffn_fused_t<32>(a1, a2, s);   // (the split k_ffn1 + k_ffn2 pair measured slower at e = 32 too)
     return 1;
 }
