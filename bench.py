@@ -28,7 +28,7 @@ PEAK_HBM_GBS = 8000.0
 PEAK_F32_MFMA_TFLOPS = 157.3
 
 # HBM bytes per launch from the PMC counters (profiles/, FETCH_SIZE x2 corrected + WRITE_SIZE; separate --pmc passes), per kernel
-TRAFFIC_BYTES = {'ffn': 234240860}   # k_ffn_fused, all launches of a step averaged (profiles/r01_bench_bs32_pmc_hbm.csv)
+TRAFFIC_BYTES = {'ffn': 228845703}   # fused FFN forward (k_ffn_strip at e=16, k_ffn_fused at e=32), all launches of a step averaged (profiles/r01_bench_bs32_pmc_hbm.csv)
 
 C, K, H, B_PER_GPU = 4, 4, 128, 32
 E, P0 = 4 * C, H * H
@@ -50,7 +50,7 @@ def algorithmic_per_launch(kernel, B):
     figures are averaged over those 5 launches."""
     px = [(E, P0)] * 4 + [(2 * E, P0 // 4)]
     if kernel == 'ffn':
-        # k_ffn_fused = the whole feed_forward half-block: x in, y out (+ planar LN half for the next mixer: e/2)
+        # k_ffn_strip (level 0, e=16) / k_ffn_fused (level 1, e=32) = the whole feed_forward half-block: x in, y out (+ planar LN half for the next mixer: e/2)
         byts = sum((2 * e + e // 2) * p * 4 for e, p in px) / 5 * B
         flops = sum((2 * (e * 4 * e + 4 * e * 4 * e + 4 * e * e) + 18 * 4 * e) * p for e, p in px) / 5 * B
         return byts, flops
