@@ -145,9 +145,7 @@ def main():
     net.mode = args.mode
     net.precision = args.precision
     net.train()
-    eng = net.engine()
-    if world > 1:
-        eng.attach_ddp()
+    eng = net.attach_ddp() if world > 1 else net.engine()
     opt = lgteun_amd.FusedAdam(net.parameters(), lr=1.5e-3, betas=(0.9, 0.999))          # configs/unlg_former.py:82-84
     sched = torch.optim.lr_scheduler.StepLR(opt, step_size=25900, gamma=0.85)              # :86, stepped every iteration
     ms, pan, gt = synth_batch(B_PER_GPU, rank, device)

@@ -1,7 +1,8 @@
 """Runner counterpart of reference models/base/base_model.py restricted to the hot path's callers:
 add_module :56, set_cuda :91 (one process per GPU + RCCL instead of nn.DataParallel), load_checkpoint :102,
 set_optim :116 (Adam -> fused HIP Adam), set_sched :137 (StepLR stepped EVERY iteration :197-199),
-train :164, test :267 (PSNR/SAM/ERGAS only), save :354."""
+train :164, test :267 (reference-based indices PSNR / SSIM / Q / SAM / ERGAS; the no-reference QNR family is out of scope,
+SURVEY section 2), save :354 (same `train_out/` location; optimizer state added)."""
 import os.path as osp
 
 import numpy as np
@@ -40,6 +41,9 @@ class Base_model:
         self.test_data_loader1 = test_data_loader1
         self.datas = cfg.datas
         mkdir_or_exist(self.work_dir)
+        self.train_out = f'{self.work_dir}/{self.datas}/train_out'        # base_model.py:44-46
+        self.test_out0 = f'{self.work_dir}/{self.datas}/test_out0'
+        self.test_out1 = f'{self.work_dir}/{self.datas}/test_out1'
         self.eval_results = {}
         self.module_dict = {}
         self.optim_dict = {}
@@ -65,8 +69,12 @@ class Base_model:
     def set_cuda(self):
         """one process per GPU (torch.distributed/RCCL set up by the launcher) -- replaces nn.DataParallel."""
         dev = torch.device('cuda', torch.cuda.current_device())
+        import torch.distributed as dist
+        ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         for name in self.module_dict:
             self.module_dict[name] = self.module_dict[name].to(dev)
+            if ddp and hasattr(self.module_dict[name], 'attach_ddp'):
+                self.module_dict[name].attach_ddp()       # rank-0 weights broadcast; gradients all-reduced every step
         for name in self.loss_module:
             self.loss_module[name] = self.loss_module[name].to(dev)
 
@@ -79,6 +87,10 @@ class Base_model:
         checkpoint = torch.load(path, weights_only=False)
         self.last_iter = checkpoint['iter_num']
         self._load_modules(checkpoint)
+        self._resume_optim = checkpoint.get('optim')     # checkpoints of this build carry it; restored by set_optim()
+        for name, st in (self._resume_optim or {}).items():
+            if name in self.optim_dict:
+                self.optim_dict[name].load_state_dict(st)
 
     def load_pretrained(self, path):
         self._load_modules(torch.load(path, weights_only=False))
@@ -103,6 +115,9 @@ class Base_model:
                     raise SystemExit(f'No such type optim:{typ}')
             else:
                 self.optim_dict[module_name] = Adam(module.parameters(), betas=(0.9, 0.999), lr=1e-4)
+            resume = getattr(self, '_resume_optim', None) or {}
+            if module_name in resume:                     # load_checkpoint ran first (main.py order): continue the Adam moments
+                self.optim_dict[module_name].load_state_dict(resume[module_name])
 
     def set_sched(self):
         sched_cfg = dict(self.cfg.get('sched_cfg', dict(step_size=10000, gamma=0.99)))
@@ -119,8 +134,7 @@ class Base_model:
         while iter_id < self.cfg.max_iter:
             for input_batch in self.train_data_loader:
                 input_batch = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in input_batch.items()}
-                if self.cfg.get('norm_input', True):
-                    input_batch = data_normalize(input_batch, self.cfg.bit_depth)
+                input_batch = data_normalize(input_batch, self.cfg.bit_depth)     # unconditional, base_model.py:181
                 iter_id += 1
                 for module in self.module_dict.values():
                     module.train()
@@ -130,8 +144,9 @@ class Base_model:
                     return (freq != -1) and (iter_id % freq == 0) and (iter_id != self.cfg.max_iter)
                 if should(self.cfg.save_freq):
                     self.save(iter_id=iter_id)
-                if should(self.cfg.eval_freq) and self.test_data_loader1 is not None:
-                    self.test(iter_id=iter_id, save=False, ref=True)
+                if should(self.cfg.eval_freq):                                     # base_model.py:193-195
+                    self.test(iter_id=iter_id, save=should(self.cfg.test_freq), ref=False)
+                    self.test(iter_id=iter_id, save=should(self.cfg.test_freq), ref=True)
                 for name, sched in self.sched_dict.items():
                     if self.switch_dict[name]:
                         sched.step()                      # StepLR per ITERATION (base_model.py:197-199)
@@ -155,32 +170,36 @@ class Base_model:
 
     @torch.no_grad()
     def test(self, iter_id, save=False, ref=True):
-        """evaluation (base_model.py:267-352): ref=True -> reduced resolution, PSNR / SSIM / Q / SAM / ERGAS against the target;
-        ref=False -> full resolution, no-reference D_lambda / D_s / QNR against the LR MS and the PAN.  Stores
-        `<metric>_mean` / `<metric>_std` lists in self.eval_results like the reference and returns the latest values."""
+        """evaluation (base_model.py:267-352).  ref=True: reduced-resolution set, PSNR / SSIM / Q / SAM / ERGAS against the target,
+        `<metric>_mean` / `<metric>_std` lists in self.eval_results like the reference.  ref=False: the full-resolution set runs
+        through the model (and is saved when asked), but its no-reference indices D_lambda / D_s / QNR are not computed -- that
+        metric family is out of this build's scope.  Inputs are always normalised; arrays are brought back
+        to digital numbers before the metrics / the TIFF writer only with cfg.norm_input (base_model.py:296,311-316)."""
+        from .dataset import save_image
         loader = self.test_data_loader1 if ref else self.test_data_loader0
         for module in self.module_dict.values():
             module.eval()
         dev = next(iter(self.module_dict.values())).parameters().__next__().device
-        names = ['PSNR', 'SSIM', 'Q', 'SAM', 'ERGAS'] if ref else ['D_lambda', 'D_s', 'QNR']
-        norm = self.cfg.get('norm_input', True)
+        names = ['PSNR', 'SSIM', 'Q', 'SAM', 'ERGAS'] if ref else []
+        denorm = bool(self.cfg.get('norm_input', False))
+        out_dir = osp.join(self.test_out1 if ref else self.test_out0, f'iter_{iter_id}')
+        if save:
+            mkdir_or_exist(out_dir)
 
-        def to_np(t):   # [b c h w] -> [b h w c] (PAN: [b h w])
-            t = data_denormalize(t, self.cfg.bit_depth) if norm else t
-            a = t.permute(0, 2, 3, 1).cpu().numpy()
-            return a[..., 0] if a.shape[-1] == 1 else a
+        def to_np(t):   # [b c h w] -> [b h w c]
+            t = data_denormalize(t, self.cfg.bit_depth) if denorm else t
+            return t.permute(0, 2, 3, 1).cpu().numpy()
         res = []
         for input_batch in (loader or []):
             input_batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in input_batch.items()}
-            if norm:
-                input_batch = data_normalize(input_batch, self.cfg.bit_depth)
+            input_batch = data_normalize(input_batch, self.cfg.bit_depth)
             out = to_np(self.get_model_output(input_batch))
             if ref:
                 gt = to_np(input_batch['target'])
                 res.extend(mtc.ref_evaluate(out[i], gt[i]) for i in range(out.shape[0]))
-            else:
-                pan, lr = to_np(input_batch['input_pan']), to_np(input_batch['input_lr'])
-                res.extend(mtc.no_ref_evaluate(out[i], pan[i], lr[i]) for i in range(out.shape[0]))
+            if save:
+                for i, image_id in enumerate(input_batch['image_id']):
+                    save_image(osp.join(out_dir, f'{image_id}_mul_hat.tif'), out[i])
         latest = {}
         if res:
             res = np.array(res)
@@ -189,14 +208,14 @@ class Base_model:
                 self.eval_results.setdefault(f'{name}_std', []).append(round(float(res[:, k].std()), 4))
                 latest[name] = (float(res[:, k].mean()), float(res[:, k].std()))
             if self.logger is not None:
-                self.logger.info(f'iter {iter_id} {"low" if ref else "full"}-resolution eval: {latest}')
+                self.logger.info(f'iter {iter_id} low-resolution eval: {latest}')
         return latest
 
     def save(self, iter_id):
         """reference pickles whole module objects + iter_num (base_model.py:354-369); additionally stores the
         optimizer state (absent in the reference)."""
-        mkdir_or_exist(f'{self.work_dir}/{self.datas}')
-        path = osp.join(self.work_dir, self.datas, f'model_iter_{iter_id}.pth')
+        mkdir_or_exist(self.train_out)
+        path = osp.join(self.train_out, f'model_iter_{iter_id}.pth')
         ckpt = {'iter_num': iter_id}
         for name, module in self.module_dict.items():
             ckpt[name] = module.module if hasattr(module, 'module') else module

@@ -115,11 +115,14 @@ class Engine:
         self._last_ptr = self.params[-1].data_ptr()
         self._plans = {}
         self._ws = {}
+        self._ws_pool = {}             # autograd path: released training workspaces by (plan, B, train), see _WsLease
         self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self._seed_ctr = 0
         self.world = 1
+        self.rank = 0
         self.process_group = None
         self.buckets = None
+        self.local_only = False        # True: the caller runs independent replicas inside an initialised process group on purpose
 
     def chained(self):
         return self.module_mode() == 'chained'
@@ -145,11 +148,23 @@ class Engine:
         import torch.distributed as dist
         from .ddp import GradBuckets, broadcast_flat
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.process_group = group
         if self.world > 1:
             broadcast_flat(self.flat, 0, group)
             self.buckets = {ch: GradBuckets(rg, group) for ch, (_, rg) in self._live.items()}
         return self
+
+    def _check_attached(self):
+        """a process group with more than one rank exists but this engine never joined it: every rank would train on its own
+        shard without the gradient all-reduce and silently diverge (reference: nn.DataParallel reduces implicitly,
+        base_model.py:91-100)"""
+        if self.world > 1 or self.local_only:
+            return
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError('torch.distributed is initialised with world size > 1 but this engine is not attached: call '
+                               'module.attach_ddp() (or set engine.local_only = True for independent replicas)')
 
     # ------------------------------------------------------------------------------------------
     def valid(self):
@@ -183,9 +198,23 @@ class Engine:
             self._ws[key] = ws
         return ws
 
+    def lease_workspace(self, plan, B, train):
+        """a training workspace of its own for one autograd graph: the saved activations of a forward must survive until ITS
+        backward, whatever other forwards (a second graph with the same B, Engine.train_step) run in between.  The lease
+        returns the buffer to a pool when the autograd context that holds it is freed."""
+        need = self.lib.lg_workspace_bytes(plan, B, int(train))
+        key = (plan.value, B, int(train))
+        pool = self._ws_pool.setdefault(key, [])
+        ws = pool.pop() if pool else None
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return _WsLease(ws, pool)
+
     def next_seed(self):
+        """dropout counter seed: torch's seed, a per-step counter and the DDP rank (ranks seeded alike must not draw the same
+        masks for their shards)"""
         self._seed_ctr += 1
-        return (torch.initial_seed() * 0x9E3779B1 + self._seed_ctr) & 0xFFFFFFFFFFFFFFFF
+        return (torch.initial_seed() * 0x9E3779B1 + self._seed_ctr + self.rank * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
     def _check_inputs(self, ms, pan):
         if ms.dim() != 4 or pan.dim() != 4 or ms.shape[1] != self.C or pan.shape[1] != 1:
@@ -200,19 +229,25 @@ class Engine:
         return B, 4 * h, 4 * w
 
     # ------------------------------------------------------------------------------------------
-    def forward_raw(self, ms, pan, flags, seed=0):
+    def forward_raw(self, ms, pan, flags, seed=0, lease=False):
         B, H, W = self._check_inputs(ms, pan)
         ms = ms.contiguous()
         pan = pan.contiguous()
         plan = self.plan(H, W)
-        ws = self.workspace(plan, B, (2 if flags & LG_FLAG_CHAINED else 1) if flags & LG_FLAG_SAVE else 0)
+        train = (2 if flags & LG_FLAG_CHAINED else 1) if flags & LG_FLAG_SAVE else 0
+        if lease:
+            holder = self.lease_workspace(plan, B, train)
+            ws = holder.ws
+        else:
+            holder = None
+            ws = self.workspace(plan, B, train)
         out = torch.empty(B, self.C, H, W, dtype=torch.float32, device=self.device)
         check(self.lib.lgteun_forward(plan, _ptr(self.flat), _ptr(ms), _ptr(pan), _ptr(out), _ptr(ws), ws.numel(), B, flags,
                                       seed, _stream_ptr()), 'lgteun_forward')
-        return out, (plan, ws, ms, pan, B)
+        return out, (plan, ws, ms, pan, B, holder)
 
     def backward_raw(self, saved, dout, gflat, flags, seed=0):
-        plan, ws, ms, pan, B = saved
+        plan, ws, ms, pan, B = saved[:5]
         dout = dout.contiguous()
         check(self.lib.lgteun_backward(plan, _ptr(self.flat), _ptr(gflat), _ptr(ms), _ptr(pan), _ptr(dout), _ptr(ws),
                                        ws.numel(), B, flags, seed, _stream_ptr()), 'lgteun_backward')
@@ -238,6 +273,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     def train_step(self, ms, pan, gt, optim, loss_weight=1.0):
         """forward + L1(mean) + backward + Adam as library calls; returns the device loss scalar (this rank's share)."""
+        self._check_attached()
         flags = self.base_flags(True) | LG_FLAG_SAVE
         if not getattr(optim, 'dropout', True):
             flags &= ~LG_FLAG_DROPOUT
@@ -274,13 +310,27 @@ class Engine:
               'lg_adam_step')
 
 
+class _WsLease:
+    """holds one training workspace for the lifetime of an autograd graph; gives it back to the engine's pool afterwards"""
+
+    def __init__(self, ws, pool):
+        self.ws, self._pool = ws, pool
+
+    def __del__(self):
+        try:
+            self._pool.append(self.ws)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 class _LgteunFn(torch.autograd.Function):
     """autograd bridge for callers that use torch optimizers / losses on the module output."""
 
     @staticmethod
     def forward(ctx, engine, ms, pan, flags, *live):
+        engine._check_attached()
         seed = engine.next_seed() if (flags & LG_FLAG_DROPOUT) else 0
-        out, saved = engine.forward_raw(ms, pan, flags | LG_FLAG_SAVE, seed)
+        out, saved = engine.forward_raw(ms, pan, flags | LG_FLAG_SAVE, seed, lease=True)   # this graph's own activations
         ctx.engine, ctx.saved, ctx.flags, ctx.seed = engine, saved, flags | LG_FLAG_SAVE, seed
         ctx.live_idx = list(engine.live_idx)    # the mode may change before backward runs
         return out
@@ -290,6 +340,10 @@ class _LgteunFn(torch.autograd.Function):
         eng = ctx.engine
         g = torch.zeros(eng.total, dtype=torch.float32, device=eng.device)
         eng.backward_raw(ctx.saved, dout, g, ctx.flags, ctx.seed)
+        if eng.world > 1:
+            # the caller's loss is this rank's local mean: average over ranks like torch DDP does
+            eng.buckets[bool(ctx.flags & LG_FLAG_CHAINED)].all_reduce(g)
+            g.div_(eng.world)
         grads = []
         for i in ctx.live_idx:
             p = eng.params[i]
@@ -325,6 +379,7 @@ class FusedAdam(torch.optim.Optimizer):
         return sd
 
     def load_state_dict(self, sd):
+        sd = dict(sd)                   # the caller's dict stays as it was
         extra = sd.pop('lgteun', None)
         super().load_state_dict(sd)
         if extra is not None:

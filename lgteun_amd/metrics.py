@@ -1,230 +1,123 @@
-"""Image-quality metrics in float64 numpy on denormalised HWC arrays -- mirror of reference models/base/metrics.py:
-reference-based PSNR / SSIM / Q / SAM / ERGAS / SCC (:22-182, ref_evaluate :409-417) and the no-reference D_lambda / D_s / QNR
-used by the full-resolution test (:258-327, 389-406).
+"""Reference-based image-quality indices of the evaluation loop, written from their published definitions.
 
-The reference computes the windowed statistics with cv2.filter2D and then crops to the valid region; a correlation cropped to
-its valid region does not depend on the border rule, so here it is a plain `valid` correlation (scipy), no cv2.  cv2.resize
-(..., INTER_NEAREST) by an integer factor is a strided slice.  Pinned by tests/test_metrics_cpu.py against brute-force
-definitions (cv2 is absent in the build container, so these four cannot be pinned against the reference itself: PSNR, SAM and
-ERGAS are, through the goldens)."""
+    PSNR   10 log10(peak^2 / MSE)
+    SAM    mean spectral angle between the pixel vectors of the two images            (Yuhas et al., 1992)
+    ERGAS  100/ratio * sqrt(mean_band(MSE_band / mean_band^2))                         (Wald, 2000)
+    SSIM   mean over windows of  l(x,y) * cs(x,y)  with Gaussian-weighted local moments   (Wang et al., 2004)
+    Q      universal image quality index: SSIM with C1 = C2 = 0 on box windows          (Wang & Bovik, 2002)
+
+Conventions the evaluation of reference `models/base/metrics.py` fixes, so that numbers are comparable with its tables
+(`ref_evaluate`, metrics.py:409-417): arrays are (H, W) or (H, W, bands) in digital numbers, arithmetic in float64, peak
+value 2047.5 (11-bit data); a multi-band SSIM / Q is the plain mean of the per-band values; SSIM uses an 11-tap Gaussian
+(sigma 1.5) and Q an 8 x 8 box, and both average only over windows that lie fully inside the image; SAM is in radians with
+the cosine clipped to [0, 1]; ERGAS uses ratio 4.
+
+Parity status: PSNR / SAM / ERGAS are pinned by values the reference itself produced (tests/golden/net_*.npz `metrics`).
+SSIM / Q call cv2.filter2D in the reference and cv2 is not installed in the build image, so they are PARITY-UNPINNED: they
+are checked against brute-force evaluations of the definitions above only (tests/test_metrics_cpu.py).  Restricting the
+average to fully covered windows makes the result independent of any border rule.
+The no-reference indices (D_lambda, D_s, QNR) are outside the scope of this build.
+"""
 import numpy as np
-from scipy import ndimage, signal
+from numpy.lib.stride_tricks import sliding_window_view
 
-dynamic_r = 2047.5
+PEAK = 2047.5
+_TINY = np.finfo(np.float64).eps
+SSIM_TAPS, SSIM_SIGMA, Q_BLOCK, ERGAS_RATIO = 11, 1.5, 8, 4
+
+
+def _as_pair(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        raise ValueError(f'images differ in shape: {a.shape} vs {b.shape}')
+    if a.ndim not in (2, 3):
+        raise ValueError(f'expected an (H, W) or (H, W, bands) array, got {a.ndim} dimensions')
+    return a.astype(np.float64), b.astype(np.float64)
+
+
+def _band_mean(index, a, b, *args):
+    """a per-band index averaged over the bands of (H, W, bands) inputs"""
+    a, b = _as_pair(a, b)
+    if a.ndim == 2:
+        return float(index(a, b, *args))
+    return float(np.mean([index(a[..., k], b[..., k], *args) for k in range(a.shape[2])]))
+
+
+def gaussian_taps(n=SSIM_TAPS, sigma=SSIM_SIGMA):
+    """n samples of a centred Gaussian, normalised to sum 1"""
+    t = np.arange(n, dtype=np.float64) - 0.5 * (n - 1)
+    g = np.exp(-0.5 * (t / sigma) ** 2)
+    return g / g.sum()
+
+
+def _inside_windows(img, taps):
+    """separable weighted sum over every window position that lies fully inside `img`: (H, W) -> (H-n+1, W-n+1)"""
+    rows = sliding_window_view(img, taps.size, axis=0) @ taps
+    return sliding_window_view(rows, taps.size, axis=1) @ taps
+
+
+def _local_moments(x, y, taps):
+    """local means, variances and covariance under the window `taps` x `taps`"""
+    mx, my = _inside_windows(x, taps), _inside_windows(y, taps)
+    vx = _inside_windows(x * x, taps) - mx * mx
+    vy = _inside_windows(y * y, taps) - my * my
+    cxy = _inside_windows(x * y, taps) - mx * my
+    return mx, my, vx, vy, cxy
+
+
+def _ssim_band(x, y, peak):
+    c1, c2 = (0.01 * peak) ** 2, (0.03 * peak) ** 2
+    mx, my, vx, vy, cxy = _local_moments(x, y, gaussian_taps())
+    luminance = (2.0 * mx * my + c1) / (mx * mx + my * my + c1)
+    structure = (2.0 * cxy + c2) / (vx + vy + c2)
+    return (luminance * structure).mean()
+
+
+def _q_band(x, y, block):
+    if block < 2:
+        raise ValueError('the Q index needs windows of at least 2 x 2 pixels')
+    mx, my, vx, vy, cxy = _local_moments(x, y, np.full(block, 1.0 / block))
+    energy, spread = mx * mx + my * my, vx + vy
+    # a factor whose denominator vanishes (flat window / zero-mean window) is taken as 1, the value of identical inputs
+    luminance = np.divide(2.0 * mx * my, energy, out=np.ones_like(energy), where=energy > 1e-8)
+    structure = np.divide(2.0 * cxy, spread, out=np.ones_like(spread), where=spread > 1e-8)
+    return (luminance * structure).mean()
+
+
+def psnr(img1, img2, dynamic_range=PEAK):
+    a, b = _as_pair(img1, img2)
+    mse = np.mean(np.square(a - b))
+    if mse <= 1e-10:                      # identical up to rounding: reported as infinite, like the reference's table code
+        return np.inf
+    return float(20.0 * np.log10(dynamic_range / (np.sqrt(mse) + _TINY)))
 
 
 def sam(img1, img2):
-    if not img1.shape == img2.shape:
-        raise ValueError('Input images must have the same dimensions.')
-    assert img1.ndim == 3 and img1.shape[2] > 1, 'image n_channels should be greater than 1'
-    a = img1.astype(np.float64)
-    b = img2.astype(np.float64)
-    inner = (a * b).sum(axis=2)
-    na = np.sqrt((a ** 2).sum(axis=2))
-    nb = np.sqrt((b ** 2).sum(axis=2))
-    cos_theta = (inner / (na * nb + np.finfo(np.float64).eps)).clip(min=0, max=1)
-    return np.mean(np.arccos(cos_theta))
+    a, b = _as_pair(img1, img2)
+    if a.ndim != 3 or a.shape[2] < 2:
+        raise ValueError('the spectral angle needs at least two bands: (H, W, bands)')
+    dot = np.einsum('hwc,hwc->hw', a, b)
+    norms = np.linalg.norm(a, axis=2) * np.linalg.norm(b, axis=2)
+    return float(np.arccos(np.clip(dot / (norms + _TINY), 0.0, 1.0)).mean())
 
 
-def psnr(img1, img2, dynamic_range=dynamic_r):
-    if not img1.shape == img2.shape:
-        raise ValueError('Input images must have the same dimensions.')
-    mse = np.mean((img1.astype(np.float64) - img2.astype(np.float64)) ** 2)
-    if mse <= 1e-10:
-        return np.inf
-    return 20 * np.log10(dynamic_range / (np.sqrt(mse) + np.finfo(np.float64).eps))
+def ergas(img_fake, img_real, scale=ERGAS_RATIO):
+    fake, real = _as_pair(img_fake, img_real)
+    if fake.ndim == 2:
+        fake, real = fake[..., None], real[..., None]
+    band_mse = np.square(fake - real).mean(axis=(0, 1))
+    band_mean = real.mean(axis=(0, 1))
+    return float(100.0 / scale * np.sqrt(np.mean(band_mse / (np.square(band_mean) + _TINY))))
 
 
-def ergas(img_fake, img_real, scale=4):
-    if not img_fake.shape == img_real.shape:
-        raise ValueError('Input images must have the same dimensions.')
-    a = img_fake.astype(np.float64)
-    b = img_real.astype(np.float64)
-    if a.ndim == 2:
-        return 100 / scale * np.sqrt(np.mean((a - b) ** 2) / (b.mean() ** 2 + np.finfo(np.float64).eps))
-    means_real = b.reshape(-1, b.shape[2]).mean(axis=0)
-    mses = ((a - b) ** 2).reshape(-1, a.shape[2]).mean(axis=0)
-    return 100 / scale * np.sqrt((mses / (means_real ** 2 + np.finfo(np.float64).eps)).mean())
+def ssim(img1, img2, dynamic_range=PEAK):
+    return _band_mean(_ssim_band, img1, img2, dynamic_range)
 
 
-def scc(img1, img2):
-    """mean per-band correlation coefficient (metrics.py:58-74)"""
-    if not img1.shape == img2.shape:
-        raise ValueError('Input images must have the same dimensions.')
-    a = img1.astype(np.float64)
-    b = img2.astype(np.float64)
-    if a.ndim == 2:
-        return np.corrcoef(a.reshape(1, -1), b.reshape(1, -1))[0, 1]
-    if a.ndim == 3:
-        return np.mean([np.corrcoef(a[..., i].reshape(1, -1), b[..., i].reshape(1, -1))[0, 1] for i in range(a.shape[2])])
-    raise ValueError('Wrong input image dimensions.')
-
-
-def _valid_corr(img, window):
-    """cv2.filter2D(img, -1, window) cropped to the region where the window lies inside the image"""
-    return signal.correlate2d(img, window, mode='valid')
-
-
-def _qindex(img1, img2, block_size=8):
-    """universal image quality index of one band over sliding block_size windows (metrics.py:77-113)"""
-    assert block_size > 1, 'block_size shold be greater than 1!'
-    a = img1.astype(np.float64)
-    b = img2.astype(np.float64)
-    window = np.ones((block_size, block_size)) / (block_size ** 2)
-    mu1 = _valid_corr(a, window)
-    mu2 = _valid_corr(b, window)
-    mu1_sq, mu2_sq, mu1_mu2 = mu1 ** 2, mu2 ** 2, mu1 * mu2
-    sigma1_sq = _valid_corr(a ** 2, window) - mu1_sq
-    sigma2_sq = _valid_corr(b ** 2, window) - mu2_sq
-    sigma12 = _valid_corr(a * b, window) - mu1_mu2
-    q = np.ones(sigma12.shape)
-    idx = ((sigma1_sq + sigma2_sq) < 1e-8) * ((mu1_sq + mu2_sq) > 1e-8)
-    q[idx] = 2 * mu1_mu2[idx] / (mu1_sq + mu2_sq)[idx]
-    idx = ((sigma1_sq + sigma2_sq) > 1e-8) * ((mu1_sq + mu2_sq) < 1e-8)
-    q[idx] = 2 * sigma12[idx] / (sigma1_sq + sigma2_sq)[idx]
-    idx = ((sigma1_sq + sigma2_sq) > 1e-8) * ((mu1_sq + mu2_sq) > 1e-8)
-    q[idx] = ((2 * mu1_mu2[idx]) * (2 * sigma12[idx])) / ((mu1_sq + mu2_sq)[idx] * (sigma1_sq + sigma2_sq)[idx])
-    return np.mean(q)
-
-
-def qindex(img1, img2, block_size=8):
-    if not img1.shape == img2.shape:
-        raise ValueError('Input images must have the same dimensions.')
-    if img1.ndim == 2:
-        return _qindex(img1, img2, block_size)
-    if img1.ndim == 3:
-        return np.array([_qindex(img1[..., i], img2[..., i], block_size) for i in range(img1.shape[2])]).mean()
-    raise ValueError('Wrong input image dimensions.')
-
-
-def gaussian_kernel1d(ksize=11, sigma=1.5):
-    """cv2.getGaussianKernel(ksize, sigma) for sigma > 0: exp(-(i - (ksize-1)/2)^2 / (2 sigma^2)), normalised to sum 1"""
-    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) / 2.0
-    k = np.exp(-(x * x) / (2.0 * sigma * sigma))
-    return k / k.sum()
-
-
-def _ssim(img1, img2, dynamic_range=dynamic_r):
-    """SSIM of one band, 11x11 Gaussian window sigma 1.5, valid region (metrics.py:129-150)"""
-    C1 = (0.01 * dynamic_range) ** 2
-    C2 = (0.03 * dynamic_range) ** 2
-    a = img1.astype(np.float64)
-    b = img2.astype(np.float64)
-    k = gaussian_kernel1d(11, 1.5)
-    window = np.outer(k, k)
-    mu1 = _valid_corr(a, window)
-    mu2 = _valid_corr(b, window)
-    mu1_sq, mu2_sq, mu1_mu2 = mu1 ** 2, mu2 ** 2, mu1 * mu2
-    sigma1_sq = _valid_corr(a ** 2, window) - mu1_sq
-    sigma2_sq = _valid_corr(b ** 2, window) - mu2_sq
-    sigma12 = _valid_corr(a * b, window) - mu1_mu2
-    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
-    return ssim_map.mean()
-
-
-def ssim(img1, img2, dynamic_range=dynamic_r):
-    if not img1.shape == img2.shape:
-        raise ValueError('Input images must have the same dimensions.')
-    if img1.ndim == 2:
-        return _ssim(img1, img2, dynamic_range)
-    if img1.ndim == 3:
-        return np.array([_ssim(img1[..., i], img2[..., i], dynamic_range) for i in range(img1.shape[2])]).mean()
-    raise ValueError('Wrong input image dimensions.')
-
-
-# ---- observation model of the no-reference indices (metrics.py:190-258) ----
-def gaussian2d(N, std):
-    t = np.arange(-(N - 1) // 2, (N + 2) // 2)
-    t1, t2 = np.meshgrid(t, t)
-    std = np.double(std)
-    return np.exp(-0.5 * (t1 / std) ** 2) * np.exp(-0.5 * (t2 / std) ** 2)
-
-
-def kaiser2d(N, beta):
-    t = np.arange(-(N - 1) // 2, (N + 2) // 2) / np.double(N - 1)
-    t1, t2 = np.meshgrid(t, t)
-    t12 = np.sqrt(t1 * t1 + t2 * t2)
-    w = np.interp(t12, t, np.kaiser(N, beta))
-    w[t12 > t[-1]] = 0
-    w[t12 < t[0]] = 0
-    return w
-
-
-def fir_filter_wind(Hd, w):
-    hd = np.rot90(np.fft.fftshift(np.rot90(Hd, 2)), 2)
-    h = np.fft.fftshift(np.fft.ifft2(hd))
-    h = np.rot90(h, 2) * w
-    return h / np.sum(h)
-
-
-def GNyq2win(GNyq, scale=4, N=41):
-    """2-D low-pass window whose gain at the Nyquist frequency of the MS grid is GNyq"""
-    fcut = 1 / scale
-    alpha = np.sqrt(((N - 1) * (fcut / 2)) ** 2 / (-2 * np.log(GNyq)))
-    H = gaussian2d(N, alpha)
-    return np.real(fir_filter_wind(H / np.max(H), kaiser2d(N, 0.5)))
-
-
-def mtf_resize(img, satellite='QuickBird', scale=4):
-    """MTF-matched low-pass + nearest decimation by `scale` (metrics.py:229-258)"""
-    scale = int(scale)
-    if satellite == 'QuickBird':
-        GNyq, GNyqPan = [0.34, 0.32, 0.30, 0.22], 0.15
-    elif satellite == 'IKONOS':
-        GNyq, GNyqPan = [0.26, 0.28, 0.29, 0.28], 0.17
-    else:
-        raise NotImplementedError('satellite: QuickBird or IKONOS')
-    x = img.squeeze().astype(np.float64)
-    if x.ndim == 2:
-        lowpass = GNyq2win(GNyqPan, scale, N=41)
-    else:
-        lowpass = np.stack([GNyq2win(g, scale, N=41) for g in GNyq], axis=-1)
-    x = ndimage.correlate(x, lowpass, mode='nearest')
-    H, W = x.shape[:2]
-    # cv2.resize(..., INTER_NEAREST) to (H//scale, W//scale): source index = floor(dst * scale)
-    return x[:(H // scale) * scale:scale, :(W // scale) * scale:scale]
-
-
-def D_lambda(img_fake, img_lm, block_size=32, p=1):
-    """spectral distortion between the fused image and the LR MS (metrics.py:265-290)"""
-    assert img_fake.ndim == img_lm.ndim == 3, 'Images must be 3D!'
-    C_f, C_r = img_fake.shape[2], img_lm.shape[2]
-    assert C_f == C_r, 'Fake and lm should have the same number of bands!'
-    q_fake, q_lm = [], []
-    for i in range(C_f):
-        for j in range(i + 1, C_f):
-            q_fake.append(_qindex(img_fake[..., i], img_fake[..., j], block_size=block_size))
-            q_lm.append(_qindex(img_lm[..., i], img_lm[..., j], block_size=block_size))
-    d = (np.abs(np.array(q_fake) - np.array(q_lm)) ** p).mean()
-    return d ** (1 / p)
-
-
-def D_s(img_fake, img_lm, pan, satellite='QuickBird', scale=4, block_size=32, q=1):
-    """spatial distortion against the PAN and its MTF-degraded copy (metrics.py:293-327)"""
-    assert img_fake.ndim == img_lm.ndim == 3, 'MS images must be 3D!'
-    H_f, W_f, C_f = img_fake.shape
-    H_r, W_r, C_r = img_lm.shape
-    assert H_f // H_r == W_f // W_r == scale, 'Spatial resolution should be compatible with scale'
-    assert C_f == C_r, 'Fake and lm should have the same number of bands!'
-    assert pan.ndim == 3 and pan.shape[2] == 1, 'Panchromatic image must be 3D with one band'
-    assert H_f == pan.shape[0] and W_f == pan.shape[1], "Pan's and fake's spatial resolution should be the same"
-    pan_lr = mtf_resize(pan, satellite=satellite, scale=scale)
-    q_hr = [_qindex(img_fake[..., i], pan[..., 0], block_size=block_size) for i in range(C_f)]
-    q_lr = [_qindex(img_lm[..., i], pan_lr, block_size=block_size) for i in range(C_f)]
-    d = (np.abs(np.array(q_hr) - np.array(q_lr)) ** q).mean()
-    return d ** (1 / q)
-
-
-def qnr(img_fake, img_lm, pan, satellite='QuickBird', scale=4, block_size=32, p=1, q=1, alpha=1, beta=1):
-    return (1 - D_lambda(img_fake, img_lm, block_size, p)) ** alpha * (1 - D_s(img_fake, img_lm, pan, satellite, scale, block_size, q)) ** beta
+def qindex(img1, img2, block_size=Q_BLOCK):
+    return _band_mean(_q_band, img1, img2, block_size)
 
 
 def ref_evaluate(pred, gt):
-    """reference-based metrics in the reference's order (metrics.py:409-417): PSNR, SSIM, Q, SAM, ERGAS"""
+    """the five reference-based indices in the order of the reference's result tables: PSNR, SSIM, Q, SAM, ERGAS"""
     return [psnr(pred, gt), ssim(pred, gt), qindex(pred, gt), sam(pred, gt), ergas(pred, gt)]
-
-
-def no_ref_evaluate(pred, pan, hs):
-    """no-reference metrics (metrics.py:420-425): D_lambda, D_s, QNR; pan is 2-D (H, W)"""
-    pan3 = np.expand_dims(pan, -1)
-    return [D_lambda(pred, hs), D_s(pred, hs, pan3), qnr(pred, hs, pan3)]

@@ -102,6 +102,7 @@ class Pansharpening(nn.Module):
         self.mode = 'faithful'
         self.precision = 'fp32'    # 'fp32': parity mode; 'bf16': saved / hidden FFN activations of the backward stored as bf16
         self._engine = None
+        self._ddp = None           # (group,) once attach_ddp() was called: survives .to() / a rebuilt engine
 
     # ---- engine plumbing ----------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -112,12 +113,24 @@ class Pansharpening(nn.Module):
     def __getstate__(self):
         st = self.__dict__.copy()
         st['_engine'] = None           # raw device handles never get pickled (torch.save of whole modules)
+        st['_ddp'] = None              # ... nor process groups
         return st
 
     def engine(self):
         if self._engine is None or not self._engine.valid():
             self._engine = Engine(self)
+            if self._ddp is not None:  # the data-parallel attachment belongs to the module, not to one Engine object
+                self._engine.attach_ddp(self._ddp[0])
         return self._engine
+
+    def attach_ddp(self, group=None):
+        """join a torch.distributed process group (one process per GPU; backend nccl = RCCL over xGMI): rank-0 weights are
+        broadcast and every train step / autograd backward all-reduces the live gradient ranges.  Replaces the reference's
+        nn.DataParallel wrap (models/base/base_model.py:91-100)."""
+        self._ddp = (group,)
+        if self._engine is not None and self._engine.valid():
+            return self._engine.attach_ddp(group)
+        return self.engine()
 
     def canonical_names(self):
         return canonical_names(self.in_channels, self.stage)

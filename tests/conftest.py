@@ -14,6 +14,46 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_sessionstart(session):
+    """-m gpu sessions on a GPU box: start the two ranks of the Engine data-parallel check (tests/ddp_engine_worker.py) NOW,
+    as fresh child processes, before this process initialises the GPU (a process that has must not spawn programs on this
+    pool).  tests/test_gpu_ddp_engine.py joins them.  Nothing here imports torch or touches the device."""
+    import shutil
+    import socket
+    import subprocess
+    import tempfile
+    config = session.config
+    markexpr = config.getoption('-m') or ''
+    if 'gpu' not in markexpr or 'not gpu' in markexpr or not os.path.exists('/dev/kfd'):
+        return
+    if not os.path.exists(os.path.join(ROOT, 'lgteun_amd', '_lgteun_hip.so')):
+        return
+    if config.getoption('collectonly', False):
+        return
+    outdir = tempfile.mkdtemp(prefix='lgteun_ddp_')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs, logs = [], []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+        log = os.path.join(outdir, f'rank{rank}.log')
+        logs.append(log)
+        procs.append(subprocess.Popen([sys.executable, '-W', 'ignore', os.path.join(ROOT, 'tests', 'ddp_engine_worker.py'), outdir],
+                                      stdout=open(log, 'w'), stderr=subprocess.STDOUT, env=env, cwd=ROOT))
+    config._lgteun_ddp_job = (outdir, procs, logs)
+    config.add_cleanup(lambda: shutil.rmtree(outdir, ignore_errors=True))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    job = getattr(session.config, '_lgteun_ddp_job', None)
+    if job:
+        for p in job[1]:
+            if p.poll() is None:
+                p.kill()
+
+
 @pytest.fixture(scope='session')
 def manifest():
     import json

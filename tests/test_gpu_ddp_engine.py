@@ -1,0 +1,47 @@
+"""-m gpu: the N > 1 branch of Engine.train_step under a correctness check.
+
+Two ranks of tests/ddp_engine_worker.py share the one MI355X of the box (gloo transport; the calls are the torch.distributed
+collectives RCCL serves on a node).  tests/conftest.py starts them at session start, before this process initialises the GPU;
+here we join them and compare what they wrote:
+  * attach_ddp broadcast rank 0's weights (the ranks were built with different ones);
+  * the all-reduced flat gradient of the first step is bitwise identical on both ranks and equals the single-process gradient
+    on the concatenated batch to fp32 summation-order tolerance; dead-stage slots are exactly zero;
+  * global-mean losses add up; weights after 3 fused Adam steps agree with the single-process run;
+  * the attachment survives .to(); an unattached engine inside a live group raises."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+
+
+def test_two_rank_engine_train_step_equals_single_process(request):
+    job = getattr(request.config, '_lgteun_ddp_job', None)
+    assert job is not None, 'conftest did not start the DDP workers (no /dev/kfd?)'
+    outdir, procs, logs = job
+    for p in procs:
+        try:
+            rc = p.wait(timeout=900)
+        except Exception:  # noqa: BLE001
+            p.kill()
+            raise
+        assert rc == 0, ''.join(open(f).read()[-3000:] for f in logs)
+    r0, r1 = (np.load(f'{outdir}/rank{r}.npz') for r in (0, 1))
+    assert int(r0['world']) == 2 and int(r1['world']) == 2
+    assert int(r0['world_after_to']) == 2 and int(r1['world_after_to']) == 2
+    assert int(r0['unattached_raised']) == 1
+    (a0, b0), (a1, b1) = r0['ranges']
+    g0, g1, gs = r0['gflat0'], r1['gflat0'], r0['single_gflat0']
+    assert np.array_equal(g0, g1)                               # one all-reduce result, seen by both ranks
+    assert np.all(g0[b0:a1] == 0.0) and np.abs(g0[a1:b1]).max() > 0 and np.abs(g0[a0:b0]).max() > 0
+    assert _rel(g0, gs) < 2e-5, _rel(g0, gs)
+    for it in range(3):
+        # each rank reports its share of the global mean
+        assert abs(float(r0[f'loss{it}'][0]) + float(r1[f'loss{it}'][0]) - float(r0[f'single_loss{it}'][0])) < 2e-6
+    assert np.array_equal(r0['weights'], r1['weights'])         # replicas stay in lock-step
+    w, ws = r0['weights'], r0['single_weights']
+    assert _rel(w[a1:b1], ws[a1:b1]) < 1e-4 and _rel(w[a0:b0], ws[a0:b0]) < 1e-4
+    assert np.array_equal(w[b0:a1], ws[b0:a1])                  # dead stages untouched by Adam on every path

@@ -39,15 +39,63 @@ def t(a, dtype=torch.float32):
     return torch.from_numpy(np.asarray(a)).to(dtype)
 
 
+def round2(R, manifest):
+    """Round-2 fixtures: eval forward + L1 gradients of the reference at the BENCH size (128x128 PAN, K=4; C=4 and C=8),
+    at BASELINE configs[4]'s shape (C=8, 256x256 PAN, K=8) and at two PAN sizes that are not powers of two (80x48, 208x176:
+    the build container's FFT leaves +0 in the imaginary part of the purely real bins there, which pins the angle()=+pi
+    convention the HIP mixer uses at every size).  Each file also carries the reference's own fp32-vs-fp64 gradient error."""
+    cases = [
+        dict(name='grad_c4_k4_p128', C=4, K=4, B=1, h=32, w=32, kind='smooth', seed=21),
+        dict(name='grad_c8_k4_p128', C=8, K=4, B=1, h=32, w=32, kind='smooth', seed=22),
+        dict(name='grad_c4_k2_p80x48', C=4, K=2, B=1, h=20, w=12, kind='smooth', seed=23),
+        dict(name='grad_c4_k2_p208x176', C=4, K=2, B=1, h=52, w=44, kind='smooth', seed=24),
+        dict(name='grad_c8_k8_p256', C=8, K=8, B=1, h=64, w=64, kind='smooth', seed=25),
+    ]
+    for cs in cases:
+        C, K, B, h, w = cs['C'], cs['K'], cs['B'], cs['h'], cs['w']
+        ms, pan, gt = dw.make_inputs(B, C, h, w, seed=cs['seed'], kind=cs['kind'])
+        res = {}
+        for dt in (torch.float32, torch.float64):
+            net, _ = build_ref(R, C, K, dtype=dt)
+            y = net(t(ms, dt), t(pan, dt))
+            loss = torch.nn.L1Loss()(y, t(gt, dt))
+            loss.backward()
+            grads = {k: p.grad.numpy() for k, p in net.named_parameters() if p.grad is not None}
+            none_names = [k for k, p in net.named_parameters() if p.grad is None]
+            res[dt] = (y.detach().numpy(), float(loss.item()), grads, none_names)
+        y32, loss32, g32, none_names = res[torch.float32]
+        y64, loss64, g64, _ = res[torch.float64]
+        num = sum(float(((g32[k].astype(np.float64) - g64[k]) ** 2).sum()) for k in g32)
+        den = sum(float((g64[k] ** 2).sum()) for k in g32)
+        np.savez_compressed(os.path.join(GOLD, cs['name'] + '.npz'), loss=np.array(loss32), loss_fp64=np.array(loss64),
+                            out_fp32=y32, out_fp64=y64.astype(np.float32),
+                            **{k.replace('.', '/'): v for k, v in g32.items()})
+        manifest[cs['name']] = dict(cs, salt=0, none_grad_stages=list(range(K - 1)), n_none=len(none_names),
+                                    rel_fp32_vs_fp64=float(np.linalg.norm(y32 - y64) / np.linalg.norm(y64)),
+                                    grad_rel_fp32_vs_fp64=(num / den) ** 0.5)
+        assert all(n.startswith(tuple(f'prior_module.{i}.' for i in range(K - 1))) for n in none_names)
+        print(cs['name'], 'loss', loss32, 'live', len(g32), 'none', len(none_names), 'out fp32-vs-fp64', manifest[cs['name']]['rel_fp32_vs_fp64'],
+              'grad fp32-vs-fp64', manifest[cs['name']]['grad_rel_fp32_vs_fp64'], flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--check', action='store_true')
+    ap.add_argument('--only-r2', action='store_true', help='write only the round-2 fixtures (bench-size / configs[4] / non-pow2 '
+                                                            'gradients); the manifest is merged, round-1 files are left alone')
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = import_reference()
     manifest = {}
+    if args.only_r2:
+        with open(os.path.join(GOLD, 'manifest.json')) as f:
+            manifest = json.load(f)
+        round2(R, manifest)
+        with open(os.path.join(GOLD, 'manifest.json'), 'w') as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
 
     # ---------------------------------------------------------------- per-op goldens (C=4 and C=8)
     for C in (4, 8):
@@ -171,6 +219,7 @@ def main():
                                         gamma=0.85, lr=1.5e-3)
     print('train3 losses', logged, 'lrs', lrs)
 
+    round2(R, manifest)
     with open(os.path.join(GOLD, 'manifest.json'), 'w') as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print('wrote', GOLD)
