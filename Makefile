@@ -12,12 +12,15 @@ FLAGS := -O3 -std=c++17 -fno-slp-vectorize -fPIC -fvisibility=hidden --offload-a
 
 all: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/workspace.h $(CSRC)/backward.h $(CSRC)/bwd_kernels.h $(CSRC)/mfma.h include/lgteun_hip.h
-	$(HIPCC) $(FLAGS) -c $< -o $@
+# prerequisites come from the compiler (-MMD writes one .d file per object: every header a source includes, hstore.h too)
+$(CSRC)/%.o: $(CSRC)/%.hip
+	$(HIPCC) $(FLAGS) -MMD -MP -c $< -o $@
+
+-include $(OBJS:.o=.d)
 
 $(LIB): $(OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
 
 clean:
-	rm -f $(OBJS) $(LIB)
+	rm -f $(OBJS) $(OBJS:.o=.d) $(LIB)
 .PHONY: all clean

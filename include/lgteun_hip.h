@@ -12,7 +12,9 @@
  * Conventions
  *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked host.
  *  - the caller (PyTorch) owns all memory: parameters, gradients, optimizer state, workspace.
- *    The library allocates nothing and keeps no mutable global state.
+ *    The library allocates no device memory.  Its only mutable process-global state is the event table of the opt-in
+ *    timing facility (lg_prof_*, mutex-protected; off by default) and per-device "kernel attribute set" bits; plans are
+ *    immutable after creation, so forward / backward calls on different streams or threads do not interact.
  *  - all work is enqueued on `stream` (a hipStream_t passed as void*); no implicit sync.
  *  - return value: 0 ok; <0 invalid argument / unsupported shape (see lg_last_error());
  *    >0 a hipError_t.  Nothing throws across the boundary.
@@ -134,6 +136,19 @@ int lg_op_block(const lg_plan* plan, const float* params, int32_t stage, int32_t
 int lg_op_block_bwd(const lg_plan* plan, const float* params, float* grads, int32_t stage, int32_t blk, int32_t which,
                     const float* x, const float* dy, float* dx, void* workspace, size_t workspace_bytes, int32_t B,
                     void* stream);
+
+/* backward of one data step (autograd of unlg_former.py:58-61 with D :29-30, DT :32-33, R :36, RT :37): runs the step's forward
+ * on z_in (to have its intermediates), then maps dz_out (gradient wrt the step's output) to dz_in (gradient wrt z_in, including the
+ * identity path) and accumulates (+=) the gradients of D / DT / R / RT and eta[stage] into grads.  workspace:
+ * lg_workspace_bytes(plan, B, 1). */
+int lg_op_data_step_bwd(const lg_plan* plan, const float* params, float* grads, int32_t stage, const float* z_in, const float* ms,
+                        const float* pan, const float* dz_out, float* dz_in, void* workspace, size_t workspace_bytes, int32_t B,
+                        void* stream);
+/* backward of one LGT (autograd of LGT.py:314-344; covers patch_embedding :64-88, down :280-281, up + fusion :294-295,337-338 and
+ * tail :302-303,342 besides the five blocks): runs the LGT forward on z with everything saved, then maps dout to dz (gradient wrt z)
+ * and accumulates (+=) the 119 parameter gradients of stage `stage` into grads.  flags: 0 or LG_FLAG_DROPOUT (with seed). */
+int lg_op_lgt_bwd(const lg_plan* plan, const float* params, float* grads, int32_t stage, const float* z, const float* dout, float* dz,
+                  void* workspace, size_t workspace_bytes, int32_t B, int32_t flags, uint64_t seed, void* stream);
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,10 @@ SIGNATURES = {
     'lg_prof_read': (c_int32, [POINTER(ctypes.c_double), POINTER(c_int64)]),
     'lg_prof_disable': (None, []),
     'lg_kernel_name': (c_char_p, [c_int32]),
+    'lg_op_data_step_bwd': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_size_t, c_int32, c_void_p]),
+    'lg_op_lgt_bwd': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_int32,
+                                c_uint64, c_void_p]),
     'lg_op_block_bwd': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_int32, c_void_p]),
 }

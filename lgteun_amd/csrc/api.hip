@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <atomic>
+#include <mutex>
 
 // only the C ABI of include/lgteun_hip.h is exported from the shared object (everything else: -fvisibility=hidden)
 #pragma GCC visibility push(default)
@@ -26,42 +28,60 @@ void lg_set_error(const char* fmt, ...) {
 // ------------------------------------------------------------------------------------------------
 // live per-kernel timing
 // ------------------------------------------------------------------------------------------------
+// The ONE piece of mutable process-global state of the library (documented in the header): the event table of the timing
+// facility.  `kid` is atomic so that the launch path pays one relaxed load while profiling is off; everything else is under the mutex.
 static struct {
-    int kid = 0;
+    std::atomic<int> kid{0};
     int cap = 0, n = 0;
     hipEvent_t* ev = nullptr;  // 2 per launch
+    std::mutex mu;
 } g_prof;
 
 void lg_prof_begin(int kid, hipStream_t s) {
-    if (kid != g_prof.kid || g_prof.n >= g_prof.cap) return;
+    if (kid != g_prof.kid.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (kid != g_prof.kid.load(std::memory_order_relaxed) || g_prof.n >= g_prof.cap) return;
     hipEventRecord(g_prof.ev[2 * g_prof.n], s);
 }
 void lg_prof_end(int kid, hipStream_t s) {
-    if (kid != g_prof.kid || g_prof.n >= g_prof.cap) return;
+    if (kid != g_prof.kid.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (kid != g_prof.kid.load(std::memory_order_relaxed) || g_prof.n >= g_prof.cap) return;
     hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
     g_prof.n++;
 }
-extern "C" void lg_prof_disable(void) {
+static void prof_disable_locked() {
     for (int i = 0; i < 2 * g_prof.cap; ++i) hipEventDestroy(g_prof.ev[i]);
     free(g_prof.ev);
     g_prof.ev = nullptr;
-    g_prof.cap = g_prof.n = g_prof.kid = 0;
+    g_prof.cap = g_prof.n = 0;
+    g_prof.kid.store(0);
+}
+extern "C" void lg_prof_disable(void) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    prof_disable_locked();
 }
 extern "C" int lg_prof_enable(int32_t kernel_id, int32_t max_launches) {
     if (kernel_id <= 0 || kernel_id >= LG_K_COUNT || max_launches <= 0) { lg_set_error("prof_enable: invalid argument"); return -1; }
-    lg_prof_disable();
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    prof_disable_locked();
     g_prof.ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * max_launches);
     for (int i = 0; i < 2 * max_launches; ++i) {
         hipError_t e = hipEventCreate(&g_prof.ev[i]);
         if (e != hipSuccess) { lg_set_error("prof_enable: hipEventCreate: %s", hipGetErrorString(e)); return (int)e; }
     }
     g_prof.cap = max_launches;
-    g_prof.kid = kernel_id;
+    g_prof.kid.store(kernel_id);
     return 0;
 }
-extern "C" int lg_prof_reset(void) { g_prof.n = 0; return 0; }
+extern "C" int lg_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.n = 0;
+    return 0;
+}
 extern "C" int lg_prof_read(double* total_ms, int64_t* launches) {
     if (!total_ms || !launches) { lg_set_error("prof_read: null argument"); return -1; }
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     double tot = 0.0;
     for (int i = 0; i < g_prof.n; ++i) {
         hipError_t e = hipEventSynchronize(g_prof.ev[2 * i + 1]);
@@ -100,6 +120,7 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
     lg_plan* p = new lg_plan;
     p->cfg = *cfg;
     p->n_offsets = n_offsets;
+    p->ffn_tile = getenv("LG_FFN_TILE") ? 1 : 0;   // read once here, never on the launch path
     p->off = (int64_t*)malloc(sizeof(int64_t) * n_offsets);
     memcpy(p->off, offsets, sizeof(int64_t) * n_offsets);
     *out = p;
@@ -185,6 +206,7 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     a1.w2 = P + pl->blk(stage, j, B_W2); a1.b2 = P + pl->blk(stage, j, B_B2);
     a1.P = (long)B * bb.h * bb.w;
     a1.hbf = pl->cfg.precision == 1 ? 1 : 0;
+    a1.tile16 = pl->ffn_tile;
     Ffn2Args a2;
     a2.h2 = bb.h2; a2.x = bb.xmid; a2.a3s = (flags & LG_FLAG_SAVE) ? bb.a3 : nullptr; a2.g3s = (flags & LG_FLAG_SAVE) ? bb.g3 : nullptr; a2.y = bb.xout;
     a2.g = g_next;
@@ -409,6 +431,39 @@ extern "C" int lg_op_block_bwd(const lg_plan* plan, const float* params, float* 
         if ((rc = block_ffn_fwd(plan, params, stage, blk, bb, nullptr, 0, B, LG_FLAG_SAVE, s))) return rc;
     }
     return op_block_bwd(plan, params, grads, stage, blk, which, dy, dx, nb, (char*)workspace + nb.bytes, B, s);
+}
+
+extern "C" int lg_op_data_step_bwd(const lg_plan* plan, const float* params, float* grads, int32_t stage, const float* z_in,
+                                   const float* ms, const float* pan, const float* dz_out, float* dz_in, void* workspace,
+                                   size_t workspace_bytes, int32_t B, void* stream) {
+    if (!plan || !params || !grads || !z_in || !ms || !pan || !dz_out || !dz_in || !workspace || B <= 0 || stage < 0 || stage >= plan->cfg.K) {
+        lg_set_error("op_data_step_bwd: invalid argument");
+        return -1;
+    }
+    if (workspace_bytes < lg_workspace_bytes(plan, B, 1)) { lg_set_error("op_data_step_bwd: workspace too small"); return -3; }
+    hipStream_t s = (hipStream_t)stream;
+    NetBufs nb;
+    carve(plan, B, 1, workspace, nb);
+    int rc;
+    // forward of the step: fills the intermediates its backward reads (t1, r, s1)
+    if ((rc = data_step_fwd(plan, params, stage, z_in, ms, pan, nb.Z[stage + 1], nb.t1[stage], nb.r[stage], nb.s1[stage], B, s))) return rc;
+    return op_data_step_bwd(plan, params, grads, stage, nb, (char*)workspace + nb.bytes, z_in, pan, dz_out, dz_in, B, s);
+}
+
+extern "C" int lg_op_lgt_bwd(const lg_plan* plan, const float* params, float* grads, int32_t stage, const float* z, const float* dout,
+                             float* dz, void* workspace, size_t workspace_bytes, int32_t B, int32_t flags, uint64_t seed, void* stream) {
+    if (!plan || !params || !grads || !z || !dout || !dz || !workspace || B <= 0 || stage < 0 || stage >= plan->cfg.K) {
+        lg_set_error("op_lgt_bwd: invalid argument");
+        return -1;
+    }
+    if (flags & ~LG_FLAG_DROPOUT) { lg_set_error("op_lgt_bwd: only LG_FLAG_DROPOUT applies"); return -2; }
+    if (workspace_bytes < lg_workspace_bytes(plan, B, 1)) { lg_set_error("op_lgt_bwd: workspace too small"); return -3; }
+    hipStream_t s = (hipStream_t)stream;
+    NetBufs nb;
+    carve(plan, B, 1, workspace, nb);
+    int rc;
+    if ((rc = lgt_fwd(plan, params, stage, z, nb.deadout, nb, B, flags | LG_FLAG_SAVE, seed, s))) return rc;
+    return op_lgt_bwd(plan, params, grads, stage, nb, (char*)workspace + nb.bytes, z, dout, dz, B, flags, seed, s);
 }
 
 // ------------------------------------------------------------------------------------------------

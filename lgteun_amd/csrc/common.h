@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 #include "../../include/lgteun_hip.h"
 
 // ----------------------------------------------------------------------------------------------
@@ -30,6 +31,7 @@ static inline int block_base(int blk) {
 struct lg_plan {
     lg_config cfg;
     int n_offsets;
+    int ffn_tile;  // A/B switch read ONCE at plan creation (env LG_FFN_TILE): level-0 fused FFN as the per-tile kernel instead of the strip kernel
     int64_t* off;  // host copy of offsets
     int64_t shared(int s) const { return off[s]; }
     int64_t eta(int i) const { return off[S_NSHARED + i]; }
@@ -38,6 +40,15 @@ struct lg_plan {
 };
 
 void lg_set_error(const char* fmt, ...);
+
+// one-time per-DEVICE setup of a kernel (hipFuncSetAttribute for > 64 KiB of dynamic LDS).  Safe from several host threads: the
+// guarded call is idempotent, so a race only repeats it.
+struct DeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+    bool need() const { return !((mask.load(std::memory_order_acquire) >> dev()) & 1); }
+    void done() { mask.fetch_or(1ull << dev(), std::memory_order_release); }
+};
 
 // per-(stage, block) dropout seed, shared by forward and backward
 static inline uint64_t mix_seed(uint64_t seed, int stage, int blk) {

@@ -193,11 +193,11 @@ static int launch_attn_t(const AttnArgs& a, hipStream_t s) {
     int nwin = a.B * (a.h / 8) * (a.w / 8);
     int nquads = (nwin + 3) / 4;
     size_t lds = (2 * 64 * 64 + 2 * 4 * 64 * HC) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_attn<HC>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) { lg_set_error("attn: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_once.done();
     }
     int grid = nquads < 768 ? nquads : 768;   // 3 resident workgroups per CU; each walks its window quads with pos_emb^T in LDS
     k_attn<HC><<<grid, 256, lds, s>>>(a, nwin, nquads);

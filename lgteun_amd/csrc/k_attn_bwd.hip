@@ -378,11 +378,11 @@ static int launch_attn_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
     int nwin = a.B * (a.h / 8) * (a.w / 8);
     int ngroups = (nwin + NW - 1) / NW;
     size_t lds = (size_t)(2 * 64 * 65 + NW * (4 * 64 * (HC / 2) + 64 * 4)) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_attn_bwd_core<HC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
         if (e != hipSuccess) { lg_set_error("attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_once.done();
     }
     int grid = grid_t<HC, NW>(a.B, a.h, a.w);
     k_attn_bwd_core<HC, NW><<<dim3(grid, 2), NW * 64, lds, s>>>(a, nwin, ngroups);

@@ -284,6 +284,30 @@ static int lgt_bwd(const lg_plan* pl, const float* P, float* G, int st, const Ne
     return 0;
 }
 
+// per-op backward entries (tests): one data step / one LGT in isolation.  The forward of the same piece has just filled `nb`
+// (data step: nb.t1 / r / s1 [st]; LGT: the saved activation set).
+int op_data_step_bwd(const lg_plan* pl, const float* P, float* G, int st, NetBufs& nb, void* bwd_ws, const float* z_in, const float* pan,
+                     const float* g, float* dz, int B, hipStream_t s) {
+    BwdBufs bb;
+    carve_bwd(pl, B, bwd_ws, bb);
+    ReduceQueueScope rqs(bb, s);
+    const int rc = data_step_bwd(pl, P, G, st, nb, bb, z_in, pan, g, dz, B, s);
+    const int rc2 = reduce_queue_end();
+    return rc ? rc : rc2;
+}
+
+int op_lgt_bwd(const lg_plan* pl, const float* P, float* G, int st, NetBufs& nb, void* bwd_ws, const float* z, const float* dout, float* dz,
+               int B, int flags, uint64_t seed, hipStream_t s) {
+    BwdBufs bb;
+    carve_bwd(pl, B, bwd_ws, bb);
+    bb.fft_scratch = nb.fft_scratch;
+    bb.dzA = dz;                       // lgt_bwd leaves the gradient wrt the LGT's input here
+    ReduceQueueScope rqs(bb, s);
+    const int rc = lgt_bwd(pl, P, G, st, nb, bb, dout, z, B, flags, seed, s);
+    const int rc2 = reduce_queue_end();
+    return rc ? rc : rc2;
+}
+
 int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, const float* pan, const float* dout, NetBufs& nb,
                  void* bwd_ws, int B, int flags, uint64_t seed, hipStream_t s) {
     (void)ms;

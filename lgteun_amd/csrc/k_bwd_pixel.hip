@@ -117,12 +117,12 @@ int launch_resample_adj(int mode, const float* gout, float* gin, int planes, int
     const int grows = grows_of(rt);
     const size_t lds = ((size_t)grows * (wo + wi) + (size_t)(wi + rt) * (NC + 1)) * sizeof(float);
     if (lds > 150 * 1024) { lg_set_error("resample_adj: plane width %d too large", wi); return -2; }
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_resample_adj<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_resample_adj<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { lg_set_error("resample_adj: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_once.done();
     }
     dim3 grid((hi + rt - 1) / rt, planes);
     if (mode == 0) k_resample_adj<0><<<grid, 256, lds, s>>>(gout, gin, hi, wi, ho, wo, accumulate, rt, grows);

@@ -116,12 +116,12 @@ static int launch_ffn1_t(const Ffn1Args& a, hipStream_t s) {
     ProfScope prof__(LG_K_FFN1, s);
     constexpr int N1 = 4 * E, MW = 16 * MT;
     size_t lds = (size_t)4 * MW * ((E + 4) + (N1 + 4)) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ffn1<E, MT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1<E, MT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn1: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_once.done();
     }
     long per_wg = 4L * MW;
     int grid = (int)((a.P + per_wg - 1) / per_wg);
@@ -254,12 +254,12 @@ static int launch_ffn2_t(const Ffn2Args& a, hipStream_t s) {
     ProfScope prof__(LG_K_FFN2, s);
     constexpr int N1 = 4 * E, M = TY * TX;
     size_t lds = (size_t)(M * (N1 + 4) + M * (E + 1)) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ffn2<E, MT, TY, TX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn2<E, MT, TY, TX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn2: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_once.done();
     }
     int tiles_x = (a.w + TX - 1) / TX, tiles_y = (a.h + TY - 1) / TY;
     int grid = a.B * tiles_x * tiles_y;
@@ -872,12 +872,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 static int launch_ffn_strip(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     ProfScope prof__(LG_K_FFN2, s);
     const size_t lds = (size_t)(4 * 16 * 68 + 128 * 17 + 10 * 18 * 68) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ffn_strip<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_strip<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn_strip: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_once.done();
     }
     const int tiles_x = (a2.w + 15) / 16;
     // strip height: the tallest multiple of 8 rows that still yields >= 512 strips (two resident workgroups per CU), at least 16
@@ -897,13 +897,13 @@ static int launch_ffn_fused_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_
     ProfScope prof__(LG_K_FFN2, s);
     constexpr int N1 = 4 * E;
     size_t lds = (size_t)(192 * (E == 16 ? E : E + 4) + 180 * (N1 + 4) + 4 * 16 * (N1 + 4)) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ffn_fused<E, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_fused<E, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_fused<E, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn_fused: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_once.done();
     }
     int tiles_x = (a2.w + 15) / 16, tiles_y = (a2.h + 7) / 8;
     const int ntiles = a2.B * tiles_x * tiles_y;
@@ -1173,12 +1173,12 @@ static int launch_ffn_fused_bf_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStre
     ProfScope prof__(LG_K_FFN2, s);
     constexpr int N1 = 4 * E;
     const size_t lds = (size_t)(180 * (N1 + 4) + 128 * (E + 1) + 8) * sizeof(float) + (size_t)(192 * (E + 8) + 4 * 16 * (N1 + 8)) * 2;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ffn_fused_bf<E, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_fused_bf<E, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn_fused_bf: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_once.done();
     }
     int tiles_x = (a2.w + 15) / 16, tiles_y = (a2.h + 7) / 8;
     const int ntiles = a2.B * tiles_x * tiles_y;
@@ -1197,7 +1197,7 @@ int launch_ffn_fused(int e, const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t 
         return 1;
     }
     // e = 16: the strip kernel (halo rows shared through the LDS ring); LG_FFN_TILE=1 selects the per-tile kernel it replaced, for A/B runs
-    if (e == 16) return getenv("LG_FFN_TILE") ? launch_ffn_fused_t<16>(a1, a2, s) : launch_ffn_strip(a1, a2, s);
+    if (e == 16) return a1.tile16 ? launch_ffn_fused_t<16>(a1, a2, s) : launch_ffn_strip(a1, a2, s);
     if (e == 32) return launch_ffn_fused_t<32>(a1, a2, s);   // (the split k_ffn1 + k_ffn2 pair measured slower at e = 32 too)
     return 1;
 }

@@ -229,12 +229,12 @@ static int launch_ffn_dw_bwd_t(const FfnDwBwdArgs& a, hipStream_t s) {
     constexpr int CG = (E >= 32 ? 64 : DW_CG);
     dim3 grid((unsigned)nwg, 4 * E / CG);
     const size_t lds = (size_t)(192 * (E + 4) + 2 * 180 * (CG + 4) + 4 * (CG / 4) * 40) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, false, CG>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, true, CG>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn_dw_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_once.done();
     }
     if (a.hbf) k_ffn_dw_bwd<E, true, CG><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
     else k_ffn_dw_bwd<E, false, CG><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
@@ -579,12 +579,12 @@ static int launch_ffn1_bwd_t(const Ffn1BwdArgs& a, hipStream_t s) {
     ProfScope prof__(LG_K_FFN1_BWD, s);
     constexpr int N1 = 4 * E, MW = 16 * MT;
     size_t lds = (size_t)(4 * MW * (2 * (N1 + 4) + E + 1) + (E == 16 ? N1 * (N1 + 4) : 0)) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ffn1_bwd<E, MT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1_bwd<E, MT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn1_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_once.done();
     }
     long per_wg = 4L * MW;
     const long nchunks = (a.P + per_wg - 1) / per_wg;

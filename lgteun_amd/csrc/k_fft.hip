@@ -686,14 +686,14 @@ static int launch_fft_generic(const FftArgs* fa, const FftBwdArgs* ba, int h, in
         lg_set_error("fftmix: plane %dx%d unsupported (sides: multiples of 8, 8..1024)", h, w);
         return -2;
     }
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         const void* fns[4] = {(const void*)k_gfft_rows_fwd, (const void*)k_gfft_cols<false>, (const void*)k_gfft_cols<true>, (const void*)k_gfft_rows_inv};
         for (int i = 0; i < 4; ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
             if (e != hipSuccess) { lg_set_error("fft generic: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         }
-        attr_done = true;
+        attr_once.done();
     }
     const GDft dw = gdft_plan(w), dh = gdft_plan(h);
     const size_t lds_r = gdft_lds_bytes(dw), lds_c = gdft_lds_bytes(dh);
@@ -728,11 +728,11 @@ int launch_fftmix(const FftArgs& a, hipStream_t s) {
     while ((1 << lg) < n) ++lg;
     if (n > 128) return launch_fft_split(&a, nullptr, s);
     size_t lds = ((size_t)n * FFT_LD(n) + n / 2) * sizeof(float2);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_fftmix<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         if (e != hipSuccess) { lg_set_error("fftmix: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_once.done();
     }
     int threads = n >= 128 ? 1024 : (n >= 64 ? 512 : 256);
     switch (lg) {
@@ -844,11 +844,11 @@ static int launch_fftmix_bwd_kernels(const FftBwdArgs& a, hipStream_t s) {
     while ((1 << lg) < n) ++lg;
     if (n > 128) return launch_fft_split(nullptr, &a, s);
     size_t lds = ((size_t)n * FFT_LD(n) + n / 2) * sizeof(float2) + 64 * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_fftmix_bwd<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         if (e != hipSuccess) { lg_set_error("fftmix_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_once.done();
     }
     int threads = n >= 128 ? 1024 : (n >= 64 ? 512 : 256);
     switch (lg) {

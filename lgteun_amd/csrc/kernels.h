@@ -105,6 +105,7 @@ struct Ffn1Args {
     void* g1s;       // optional save [P,4e]: gelu'(h1)       (backward never re-evaluates GELU)
     void* h2;        // [P,4e] = W2 gelu(W1 LN(x) + b1) + b2
     int hbf;         // hidden storage: 0 fp32, 1 bf16 (hstore.h)
+    int tile16;      // e = 16 only: per-tile fused kernel instead of the strip kernel (lg_plan::ffn_tile, A/B runs)
     const float *ln2g, *ln2b, *w1, *b1, *w2, *b2;
     long P;
 };

@@ -77,6 +77,26 @@ class Ops:
                                             _ptr(dx), _ptr(ws), ws.numel(), B, _stream_ptr()), 'lg_op_block_bwd')
         return dx, grads
 
+    def data_step_bwd(self, stage, z, ms, pan, dz_out):
+        """returns (dz_in, flat_param_grads) of one data step"""
+        B = z.shape[0]
+        dz = torch.empty_like(z)
+        grads = torch.zeros_like(self.eng.flat)
+        ws = self.ws(B, train=True)
+        _lib.check(self.lib.lg_op_data_step_bwd(self.plan, _ptr(self.eng.flat), _ptr(grads), stage, _ptr(z), _ptr(ms), _ptr(pan),
+                                                _ptr(dz_out), _ptr(dz), _ptr(ws), ws.numel(), B, _stream_ptr()), 'lg_op_data_step_bwd')
+        return dz, grads
+
+    def lgt_bwd(self, stage, z, dout):
+        """returns (dz, flat_param_grads) of one LGT (dropout off)"""
+        B = z.shape[0]
+        dz = torch.empty_like(z)
+        grads = torch.zeros_like(self.eng.flat)
+        ws = self.ws(B, train=True)
+        _lib.check(self.lib.lg_op_lgt_bwd(self.plan, _ptr(self.eng.flat), _ptr(grads), stage, _ptr(z), _ptr(dout), _ptr(dz), _ptr(ws),
+                                          ws.numel(), B, 0, 0, _stream_ptr()), 'lg_op_lgt_bwd')
+        return dz, grads
+
     def grad_of(self, flat_grads, name):
         i = self.eng.names.index(name)
         o, p = self.eng.offsets[i], self.eng.params[i]

@@ -131,3 +131,26 @@ def test_reference_checkpoint_converter(tmp_path):
     net.load_state_dict(ck['core_module'])
     for k, v in net.state_dict().items():
         assert torch.equal(v, ck['core_module'][k]), k
+
+
+@pytest.mark.skipif(not os.path.isfile('/root/reference/configs/unlg_former.py'), reason='needs the reference tree (build container only)')
+def test_reference_config_file_builds_the_model(tmp_path):
+    """the reference's own entry config (configs/unlg_former.py:23 model_type, :92-94 model_cfg, :82-86 optimiser / schedule)
+    loads through Config.fromfile -> build_model exactly as main.py:90 does, and yields the canonical parameter surface"""
+    import logging
+    import lgteun_amd
+    from lgteun_amd.compat import Config
+    cfg = Config.fromfile('/root/reference/configs/unlg_former.py')
+    assert cfg.model_type == 'UnlgFormer' and cfg.ms_chans == 8 and cfg.model_cfg['core_module']['stage'] == 2
+    cfg.work_dir = str(tmp_path)                       # the file's own work_dir is relative to the author's checkout
+    runner = lgteun_amd.build_model(cfg.model_type, cfg, logging.getLogger('cfgtest'), None, None, None)
+    assert isinstance(runner, lgteun_amd.UnlgFormer)
+    core = runner.module_dict['core_module']
+    assert list(core.state_dict().keys()) == lgteun_amd.canonical_names(8, 2)
+    assert sum(p.numel() for p in core.parameters()) == 2 * 269848 + 2 + 4 * 80 + 9 + 16      # 2 LGTs + eta + D/DT + R/RT at C=8
+    runner.set_optim()
+    runner.set_sched()
+    opt = runner.optim_dict['core_module']
+    assert getattr(opt, 'is_fused_lgteun', False) and opt.param_groups[0]['lr'] == 1.5e-3 and opt.param_groups[0]['betas'] == (0.9, 0.999)
+    assert runner.sched_dict['core_module'].step_size == cfg.step and runner.sched_dict['core_module'].gamma == 0.85
+    assert runner.train_out.endswith('/WV-3/train_out')

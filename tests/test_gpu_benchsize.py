@@ -108,7 +108,6 @@ def test_two_autograd_graphs_keep_their_own_activations():
     def both():
         ya = net(a[0], a[1])
         yb = net(b[0], b[1])          # same B: would have overwritten graph a's workspace
-        # and a fused train step in between, which uses the engine's cached workspace
         return l1(ya, a[2]) + l1(yb, b[2])
     gab = grads_of(both)
     assert set(gab) == set(ga)
