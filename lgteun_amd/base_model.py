@@ -199,7 +199,9 @@ class Base_model:
                 res.extend(mtc.ref_evaluate(out[i], gt[i]) for i in range(out.shape[0]))
             if save:
                 for i, image_id in enumerate(input_batch['image_id']):
-                    save_image(osp.join(out_dir, f'{image_id}_mul_hat.tif'), out[i])
+                    # [C, H, W] for the writer (the reference hands its HWC array to a CHW writer, base_model.py:336: a
+                    # transposed file; not reproduced)
+                    save_image(osp.join(out_dir, f'{image_id}_mul_hat.tif'), np.moveaxis(out[i], -1, 0))
         latest = {}
         if res:
             res = np.array(res)

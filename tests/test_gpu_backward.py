@@ -256,7 +256,7 @@ def test_runner_train_eval_save_load_roundtrip(tmp_path):
     after = runner.test(iter_id=6, ref=True)
     assert after['PSNR'][0] > before['PSNR'][0]                       # six Adam steps on three batches help
     assert abs(runner.optim_dict['core_module'].param_groups[0]['lr'] - 1.5e-3 * 0.85 ** 3) < 1e-12
-    ckpt = tmp_path / 'GF-2' / 'model_iter_3.pth'
+    ckpt = tmp_path / 'GF-2' / 'train_out' / 'model_iter_3.pth'      # the reference's location (base_model.py:44,360)
     assert ckpt.exists()                                              # save_freq = 3
     path = runner.save(iter_id=6)
     runner2 = lgteun_amd.build_model('UnlgFormer', cfg, logging.getLogger('runner2'), loader, None, loader)
@@ -265,6 +265,15 @@ def test_runner_train_eval_save_load_roundtrip(tmp_path):
     runner2.set_cuda()
     again = runner2.test(iter_id=6, ref=True)
     assert abs(again['PSNR'][0] - after['PSNR'][0]) < 1e-9 and abs(again['SAM'][0] - after['SAM'][0]) < 1e-12
+    # resume: the optimizer state saved with the checkpoint (absent in the reference) continues the Adam moments and step count
+    runner2.set_optim()
+    o1, o2 = runner.optim_dict['core_module'], runner2.optim_dict['core_module']
+    assert o2._step == o1._step == 6
+    assert torch.equal(o2._state['exp_avg'], o1._state['exp_avg']) and torch.equal(o2._state['exp_avg_sq'], o1._state['exp_avg_sq'])
+    # the full-resolution pass runs the model and writes the fused images when asked (its no-reference indices are out of scope)
+    runner2.test_data_loader0 = loader[:1]
+    assert runner2.test(iter_id=6, save=True, ref=False) == {}
+    assert (tmp_path / 'GF-2' / 'test_out0' / 'iter_6' / 'a0_mul_hat.tif').exists()
 
 
 @pytest.mark.parametrize('C,H', [(4, 32), (4, 256)])

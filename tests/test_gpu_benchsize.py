@@ -44,7 +44,7 @@ def test_train_step_vs_reference_gradients(manifest, name, mode):
     loss = float(eng.train_step(ms, pan, gt, opt).item())
     assert abs(loss - float(g['loss'])) < 2e-5 * max(1.0, float(g['loss']))
     grads = _live_grads(eng)
-    assert len(grads) == len(g.files) - 4                     # loss, loss_fp64, out_fp32, out_fp64 + one entry per live tensor
+    assert len(grads) == len(g.files) - 5                     # loss, loss_fp64, out_fp32, out_fp64, self_err + one entry per live tensor
     dead = [n for n in eng.names if n.startswith(tuple(f'prior_module.{i}.' for i in m['none_grad_stages']))]
     assert len(dead) == m['n_none'] and not set(dead) & set(grads)
     num = sum(float(((v.astype(np.float64) - g[k.replace('.', '/')]) ** 2).sum()) for k, v in grads.items())
@@ -52,10 +52,13 @@ def test_train_step_vs_reference_gradients(manifest, name, mode):
     err = (num / den) ** 0.5
     # gate: global relative L2 1e-3; for scale, the reference's own fp32 gradients are m['grad_rel_fp32_vs_fp64'] off its fp64 ones
     assert err < 1e-3, (err, m['grad_rel_fp32_vs_fp64'])
-    # per tensor, on the tensor's own scale (floored: cancellation-dominated sums such as pos_emb rows are ~1e-7 in size)
-    worst = max((float(np.abs(v - g[k.replace('.', '/')]).max() / max(float(np.abs(g[k.replace('.', '/')]).max()), 2e-5)), k)
-                for k, v in grads.items())
-    assert worst[0] < 3e-2, worst
+    # per tensor, on the tensor's own scale (floored at 2e-5).  Allowance: 3e-2, or 3x the reference's OWN fp32-vs-fp64 error on that
+    # tensor where that is larger (`self_err`: sums that cancel to ~1e-5 -- FFT-mixer amplitude biases -- are known to a few per cent
+    # only in the reference's fp32 itself; measured by tools/gen_goldens.py on the reference)
+    self_err = dict(zip(sorted(grads), g['self_err']))
+    worst = max((float(np.abs(v - g[k.replace('.', '/')]).max() / max(float(np.abs(g[k.replace('.', '/')]).max()), 2e-5))
+                 / max(3e-2, 3.0 * self_err[k]), k) for k, v in grads.items())
+    assert worst[0] < 1.0, worst
     a, b = eng.live_ranges[0][1], eng.live_ranges[1][0]
     assert float(eng.gflat[a:b].abs().max()) == 0.0            # dead-stage slots of the flat gradient buffer: never written
 
