@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, '_lgteun_hip.so')
+LIB_PATH = os.environ.get('LGTEUN_HIP_LIB') or os.path.join(_HERE, '_lgteun_hip.so')   # override: diagnostic builds (tools/build_stamps.sh)
 
 LG_FLAG_FAITHFUL = 1
 LG_FLAG_SAVE = 2

@@ -31,7 +31,7 @@ static inline int block_base(int blk) {
 struct lg_plan {
     lg_config cfg;
     int n_offsets;
-    int ffn_tile;  // A/B switch read ONCE at plan creation (env LG_FFN_TILE): level-0 fused FFN as the per-tile kernel instead of the strip kernel
+    int ffn_tile;  // A/B switch read ONCE at plan creation (env LG_FFN_IMPL = strip | tile): the f32-MFMA fused FFN kernels instead of the split-bf16 ones
     int64_t* off;  // host copy of offsets
     int64_t shared(int s) const { return off[s]; }
     int64_t eta(int i) const { return off[S_NSHARED + i]; }

@@ -1,0 +1,385 @@
+// k_ffn_xs: the fused feed_forward half-block (reference models/common/LGT.py:91-109 + pre_norm / residual :45-61) at e = 16 with its
+// three 1x1-conv GEMMs on the bf16 matrix pipe in fp32-equivalent arithmetic (split_bf16.h: three bf16 pieces per operand, six
+// piece products, fp32 accumulation: measured error against fp64 no larger than the fp32 MFMA's).
+//
+//   y = x + W3 gelu( dw3x3( W2 gelu( W1 LN(x) + b1 ) + b2 ) ) + b3
+//
+// Same strip walk as k_ffn_strip (k_ffn.hip): a workgroup walks DOWN a 16-column strip in 8-row steps and keeps h2 of the last 10
+// halo rows in an LDS ring (fp32: the depthwise conv and both GELUs stay fp32 VALU work), so a step computes only its 8 new halo
+// rows (8 x 18 = 144 pixels).  What changed:
+//   * the f32-input MFMA shares the SIMD's vector ALU time (the old kernel sat exactly at MFMA cycles + VALU cycles); the bf16
+//     matrix pipe is separate, so the GEMMs now hide behind the VALU work (GELU, depthwise conv, LayerNorm, operand splitting);
+//   * weights ride on the A side of the MFMA (rows = output channels), pixels on the B side: a lane holds FOUR CONSECUTIVE
+//     CHANNELS of one pixel, so h1 / h2 / h3 / y leave its registers as 8- or 16-byte accesses (LDS and, for the saved
+//     activations of the live stage, HBM) instead of four 4-byte ones, and masks / ring slots are computed once per pixel;
+//   * the output tile needs no LDS round trip: the wave that ran GEMM3 adds bias + residual and does the next block's LayerNorm
+//     statistics across its four lane groups in registers.
+// Per step and wave: 54 + 108 + 24 MFMAs of 16 cycles (3.0 k matrix cycles, was 6.8 k vector-ALU cycles).
+//
+// LDS (78.9 KB, two workgroups per CU): ring [10][18][68] fp32 | A2: gelu(h1) pieces [3][48][72] bf16 | XA: LN(x) pieces
+// [2][3][48][16] bf16 (double buffer: chunk c+1 is normalised while chunk c's GEMM2 runs) ; the per-wave gelu(h3) pieces
+// [4][3][16][72] of the depthwise phase alias A2 + XA.
+#include "kernels.h"
+
+#include "hstore.h"
+#include "split_bf16.h"
+
+// In-kernel phase stamps (diagnostic build only, -DLG_STAMPS: tools/build_stamps.sh): the four waves of workgroup 0 write
+// s_memtime at the phase boundaries of their third step into a buffer nothing else reads; no stamp executes in the product build.
+#ifdef LG_STAMPS
+__device__ unsigned long long g_ffn_stamps[4 * 32];
+#define STAMP(i) do { if (blockIdx.x == 0 && lane == 0 && stamp_on) g_ffn_stamps[wave * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" __attribute__((visibility("default"))) int lg_debug_ffn_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ffn_stamps), sizeof(g_ffn_stamps));
+}
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+namespace {
+
+constexpr int E = 16, N1 = 64, TX = 16, HX = 18, TY = 8, RING = 10, LDR = 68, CH = 48, LDP = 72, CQ = 16;
+constexpr int A2_HALVES = 3 * CH * LDP;          // 10368
+constexpr int XA_SLOT = 3 * CH * E;              // 2304 halves per slot
+constexpr int G3_WAVE = 3 * 16 * LDP;            // 3456 halves per wave
+constexpr size_t LDS_BYTES = (size_t)RING * HX * LDR * 4 + (size_t)(A2_HALVES + 2 * XA_SLOT) * 2;
+static_assert(4 * G3_WAVE <= A2_HALVES + 2 * XA_SLOT, "gelu(h3) pieces must fit in the aliased region");
+
+// sum over the four lanes of a quad (lanes 4k .. 4k+3) with DPP quad_perm moves: VALU only, no LDS crossbar round trip
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    return v;
+}
+
+__device__ __forceinline__ bf16x8_t lds_x8(const uint16_t* p) { return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(p)); }
+__device__ __forceinline__ s16x4_t lds_x4(const uint16_t* p) { return __builtin_bit_cast(s16x4_t, *reinterpret_cast<const u32x2_t*>(p)); }
+
+template <bool SAVE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn_xs(Ffn1Args a1, Ffn2Args a2, int tiles_x, int strips_y, int nstrips,
+                                                                                       int SH) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* ring = reinterpret_cast<float*>(smem_raw);                                   // [RING*HX][LDR]
+    uint16_t* A2 = reinterpret_cast<uint16_t*>(smem_raw + (size_t)RING * HX * LDR * 4);   // [3][CH][LDP]
+    uint16_t* XA = A2 + A2_HALVES;                                                      // [2][3][CH][E]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    uint16_t* G3 = A2 + wave * G3_WAVE;                                                 // [3][16][LDP], aliases A2 / XA
+    const int h = a2.h, w = a2.w;
+    __shared__ __attribute__((aligned(16))) float sPar[5 * E];
+    __shared__ __attribute__((aligned(16))) float sMask[2][CH];   // 1 for halo pixels inside the image (dep_conv zero-pads h2)
+    float* sLn2g = sPar;            float* sLn2b = sPar + E;
+    float* sN1g = sPar + 2 * E;     float* sN1b = sPar + 3 * E;
+    float* sB3 = sPar + 4 * E;
+    for (int i = threadIdx.x; i < E; i += 256) {
+        sLn2g[i] = a1.ln2g[i]; sLn2b[i] = a1.ln2b[i]; sB3[i] = a2.b3[i];
+        sN1g[i] = a2.g ? a2.n1g[i] : 0.f; sN1b[i] = a2.g ? a2.n1b[i] : 0.f;
+    }
+    // ---- weights: split once, register-resident for every strip of this workgroup
+    const int c0 = wave * 16 + 4 * g;                 // first of the four h1 / h2 channels this lane holds after GEMM1 / GEMM2
+    const float4 b1v = *reinterpret_cast<const float4*>(a1.b1 + c0);
+    const float4 b2v = *reinterpret_cast<const float4*>(a1.b2 + c0);
+    const WFrag16 w1f = load_wfrag16(a1.w1 + (size_t)(wave * 16) * E, E, 0);
+    const WFrag32 w2f0 = load_wfrag32(a1.w2 + (size_t)(wave * 16) * N1, N1, 0);
+    const WFrag32 w2f1 = load_wfrag32(a1.w2 + (size_t)(wave * 16) * N1, N1, 1);
+    const WFrag32 w3f0 = load_wfrag32(a2.w3, N1, 0);
+    const WFrag32 w3f1 = load_wfrag32(a2.w3, N1, 1);
+    // depthwise taps of the lane's four channels (phase P2: lane = (pixel slot lane / 16, channel quad q)): 36 + 4 contiguous
+    // floats, re-read (L1 / L2 hits) at the top of every step instead of pinning 40 VGPRs through the GEMM phases
+    const int q = lane % CQ;
+    // LayerNorm phase: thread t < 192 = (chunk pixel t / 4, channel quad t % 4)
+    const int lpx = threadIdx.x >> 2, lq = threadIdx.x & 3;
+    const bool ln_thread = threadIdx.x < 4 * CH;
+    __syncthreads();
+    const float4 lng = *reinterpret_cast<const float4*>(sLn2g + 4 * lq), lnb = *reinterpret_cast<const float4*>(sLn2b + 4 * lq);
+
+#pragma unroll 1
+    for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+    int t = strip;
+    const int tx_i = t % tiles_x;
+    t /= tiles_x;
+    const int sy = t % strips_y;
+    const long b = t / strips_y;
+    const int x0 = tx_i * TX, Y0 = sy * SH, Yend = min(Y0 + SH, h);
+#ifdef LG_STAMPS
+    bool stamp_on = false;
+#endif
+
+    // request the x vector of halo pixel m of the row block starting at ya (zeros outside the image / beyond npx)
+    auto ln_fetch = [&](int ya, int npx, int c, float4& xv, bool& in) {
+        const int m = c * CH + lpx;
+        const int hy = m / HX, hx = m - hy * HX;
+        const int y = ya + hy, x = x0 + hx - 1;
+        in = ln_thread && (m < npx) && y >= 0 && y < h && x >= 0 && x < w;
+        xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) xv = *reinterpret_cast<const float4*>(a1.x + ((b * h + y) * (long)w + x) * E + 4 * lq);
+    };
+    // LayerNorm of the fetched vector over its 16 channels (4 lanes of a quad), split into pieces -> XA[slot]
+    auto ln_store = [&](int slot, const float4& xv, bool in) {
+        if (!ln_thread) return;
+        const float s = quad_sum((xv.x + xv.y) + (xv.z + xv.w));
+        const float mu = s * (1.0f / E);
+        const float d0 = xv.x - mu, d1 = xv.y - mu, d2 = xv.z - mu, d3 = xv.w - mu;
+        const float v = quad_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+        const float rstd = __builtin_amdgcn_rsqf(v * (1.0f / E) + LG_EPS);
+        const float m_ = in ? 1.0f : 0.0f;
+        const float yv[4] = {(d0 * rstd * lng.x + lnb.x) * m_, (d1 * rstd * lng.y + lnb.y) * m_, (d2 * rstd * lng.z + lnb.z) * m_,
+                             (d3 * rstd * lng.w + lnb.w) * m_};
+        u32x2_t q1, q2, q3;
+        split3_x4(yv, q1, q2, q3);
+        uint16_t* dst = XA + slot * XA_SLOT + lpx * E + 4 * lq;
+        *reinterpret_cast<u32x2_t*>(dst) = q1;
+        *reinterpret_cast<u32x2_t*>(dst + CH * E) = q2;
+        *reinterpret_cast<u32x2_t*>(dst + 2 * CH * E) = q3;
+        if (lq == 0) sMask[slot][lpx] = m_;
+    };
+
+    // h2 of halo rows [ya, ya + nr) x columns [x0 - 1, x0 + 17) -> ring   (nr = 2: strip prologue, 8: one step).
+    // pre / pre_in: chunk 0's x vector, fetched by the caller ahead of time.
+    auto compute_rows = [&](int ya, int nr, float4 pre, bool pre_in) {
+        const int npx = nr * HX, nchunks = (npx + CH - 1) / CH;
+        __syncthreads();                 // the previous phase's readers of the aliased region (gelu(h3) pieces) are done
+        STAMP(1);
+        ln_store(0, pre, pre_in);
+        STAMP(2);
+        __syncthreads();
+        STAMP(3);
+        const int ring0 = ((ya - Y0 + 1) % RING) * HX;
+        for (int c = 0; c < nchunks; ++c) {
+            const int slot = c & 1;
+            // next chunk's x: requested now, normalised while GEMM2 runs
+            float4 nx;
+            bool nin = false;
+            const bool more = c + 1 < nchunks;
+            if (more) ln_fetch(ya, npx, c + 1, nx, nin);
+            // per pixel block: image coordinates of this lane's pixel (SAVE) -- one pixel per block, not one per value
+            long prow[3];
+            bool inner[3];
+            if (SAVE) {
+#pragma unroll
+                for (int pb = 0; pb < 3; ++pb) {
+                    const int m = c * CH + pb * 16 + r;
+                    const int hy = m / HX, hx = m - hy * HX;
+                    const int y = ya + hy, x = x0 + hx - 1;
+                    inner[pb] = m < npx && hx >= 1 && hx <= TX && x < w && y >= Y0 && y < Yend;
+                    prow[pb] = ((b * h + y) * (long)w + x) * N1 + c0;
+                }
+            }
+            // ---- GEMM1 (K = 16): h1[16 w .. +15][48 pixels] = W1 LN(x)
+            f32x4_t acc[3];
+            const uint16_t* xa = XA + slot * XA_SLOT + r * E + 4 * g;
+#pragma unroll
+            for (int pb = 0; pb < 3; ++pb) {
+                acc[pb] = (f32x4_t){b1v.x, b1v.y, b1v.z, b1v.w};
+                const uint16_t* p = xa + pb * 16 * E;
+                mfma_split16(acc[pb], w1f, lds_x4(p), lds_x4(p + CH * E), lds_x4(p + 2 * CH * E));
+            }
+            // ---- GELU, split, -> A2 (8 bytes per piece and pixel)
+#pragma unroll
+            for (int pb = 0; pb < 3; ++pb) {
+                float av[4];
+                if (SAVE) {
+                    lg_v2f a01, a23, g01, g23;
+                    gelu2_both_f((lg_v2f){acc[pb][0], acc[pb][1]}, a01, g01);
+                    gelu2_both_f((lg_v2f){acc[pb][2], acc[pb][3]}, a23, g23);
+                    av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
+                    if (inner[pb]) {
+                        HS<false>::st4(a1.a1s, prow[pb], make_float4(av[0], av[1], av[2], av[3]));
+                        HS<false>::st4(a1.g1s, prow[pb], make_float4(g01.x, g01.y, g23.x, g23.y));
+                    }
+                } else {
+                    const lg_v2f a01 = gelu2_f((lg_v2f){acc[pb][0], acc[pb][1]}), a23 = gelu2_f((lg_v2f){acc[pb][2], acc[pb][3]});
+                    av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
+                }
+                u32x2_t q1, q2, q3;
+                split3_x4(av, q1, q2, q3);
+                uint16_t* dst = A2 + (pb * 16 + r) * LDP + c0;
+                *reinterpret_cast<u32x2_t*>(dst) = q1;
+                *reinterpret_cast<u32x2_t*>(dst + CH * LDP) = q2;
+                *reinterpret_cast<u32x2_t*>(dst + 2 * CH * LDP) = q3;
+            }
+            STAMP(4 + 4 * c);
+            __syncthreads();
+            STAMP(5 + 4 * c);
+            // ---- GEMM2 (K = 64): h2[16 w .. +15][48 pixels] = W2 gelu(h1) ; beside it (VALU): LayerNorm of the next chunk
+#pragma unroll
+            for (int pb = 0; pb < 3; ++pb) {
+                acc[pb] = (f32x4_t){b2v.x, b2v.y, b2v.z, b2v.w};
+                const uint16_t* p = A2 + (pb * 16 + r) * LDP + 8 * g;
+                mfma_split32(acc[pb], w2f0, lds_x8(p), lds_x8(p + CH * LDP), lds_x8(p + 2 * CH * LDP));
+                mfma_split32(acc[pb], w2f1, lds_x8(p + 32), lds_x8(p + 32 + CH * LDP), lds_x8(p + 32 + 2 * CH * LDP));
+            }
+            if (more) ln_store(slot ^ 1, nx, nin);
+#pragma unroll
+            for (int pb = 0; pb < 3; ++pb) {
+                const int m = c * CH + pb * 16 + r;
+                const float mk = sMask[slot][pb * 16 + r];
+                const float4 hh = make_float4(acc[pb][0] * mk, acc[pb][1] * mk, acc[pb][2] * mk, acc[pb][3] * mk);
+                if (SAVE && inner[pb]) HS<false>::st4(a1.h2, prow[pb], hh);
+                int rp = ring0 + m;
+                rp = rp >= RING * HX ? rp - RING * HX : rp;
+                if (m < npx) *reinterpret_cast<float4*>(ring + rp * LDR + c0) = hh;
+            }
+            STAMP(6 + 4 * c);
+            __syncthreads();   // A2 / XA[slot] are rewritten by the next chunk; the ring rows are complete after the last one
+            STAMP(7 + 4 * c);
+        }
+    };
+
+    {
+        float4 pre;
+        bool pin;
+        ln_fetch(Y0 - 1, 2 * HX, 0, pre, pin);
+        compute_rows(Y0 - 1, 2, pre, pin);
+    }
+    float4 pre;
+    bool pin;
+    ln_fetch(Y0 + 1, TY * HX, 0, pre, pin);
+#pragma unroll 1
+    for (int y0 = Y0; y0 < Yend; y0 += TY) {
+#ifdef LG_STAMPS
+    stamp_on = (y0 == Y0 + 2 * TY) && strip == 0;
+#endif
+    STAMP(0);
+    // the residual rows of the epilogue are requested first: their HBM round trip hides under the whole step.
+    // wave w owns tile rows 2 w and 2 w + 1; lane (r, g): pixel x0 + r, channels 4 g .. 4 g + 3
+    float4 xres[2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        const int y = y0 + 2 * wave + ch, x = x0 + r;
+        xres[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y < Yend && x < w) xres[ch] = *reinterpret_cast<const float4*>(a2.x + ((b * h + y) * (long)w + x) * E + 4 * g);
+    }
+    compute_rows(y0 + 1, TY, pre, pin);
+    if (y0 + TY < Yend) ln_fetch(y0 + TY + 1, TY * HX, 0, pre, pin);   // next step's first chunk: in flight during P2
+    float wq[4][9], bq[4];
+    {
+        const float* tp = a2.dww + 36 * q;
+        asm volatile("" : "+v"(tp));            // keep the loads inside the step loop (not hoisted back into 40 live registers)
+        float t36[36];
+#pragma unroll
+        for (int k4 = 0; k4 < 9; ++k4) {
+            const float4 v = *reinterpret_cast<const float4*>(tp + 4 * k4);
+            t36[4 * k4] = v.x; t36[4 * k4 + 1] = v.y; t36[4 * k4 + 2] = v.z; t36[4 * k4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int kk = 0; kk < 9; ++kk) wq[u][kk] = t36[9 * u + kk];
+        const float* bp = a2.dwb + 4 * q;
+        asm volatile("" : "+v"(bp));
+        const float4 bv = *reinterpret_cast<const float4*>(bp);
+        bq[0] = bv.x; bq[1] = bv.y; bq[2] = bv.z; bq[3] = bv.w;
+    }
+    // ---- P2: per wave, 2 tile rows of 16 pixels: dw3x3 over the ring + GELU -> pieces -> GEMM3 -> bias + residual -> y (+ planar LN half)
+    {
+        const int sbase = (y0 - Y0) % RING;            // ring slot of row y0 - 1
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int ty = 2 * wave + ch;
+#pragma unroll(SAVE ? 1 : 4)
+            for (int it = 0; it < 4; ++it) {
+                const int tx = (lane >> 4) + 4 * it;
+                float4 acc = make_float4(bq[0], bq[1], bq[2], bq[3]);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    int sl = sbase + ty + dy;
+                    sl = sl >= RING ? sl - RING : sl;
+                    sl = sl >= RING ? sl - RING : sl;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float4 v = *reinterpret_cast<const float4*>(ring + (sl * HX + tx + dx) * LDR + 4 * q);
+                        acc.x += wq[0][dy * 3 + dx] * v.x; acc.y += wq[1][dy * 3 + dx] * v.y;
+                        acc.z += wq[2][dy * 3 + dx] * v.z; acc.w += wq[3][dy * 3 + dx] * v.w;
+                    }
+                }
+                float av[4];
+                if (SAVE) {
+                    lg_v2f a01, a23, g01, g23;
+                    gelu2_both_f((lg_v2f){acc.x, acc.y}, a01, g01);
+                    gelu2_both_f((lg_v2f){acc.z, acc.w}, a23, g23);
+                    av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
+                    const int y = y0 + ty, x = x0 + tx;
+                    if (y < Yend && x < w) {
+                        const long o = ((b * h + y) * (long)w + x) * N1 + 4 * q;
+                        HS<false>::st4(a2.a3s, o, make_float4(av[0], av[1], av[2], av[3]));
+                        HS<false>::st4(a2.g3s, o, make_float4(g01.x, g01.y, g23.x, g23.y));
+                    }
+                } else {
+                    const lg_v2f a01 = gelu2_f((lg_v2f){acc.x, acc.y}), a23 = gelu2_f((lg_v2f){acc.z, acc.w});
+                    av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
+                }
+                u32x2_t q1, q2, q3;
+                split3_x4(av, q1, q2, q3);
+                uint16_t* dst = G3 + tx * LDP + 4 * q;
+                *reinterpret_cast<u32x2_t*>(dst) = q1;
+                *reinterpret_cast<u32x2_t*>(dst + 16 * LDP) = q2;
+                *reinterpret_cast<u32x2_t*>(dst + 2 * 16 * LDP) = q3;
+            }
+            STAMP(16 + 3 * ch);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- GEMM3 (K = 64): out[16 channels][16 pixels of tile row ty]
+            const float4 b3v = *reinterpret_cast<const float4*>(sB3 + 4 * g);
+            f32x4_t o = (f32x4_t){b3v.x, b3v.y, b3v.z, b3v.w};
+            {
+                const uint16_t* p = G3 + r * LDP + 8 * g;
+                mfma_split32(o, w3f0, lds_x8(p), lds_x8(p + 16 * LDP), lds_x8(p + 2 * 16 * LDP));
+                mfma_split32(o, w3f1, lds_x8(p + 32), lds_x8(p + 32 + 16 * LDP), lds_x8(p + 32 + 2 * 16 * LDP));
+            }
+            __builtin_amdgcn_wave_barrier();           // G3 is rewritten by the next tile row
+            STAMP(17 + 3 * ch);
+            // ---- epilogue in registers: residual, store, LayerNorm statistics of the next block across the four lane groups
+            const int y = y0 + ty, x = x0 + r;
+            const float o0 = o[0] + xres[ch].x, o1 = o[1] + xres[ch].y, o2 = o[2] + xres[ch].z, o3 = o[3] + xres[ch].w;
+            const bool ok = y < Yend && x < w;
+            if (ok) *reinterpret_cast<float4*>(a2.y + ((b * h + y) * (long)w + x) * E + 4 * g) = make_float4(o0, o1, o2, o3);
+            if (a2.g) {
+                float s = (o0 + o1) + (o2 + o3);
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                const float mu = s * (1.0f / E);
+                const float d0 = o0 - mu, d1 = o1 - mu, d2 = o2 - mu, d3 = o3 - mu;
+                float v = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                const float rstd = __builtin_amdgcn_rsqf(v * (1.0f / E) + LG_EPS);
+                if (ok && g >= 2) {      // channels 8..15 = the global-mixer half, planar [B, e/2, h, w]
+                    const long hw = (long)h * w, sp = (long)y * w + x;
+                    const float4 ng = *reinterpret_cast<const float4*>(sN1g + 4 * g), nb = *reinterpret_cast<const float4*>(sN1b + 4 * g);
+                    float* dst = a2.g + (b * (E / 2) + (4 * g - E / 2)) * hw + sp;
+                    dst[0] = d0 * rstd * ng.x + nb.x;
+                    dst[hw] = d1 * rstd * ng.y + nb.y;
+                    dst[2 * hw] = d2 * rstd * ng.z + nb.z;
+                    dst[3 * hw] = d3 * rstd * ng.w + nb.w;
+                }
+            }
+            STAMP(18 + 3 * ch);
+        }
+    }
+    }   // steps of the strip
+    }   // strips of this workgroup
+}
+
+}   // namespace
+
+int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
+    ProfScope prof__(LG_K_FFN2, s);
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_xs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e != hipSuccess) { lg_set_error("ffn_xs: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_once.done();
+    }
+    const int tiles_x = (a2.w + 15) / 16;
+    // strip height: the tallest multiple of 8 rows that still yields >= 512 strips (two resident workgroups per CU), at least 16
+    int SH = (a2.h + 7) / 8 * 8;
+    while (SH > 16 && (long)a2.B * tiles_x * ((a2.h + SH - 1) / SH) < 512) SH = (SH / 2 + 7) / 8 * 8;
+    const int strips_y = (a2.h + SH - 1) / SH;
+    const int nstrips = a2.B * tiles_x * strips_y;
+    const int grid = nstrips < 512 ? nstrips : 512;
+    if (a1.a1s != nullptr) k_ffn_xs<true><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    else k_ffn_xs<false><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    LG_CHECK_LAUNCH();
+    return 0;
+}

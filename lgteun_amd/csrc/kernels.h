@@ -105,7 +105,7 @@ struct Ffn1Args {
     void* g1s;       // optional save [P,4e]: gelu'(h1)       (backward never re-evaluates GELU)
     void* h2;        // [P,4e] = W2 gelu(W1 LN(x) + b1) + b2
     int hbf;         // hidden storage: 0 fp32, 1 bf16 (hstore.h)
-    int tile16;      // e = 16 only: per-tile fused kernel instead of the strip kernel (lg_plan::ffn_tile, A/B runs)
+    int tile16;      // A/B switch (lg_plan::ffn_tile): 0 = split-bf16 kernels (default), 1 = f32-MFMA strip kernel, 2 = f32-MFMA per-tile kernel
     const float *ln2g, *ln2b, *w1, *b1, *w2, *b2;
     long P;
 };
@@ -124,6 +124,7 @@ struct Ffn2Args {
 int launch_ffn2(int e, const Ffn2Args& a, hipStream_t s);
 // fused feed_forward half-block (h2 stays in LDS); returns 1 when e is not covered -> use launch_ffn1 + launch_ffn2
 int launch_ffn_fused(int e, const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s);
+int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s);   // e = 16, fp32 storage (k_ffn_x.hip)
 
 // test helper: g[B,e/2,HW] = LayerNorm(x)[..., e/2:] (the epilogue the producing kernels fuse)
 int launch_ln_split(int e, const float* x, const float* n1g, const float* n1b, float* g, int B, int HW, hipStream_t s);

@@ -1,0 +1,105 @@
+// fp32-equivalent GEMM tiles out of bf16 matrix-core instructions (gfx950).
+//
+// Why: on gfx950 the f32-input MFMA (v_mfma_f32_16x16x4_f32) runs at the fp32 VECTOR rate and its time ADDS to the VALU time of the
+// SIMD -- same wave or another (tools/micro/mfma_valu_overlap.hip, tools/micro/split_bf16_gemm.hip: 961 us of fp32 MFMA + 807 us
+// of v_fma = 1768 us together).  The bf16 matrix pipe is separate (16x the rate) and does overlap with VALU work.
+//
+// How: every fp32 number is EXACTLY the sum of three bf16 numbers, a = a1 + a2 + a3 (8 + 8 + 8 significand bits: a1 = the high
+// half of a's bit pattern, a2 = the high half of (a - a1), a3 = a - a1 - a2, all exact in fp32).  A product a*b is the sum of nine
+// piece products; the six with piece indices i + j <= 4 are kept (the dropped three are <= 2^-24 relative, i.e. below fp32's own
+// rounding), each one is exact in the matrix core's fp32 accumulator input, and v_mfma_f32_16x16x32_bf16 sums them in fp32:
+//     a*b ~ a1 b3 + a3 b1 + a2 b2 + a1 b2 + a2 b1 + a1 b1            (small terms first)
+// Measured against fp64 on random K = 64 / 128 / 256 dot products: 1.0e-7 / 1.4e-7 / 2.2e-7 relative L2, against 1.7e-7 / 2.2e-7 /
+// 3.1e-7 for the fp32 MFMA (an fp32 fma chain) -- i.e. at least fp32 accuracy -- in 6 x 16 = 96 matrix-pipe cycles per 16x16x32
+// block instead of 8 x 32 = 256, and off the VALU.  A 2-piece split (3 products) gives 3.5e-6 and plain bf16 2e-3.
+//
+// Operand maps (cdna guide section 3): for D = A * B with A [16 x K] and B [K x 16], lane l = (r = l & 15, g = l >> 4) supplies
+// A[row r][k = 8 g + j] and B[k = 8 g + j][col r], j = 0..7 (16x16x32) or k = 4 g + j, j = 0..3 (16x16x16), and receives
+// D[row 4 g + v][col r], v = 0..3.  The FFN kernels put the WEIGHTS on the A side (rows = output channels) and the pixels on the B
+// side, so that a lane ends up with four CONSECUTIVE channels of one pixel: its results leave as one 8-byte (bf16 pieces) or 16-byte
+// (fp32) access per pixel instead of four scattered 4-byte ones.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+// the three pieces of v as fp32 bit patterns whose HIGH halves are the bf16 pieces (the low halves of p2 / p3 are don't-care)
+struct Split3 {
+    uint32_t p1, p2, p3;
+};
+__device__ __forceinline__ Split3 split3(float v) {
+    Split3 s;
+    s.p1 = __float_as_uint(v);
+    const float r1 = v - __uint_as_float(s.p1 & 0xffff0000u);
+    s.p2 = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(s.p2 & 0xffff0000u);
+    s.p3 = __float_as_uint(r2);   // <= 8 significant bits: its high half is exact
+    return s;
+}
+// one dword = the bf16 (high halves) of two fp32 patterns: `lo` in bits 0..15, `hi` in bits 16..31   (one v_perm_b32)
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+// four consecutive-k values -> the 8-byte fragment of each piece
+__device__ __forceinline__ void split3_x4(const float (&v)[4], u32x2_t& q1, u32x2_t& q2, u32x2_t& q3) {
+    const Split3 a = split3(v[0]), b = split3(v[1]), c = split3(v[2]), d = split3(v[3]);
+    q1 = (u32x2_t){pack_hi16(a.p1, b.p1), pack_hi16(c.p1, d.p1)};
+    q2 = (u32x2_t){pack_hi16(a.p2, b.p2), pack_hi16(c.p2, d.p2)};
+    q3 = (u32x2_t){pack_hi16(a.p3, b.p3), pack_hi16(c.p3, d.p3)};
+}
+
+// weight fragments, split once per workgroup.  W: fp32 [rows][K] row-major, this wave's 16 rows start at W.
+struct WFrag32 {   // one 16x32 block of the A operand, three pieces
+    bf16x8_t p[3];
+};
+struct WFrag16 {   // one 16x16 block (K = 16)
+    s16x4_t p[3];
+};
+__device__ __forceinline__ WFrag32 load_wfrag32(const float* __restrict__ W, int K, int kb) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const float4 lo = *reinterpret_cast<const float4*>(W + (size_t)r * K + kb * 32 + 8 * g);
+    const float4 hi = *reinterpret_cast<const float4*>(W + (size_t)r * K + kb * 32 + 8 * g + 4);
+    const float a[4] = {lo.x, lo.y, lo.z, lo.w}, b[4] = {hi.x, hi.y, hi.z, hi.w};
+    u32x2_t a1, a2, a3, b1, b2, b3;
+    split3_x4(a, a1, a2, a3);
+    split3_x4(b, b1, b2, b3);
+    WFrag32 f;
+    f.p[0] = __builtin_bit_cast(bf16x8_t, (u32x4_t){a1.x, a1.y, b1.x, b1.y});
+    f.p[1] = __builtin_bit_cast(bf16x8_t, (u32x4_t){a2.x, a2.y, b2.x, b2.y});
+    f.p[2] = __builtin_bit_cast(bf16x8_t, (u32x4_t){a3.x, a3.y, b3.x, b3.y});
+    return f;
+}
+__device__ __forceinline__ WFrag16 load_wfrag16(const float* __restrict__ W, int K, int k0) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const float4 v = *reinterpret_cast<const float4*>(W + (size_t)r * K + k0 + 4 * g);
+    const float a[4] = {v.x, v.y, v.z, v.w};
+    u32x2_t a1, a2, a3;
+    split3_x4(a, a1, a2, a3);
+    WFrag16 f;
+    f.p[0] = __builtin_bit_cast(s16x4_t, a1);
+    f.p[1] = __builtin_bit_cast(s16x4_t, a2);
+    f.p[2] = __builtin_bit_cast(s16x4_t, a3);
+    return f;
+}
+
+// acc += W(16 x 32 block) * X(32 x 16 pixels); x1..x3 = the three pieces of the pixel operand (16 bytes per lane each)
+__device__ __forceinline__ void mfma_split32(f32x4_t& acc, const WFrag32& w, bf16x8_t x1, bf16x8_t x2, bf16x8_t x3) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[0], x3, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[2], x1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[1], x2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[0], x2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[1], x1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[0], x1, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma_split16(f32x4_t& acc, const WFrag16& w, s16x4_t x1, s16x4_t x2, s16x4_t x3) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.p[0], x3, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.p[2], x1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.p[1], x2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.p[0], x2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.p[1], x1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.p[0], x1, acc, 0, 0, 0);
+}

@@ -20,6 +20,35 @@ __device__ inline void split3(float v, __bf16& p1, __bf16& p2, __bf16& p3) {
     const float r2 = r1 - (float)p2;
     p3 = (__bf16)r2;
 }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// two fp16 pieces (11 + 11 significand bits), round-toward-zero conversions (v_cvt_pkrtz_f16_f32 saturates instead of overflowing)
+__device__ inline void split2h(float v, _Float16& p1, _Float16& p2) {
+    const auto h = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
+    p1 = (_Float16)h[0];
+    const float r = v - (float)p1;
+    const auto l = __builtin_amdgcn_cvt_pkrtz(r, 0.f);
+    p2 = (_Float16)l[0];
+}
+// fp16 two-piece split, three products (a1 b2 + a2 b1 + a1 b1); SB = power-of-two pre-scale of the B ("weight") operand
+template <int SB>
+__global__ void k_acc_h(const float* A, const float* B, float* C, int K) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        f16x8 a1, a2, b1, b2;
+        for (int j = 0; j < 8; ++j) {
+            _Float16 x, y;
+            split2h(A[r * K + k0 + 8 * g + j], x, y); a1[j] = x; a2[j] = y;
+            split2h(B[r * K + k0 + 8 * g + j] * (float)SB, x, y); b1[j] = x; b2[j] = y;
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc, 0, 0, 0);
+    }
+    for (int v = 0; v < 4; ++v) C[(4 * g + v) * 16 + r] = acc[v] * (1.0f / SB);
+}
+
 template <int MODE>   // 0: fp32 MFMA, 1: 6-term split, 2: 3-term split (two pieces), 3: plain bf16
 __global__ void k_acc(const float* A, const float* B, float* C, int K) {
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
@@ -95,11 +124,12 @@ static float run_speed(float* d, int iters, int wg_per_cu) {
 
 int main() {
     // ---- accuracy
-    for (int K : {16, 64, 128, 256}) {
-        for (int dist = 0; dist < 2; ++dist) {
+    for (int K : {64, 128, 256}) {
+        for (int dist = 0; dist < 3; ++dist) {
             std::vector<float> A(16 * K), B(16 * K);
             srand(K + dist);
-            for (auto& x : A) x = dist ? (float)(rand() / (double)RAND_MAX) : (float)(2.0 * rand() / RAND_MAX - 1.0);           // gelu-like (>=0) / signed
+            for (auto& x : A) x = dist == 1 ? (float)(rand() / (double)RAND_MAX) : (float)(2.0 * rand() / RAND_MAX - 1.0);           // gelu-like (>=0) / signed
+            if (dist == 2) for (auto& x : A) x *= (float)exp(-8.0 * rand() / RAND_MAX);   // wide dynamic range: many tiny activations
             for (auto& x : B) x = (float)((2.0 * rand() / RAND_MAX - 1.0) / sqrt((double)K));
             std::vector<double> ref(256, 0.0), mag(256, 0.0);
             for (int i = 0; i < 16; ++i)
@@ -109,19 +139,23 @@ int main() {
             hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dC, 256 * 4);
             hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
             hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
-            double err[4];
-            for (int mode = 0; mode < 4; ++mode) {
+            double err[7];
+            for (int mode = 0; mode < 7; ++mode) {
                 if (mode == 0) k_acc<0><<<1, 64>>>(dA, dB, dC, K);
                 if (mode == 1) k_acc<1><<<1, 64>>>(dA, dB, dC, K);
                 if (mode == 2) k_acc<2><<<1, 64>>>(dA, dB, dC, K);
                 if (mode == 3) k_acc<3><<<1, 64>>>(dA, dB, dC, K);
+                if (mode == 4) k_acc_h<1><<<1, 64>>>(dA, dB, dC, K);
+                if (mode == 5) k_acc_h<16><<<1, 64>>>(dA, dB, dC, K);
+                if (mode == 6) k_acc_h<256><<<1, 64>>>(dA, dB, dC, K);
                 std::vector<float> C(256);
                 hipMemcpy(C.data(), dC, 256 * 4, hipMemcpyDeviceToHost);
                 double num = 0, den = 0;
                 for (int i = 0; i < 256; ++i) { num += (C[i] - ref[i]) * (C[i] - ref[i]); den += ref[i] * ref[i]; }
                 err[mode] = sqrt(num / den);
             }
-            printf("K=%3d %s  rel-L2 vs fp64: fp32-mfma %.3e | bf16x6 %.3e | bf16x3 %.3e | bf16 %.3e\n", K, dist ? "A>=0  " : "signed", err[0], err[1], err[2], err[3]);
+            printf("K=%3d %s  rel-L2 vs fp64: fp32-mfma %.3e | bf16x6 %.3e | bf16x3 %.3e | bf16 %.3e | fp16x3 %.3e  (B x16) %.3e  (B x256) %.3e\n", K,
+                   dist == 1 ? "A>=0  " : (dist == 2 ? "A small" : "signed"), err[0], err[1], err[2], err[3], err[4], err[5], err[6]);
             hipFree(dA); hipFree(dB); hipFree(dC);
         }
     }
