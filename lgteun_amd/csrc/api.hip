@@ -200,7 +200,7 @@ static int block_mixer_fwd(const lg_plan* pl, const float* P, int stage, int j, 
 }
 
 static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, const BlockBufs& bb, float* g_next, int next_blk,
-                         int B, int flags, hipStream_t s) {
+                         int B, int flags, hipStream_t s, float* wsplit) {
     int rc;
     Ffn1Args a1;
     a1.x = bb.xmid; a1.a1s = (flags & LG_FLAG_SAVE) ? bb.a1 : nullptr; a1.g1s = (flags & LG_FLAG_SAVE) ? bb.g1 : nullptr; a1.h2 = bb.h2;
@@ -210,6 +210,7 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     a1.P = (long)B * bb.h * bb.w;
     a1.hbf = pl->cfg.precision == 1 ? 1 : 0;
     a1.tile16 = pl->ffn_tile;
+    a1.wsplit = wsplit;
     Ffn2Args a2;
     a2.h2 = bb.h2; a2.x = bb.xmid; a2.a3s = (flags & LG_FLAG_SAVE) ? bb.a3 : nullptr; a2.g3s = (flags & LG_FLAG_SAVE) ? bb.g3 : nullptr; a2.y = bb.xout;
     a2.g = g_next;
@@ -220,7 +221,7 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     a2.B = B; a2.h = bb.h; a2.w = bb.w; a2.hbf = a1.hbf;
     a1.h2 = (flags & LG_FLAG_SAVE) ? bb.h2 : nullptr;   // fused path: h2 only leaves the chip when the backward needs it
     rc = launch_ffn_fused(bb.e, a1, a2, s);
-    if (rc != 1) return rc;
+    if (rc != LG_FFN_NOT_FUSED) return rc;
     a1.h2 = bb.h2;
     if ((rc = launch_ffn1(bb.e, a1, s))) return rc;
     return launch_ffn2(bb.e, a2, s);
@@ -251,9 +252,9 @@ static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z,
     if ((rc = launch_embed(c.C, ea, s))) return rc;
     // encoder LGB (2 blocks)
     if ((rc = block_mixer_fwd(pl, P, stage, 0, nb.blk[0], posT + 0 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
-    if ((rc = block_ffn_fwd(pl, P, stage, 0, nb.blk[0], nb.blk[1].g, 1, B, flags, s))) return rc;
+    if ((rc = block_ffn_fwd(pl, P, stage, 0, nb.blk[0], nb.blk[1].g, 1, B, flags, s, nb.wsplit))) return rc;
     if ((rc = block_mixer_fwd(pl, P, stage, 1, nb.blk[1], posT + 1 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
-    if ((rc = block_ffn_fwd(pl, P, stage, 1, nb.blk[1], nullptr, 0, B, flags, s))) return rc;
+    if ((rc = block_ffn_fwd(pl, P, stage, 1, nb.blk[1], nullptr, 0, B, flags, s, nb.wsplit))) return rc;
     // down
     DownArgs da;
     da.x = nb.blk[1].xout; da.y = nb.blk[2].xin; da.g = nb.blk[2].g;
@@ -264,7 +265,7 @@ static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z,
     if ((rc = launch_down(E, da, s))) return rc;
     // bottleneck
     if ((rc = block_mixer_fwd(pl, P, stage, 2, nb.blk[2], posT + 2 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
-    if ((rc = block_ffn_fwd(pl, P, stage, 2, nb.blk[2], nullptr, 0, B, flags, s))) return rc;
+    if ((rc = block_ffn_fwd(pl, P, stage, 2, nb.blk[2], nullptr, 0, B, flags, s, nb.wsplit))) return rc;
     // up + fusion
     UpFuseArgs ua;
     ua.xb = nb.blk[2].xout; ua.skip = nb.blk[1].xout; ua.y = nb.blk[3].xin; ua.g = nb.blk[3].g;
@@ -276,9 +277,9 @@ static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z,
     if ((rc = launch_upfuse(E, ua, s))) return rc;
     // decoder LGB (2 blocks)
     if ((rc = block_mixer_fwd(pl, P, stage, 3, nb.blk[3], posT + 3 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
-    if ((rc = block_ffn_fwd(pl, P, stage, 3, nb.blk[3], nb.blk[4].g, 4, B, flags, s))) return rc;
+    if ((rc = block_ffn_fwd(pl, P, stage, 3, nb.blk[3], nb.blk[4].g, 4, B, flags, s, nb.wsplit))) return rc;
     if ((rc = block_mixer_fwd(pl, P, stage, 4, nb.blk[4], posT + 4 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
-    if ((rc = block_ffn_fwd(pl, P, stage, 4, nb.blk[4], nullptr, 0, B, flags, s))) return rc;
+    if ((rc = block_ffn_fwd(pl, P, stage, 4, nb.blk[4], nullptr, 0, B, flags, s, nb.wsplit))) return rc;
     // tail
     TailArgs ta;
     ta.x = nb.blk[4].xout; ta.z = z; ta.out = out;
@@ -404,7 +405,7 @@ extern "C" int lg_op_block(const lg_plan* plan, const float* params, int32_t sta
     bb.xmid = const_cast<float*>(x);
     bb.xout = y;
     (void)npix;
-    return block_ffn_fwd(plan, params, stage, blk, bb, nullptr, 0, B, 0, s);
+    return block_ffn_fwd(plan, params, stage, blk, bb, nullptr, 0, B, 0, s, nb.wsplit);
 }
 
 extern "C" int lg_op_block_bwd(const lg_plan* plan, const float* params, float* grads, int32_t stage, int32_t blk, int32_t which,
@@ -431,7 +432,7 @@ extern "C" int lg_op_block_bwd(const lg_plan* plan, const float* params, float* 
         if ((rc = block_mixer_fwd(plan, params, stage, blk, bb, nb.posT, B, LG_FLAG_SAVE, 0, s, nb.fft_scratch))) return rc;
     } else {
         bb.xmid = const_cast<float*>(x);
-        if ((rc = block_ffn_fwd(plan, params, stage, blk, bb, nullptr, 0, B, LG_FLAG_SAVE, s))) return rc;
+        if ((rc = block_ffn_fwd(plan, params, stage, blk, bb, nullptr, 0, B, LG_FLAG_SAVE, s, nb.wsplit))) return rc;
     }
     return op_block_bwd(plan, params, grads, stage, blk, which, dy, dx, nb, (char*)workspace + nb.bytes, B, s);
 }

@@ -108,6 +108,7 @@ struct Ffn1Args {
     int tile16;      // A/B switch (lg_plan::ffn_tile): 0 = split-bf16 kernels (default), 1 = f32-MFMA strip kernel, 2 = f32-MFMA per-tile kernel
     const float *ln2g, *ln2b, *w1, *b1, *w2, *b2;
     long P;
+    void* wsplit;    // workspace scratch for pre-split weight fragments (ffn_wsplit_bytes; k_ffn_x32.hip), or nullptr
 };
 int launch_ffn1(int e, const Ffn1Args& a, hipStream_t s);
 struct Ffn2Args {
@@ -122,9 +123,13 @@ struct Ffn2Args {
     int B, h, w;
 };
 int launch_ffn2(int e, const Ffn2Args& a, hipStream_t s);
-// fused feed_forward half-block (h2 stays in LDS); returns 1 when e is not covered -> use launch_ffn1 + launch_ffn2
+// fused feed_forward half-block (h2 stays in LDS); returns LG_FFN_NOT_FUSED when e is not covered -> use launch_ffn1 + launch_ffn2
+// (a code of its own: 1 is hipErrorInvalidValue)
+#define LG_FFN_NOT_FUSED (-1000)
 int launch_ffn_fused(int e, const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s);
 int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s);   // e = 16, fp32 storage (k_ffn_x.hip)
+int launch_ffn_x32(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s);  // e = 32, fp32 storage (k_ffn_x32.hip)
+size_t ffn_wsplit_bytes(int e);   // bytes of a1.wsplit for hidden width 4e
 
 // test helper: g[B,e/2,HW] = LayerNorm(x)[..., e/2:] (the epilogue the producing kernels fuse)
 int launch_ln_split(int e, const float* x, const float* n1g, const float* n1b, float* g, int B, int HW, hipStream_t s);
