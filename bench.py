@@ -5,11 +5,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = forward + L1 + backward + Adam (+ StepLR tick) over one synthetic batch already resident in HBM.
-Workload = BASELINE.json configs[1]: GF-2-shaped 4-band 32x32 MS / 128x128 PAN, K=4 stages, 32 pairs per GPU, executed in
-FAITHFUL mode (all K LGTs run forward like the reference; backward over the live graph).  Weak scaling: per-GPU batch fixed.
+Workload (default --config c2) = BASELINE.json configs[1]: GF-2-shaped 4-band 32x32 MS / 128x128 PAN, K=4 stages, 32 pairs per
+GPU, executed in FAITHFUL mode (all K LGTs run forward like the reference; backward over the live graph).  Weak scaling: per-GPU
+batch fixed.  --config c3 / c5 run BASELINE configs[2] / [4] (8 bands; parity-test cases that a driver run can also record).
 Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline     -- the dominant kernel timed live with HIP events on its launch stream (lg_prof_*), against its roof
-  cpu_baseline -- the oracle's CPU train step (kind "port") on this host's cores, bounded sample (rank 0, N=1 only)
+  roofline     -- the dominant kernel timed live with HIP events on its launch stream (lg_prof_*), against its roof; `traffic`
+                  is read from the committed PMC summary of the same command (profiles/r02_bench_bs32_pmc_hbm.csv)
+  eval_forward -- eval-mode forward pairs/s on the same batch (faithful and live), SURVEY 8d
+  cpu_baseline -- the oracle's CPU train step at the same batch size and its B=1 eval forward (kind "port") on this host's cores,
+                  bounded sample (rank 0, N=1 only), with the CPU model string
 """
 import argparse
 import ctypes
@@ -27,11 +31,36 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0
 PEAK_F32_MFMA_TFLOPS = 157.3
 
-# HBM bytes per launch from the PMC counters (profiles/, FETCH_SIZE x2 corrected + WRITE_SIZE; separate --pmc passes), per kernel
-TRAFFIC_BYTES = {'ffn': 228845703}   # fused FFN forward (k_ffn_strip at e=16, k_ffn_fused at e=32), all launches of a step averaged (profiles/r01_bench_bs32_pmc_hbm.csv)
+# fp32-equivalent split arithmetic (csrc/split_bf16.h): six bf16 MFMAs per 16x16x32 block -> what the bf16 pipe could deliver
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
-C, K, H, B_PER_GPU = 4, 4, 128, 32
+CONFIGS = {   # BASELINE.json configs[...] that fit one GPU: (C, K, PAN size, pairs per GPU, label)
+    'c2': (4, 4, 128, 32, 'BASELINE configs[1]: C=4, MS 32x32, PAN 128x128, K=4, 32 pairs/GPU'),
+    'c3': (8, 4, 128, 32, 'BASELINE configs[2]: C=8, MS 32x32, PAN 128x128, K=4, 32 pairs/GPU'),
+    'c5': (8, 8, 256, 16, 'BASELINE configs[4]: C=8, MS 64x64, PAN 256x256, K=8, 16 pairs/GPU'),
+}
+C, K, H, B_PER_GPU = CONFIGS['c2'][:4]
 E, P0 = 4 * C, H * H
+
+# kernels that make up the "ffn" launch slot (lg_kernel_id LG_K_FFN2): the fused feed_forward half-block, all variants
+FFN_KERNELS = ('k_ffn_xs', 'k_ffn_x32', 'k_ffn_strip', 'k_ffn_fused')
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r02_bench_bs32_pmc_hbm.csv')
+
+
+def traffic_from_profile(kernel):
+    """HBM bytes per launch of the roofline kernel from the committed PMC summary (FETCH_SIZE x2 corrected + WRITE_SIZE, separate
+    --pmc passes of `python bench.py`; tools/summarize_profiles.py), launch-weighted over the kernel's variants.  None if absent."""
+    import csv
+    names = {'ffn': FFN_KERNELS, 'attn': ('k_attn<',), 'fft': ('k_fftmix<',), 'attn_bwd': ('k_attn_bwd_core',), 'fft_bwd': ('k_fftmix_bwd',)}.get(kernel)
+    if not names or not os.path.exists(PMC_SUMMARY):
+        return None
+    num = den = 0.0
+    for r in csv.DictReader(open(PMC_SUMMARY)):
+        if any(n in r['Kernel_Name'] for n in names):
+            num += float(r['HBM_bytes_per_launch']) * int(r['launches'])
+            den += int(r['launches'])
+    return int(num / den) if den else None
 
 
 def synth_batch(B, rank, device):
@@ -74,14 +103,25 @@ def host_cores():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(cores):
-    """oracle (CPU restatement, torch CPU fp32) train step: forward(faithful) + L1 + backward + Adam, bounded sample"""
-    import numpy as np
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:  # noqa: BLE001
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(cores, config):
+    """oracle (CPU restatement, torch CPU fp32; SURVEY 8d "CPU baseline beside it"): train step (forward faithful + L1 + backward +
+    Adam) at the bench batch size, >= 3 timed steps after 1 warm-up, and the B=1 eval forward of configs[0]; bounded to ~10-30 s of
+    CPU work (the 8-band configs time a smaller batch and say so)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from helpers import det_params
     from oracle import lgteun_oracle as orc
     torch.set_num_threads(cores)
-    Bc = 4
+    Bc = B_PER_GPU if config == 'c2' else (8 if config == 'c3' else 1)
     P = det_params(C, K, requires_grad=True)
     ms, pan, gt = synth_batch(Bc, 0, 'cpu')
     mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in P.items()}
@@ -99,28 +139,45 @@ def cpu_baseline(cores):
                 v.copy_(p)
                 mom[k] = (m1, v1)
     step(1)                                   # warm-up
+    n = 3
     t0 = time.time()
-    n = 2
     for it in range(n):
         step(it + 2)
     dt = (time.time() - t0) / n
-    return dict(value=round(Bc / dt, 3), unit='train image-pairs/sec', cores=cores, kind='port',
-                sample=f'{n} timed train steps (fwd faithful + L1 + bwd + Adam), batch {Bc}, fp32 torch-CPU oracle, after 1 warm-up')
+    # configs[0]: GF-2 4-band, 32x32 MS / 128x128 PAN, K=4, batch 1, eval forward (the reference's own CPU-runnable case)
+    P1 = det_params(4, 4)
+    g = torch.Generator().manual_seed(19971118)
+    ms1 = torch.randint(0, 2048, (1, 4, 32, 32), generator=g).float() / 2047.5
+    pan1 = torch.randint(0, 2048, (1, 1, 128, 128), generator=g).float() / 2047.5
+    with torch.no_grad():
+        orc.forward(P1, ms1, pan1, 4, mode='faithful')
+        t1 = time.time()
+        for _ in range(3):
+            orc.forward(P1, ms1, pan1, 4, mode='faithful')
+        dt1 = (time.time() - t1) / 3
+    return dict(value=round(Bc / dt, 3), unit='train image-pairs/sec', cores=cores, kind='port', cpu_model=cpu_model(),
+                sample=f'{n} timed train steps (fwd faithful + L1 + bwd + Adam), batch {Bc}, fp32 torch-CPU oracle, after 1 warm-up',
+                eval_forward_b1=dict(value=round(1.0 / dt1, 3), unit='eval image-pairs/sec',
+                                     sample='3 timed eval forwards (faithful), configs[0]: C=4, 128x128 PAN, K=4, batch 1'))
 
 
 def main():
+    global C, K, H, B_PER_GPU, E, P0
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS), help='c2 = BASELINE configs[1] (the metric; default); c3 / c5 = the 8-band configs')
     ap.add_argument('--prof-kernel', default='ffn', help='kernel timed live for the roofline object (default: the dominant one)')
     ap.add_argument('--mode', default='faithful', choices=['faithful', 'live', 'chained'],
                     help="'faithful' = the reference's graph (headline); 'live' / 'chained' are labelled non-headline variants")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-live', action='store_true', help='skip the live-mode side measurement (profiling runs)')
+    ap.add_argument('--no-live', action='store_true', help='skip the side measurements (profiling runs)')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                     help="fp32: parity mode (default).  bf16: saved/hidden FFN activations of the backward stored as bf16")
     args = ap.parse_args()
+    C, K, H, B_PER_GPU, label = CONFIGS[args.config]
+    E, P0 = 4 * C, H * H
 
     from lgteun_amd import ddp
     rank, world, local_rank = ddp.env_world()
@@ -154,6 +211,16 @@ def main():
         eng.train_step(ms, pan, gt, opt)
         sched.step()
 
+    def timed(fn, n_warm, n):
+        for _ in range(n_warm):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n
+
     import warnings
     warnings.filterwarnings('ignore', message='Detected call of')
     L = _lib.lib()
@@ -180,41 +247,40 @@ def main():
     _lib.check(L.lg_prof_read(ctypes.byref(tot_ms), ctypes.byref(n_l)), 'lg_prof_read')
     L.lg_prof_disable()
     loss = float(eng._loss.item()) * world if world == 1 else None
+    side = world == 1 and not args.no_live
+    n_side = max(5, args.steps // 2)
     # side measurement (NOT `value`): the same train step with the K-1 dead LGT forwards skipped -- bit-identical outputs,
     # gradients and weights (tests/test_gpu_fullsize.py), i.e. what a user of this framework can run instead
     live = None
-    if args.mode == 'faithful' and world == 1 and not args.no_live:
+    if args.mode == 'faithful' and side:
         net.mode = 'live'
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n_live = max(5, args.steps // 2)
-        for _ in range(n_live):
-            step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t1) / n_live
+        dt = timed(step, 2, n_side)
         live = dict(value=round(B_PER_GPU / dt, 2), ms_per_step=round(dt * 1e3, 3), note='dead-stage LGT forwards skipped; identical results')
         net.mode = args.mode
-    # second side measurement (NOT `value`): BASELINE configs[1] names bf16 training.  The opt-in throughput mode (FFN GEMMs on
-    # the bf16 matrix cores with fp32 accumulation, bf16 storage of the tensors saved for the backward; everything else fp32)
-    # is gated against the fp32 mode in tests/test_gpu_backward.py (>= 50 dB PSNR, gradients within 2e-2); the headline stays
-    # the fp32 parity mode, which is what the 1e-3 output gate is stated for.
+    # second side measurement (NOT `value`): BASELINE configs[1] names bf16 training.  The opt-in throughput mode (plain bf16 MFMA in
+    # the FFN forward, bf16 storage of the tensors saved for the backward; everything else fp32) is gated against the default mode in
+    # tests/test_gpu_backward.py (>= 50 dB PSNR, gradients within 2e-2); the headline stays the fp32-accurate mode the 1e-3 gate is
+    # stated for.
     bf16 = None
-    if args.precision == 'fp32' and world == 1 and not args.no_live:
+    if args.precision == 'fp32' and side:
         net.precision = 'bf16'
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n_bf = max(5, args.steps // 2)
-        for _ in range(n_bf):
-            step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t1) / n_bf
+        dt = timed(step, 3, n_side)
         bf16 = dict(value=round(B_PER_GPU / dt, 2), ms_per_step=round(dt * 1e3, 3), mode=args.mode,
-                    note='precision="bf16" throughput mode: bf16 MFMA in the FFN forward + bf16 saved activations; PSNR vs fp32 mode >= 50 dB (tested)')
+                    note='precision="bf16" throughput mode: plain bf16 MFMA in the FFN forward + bf16 saved activations; PSNR vs default mode >= 50 dB (tested)')
         net.precision = 'fp32'
+    # third side measurement: eval-mode forward (no dropout, nothing saved), the reference's get_model_output path
+    evalf = None
+    if side:
+        net.eval()
+        evalf = {}
+        with torch.no_grad():
+            for mode in ('faithful', 'live'):
+                net.mode = mode
+                net.faithful_eval = True           # time exactly the requested graph (the module would otherwise skip dead stages in eval)
+                dt = timed(lambda: net(ms, pan), 3, n_side)
+                evalf[mode] = dict(value=round(B_PER_GPU / dt, 2), ms_per_batch=round(dt * 1e3, 3))
+        net.mode = args.mode
+        net.train()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -229,16 +295,23 @@ def main():
             roof = dict(bound='mfma', achieved=round(ach_tf, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=round(f_mfma, 4))
         else:
             roof = dict(bound='hbm', achieved=round(ach_gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(f_hbm, 4))
-        roof.update(traffic=TRAFFIC_BYTES.get(args.prof_kernel), kernel=L.lg_kernel_name(kid).decode(), launches=int(n_l.value),
+        roof.update(traffic=traffic_from_profile(args.prof_kernel) if args.config == 'c2' else None,
+                    traffic_source=os.path.relpath(PMC_SUMMARY, ROOT) if args.config == 'c2' and os.path.exists(PMC_SUMMARY) else None,
+                    kernel=L.lg_kernel_name(kid).decode(), launches=int(n_l.value),
                     avg_launch_us=round(avg_us, 2), algorithmic_bytes_per_launch=int(byts), algorithmic_flops_per_launch=int(flops),
                     hbm_frac=round(f_hbm, 4), mfma_frac_fp32=round(f_mfma, 4), peak_hbm_GBs=PEAK_HBM_GBS,
-                    peak_fp32_mfma_TFLOPs=PEAK_F32_MFMA_TFLOPS)
-        out = dict(metric='train image-pairs/sec, GF-2 4-band 128x128, K=4, bs=32/GPU', value=round(value, 2), unit='image-pairs/sec',
+                    peak_fp32_mfma_TFLOPs=PEAK_F32_MFMA_TFLOPS,
+                    note='peak = the f32 matrix rate (the reference arithmetic\'s dtype). The GEMMs execute as 6 bf16 MFMAs per product '
+                         f'(fp32-equivalent 3-piece split): their own pipe would allow {PEAK_SPLIT_TFLOPS:.0f} TFLOP/s; the kernel is bound by its '
+                         'VALU work (two erf-GELUs per hidden element, depthwise 3x3, LayerNorm, operand splitting), not by either matrix rate')
+        metric = 'train image-pairs/sec, GF-2 4-band 128x128, K=4, bs=32/GPU' if args.config == 'c2' else f'train image-pairs/sec, {label}'
+        out = dict(metric=metric, value=round(value, 2), unit='image-pairs/sec',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
-                   scaling='weak', vs_baseline=None, dtype='f32' if args.precision == 'fp32' else 'f32 compute, bf16 saved activations', data='synthetic',
-                   config=dict(workload='BASELINE configs[1]: C=4, MS 32x32, PAN 128x128, K=4, 32 pairs/GPU, train step = fwd + L1 + '
-                                        'bwd + Adam + StepLR tick', mode=args.mode, global_batch=B_PER_GPU * world, parallelism=f'dp{world}',
-                               dropout=True),
+                   scaling='weak', vs_baseline=None,
+                   dtype='f32 (GEMMs: bf16x3-split MFMA, fp32 accumulate; fp32-equivalent)' if args.precision == 'fp32'
+                         else 'bf16 MFMA + bf16 saved activations, f32 elsewhere', data='synthetic',
+                   config=dict(workload=label + ', train step = fwd + L1 + bwd + Adam + StepLR tick', mode=args.mode,
+                               global_batch=B_PER_GPU * world, parallelism=f'dp{world}', dropout=True),
                    roofline=roof)
         if loss is not None:
             out['final_loss'] = round(loss, 6)
@@ -246,8 +319,10 @@ def main():
             out['live_mode'] = live
         if bf16 is not None:
             out['bf16_mode'] = bf16
+        if evalf is not None:
+            out['eval_forward'] = dict(unit='eval image-pairs/sec', batch=B_PER_GPU, **evalf)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(host_cores())
+            out['cpu_baseline'] = cpu_baseline(host_cores(), args.config)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -83,6 +83,7 @@ class Engine:
         self.C = int(module.in_channels)
         self.K = int(module.stage)
         self.module_mode = lambda: module.mode
+        self.module_faithful_eval = lambda: getattr(module, 'faithful_eval', False)
         self.module_precision = lambda: getattr(module, 'precision', 'fp32')
         names = canonical_names(self.C, self.K)
         params = dict(module.named_parameters())
@@ -265,6 +266,10 @@ class Engine:
         flags = self.base_flags(training)
         need_grad = torch.is_grad_enabled() and any(self.params[i].requires_grad for i in self.live_idx)
         if not need_grad:
+            if not training and not self.module_faithful_eval():
+                # inference: the K-1 dead-stage LGTs change nothing in the output (bitwise, tested) -- they run only
+                # where the reference's WORK is being reproduced (training in 'faithful' mode, or module.faithful_eval = True)
+                flags &= ~LG_FLAG_FAITHFUL
             out, _ = self.forward_raw(ms, pan, flags, self.next_seed() if training else 0)
             return out
         live = [self.params[i] for i in self.live_idx]

@@ -100,6 +100,7 @@ class Pansharpening(nn.Module):
         # 'chained': the intended unfolding (stage i+1 consumes LGT_i's output; every parameter trains) -- NOT the reference's
         # results, opt-in only
         self.mode = 'faithful'
+        self.faithful_eval = False  # True: also run the dead-stage LGTs in eval / no-grad forwards (timing the reference's work)
         self.precision = 'fp32'    # 'fp32': parity mode; 'bf16': saved / hidden FFN activations of the backward stored as bf16
         self._engine = None
         self._ddp = None           # (group,) once attach_ddp() was called: survives .to() / a rebuilt engine

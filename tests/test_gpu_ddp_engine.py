@@ -39,8 +39,11 @@ def test_two_rank_engine_train_step_equals_single_process(request):
     assert np.all(g0[b0:a1] == 0.0) and np.abs(g0[a1:b1]).max() > 0 and np.abs(g0[a0:b0]).max() > 0
     assert _rel(g0, gs) < 2e-5, _rel(g0, gs)
     for it in range(3):
-        # each rank reports its share of the global mean
-        assert abs(float(r0[f'loss{it}'][0]) + float(r1[f'loss{it}'][0]) - float(r0[f'single_loss{it}'][0])) < 2e-6
+        # each rank reports its share of the global mean.  Step 0 runs on identical weights; afterwards the replicas and the single
+        # process differ by what Adam makes of fp32 summation-order noise in near-zero gradients (g / sqrt(v) ~ +-1), see the
+        # weight tolerance below
+        tol = 2e-6 if it == 0 else 1e-4 * float(r0[f'single_loss{it}'][0])
+        assert abs(float(r0[f'loss{it}'][0]) + float(r1[f'loss{it}'][0]) - float(r0[f'single_loss{it}'][0])) < tol, it
     assert np.array_equal(r0['weights'], r1['weights'])         # replicas stay in lock-step
     w, ws = r0['weights'], r0['single_weights']
     assert _rel(w[a1:b1], ws[a1:b1]) < 1e-4 and _rel(w[a0:b0], ws[a0:b0]) < 1e-4

@@ -99,6 +99,7 @@ def test_whole_net_vs_reference_golden(gpu, manifest, name, mode):
     ms, pan, gt = dw.make_inputs(m['B'], m['C'], m['h'], m['h'], seed=m['seed'], kind=m['kind'])
     net = make_module(m['C'], m['K'])
     net.mode = mode
+    net.faithful_eval = True          # run exactly the requested graph (inference skips dead stages by default)
     with torch.no_grad():
         y = net(T(ms).cuda(), T(pan).cuda()).cpu()
     assert y.shape == g['out_fp32'].shape and y.dtype == torch.float32

@@ -41,6 +41,7 @@ def test_full_size_forward_properties():
     ms, pan, _ = (T(a).cuda() for a in dw.make_inputs(32, 4, 32, 32, seed=5, kind='dn'))
     with torch.no_grad():
         net.mode = 'faithful'
+        net.faithful_eval = True      # otherwise inference skips the dead stages by itself
         y = net(ms, pan)
         y2 = net(ms, pan)
         net.mode = 'live'

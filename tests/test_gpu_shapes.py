@@ -25,6 +25,7 @@ def test_forward_and_gradients_vs_oracle(C, K, H, B):
     from lgteun_amd import FusedAdam
     ms, pan, gt = (T(a) for a in dw.make_inputs(B, C, H // 4, H // 4, seed=100 + H + B, kind='smooth'))
     net = make_module(C, K)
+    net.faithful_eval = True            # the first forward really runs the K-1 dead-stage LGTs
     with torch.no_grad():
         y = net(ms.cuda(), pan.cuda()).cpu()
         net.mode = 'live'

@@ -39,9 +39,9 @@ with open(f'profiles/{prefix}_bench_bs32_pmc_hbm.csv', 'w', newline='') as fh:
                 'WRITE_bytes_per_launch', 'HBM_bytes_per_launch'])
     for r in rows:
         w.writerow([r[0], r[1], f'{r[2]:.1f}', int(r[3]), f'{r[4]:.1f}', int(r[5]), int(r[6])])
-fused = [r for r in rows if 'k_ffn_fused' in r[0] or 'k_ffn_strip' in r[0]]   # the fused FFN forward: strip kernel at e = 16, tile kernel at e = 32
+fused = [r for r in rows if any(n in r[0] for n in ('k_ffn_xs', 'k_ffn_x32', 'k_ffn_fused', 'k_ffn_strip'))]   # the fused FFN forward, all variants
 if fused:
     tot = sum(r[6] * r[1] for r in fused) / sum(r[1] for r in fused)
-    print(f'fused FFN forward (k_ffn_strip + k_ffn_fused), all variants averaged: {int(tot)} HBM bytes per launch  (bench.py TRAFFIC_BYTES["ffn"])')
+    print(f'fused FFN forward (k_ffn_xs + k_ffn_x32), all variants averaged: {int(tot)} HBM bytes per launch  (what bench.py reads as roofline.traffic)')
 for r in rows[:12]:
     print(f'{r[0][:70]:70s} n={r[1]:4d}  {r[6] / 1e6:9.1f} MB/launch')
