@@ -122,7 +122,7 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
     p->n_offsets = n_offsets;
     {   // read once here, never on the launch path
         const char* impl = getenv("LG_FFN_IMPL");
-        p->ffn_tile = !impl ? 0 : (!strcmp(impl, "strip") ? 1 : (!strcmp(impl, "tile") ? 2 : 0));
+        p->ffn_tile = !impl ? 0 : (!strcmp(impl, "strip") ? 1 : (!strcmp(impl, "tile") ? 2 : (!strcmp(impl, "xp") ? 3 : 0)));
     }
     p->off = (int64_t*)malloc(sizeof(int64_t) * n_offsets);
     memcpy(p->off, offsets, sizeof(int64_t) * n_offsets);
