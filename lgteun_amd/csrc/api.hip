@@ -219,7 +219,8 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     a2.n1g = g_next ? P + pl->blk(stage, next_blk, B_LN1G) : nullptr;
     a2.n1b = g_next ? P + pl->blk(stage, next_blk, B_LN1B) : nullptr;
     a2.B = B; a2.h = bb.h; a2.w = bb.w; a2.hbf = a1.hbf;
-    a1.h2 = (flags & LG_FLAG_SAVE) ? bb.h2 : nullptr;   // fused path: h2 only leaves the chip when the backward needs it
+    // fused path (e <= 32): h2 only leaves the chip when the backward needs it; e = 64 passes it through HBM between its two kernels
+    a1.h2 = ((flags & LG_FLAG_SAVE) || bb.e == 64) ? bb.h2 : nullptr;
     rc = launch_ffn_fused(bb.e, a1, a2, s);
     if (rc != LG_FFN_NOT_FUSED) return rc;
     a1.h2 = bb.h2;

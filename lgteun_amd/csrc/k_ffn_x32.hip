@@ -31,16 +31,6 @@ __device__ __forceinline__ float quad_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
     return v;
 }
-// fragment `f` of a pre-split weight (k_split_w layout: [fragment][piece][lane] 16-byte units)
-__device__ __forceinline__ WFrag32 ld_wfrag(const u32x4_t* __restrict__ base, int f) {
-    const int lane = threadIdx.x & 63;
-    WFrag32 w;
-    w.p[0] = __builtin_bit_cast(bf16x8_t, base[(f * 3 + 0) * 64 + lane]);
-    w.p[1] = __builtin_bit_cast(bf16x8_t, base[(f * 3 + 1) * 64 + lane]);
-    w.p[2] = __builtin_bit_cast(bf16x8_t, base[(f * 3 + 2) * 64 + lane]);
-    return w;
-}
-
 // W [rows][K] fp32 -> fragments (mb, kb) of 16 x 32, three bf16 pieces each, in the order a wave loads them
 __global__ __launch_bounds__(256) void k_split_w(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
                                                  u32x4_t* __restrict__ out, int e) {
@@ -377,6 +367,15 @@ size_t ffn_wsplit_bytes(int e) {
     return nf * 3 * 64 * 16;
 }
 
+// fragments in the order W1 (mb, kb), W2 (mb, kb), W3 (mb, kb); e a multiple of 32
+int launch_split_w(const float* w1, const float* w2, const float* w3, void* out, int e, hipStream_t s) {
+    const int n1 = 4 * e, kb1 = e / 32, kb2 = n1 / 32;
+    const int nfrag = (n1 / 16) * kb1 + (n1 / 16) * kb2 + (e / 16) * kb2;
+    k_split_w<<<(nfrag * 64 + 255) / 256, 256, 0, s>>>(w1, w2, w3, reinterpret_cast<u32x4_t*>(out), e);
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch_ffn_x32(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     ProfScope prof__(LG_K_FFN2, s);
     if (!a1.wsplit) { lg_set_error("ffn_x32: no weight-fragment scratch in the workspace"); return -3; }
@@ -387,9 +386,10 @@ int launch_ffn_x32(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
         if (e != hipSuccess) { lg_set_error("ffn_x32: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
-    const int nfrag = NF_W1 + NF_W2 + NF_W3;
-    k_split_w<<<(nfrag * 64 + 255) / 256, 256, 0, s>>>(a1.w1, a1.w2, a2.w3, reinterpret_cast<u32x4_t*>(a1.wsplit), E);
-    LG_CHECK_LAUNCH();
+    {
+        const int rc = launch_split_w(a1.w1, a1.w2, a2.w3, a1.wsplit, E, s);
+        if (rc) return rc;
+    }
     const int tiles_x = (a2.w + 15) / 16;
     // strip height: the tallest multiple of 8 rows that still yields >= 256 strips (one resident workgroup per CU), at least 16
     int SH = (a2.h + 7) / 8 * 8;

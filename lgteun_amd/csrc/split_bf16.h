@@ -103,3 +103,14 @@ __device__ __forceinline__ void mfma_split16(f32x4_t& acc, const WFrag16& w, s16
     acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.p[1], x1, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.p[0], x1, acc, 0, 0, 0);
 }
+
+// fragment `f` of a PRE-SPLIT weight (k_split_w layout, k_ffn_x32.hip: [fragment][piece][lane] 16-byte units): one coalesced 1 KB
+// read per piece
+__device__ __forceinline__ WFrag32 ld_wfrag(const u32x4_t* __restrict__ base, int f) {
+    const int lane = threadIdx.x & 63;
+    WFrag32 w;
+    w.p[0] = __builtin_bit_cast(bf16x8_t, base[(f * 3 + 0) * 64 + lane]);
+    w.p[1] = __builtin_bit_cast(bf16x8_t, base[(f * 3 + 1) * 64 + lane]);
+    w.p[2] = __builtin_bit_cast(bf16x8_t, base[(f * 3 + 2) * 64 + lane]);
+    return w;
+}
