@@ -71,11 +71,12 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
         s = (long)y * a.w + x;
         return b * hw + s;
     };
+    __syncthreads();   // pos_emb and the weight slices are staged; inside the loop every wave only touches its own K / V / Q / dO tiles
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int win = grp * NW + wave;
         const bool active = win < nwin;
         long p = 0;
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         if (active) {
             long b, s;
             p = pixel_of(win, b, s);
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                 }
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // per-wave tiles: no workgroup barrier needed
         if (active) {
             // ---------------- pass 1: lane = query i
             float q[D], dOi[D];
@@ -227,7 +229,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
             sSt[lane * 4 + 1] = inv;
             sSt[lane * 4 + 2] = Dv;
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // per-wave tiles: no workgroup barrier needed
         if (active) {
             // ---------------- pass 2: lane = key j
             float kj[D], vj[D], dkh[D], dvh[D];
