@@ -1192,8 +1192,8 @@ static int launch_ffn_fused_bf_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStre
 // returns LG_FFN_NOT_FUSED if the fused kernels do not cover this size (caller falls back to k_ffn1 + k_ffn2)
 int launch_ffn_fused(int e, const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     if (a1.hbf) {   // throughput mode: bf16 matrix cores for the three GEMMs
-        if (e == 16) return launch_ffn_fused_bf_t<16>(a1, a2, s);
-        if (e == 32) return launch_ffn_fused_bf_t<32>(a1, a2, s);
+        if (e == 16) return a1.tile16 == 0 ? launch_ffn_xs(a1, a2, s) : launch_ffn_fused_bf_t<16>(a1, a2, s);   // k_ffn_xs<., NP = 1>
+        if (e == 32) return (a1.tile16 == 0 && a1.wsplit) ? launch_ffn_x32(a1, a2, s) : launch_ffn_fused_bf_t<32>(a1, a2, s);   // k_ffn_x32<., NP = 1>
         return LG_FFN_NOT_FUSED;
     }
     // e = 16: the strip kernel on the bf16 matrix pipe in fp32-equivalent split arithmetic (k_ffn_x.hip); for A/B runs the plan's

@@ -55,7 +55,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 __device__ __forceinline__ bf16x8_t lds_x8(const uint16_t* p) { return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(p)); }
 __device__ __forceinline__ s16x4_t lds_x4(const uint16_t* p) { return __builtin_bit_cast(s16x4_t, *reinterpret_cast<const u32x2_t*>(p)); }
 
-template <bool SAVE>
+template <bool SAVE, int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn_xs(Ffn1Args a1, Ffn2Args a2, int tiles_x, int strips_y, int nstrips,
                                                                                        int SH) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -78,11 +78,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int c0 = wave * 16 + 4 * g;                 // first of the four h1 / h2 channels this lane holds after GEMM1 / GEMM2
     const float4 b1v = *reinterpret_cast<const float4*>(a1.b1 + c0);
     const float4 b2v = *reinterpret_cast<const float4*>(a1.b2 + c0);
-    const WFrag16 w1f = load_wfrag16(a1.w1 + (size_t)(wave * 16) * E, E, 0);
-    const WFrag32 w2f0 = load_wfrag32(a1.w2 + (size_t)(wave * 16) * N1, N1, 0);
-    const WFrag32 w2f1 = load_wfrag32(a1.w2 + (size_t)(wave * 16) * N1, N1, 1);
-    const WFrag32 w3f0 = load_wfrag32(a2.w3, N1, 0);
-    const WFrag32 w3f1 = load_wfrag32(a2.w3, N1, 1);
+    constexpr bool BF = (NP == 1);                    // plain-bf16 mode: saved activations are stored as bf16 too (hstore.h)
+    const WFrag16 w1f = NP == 3 ? load_wfrag16(a1.w1 + (size_t)(wave * 16) * E, E, 0) : load_wfrag16_rne(a1.w1 + (size_t)(wave * 16) * E, E, 0);
+    const WFrag32 w2f0 = NP == 3 ? load_wfrag32(a1.w2 + (size_t)(wave * 16) * N1, N1, 0) : load_wfrag32_rne(a1.w2 + (size_t)(wave * 16) * N1, N1, 0);
+    const WFrag32 w2f1 = NP == 3 ? load_wfrag32(a1.w2 + (size_t)(wave * 16) * N1, N1, 1) : load_wfrag32_rne(a1.w2 + (size_t)(wave * 16) * N1, N1, 1);
+    const WFrag32 w3f0 = NP == 3 ? load_wfrag32(a2.w3, N1, 0) : load_wfrag32_rne(a2.w3, N1, 0);
+    const WFrag32 w3f1 = NP == 3 ? load_wfrag32(a2.w3, N1, 1) : load_wfrag32_rne(a2.w3, N1, 1);
     // depthwise taps of the lane's four channels (phase P2: lane = (pixel slot lane / 16, channel quad q)): 36 + 4 contiguous
     // floats, re-read (L1 / L2 hits) at the top of every step instead of pinning 40 VGPRs through the GEMM phases
     const int q = lane % CQ;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         const float yv[4] = {(d0 * rstd * lng.x + lnb.x) * m_, (d1 * rstd * lng.y + lnb.y) * m_, (d2 * rstd * lng.z + lnb.z) * m_,
                              (d3 * rstd * lng.w + lnb.w) * m_};
         u32x2_t q1, q2, q3;
-        split3_x4(yv, q1, q2, q3);
+        split_x4<NP>(yv, q1, q2, q3);
         uint16_t* dst = XA + slot * XA_SLOT + lpx * E + 4 * lq;
         *reinterpret_cast<u32x2_t*>(dst) = q1;
         *reinterpret_cast<u32x2_t*>(dst + CH * E) = q2;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             for (int pb = 0; pb < 3; ++pb) {
                 acc[pb] = (f32x4_t){b1v.x, b1v.y, b1v.z, b1v.w};
                 const uint16_t* p = xa + pb * 16 * E;
-                mfma_split16(acc[pb], w1f, lds_x4(p), lds_x4(p + CH * E), lds_x4(p + 2 * CH * E));
+                mfma_np16<NP>(acc[pb], w1f, lds_x4(p), lds_x4(p + CH * E), lds_x4(p + 2 * CH * E));
             }
             // ---- GELU, split, -> A2 (8 bytes per piece and pixel)
 #pragma unroll
@@ -183,15 +184,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     gelu2_both_f((lg_v2f){acc[pb][2], acc[pb][3]}, a23, g23);
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                     if (inner[pb]) {
-                        HS<false>::st4(a1.a1s, prow[pb], make_float4(av[0], av[1], av[2], av[3]));
-                        HS<false>::st4(a1.g1s, prow[pb], make_float4(g01.x, g01.y, g23.x, g23.y));
+                        HS<BF>::st4(a1.a1s, prow[pb], make_float4(av[0], av[1], av[2], av[3]));
+                        HS<BF>::st4(a1.g1s, prow[pb], make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
                 } else {
                     const lg_v2f a01 = gelu2_f((lg_v2f){acc[pb][0], acc[pb][1]}), a23 = gelu2_f((lg_v2f){acc[pb][2], acc[pb][3]});
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 }
                 u32x2_t q1, q2, q3;
-                split3_x4(av, q1, q2, q3);
+                split_x4<NP>(av, q1, q2, q3);
                 uint16_t* dst = A2 + (pb * 16 + r) * LDP + c0;
                 *reinterpret_cast<u32x2_t*>(dst) = q1;
                 *reinterpret_cast<u32x2_t*>(dst + CH * LDP) = q2;
@@ -205,8 +206,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             for (int pb = 0; pb < 3; ++pb) {
                 acc[pb] = (f32x4_t){b2v.x, b2v.y, b2v.z, b2v.w};
                 const uint16_t* p = A2 + (pb * 16 + r) * LDP + 8 * g;
-                mfma_split32(acc[pb], w2f0, lds_x8(p), lds_x8(p + CH * LDP), lds_x8(p + 2 * CH * LDP));
-                mfma_split32(acc[pb], w2f1, lds_x8(p + 32), lds_x8(p + 32 + CH * LDP), lds_x8(p + 32 + 2 * CH * LDP));
+                mfma_np32<NP>(acc[pb], w2f0, lds_x8(p), lds_x8(p + CH * LDP), lds_x8(p + 2 * CH * LDP));
+                mfma_np32<NP>(acc[pb], w2f1, lds_x8(p + 32), lds_x8(p + 32 + CH * LDP), lds_x8(p + 32 + 2 * CH * LDP));
             }
             if (more) ln_store(slot ^ 1, nx, nin);
 #pragma unroll
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 const int m = c * CH + pb * 16 + r;
                 const float mk = sMask[slot][pb * 16 + r];
                 const float4 hh = make_float4(acc[pb][0] * mk, acc[pb][1] * mk, acc[pb][2] * mk, acc[pb][3] * mk);
-                if (SAVE && inner[pb]) HS<false>::st4(a1.h2, prow[pb], hh);
+                if (SAVE && inner[pb]) HS<BF>::st4(a1.h2, prow[pb], hh);
                 int rp = ring0 + m;
                 rp = rp >= RING * HX ? rp - RING * HX : rp;
                 if (m < npx) *reinterpret_cast<float4*>(ring + rp * LDR + c0) = hh;
@@ -301,15 +302,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     const int y = y0 + ty, x = x0 + tx;
                     if (y < Yend && x < w) {
                         const long o = ((b * h + y) * (long)w + x) * N1 + 4 * q;
-                        HS<false>::st4(a2.a3s, o, make_float4(av[0], av[1], av[2], av[3]));
-                        HS<false>::st4(a2.g3s, o, make_float4(g01.x, g01.y, g23.x, g23.y));
+                        HS<BF>::st4(a2.a3s, o, make_float4(av[0], av[1], av[2], av[3]));
+                        HS<BF>::st4(a2.g3s, o, make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
                 } else {
                     const lg_v2f a01 = gelu2_f((lg_v2f){acc.x, acc.y}), a23 = gelu2_f((lg_v2f){acc.z, acc.w});
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 }
                 u32x2_t q1, q2, q3;
-                split3_x4(av, q1, q2, q3);
+                split_x4<NP>(av, q1, q2, q3);
                 uint16_t* dst = G3 + tx * LDP + 4 * q;
                 *reinterpret_cast<u32x2_t*>(dst) = q1;
                 *reinterpret_cast<u32x2_t*>(dst + 16 * LDP) = q2;
@@ -323,8 +324,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             f32x4_t o = (f32x4_t){b3v.x, b3v.y, b3v.z, b3v.w};
             {
                 const uint16_t* p = G3 + r * LDP + 8 * g;
-                mfma_split32(o, w3f0, lds_x8(p), lds_x8(p + 16 * LDP), lds_x8(p + 2 * 16 * LDP));
-                mfma_split32(o, w3f1, lds_x8(p + 32), lds_x8(p + 32 + 16 * LDP), lds_x8(p + 32 + 2 * 16 * LDP));
+                mfma_np32<NP>(o, w3f0, lds_x8(p), lds_x8(p + 16 * LDP), lds_x8(p + 2 * 16 * LDP));
+                mfma_np32<NP>(o, w3f1, lds_x8(p + 32), lds_x8(p + 32 + 16 * LDP), lds_x8(p + 32 + 2 * 16 * LDP));
             }
             __builtin_amdgcn_wave_barrier();           // G3 is rewritten by the next tile row
             STAMP(17 + 3 * ch);
@@ -366,8 +367,10 @@ int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     ProfScope prof__(LG_K_FFN2, s);
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_xs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_xs<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn_xs: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
@@ -378,8 +381,12 @@ int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     const int strips_y = (a2.h + SH - 1) / SH;
     const int nstrips = a2.B * tiles_x * strips_y;
     const int grid = nstrips < 512 ? nstrips : 512;
-    if (a1.a1s != nullptr) k_ffn_xs<true><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
-    else k_ffn_xs<false><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    const bool save = a1.a1s != nullptr;
+    if (a1.hbf) {   // precision = 'bf16': plain bf16 operands, bf16 storage of the saved tensors
+        if (save) k_ffn_xs<true, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+        else k_ffn_xs<false, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    } else if (save) k_ffn_xs<true, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    else k_ffn_xs<false, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
     LG_CHECK_LAUNCH();
     return 0;
 }

@@ -33,7 +33,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 }
 // W [rows][K] fp32 -> fragments (mb, kb) of 16 x 32, three bf16 pieces each, in the order a wave loads them
 __global__ __launch_bounds__(256) void k_split_w(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
-                                                 u32x4_t* __restrict__ out, int e) {
+                                                 u32x4_t* __restrict__ out, int e, int np) {
     const int n1 = 4 * e, kb1 = e / 32, kb2 = n1 / 32;
     const int nf1 = (n1 / 16) * kb1, nf2 = (n1 / 16) * kb2, nf3 = (e / 16) * kb2;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -49,14 +49,19 @@ __global__ __launch_bounds__(256) void k_split_w(const float* __restrict__ w1, c
     const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
     const float a[4] = {lo.x, lo.y, lo.z, lo.w}, b[4] = {hi.x, hi.y, hi.z, hi.w};
     u32x2_t a1, a2, a3, b1, b2, b3;
-    split3_x4(a, a1, a2, a3);
-    split3_x4(b, b1, b2, b3);
+    if (np == 3) {
+        split3_x4(a, a1, a2, a3);
+        split3_x4(b, b1, b2, b3);
+    } else {   // plain-bf16 mode: piece 0 rounded to nearest, the others unused
+        split_x4<1>(a, a1, a2, a3);
+        split_x4<1>(b, b1, b2, b3);
+    }
     out[(f * 3 + 0) * 64 + lane] = (u32x4_t){a1.x, a1.y, b1.x, b1.y};
     out[(f * 3 + 1) * 64 + lane] = (u32x4_t){a2.x, a2.y, b2.x, b2.y};
     out[(f * 3 + 2) * 64 + lane] = (u32x4_t){a3.x, a3.y, b3.x, b3.y};
 }
 
-template <bool SAVE>
+template <bool SAVE, int NP>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ffn_x32(Ffn1Args a1, Ffn2Args a2, const u32x4_t* __restrict__ wsp, int tiles_x, int strips_y, int nstrips, int SH) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* ring = reinterpret_cast<float*>(smem_raw);                                   // [RING*HX][LDR]
@@ -74,6 +79,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         sLn2g[i] = a1.ln2g[i]; sLn2b[i] = a1.ln2b[i]; sB3[i] = a2.b3[i];
         sN1g[i] = a2.g ? a2.n1g[i] : 0.f; sN1b[i] = a2.g ? a2.n1b[i] : 0.f;
     }
+    constexpr bool BF = (NP == 1);                    // plain-bf16 mode: saved activations stored as bf16 (hstore.h)
     const int c0 = wave * 16 + 4 * g;                 // first of the four h1 / h2 channels this lane holds after GEMM1 / GEMM2
     const float4 b1v = *reinterpret_cast<const float4*>(a1.b1 + c0);
     const float4 b2v = *reinterpret_cast<const float4*>(a1.b2 + c0);
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float yv[4] = {(d0 * rstd * lng.x + lnb.x) * m_, (d1 * rstd * lng.y + lnb.y) * m_, (d2 * rstd * lng.z + lnb.z) * m_,
                              (d3 * rstd * lng.w + lnb.w) * m_};
         u32x2_t q1, q2, q3;
-        split3_x4(yv, q1, q2, q3);
+        split_x4<NP>(yv, q1, q2, q3);
         uint16_t* dst = XA + slot * XA_SLOT + lpx * E + 4 * lq;
         *reinterpret_cast<u32x2_t*>(dst) = q1;
         *reinterpret_cast<u32x2_t*>(dst + CH * E) = q2;
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int pb = 0; pb < 3; ++pb) {
                 acc[pb] = (f32x4_t){b1v.x, b1v.y, b1v.z, b1v.w};
                 const uint16_t* p = xa + pb * 16 * E;
-                mfma_split32(acc[pb], w1f, lds_x8(p), lds_x8(p + CH * E), lds_x8(p + 2 * CH * E));
+                mfma_np32<NP>(acc[pb], w1f, lds_x8(p), lds_x8(p + CH * E), lds_x8(p + 2 * CH * E));
             }
             // ---- GELU, split, -> A2: logical 16-byte chunk 2 w + g / 2 of the pixel's row, stored at chunk ^ (pixel & 15)
 #pragma unroll
@@ -172,15 +178,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     gelu2_both_f((lg_v2f){acc[pb][2], acc[pb][3]}, a23, g23);
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                     if (inner[pb]) {
-                        HS<false>::st4(a1.a1s, prow[pb], make_float4(av[0], av[1], av[2], av[3]));
-                        HS<false>::st4(a1.g1s, prow[pb], make_float4(g01.x, g01.y, g23.x, g23.y));
+                        HS<BF>::st4(a1.a1s, prow[pb], make_float4(av[0], av[1], av[2], av[3]));
+                        HS<BF>::st4(a1.g1s, prow[pb], make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
                 } else {
                     const lg_v2f a01 = gelu2_f((lg_v2f){acc[pb][0], acc[pb][1]}), a23 = gelu2_f((lg_v2f){acc[pb][2], acc[pb][3]});
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 }
                 u32x2_t q1, q2, q3;
-                split3_x4(av, q1, q2, q3);
+                split_x4<NP>(av, q1, q2, q3);
                 const int px = pb * 16 + r;
                 uint16_t* dst = A2 + px * N1 + (((2 * wave + (g >> 1)) ^ (px & 15)) << 3) + 4 * (g & 1);
                 *reinterpret_cast<u32x2_t*>(dst) = q1;
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
                     const uint16_t* p = row + (((4 * kb + g) ^ (px & 15)) << 3);
-                    mfma_split32(acc[pb], w2f[kb], lds_x8(p), lds_x8(p + CH * N1), lds_x8(p + 2 * CH * N1));
+                    mfma_np32<NP>(acc[pb], w2f[kb], lds_x8(p), lds_x8(p + CH * N1), lds_x8(p + 2 * CH * N1));
                 }
             }
             if (more) ln_store(slot ^ 1, nx, nin);
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int m = c * CH + pb * 16 + r;
                 const float mk = sMask[slot][pb * 16 + r];
                 const float4 hh = make_float4(acc[pb][0] * mk, acc[pb][1] * mk, acc[pb][2] * mk, acc[pb][3] * mk);
-                if (SAVE && inner[pb]) HS<false>::st4(a1.h2, prow[pb], hh);
+                if (SAVE && inner[pb]) HS<BF>::st4(a1.h2, prow[pb], hh);
                 int rp = ring0 + m;
                 rp = rp >= RING * HX ? rp - RING * HX : rp;
                 if (m < npx) *reinterpret_cast<float4*>(ring + rp * LDR + c0) = hh;
@@ -292,15 +298,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int y = y0 + ty, x = x0 + tx;
                     if (y < Yend && x < w) {
                         const long off = ((b * h + y) * (long)w + x) * N1 + 4 * qc;
-                        HS<false>::st4(a2.a3s, off, make_float4(av[0], av[1], av[2], av[3]));
-                        HS<false>::st4(a2.g3s, off, make_float4(g01.x, g01.y, g23.x, g23.y));
+                        HS<BF>::st4(a2.a3s, off, make_float4(av[0], av[1], av[2], av[3]));
+                        HS<BF>::st4(a2.g3s, off, make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
                 } else {
                     const lg_v2f a01 = gelu2_f((lg_v2f){acc.x, acc.y}), a23 = gelu2_f((lg_v2f){acc.z, acc.w});
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 }
                 u32x2_t q1, q2, q3;
-                split3_x4(av, q1, q2, q3);
+                split_x4<NP>(av, q1, q2, q3);
                 // row of 64 halves = 8 chunks of 16 bytes: logical chunk q16 / 2, stored at chunk ^ (pixel & 7)
                 uint16_t* dst = G3 + tx * 64 + ((((q16 >> 1)) ^ (tx & 7)) << 3) + 4 * (q16 & 1);
                 *reinterpret_cast<u32x2_t*>(dst) = q1;
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
                     const WFrag32 wf = ld_wfrag(w3p, mb * 4 + 2 * kh + kb);
-                    mfma_split32(o[mb], wf, x1, x2, x3);
+                    mfma_np32<NP>(o[mb], wf, x1, x2, x3);
                 }
             }
             __builtin_amdgcn_wave_barrier();           // G3 is rewritten by the next half
@@ -368,10 +374,10 @@ size_t ffn_wsplit_bytes(int e) {
 }
 
 // fragments in the order W1 (mb, kb), W2 (mb, kb), W3 (mb, kb); e a multiple of 32
-int launch_split_w(const float* w1, const float* w2, const float* w3, void* out, int e, hipStream_t s) {
+int launch_split_w(const float* w1, const float* w2, const float* w3, void* out, int e, int np, hipStream_t s) {
     const int n1 = 4 * e, kb1 = e / 32, kb2 = n1 / 32;
     const int nfrag = (n1 / 16) * kb1 + (n1 / 16) * kb2 + (e / 16) * kb2;
-    k_split_w<<<(nfrag * 64 + 255) / 256, 256, 0, s>>>(w1, w2, w3, reinterpret_cast<u32x4_t*>(out), e);
+    k_split_w<<<(nfrag * 64 + 255) / 256, 256, 0, s>>>(w1, w2, w3, reinterpret_cast<u32x4_t*>(out), e, np);
     LG_CHECK_LAUNCH();
     return 0;
 }
@@ -381,13 +387,15 @@ int launch_ffn_x32(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     if (!a1.wsplit) { lg_set_error("ffn_x32: no weight-fragment scratch in the workspace"); return -3; }
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_x32<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_x32<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) { lg_set_error("ffn_x32: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
     {
-        const int rc = launch_split_w(a1.w1, a1.w2, a2.w3, a1.wsplit, E, s);
+        const int rc = launch_split_w(a1.w1, a1.w2, a2.w3, a1.wsplit, E, a1.hbf ? 1 : 3, s);
         if (rc) return rc;
     }
     const int tiles_x = (a2.w + 15) / 16;
@@ -398,8 +406,12 @@ int launch_ffn_x32(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     const int nstrips = a2.B * tiles_x * strips_y;
     const int grid = nstrips < 256 ? nstrips : 256;
     const u32x4_t* wsp = reinterpret_cast<const u32x4_t*>(a1.wsplit);
-    if (a1.a1s != nullptr) k_ffn_x32<true><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
-    else k_ffn_x32<false><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
+    const bool save = a1.a1s != nullptr;
+    if (a1.hbf) {   // precision = 'bf16'
+        if (save) k_ffn_x32<true, 1><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
+        else k_ffn_x32<false, 1><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
+    } else if (save) k_ffn_x32<true, 3><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
+    else k_ffn_x32<false, 3><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
     LG_CHECK_LAUNCH();
     return 0;
 }

@@ -374,7 +374,7 @@ int launch_ffn_x64(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
         attr_once.done();
     }
     {
-        const int rc = launch_split_w(a1.w1, a1.w2, a2.w3, a1.wsplit, E, s);
+        const int rc = launch_split_w(a1.w1, a1.w2, a2.w3, a1.wsplit, E, 3, s);
         if (rc) return rc;
     }
     const u32x4_t* wsp = reinterpret_cast<const u32x4_t*>(a1.wsplit);

@@ -104,6 +104,50 @@ __device__ __forceinline__ void mfma_split16(f32x4_t& acc, const WFrag16& w, s16
     acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.p[0], x1, acc, 0, 0, 0);
 }
 
+// ---- NP = number of pieces: 3 = the fp32-equivalent arithmetic above; 1 = plain bf16 operands (round-to-nearest), the opt-in
+// `precision='bf16'` throughput mode: one MFMA per block instead of six, one conversion per value pair instead of 5.5 instructions.
+template <int NP>
+__device__ __forceinline__ void split_x4(const float (&v)[4], u32x2_t& q1, u32x2_t& q2, u32x2_t& q3) {
+    if (NP == 3) {
+        split3_x4(v, q1, q2, q3);
+    } else {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const bf16x2_t lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};      // v_cvt_pk_bf16_f32 (RNE)
+        q1 = (u32x2_t){__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
+        q2 = q1; q3 = q1;   // unused
+    }
+}
+template <int NP>
+__device__ __forceinline__ void mfma_np32(f32x4_t& acc, const WFrag32& w, bf16x8_t x1, bf16x8_t x2, bf16x8_t x3) {
+    if (NP == 3) mfma_split32(acc, w, x1, x2, x3);
+    else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[0], x1, acc, 0, 0, 0);
+}
+template <int NP>
+__device__ __forceinline__ void mfma_np16(f32x4_t& acc, const WFrag16& w, s16x4_t x1, s16x4_t x2, s16x4_t x3) {
+    if (NP == 3) mfma_split16(acc, w, x1, x2, x3);
+    else acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.p[0], x1, acc, 0, 0, 0);
+}
+// weight fragments for NP = 1: piece 0 rounded to nearest (pieces 1, 2 unused)
+__device__ __forceinline__ WFrag32 load_wfrag32_rne(const float* __restrict__ W, int K, int kb) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const float4 lo = *reinterpret_cast<const float4*>(W + (size_t)r * K + kb * 32 + 8 * g);
+    const float4 hi = *reinterpret_cast<const float4*>(W + (size_t)r * K + kb * 32 + 8 * g + 4);
+    WFrag32 f;
+    f.p[0] = (bf16x8_t){(__bf16)lo.x, (__bf16)lo.y, (__bf16)lo.z, (__bf16)lo.w, (__bf16)hi.x, (__bf16)hi.y, (__bf16)hi.z, (__bf16)hi.w};
+    f.p[1] = f.p[0]; f.p[2] = f.p[0];
+    return f;
+}
+__device__ __forceinline__ WFrag16 load_wfrag16_rne(const float* __restrict__ W, int K, int k0) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const float4 v = *reinterpret_cast<const float4*>(W + (size_t)r * K + k0 + 4 * g);
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    const bf16x4_t h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    WFrag16 f;
+    f.p[0] = __builtin_bit_cast(s16x4_t, h);
+    f.p[1] = f.p[0]; f.p[2] = f.p[0];
+    return f;
+}
+
 // fragment `f` of a PRE-SPLIT weight (k_split_w layout, k_ffn_x32.hip: [fragment][piece][lane] 16-byte units): one coalesced 1 KB
 // read per piece
 __device__ __forceinline__ WFrag32 ld_wfrag(const u32x4_t* __restrict__ base, int f) {
