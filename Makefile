@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := lgteun_amd/csrc
-SRCS  := $(CSRC)/api.hip $(CSRC)/k_pixel.hip $(CSRC)/k_fft.hip $(CSRC)/k_attn.hip $(CSRC)/k_ffn.hip $(CSRC)/k_ffn_x.hip $(CSRC)/k_ffn_x32.hip $(CSRC)/k_ffn_xp.hip $(CSRC)/k_ffn_x64.hip $(CSRC)/k_bwd.hip $(CSRC)/k_bwd_pixel.hip $(CSRC)/k_wgrad.hip $(CSRC)/k_ffn_bwd.hip $(CSRC)/k_attn_bwd.hip
+SRCS  := $(CSRC)/api.hip $(CSRC)/k_pixel.hip $(CSRC)/k_fft.hip $(CSRC)/k_attn.hip $(CSRC)/k_ffn.hip $(CSRC)/k_ffn_x.hip $(CSRC)/k_ffn_x32.hip $(CSRC)/k_ffn_xp.hip $(CSRC)/k_ffn_x64.hip $(CSRC)/k_bwd.hip $(CSRC)/k_bwd_pixel.hip $(CSRC)/k_wgrad.hip $(CSRC)/k_ffn_bwd.hip $(CSRC)/k_ffn1_bwd_x32.hip $(CSRC)/k_attn_bwd.hip
 OBJS  := $(SRCS:.hip=.o)
 LIB   := lgteun_amd/_lgteun_hip.so
 # -fno-slp-vectorize: the SLP vectoriser turns scalar fp32 chains into v_pk_mul_f32 / v_pk_add_f32 pairs; packed fp32 issues at

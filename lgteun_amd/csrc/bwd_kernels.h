@@ -175,10 +175,15 @@ struct Ffn1BwdArgs {
     float *w1slab, *d_w1, *d_b1;
     long P;
     int hbf;           // hidden storage: 0 fp32, 1 bf16
+    // e = 32: the split-bf16 kernel k_ffn1_bwd_x32 runs when both are set (w1 = the forward W1 [4e][e], wsplit = ffn_wsplit_bytes(32)
+    // bytes of scratch for the pre-split W2^T / W1^T fragments); null -> the f32-MFMA kernel k_ffn1_bwd<32>
+    const float* w1;
+    void* wsplit;
 };
 #define FFN1_BWD_WGS 512   // persistent grid cap of k_ffn1_bwd
 inline bool ffn1_bwd_fuses_w1(int e) { return e <= 32; }
 int launch_ffn1_bwd(int e, const Ffn1BwdArgs& a, hipStream_t s);
+int launch_ffn1_bwd_x32(const Ffn1BwdArgs& a, const float* w1, void* wsplit, hipStream_t s);   // k_ffn1_bwd_x32.hip
 int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[cols][rows]
 int launch_transpose3(const float* const* src, float* const* dst, const int* rows, const int* cols, int njobs, hipStream_t s);
 

@@ -41,9 +41,11 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
         x = wx * 8 + (lane & 7);
         return (b * a.h + y) * (long)a.w + x;
     };
-    // software prefetch: the x row of the NEXT quad's window is requested while the current window is processed
-    float4 xpre[E / 4];
-    {
+    // software prefetch: the x row of the NEXT quad's window is requested while the current window is processed.  Only where the
+    // registers allow it: at HC = 32 the prefetched row, the residual row and o2 (160 registers) pushed the kernel into AGPR spills.
+    constexpr bool PRE = HC <= 16;
+    float4 xpre[PRE ? E / 4 : 1];
+    if (PRE) {
         const int win0 = blockIdx.x * 4 + wave;
         if (blockIdx.x < nquads && win0 < nwin) {
             long b0; int y0, x0;
@@ -62,9 +64,17 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
         if (active) {
             p = pixel_of(win, b, y, x);
             float xv[E];
+            if (PRE) {
 #pragma unroll
-            for (int k = 0; k < E / 4; ++k) { xv[4 * k] = xpre[k].x; xv[4 * k + 1] = xpre[k].y; xv[4 * k + 2] = xpre[k].z; xv[4 * k + 3] = xpre[k].w; }
-            {
+                for (int k = 0; k < E / 4; ++k) { xv[4 * k] = xpre[k].x; xv[4 * k + 1] = xpre[k].y; xv[4 * k + 2] = xpre[k].z; xv[4 * k + 3] = xpre[k].w; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < E / 4; ++k) {
+                    const float4 t = reinterpret_cast<const float4*>(a.x + p * E)[k];
+                    xv[4 * k] = t.x; xv[4 * k + 1] = t.y; xv[4 * k + 2] = t.z; xv[4 * k + 3] = t.w;
+                }
+            }
+            if (PRE) {
                 const int wnext = (quad + (int)gridDim.x) * 4 + wave;
                 if (quad + (int)gridDim.x < nquads && wnext < nwin) {
                     long bn; int yn, xn;
@@ -99,11 +109,13 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
             float o2[HC];
             const long hw = (long)a.h * a.w;
             const long s = (long)y * a.w + x;
+            float4 xres[PRE ? E / 4 : 1];
+            if (PRE) {
 #pragma unroll
-            for (int c = 0; c < HC; ++c) o2[c] = a.o2[(b * HC + c) * hw + s];
-            float4 xres[E / 4];
+                for (int c = 0; c < HC; ++c) o2[c] = a.o2[(b * HC + c) * hw + s];
 #pragma unroll
-            for (int k = 0; k < E / 4; ++k) xres[k] = reinterpret_cast<const float4*>(a.x + p * E)[k];
+                for (int k = 0; k < E / 4; ++k) xres[k] = reinterpret_cast<const float4*>(a.x + p * E)[k];
+            }
             float o1[HC];
 #pragma unroll
             for (int hd = 0; hd < 2; ++hd) {
@@ -142,6 +154,10 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
 #pragma unroll
                 for (int c = 0; c < D; ++c) o1[hd * D + c] = acc[c] * inv;
             }
+            if (!PRE) {
+#pragma unroll
+                for (int c = 0; c < HC; ++c) o2[c] = a.o2[(b * HC + c) * hw + s];
+            }
             // proj (E x E), dropout, residual -- in chunks of 4 outputs
             float4* yo = reinterpret_cast<float4*>(a.y + p * E);
 #pragma unroll
@@ -159,7 +175,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
                     if (a.dropout) v *= dropout_scale(a.seed, (uint64_t)(p * E + n));
                     o[u] = v;
                 }
-                const float4 xr = xres[n4];
+                const float4 xr = PRE ? xres[n4] : reinterpret_cast<const float4*>(a.x + p * E)[n4];
                 yo[n4] = make_float4(xr.x + o[0], xr.y + o[1], xr.z + o[2], xr.w + o[3]);
             }
         }
@@ -199,7 +215,12 @@ static int launch_attn_t(const AttnArgs& a, hipStream_t s) {
         if (e != hipSuccess) { lg_set_error("attn: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
-    int grid = nquads < 768 ? nquads : 768;   // 3 resident workgroups per CU; each walks its window quads with pos_emb^T in LDS
+    // persistent grid = the workgroups that are resident at once (LDS: 50 KB / 72 KB / 125 KB per workgroup -> 3 / 2 / 1 per CU;
+    // the VGPR counts allow the same), each walking its window quads with pos_emb^T in LDS.  A larger grid runs in rounds and the
+    // last round is ragged (HC = 16 at C = 8, 2048 quads: 768 workgroups on 512 slots took 6 quad-times instead of 4).
+    constexpr int cap = 256 * (HC <= 8 ? 3 : (HC <= 16 ? 2 : 1));
+    const int rounds = (nquads + cap - 1) / cap;
+    int grid = nquads < cap ? nquads : (nquads + rounds - 1) / rounds;
     k_attn<HC><<<grid, 256, lds, s>>>(a, nwin, nquads);
     LG_CHECK_LAUNCH();
     return 0;

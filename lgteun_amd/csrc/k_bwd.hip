@@ -10,7 +10,7 @@ struct BwdBufs {
     float *dzA, *dzB, *gu3, *gs1, *gu1, *gr, *gd3, *gt1, *gd1;
     float *dx[3];
     float *doutp, *de, *tp, *dh2, *dh1, *y2, *do2, *dg, *dym, *cat, *y1, *dqkv, *dpos_slab;
-    float *w3t, *w2t, *w1t, *dt, *dskip, *v, *du, *fft_scratch;
+    float *w3t, *w2t, *w1t, *wsp, *dt, *dskip, *v, *du, *fft_scratch;
     float* slab_arena;    // scratch of the deferred parameter-gradient reductions (ReduceQueue, bwd_kernels.h)
     size_t slab_cap;      // floats
     ReduceQueue rq;
@@ -32,6 +32,7 @@ static void carve_bwd(const lg_plan* plan, int B, void* base, BwdBufs& bb) {
     bb.dqkv = cv.take(P0 * 2 * E);
     bb.dpos_slab = cv.take((size_t)512 * 2 * 64 * 64);
     bb.w3t = cv.take(8 * E * 2 * E); bb.w2t = cv.take(8 * E * 8 * E); bb.w1t = cv.take(8 * E * 2 * E);
+    bb.wsp = cv.take(ffn_wsplit_bytes(32) / sizeof(float));   // pre-split W2^T / W1^T fragments of k_ffn1_bwd_x32 (e = 32 blocks)
     size_t sl = wgrad_slab_floats((int)(8 * E), (int)(8 * E), (long)P0);
     size_t sl2 = wgrad_slab_floats(64, 64, (long)P0);
     size_t sl3 = ffn_dw_bwd_slab_floats((int)E, B, c.H, c.W);
@@ -105,6 +106,8 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
     f1.d_ln2g = G + pl->blk(st, j, B_LN2G); f1.d_ln2b = G + pl->blk(st, j, B_LN2B); f1.part = bb.rq.take((size_t)PIXEL_PART_WGS * 2 * e);
     if (!f1.part) return -3;
     f1.P = Pn; f1.hbf = hbf;
+    f1.w1 = nullptr; f1.wsplit = nullptr;
+    if (e == 32 && pl->ffn_tile == 0) { f1.w1 = P + pl->blk(st, j, B_W1); f1.wsplit = bb.wsp; }   // LG_FFN_IMPL=strip|tile: the f32-MFMA kernel (A/B)
     f1.w1slab = nullptr; f1.d_w1 = nullptr; f1.d_b1 = nullptr;
     if (ffn1_bwd_fuses_w1(e)) {   // dW1 / db1 come out of k_ffn1_bwd itself
         f1.w1slab = bb.rq.take((size_t)FFN1_BWD_WGS * ((size_t)n1 * e + n1));

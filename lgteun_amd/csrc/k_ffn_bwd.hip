@@ -601,7 +601,7 @@ static int launch_ffn1_bwd_t(const Ffn1BwdArgs& a, hipStream_t s) {
 }
 int launch_ffn1_bwd(int e, const Ffn1BwdArgs& a, hipStream_t s) {
     if (e == 16) return launch_ffn1_bwd_t<16, 1>(a, s);
-    if (e == 32) return launch_ffn1_bwd_t<32, 2>(a, s);
+    if (e == 32) return (a.w1 && a.wsplit) ? launch_ffn1_bwd_x32(a, a.w1, a.wsplit, s) : launch_ffn1_bwd_t<32, 2>(a, s);
     if (e == 64) return launch_ffn1_bwd_t<64, 1>(a, s);
     lg_set_error("ffn1_bwd: e=%d unsupported", e);
     return -1;
