@@ -45,18 +45,19 @@ E, P0 = 4 * C, H * H
 
 # kernels that make up the "ffn" launch slot (lg_kernel_id LG_K_FFN2): the fused feed_forward half-block, all variants
 FFN_KERNELS = ('k_ffn_xs', 'k_ffn_x32', 'k_ffn_strip', 'k_ffn_fused')
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r02_bench_bs32_pmc_hbm.csv')
+PMC_SUMMARIES = {c: os.path.join(ROOT, 'profiles', f'r02_bench_{n}_pmc_hbm.csv') for c, n in (('c2', 'bs32'), ('c3', 'c3'), ('c5', 'c5'))}
 
 
-def traffic_from_profile(kernel):
+def traffic_from_profile(kernel, config='c2'):
     """HBM bytes per launch of the roofline kernel from the committed PMC summary (FETCH_SIZE x2 corrected + WRITE_SIZE, separate
     --pmc passes of `python bench.py`; tools/summarize_profiles.py), launch-weighted over the kernel's variants.  None if absent."""
     import csv
     names = {'ffn': FFN_KERNELS, 'attn': ('k_attn<',), 'fft': ('k_fftmix<',), 'attn_bwd': ('k_attn_bwd_core',), 'fft_bwd': ('k_fftmix_bwd',)}.get(kernel)
-    if not names or not os.path.exists(PMC_SUMMARY):
+    path = PMC_SUMMARIES.get(config)
+    if not names or not path or not os.path.exists(path):
         return None
     num = den = 0.0
-    for r in csv.DictReader(open(PMC_SUMMARY)):
+    for r in csv.DictReader(open(path)):
         if any(n in r['Kernel_Name'] for n in names):
             num += float(r['HBM_bytes_per_launch']) * int(r['launches'])
             den += int(r['launches'])
@@ -295,8 +296,9 @@ def main():
             roof = dict(bound='mfma', achieved=round(ach_tf, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=round(f_mfma, 4))
         else:
             roof = dict(bound='hbm', achieved=round(ach_gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(f_hbm, 4))
-        roof.update(traffic=traffic_from_profile(args.prof_kernel) if args.config == 'c2' else None,
-                    traffic_source=os.path.relpath(PMC_SUMMARY, ROOT) if args.config == 'c2' and os.path.exists(PMC_SUMMARY) else None,
+        pmc_path = PMC_SUMMARIES.get(args.config)
+        roof.update(traffic=traffic_from_profile(args.prof_kernel, args.config),
+                    traffic_source=os.path.relpath(pmc_path, ROOT) if pmc_path and os.path.exists(pmc_path) else None,
                     kernel=L.lg_kernel_name(kid).decode(), launches=int(n_l.value),
                     avg_launch_us=round(avg_us, 2), algorithmic_bytes_per_launch=int(byts), algorithmic_flops_per_launch=int(flops),
                     hbm_frac=round(f_hbm, 4), mfma_frac_fp32=round(f_mfma, 4), peak_hbm_GBs=PEAK_HBM_GBS,
