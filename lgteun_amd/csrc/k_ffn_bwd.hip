@@ -44,14 +44,17 @@ int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream
 #define DW_CG 32   // channels per workgroup (depthwise work is per channel); 16 (3 workgroups per CU) measured no faster
 #define DW_TPW 8   // tiles walked by one workgroup (weight-gradient partials stay in registers across them)
 template <int E, bool BF, int CG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2 : 1))) void k_ffn_dw_bwd(FfnDwBwdArgs a, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((E == 16 || (E == 32 && CG == 32)) ? 2 : 1))) void k_ffn_dw_bwd(FfnDwBwdArgs a, int tiles_x, int tiles_y) {
     constexpr int N1 = 4 * E, TY = 8, TX = 16, HX = TX + 2, HY = TY + 2, NH = HX * HY, MH = 192, CQ = CG / 4, NTG = CG / 16;
     constexpr int LDY = E + 4, LDG = CG + 4;
     extern __shared__ float smem[];
     float* bufY = smem;                  // [MH][LDY] dy on the halo tile
     float* bufG = bufY + MH * LDY;       // [NH][LDG] dh3 on the halo tile, this workgroup's 32 channels (0 outside the image)
     float* bufH = bufG + NH * LDG;       // [NH][LDG] h2 on the halo tile
-    float* red = bufH + NH * LDG;        // [4][CQ][40]
+    // [4][CQ][40] partial rows of the final reduction: behind the tiles, or (e = 32 in 32-channel groups: two workgroups per CU need
+    // <= 80 KB each) on top of bufY, which is dead after the tile loop
+    constexpr bool RED_ALIAS = (E == 32 && CG == 32);
+    float* red = RED_ALIAS ? bufY : bufH + NH * LDG;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int c0 = blockIdx.y * CG;
     const int h = a.h, w = a.w;
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
     }
     }   // tiles of this workgroup
     const int tile_id = blockIdx.x;
+    if (RED_ALIAS) __syncthreads();   // the last tile's GEMM has read bufY
     // ---- P3: partials -> one slab row per workgroup (fixed-order reduction later; no float atomics)
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -227,9 +231,9 @@ static int launch_ffn_dw_bwd_t(const FfnDwBwdArgs& a, hipStream_t s) {
     const long nwg = ((long)a.B * tiles_x * tiles_y + DW_TPW - 1) / DW_TPW;
     // channel group per workgroup: 32 at e = 16 (two groups); 64 from e = 32 up, where every extra group re-reads the dy halo tile
     // and repeats the dy x W3 GEMM rows
-    constexpr int CG = (E >= 32 ? 64 : DW_CG);
+    constexpr int CG = (E >= 64 ? 64 : DW_CG);
     dim3 grid((unsigned)nwg, 4 * E / CG);
-    const size_t lds = (size_t)(192 * (E + 4) + 2 * 180 * (CG + 4) + 4 * (CG / 4) * 40) * sizeof(float);
+    const size_t lds = (size_t)(192 * (E + 4) + 2 * 180 * (CG + 4) + ((E == 32 && CG == 32) ? 0 : 4 * (CG / 4) * 40)) * sizeof(float);
     static DeviceOnce attr_once;
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, false, CG>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
