@@ -123,6 +123,8 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
     {   // read once here, never on the launch path
         const char* impl = getenv("LG_FFN_IMPL");
         p->ffn_tile = !impl ? 0 : (!strcmp(impl, "strip") ? 1 : (!strcmp(impl, "tile") ? 2 : (!strcmp(impl, "xp") ? 3 : 0)));
+        const char* sv = getenv("LG_FFN_SAVE");
+        p->save5 = (sv && !strcmp(sv, "5")) ? 1 : 0;
     }
     p->off = (int64_t*)malloc(sizeof(int64_t) * n_offsets);
     memcpy(p->off, offsets, sizeof(int64_t) * n_offsets);
@@ -203,7 +205,8 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
                          int B, int flags, hipStream_t s, float* wsplit) {
     int rc;
     Ffn1Args a1;
-    a1.x = bb.xmid; a1.a1s = (flags & LG_FLAG_SAVE) ? bb.a1 : nullptr; a1.g1s = (flags & LG_FLAG_SAVE) ? bb.g1 : nullptr; a1.h2 = bb.h2;
+    const bool pre = pl->ffn_saves_preact(bb.e);   // h1 / h3 go to the a1 / a3 slots, nothing to g1 / g3
+    a1.x = bb.xmid; a1.a1s = (flags & LG_FLAG_SAVE) ? bb.a1 : nullptr; a1.g1s = ((flags & LG_FLAG_SAVE) && !pre) ? bb.g1 : nullptr; a1.h2 = bb.h2;
     a1.ln2g = P + pl->blk(stage, j, B_LN2G); a1.ln2b = P + pl->blk(stage, j, B_LN2B);
     a1.w1 = P + pl->blk(stage, j, B_W1); a1.b1 = P + pl->blk(stage, j, B_B1);
     a1.w2 = P + pl->blk(stage, j, B_W2); a1.b2 = P + pl->blk(stage, j, B_B2);
@@ -212,7 +215,7 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     a1.tile16 = pl->ffn_tile;
     a1.wsplit = wsplit;
     Ffn2Args a2;
-    a2.h2 = bb.h2; a2.x = bb.xmid; a2.a3s = (flags & LG_FLAG_SAVE) ? bb.a3 : nullptr; a2.g3s = (flags & LG_FLAG_SAVE) ? bb.g3 : nullptr; a2.y = bb.xout;
+    a2.h2 = bb.h2; a2.x = bb.xmid; a2.a3s = (flags & LG_FLAG_SAVE) ? bb.a3 : nullptr; a2.g3s = ((flags & LG_FLAG_SAVE) && !pre) ? bb.g3 : nullptr; a2.y = bb.xout;
     a2.g = g_next;
     a2.dww = P + pl->blk(stage, j, B_DWW); a2.dwb = P + pl->blk(stage, j, B_DWB);
     a2.w3 = P + pl->blk(stage, j, B_W3); a2.b3 = P + pl->blk(stage, j, B_B3);

@@ -13,6 +13,7 @@ struct WgradArgs {
     int N, K;              // multiples of 16 (padded)
     int n_valid, k_valid;  // rows / cols of dW that exist
     int ybf, xbf;          // operand storage: 0 fp32, 1 bf16 (hstore.h)
+    int xgelu;             // 1: the conv input is gelu(X) of the stored pre-activation X (fp32 storage, 64-wide K blocks)
 };
 size_t wgrad_slab_floats(int N, int K, long P);
 // Parameter-gradient partial sums: every workgroup writes its partial to its own row of a scratch slab and a second tiny
@@ -151,6 +152,7 @@ struct FfnDwBwdArgs {
     const void* h2;    // [B,h,w,4e] saved              (hidden storage)
     void* dh2;         // [B,h,w,4e] out: dw3x3^T ((dy W3) * g3)   (hidden storage)
     int hbf;           // hidden storage: 0 fp32, 1 bf16
+    int pre;           // 1: g3 holds the PRE-ACTIVATION h3 (forward saved h1 / h2 / h3 only); gelu'(h3) is evaluated in the kernel
     const float *w3t;  // [4e][e] transposed W3
     const float* dww;  // [4e,1,3,3]
     float *slab_w, *slab_b;  // [tiles][4e*9], [tiles][4e] partials
@@ -175,6 +177,7 @@ struct Ffn1BwdArgs {
     float *w1slab, *d_w1, *d_b1;
     long P;
     int hbf;           // hidden storage: 0 fp32, 1 bf16
+    int pre;           // 1: g1 holds the PRE-ACTIVATION h1; gelu'(h1) is evaluated in the kernel
     // e = 32: the split-bf16 kernel k_ffn1_bwd_x32 runs when both are set (w1 = the forward W1 [4e][e], wsplit = ffn_wsplit_bytes(32)
     // bytes of scratch for the pre-split W2^T / W1^T fragments); null -> the f32-MFMA kernel k_ffn1_bwd<32>
     const float* w1;

@@ -69,12 +69,12 @@ struct ReduceQueueScope {
 };
 
 static int wgrad(const void* Y, int ldy, const void* X, int ldx, float* dW, int ldw, float* db, long P, int N, int K, int nv, int kv,
-                 int ybf, int xbf, BwdBufs& bb, hipStream_t s) {
+                 int ybf, int xbf, BwdBufs& bb, hipStream_t s, int xgelu = 0) {
     float* slab = bb.rq.take(wgrad_slab_floats(N, K, P));
     if (!slab) return -3;
     WgradArgs a;
     a.Y = Y; a.X = X; a.dW = dW; a.db = db; a.P = P; a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.N = N; a.K = K;
-    a.n_valid = nv; a.k_valid = kv; a.ybf = ybf; a.xbf = xbf;
+    a.n_valid = nv; a.k_valid = kv; a.ybf = ybf; a.xbf = xbf; a.xgelu = xgelu;
     return launch_wgrad(a, slab, s);
 }
 
@@ -83,6 +83,7 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
                         float* tmp, int B, hipStream_t s) {
     const int e = fb.e, n1 = 4 * e;
     const int hbf = pl->cfg.precision == 1 ? 1 : 0;   // bf16 storage of the hidden / saved FFN tensors
+    const int pre = pl->ffn_saves_preact(e) ? 1 : 0;  // fb.a1 / fb.a3 hold h1 / h3 (fb.g1 / fb.g3 unused): GELU re-evaluated where needed
     const long Pn = (long)B * fb.h * fb.w;
     {
         const float* tsrc[3] = {P + pl->blk(st, j, B_W3), P + pl->blk(st, j, B_W2), P + pl->blk(st, j, B_W1)};
@@ -91,21 +92,21 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         RC(launch_transpose3(tsrc, tdst, trows, tcols, 3, s));
     }
     FfnDwBwdArgs fd;
-    fd.dy = dy; fd.g3 = fb.g3; fd.h2 = fb.h2; fd.dh2 = bb.dh2; fd.w3t = bb.w3t; fd.dww = P + pl->blk(st, j, B_DWW);
+    fd.dy = dy; fd.g3 = pre ? fb.a3 : fb.g3; fd.h2 = fb.h2; fd.dh2 = bb.dh2; fd.w3t = bb.w3t; fd.dww = P + pl->blk(st, j, B_DWW);
     fd.slab_w = bb.rq.take(ffn_dw_bwd_slab_floats(e, B, fb.h, fb.w));
     if (!fd.slab_w) return -3;
     fd.slab_b = fd.slab_w + ffn_dw_bwd_slab_floats(e, B, fb.h, fb.w) / 10 * 9;
     fd.d_dww = G + pl->blk(st, j, B_DWW); fd.d_dwb = G + pl->blk(st, j, B_DWB);
-    fd.B = B; fd.h = fb.h; fd.w = fb.w; fd.hbf = hbf;
+    fd.B = B; fd.h = fb.h; fd.w = fb.w; fd.hbf = hbf; fd.pre = pre;
     RC(launch_ffn_dw_bwd(e, fd, s));
-    RC(wgrad(dy, e, fb.a3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 0, hbf, bb, s));
+    RC(wgrad(dy, e, fb.a3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 0, hbf, bb, s, pre));
     Ffn1BwdArgs f1;
-    f1.dh2 = bb.dh2; f1.g1 = fb.g1; f1.x = fb.xmid; f1.dy = dy; f1.dh1 = bb.dh1; f1.y2 = bb.y2; f1.dx = tmp;
+    f1.dh2 = bb.dh2; f1.g1 = pre ? fb.a1 : fb.g1; f1.x = fb.xmid; f1.dy = dy; f1.dh1 = bb.dh1; f1.y2 = bb.y2; f1.dx = tmp;
     f1.w2t = bb.w2t; f1.w1t = bb.w1t;
     f1.ln2g = P + pl->blk(st, j, B_LN2G); f1.ln2b = P + pl->blk(st, j, B_LN2B);
     f1.d_ln2g = G + pl->blk(st, j, B_LN2G); f1.d_ln2b = G + pl->blk(st, j, B_LN2B); f1.part = bb.rq.take((size_t)PIXEL_PART_WGS * 2 * e);
     if (!f1.part) return -3;
-    f1.P = Pn; f1.hbf = hbf;
+    f1.P = Pn; f1.hbf = hbf; f1.pre = pre;
     f1.w1 = nullptr; f1.wsplit = nullptr;
     if (e == 32 && pl->ffn_tile == 0) { f1.w1 = P + pl->blk(st, j, B_W1); f1.wsplit = bb.wsp; }   // LG_FFN_IMPL=strip|tile: the f32-MFMA kernel (A/B)
     f1.w1slab = nullptr; f1.d_w1 = nullptr; f1.d_b1 = nullptr;
@@ -115,7 +116,7 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         f1.d_w1 = G + pl->blk(st, j, B_W1); f1.d_b1 = G + pl->blk(st, j, B_B1);
     }
     RC(launch_ffn1_bwd(e, f1, s));
-    RC(wgrad(bb.dh2, n1, fb.a1, n1, G + pl->blk(st, j, B_W2), n1, G + pl->blk(st, j, B_B2), Pn, n1, n1, n1, n1, hbf, hbf, bb, s));
+    RC(wgrad(bb.dh2, n1, fb.a1, n1, G + pl->blk(st, j, B_W2), n1, G + pl->blk(st, j, B_B2), Pn, n1, n1, n1, n1, hbf, hbf, bb, s, pre));
     if (!ffn1_bwd_fuses_w1(e))
         RC(wgrad(bb.dh1, n1, bb.y2, e, G + pl->blk(st, j, B_W1), e, G + pl->blk(st, j, B_B1), Pn, n1, e, n1, e, hbf, 0, bb, s));
     return 0;

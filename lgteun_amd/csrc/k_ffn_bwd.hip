@@ -43,7 +43,8 @@ int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream
 // ------------------------------------------------------------------------------------------------
 #define DW_CG 32   // channels per workgroup (depthwise work is per channel); 16 (3 workgroups per CU) measured no faster
 #define DW_TPW 8   // tiles walked by one workgroup (weight-gradient partials stay in registers across them)
-template <int E, bool BF, int CG>
+// PRE: a.g3 holds the pre-activation h3 (the forward saved h1 / h2 / h3 only): gelu'(h3) is evaluated here, on the halo tile
+template <int E, bool BF, int CG, bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((E == 16 || (E == 32 && CG == 32)) ? 2 : 1))) void k_ffn_dw_bwd(FfnDwBwdArgs a, int tiles_x, int tiles_y) {
     constexpr int N1 = 4 * E, TY = 8, TX = 16, HX = TX + 2, HY = TY + 2, NH = HX * HY, MH = 192, CQ = CG / 4, NTG = CG / 16;
     constexpr int LDY = E + 4, LDG = CG + 4;
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((E == 16 ||
     for (int it = 0; it < NG3; ++it) {
         const int i = threadIdx.x + it * 256;
         g3r[it] = HS<BF>::widen(g3n[it]);
+        if (PRE) g3r[it] = make_float4(gelu_grad_f(g3r[it].x), gelu_grad_f(g3r[it].y), gelu_grad_f(g3r[it].z), gelu_grad_f(g3r[it].w));   // dy = 0 outside the image
         if (i < NH * CQ) {
             const int m = i / CQ, qq = i - m * CQ;
             *reinterpret_cast<float4*>(bufH + m * LDG + 4 * qq) = HS<BF>::widen(h2r[it]);
@@ -236,13 +238,16 @@ static int launch_ffn_dw_bwd_t(const FfnDwBwdArgs& a, hipStream_t s) {
     const size_t lds = (size_t)(192 * (E + 4) + 2 * 180 * (CG + 4) + ((E == 32 && CG == 32) ? 0 : 4 * (CG / 4) * 40)) * sizeof(float);
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, false, CG>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, true, CG>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, false, CG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, true, CG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, false, CG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn_dw_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
-    if (a.hbf) k_ffn_dw_bwd<E, true, CG><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
-    else k_ffn_dw_bwd<E, false, CG><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
+    if (a.pre && a.hbf) { lg_set_error("ffn_dw_bwd: pre-activation saves are fp32"); return -2; }
+    if (a.hbf) k_ffn_dw_bwd<E, true, CG, false><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
+    else if (a.pre) k_ffn_dw_bwd<E, false, CG, true><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
+    else k_ffn_dw_bwd<E, false, CG, false><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
     LG_CHECK_LAUNCH();
     int rc = launch_reduce_slab(a.slab_w, nwg, 4 * E, 9, a.d_dww, 9, 4 * E, 9, s);
     if (rc) return rc;
@@ -258,7 +263,8 @@ int launch_ffn_dw_bwd(int e, const FfnDwBwdArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int E, int MT, bool BF>
+// PRE: a.g1 holds the pre-activation h1: gelu'(h1) is evaluated here
+template <int E, int MT, bool BF, bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2 : 1))) void k_ffn1_bwd(Ffn1BwdArgs a, long nchunks) {
     constexpr int N1 = 4 * E, MW = 16 * MT, LDH = N1 + 4, LDO = E + 1, NTE = E / 16, LDY = LDO;
     constexpr bool RB = (E == 16);
@@ -346,6 +352,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
         const int i = lane + it * 64;
         const int m = i / (N1 / 4), k4 = i - m * (N1 / 4);
         g1r[it] = HS<BF>::widen(g1n[it]);
+        if (PRE) g1r[it] = make_float4(gelu_grad_f(g1r[it].x), gelu_grad_f(g1r[it].y), gelu_grad_f(g1r[it].z), gelu_grad_f(g1r[it].w));
         *reinterpret_cast<float4*>(bufD + m * LDH + 4 * k4) = HS<BF>::widen(dh2n[it]);
     }
     float4 xr[NX], dyr[NX];
@@ -586,8 +593,9 @@ static int launch_ffn1_bwd_t(const Ffn1BwdArgs& a, hipStream_t s) {
     size_t lds = (size_t)(4 * MW * (2 * (N1 + 4) + E + 1) + (E == 16 ? N1 * (N1 + 4) : 0)) * sizeof(float);
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn1_bwd<E, MT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1_bwd<E, MT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn1_bwd<E, MT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1_bwd<E, MT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1_bwd<E, MT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn1_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
@@ -597,8 +605,10 @@ static int launch_ffn1_bwd_t(const Ffn1BwdArgs& a, hipStream_t s) {
     if (!a.part) { lg_set_error("ffn1_bwd: partial-sum scratch missing"); return -2; }
     if (ffn1_bwd_fuses_w1(E) && (!a.w1slab || !a.d_w1 || !a.d_b1)) { lg_set_error("ffn1_bwd: dW1 slab / destinations missing"); return -2; }
     if (!ffn1_bwd_fuses_w1(E) && (!a.dh1 || !a.y2)) { lg_set_error("ffn1_bwd: dh1 / y2 outputs missing"); return -2; }
-    if (a.hbf) k_ffn1_bwd<E, MT, true><<<grid, 256, lds, s>>>(a, nchunks);
-    else k_ffn1_bwd<E, MT, false><<<grid, 256, lds, s>>>(a, nchunks);
+    if (a.pre && a.hbf) { lg_set_error("ffn1_bwd: pre-activation saves are fp32"); return -2; }
+    if (a.hbf) k_ffn1_bwd<E, MT, true, false><<<grid, 256, lds, s>>>(a, nchunks);
+    else if (a.pre) k_ffn1_bwd<E, MT, false, true><<<grid, 256, lds, s>>>(a, nchunks);
+    else k_ffn1_bwd<E, MT, false, false><<<grid, 256, lds, s>>>(a, nchunks);
     LG_CHECK_LAUNCH();
     int rc = launch_reduce_slab_pair(a.part, a.part + (size_t)grid * E, grid, E, a.d_ln2g, a.d_ln2b, s);
     if (rc || !ffn1_bwd_fuses_w1(E)) return rc;

@@ -55,7 +55,10 @@ __device__ __forceinline__ float quad_sum(float v) {
 __device__ __forceinline__ bf16x8_t lds_x8(const uint16_t* p) { return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(p)); }
 __device__ __forceinline__ s16x4_t lds_x4(const uint16_t* p) { return __builtin_bit_cast(s16x4_t, *reinterpret_cast<const u32x2_t*>(p)); }
 
-template <bool SAVE, int NP>
+// SAVE: 0 nothing; 1 gelu(h1), gelu'(h1), h2, gelu(h3), gelu'(h3) (GELU-free backward: the precision = 'bf16' layout);
+// 2 the PRE-ACTIVATIONS h1, h2, h3 only (three tensors instead of five: the backward kernels re-evaluate gelu / gelu' from
+// them, bwd_kernels.h `pre`)
+template <int SAVE, int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn_xs(Ffn1Args a1, Ffn2Args a2, int tiles_x, int strips_y, int nstrips,
                                                                                        int SH) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int pb = 0; pb < 3; ++pb) {
                 float av[4];
-                if (SAVE) {
+                if (SAVE == 1) {
                     lg_v2f a01, a23, g01, g23;
                     gelu2_both_f((lg_v2f){acc[pb][0], acc[pb][1]}, a01, g01);
                     gelu2_both_f((lg_v2f){acc[pb][2], acc[pb][3]}, a23, g23);
@@ -188,6 +191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                         HS<BF>::st4(a1.g1s, prow[pb], make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
                 } else {
+                    if (SAVE == 2 && inner[pb]) HS<BF>::st4(a1.a1s, prow[pb], make_float4(acc[pb][0], acc[pb][1], acc[pb][2], acc[pb][3]));
                     const lg_v2f a01 = gelu2_f((lg_v2f){acc[pb][0], acc[pb][1]}), a23 = gelu2_f((lg_v2f){acc[pb][2], acc[pb][3]});
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 }
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
             const int ty = 2 * wave + ch;
-#pragma unroll(SAVE ? 1 : 4)
+#pragma unroll(SAVE == 1 ? 1 : 4)
             for (int it = 0; it < 4; ++it) {
                 const int tx = (lane >> 4) + 4 * it;
                 float4 acc = make_float4(bq[0], bq[1], bq[2], bq[3]);
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     }
                 }
                 float av[4];
-                if (SAVE) {
+                if (SAVE == 1) {
                     lg_v2f a01, a23, g01, g23;
                     gelu2_both_f((lg_v2f){acc.x, acc.y}, a01, g01);
                     gelu2_both_f((lg_v2f){acc.z, acc.w}, a23, g23);
@@ -306,6 +310,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                         HS<BF>::st4(a2.g3s, o, make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
                 } else {
+                    if (SAVE == 2) {
+                        const int y = y0 + ty, x = x0 + tx;
+                        if (y < Yend && x < w) HS<BF>::st4(a2.a3s, ((b * h + y) * (long)w + x) * N1 + 4 * q, acc);
+                    }
                     const lg_v2f a01 = gelu2_f((lg_v2f){acc.x, acc.y}), a23 = gelu2_f((lg_v2f){acc.z, acc.w});
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 }
@@ -367,10 +375,11 @@ int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     ProfScope prof__(LG_K_FFN2, s);
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_xs<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_xs<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn_xs: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
@@ -382,11 +391,14 @@ int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     const int nstrips = a2.B * tiles_x * strips_y;
     const int grid = nstrips < 512 ? nstrips : 512;
     const bool save = a1.a1s != nullptr;
+    const bool pre = save && a1.g1s == nullptr;   // pre-activation saves (h1 in a1s, h3 in a3s)
+    if (pre && (a1.hbf || !a2.a3s || a2.g3s || !a1.h2)) { lg_set_error("ffn_xs: pre-activation saves need fp32 storage and h1 / h2 / h3 slots"); return -2; }
     if (a1.hbf) {   // precision = 'bf16': plain bf16 operands, bf16 storage of the saved tensors
-        if (save) k_ffn_xs<true, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
-        else k_ffn_xs<false, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
-    } else if (save) k_ffn_xs<true, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
-    else k_ffn_xs<false, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+        if (save) k_ffn_xs<1, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+        else k_ffn_xs<0, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    } else if (pre) k_ffn_xs<2, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    else if (save) k_ffn_xs<1, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    else k_ffn_xs<0, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
     LG_CHECK_LAUNCH();
     return 0;
 }

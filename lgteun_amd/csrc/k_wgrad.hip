@@ -21,7 +21,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // 4-pixel MFMA steps per batch: narrow blocks have few MFMAs per pixel, so they keep more pixels in flight
 __host__ __device__ constexpr int wgrad_batch(int nt, int kt, bool vec) { return vec ? 4 : (nt + kt <= 2 ? 16 : (nt + kt <= 4 ? 8 : 4)); }
 
-template <int NT, int KT, bool VEC, bool YBF, bool XBF>
+// XGELU: the stored X is a pre-activation and the conv input is gelu(X) (feed_forward's second and third 1x1 convs when the forward
+// saved h1 / h3 instead of gelu(h1) / gelu(h3)): evaluated on the operand registers, under the loads of the next batch
+template <int NT, int KT, bool VEC, bool YBF, bool XBF, bool XGELU = false>
 __global__ __launch_bounds__(256) void k_wgrad_t(WgradArgs a, int k_blocks, long px_per_wave, float* slab, float* bslab) {
     constexpr int U = wgrad_batch(NT, KT, VEC);
     constexpr int NB = 16 * NT, KB = 16 * KT;
@@ -90,7 +92,10 @@ __global__ __launch_bounds__(256) void k_wgrad_t(WgradArgs a, int k_blocks, long
 #pragma unroll
                 for (int i = 0; i < NT; ++i) { yv[i] = yc[u][i] * (VEC ? rm : rm * ym[i]); bsum[i] += yv[i]; }
 #pragma unroll
-                for (int j = 0; j < KT; ++j) xv[j] = VEC ? xc[u][j] : xc[u][j] * xm[j];
+                for (int j = 0; j < KT; ++j) {
+                    const float xg = XGELU ? gelu_f(xc[u][j]) : xc[u][j];
+                    xv[j] = VEC ? xg : xg * xm[j];
+                }
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -326,6 +331,9 @@ size_t wgrad_slab_floats(int N, int K, long P) {
 
 template <int NT, int KT, bool VEC>
 static void wgrad_dispatch_bf(const WgradArgs& a, dim3 grid, int k_blocks, long px, float* slab, float* bslab, hipStream_t s) {
+    if constexpr (KT == 4) {
+        if (a.xgelu) { k_wgrad_t<NT, KT, VEC, false, false, true><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab); return; }
+    }
     if (a.ybf && a.xbf) k_wgrad_t<NT, KT, VEC, true, true><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);
     else if (a.ybf) k_wgrad_t<NT, KT, VEC, true, false><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);
     else if (a.xbf) k_wgrad_t<NT, KT, VEC, false, true><<<grid, 256, 0, s>>>(a, k_blocks, px, slab, bslab);
@@ -346,6 +354,7 @@ int launch_wgrad(const WgradArgs& a, float* slab, hipStream_t s) {
     if ((a.N & 15) || (a.K & 15) || a.N <= 0 || a.K <= 0 || a.P <= 0) { lg_set_error("wgrad: N,K must be positive multiples of 16"); return -2; }
     if (a.n_valid > a.N || a.k_valid > a.K || a.n_valid > a.ldy || a.k_valid > a.ldx) { lg_set_error("wgrad: valid extents exceed the operands"); return -2; }
     const int NT = tiles_per_block(a.N / 16), KT = tiles_per_block(a.K / 16);
+    if (a.xgelu && (KT != 4 || a.ybf || a.xbf)) { lg_set_error("wgrad: gelu(X) operands need fp32 storage and K a multiple of 64"); return -2; }
     const int n_blocks = a.N / (16 * NT), k_blocks = a.K / (16 * KT);
     const int blocks = n_blocks * k_blocks;
     long splits = wgrad_splits(a.N, a.K);
