@@ -175,6 +175,8 @@ struct Ffn1BwdArgs {
     // e <= 32: the first conv's weight / bias gradient (dW1 = sum_p dh1 (x) LN2(x), db1 = sum_p dh1) is accumulated in this
     // kernel (dh1 and LN2(x) are already on chip), so dh1 / y2 never go to HBM: w1slab = FFN1_BWD_WGS * (4e*e + 4e) floats
     float *w1slab, *d_w1, *d_b1;
+    // e = 16 with pre-activation saves: dW2 / db2 as well (gelu(h1) is evaluated here): w2slab = FFN1_BWD_WGS * (4e*4e + 4e) floats
+    float *w2slab, *d_w2, *d_b2;
     long P;
     int hbf;           // hidden storage: 0 fp32, 1 bf16
     int pre;           // 1: g1 holds the PRE-ACTIVATION h1; gelu'(h1) is evaluated in the kernel
@@ -185,6 +187,7 @@ struct Ffn1BwdArgs {
 };
 #define FFN1_BWD_WGS 512   // persistent grid cap of k_ffn1_bwd
 inline bool ffn1_bwd_fuses_w1(int e) { return e <= 32; }
+inline bool ffn1_bwd_fuses_w2(int e, int pre) { return pre && e == 16; }
 int launch_ffn1_bwd(int e, const Ffn1BwdArgs& a, hipStream_t s);
 int launch_ffn1_bwd_x32(const Ffn1BwdArgs& a, const float* w1, void* wsplit, hipStream_t s);   // k_ffn1_bwd_x32.hip
 int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[cols][rows]

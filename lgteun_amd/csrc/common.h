@@ -32,10 +32,12 @@ struct lg_plan {
     lg_config cfg;
     int n_offsets;
     int ffn_tile;  // A/B switch read ONCE at plan creation (env LG_FFN_IMPL = strip | tile): the f32-MFMA fused FFN kernels instead of the split-bf16 ones
-    int save5;     // A/B switch read ONCE at plan creation (env LG_FFN_SAVE = 5): the live stage's e = 16 FFN saves gelu / gelu' (5 tensors, GELU-free backward) instead of h1 / h2 / h3
-    // true: the live stage's FFN half-blocks of width e save the PRE-ACTIVATIONS h1, h2, h3 (in the a1 / h2 / a3 slots) and the backward
-    // re-evaluates gelu / gelu' (three 4e-wide tensors of HBM traffic instead of five, each way)
-    bool ffn_saves_preact(int e) const { return e == 16 && cfg.precision == 0 && ffn_tile == 0 && !save5; }
+    int save3;     // A/B switch read ONCE at plan creation (env LG_FFN_SAVE = 3), see ffn_saves_preact
+    // true: the live stage's e = 16 FFN half-blocks save the PRE-ACTIVATIONS h1, h2, h3 (in the a1 / h2 / a3 slots) instead of gelu / gelu'
+    // (five tensors), the backward re-evaluates gelu / gelu' and k_ffn1_bwd accumulates dW2 itself.  Measured: the
+    // forward's SAVE launch 184 -> 158 us and 40 % less saved-activation traffic, but the GELUs and the extra f32 MFMAs cost the backward
+    // what the forward gains, so the default stays the GELU-free backward.
+    bool ffn_saves_preact(int e) const { return e == 16 && cfg.precision == 0 && ffn_tile == 0 && save3; }
     int64_t* off;  // host copy of offsets
     int64_t shared(int s) const { return off[s]; }
     int64_t eta(int i) const { return off[S_NSHARED + i]; }

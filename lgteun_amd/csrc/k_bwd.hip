@@ -115,8 +115,15 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         if (!f1.w1slab) return -3;
         f1.d_w1 = G + pl->blk(st, j, B_W1); f1.d_b1 = G + pl->blk(st, j, B_B1);
     }
+    f1.w2slab = nullptr; f1.d_w2 = nullptr; f1.d_b2 = nullptr;
+    if (ffn1_bwd_fuses_w2(e, pre)) {   // dW2 / db2 too
+        f1.w2slab = bb.rq.take((size_t)FFN1_BWD_WGS * ((size_t)n1 * n1 + n1));
+        if (!f1.w2slab) return -3;
+        f1.d_w2 = G + pl->blk(st, j, B_W2); f1.d_b2 = G + pl->blk(st, j, B_B2);
+    }
     RC(launch_ffn1_bwd(e, f1, s));
-    RC(wgrad(bb.dh2, n1, fb.a1, n1, G + pl->blk(st, j, B_W2), n1, G + pl->blk(st, j, B_B2), Pn, n1, n1, n1, n1, hbf, hbf, bb, s, pre));
+    if (!ffn1_bwd_fuses_w2(e, pre))
+        RC(wgrad(bb.dh2, n1, fb.a1, n1, G + pl->blk(st, j, B_W2), n1, G + pl->blk(st, j, B_B2), Pn, n1, n1, n1, n1, hbf, hbf, bb, s, pre));
     if (!ffn1_bwd_fuses_w1(e))
         RC(wgrad(bb.dh1, n1, bb.y2, e, G + pl->blk(st, j, B_W1), e, G + pl->blk(st, j, B_B1), Pn, n1, e, n1, e, hbf, 0, bb, s));
     return 0;

@@ -142,7 +142,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((E == 16 ||
     for (int it = 0; it < NG3; ++it) {
         const int i = threadIdx.x + it * 256;
         g3r[it] = HS<BF>::widen(g3n[it]);
-        if (PRE) g3r[it] = make_float4(gelu_grad_f(g3r[it].x), gelu_grad_f(g3r[it].y), gelu_grad_f(g3r[it].z), gelu_grad_f(g3r[it].w));   // dy = 0 outside the image
+        if (PRE) {   // gelu'(h3) from the saved pre-activation (dy is 0 outside the image, so is dh3)
+            lg_v2f a01, a23, g01, g23;
+            gelu2_both_f((lg_v2f){g3r[it].x, g3r[it].y}, a01, g01);
+            gelu2_both_f((lg_v2f){g3r[it].z, g3r[it].w}, a23, g23);
+            g3r[it] = make_float4(g01.x, g01.y, g23.x, g23.y);
+        }
         if (i < NH * CQ) {
             const int m = i / CQ, qq = i - m * CQ;
             *reinterpret_cast<float4*>(bufH + m * LDG + 4 * qq) = HS<BF>::widen(h2r[it]);
@@ -240,13 +245,13 @@ static int launch_ffn_dw_bwd_t(const FfnDwBwdArgs& a, hipStream_t s) {
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, false, CG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, true, CG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, false, CG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if constexpr (E == 16) { if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd<E, false, CG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }
         if (e != hipSuccess) { lg_set_error("ffn_dw_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
-    if (a.pre && a.hbf) { lg_set_error("ffn_dw_bwd: pre-activation saves are fp32"); return -2; }
+    if (a.pre && (a.hbf || E != 16)) { lg_set_error("ffn_dw_bwd: pre-activation saves are fp32, e = 16"); return -2; }
     if (a.hbf) k_ffn_dw_bwd<E, true, CG, false><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
-    else if (a.pre) k_ffn_dw_bwd<E, false, CG, true><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
+    else if (a.pre) { if constexpr (E == 16) k_ffn_dw_bwd<E, false, CG, true><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y); }
     else k_ffn_dw_bwd<E, false, CG, false><<<grid, 256, lds, s>>>(a, tiles_x, tiles_y);
     LG_CHECK_LAUNCH();
     int rc = launch_reduce_slab(a.slab_w, nwg, 4 * E, 9, a.d_dww, 9, 4 * E, 9, s);
@@ -298,6 +303,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
             const int row = i2 / (N1 / 4), k4 = i2 - row * (N1 / 4);
             *reinterpret_cast<float4*>(w2l + row * LDH + 4 * k4) = *reinterpret_cast<const float4*>(a.w2t + (size_t)row * N1 + 4 * k4);
         }
+    }
+    // FW2 (pre-activation saves, e = 16): gelu(h1) is evaluated here for gelu'(h1) anyway, so dW2 = sum_p dh2 (x) gelu(h1) and db2 are
+    // accumulated in this kernel too: the rows of all four waves (dh2 in bufD, gelu(h1) in bufA) are the operands, wave w owns the
+    // output rows n = 4 i + w (tile t of a float4 at column 4r = channel 4r + t, as in k_wgrad_t's VEC layout)
+    constexpr bool FW2 = PRE && E == 16;
+    float* bufA_all = w2l + N1 * LDH;            // [4][MW][LDH] gelu(h1) rows (FW2)
+    float* bufA = bufA_all + wave * (MW * LDH);
+    f32x4 acc2[FW2 ? 4 : 1];
+    float4 bs2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FW2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     float4 w1r[PF ? NTE : 1][PF ? N1 / 16 : 1];
     if (PF) load_bfrag<NTE, N1 / 16>(reinterpret_cast<float4(&)[NTE][N1 / 16]>(w1r), a.w1t, N1);
@@ -352,8 +369,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
         const int i = lane + it * 64;
         const int m = i / (N1 / 4), k4 = i - m * (N1 / 4);
         g1r[it] = HS<BF>::widen(g1n[it]);
-        if (PRE) g1r[it] = make_float4(gelu_grad_f(g1r[it].x), gelu_grad_f(g1r[it].y), gelu_grad_f(g1r[it].z), gelu_grad_f(g1r[it].w));
-        *reinterpret_cast<float4*>(bufD + m * LDH + 4 * k4) = HS<BF>::widen(dh2n[it]);
+        const float4 d2 = HS<BF>::widen(dh2n[it]);
+        if (PRE) {   // gelu'(h1) and gelu(h1) from the saved pre-activation, one exponential for both
+            lg_v2f a01, a23, g01, g23;
+            gelu2_both_f((lg_v2f){g1r[it].x, g1r[it].y}, a01, g01);
+            gelu2_both_f((lg_v2f){g1r[it].z, g1r[it].w}, a23, g23);
+            g1r[it] = make_float4(g01.x, g01.y, g23.x, g23.y);
+            if (FW2) {
+                *reinterpret_cast<float4*>(bufA + m * LDH + 4 * k4) = make_float4(a01.x, a01.y, a23.x, a23.y);
+                bs2.x += d2.x; bs2.y += d2.y; bs2.z += d2.z; bs2.w += d2.w;   // k4 = lane % (N1/4) is the same for every `it`
+            }
+        }
+        *reinterpret_cast<float4*>(bufD + m * LDH + 4 * k4) = d2;
     }
     float4 xr[NX], dyr[NX];
 #pragma unroll
@@ -391,6 +418,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
         for (int c = 0; c < E; ++c) bufY[lane * LDY + c] = pv ? (xv[c] - mu) * rstd * lnp[c] + lnp[E + c] : 0.f;
     }
     __syncthreads();
+    if constexpr (FW2) {
+        // ---- dW2[4 i + wave][4 j + t] += sum over the workgroup's 64 pixels: A[i = r][k = g] = dh2[pixel g][4 r + wave],
+        // B[k = g][j = r] = gelu(h1)[pixel g][4 r + t]
+#pragma unroll 1
+        for (int sw = 0; sw < 4; ++sw) {
+            const float* dsrc = smem + sw * (MW * (2 * LDH + LDO));
+            const float* asrc = bufA_all + sw * (MW * LDH);
+#pragma unroll
+            for (int ks = 0; ks < MW / 4; ++ks) {
+                const float yv = dsrc[(4 * ks + g) * LDH + 4 * r + wave];
+                const float4 xv = *reinterpret_cast<const float4*>(asrc + (4 * ks + g) * LDH + 4 * r);
+                acc2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv, xv.x, acc2[0], 0, 0, 0);
+                acc2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv, xv.y, acc2[1], 0, 0, 0);
+                acc2[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv, xv.z, acc2[2], 0, 0, 0);
+                acc2[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv, xv.w, acc2[3], 0, 0, 0);
+            }
+        }
+    }
     // ---- dh1 = (dh2 W2) * g1
     for (int nc = 0; nc < N1; nc += 64) {
         f32x4 acc[MT][4];
@@ -584,6 +629,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
         float* brow = a.w1slab + (size_t)gridDim.x * (N1 * E) + (size_t)blockIdx.x * N1;
         for (int i = threadIdx.x; i < N1; i += 256) brow[i] = rw[N1 * E + i];
     }
+    if constexpr (FW2) {
+        // dW2: the waves own disjoint output rows -> straight to the slab row of this workgroup; db2 through LDS (4 waves, fixed order)
+        float* wrow = a.w2slab + (size_t)blockIdx.x * (N1 * N1);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int n = 4 * (4 * g + v) + wave;
+            *reinterpret_cast<float4*>(wrow + n * N1 + 4 * r) = make_float4(acc2[0][v], acc2[1][v], acc2[2][v], acc2[3][v]);
+        }
+        float4 b4 = bs2;
+#pragma unroll
+        for (int off = N1 / 4; off < 64; off <<= 1) {
+            b4.x += __shfl_xor(b4.x, off); b4.y += __shfl_xor(b4.y, off); b4.z += __shfl_xor(b4.z, off); b4.w += __shfl_xor(b4.w, off);
+        }
+        float* rb2 = smem;   // [N1]
+        __syncthreads();
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w && lane < N1 / 4) {
+                float* rb = rb2 + 4 * lane;
+                rb[0] = (w == 0 ? 0.f : rb[0]) + b4.x; rb[1] = (w == 0 ? 0.f : rb[1]) + b4.y;
+                rb[2] = (w == 0 ? 0.f : rb[2]) + b4.z; rb[3] = (w == 0 ? 0.f : rb[3]) + b4.w;
+            }
+            __syncthreads();
+        }
+        float* brow2 = a.w2slab + (size_t)gridDim.x * (N1 * N1) + (size_t)blockIdx.x * N1;
+        for (int i = threadIdx.x; i < N1; i += 256) brow2[i] = rb2[i];
+    }
 }
 
 template <int E, int MT>
@@ -591,11 +662,12 @@ static int launch_ffn1_bwd_t(const Ffn1BwdArgs& a, hipStream_t s) {
     ProfScope prof__(LG_K_FFN1_BWD, s);
     constexpr int N1 = 4 * E, MW = 16 * MT;
     size_t lds = (size_t)(4 * MW * (2 * (N1 + 4) + E + 1) + (E == 16 ? N1 * (N1 + 4) : 0)) * sizeof(float);
+    if (ffn1_bwd_fuses_w2(E, a.pre)) lds += (size_t)4 * MW * (N1 + 4) * sizeof(float);   // gelu(h1) rows
     static DeviceOnce attr_once;
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ffn1_bwd<E, MT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1_bwd<E, MT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1_bwd<E, MT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if constexpr (E == 16) { if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1_bwd<E, MT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }
         if (e != hipSuccess) { lg_set_error("ffn1_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
@@ -605,14 +677,17 @@ static int launch_ffn1_bwd_t(const Ffn1BwdArgs& a, hipStream_t s) {
     if (!a.part) { lg_set_error("ffn1_bwd: partial-sum scratch missing"); return -2; }
     if (ffn1_bwd_fuses_w1(E) && (!a.w1slab || !a.d_w1 || !a.d_b1)) { lg_set_error("ffn1_bwd: dW1 slab / destinations missing"); return -2; }
     if (!ffn1_bwd_fuses_w1(E) && (!a.dh1 || !a.y2)) { lg_set_error("ffn1_bwd: dh1 / y2 outputs missing"); return -2; }
-    if (a.pre && a.hbf) { lg_set_error("ffn1_bwd: pre-activation saves are fp32"); return -2; }
+    if (ffn1_bwd_fuses_w2(E, a.pre) && (!a.w2slab || !a.d_w2 || !a.d_b2)) { lg_set_error("ffn1_bwd: dW2 slab / destinations missing"); return -2; }
+    if (a.pre && (a.hbf || E != 16)) { lg_set_error("ffn1_bwd: pre-activation saves are fp32, e = 16"); return -2; }
     if (a.hbf) k_ffn1_bwd<E, MT, true, false><<<grid, 256, lds, s>>>(a, nchunks);
-    else if (a.pre) k_ffn1_bwd<E, MT, false, true><<<grid, 256, lds, s>>>(a, nchunks);
+    else if (a.pre) { if constexpr (E == 16) k_ffn1_bwd<E, MT, false, true><<<grid, 256, lds, s>>>(a, nchunks); }
     else k_ffn1_bwd<E, MT, false, false><<<grid, 256, lds, s>>>(a, nchunks);
     LG_CHECK_LAUNCH();
     int rc = launch_reduce_slab_pair(a.part, a.part + (size_t)grid * E, grid, E, a.d_ln2g, a.d_ln2b, s);
     if (rc || !ffn1_bwd_fuses_w1(E)) return rc;
-    return launch_reduce_slab_wb(a.w1slab, a.w1slab + (size_t)grid * N1 * E, grid, N1, E, a.d_w1, E, a.d_b1, s);
+    rc = launch_reduce_slab_wb(a.w1slab, a.w1slab + (size_t)grid * N1 * E, grid, N1, E, a.d_w1, E, a.d_b1, s);
+    if (rc || !ffn1_bwd_fuses_w2(E, a.pre)) return rc;
+    return launch_reduce_slab_wb(a.w2slab, a.w2slab + (size_t)grid * N1 * N1, grid, N1, N1, a.d_w2, N1, a.d_b2, s);
 }
 int launch_ffn1_bwd(int e, const Ffn1BwdArgs& a, hipStream_t s) {
     if (e == 16) return launch_ffn1_bwd_t<16, 1>(a, s);
