@@ -6,6 +6,7 @@
 
 #include "kernels.h"
 #include "bwd_kernels.h"
+#include "resample_tile.h"
 
 // sum v[0..N) over the 256 threads of the block; result valid in threads 0..N-1 (returned value for index tid)
 template <int N>
@@ -139,22 +140,24 @@ __global__ __launch_bounds__(256) void k_dw_bwd(DwBwdArgs a) {
     __shared__ float Gt[34][35];
     __shared__ float Ut[34][35];
     __shared__ float red[4 * 10];
+    __shared__ float rs_scratch[MODE == 1 ? RsTile<1>::FLOATS : 1];   // x2 only (k_resample_dw)
     const int plane = blockIdx.z;
     const int c = plane % a.C;
     const int ty0 = blockIdx.y * 32, tx0 = blockIdx.x * 32;
-    const float* in = a.in + (size_t)plane * a.hi * a.wi;
-    const float* go = a.gout + (size_t)plane * a.n_h * a.n_w;
+    const float* __restrict__ in = a.in + (size_t)plane * a.hi * a.wi;
+    const float* __restrict__ go = a.gout + (size_t)plane * a.n_h * a.n_w;
     for (int i = threadIdx.x; i < 34 * 34; i += 256) {
         int uy = i / 34, ux = i - uy * 34;
         int oy = ty0 + uy - 1, ox = tx0 + ux - 1;
         float u = 0.f, g = 0.f;
         if (oy >= 0 && oy < a.n_h && ox >= 0 && ox < a.n_w) {
-            u = resample_at<MODE>(in, a.hi, a.wi, oy, ox);
+            if (MODE == 0) u = resample_at<MODE>(in, a.hi, a.wi, oy, ox);
             g = go[oy * a.n_w + ox];
         }
-        Ut[uy][ux] = u;
+        if (MODE == 0) Ut[uy][ux] = u;
         Gt[uy][ux] = g;
     }
+    if constexpr (MODE == 1) resample_tile34<1>(in, a.hi, a.wi, a.n_h, a.n_w, ty0, tx0, Ut, rs_scratch);
     __syncthreads();
     float w[9];
 #pragma unroll
@@ -237,44 +240,68 @@ int launch_dw_bwd(int mode, const DwBwdArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // top of the data-step backward: through Z' = Z - eta*(dw(up(s1)) + RT(R(Z)-pan))   (unlg_former.py:59-61)
 // ------------------------------------------------------------------------------------------------
+template <int C>
 __global__ __launch_bounds__(256) void k_dstep_top_bwd(DstepTopArgs a) {
     __shared__ float Gm[34][35];
     __shared__ float Ut[34][35];
     __shared__ float red[4 * 14];
+    __shared__ float rs_scratch[RsTile<1>::FLOATS];
     const int plane = blockIdx.z;
-    const int c = plane % a.C;
-    const int b = plane / a.C;
+    const int c = plane % C;
+    const int b = plane / C;
     const int ty0 = blockIdx.y * 32, tx0 = blockIdx.x * 32;
     const size_t hw = (size_t)a.H * a.W;
-    const float* s1 = a.s1 + (size_t)plane * (a.H / 2) * (a.W / 2);
-    const float* g = a.g + (size_t)plane * hw;
+    const float* __restrict__ s1 = a.s1 + (size_t)plane * (a.H / 2) * (a.W / 2);
+    const float* __restrict__ g = a.g + (size_t)plane * hw;
+    const float* __restrict__ gb = a.g + (size_t)b * C * hw;
+    const float* __restrict__ zb = a.z + (size_t)b * C * hw;
+    const float* __restrict__ panb = a.pan + (size_t)b * hw;
     const float eta = a.eta[0];
+    // the pixelwise operands of the thread's four pixels (all C planes of Z and of the incoming gradient, PAN) are requested FIRST: their
+    // round trip overlaps the LDS phases below instead of sitting, one dependent load after the other, inside the per-pixel loop
+    float rz[4], dpr[4], zc[4], gv[4], pn[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const int oy = ty0 + (i >> 5), ox = tx0 + (i & 31);
+        ok[k] = oy < a.H && ox < a.W;
+        const size_t pix = ok[k] ? (size_t)oy * a.W + ox : 0;
+        float r = a.rb[0], d = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) {
+            const float zv = zb[cc * hw + pix], gg = gb[cc * hw + pix];
+            r += a.rw[cc] * zv;
+            d += a.rtw[cc] * gg;
+            if (cc == c) { zc[k] = zv; gv[k] = gg; }
+        }
+        rz[k] = r; dpr[k] = -eta * d; pn[k] = panb[pix];
+    }
     for (int i = threadIdx.x; i < 34 * 34; i += 256) {
         int uy = i / 34, ux = i - uy * 34;
         int oy = ty0 + uy - 1, ox = tx0 + ux - 1;
-        float u = 0.f, gm = 0.f;
-        if (oy >= 0 && oy < a.H && ox >= 0 && ox < a.W) {
-            u = resample_at<1>(s1, a.H / 2, a.W / 2, oy, ox);
-            gm = -eta * g[(size_t)oy * a.W + ox];
-        }
-        Ut[uy][ux] = u;
+        float gm = 0.f;
+        if (oy >= 0 && oy < a.H && ox >= 0 && ox < a.W) gm = -eta * g[(size_t)oy * a.W + ox];
         Gm[uy][ux] = gm;
     }
+    resample_tile34<1>(s1, a.H / 2, a.W / 2, a.H, a.W, ty0, tx0, Ut, rs_scratch);
     __syncthreads();
     float w[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) w[k] = a.w9[c * 9 + k];
-    const float bias3 = a.b9[c];
+    const float bias3 = a.b9[c], rtw_c = a.rtw[c], rtb_c = a.rtb[c], rw_c = a.rw[c];
     float part[14];
 #pragma unroll
     for (int k = 0; k < 14; ++k) part[k] = 0.f;
-    for (int i = threadIdx.x; i < 1024; i += 256) {
-        int ly = i >> 5, lx = i & 31;
-        int oy = ty0 + ly, ox = tx0 + lx;
-        if (oy < a.H && ox < a.W) {
-            const size_t pix = (size_t)oy * a.W + ox;
+    float* __restrict__ gu_o = a.gu + (size_t)plane * hw;
+    float* __restrict__ dz_o = a.dz + (size_t)plane * hw;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int i = threadIdx.x + 256 * kk;
+        const int ly = i >> 5, lx = i & 31;
+        if (ok[kk]) {
+            const size_t pix = (size_t)(ty0 + ly) * a.W + tx0 + lx;
             const float gm = Gm[ly + 1][lx + 1];
-            const float gv = g[pix];
             float mt = bias3, gu = 0.f;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
@@ -285,33 +312,29 @@ __global__ __launch_bounds__(256) void k_dstep_top_bwd(DstepTopArgs a) {
                     gu += w[dy * 3 + dx] * Gm[ly + 2 - dy][lx + 2 - dx];
                     part[dy * 3 + dx] += gm * u;
                 }
-            float rz = a.rb[0], dpr = 0.f;
-            for (int cc = 0; cc < a.C; ++cc) {
-                rz += a.rw[cc] * a.z[((size_t)b * a.C + cc) * hw + pix];
-                dpr += a.rtw[cc] * a.g[((size_t)b * a.C + cc) * hw + pix];
-            }
-            dpr *= -eta;
-            const float pr = rz - a.pan[(size_t)b * hw + pix];
-            const float pt = a.rtw[c] * pr + a.rtb[c];
+            const float pr = rz[kk] - pn[kk];
+            const float pt = rtw_c * pr + rtb_c;
             part[9] += gm;                                   // d bias(DT.3) and d RT.bias
-            part[10] += -gv * (mt + pt);                     // d eta
+            part[10] += -gv[kk] * (mt + pt);                 // d eta
             part[11] += gm * pr;                             // d RT.weight[c]
-            part[12] += dpr * a.z[((size_t)b * a.C + c) * hw + pix];  // d R.weight[c]
-            part[13] += (c == 0) ? dpr : 0.f;                // d R.bias
-            a.gu[(size_t)plane * hw + pix] = gu;
-            a.dz[(size_t)plane * hw + pix] = gv + a.rw[c] * dpr;
+            part[12] += dpr[kk] * zc[kk];                    // d R.weight[c]
+            part[13] += (c == 0) ? dpr[kk] : 0.f;            // d R.bias
+            gu_o[pix] = gu;
+            dz_o[pix] = gv[kk] + rw_c * dpr[kk];
         }
     }
     float r = block_sum<14>(part, red);
     const int tiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
     const size_t slice = (size_t)b * tiles + tile;
-    if (threadIdx.x < 14) a.part[(slice * a.C + c) * 14 + threadIdx.x] = r;
+    if (threadIdx.x < 14) a.part[(slice * C + c) * 14 + threadIdx.x] = r;
 }
 
 int launch_dstep_top_bwd(const DstepTopArgs& a, hipStream_t s) {
     if (!a.part) { lg_set_error("dstep_top_bwd: partial-sum scratch missing"); return -2; }
     dim3 grid((a.W + 31) / 32, (a.H + 31) / 32, a.B * a.C);
-    k_dstep_top_bwd<<<grid, 256, 0, s>>>(a);
+    if (a.C == 4) k_dstep_top_bwd<4><<<grid, 256, 0, s>>>(a);
+    else if (a.C == 8) k_dstep_top_bwd<8><<<grid, 256, 0, s>>>(a);
+    else { lg_set_error("dstep_top_bwd: C=%d unsupported", a.C); return -1; }
     LG_CHECK_LAUNCH();
     ChanReduce m;
     memset(&m, 0, sizeof(m));
