@@ -477,14 +477,30 @@ extern "C" int lg_op_lgt_bwd(const lg_plan* plan, const float* params, float* gr
 // ------------------------------------------------------------------------------------------------
 // L1 loss (mean) forward + backward -- models/base/losses.py:19-40, unlg_former.py:99-104
 // ------------------------------------------------------------------------------------------------
+// 16-byte accesses, four of them in flight per thread, and at most 256 workgroups: every workgroup ends in one float atomic on the
+// loss scalar, and those serialise in L2 (the 1024-workgroup scalar-load form spent its 21 us there and in load latency)
 __global__ __launch_bounds__(256) void k_l1(const float* __restrict__ out, const float* __restrict__ gt, float* __restrict__ dout,
                                             float* loss_accum, long n, float inv_n, float gscale) {
     float part = 0.f;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
-        float d = out[i] - gt[i];
-        part += fabsf(d);
-        dout[i] = (d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f));
+    const long n4 = n >> 2, stride = (long)gridDim.x * 256L;
+    const float4* __restrict__ o4 = reinterpret_cast<const float4*>(out);
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gt);
+    float4* __restrict__ d4 = reinterpret_cast<float4*>(dout);
+    auto one = [&](float d) { part += fabsf(d); return d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f); };
+    long i = blockIdx.x * 256L + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = o4[i + u * stride]; b[u] = g4[i + u * stride]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            d4[i + u * stride] = make_float4(one(a[u].x - b[u].x), one(a[u].y - b[u].y), one(a[u].z - b[u].z), one(a[u].w - b[u].w));
     }
+    for (; i < n4; i += stride) {
+        const float4 a = o4[i], b = g4[i];
+        d4[i] = make_float4(one(a.x - b.x), one(a.y - b.y), one(a.z - b.z), one(a.w - b.w));
+    }
+    for (long j = 4 * n4 + blockIdx.x * 256L + threadIdx.x; j < n; j += stride) dout[j] = one(out[j] - gt[j]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
     __shared__ float sm[4];
@@ -496,8 +512,10 @@ __global__ __launch_bounds__(256) void k_l1(const float* __restrict__ out, const
 extern "C" int lg_l1_loss(const float* out, const float* gt, float* dout, float* loss_accum, int64_t n_local, int64_t n_global,
                           float scale, void* stream) {
     if (!out || !gt || !dout || !loss_accum || n_local <= 0 || n_global <= 0) { lg_set_error("l1_loss: invalid argument"); return -1; }
-    int grid = (int)((n_local + 255) / 256);
-    if (grid > 1024) grid = 1024;
+    if (((uintptr_t)out | (uintptr_t)gt | (uintptr_t)dout) & 15) { lg_set_error("l1_loss: tensors must be 16-byte aligned"); return -1; }
+    int grid = (int)((n_local / 4 + 255) / 256);
+    if (grid > 256) grid = 256;
+    if (grid < 1) grid = 1;
     k_l1<<<grid, 256, 0, (hipStream_t)stream>>>(out, gt, dout, loss_accum, n_local, 1.0f / (float)n_global, scale / (float)n_global);
     LG_CHECK_LAUNCH();
     return 0;

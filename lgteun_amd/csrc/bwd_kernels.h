@@ -99,27 +99,30 @@ int launch_resample_adj(int mode, const float* gout, float* gin, int planes, int
 // ---------------- LGT pixelwise backward ----------------
 struct TailBwdArgs {
     const float* dout;  // [B,C,H,W]
+    const float* x;     // [P,E] the last block's output (the conv input)
     float* dx;          // [P,E] = Wt^T dout
-    float* doutp;       // [P,16] zero-padded pixel-major copy of dout (wgrad operand)
     float* dz;          // [B,C,H,W] = dout (residual path)
     const float* w;
+    float *d_w, *d_b;   // the conv's weight [C][E] / bias [C] gradients, accumulated in the kernel (+=)
+    float* part;        // scratch: per-workgroup partial sums, tail_bwd_part_floats(C) floats
     int HW;
     long total;
 };
+size_t tail_bwd_part_floats(int C);
 int launch_tail_bwd(int C, const TailBwdArgs& a, hipStream_t s);
 
 struct EmbedBwdArgs {
     const float* dx;  // [P,E] grad wrt embed output
     const float* z;   // [B,C,H,W]
     float* dz;        // [B,C,H,W]  += dt * dww
-    float* de;        // [P,E] grad wrt the 1x1 conv output (wgrad operand)
-    float* tp;        // [P,16] padded conv input (wgrad operand)
     const float *dww, *dwb, *w, *b, *lng;
     float *d_dww, *d_dwb, *d_lng, *d_lnb;
-    float* part;      // scratch: per-workgroup partial sums, PIXEL_PART_WGS * (2E + 2C) floats
+    float *d_w, *d_b; // the 1x1 conv's weight [E][C] / bias [E] gradients, accumulated in the kernel (+=)
+    float* part;      // scratch: per-workgroup partial sums, embed_bwd_part_floats(C) floats
     int HW;
     long total;
 };
+size_t embed_bwd_part_floats(int C);
 int launch_embed_bwd(int C, const EmbedBwdArgs& a, hipStream_t s);
 
 struct DownBwdArgs {

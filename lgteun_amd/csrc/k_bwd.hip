@@ -9,7 +9,7 @@
 struct BwdBufs {
     float *dzA, *dzB, *gu3, *gs1, *gu1, *gr, *gd3, *gt1, *gd1;
     float *dx[3];
-    float *doutp, *de, *tp, *dh2, *dh1, *y2, *do2, *dg, *dym, *cat, *y1, *dqkv, *dpos_slab;
+    float *dh2, *dh1, *y2, *do2, *dg, *dym, *cat, *y1, *dqkv, *dpos_slab;
     float *w3t, *w2t, *w1t, *wsp, *dt, *dskip, *v, *du, *fft_scratch;
     float* slab_arena;    // scratch of the deferred parameter-gradient reductions (ReduceQueue, bwd_kernels.h)
     size_t slab_cap;      // floats
@@ -25,7 +25,6 @@ static void carve_bwd(const lg_plan* plan, int B, void* base, BwdBufs& bb) {
     bb.gs1 = cv.take(C * P1); bb.gu1 = cv.take(C * P1); bb.gt1 = cv.take(C * P1); bb.gd1 = cv.take(C * P1);
     bb.gr = cv.take(C * P1 / 4); bb.gd3 = cv.take(C * P1 / 4);
     for (int i = 0; i < 3; ++i) bb.dx[i] = cv.take(P0 * E);
-    bb.doutp = cv.take(P0 * 16); bb.de = cv.take(P0 * E); bb.tp = cv.take(P0 * 16);
     bb.dh2 = cv.take(P0 * 4 * E); bb.dh1 = cv.take(P0 * 4 * E);
     bb.y2 = cv.take(P0 * E); bb.do2 = cv.take(P0 * E / 2); bb.dg = cv.take(P0 * E / 2);
     bb.dym = cv.take(P0 * E); bb.cat = cv.take(P0 * E); bb.y1 = cv.take(P0 * 16 > P0 * E / 2 ? P0 * 16 : P0 * E / 2);
@@ -253,10 +252,11 @@ static int lgt_bwd(const lg_plan* pl, const float* P, float* G, int st, const Ne
     const float* posT = nb.posT + (size_t)st * 5 * 2 * 64 * 64;
     float *A = bb.dx[0], *Bf = bb.dx[1], *Cf = bb.dx[2];
     TailBwdArgs tb;
-    tb.dout = dout; tb.dx = A; tb.doutp = bb.doutp; tb.dz = bb.dzA; tb.w = P + pl->lgt(st, L_TAILW);
-    tb.HW = c.H * c.W; tb.total = P0;
+    tb.dout = dout; tb.x = nb.blk[4].xout; tb.dx = A; tb.dz = bb.dzA; tb.w = P + pl->lgt(st, L_TAILW);
+    tb.d_w = G + pl->lgt(st, L_TAILW); tb.d_b = G + pl->lgt(st, L_TAILB);   // the conv's own weight gradient comes out of the same kernel
+    tb.HW = c.H * c.W; tb.total = P0; tb.part = bb.rq.take(tail_bwd_part_floats(c.C));
+    if (!tb.part) return -3;
     RC(launch_tail_bwd(c.C, tb, s));
-    RC(wgrad(bb.doutp, 16, nb.blk[4].xout, E, G + pl->lgt(st, L_TAILW), E, G + pl->lgt(st, L_TAILB), P0, 16, E, c.C, E, 0, 0, bb, s));
     RC(block_bwd(pl, P, G, st, 4, nb.blk[4], bb, posT + 4 * 8192, A, Bf, Cf, B, flags, seed, s));
     RC(block_bwd(pl, P, G, st, 3, nb.blk[3], bb, posT + 3 * 8192, Cf, Bf, A, B, flags, seed, s));
     // up + fusion
@@ -283,15 +283,15 @@ static int lgt_bwd(const lg_plan* pl, const float* P, float* G, int st, const Ne
     RC(block_bwd(pl, P, G, st, 0, nb.blk[0], bb, posT + 0 * 8192, A, Bf, Cf, B, flags, seed, s));
     // patch embed
     EmbedBwdArgs eb;
-    eb.dx = Cf; eb.z = zin; eb.dz = bb.dzA; eb.de = bb.de; eb.tp = bb.tp;
+    eb.dx = Cf; eb.z = zin; eb.dz = bb.dzA;
     eb.dww = P + pl->lgt(st, L_PE_DWW); eb.dwb = P + pl->lgt(st, L_PE_DWB); eb.w = P + pl->lgt(st, L_PE_W); eb.b = P + pl->lgt(st, L_PE_B);
     eb.lng = P + pl->lgt(st, L_PE_LNG);
     eb.d_dww = G + pl->lgt(st, L_PE_DWW); eb.d_dwb = G + pl->lgt(st, L_PE_DWB);
     eb.d_lng = G + pl->lgt(st, L_PE_LNG); eb.d_lnb = G + pl->lgt(st, L_PE_LNB);
-    eb.HW = c.H * c.W; eb.total = P0; eb.part = bb.rq.take((size_t)PIXEL_PART_WGS * (2 * E + 2 * c.C));
+    eb.d_w = G + pl->lgt(st, L_PE_W); eb.d_b = G + pl->lgt(st, L_PE_B);   // the conv's own weight gradient comes out of the same kernel
+    eb.HW = c.H * c.W; eb.total = P0; eb.part = bb.rq.take(embed_bwd_part_floats(c.C));
     if (!eb.part) return -3;
     RC(launch_embed_bwd(c.C, eb, s));
-    RC(wgrad(bb.de, E, bb.tp, 16, G + pl->lgt(st, L_PE_W), c.C, G + pl->lgt(st, L_PE_B), P0, E, 16, E, c.C, 0, 0, bb, s));
     return 0;
 }
 

@@ -351,147 +351,232 @@ int launch_dstep_top_bwd(const DstepTopArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // tail backward: out = Wt x + bt + z
 // ------------------------------------------------------------------------------------------------
+// Same lane = (pixel, channel quad) layout as k_embed_bwd below: dx leaves as one contiguous 1 KB row per wave-store, lane q copies plane
+// q of the residual path, and the conv's own weight gradient dWt[c][k] = sum_p dout[p][c] x[p][k] (C x E values) and bias gradient are
+// accumulated here from the block output x the kernel reads anyway -- no padded pixel-major copy of dout, no separate launch.
+#define TAIL_BWD_WGS 1024
 template <int C, int E>
 __global__ __launch_bounds__(256) void k_tail_bwd(TailBwdArgs a) {
-    __shared__ float sW[C * E];
-    lds_stage(sW, a.w, C * E);
-    __syncthreads();
-    long p = blockIdx.x * 256L + threadIdx.x;
-    if (p >= a.total) return;
-    long b = p / a.HW, s = p - b * a.HW;
-    float d[C];
+    static_assert(E == 4 * C, "one lane per channel quad");
+    constexpr int PPW = 256 / C, NACC = 4 * C + 1;   // dWt[c][4q + u] | db[q]
+    __shared__ float red[4 * C * NACC];
+    const int q = threadIdx.x % C, slot = threadIdx.x / C, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float wq[C][4];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        long o = (b * C + c) * a.HW + s;
-        d[c] = a.dout[o];
-        a.dz[o] = d[c];
-    }
-    float4* dxo = reinterpret_cast<float4*>(a.dx + p * E);
+    for (int c = 0; c < C; ++c)
 #pragma unroll
-    for (int k4 = 0; k4 < E / 4; ++k4) {
-        float v[4];
+        for (int u = 0; u < 4; ++u) wq[c][u] = a.w[c * E + 4 * q + u];
+    float acc[NACC];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float acc = 0.f;
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+    const float* __restrict__ dout = a.dout;
+    const float* __restrict__ xp = a.x;
+    for (long p0 = (long)blockIdx.x * PPW; p0 < a.total; p0 += (long)gridDim.x * PPW) {
+        const long p = p0 + slot;
+        const bool pv = p < a.total;
+        const long pc_ = pv ? p : 0;
+        const long b = pc_ / a.HW, s = pc_ - b * a.HW;
+        const float m_ = pv ? 1.f : 0.f;
+        float d[C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) acc += sW[c * E + k4 * 4 + u] * d[c];
-            v[u] = acc;
+        for (int c = 0; c < C; ++c) d[c] = dout[(b * C + c) * a.HW + s] * m_;
+        const float4 xv = *reinterpret_cast<const float4*>(xp + pc_ * E + 4 * q);
+        const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+        float o[4] = {0.f, 0.f, 0.f, 0.f}, dq = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                o[u] += wq[c][u] * d[c];
+                acc[c * 4 + u] += d[c] * xx[u];
+            }
+            if (q == c) dq = d[c];
         }
-        dxo[k4] = make_float4(v[0], v[1], v[2], v[3]);
+        acc[4 * C] += dq;
+        if (pv) {
+            *reinterpret_cast<float4*>(a.dx + p * E + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+            a.dz[(b * C + q) * a.HW + s] = dq;
+        }
     }
-    float4* dp = reinterpret_cast<float4*>(a.doutp + p * 16);
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-        float v[4];
+    for (int i = 0; i < NACC; ++i) {
+        float v = acc[i];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = (k4 * 4 + u < C) ? d[(k4 * 4 + u) % C] : 0.f;
-        dp[k4] = make_float4(v[0], v[1], v[2], v[3]);
+        for (int off = C; off < 64; off <<= 1) v += __shfl_xor(v, off);
+        if (lane < C) red[(wave * C + q) * NACC + i] = v;
+    }
+    __syncthreads();
+    // partial rows of this workgroup: [grid][C*E] dWt | [grid][C] db
+    const size_t nwg = gridDim.x, wg = blockIdx.x;
+    for (int i = threadIdx.x; i < C * NACC; i += 256) {
+        const float v = (red[i] + red[C * NACC + i]) + (red[2 * C * NACC + i] + red[3 * C * NACC + i]);
+        const int qq = i / NACC, k = i - qq * NACC;
+        if (k < 4 * C) a.part[wg * (C * E) + (k / 4) * E + 4 * qq + (k % 4)] = v;
+        else a.part[nwg * (C * E) + wg * C + qq] = v;
     }
 }
 
+size_t tail_bwd_part_floats(int C) { return (size_t)TAIL_BWD_WGS * ((size_t)4 * C * C + C); }
 int launch_tail_bwd(int C, const TailBwdArgs& a, hipStream_t s) {
-    int grid = (int)((a.total + 255) / 256);
+    if (!a.part || !a.x || !a.d_w || !a.d_b) { lg_set_error("tail_bwd: block output / partial-sum scratch / destinations missing"); return -2; }
+    const int E = 4 * C, ppw = 256 / C;
+    long nb = (a.total + ppw - 1) / ppw;
+    const int grid = (int)(nb < TAIL_BWD_WGS ? nb : TAIL_BWD_WGS);
     if (C == 4) k_tail_bwd<4, 16><<<grid, 256, 0, s>>>(a);
     else if (C == 8) k_tail_bwd<8, 32><<<grid, 256, 0, s>>>(a);
     else { lg_set_error("tail_bwd: C=%d unsupported", C); return -1; }
     LG_CHECK_LAUNCH();
-    return 0;
+    return launch_reduce_slab_wb(a.part, a.part + (size_t)grid * C * E, grid, C, E, a.d_w, E, a.d_b, s);
 }
 
 // ------------------------------------------------------------------------------------------------
 // patch_embed backward: x = LN(W (z*dww + dwb) + b)
 // ------------------------------------------------------------------------------------------------
+// Lane = (pixel, channel quad): the C = E/4 lanes of a pixel each own four of its E channels, so the [P, E] gradient is read as ONE
+// contiguous 1 KB row per wave-load (a lane per pixel fetched 64 scattered 16-byte pieces per instruction: 1.4 TB/s), LayerNorm sums
+// run across the C lanes with DPP / shuffles, and lane q finishes channel q of the C-channel side (dz, depthwise-1x1 gradients).
+// The 1x1 conv's weight gradient dW[n][c] = sum_p de[p][n] t[p][c] (E x C values) and its bias gradient are accumulated right here
+// in registers: de and the conv input t never reach HBM and the separate weight-gradient launch is gone.
+template <int C>
+__device__ __forceinline__ float group_sum(float v) {   // over the C lanes (4 or 8) of a pixel
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    if (C == 8) v += __shfl_xor(v, 4);
+    return v;
+}
+#define EMBED_BWD_WGS 1024
 template <int C, int E>
 __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
-    __shared__ float red[4 * 2 * E];
-    __shared__ float red2[4 * 2 * C];
-    float pl[2 * E], pc[2 * C];
+    static_assert(E == 4 * C, "one lane per channel quad");
+    constexpr int PPW = 256 / C;               // pixels per workgroup pass
+    constexpr int NACC = 4 * C + 4 + 8 + 2;    // dW rows of the lane's quad | db | d gamma | d beta | d dww, d dwb of channel q
+    __shared__ float red[4 * C * NACC];
+    const int q = threadIdx.x % C, slot = threadIdx.x / C, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float wq[4][C], bq[4], gq[4], dwwv[C], dwbv[C];
 #pragma unroll
-    for (int i = 0; i < 2 * E; ++i) pl[i] = 0.f;
+    for (int u = 0; u < 4; ++u) {
 #pragma unroll
-    for (int i = 0; i < 2 * C; ++i) pc[i] = 0.f;
-    for (long p = blockIdx.x * 256L + threadIdx.x; p < a.total; p += (long)gridDim.x * 256L) {
-        long b = p / a.HW, s = p - b * a.HW;
+        for (int c = 0; c < C; ++c) wq[u][c] = a.w[(4 * q + u) * C + c];
+        bq[u] = a.b[4 * q + u];
+        gq[u] = a.lng[4 * q + u];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) { dwwv[c] = a.dww[c]; dwbv[c] = a.dwb[c]; }
+    float acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+    const float* __restrict__ zp = a.z;
+    const float* __restrict__ dxp = a.dx;
+    for (long p0 = (long)blockIdx.x * PPW; p0 < a.total; p0 += (long)gridDim.x * PPW) {
+        const long p = p0 + slot;
+        const bool pv = p < a.total;
+        const long pc_ = pv ? p : 0;
+        const long b = pc_ / a.HW, s = pc_ - b * a.HW;
         float zc[C], t[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) { zc[c] = a.z[(b * C + c) * a.HW + s]; t[c] = zc[c] * a.dww[c] + a.dwb[c]; }
-        float e[E];
+        for (int c = 0; c < C; ++c) zc[c] = zp[(b * C + c) * a.HW + s];
+        const float4 dv = *reinterpret_cast<const float4*>(dxp + pc_ * E + 4 * q);
+        const float m_ = pv ? 1.f : 0.f;
+        float dxh[4] = {dv.x * m_, dv.y * m_, dv.z * m_, dv.w * m_};
 #pragma unroll
-        for (int n = 0; n < E; ++n) {
+        for (int c = 0; c < C; ++c) t[c] = zc[c] * dwwv[c] + dwbv[c];
+        float e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
             float v = 0.f;
 #pragma unroll
-            for (int c = 0; c < C; ++c) v += a.w[n * C + c] * t[c];
-            e[n] = v + a.b[n];
+            for (int c = 0; c < C; ++c) v += wq[u][c] * t[c];
+            e[u] = v + bq[u];
         }
-        float mu, rstd;
-        ln_stats<E>(e, mu, rstd);
-        float dxh[E];
+        const float mu = group_sum<C>((e[0] + e[1]) + (e[2] + e[3])) * (1.0f / E);
+        float vs = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { e[u] -= mu; vs += e[u] * e[u]; }
+        const float rstd = __builtin_amdgcn_rsqf(group_sum<C>(vs) * (1.0f / E) + LG_EPS);
         float m1 = 0.f, m2 = 0.f;
-        const float4* dxs = reinterpret_cast<const float4*>(a.dx + p * E);
 #pragma unroll
-        for (int k = 0; k < E / 4; ++k) {
-            float4 v = dxs[k];
-            dxh[4 * k] = v.x; dxh[4 * k + 1] = v.y; dxh[4 * k + 2] = v.z; dxh[4 * k + 3] = v.w;
+        for (int u = 0; u < 4; ++u) {
+            e[u] *= rstd;                              // x hat
+            acc[4 * C + 4 + u] += dxh[u] * e[u];       // d gamma
+            acc[4 * C + 8 + u] += dxh[u];              // d beta
+            dxh[u] *= gq[u];
+            m1 += dxh[u];
+            m2 += dxh[u] * e[u];
         }
+        m1 = group_sum<C>(m1) * (1.0f / E);
+        m2 = group_sum<C>(m2) * (1.0f / E);
+        float dt[C];
 #pragma unroll
-        for (int n = 0; n < E; ++n) {
-            const float xh = (e[n] - mu) * rstd;
-            pl[n] += dxh[n] * xh;     // d gamma
-            pl[E + n] += dxh[n];      // d beta
-            dxh[n] *= a.lng[n];
-            m1 += dxh[n];
-            m2 += dxh[n] * xh;
-            e[n] = xh;
+        for (int c = 0; c < C; ++c) dt[c] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float de = rstd * (dxh[u] - m1 - e[u] * m2);
+            acc[4 * C + u] += de;                      // db
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                acc[u * C + c] += de * t[c];           // dW[4q + u][c]
+                dt[c] += wq[u][c] * de;
+            }
         }
-        m1 *= (1.0f / E);
-        m2 *= (1.0f / E);
-        float de[E];
-#pragma unroll
-        for (int n = 0; n < E; ++n) de[n] = rstd * (dxh[n] - m1 - e[n] * m2);
-        float4* deo = reinterpret_cast<float4*>(a.de + p * E);
-#pragma unroll
-        for (int k = 0; k < E / 4; ++k) deo[k] = make_float4(de[4 * k], de[4 * k + 1], de[4 * k + 2], de[4 * k + 3]);
-        float4* tpo = reinterpret_cast<float4*>(a.tp + p * 16);
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-            float v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = (k4 * 4 + u < C) ? t[(k4 * 4 + u) % C] : 0.f;
-            tpo[k4] = make_float4(v[0], v[1], v[2], v[3]);
-        }
+        float dtq = 0.f, zq = 0.f, dwq = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            float dt = 0.f;
-#pragma unroll
-            for (int n = 0; n < E; ++n) dt += a.w[n * C + c] * de[n];
-            pc[c] += dt * zc[c];   // d dww
-            pc[C + c] += dt;       // d dwb
-            a.dz[(b * C + c) * a.HW + s] += dt * a.dww[c];
+            const float full = group_sum<C>(dt[c]);
+            if (q == c) { dtq = full; zq = zc[c]; dwq = dwwv[c]; }
         }
+        acc[4 * C + 12] += dtq * zq;                   // d dww[q]
+        acc[4 * C + 13] += dtq;                        // d dwb[q]
+        if (pv) a.dz[(b * C + q) * a.HW + s] += dtq * dwq;
     }
-    // partial rows: [grid][E] d gamma | [grid][E] d beta | [grid][C] d dww | [grid][C] d dwb
-    const size_t nwg = gridDim.x;
-    float r = block_sum<2 * E>(pl, red);
-    if (threadIdx.x < E) a.part[blockIdx.x * (size_t)E + threadIdx.x] = r;
-    else if (threadIdx.x < 2 * E) a.part[nwg * E + blockIdx.x * (size_t)E + threadIdx.x - E] = r;
-    float r2 = block_sum<2 * C>(pc, red2);
-    if (threadIdx.x < C) a.part[2 * nwg * E + blockIdx.x * (size_t)C + threadIdx.x] = r2;
-    else if (threadIdx.x < 2 * C) a.part[2 * nwg * E + nwg * C + blockIdx.x * (size_t)C + threadIdx.x - C] = r2;
+    // lanes with equal q hold partials of the same outputs: across the wave, then the 4 waves in LDS (fixed order)
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int off = C; off < 64; off <<= 1) v += __shfl_xor(v, off);
+        if (lane < C) red[(wave * C + q) * NACC + i] = v;
+    }
+    __syncthreads();
+    // partial rows of this workgroup: [grid][E*C] dW | [grid][E] db | [grid][E] d gamma | [grid][E] d beta | [grid][C] d dww | [grid][C] d dwb
+    const size_t nwg = gridDim.x, wg = blockIdx.x;
+    for (int i = threadIdx.x; i < C * NACC; i += 256) {
+        const float v = (red[i] + red[C * NACC + i]) + (red[2 * C * NACC + i] + red[3 * C * NACC + i]);
+        const int qq = i / NACC, k = i - qq * NACC;
+        float* base = a.part;
+        if (k < 4 * C) { base[wg * (E * C) + (4 * qq + k / C) * C + (k % C)] = v; continue; }
+        base += nwg * (E * C);
+        if (k < 4 * C + 4) { base[wg * E + 4 * qq + (k - 4 * C)] = v; continue; }
+        base += nwg * E;
+        if (k < 4 * C + 8) { base[wg * E + 4 * qq + (k - 4 * C - 4)] = v; continue; }
+        base += nwg * E;
+        if (k < 4 * C + 12) { base[wg * E + 4 * qq + (k - 4 * C - 8)] = v; continue; }
+        base += nwg * E;
+        if (k == 4 * C + 12) base[wg * C + qq] = v;
+        else base[nwg * C + wg * C + qq] = v;
+    }
 }
 
+size_t embed_bwd_part_floats(int C) { return (size_t)EMBED_BWD_WGS * ((size_t)4 * C * C + 12 * C + 2 * C); }
 int launch_embed_bwd(int C, const EmbedBwdArgs& a, hipStream_t s) {
-    if (!a.part) { lg_set_error("embed_bwd: partial-sum scratch missing"); return -2; }
-    long nb = (a.total + 255) / 256;
-    const int grid = (int)(nb < PIXEL_PART_WGS ? nb : PIXEL_PART_WGS);
-    const int E = 4 * C;
+    if (!a.part || !a.d_w || !a.d_b) { lg_set_error("embed_bwd: partial-sum scratch / weight-gradient destinations missing"); return -2; }
+    const int E = 4 * C, ppw = 256 / C;
+    long nb = (a.total + ppw - 1) / ppw;
+    const int grid = (int)(nb < EMBED_BWD_WGS ? nb : EMBED_BWD_WGS);
     if (C == 4) k_embed_bwd<4, 16><<<grid, 256, 0, s>>>(a);
     else if (C == 8) k_embed_bwd<8, 32><<<grid, 256, 0, s>>>(a);
     else { lg_set_error("embed_bwd: C=%d unsupported", C); return -1; }
     LG_CHECK_LAUNCH();
     const size_t g = (size_t)grid;
-    int rc = launch_reduce_slab_pair(a.part, a.part + g * E, grid, E, a.d_lng, a.d_lnb, s);
+    const float* pw = a.part;
+    const float* pb = pw + g * E * C;
+    const float* pg = pb + g * E;
+    const float* pbt = pg + g * E;
+    const float* pd = pbt + g * E;
+    int rc = launch_reduce_slab_wb(pw, pb, grid, E, C, a.d_w, C, a.d_b, s);
     if (rc) return rc;
-    return launch_reduce_slab_pair(a.part + 2 * g * E, a.part + 2 * g * E + g * C, grid, C, a.d_dww, a.d_dwb, s);
+    rc = launch_reduce_slab_pair(pg, pbt, grid, E, a.d_lng, a.d_lnb, s);
+    if (rc) return rc;
+    return launch_reduce_slab_pair(pd, pd + g * C, grid, C, a.d_dww, a.d_dwb, s);
 }
 
 // ------------------------------------------------------------------------------------------------
