@@ -142,6 +142,7 @@ struct UpFuseBwdArgs {
     float* dskip;     // [B,H,W,E]
     float* v;         // [B,H/2,W/2,E] = up2^T(dt)
     float* dxb;       // [B,H/2,W/2,2E] = Wu^T v
+    float* tmp;       // scratch [B,H,W/2,E]: dt contracted along x (k_upadj_h)
     const float *fw, *upw;
     int B, H, W;
 };

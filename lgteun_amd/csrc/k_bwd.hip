@@ -261,7 +261,7 @@ static int lgt_bwd(const lg_plan* pl, const float* P, float* G, int st, const Ne
     RC(block_bwd(pl, P, G, st, 3, nb.blk[3], bb, posT + 3 * 8192, Cf, Bf, A, B, flags, seed, s));
     // up + fusion
     UpFuseBwdArgs ub;
-    ub.dy = A; ub.dt = bb.dt; ub.dskip = bb.dskip; ub.v = bb.v; ub.dxb = Bf;
+    ub.dy = A; ub.dt = bb.dt; ub.dskip = bb.dskip; ub.v = bb.v; ub.dxb = Bf; ub.tmp = Cf;   // Cf is free until the bottleneck block
     ub.fw = P + pl->lgt(st, L_FUSEW); ub.upw = P + pl->lgt(st, L_UPW);
     ub.B = B; ub.H = c.H; ub.W = c.W;
     RC(launch_upfuse_bwd_a(E, ub, s));

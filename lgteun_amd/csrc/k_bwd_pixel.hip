@@ -437,13 +437,6 @@ int launch_tail_bwd(int C, const TailBwdArgs& a, hipStream_t s) {
 // run across the C lanes with DPP / shuffles, and lane q finishes channel q of the C-channel side (dz, depthwise-1x1 gradients).
 // The 1x1 conv's weight gradient dW[n][c] = sum_p de[p][n] t[p][c] (E x C values) and its bias gradient are accumulated right here
 // in registers: de and the conv input t never reach HBM and the separate weight-gradient launch is gone.
-template <int C>
-__device__ __forceinline__ float group_sum(float v) {   // over the C lanes (4 or 8) of a pixel
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-    if (C == 8) v += __shfl_xor(v, 4);
-    return v;
-}
 #define EMBED_BWD_WGS 1024
 template <int C, int E>
 __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
@@ -488,11 +481,11 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
             for (int c = 0; c < C; ++c) v += wq[u][c] * t[c];
             e[u] = v + bq[u];
         }
-        const float mu = group_sum<C>((e[0] + e[1]) + (e[2] + e[3])) * (1.0f / E);
+        const float mu = lane_group_sum<C>((e[0] + e[1]) + (e[2] + e[3])) * (1.0f / E);
         float vs = 0.f;
 #pragma unroll
         for (int u = 0; u < 4; ++u) { e[u] -= mu; vs += e[u] * e[u]; }
-        const float rstd = __builtin_amdgcn_rsqf(group_sum<C>(vs) * (1.0f / E) + LG_EPS);
+        const float rstd = __builtin_amdgcn_rsqf(lane_group_sum<C>(vs) * (1.0f / E) + LG_EPS);
         float m1 = 0.f, m2 = 0.f;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -503,8 +496,8 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
             m1 += dxh[u];
             m2 += dxh[u] * e[u];
         }
-        m1 = group_sum<C>(m1) * (1.0f / E);
-        m2 = group_sum<C>(m2) * (1.0f / E);
+        m1 = lane_group_sum<C>(m1) * (1.0f / E);
+        m2 = lane_group_sum<C>(m2) * (1.0f / E);
         float dt[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) dt[c] = 0.f;
@@ -521,7 +514,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbedBwdArgs a) {
         float dtq = 0.f, zq = 0.f, dwq = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const float full = group_sum<C>(dt[c]);
+            const float full = lane_group_sum<C>(dt[c]);
             if (q == c) { dtq = full; zq = zc[c]; dwq = dwwv[c]; }
         }
         acc[4 * C + 12] += dtq * zq;                   // d dww[q]
@@ -710,55 +703,84 @@ __global__ __launch_bounds__(256) void k_upfuse_bwd_a(UpFuseBwdArgs a) {
     }
 }
 
+// Second half, SEPARABLY and in the lane = (pixel, channel quad) layout: k_upadj_h contracts the x2 resampler's adjoint along x
+// (dt [B,H,W,E] -> tmp [B,H,W/2,E]), k_upfuse_bwd_b along y and applies Wu^T.  10 + 10 coalesced float4 taps per lane instead of the
+// 10 x 10 window of 64-byte gathers per level-1 pixel of the direct form (92 us -> two launches of ~12 us).
+template <int E>
+__global__ __launch_bounds__(256) void k_upadj_h(const float* __restrict__ dt, float* __restrict__ tmp, int rows, int W) {
+    constexpr int LPP = E / 4, PPW = 256 / LPP;
+    const int q = threadIdx.x % LPP, slot = threadIdx.x / LPP;
+    const int wi = W / 2;
+    const int ix = blockIdx.x * PPW + slot;
+    if (ix >= wi) return;
+    AdjPlan<1> px;
+    px.make(ix, wi, W);
+    for (long row = blockIdx.y; row < rows; row += gridDim.y) {   // row = b * H + y
+        const float* __restrict__ src = dt + (row * W) * E + 4 * q;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const int x = clampi(px.base + k, 0, W - 1);     // clamped taps carry coefficient 0
+            const float4 v = *reinterpret_cast<const float4*>(src + (long)x * E);
+            const float c = px.coef[k];
+            acc.x += c * v.x; acc.y += c * v.y; acc.z += c * v.z; acc.w += c * v.w;
+        }
+        *reinterpret_cast<float4*>(tmp + (row * wi + ix) * E + 4 * q) = acc;
+    }
+}
+
 template <int E>
 __global__ __launch_bounds__(256) void k_upfuse_bwd_b(UpFuseBwdArgs a) {
+    constexpr int LPP = E / 4, PPW = 256 / LPP, NO = 2 * E / LPP, LDU = E + 4;
+    static_assert(NO == 8, "eight outputs per lane");
     __shared__ float sUw[E * 2 * E];
+    __shared__ __attribute__((aligned(16))) float vx[PPW * LDU];
     lds_stage(sUw, a.upw, E * 2 * E);
     __syncthreads();
+    const int q = threadIdx.x % LPP, slot = threadIdx.x / LPP;
     const int hi = a.H / 2, wi = a.W / 2;
-    long total = (long)a.B * hi * wi;
-    long p = blockIdx.x * 256L + threadIdx.x;
-    if (p >= total) return;
-    int ix = (int)(p % wi);
-    long r = p / wi;
-    int iy = (int)(r % hi);
-    long b = r / hi;
-    AdjPlan<1> py, px;
+    const long total = (long)a.B * hi * wi;
+    const long p = (long)blockIdx.x * PPW + slot;
+    const bool pv = p < total;
+    const long pc_ = pv ? p : 0;
+    const int ix = (int)(pc_ % wi);
+    const long r = pc_ / wi;
+    const int iy = (int)(r % hi);
+    const long b = r / hi;
+    AdjPlan<1> py;
     py.make(iy, hi, a.H);
-    px.make(ix, wi, a.W);
+    const float* __restrict__ src = a.tmp + ((b * a.H) * (long)wi + ix) * E + 4 * q;
+    float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const int y = clampi(py.base + k, 0, a.H - 1);
+        const float4 t = *reinterpret_cast<const float4*>(src + (long)y * wi * E);
+        const float c = py.coef[k];
+        v4.x += c * t.x; v4.y += c * t.y; v4.z += c * t.z; v4.w += c * t.w;
+    }
+    if (pv) *reinterpret_cast<float4*>(a.v + p * E + 4 * q) = v4;
+    *reinterpret_cast<float4*>(vx + slot * LDU + 4 * q) = v4;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();     // the lanes of a pixel sit in one wave
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float v[E];
 #pragma unroll
-    for (int k = 0; k < E; ++k) v[k] = 0.f;
-    for (int ya = 0; ya < 10; ++ya) {
-        const float cy = py.coef[ya];
-        if (cy == 0.f) continue;
-        for (int xb = 0; xb < 10; ++xb) {
-            const float cx = px.coef[xb];
-            if (cx == 0.f) continue;
-            const float wgt = cy * cx;
-            const float4* src = reinterpret_cast<const float4*>(a.dt + ((b * a.H + py.base + ya) * (long)a.W + px.base + xb) * E);
-#pragma unroll
-            for (int k = 0; k < E / 4; ++k) {
-                float4 t = src[k];
-                v[4 * k] += wgt * t.x; v[4 * k + 1] += wgt * t.y; v[4 * k + 2] += wgt * t.z; v[4 * k + 3] += wgt * t.w;
-            }
-        }
+    for (int k = 0; k < E / 4; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(vx + slot * LDU + 4 * k);
+        v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
     }
-    float4* vo = reinterpret_cast<float4*>(a.v + p * E);
+    float o[NO];
 #pragma unroll
-    for (int k = 0; k < E / 4; ++k) vo[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
-    float4* dxo = reinterpret_cast<float4*>(a.dxb + p * 2 * E);
+    for (int j = 0; j < NO; ++j) {
+        float acc = 0.f;
 #pragma unroll
-    for (int k4 = 0; k4 < 2 * E / 4; ++k4) {
-        float q[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float acc = 0.f;
-#pragma unroll
-            for (int n = 0; n < E; ++n) acc += sUw[n * 2 * E + k4 * 4 + u] * v[n];
-            q[u] = acc;
-        }
-        dxo[k4] = make_float4(q[0], q[1], q[2], q[3]);
+        for (int n = 0; n < E; ++n) acc += sUw[n * 2 * E + NO * q + j] * v[n];
+        o[j] = acc;
+    }
+    if (pv) {
+        float4* dxo = reinterpret_cast<float4*>(a.dxb + p * 2 * E + NO * q);
+        dxo[0] = make_float4(o[0], o[1], o[2], o[3]);
+        dxo[1] = make_float4(o[4], o[5], o[6], o[7]);
     }
 }
 
@@ -772,11 +794,18 @@ int launch_upfuse_bwd_a(int E, const UpFuseBwdArgs& a, hipStream_t s) {
     return 0;
 }
 int launch_upfuse_bwd_b(int E, const UpFuseBwdArgs& a, hipStream_t s) {
-    long total = (long)a.B * (a.H / 2) * (a.W / 2);
-    int grid = (int)((total + 255) / 256);
+    if (!a.tmp) { lg_set_error("upfuse_bwd: row-contracted scratch missing"); return -2; }
+    if (E != 16 && E != 32) { lg_set_error("upfuse_bwd: E=%d unsupported", E); return -1; }
+    const int ppw = 256 / (E / 4), wi = a.W / 2;
+    const int rows = a.B * a.H;
+    dim3 gh((wi + ppw - 1) / ppw, rows < 1024 ? rows : 1024);
+    if (E == 16) k_upadj_h<16><<<gh, 256, 0, s>>>(a.dt, a.tmp, rows, a.W);
+    else k_upadj_h<32><<<gh, 256, 0, s>>>(a.dt, a.tmp, rows, a.W);
+    LG_CHECK_LAUNCH();
+    const long total = (long)a.B * (a.H / 2) * wi;
+    const int grid = (int)((total + ppw - 1) / ppw);
     if (E == 16) k_upfuse_bwd_b<16><<<grid, 256, 0, s>>>(a);
-    else if (E == 32) k_upfuse_bwd_b<32><<<grid, 256, 0, s>>>(a);
-    else { lg_set_error("upfuse_bwd: E=%d unsupported", E); return -1; }
+    else k_upfuse_bwd_b<32><<<grid, 256, 0, s>>>(a);
     LG_CHECK_LAUNCH();
     return 0;
 }

@@ -141,6 +141,8 @@ __device__ __forceinline__ void emit_g(const float (&x)[E], const float* __restr
 // ------------------------------------------------------------------------------------------------
 // patch_embedding (patch_size 1): dw1x1 -> 1x1 C->E -> LayerNorm(E)        LGT.py:64-88
 // ------------------------------------------------------------------------------------------------
+// (a lane = (pixel, channel quad) form of this kernel measured SLOWER, 21 vs 17 us: its planar input and planar LN-half output want a
+// lane per pixel; only the NHWC store gains)
 template <int C, int E>
 __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
     long p = blockIdx.x * 256L + threadIdx.x;
@@ -180,63 +182,97 @@ int launch_embed(int C, const EmbedArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // encoder down-sampling: bicubic x0.5 (per channel) then 1x1 E->2E          LGT.py:280-281,325-326
 // ------------------------------------------------------------------------------------------------
+// Lane = (output pixel, channel quad): the E/4 lanes of a level-1 pixel each gather ONE float4 per tap, so a wave-load touches whole
+// 64-byte (E = 16) / 128-byte pixel vectors instead of 64 separate 16-byte pieces (a lane per pixel ran at 2.4 TB/s); the resampled vector
+// is exchanged through LDS inside the wave, lane q computes outputs 8q .. 8q+7 of the 1x1 conv and stores 32 contiguous bytes of the
+// pixel's row.  Same tap and channel order as before: same values.
 template <int E>
 __global__ __launch_bounds__(256) void k_down(DownArgs a) {
-    __shared__ float sW[2 * E * E], sB[2 * E];
+    constexpr int LPP = E / 4, PPW = 256 / LPP, NO = 2 * E / LPP, LDU = E + 4;
+    static_assert(NO == 8, "eight outputs per lane");
+    __shared__ float sW[2 * E * E], sB[2 * E], sNg[2 * E], sNb[2 * E];
+    __shared__ __attribute__((aligned(16))) float ux[PPW * LDU];
     lds_stage(sW, a.w, 2 * E * E);
     lds_stage(sB, a.b, 2 * E);
+    if (a.g) { lds_stage(sNg, a.n1g, 2 * E); lds_stage(sNb, a.n1b, 2 * E); }
     __syncthreads();
+    const int q = threadIdx.x % LPP, slot = threadIdx.x / LPP;
     const int ho = a.H / 2, wo = a.W / 2;
-    long total = (long)a.B * ho * wo;
-    long p = blockIdx.x * 256L + threadIdx.x;
-    if (p >= total) return;
-    int ox = (int)(p % wo);
-    long r = p / wo;
-    int oy = (int)(r % ho);
-    long b = r / ho;
+    const long total = (long)a.B * ho * wo;
+    const long p = (long)blockIdx.x * PPW + slot;
+    const bool pv = p < total;
+    const long pc_ = pv ? p : 0;
+    const int ox = (int)(pc_ % wo);
+    const long r = pc_ / wo;
+    const int oy = (int)(r % ho);
+    const long b = r / ho;
     int iy0, ix0;
     float wy[4], wx[4];
     resample_plan<0>(oy, iy0, wy);
     resample_plan<0>(ox, ix0, wx);
-    float u[E];
+    float4 u4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* __restrict__ xin = a.x + 4 * q;
 #pragma unroll
-    for (int k = 0; k < E; ++k) u[k] = 0.f;
     for (int ta = 0; ta < 4; ++ta) {
-        int yy = clampi(iy0 - 1 + ta, 0, a.H - 1);
-        for (int tb = 0; tb < 4; ++tb) {
-            int xx = clampi(ix0 - 1 + tb, 0, a.W - 1);
-            float wgt = wy[ta] * wx[tb];
-            const float4* src = reinterpret_cast<const float4*>(a.x + ((b * a.H + yy) * (long)a.W + xx) * E);
+        const int yy = clampi(iy0 - 1 + ta, 0, a.H - 1);
 #pragma unroll
-            for (int k = 0; k < E / 4; ++k) {
-                float4 v = src[k];
-                u[4 * k] += wgt * v.x; u[4 * k + 1] += wgt * v.y; u[4 * k + 2] += wgt * v.z; u[4 * k + 3] += wgt * v.w;
-            }
+        for (int tb = 0; tb < 4; ++tb) {
+            const int xx = clampi(ix0 - 1 + tb, 0, a.W - 1);
+            const float wgt = wy[ta] * wx[tb];
+            const float4 v = *reinterpret_cast<const float4*>(xin + ((b * a.H + yy) * (long)a.W + xx) * E);
+            u4.x += wgt * v.x; u4.y += wgt * v.y; u4.z += wgt * v.z; u4.w += wgt * v.w;
         }
     }
-    if (a.u_save) {
-        float4* uo = reinterpret_cast<float4*>(a.u_save + p * E);
+    if (a.u_save && pv) *reinterpret_cast<float4*>(a.u_save + p * E + 4 * q) = u4;
+    *reinterpret_cast<float4*>(ux + slot * LDU + 4 * q) = u4;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();     // the lanes of a pixel sit in one wave
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float u[E];
 #pragma unroll
-        for (int k = 0; k < E / 4; ++k) uo[k] = make_float4(u[4 * k], u[4 * k + 1], u[4 * k + 2], u[4 * k + 3]);
+    for (int k = 0; k < E / 4; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(ux + slot * LDU + 4 * k);
+        u[4 * k] = v.x; u[4 * k + 1] = v.y; u[4 * k + 2] = v.z; u[4 * k + 3] = v.w;
     }
-    float o[2 * E];
+    float o[NO];
 #pragma unroll
-    for (int n = 0; n < 2 * E; ++n) {
+    for (int j = 0; j < NO; ++j) {
+        const int n = NO * q + j;
         float v = 0.f;
 #pragma unroll
         for (int k = 0; k < E; ++k) v += sW[n * E + k] * u[k];
-        o[n] = v + sB[n];
+        o[j] = v + sB[n];
     }
-    float4* yo = reinterpret_cast<float4*>(a.y + p * (2 * E));
+    if (pv) {
+        float4* yo = reinterpret_cast<float4*>(a.y + p * (2 * E) + NO * q);
+        yo[0] = make_float4(o[0], o[1], o[2], o[3]);
+        yo[1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    if (a.g) {   // LayerNorm over the 2E outputs of the pixel (its LPP lanes), planar global half = channels E .. 2E-1 = lanes q >= LPP/2
+        float s = 0.f;
 #pragma unroll
-    for (int n = 0; n < 2 * E / 4; ++n) yo[n] = make_float4(o[4 * n], o[4 * n + 1], o[4 * n + 2], o[4 * n + 3]);
-    if (a.g) emit_g<2 * E>(o, a.n1g, a.n1b, a.g, b, (long)oy * wo + ox, (long)ho * wo);
+        for (int j = 0; j < NO; ++j) s += o[j];
+        const float mu = lane_group_sum<LPP>(s) * (1.0f / (2 * E));
+        float vs = 0.f;
+#pragma unroll
+        for (int j = 0; j < NO; ++j) { const float d = o[j] - mu; vs += d * d; }
+        const float rstd = __builtin_amdgcn_rsqf(lane_group_sum<LPP>(vs) * (1.0f / (2 * E)) + LG_EPS);
+        if (pv && q >= LPP / 2) {
+            const long HWo = (long)ho * wo, sp = (long)oy * wo + ox;
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+                const int n = NO * q + j;
+                a.g[(b * E + (n - E)) * HWo + sp] = (o[j] - mu) * rstd * sNg[n] + sNb[n];
+            }
+        }
+    }
 }
 
 int launch_down(int E, const DownArgs& a, hipStream_t s) {
     ProfScope prof__(LG_K_DOWN, s);
-    long total = (long)a.B * (a.H / 2) * (a.W / 2);
-    int grid = (int)((total + 255) / 256);
+    const long total = (long)a.B * (a.H / 2) * (a.W / 2);
+    const int ppw = 256 / (E / 4);
+    int grid = (int)((total + ppw - 1) / ppw);
     if (E == 16) k_down<16><<<grid, 256, 0, s>>>(a);
     else if (E == 32) k_down<32><<<grid, 256, 0, s>>>(a);
     else { lg_set_error("down: E=%d unsupported", E); return -1; }

@@ -3,6 +3,8 @@
 k_ffn_strip<SAVE>, the e=32 fused FFN and the e=64 pair with their backwards), BASELINE configs[4]'s shape (C=8, 256x256 PAN,
 K=8: split-FFT forward AND backward) and two PAN sizes that are not powers of two (Bluestein mixer; pinned directly against the
 reference, not through the oracle).  Plus the two-call backward the data-parallel step uses.  Dropout off."""
+import re
+
 import numpy as np
 import pytest
 import torch
@@ -56,9 +58,17 @@ def test_train_step_vs_reference_gradients(manifest, name, mode):
     # per tensor, on the tensor's own scale (floored at 2e-5).  Allowance: 3e-2, or 3x the reference's OWN fp32-vs-fp64 error on that
     # tensor where that is larger (`self_err`: sums that cancel to ~1e-5 -- FFT-mixer amplitude biases -- are known to a few per cent
     # only in the reference's fp32 itself; measured by tools/gen_goldens.py on the reference)
+    # The noise is a property of the parameter KIND, not of one tensor's single draw: the reference's fp32 conv_amp biases of this golden are
+    # 0.08 % ... 7.2 % off their fp64 values depending on the block, so a tensor's allowance uses the largest self_err among the tensors
+    # of its kind (same name with the block position stripped).  A different but equally valid fp32 summation order (e.g. the LayerNorm
+    # statistics of a producing kernel) moves these cancelling sums by that much.
     self_err = dict(zip(sorted(grads), g['self_err']))
+    kind = lambda k: re.sub(r'^prior_module\.\d+\.((encoder_layers|decoder_layers)\.\d+\.\d+|bottleneck)\.blocks\.\d+\.', 'block.', k)
+    kind_err = {}
+    for k in grads:
+        kind_err[kind(k)] = max(kind_err.get(kind(k), 0.0), float(self_err[k]))
     worst = max((float(np.abs(v - g[k.replace('.', '/')]).max() / max(float(np.abs(g[k.replace('.', '/')]).max()), 2e-5))
-                 / max(3e-2, 3.0 * self_err[k]), k) for k, v in grads.items())
+                 / max(3e-2, 3.0 * kind_err[kind(k)]), k) for k, v in grads.items())
     assert worst[0] < 1.0, worst
     a, b = eng.live_ranges[0][1], eng.live_ranges[1][0]
     assert float(eng.gflat[a:b].abs().max()) == 0.0            # dead-stage slots of the flat gradient buffer: never written
