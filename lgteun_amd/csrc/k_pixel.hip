@@ -330,19 +330,29 @@ __global__ __launch_bounds__(256) void k_upfuse(UpFuseArgs a, int tiles_x, int t
     __syncthreads();
     const int ly = threadIdx.x / TX, lx = threadIdx.x - ly * TX;
     const int oy = Y0 + ly, ox = X0 + lx;
-    if (oy >= a.H || ox >= a.W) return;
-    const long p = (b * a.H + oy) * (long)a.W + ox;
-    // skip-path row requested early: its latency hides under the resample
-    float4 skr[E / 4];
-    {
-        const float4* src = reinterpret_cast<const float4*>(a.skip + p * E);
+    const bool inimg = oy < a.H && ox < a.W;
+    const long p = (b * a.H + min(oy, a.H - 1)) * (long)a.W + min(ox, a.W - 1);
+    // NHWC rows move COALESCED: thread t takes the float4 items t, t + 256, ... of the tile's rows (one tile row = TX pixels = TX * E
+    // contiguous floats) and the per-pixel vectors are exchanged through LDS (a thread reading / writing its own 64-byte pixel vector
+    // touches 64 scattered 16-byte pieces per wave-instruction).  The skip rows are requested here, early: their latency hides under
+    // the resample; they go to LDS once the source-pixel buffer (srcb) is dead.
+    constexpr int Q4 = E / 4, LDT = E + 4;
+    float* stg = reinterpret_cast<float*>(srcb);          // [256][LDT] exchange buffer (srcb is dead after the up-conv above)
+    static_assert(sizeof(srcb) >= 256 * LDT * sizeof(float), "exchange buffer fits the source-pixel buffer");
+    float4 skc[Q4];
+    bool cok[Q4];
 #pragma unroll
-        for (int k = 0; k < E / 4; ++k) skr[k] = src[k];
+    for (int k = 0; k < Q4; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const int px = i / Q4, row = px / TX, col = px - row * TX;
+        cok[k] = Y0 + row < a.H && X0 + col < a.W;
+        skc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cok[k]) skc[k] = reinterpret_cast<const float4*>(a.skip + ((b * a.H + Y0 + row) * (long)a.W + X0 + col) * E)[i - px * Q4];
     }
     int iy0, ix0;
     float wy[4], wx[4];
-    resample_plan<1>(oy, iy0, wy);
-    resample_plan<1>(ox, ix0, wx);
+    resample_plan<1>(min(oy, a.H - 1), iy0, wy);
+    resample_plan<1>(min(ox, a.W - 1), ix0, wx);
     float tt[E];
 #pragma unroll
     for (int n = 0; n < E; ++n) tt[n] = 0.f;
@@ -363,14 +373,36 @@ __global__ __launch_bounds__(256) void k_upfuse(UpFuseArgs a, int tiles_x, int t
     }
 #pragma unroll
     for (int n = 0; n < E; ++n) tt[n] += sFb[n];
-    if (a.t_save) {
-        float4* to = reinterpret_cast<float4*>(a.t_save + p * E);
+    // coalesced item <-> (pixel, float4) mapping of the exchange buffer
+    auto stage_out = [&](const float (&v)[E], float* dst) {
 #pragma unroll
-        for (int k = 0; k < E / 4; ++k) to[k] = make_float4(tt[4 * k], tt[4 * k + 1], tt[4 * k + 2], tt[4 * k + 3]);
+        for (int k = 0; k < Q4; ++k) *reinterpret_cast<float4*>(stg + threadIdx.x * LDT + 4 * k) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < Q4; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            const int px = i / Q4, row = px / TX, col = px - row * TX;
+            if (cok[k]) reinterpret_cast<float4*>(dst + ((b * a.H + Y0 + row) * (long)a.W + X0 + col) * E)[i - px * Q4] =
+                            *reinterpret_cast<const float4*>(stg + px * LDT + 4 * (i - px * Q4));
+        }
+        __syncthreads();
+    };
+    // skip rows: registers -> exchange buffer -> this thread's pixel vector
+#pragma unroll
+    for (int k = 0; k < Q4; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const int px = i / Q4;
+        *reinterpret_cast<float4*>(stg + px * LDT + 4 * (i - px * Q4)) = skc[k];
     }
+    __syncthreads();
     float sk[E];
 #pragma unroll
-    for (int k = 0; k < E / 4; ++k) { sk[4 * k] = skr[k].x; sk[4 * k + 1] = skr[k].y; sk[4 * k + 2] = skr[k].z; sk[4 * k + 3] = skr[k].w; }
+    for (int k = 0; k < Q4; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(stg + threadIdx.x * LDT + 4 * k);
+        sk[4 * k] = v.x; sk[4 * k + 1] = v.y; sk[4 * k + 2] = v.z; sk[4 * k + 3] = v.w;
+    }
+    __syncthreads();
+    if (a.t_save) stage_out(tt, a.t_save);
     float o[E];
 #pragma unroll
     for (int n = 0; n < E; ++n) {
@@ -381,10 +413,8 @@ __global__ __launch_bounds__(256) void k_upfuse(UpFuseArgs a, int tiles_x, int t
         for (int k = 0; k < E; ++k) v += sFw[n * 2 * E + E + k] * sk[k];
         o[n] = v + sFb[E + n];
     }
-    float4* yo = reinterpret_cast<float4*>(a.y + p * E);
-#pragma unroll
-    for (int n = 0; n < E / 4; ++n) yo[n] = make_float4(o[4 * n], o[4 * n + 1], o[4 * n + 2], o[4 * n + 3]);
-    if (a.g) emit_g<E>(o, a.n1g, a.n1b, a.g, b, (long)oy * a.W + ox, (long)a.H * a.W);
+    stage_out(o, a.y);
+    if (a.g && inimg) emit_g<E>(o, a.n1g, a.n1b, a.g, b, (long)oy * a.W + ox, (long)a.H * a.W);
 }
 
 int launch_upfuse(int E, const UpFuseArgs& a, hipStream_t s) {
