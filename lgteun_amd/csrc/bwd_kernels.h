@@ -241,8 +241,11 @@ struct AttnBwdArgs {
     float* dpos_slab;   // [grid][2*64*64] partial pos_emb grads
     const float *ln1g, *ln1b, *qkvw, *qkvb, *projw;
     float *d_ln1g, *d_ln1b;
-    float* part;        // scratch: per-workgroup LN1 partial sums, PIXEL_PART_WGS * 2e floats
+    float *d_qkvw, *d_qkvb;   // e = 16 (attn_bwd_fuses_qkv): to_qkv's weight / bias gradients are accumulated in the epilogue kernel (+=); y1 may be null
+    float* part;        // scratch: per-workgroup partial sums, attn_bwd_part_floats(e) floats
     int B, h, w;
 };
+constexpr bool attn_bwd_fuses_qkv(int e) { return e == 16; }
+inline size_t attn_bwd_part_floats(int e) { return (size_t)PIXEL_PART_WGS * 2 * e + (attn_bwd_fuses_qkv(e) ? (size_t)1024 * ((3 * e / 2) * (e / 2) + 3 * e / 2) : 0); }
 int attn_bwd_grid(int e, int B, int h, int w);
 int launch_attn_bwd(int e, const AttnBwdArgs& a, hipStream_t s);

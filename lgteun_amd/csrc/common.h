@@ -210,14 +210,15 @@ __device__ __forceinline__ void ln_stats(const float (&x)[E], float& mu, float& 
     rstd = __builtin_amdgcn_rsqf(v * (1.0f / E) + LG_EPS);   // v_rsq_f32 (1 ulp) instead of the IEEE sqrt + divide sequence
 }
 
-// sum over an aligned group of N = 4 or 8 consecutive lanes (the lanes of one pixel in the lane = (pixel, channel quad) kernels):
+// sum over an aligned group of N = 4, 8 or 16 consecutive lanes (the lanes of one pixel in the lane = (pixel, channel quad) kernels):
 // DPP quad_perm moves inside the quad (VALU only), one xor-4 shuffle on top for N = 8
 template <int N>
 __device__ __forceinline__ float lane_group_sum(float v) {
-    static_assert(N == 4 || N == 8, "group of 4 or 8 lanes");
+    static_assert(N == 4 || N == 8 || N == 16, "group of 4, 8 or 16 lanes");
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-    if (N == 8) v += __shfl_xor(v, 4);
+    if (N >= 8) v += __shfl_xor(v, 4);
+    if (N >= 16) v += __shfl_xor(v, 8);
     return v;
 }
 // counter-hash RNG for dropout: keep-mask of element idx under seed (keep prob 0.9)

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                 float y1[HC];
 #pragma unroll
                 for (int c = 0; c < HC; ++c) y1[c] = (xv[c] - mu) * rstd * sLn[c] + sLn[HC + c];
-                if (hd == 0) {
+                if (hd == 0 && a.y1) {   // to_qkv's conv input for its weight gradient (null when k_attn_bwd_epi accumulates that itself)
                     float4* y1o = reinterpret_cast<float4*>(a.y1 + p * Y1LD);
 #pragma unroll
                     for (int k = 0; k < Y1LD / 4; ++k)
@@ -281,9 +281,9 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
     for (int idx = threadIdx.x; idx < 64 * 64; idx += NW * 64) slab[idx] = sDpos[(idx >> 6) * PLD + (idx & 63)];
 }
 
-// per-pixel epilogue: dqkv -> to_qkv^T, join the FFT-mixer gradient, LayerNorm-1 backward + residual, LN1 param grads
+// per-pixel epilogue, one lane per pixel (e = 64; the narrower blocks use k_attn_bwd_epi below): dqkv -> to_qkv^T, join the FFT-mixer gradient, LayerNorm-1 backward + residual, LN1 param grads
 template <int E>
-__global__ __launch_bounds__(256) void k_attn_bwd_epi(AttnBwdArgs a, long total) {
+__global__ __launch_bounds__(256) void k_attn_bwd_epi_px(AttnBwdArgs a, long total) {
     constexpr int HC = E / 2, DQLD = (3 * HC + 15) / 16 * 16;
     __shared__ float red[4 * 2 * E];
     float pl[2 * E];
@@ -360,6 +360,126 @@ __global__ __launch_bounds__(256) void k_attn_bwd_epi(AttnBwdArgs a, long total)
     }
 }
 
+// Per-pixel epilogue in the lane = (pixel, channel quad) layout (e = 16, 32): dqkv -> to_qkv^T, join the FFT-mixer gradient, LayerNorm-1
+// backward + residual, LN1 parameter gradients.  The E/4 lanes of a pixel own four channels each, so x / dy / dx move as contiguous 1 KB
+// rows per wave; lane q also owns rows 6q .. 6q+5 of dqkv: it forms their share of to_qkv^T dqkv for every attention channel (the pixel's
+// lanes add up with DPP) and -- FQ, e = 16 -- accumulates those rows of the to_qkv weight gradient dW[c][k] = sum_p dqkv[p][c] y1[p][k]
+// and its bias gradient right here (y1 = LN1(x)[:e/2] is on chip), so the core kernel no longer writes y1 and the separate
+// weight-gradient launch with its second pass over dqkv is gone.
+#define ATTN_EPI_WGS 1024
+template <int E, bool FQ>
+__global__ __launch_bounds__(256) void k_attn_bwd_epi(AttnBwdArgs a, long total) {
+    constexpr int HC = E / 2, DQLD = (3 * HC + 15) / 16 * 16, LPP = E / 4, PPW = 256 / LPP, R = 3 * HC / LPP, LDX = HC + 4;
+    static_assert(R == 6, "six dqkv rows per lane");
+    constexpr int NW_ = FQ ? R * HC + R : 0, NACC = 8 + NW_;
+    __shared__ float red[4 * LPP * NACC];
+    __shared__ __attribute__((aligned(16))) float ex[FQ ? PPW * LDX : 4];
+    const int q = threadIdx.x % LPP, slot = threadIdx.x / LPP, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool attn_half = q < LPP / 2;
+    float wr[R][HC], g1[4], b1[4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < HC; ++k) wr[r][k] = a.qkvw[(R * q + r) * HC + k];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { g1[u] = a.ln1g[4 * q + u]; b1[u] = a.ln1b[4 * q + u]; }
+    float acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+    const long hw = (long)a.h * a.w;
+    for (long p = (long)blockIdx.x * PPW + slot; p < total; p += (long)gridDim.x * PPW) {   // total is a multiple of PPW (launcher)
+        const long b = p / hw, s = p - b * hw;
+        const float4 x4 = *reinterpret_cast<const float4*>(a.x + p * E + 4 * q);
+        const float4 dy4 = *reinterpret_cast<const float4*>(a.dy + p * E + 4 * q);
+        float dq[R];
+#pragma unroll
+        for (int r2 = 0; r2 < R / 2; ++r2) {
+            const float2 v = *reinterpret_cast<const float2*>(a.dqkv + p * DQLD + R * q + 2 * r2);
+            dq[2 * r2] = v.x; dq[2 * r2 + 1] = v.y;
+        }
+        float dgv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!attn_half) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dgv[u] = a.dg[(b * HC + (4 * q + u - HC)) * hw + s];
+        }
+        // LayerNorm statistics over the pixel's E channels
+        const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+        const float mu = lane_group_sum<LPP>((xv[0] + xv[1]) + (xv[2] + xv[3])) * (1.0f / E);
+        float xh[4], vs = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { xh[u] = xv[u] - mu; vs += xh[u] * xh[u]; }
+        const float rstd = __builtin_amdgcn_rsqf(lane_group_sum<LPP>(vs) * (1.0f / E) + LG_EPS);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xh[u] *= rstd;
+        // to_qkv^T dqkv: this lane's six rows for every attention channel, summed over the pixel's lanes
+        float dyf[4] = {dgv[0], dgv[1], dgv[2], dgv[3]};
+#pragma unroll
+        for (int k = 0; k < HC; ++k) {
+            float pt = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) pt += wr[r][k] * dq[r];
+            const float full = lane_group_sum<LPP>(pt);
+            if (q == k / 4) dyf[k & 3] = full;     // k < HC: only attention-half lanes match
+        }
+        if constexpr (FQ) {
+            if (attn_half) *reinterpret_cast<float4*>(ex + slot * LDX + 4 * q) =
+                make_float4(xh[0] * g1[0] + b1[0], xh[1] * g1[1] + b1[1], xh[2] * g1[2] + b1[2], xh[3] * g1[3] + b1[3]);
+        }
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[u] += dyf[u] * xh[u];       // d gamma
+            acc[4 + u] += dyf[u];           // d beta
+            dyf[u] *= g1[u];
+            m1 += dyf[u];
+            m2 += dyf[u] * xh[u];
+        }
+        m1 = lane_group_sum<LPP>(m1) * (1.0f / E);
+        m2 = lane_group_sum<LPP>(m2) * (1.0f / E);
+        // residual with the UNMASKED upstream gradient
+        *reinterpret_cast<float4*>(a.dx + p * E + 4 * q) =
+            make_float4(dy4.x + rstd * (dyf[0] - m1 - xh[0] * m2), dy4.y + rstd * (dyf[1] - m1 - xh[1] * m2),
+                        dy4.z + rstd * (dyf[2] - m1 - xh[2] * m2), dy4.w + rstd * (dyf[3] - m1 - xh[3] * m2));
+        if constexpr (FQ) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();     // the lanes of a pixel sit in one wave
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float yv[HC];
+#pragma unroll
+            for (int k4 = 0; k4 < HC / 4; ++k4) {
+                const float4 t = *reinterpret_cast<const float4*>(ex + slot * LDX + 4 * k4);
+                yv[4 * k4] = t.x; yv[4 * k4 + 1] = t.y; yv[4 * k4 + 2] = t.z; yv[4 * k4 + 3] = t.w;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int k = 0; k < HC; ++k) acc[8 + r * HC + k] += dq[r] * yv[k];
+                acc[8 + R * HC + r] += dq[r];
+            }
+            __builtin_amdgcn_wave_barrier();     // ex is rewritten by the next pixel group
+        }
+    }
+    // lanes with equal q hold partials of the same outputs: across the wave, then the 4 waves in LDS (fixed order)
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int off = LPP; off < 64; off <<= 1) v += __shfl_xor(v, off);
+        if (lane < LPP) red[(wave * LPP + q) * NACC + i] = v;
+    }
+    __syncthreads();
+    // partial rows of this workgroup: [grid][E] d gamma | [grid][E] d beta | (FQ) [grid][3HC * HC] dWqkv | [grid][3HC] dbqkv
+    const size_t nwg = gridDim.x, wg = blockIdx.x;
+    for (int i = threadIdx.x; i < LPP * NACC; i += 256) {
+        const float v = (red[i] + red[LPP * NACC + i]) + (red[2 * LPP * NACC + i] + red[3 * LPP * NACC + i]);
+        const int qq = i / NACC, k = i - qq * NACC;
+        if (k < 4) a.part[wg * E + 4 * qq + k] = v;
+        else if (k < 8) a.part[nwg * E + wg * E + 4 * qq + (k - 4)] = v;
+        else if (k < 8 + R * HC) a.part[2 * nwg * E + wg * (3 * HC * HC) + (R * qq) * HC + (k - 8)] = v;
+        else a.part[2 * nwg * E + nwg * (3 * HC * HC) + wg * (3 * HC) + R * qq + (k - 8 - R * HC)] = v;
+    }
+}
+
 template <int HC, int NW>
 static int grid_t(int B, int h, int w) {
     int nwin = B * (h / 8) * (w / 8);
@@ -392,11 +512,28 @@ static int launch_attn_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
     LG_CHECK_LAUNCH();
     const long total = (long)a.B * a.h * a.w;
     if (!a.part) { lg_set_error("attn_bwd: partial-sum scratch missing"); return -2; }
-    const long nb = (total + 255) / 256;
-    const int egrid = (int)(nb < PIXEL_PART_WGS ? nb : PIXEL_PART_WGS);
-    k_attn_bwd_epi<2 * HC><<<egrid, 256, 0, s>>>(a, total);
-    LG_CHECK_LAUNCH();
-    return launch_reduce_slab_pair(a.part, a.part + (size_t)egrid * 2 * HC, egrid, 2 * HC, a.d_ln1g, a.d_ln1b, s);
+    constexpr int E = 2 * HC;
+    if constexpr (E <= 32) {
+        constexpr int PPW = 256 / (E / 4);
+        constexpr bool FQ = attn_bwd_fuses_qkv(E);
+        if (total % PPW) { lg_set_error("attn_bwd: %ld pixels are not a multiple of %d", total, PPW); return -2; }
+        if (FQ && (!a.d_qkvw || !a.d_qkvb)) { lg_set_error("attn_bwd: to_qkv gradient destinations missing"); return -2; }
+        const long ng = total / PPW;
+        const int egrid = (int)(ng < ATTN_EPI_WGS ? ng : ATTN_EPI_WGS);
+        k_attn_bwd_epi<E, FQ><<<egrid, 256, 0, s>>>(a, total);
+        LG_CHECK_LAUNCH();
+        const size_t g = (size_t)egrid;
+        int rc = launch_reduce_slab_pair(a.part, a.part + g * E, egrid, E, a.d_ln1g, a.d_ln1b, s);
+        if (rc || !FQ) return rc;
+        const float* pw = a.part + 2 * g * E;
+        return launch_reduce_slab_wb(pw, pw + g * (3 * HC * HC), egrid, 3 * HC, HC, a.d_qkvw, HC, a.d_qkvb, s);
+    } else {
+        const long nb = (total + 255) / 256;
+        const int egrid = (int)(nb < PIXEL_PART_WGS ? nb : PIXEL_PART_WGS);
+        k_attn_bwd_epi_px<E><<<egrid, 256, 0, s>>>(a, total);
+        LG_CHECK_LAUNCH();
+        return launch_reduce_slab_pair(a.part, a.part + (size_t)egrid * E, egrid, E, a.d_ln1g, a.d_ln1b, s);
+    }
 }
 
 int launch_attn_bwd(int e, const AttnBwdArgs& a, hipStream_t s) {

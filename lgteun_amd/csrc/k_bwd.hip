@@ -98,7 +98,6 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
     fd.d_dww = G + pl->blk(st, j, B_DWW); fd.d_dwb = G + pl->blk(st, j, B_DWB);
     fd.B = B; fd.h = fb.h; fd.w = fb.w; fd.hbf = hbf; fd.pre = pre;
     RC(launch_ffn_dw_bwd(e, fd, s));
-    RC(wgrad(dy, e, fb.a3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 0, hbf, bb, s, pre));
     Ffn1BwdArgs f1;
     f1.dh2 = bb.dh2; f1.g1 = pre ? fb.a1 : fb.g1; f1.x = fb.xmid; f1.dy = dy; f1.dh1 = bb.dh1; f1.y2 = bb.y2; f1.dx = tmp;
     f1.w2t = bb.w2t; f1.w1t = bb.w1t;
@@ -125,6 +124,8 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         RC(wgrad(bb.dh2, n1, fb.a1, n1, G + pl->blk(st, j, B_W2), n1, G + pl->blk(st, j, B_B2), Pn, n1, n1, n1, n1, hbf, hbf, bb, s, pre));
     if (!ffn1_bwd_fuses_w1(e))
         RC(wgrad(bb.dh1, n1, bb.y2, e, G + pl->blk(st, j, B_W1), e, G + pl->blk(st, j, B_B1), Pn, n1, e, n1, e, hbf, 0, bb, s));
+    // last: dh2's two readers run right behind its producer (Infinity Cache), this one only needs the saved gelu(h3) and dy
+    RC(wgrad(dy, e, fb.a3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 0, hbf, bb, s, pre));
     return 0;
 }
 
@@ -161,16 +162,20 @@ static int mixer_half_bwd(const lg_plan* pl, const float* P, float* G, int st, i
     at.pos = P + pl->blk(st, j, B_POS); at.posT = posT; at.dpos_slab = bb.dpos_slab;
     at.ln1g = P + pl->blk(st, j, B_LN1G); at.ln1b = P + pl->blk(st, j, B_LN1B);
     at.qkvw = P + pl->blk(st, j, B_QKVW); at.qkvb = P + pl->blk(st, j, B_QKVB); at.projw = P + pl->blk(st, j, B_PROJW);
-    at.d_ln1g = G + pl->blk(st, j, B_LN1G); at.d_ln1b = G + pl->blk(st, j, B_LN1B); at.part = bb.rq.take((size_t)PIXEL_PART_WGS * 2 * e);
+    at.d_ln1g = G + pl->blk(st, j, B_LN1G); at.d_ln1b = G + pl->blk(st, j, B_LN1B); at.part = bb.rq.take(attn_bwd_part_floats(e));
+    at.d_qkvw = G + pl->blk(st, j, B_QKVW); at.d_qkvb = G + pl->blk(st, j, B_QKVB);
+    if (attn_bwd_fuses_qkv(e)) at.y1 = nullptr;   // the epilogue kernel forms y1 itself and accumulates the to_qkv weight gradient
     if (!at.part) return -3;
     at.B = B; at.h = fb.h; at.w = fb.w;
     RC(launch_attn_bwd(e, at, s));
     const int grid = attn_bwd_grid(e, B, fb.h, fb.w);
     RC(launch_reduce_slab(bb.dpos_slab, grid, 1, 2 * 64 * 64, G + pl->blk(st, j, B_POS), 2 * 64 * 64, 1, 2 * 64 * 64, s));
     RC(wgrad(dym, e, bb.cat, e, G + pl->blk(st, j, B_PROJW), e, G + pl->blk(st, j, B_PROJB), Pn, e, e, e, e, 0, 0, bb, s));
-    const int y1ld = (hc + 15) / 16 * 16, dqld = (3 * hc + 15) / 16 * 16;
-    RC(wgrad(bb.dqkv, dqld, bb.y1, y1ld, G + pl->blk(st, j, B_QKVW), hc, G + pl->blk(st, j, B_QKVB), Pn, dqld, y1ld, 3 * hc, hc, 0, 0,
-             bb, s));
+    if (!attn_bwd_fuses_qkv(e)) {
+        const int y1ld = (hc + 15) / 16 * 16, dqld = (3 * hc + 15) / 16 * 16;
+        RC(wgrad(bb.dqkv, dqld, bb.y1, y1ld, G + pl->blk(st, j, B_QKVW), hc, G + pl->blk(st, j, B_QKVB), Pn, dqld, y1ld, 3 * hc, hc, 0, 0,
+                 bb, s));
+    }
     return 0;
 }
 

@@ -19,7 +19,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // lanes and 2 loads feed 16 MFMAs.  Output acc[i][j][v] (MFMA row 4g+v, col r) is then dW[n0 + 4(4g+v) + i][k0 + 4r + j].
 // Non-VEC: scalar loads in the natural tile order (tile t = channels 16t .. 16t+15), columns >= n_valid / k_valid read as 0.
 // 4-pixel MFMA steps per batch: narrow blocks have few MFMAs per pixel, so they keep more pixels in flight
-__host__ __device__ constexpr int wgrad_batch(int nt, int kt, bool vec) { return vec ? 4 : (nt + kt <= 2 ? 16 : (nt + kt <= 4 ? 8 : 4)); }
+#ifndef LG_WGRAD_VEC_U
+#define LG_WGRAD_VEC_U 4
+#endif
+#ifndef LG_WGRAD_WGS
+#define LG_WGRAD_WGS 512
+#endif
+__host__ __device__ constexpr int wgrad_batch(int nt, int kt, bool vec) { return vec ? LG_WGRAD_VEC_U : (nt + kt <= 2 ? 16 : (nt + kt <= 4 ? 8 : 4)); }
 
 // XGELU: the stored X is a pre-activation and the conv input is gelu(X) (feed_forward's second and third 1x1 convs when the forward
 // saved h1 / h3 instead of gelu(h1) / gelu(h3)): evaluated on the operand registers, under the loads of the next batch
@@ -320,7 +326,7 @@ static int tiles_per_block(int n16) {   // largest of 4,3,2,1 dividing the tile 
 }
 static long wgrad_splits(int N, int K) {
     const int blocks = (N / 16 / tiles_per_block(N / 16)) * (K / 16 / tiles_per_block(K / 16));
-    long splits = 512 / blocks;   // two waves per SIMD
+    long splits = LG_WGRAD_WGS / blocks;   // two waves per SIMD
     return splits < 1 ? 1 : splits;
 }
 size_t wgrad_slab_floats(int N, int K, long P) {
