@@ -53,6 +53,12 @@ extern "C" {
  * data-step backwards interleave) and are rejected. */
 #define LG_FLAG_CHAINED 32
 
+/* forward, with LG_FLAG_FAITHFUL: leave the K-1 dead-stage LGT forwards (the reference executes them and discards the
+ * result) to a later lgteun_dead_forward call.  They depend on nothing but the data-step outputs, so a training step can enqueue them
+ * on a second stream BEHIND the LGT backward (they reuse the LGT activation buffers) and beside the K data-step backwards + Adam --
+ * a chain of ~40 small latency-bound launches that leaves most of the GPU idle.  Same kernels, same work, same results. */
+#define LG_FLAG_DEFER_DEAD 64
+
 /* kernel ids for the live HIP-event timing facility (lg_prof_*) */
 enum lg_kernel_id {
     LG_K_NONE = 0, LG_K_FFN1, LG_K_FFN2, LG_K_FFT, LG_K_ATTN, LG_K_UPFUSE, LG_K_DOWN, LG_K_EMBED, LG_K_TAIL, LG_K_DATASTEP,
@@ -83,6 +89,13 @@ size_t lg_workspace_bytes(const lg_plan* plan, int32_t B, int32_t train);
 /* Pansharpening.forward (unlg_former.py:50-67).  seed: dropout counter seed (used with LG_FLAG_DROPOUT). */
 int lgteun_forward(const lg_plan* plan, const float* params, const float* ms, const float* pan, float* out,
                    void* workspace, size_t workspace_bytes, int32_t B, int32_t flags, uint64_t seed, void* stream);
+
+/* The dead-stage LGT forwards a forward with LG_FLAG_FAITHFUL | LG_FLAG_DEFER_DEAD left out (unlg_former.py:63-67 for stages
+ * 0..K-2): same workspace, B, flags and seed as that forward.  Overwrites the LGT activation set, so it must be ordered behind the
+ * LGT part of lgteun_backward (LG_FLAG_BWD_LGT) and before the next forward on the workspace; reads only dead-stage parameters
+ * (Adam never touches those) and the data-step outputs. */
+int lgteun_dead_forward(const lg_plan* plan, const float* params, void* workspace, size_t workspace_bytes, int32_t B, int32_t flags,
+                        uint64_t seed, void* stream);
 
 /* Backward of the same graph (autograd of unlg_former.py:50-67): needs the workspace of a forward run
  * with LG_FLAG_SAVE.  dout [B,C,H,W].  Accumulates (+=) into `grads` for the live tensors only

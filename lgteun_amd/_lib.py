@@ -17,6 +17,7 @@ LG_FLAG_DROPOUT = 4
 LG_FLAG_BWD_LGT = 8
 LG_FLAG_BWD_DATA = 16
 LG_FLAG_CHAINED = 32
+LG_FLAG_DEFER_DEAD = 64
 KERNEL_IDS = {n: i for i, n in enumerate(['none', 'ffn1', 'ffn', 'fft', 'attn', 'upfuse', 'down', 'embed', 'tail', 'datastep', 'ffn1_bwd',
                                            'ffn2_bwd', 'fft_bwd', 'attn_bwd', 'wgrad'])}
 
@@ -42,6 +43,7 @@ SIGNATURES = {
                                  c_uint64, c_void_p]),
     'lgteun_backward': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int32,
                                   c_int32, c_uint64, c_void_p]),
+    'lgteun_dead_forward': (c_int32, [c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_int32, c_uint64, c_void_p]),
     'lg_l1_loss': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p]),
     'lg_adam_step': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_float, c_float,
                                c_float, c_float, c_float, c_void_p]),

@@ -322,10 +322,25 @@ extern "C" int lgteun_forward(const lg_plan* plan, const float* params, const fl
         const bool last = (i == c.K - 1);
         if (last) {
             if ((rc = lgt_fwd(plan, params, i, nb.Z[i + 1], out, nb, B, flags, seed, s))) return rc;
-        } else if (flags & LG_FLAG_FAITHFUL) {
+        } else if ((flags & LG_FLAG_FAITHFUL) && !(flags & LG_FLAG_DEFER_DEAD)) {
             // the reference executes these LGTs and discards their result (unlg_former.py:63-67)
             if ((rc = lgt_fwd(plan, params, i, nb.Z[i + 1], nb.deadout, nb, B, flags & ~LG_FLAG_SAVE, seed, s))) return rc;
         }
+    }
+    return 0;
+}
+
+extern "C" int lgteun_dead_forward(const lg_plan* plan, const float* params, void* workspace, size_t workspace_bytes, int32_t B,
+                                   int32_t flags, uint64_t seed, void* stream) {
+    if (!plan || !params || !workspace || B <= 0) { lg_set_error("dead_forward: null/invalid argument"); return -1; }
+    if ((flags & LG_FLAG_CHAINED) || !(flags & LG_FLAG_FAITHFUL)) { lg_set_error("dead_forward: only the faithful unfolding has dead stages"); return -2; }
+    const int train = (flags & LG_FLAG_SAVE) ? 1 : 0;
+    if (workspace_bytes < lg_workspace_bytes(plan, B, train)) { lg_set_error("dead_forward: workspace too small"); return -3; }
+    NetBufs nb;
+    carve(plan, B, train, workspace, nb);
+    for (int i = 0; i + 1 < plan->cfg.K; ++i) {
+        const int rc = lgt_fwd(plan, params, i, nb.Z[i + 1], nb.deadout, nb, B, flags & ~LG_FLAG_SAVE, seed, (hipStream_t)stream);
+        if (rc) return rc;
     }
     return 0;
 }

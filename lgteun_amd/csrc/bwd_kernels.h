@@ -245,7 +245,10 @@ struct AttnBwdArgs {
     float* part;        // scratch: per-workgroup partial sums, attn_bwd_part_floats(e) floats
     int B, h, w;
 };
-constexpr bool attn_bwd_fuses_qkv(int e) { return e == 16; }
+#ifndef LG_ATTN_FUSE_QKV
+#define LG_ATTN_FUSE_QKV 1
+#endif
+constexpr bool attn_bwd_fuses_qkv(int e) { return LG_ATTN_FUSE_QKV && e == 16; }
 inline size_t attn_bwd_part_floats(int e) { return (size_t)PIXEL_PART_WGS * 2 * e + (attn_bwd_fuses_qkv(e) ? (size_t)1024 * ((3 * e / 2) * (e / 2) + 3 * e / 2) : 0); }
 int attn_bwd_grid(int e, int B, int h, int w);
 int launch_attn_bwd(int e, const AttnBwdArgs& a, hipStream_t s);

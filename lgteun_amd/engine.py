@@ -10,12 +10,14 @@ Layout decisions (MI355X-first):
   * one workspace tensor per (B, train) holds every activation; the library allocates nothing.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (LG_FLAG_BWD_DATA, LG_FLAG_BWD_LGT, LG_FLAG_CHAINED, LG_FLAG_DROPOUT, LG_FLAG_FAITHFUL, LG_FLAG_SAVE, LgConfig,
+from ._lib import (LG_FLAG_BWD_DATA, LG_FLAG_BWD_LGT, LG_FLAG_CHAINED, LG_FLAG_DEFER_DEAD, LG_FLAG_DROPOUT, LG_FLAG_FAITHFUL, LG_FLAG_SAVE,
+                   LgConfig,
                    check)
 
 
@@ -119,6 +121,10 @@ class Engine:
         self._ws_pool = {}             # autograd path: released training workspaces by (plan, B, train), see _WsLease
         self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self._seed_ctr = 0
+        # 'faithful' training: the K-1 dead-stage LGT forwards are enqueued on a second stream behind the LGT backward, beside the K
+        # data-step backwards + Adam (a chain of small latency-bound launches); False = one stream, reference order (A/B, tests)
+        self.overlap_dead = os.environ.get('LG_OVERLAP_DEAD', '1') != '0'
+        self._side_stream = None
         self.world = 1
         self.rank = 0
         self.process_group = None
@@ -285,6 +291,9 @@ class Engine:
         seed = self.next_seed()
         self.gflat.zero_()
         self._loss.zero_()
+        defer = bool(self.overlap_dead and (flags & LG_FLAG_FAITHFUL) and not (flags & LG_FLAG_CHAINED) and self.K > 1)
+        if defer:
+            flags |= LG_FLAG_DEFER_DEAD
         out, saved = self.forward_raw(ms, pan, flags, seed)
         gt = gt.contiguous()
         dout = torch.empty_like(out)
@@ -295,18 +304,36 @@ class Engine:
             # every tensor is live and the LGT / data-step backwards interleave: one all-reduce of the whole flat buffer
             self.backward_raw(saved, dout, self.gflat, flags, seed)
             self.buckets[True].all_reduce(self.gflat)
-        elif self.world > 1:
+        elif self.world > 1 or defer:
             # bucket 1 (last stage's LGT) is reduced over RCCL while the K data-step backwards still run
-            bk = self.buckets[False]
+            bk = self.buckets[False] if self.world > 1 else None
             self.backward_raw(saved, dout, self.gflat, flags | LG_FLAG_BWD_LGT, seed)
-            bk.start(self.gflat, 1)
+            if defer:
+                self._dead_forward(saved, flags, seed)
+            if bk:
+                bk.start(self.gflat, 1)
             self.backward_raw(saved, dout, self.gflat, flags | LG_FLAG_BWD_DATA, seed)
-            bk.start(self.gflat, 0)
-            bk.finish()
+            if bk:
+                bk.start(self.gflat, 0)
+                bk.finish()
         else:
             self.backward_raw(saved, dout, self.gflat, flags, seed)
         optim.step_flat(self)
+        if defer:
+            torch.cuda.current_stream().wait_stream(self._side_stream)   # the step ends when its dead-stage work has ended
         return self._loss
+
+    def _dead_forward(self, saved, flags, seed):
+        """the dead-stage LGT forwards of a LG_FLAG_DEFER_DEAD forward, on the side stream: ordered behind everything enqueued so far
+        (the LGT backward has read the saved activations they overwrite), concurrent with what the caller enqueues next"""
+        plan, ws, _, _, B = saved[:5]
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        side = self._side_stream
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            check(self.lib.lgteun_dead_forward(plan, _ptr(self.flat), _ptr(ws), ws.numel(), B, flags, seed, _stream_ptr()),
+                  'lgteun_dead_forward')
 
     def adam(self, state, step, lr, betas, eps, grad_scale=1.0):
         check(self.lib.lg_adam_step(_ptr(self.flat), _ptr(self.gflat), _ptr(state['exp_avg']), _ptr(state['exp_avg_sq']),

@@ -162,3 +162,29 @@ def test_training_converges_on_a_fixed_batch():
         eng.train_step(ms, pan, gt, opt)
     last = float(eng.train_step(ms, pan, gt, opt).item())
     assert np.isfinite(first) and np.isfinite(last) and last < 0.25 * first, (first, last)
+
+
+@pytest.mark.parametrize('drop', [False, True])
+def test_deferred_dead_stage_forwards_change_nothing(drop):
+    """'faithful' training enqueues the K-1 dead-stage LGT forwards on a second stream behind the LGT backward (LG_FLAG_DEFER_DEAD +
+    lgteun_dead_forward); loss, flat gradient and the weights after three Adam steps are bitwise those of the one-stream order, and the
+    dead-stage output the deferred call leaves in the workspace is the one the in-order forward leaves"""
+    from gpu_helpers import make_module
+    from lgteun_amd import FusedAdam
+    ms, pan, gt = (T(a).cuda() for a in dw.make_inputs(4, 4, 32, 32, seed=5, kind='dn'))
+    res = []
+    for overlap in (False, True):
+        torch.manual_seed(1234)
+        net = make_module(4, 4)
+        opt = FusedAdam(net.parameters(), lr=1e-3)
+        opt.dropout = drop
+        eng = net.engine()
+        eng.overlap_dead = overlap
+        losses = []
+        for _ in range(3):
+            losses.append(float(eng.train_step(ms, pan, gt, opt).item()))
+        torch.cuda.synchronize()
+        res.append((losses, eng.gflat.clone(), eng.flat.clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert float(res[1][1].abs().max()) > 0
