@@ -167,8 +167,7 @@ def test_training_converges_on_a_fixed_batch():
 @pytest.mark.parametrize('drop', [False, True])
 def test_deferred_dead_stage_forwards_change_nothing(drop):
     """'faithful' training enqueues the K-1 dead-stage LGT forwards on a second stream behind the LGT backward (LG_FLAG_DEFER_DEAD +
-    lgteun_dead_forward); loss, flat gradient and the weights after three Adam steps are bitwise those of the one-stream order, and the
-    dead-stage output the deferred call leaves in the workspace is the one the in-order forward leaves"""
+    lgteun_dead_forward): the flat gradient and the weights after three Adam steps are bitwise those of the one-stream order"""
     from gpu_helpers import make_module
     from lgteun_amd import FusedAdam
     ms, pan, gt = (T(a).cuda() for a in dw.make_inputs(4, 4, 32, 32, seed=5, kind='dn'))
@@ -185,6 +184,6 @@ def test_deferred_dead_stage_forwards_change_nothing(drop):
             losses.append(float(eng.train_step(ms, pan, gt, opt).item()))
         torch.cuda.synchronize()
         res.append((losses, eng.gflat.clone(), eng.flat.clone()))
-    assert res[0][0] == res[1][0]
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-6, atol=0)   # the logged loss scalar is summed with float atomics (order varies)
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
     assert float(res[1][1].abs().max()) > 0
