@@ -605,44 +605,35 @@ __global__ __launch_bounds__(256) void k_down_bwd_a(DownBwdArgs a) {
     }
 }
 
+// lane = (pixel, channel quad): one float4 of the skip gradient and of each adjoint tap per lane
 template <int E>
 __global__ __launch_bounds__(256) void k_down_bwd_b(DownBwdArgs a) {
-    long total = (long)a.B * a.H * a.W;
-    long p = blockIdx.x * 256L + threadIdx.x;
+    constexpr int LPP = E / 4, PPW = 256 / LPP;
+    const int q = threadIdx.x % LPP, slot = threadIdx.x / LPP;
+    const long total = (long)a.B * a.H * a.W;
+    const long p = (long)blockIdx.x * PPW + slot;
     if (p >= total) return;
-    int ix = (int)(p % a.W);
-    long r = p / a.W;
-    int iy = (int)(r % a.H);
-    long b = r / a.H;
+    const int ix = (int)(p % a.W);
+    const long r = p / a.W;
+    const int iy = (int)(r % a.H);
+    const long b = r / a.H;
     const int ho = a.H / 2, wo = a.W / 2;
     AdjPlan<0> py, px;
     py.make(iy, a.H, ho);
     px.make(ix, a.W, wo);
-    float acc[E];
-    const float4* sk = reinterpret_cast<const float4*>(a.dskip + p * E);
-#pragma unroll
-    for (int k = 0; k < E / 4; ++k) {
-        float4 v = sk[k];
-        acc[4 * k] = v.x; acc[4 * k + 1] = v.y; acc[4 * k + 2] = v.z; acc[4 * k + 3] = v.w;
-    }
+    float4 acc = *reinterpret_cast<const float4*>(a.dskip + p * E + 4 * q);
 #pragma unroll
     for (int ya = 0; ya < 3; ++ya) {
-        if (py.coef[ya] == 0.f) continue;
+        const int yy = clampi(py.base + ya, 0, ho - 1);       // taps outside carry coefficient 0
 #pragma unroll
         for (int xb = 0; xb < 3; ++xb) {
-            if (px.coef[xb] == 0.f) continue;
+            const int xx = clampi(px.base + xb, 0, wo - 1);
             const float wgt = py.coef[ya] * px.coef[xb];
-            const float4* src = reinterpret_cast<const float4*>(a.du + ((b * ho + py.base + ya) * (long)wo + px.base + xb) * E);
-#pragma unroll
-            for (int k = 0; k < E / 4; ++k) {
-                float4 v = src[k];
-                acc[4 * k] += wgt * v.x; acc[4 * k + 1] += wgt * v.y; acc[4 * k + 2] += wgt * v.z; acc[4 * k + 3] += wgt * v.w;
-            }
+            const float4 v = *reinterpret_cast<const float4*>(a.du + ((b * ho + yy) * (long)wo + xx) * E + 4 * q);
+            acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
         }
     }
-    float4* dxo = reinterpret_cast<float4*>(a.dx + p * E);
-#pragma unroll
-    for (int k = 0; k < E / 4; ++k) dxo[k] = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+    *reinterpret_cast<float4*>(a.dx + p * E + 4 * q) = acc;
 }
 
 int launch_down_bwd_a(int E, const DownBwdArgs& a, hipStream_t s) {
@@ -656,7 +647,8 @@ int launch_down_bwd_a(int E, const DownBwdArgs& a, hipStream_t s) {
 }
 int launch_down_bwd_b(int E, const DownBwdArgs& a, hipStream_t s) {
     long total = (long)a.B * a.H * a.W;
-    int grid = (int)((total + 255) / 256);
+    const int ppw = 256 / (E / 4);
+    int grid = (int)((total + ppw - 1) / ppw);
     if (E == 16) k_down_bwd_b<16><<<grid, 256, 0, s>>>(a);
     else if (E == 32) k_down_bwd_b<32><<<grid, 256, 0, s>>>(a);
     else { lg_set_error("down_bwd: E=%d unsupported", E); return -1; }
@@ -667,39 +659,38 @@ int launch_down_bwd_b(int E, const DownBwdArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // up + fusion backward: y = Wf [t ; skip] + bf,  t = Wu up2(xb) + bu  (1x1 conv and resampler commute)
 // ------------------------------------------------------------------------------------------------
+// lane = (pixel, channel quad): dy is exchanged inside the wave through LDS, lane q forms columns 4q .. 4q+3 of both halves of Wf^T dy
 template <int E>
 __global__ __launch_bounds__(256) void k_upfuse_bwd_a(UpFuseBwdArgs a) {
+    constexpr int LPP = E / 4, PPW = 256 / LPP, LDU = E + 4;
     __shared__ float sFw[E * 2 * E];
+    __shared__ __attribute__((aligned(16))) float dx_[PPW * LDU];
     lds_stage(sFw, a.fw, E * 2 * E);
     __syncthreads();
-    long total = (long)a.B * a.H * a.W;
-    long p = blockIdx.x * 256L + threadIdx.x;
-    if (p >= total) return;
-    float dy[E];
-    const float4* src = reinterpret_cast<const float4*>(a.dy + p * E);
+    const int q = threadIdx.x % LPP, slot = threadIdx.x / LPP;
+    const long total = (long)a.B * a.H * a.W;
+    for (long p = (long)blockIdx.x * PPW + slot; p < total; p += (long)gridDim.x * PPW) {   // whole pixels (total is a multiple of PPW)
+        *reinterpret_cast<float4*>(dx_ + slot * LDU + 4 * q) = *reinterpret_cast<const float4*>(a.dy + p * E + 4 * q);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();     // the lanes of a pixel sit in one wave
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float dy[E];
 #pragma unroll
-    for (int k = 0; k < E / 4; ++k) {
-        float4 v = src[k];
-        dy[4 * k] = v.x; dy[4 * k + 1] = v.y; dy[4 * k + 2] = v.z; dy[4 * k + 3] = v.w;
-    }
-    float4* dto = reinterpret_cast<float4*>(a.dt + p * E);
-    float4* dso = reinterpret_cast<float4*>(a.dskip + p * E);
-#pragma unroll
-    for (int k4 = 0; k4 < E / 4; ++k4) {
-        float v[4], q[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float acc = 0.f, acc2 = 0.f;
-#pragma unroll
-            for (int n = 0; n < E; ++n) {
-                acc += sFw[n * 2 * E + k4 * 4 + u] * dy[n];
-                acc2 += sFw[n * 2 * E + E + k4 * 4 + u] * dy[n];
-            }
-            v[u] = acc;
-            q[u] = acc2;
+        for (int k = 0; k < E / 4; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(dx_ + slot * LDU + 4 * k);
+            dy[4 * k] = v.x; dy[4 * k + 1] = v.y; dy[4 * k + 2] = v.z; dy[4 * k + 3] = v.w;
         }
-        dto[k4] = make_float4(v[0], v[1], v[2], v[3]);
-        dso[k4] = make_float4(q[0], q[1], q[2], q[3]);
+        __builtin_amdgcn_wave_barrier();     // dx_ is rewritten by the next pixel group
+        float v[4] = {0.f, 0.f, 0.f, 0.f}, w[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < E; ++n) {
+            const float4 f1 = *reinterpret_cast<const float4*>(sFw + n * 2 * E + 4 * q);
+            const float4 f2 = *reinterpret_cast<const float4*>(sFw + n * 2 * E + E + 4 * q);
+            v[0] += f1.x * dy[n]; v[1] += f1.y * dy[n]; v[2] += f1.z * dy[n]; v[3] += f1.w * dy[n];
+            w[0] += f2.x * dy[n]; w[1] += f2.y * dy[n]; w[2] += f2.z * dy[n]; w[3] += f2.w * dy[n];
+        }
+        *reinterpret_cast<float4*>(a.dt + p * E + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(a.dskip + p * E + 4 * q) = make_float4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -785,11 +776,14 @@ __global__ __launch_bounds__(256) void k_upfuse_bwd_b(UpFuseBwdArgs a) {
 }
 
 int launch_upfuse_bwd_a(int E, const UpFuseBwdArgs& a, hipStream_t s) {
-    long total = (long)a.B * a.H * a.W;
-    int grid = (int)((total + 255) / 256);
+    if (E != 16 && E != 32) { lg_set_error("upfuse_bwd: E=%d unsupported", E); return -1; }
+    const long total = (long)a.B * a.H * a.W;
+    const int ppw = 256 / (E / 4);
+    if (total % ppw) { lg_set_error("upfuse_bwd: %ld pixels are not a multiple of %d", total, ppw); return -2; }
+    const long ng = total / ppw;
+    const int grid = (int)(ng < 2048 ? ng : 2048);
     if (E == 16) k_upfuse_bwd_a<16><<<grid, 256, 0, s>>>(a);
-    else if (E == 32) k_upfuse_bwd_a<32><<<grid, 256, 0, s>>>(a);
-    else { lg_set_error("upfuse_bwd: E=%d unsupported", E); return -1; }
+    else k_upfuse_bwd_a<32><<<grid, 256, 0, s>>>(a);
     LG_CHECK_LAUNCH();
     return 0;
 }
