@@ -36,6 +36,9 @@ extern "C" __attribute__((visibility("default"))) int lg_debug_ffn_stamps(unsign
 #define STAMP(i) do { } while (0)
 #endif
 
+#ifndef LG_XS_SAVE_UNROLL
+#define LG_XS_SAVE_UNROLL 1
+#endif
 namespace {
 
 constexpr int E = 16, N1 = 64, TX = 16, HX = 18, TY = 8, RING = 10, LDR = 68, CH = 48, LDP = 72, CQ = 16;
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
             const int ty = 2 * wave + ch;
-#pragma unroll(SAVE == 1 ? 1 : 4)
+#pragma unroll(SAVE == 1 ? LG_XS_SAVE_UNROLL : 4)
             for (int it = 0; it < 4; ++it) {
                 const int tx = (lane >> 4) + 4 * it;
                 float4 acc = make_float4(bq[0], bq[1], bq[2], bq[3]);
