@@ -55,3 +55,29 @@ __device__ __forceinline__ void resample_tile34(const float* __restrict__ in, in
         U[uy][ux] = acc;
     }
 }
+
+// adjoint coefficients of the 1-D resampler: input index i (size n_in) receives coef[a] * gout[base + a]
+template <int MODE>
+struct AdjPlan {
+    static constexpr int NC = (MODE == 0) ? 3 : 10;
+    int base;
+    float coef[NC];
+    __device__ __forceinline__ void make(int i, int n_in, int n_out) {
+        base = (MODE == 0) ? (i / 2 - 1) : (2 * i - 4);
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            const int o = base + a;
+            float c = 0.f;
+            if (o >= 0 && o < n_out) {
+                int i0;
+                float w[4];
+                resample_plan<MODE>(o, i0, w);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (clampi(i0 - 1 + t, 0, n_in - 1) == i) c += w[t];
+            }
+            coef[a] = c;
+        }
+    }
+};
+
