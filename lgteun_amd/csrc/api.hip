@@ -231,21 +231,26 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     return launch_ffn2(bb.e, a2, s);
 }
 
-static int pos_transpose_stage(const lg_plan* pl, const float* P, int stage, float* posT_stage, hipStream_t s) {
-    const float* src[5];
-    float* dst[5];
-    for (int j = 0; j < 5; ++j) { src[j] = P + pl->blk(stage, j, B_POS); dst[j] = posT_stage + (size_t)j * 2 * 64 * 64; }
-    return launch_pos_transpose_n(5, src, dst, s);
+// pos_emb^T of stages [st0, st1) into nb.posT, all tables in ONE launch (a launch per stage was 5 us + a launch gap each)
+static int pos_transpose_stages(const lg_plan* pl, const float* P, int st0, int st1, float* posT_all, hipStream_t s) {
+    if (st1 <= st0) return 0;
+    const float* src[5 * LG_MAX_K];
+    float* dst[5 * LG_MAX_K];
+    int n = 0;
+    for (int st = st0; st < st1; ++st)
+        for (int j = 0; j < 5; ++j, ++n) { src[n] = P + pl->blk(st, j, B_POS); dst[n] = posT_all + ((size_t)st * 5 + j) * 2 * 64 * 64; }
+    return launch_pos_transpose_n(n, src, dst, s);
 }
 
 // LGT.forward (LGT.py:314-344) on z -> out with the buffers of `nb`
+// pos_ready: nb.posT already holds this stage's transposed pos_emb tables (the net-level entries transpose all stages in one launch)
 static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z, float* out, NetBufs& nb, int B, int flags,
-                   uint64_t seed, hipStream_t s) {
+                   uint64_t seed, hipStream_t s, bool pos_ready = false) {
     const lg_config& c = pl->cfg;
     const int E = 4 * c.C;
     int rc;
     float* posT = nb.posT + (size_t)stage * 5 * 2 * 64 * 64;
-    if ((rc = pos_transpose_stage(pl, P, stage, posT, s))) return rc;
+    if (!pos_ready && (rc = pos_transpose_stages(pl, P, stage, stage + 1, nb.posT, s))) return rc;
     EmbedArgs ea;
     ea.z = z; ea.x = nb.x0; ea.g = nb.blk[0].g;
     ea.dww = P + pl->lgt(stage, L_PE_DWW); ea.dwb = P + pl->lgt(stage, L_PE_DWB);
@@ -306,6 +311,9 @@ extern "C" int lgteun_forward(const lg_plan* plan, const float* params, const fl
     NetBufs nb;
     carve(plan, B, train, workspace, nb);
     int rc;
+    // pos_emb^T of every stage whose LGT runs in this call
+    const bool all_stages = chained || ((flags & LG_FLAG_FAITHFUL) && !(flags & LG_FLAG_DEFER_DEAD));
+    if ((rc = pos_transpose_stages(plan, params, all_stages ? 0 : c.K - 1, c.K, nb.posT, s))) return rc;
     // Z0 = bicubic x4 (unlg_former.py:53)
     if ((rc = launch_resample(2, ms, nb.Z[0], B * c.C, c.H / 4, c.W / 4, s))) return rc;
     if (chained) {
@@ -313,7 +321,7 @@ extern "C" int lgteun_forward(const lg_plan* plan, const float* params, const fl
         for (int i = 0; i < c.K; ++i) {
             if ((rc = data_step_fwd(plan, params, i, nb.X[i], ms, pan, nb.Z[i + 1], nb.t1[i], nb.r[i], nb.s1[i], B, s))) return rc;
             NetBufs sv = (train == 2) ? stage_view(nb, i) : nb;
-            if ((rc = lgt_fwd(plan, params, i, nb.Z[i + 1], i == c.K - 1 ? out : nb.X[i + 1], sv, B, flags, seed, s))) return rc;
+            if ((rc = lgt_fwd(plan, params, i, nb.Z[i + 1], i == c.K - 1 ? out : nb.X[i + 1], sv, B, flags, seed, s, true))) return rc;
         }
         return 0;
     }
@@ -321,10 +329,10 @@ extern "C" int lgteun_forward(const lg_plan* plan, const float* params, const fl
         if ((rc = data_step_fwd(plan, params, i, nb.Z[i], ms, pan, nb.Z[i + 1], nb.t1[i], nb.r[i], nb.s1[i], B, s))) return rc;
         const bool last = (i == c.K - 1);
         if (last) {
-            if ((rc = lgt_fwd(plan, params, i, nb.Z[i + 1], out, nb, B, flags, seed, s))) return rc;
+            if ((rc = lgt_fwd(plan, params, i, nb.Z[i + 1], out, nb, B, flags, seed, s, true))) return rc;
         } else if ((flags & LG_FLAG_FAITHFUL) && !(flags & LG_FLAG_DEFER_DEAD)) {
             // the reference executes these LGTs and discards their result (unlg_former.py:63-67)
-            if ((rc = lgt_fwd(plan, params, i, nb.Z[i + 1], nb.deadout, nb, B, flags & ~LG_FLAG_SAVE, seed, s))) return rc;
+            if ((rc = lgt_fwd(plan, params, i, nb.Z[i + 1], nb.deadout, nb, B, flags & ~LG_FLAG_SAVE, seed, s, true))) return rc;
         }
     }
     return 0;
@@ -338,8 +346,12 @@ extern "C" int lgteun_dead_forward(const lg_plan* plan, const float* params, voi
     if (workspace_bytes < lg_workspace_bytes(plan, B, train)) { lg_set_error("dead_forward: workspace too small"); return -3; }
     NetBufs nb;
     carve(plan, B, train, workspace, nb);
+    {
+        const int rc = pos_transpose_stages(plan, params, 0, plan->cfg.K - 1, nb.posT, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     for (int i = 0; i + 1 < plan->cfg.K; ++i) {
-        const int rc = lgt_fwd(plan, params, i, nb.Z[i + 1], nb.deadout, nb, B, flags & ~LG_FLAG_SAVE, seed, (hipStream_t)stream);
+        const int rc = lgt_fwd(plan, params, i, nb.Z[i + 1], nb.deadout, nb, B, flags & ~LG_FLAG_SAVE, seed, (hipStream_t)stream, true);
         if (rc) return rc;
     }
     return 0;

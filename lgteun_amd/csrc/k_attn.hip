@@ -182,7 +182,9 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
     }
 }
 
-struct PosTArgs { const float* src[5]; float* dst[5]; };
+#include "workspace.h"
+#define LG_MAX_POS_JOBS (5 * LG_MAX_K)
+struct PosTArgs { const float* src[LG_MAX_POS_JOBS]; float* dst[LG_MAX_POS_JOBS]; };
 __global__ void k_pos_transpose(PosTArgs a) {
     // pos [2][64][64] (h,i,j) -> posT [2][64][64] (h,j,i); blockIdx.y = block of the stage
     const float* __restrict__ pos = a.src[blockIdx.y];
@@ -194,9 +196,9 @@ __global__ void k_pos_transpose(PosTArgs a) {
     }
 }
 int launch_pos_transpose_n(int n, const float* const* pos, float* const* posT, hipStream_t s) {
-    if (n < 1 || n > 5) { lg_set_error("pos_transpose: n=%d", n); return -2; }
+    if (n < 1 || n > LG_MAX_POS_JOBS) { lg_set_error("pos_transpose: n=%d", n); return -2; }
     PosTArgs a;
-    for (int j = 0; j < 5; ++j) { a.src[j] = pos[j < n ? j : 0]; a.dst[j] = posT[j < n ? j : 0]; }
+    for (int j = 0; j < LG_MAX_POS_JOBS; ++j) { a.src[j] = pos[j < n ? j : 0]; a.dst[j] = posT[j < n ? j : 0]; }
     k_pos_transpose<<<dim3(32, n), 256, 0, s>>>(a);
     LG_CHECK_LAUNCH();
     return 0;

@@ -10,7 +10,7 @@ struct BwdBufs {
     float *dzA, *dzB, *gu3, *gs1, *gu1, *gr, *gd3, *gt1, *gd1;
     float *dx[3];
     float *dh2, *dh1, *y2, *do2, *dg, *dym, *cat, *y1, *dqkv, *dpos_slab;
-    float *w3t, *w2t, *w1t, *wsp, *dt, *dskip, *v, *du, *fft_scratch;
+    float *w3t[5], *w2t[5], *w1t[5], *wsp, *dt, *dskip, *v, *du, *fft_scratch;   // transposed FFN weights, one set per block of the LGT
     float* slab_arena;    // scratch of the deferred parameter-gradient reductions (ReduceQueue, bwd_kernels.h)
     size_t slab_cap;      // floats
     ReduceQueue rq;
@@ -30,7 +30,7 @@ static void carve_bwd(const lg_plan* plan, int B, void* base, BwdBufs& bb) {
     bb.dym = cv.take(P0 * E); bb.cat = cv.take(P0 * E); bb.y1 = cv.take(P0 * 16 > P0 * E / 2 ? P0 * 16 : P0 * E / 2);
     bb.dqkv = cv.take(P0 * 2 * E);
     bb.dpos_slab = cv.take((size_t)512 * 2 * 64 * 64);
-    bb.w3t = cv.take(8 * E * 2 * E); bb.w2t = cv.take(8 * E * 8 * E); bb.w1t = cv.take(8 * E * 2 * E);
+    for (int j = 0; j < 5; ++j) { bb.w3t[j] = cv.take(8 * E * 2 * E); bb.w2t[j] = cv.take(8 * E * 8 * E); bb.w1t[j] = cv.take(8 * E * 2 * E); }
     bb.wsp = cv.take(ffn_wsplit_bytes(32) / sizeof(float));   // pre-split W2^T / W1^T fragments of k_ffn1_bwd_x32 (e = 32 blocks)
     size_t sl = wgrad_slab_floats((int)(8 * E), (int)(8 * E), (long)P0);
     size_t sl2 = wgrad_slab_floats(64, 64, (long)P0);
@@ -77,21 +77,29 @@ static int wgrad(const void* Y, int ldy, const void* X, int ldx, float* dW, int 
     return launch_wgrad(a, slab, s);
 }
 
-// feed_forward half-block backward: dy (grad wrt block output) -> tmp (grad wrt the mid activation)
+// W3^T / W2^T / W1^T of blocks [j0, j1) of stage st into bb.w?t[j], all in ONE launch (backward GEMMs read transposed weights)
+static int ffn_transposes(const lg_plan* pl, const float* P, int st, int j0, int j1, const NetBufs& nb, BwdBufs& bb, hipStream_t s) {
+    const float* tsrc[15];
+    float* tdst[15];
+    int trows[15], tcols[15], n = 0;
+    for (int j = j0; j < j1; ++j) {
+        const int e = nb.blk[j].e, n1 = 4 * e;
+        tsrc[n] = P + pl->blk(st, j, B_W3); tdst[n] = bb.w3t[j]; trows[n] = e; tcols[n] = n1; ++n;
+        tsrc[n] = P + pl->blk(st, j, B_W2); tdst[n] = bb.w2t[j]; trows[n] = n1; tcols[n] = n1; ++n;
+        tsrc[n] = P + pl->blk(st, j, B_W1); tdst[n] = bb.w1t[j]; trows[n] = n1; tcols[n] = e; ++n;
+    }
+    return launch_transpose3(tsrc, tdst, trows, tcols, n, s);
+}
+
+// feed_forward half-block backward: dy (grad wrt block output) -> tmp (grad wrt the mid activation); bb.w?t[j] hold the transposed weights
 static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int j, const BlockBufs& fb, BwdBufs& bb, const float* dy,
                         float* tmp, int B, hipStream_t s) {
     const int e = fb.e, n1 = 4 * e;
     const int hbf = pl->cfg.precision == 1 ? 1 : 0;   // bf16 storage of the hidden / saved FFN tensors
     const int pre = pl->ffn_saves_preact(e) ? 1 : 0;  // fb.a1 / fb.a3 hold h1 / h3 (fb.g1 / fb.g3 unused): GELU re-evaluated where needed
     const long Pn = (long)B * fb.h * fb.w;
-    {
-        const float* tsrc[3] = {P + pl->blk(st, j, B_W3), P + pl->blk(st, j, B_W2), P + pl->blk(st, j, B_W1)};
-        float* tdst[3] = {bb.w3t, bb.w2t, bb.w1t};
-        const int trows[3] = {e, n1, n1}, tcols[3] = {n1, n1, e};
-        RC(launch_transpose3(tsrc, tdst, trows, tcols, 3, s));
-    }
     FfnDwBwdArgs fd;
-    fd.dy = dy; fd.g3 = pre ? fb.a3 : fb.g3; fd.h2 = fb.h2; fd.dh2 = bb.dh2; fd.w3t = bb.w3t; fd.dww = P + pl->blk(st, j, B_DWW);
+    fd.dy = dy; fd.g3 = pre ? fb.a3 : fb.g3; fd.h2 = fb.h2; fd.dh2 = bb.dh2; fd.w3t = bb.w3t[j]; fd.dww = P + pl->blk(st, j, B_DWW);
     fd.slab_w = bb.rq.take(ffn_dw_bwd_slab_floats(e, B, fb.h, fb.w));
     if (!fd.slab_w) return -3;
     fd.slab_b = fd.slab_w + ffn_dw_bwd_slab_floats(e, B, fb.h, fb.w) / 10 * 9;
@@ -100,7 +108,7 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
     RC(launch_ffn_dw_bwd(e, fd, s));
     Ffn1BwdArgs f1;
     f1.dh2 = bb.dh2; f1.g1 = pre ? fb.a1 : fb.g1; f1.x = fb.xmid; f1.dy = dy; f1.dh1 = bb.dh1; f1.y2 = bb.y2; f1.dx = tmp;
-    f1.w2t = bb.w2t; f1.w1t = bb.w1t;
+    f1.w2t = bb.w2t[j]; f1.w1t = bb.w1t[j];
     f1.ln2g = P + pl->blk(st, j, B_LN2G); f1.ln2b = P + pl->blk(st, j, B_LN2B);
     f1.d_ln2g = G + pl->blk(st, j, B_LN2G); f1.d_ln2b = G + pl->blk(st, j, B_LN2B); f1.part = bb.rq.take((size_t)PIXEL_PART_WGS * 2 * e);
     if (!f1.part) return -3;
@@ -195,8 +203,9 @@ int op_block_bwd(const lg_plan* pl, const float* P, float* G, int st, int j, int
     const BlockBufs& fb = nb.blk[j];
     if (which == 0) return fft_bwd_call(pl, P, G, st, j, fb, dy, dx, B, s, nb.fft_scratch, bb.slab_arena);   // no queue: summed at once
     ReduceQueueScope rqs(bb, s);
-    const int rc = which == 1 ? mixer_half_bwd(pl, P, G, st, j, fb, bb, nb.posT, dy, dx, B, 0, 0, s)
-                              : ffn_half_bwd(pl, P, G, st, j, fb, bb, dy, dx, B, s);
+    int rc = which == 1 ? 0 : ffn_transposes(pl, P, st, j, j + 1, nb, bb, s);
+    if (!rc) rc = which == 1 ? mixer_half_bwd(pl, P, G, st, j, fb, bb, nb.posT, dy, dx, B, 0, 0, s)
+                             : ffn_half_bwd(pl, P, G, st, j, fb, bb, dy, dx, B, s);
     const int rc2 = reduce_queue_end();
     return rc ? rc : rc2;
 }
@@ -256,6 +265,7 @@ static int lgt_bwd(const lg_plan* pl, const float* P, float* G, int st, const Ne
     const long P0 = (long)B * c.H * c.W, P1 = P0 / 4;
     const float* posT = nb.posT + (size_t)st * 5 * 2 * 64 * 64;
     float *A = bb.dx[0], *Bf = bb.dx[1], *Cf = bb.dx[2];
+    RC(ffn_transposes(pl, P, st, 0, 5, nb, bb, s));
     TailBwdArgs tb;
     tb.dout = dout; tb.x = nb.blk[4].xout; tb.dx = A; tb.dz = bb.dzA; tb.w = P + pl->lgt(st, L_TAILW);
     tb.d_w = G + pl->lgt(st, L_TAILW); tb.d_b = G + pl->lgt(st, L_TAILB);   // the conv's own weight gradient comes out of the same kernel

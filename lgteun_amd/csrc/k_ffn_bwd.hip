@@ -11,7 +11,8 @@
 #include "mfma.h"
 #include "hstore.h"
 
-struct TransposeJobs { const float* src[3]; float* dst[3]; int rows[3], cols[3]; };
+#define LG_MAX_TRANSPOSE_JOBS 15   // W3 / W2 / W1 of the five blocks of an LGT in one launch
+struct TransposeJobs { const float* src[LG_MAX_TRANSPOSE_JOBS]; float* dst[LG_MAX_TRANSPOSE_JOBS]; int rows[LG_MAX_TRANSPOSE_JOBS], cols[LG_MAX_TRANSPOSE_JOBS]; };
 __global__ __launch_bounds__(256) void k_transpose(TransposeJobs t) {
     const int q = blockIdx.y;
     const float* __restrict__ src = t.src[q];
@@ -24,10 +25,10 @@ __global__ __launch_bounds__(256) void k_transpose(TransposeJobs t) {
     }
 }
 int launch_transpose3(const float* const* src, float* const* dst, const int* rows, const int* cols, int njobs, hipStream_t s) {
-    if (njobs < 1 || njobs > 3) { lg_set_error("transpose: njobs=%d", njobs); return -2; }
+    if (njobs < 1 || njobs > LG_MAX_TRANSPOSE_JOBS) { lg_set_error("transpose: njobs=%d", njobs); return -2; }
     TransposeJobs t;
     long nmax = 0;
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < LG_MAX_TRANSPOSE_JOBS; ++q) {
         const int u = q < njobs ? q : 0;
         t.src[q] = src[u]; t.dst[q] = dst[u]; t.rows[q] = rows[u]; t.cols[q] = cols[u];
         if ((long)rows[u] * cols[u] > nmax) nmax = (long)rows[u] * cols[u];

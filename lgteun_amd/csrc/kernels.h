@@ -96,7 +96,7 @@ struct AttnArgs {
 int launch_attn(int e, const AttnArgs& a, hipStream_t s);
 // posT[blk] for nblk blocks: src pointers via offsets into params
 int launch_pos_transpose(const float* pos, float* posT, hipStream_t s);
-int launch_pos_transpose_n(int n, const float* const* pos, float* const* posT, hipStream_t s);   // n <= 5 tables in one launch
+int launch_pos_transpose_n(int n, const float* const* pos, float* const* posT, hipStream_t s);   // n <= 5 * LG_MAX_K tables in one launch
 
 // ---------------- feed_forward, LGT.py:91-109 ----------------
 struct Ffn1Args {
