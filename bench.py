@@ -43,6 +43,7 @@ CONFIGS = {   # BASELINE.json configs[...] that fit one GPU: (C, K, PAN size, pa
 C, K, H, B_PER_GPU = CONFIGS['c2'][:4]
 E, P0 = 4 * C, H * H
 
+PROF_EVERY = 4   # live HIP-event timing of the roofline kernel: every 4th step of the timed region
 # kernels that make up the "ffn" launch slot (lg_kernel_id LG_K_FFN2): the fused feed_forward half-block, all variants
 FFN_KERNELS = ('k_ffn_xs', 'k_ffn_x32', 'k_ffn_strip', 'k_ffn_fused')
 PMC_SUMMARIES = {c: os.path.join(ROOT, 'profiles', f'r02_bench_{n}_pmc_hbm.csv') for c, n in (('c2', 'bs32'), ('c3', 'c3'), ('c5', 'c5'))}
@@ -226,27 +227,37 @@ def main():
     warnings.filterwarnings('ignore', message='Detected call of')
     L = _lib.lib()
     kid = _lib.KERNEL_IDS[args.prof_kernel]
-    _lib.check(L.lg_prof_enable(kid, 64 * (args.steps + 1)), 'lg_prof_enable')
+    if kid:   # --prof-kernel none: no HIP events inside the timed region (A/B of their cost; the roofline object is then empty)
+        _lib.check(L.lg_prof_enable(kid, 64 * (args.steps + 1)), 'lg_prof_enable')
     for _ in range(args.warmup):
         step()
-    L.lg_prof_reset()
+    if kid:
+        L.lg_prof_reset()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # the roofline kernel is timed live with HIP events on every PROF_EVERY-th step of the timed region: an event pair costs ~2 us of
+    # stream time, 40 of them per step were 1.1 % of the step (same-box A/B: 7.89 vs 7.80 ms); the sampled launches are still inside
+    # the region and `roofline.launches` says how many there were
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for it in range(args.steps):
+        if kid:
+            L.lg_prof_pause(0 if it % PROF_EVERY == 0 else 1)
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if kid:
+        L.lg_prof_pause(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tot_ms, n_l = ctypes.c_double(), ctypes.c_int64()
-    _lib.check(L.lg_prof_read(ctypes.byref(tot_ms), ctypes.byref(n_l)), 'lg_prof_read')
-    L.lg_prof_disable()
+    if kid:
+        _lib.check(L.lg_prof_read(ctypes.byref(tot_ms), ctypes.byref(n_l)), 'lg_prof_read')
+        L.lg_prof_disable()
     loss = float(eng._loss.item()) * world if world == 1 else None
     side = world == 1 and not args.no_live
     n_side = max(5, args.steps // 2)
@@ -309,7 +320,7 @@ def main():
         pmc_path = PMC_SUMMARIES.get(args.config)
         roof.update(traffic=traffic_from_profile(args.prof_kernel, args.config),
                     traffic_source=os.path.relpath(pmc_path, ROOT) if pmc_path and os.path.exists(pmc_path) else None,
-                    kernel=L.lg_kernel_name(kid).decode(), launches=int(n_l.value),
+                    kernel=L.lg_kernel_name(kid).decode(), launches=int(n_l.value), timed_every_n_steps=PROF_EVERY,
                     avg_launch_us=round(avg_us, 2), algorithmic_bytes_per_launch=int(byts), algorithmic_flops_per_launch=int(flops),
                     hbm_frac=round(f_hbm, 4), mfma_frac_fp32=round(f_mfma, 4), peak_hbm_GBs=PEAK_HBM_GBS,
                     peak_fp32_mfma_TFLOPs=PEAK_F32_MFMA_TFLOPS,

@@ -121,6 +121,7 @@ int lg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
  * ever creates; lg_prof_disable destroys them. */
 int lg_prof_enable(int32_t kernel_id, int32_t max_launches);
 int lg_prof_reset(void);
+void lg_prof_pause(int32_t paused);   /* 1: launches are neither timed nor counted until lg_prof_pause(0) (sampling: an event pair costs ~2 us of stream time) */
 int lg_prof_read(double* total_ms, int64_t* launches);
 void lg_prof_disable(void);
 const char* lg_kernel_name(int32_t kernel_id);

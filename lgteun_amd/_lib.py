@@ -56,6 +56,7 @@ SIGNATURES = {
                               c_void_p]),
     'lg_prof_enable': (c_int32, [c_int32, c_int32]),
     'lg_prof_reset': (c_int32, []),
+    'lg_prof_pause': (None, [c_int32]),
     'lg_prof_read': (c_int32, [POINTER(ctypes.c_double), POINTER(c_int64)]),
     'lg_prof_disable': (None, []),
     'lg_kernel_name': (c_char_p, [c_int32]),

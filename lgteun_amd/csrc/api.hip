@@ -32,19 +32,20 @@ void lg_set_error(const char* fmt, ...) {
 // facility.  `kid` is atomic so that the launch path pays one relaxed load while profiling is off; everything else is under the mutex.
 static struct {
     std::atomic<int> kid{0};
+    std::atomic<int> paused{0};
     int cap = 0, n = 0;
     hipEvent_t* ev = nullptr;  // 2 per launch
     std::mutex mu;
 } g_prof;
 
 void lg_prof_begin(int kid, hipStream_t s) {
-    if (kid != g_prof.kid.load(std::memory_order_relaxed)) return;
+    if (kid != g_prof.kid.load(std::memory_order_relaxed) || g_prof.paused.load(std::memory_order_relaxed)) return;
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if (kid != g_prof.kid.load(std::memory_order_relaxed) || g_prof.n >= g_prof.cap) return;
     hipEventRecord(g_prof.ev[2 * g_prof.n], s);
 }
 void lg_prof_end(int kid, hipStream_t s) {
-    if (kid != g_prof.kid.load(std::memory_order_relaxed)) return;
+    if (kid != g_prof.kid.load(std::memory_order_relaxed) || g_prof.paused.load(std::memory_order_relaxed)) return;
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if (kid != g_prof.kid.load(std::memory_order_relaxed) || g_prof.n >= g_prof.cap) return;
     hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
@@ -56,6 +57,7 @@ static void prof_disable_locked() {
     g_prof.ev = nullptr;
     g_prof.cap = g_prof.n = 0;
     g_prof.kid.store(0);
+    g_prof.paused.store(0);
 }
 extern "C" void lg_prof_disable(void) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
@@ -74,6 +76,9 @@ extern "C" int lg_prof_enable(int32_t kernel_id, int32_t max_launches) {
     g_prof.kid.store(kernel_id);
     return 0;
 }
+// sampling: while paused, launches are neither timed nor counted (an event pair costs ~2 us of stream time; a caller that times whole
+// steps around the kernels keeps that out of most of them).  Toggle between launches of the profiled kernel only.
+extern "C" void lg_prof_pause(int32_t paused) { g_prof.paused.store(paused ? 1 : 0); }
 extern "C" int lg_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.n = 0;
