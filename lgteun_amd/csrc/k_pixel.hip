@@ -289,7 +289,7 @@ int launch_down(int E, const DownArgs& a, hipStream_t s) {
 // added after the resample): the conv runs on a quarter of the pixels and the 16-tap gather reads E channels from LDS instead of
 // 2E channels from HBM with one address per lane (that gather was 280 scattered load instructions per wave, 126 us per call).
 template <int E>
-__global__ __launch_bounds__(256) void k_upfuse(UpFuseArgs a, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_upfuse(UpFuseArgs a, int tiles_x, int tiles_y) {
     constexpr int TY = 8, TX = 32, SY = TY / 2 + 4, SX = TX / 2 + 4, NS = SY * SX /*160*/, LDV = E + 4, Q = 2 * E / 4;
     __shared__ float4 srcb[NS * Q];                          // [NS][2E] level-1 pixels
     __shared__ __attribute__((aligned(16))) float vb[NS * LDV];   // [NS][E] up-conv of them (no bias)
@@ -373,11 +373,37 @@ __global__ __launch_bounds__(256) void k_upfuse(UpFuseArgs a, int tiles_x, int t
     }
 #pragma unroll
     for (int n = 0; n < E; ++n) tt[n] += sFb[n];
-    // coalesced item <-> (pixel, float4) mapping of the exchange buffer
-    auto stage_out = [&](const float (&v)[E], float* dst) {
+    // ---- fusion 1x1 conv (2E -> E) on the matrix cores: out[px][n] = bf[n] + sum_k Wf[n][E + k] skip[px][k] + sum_k Wf[n][k] t[px][k].
+    // The pixel rows pass through the exchange buffer anyway (skip comes in coalesced, t / y go out coalesced), so they ARE the A operand
+    // of v_mfma_f32_16x16x4_f32 (row pitch E + 4: conflict-free ds_read_b32), the weights sit in registers as B fragments and wave w
+    // owns pixels [64 w, 64 w + 64).  As 512 (e = 16) / 2048 (e = 32) FMAs per thread fed by LDS weight broadcasts this was the LDS-bound
+    // bulk of the kernel.
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    constexpr int NTL = E / 16, KS = E / 4;
+    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6, r_ = lane_ & 15, g_ = lane_ >> 4;
+    float bw[2][NTL][KS];
 #pragma unroll
-        for (int k = 0; k < Q4; ++k) *reinterpret_cast<float4*>(stg + threadIdx.x * LDT + 4 * k) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
-        __syncthreads();
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bw[hf][nt][ks] = sFw[(nt * 16 + r_) * 2 * E + hf * E + 4 * ks + g_];
+    f32x4_ acc[4][NTL];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) { const float bz = sFb[E + nt * 16 + r_]; acc[mt][nt] = (f32x4_){bz, bz, bz, bz}; }
+    auto gemm_half = [&](int hf) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float av = stg[(64 * wave_ + 16 * mt + r_) * LDT + 4 * ks + g_];
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[hf][nt][ks], acc[mt][nt], 0, 0, 0);
+            }
+    };
+    auto rows_out = [&](float* dst) {   // coalesced store of the tile's rows from the exchange buffer
 #pragma unroll
         for (int k = 0; k < Q4; ++k) {
             const int i = threadIdx.x + 256 * k;
@@ -385,9 +411,8 @@ __global__ __launch_bounds__(256) void k_upfuse(UpFuseArgs a, int tiles_x, int t
             if (cok[k]) reinterpret_cast<float4*>(dst + ((b * a.H + Y0 + row) * (long)a.W + X0 + col) * E)[i - px * Q4] =
                             *reinterpret_cast<const float4*>(stg + px * LDT + 4 * (i - px * Q4));
         }
-        __syncthreads();
     };
-    // skip rows: registers -> exchange buffer -> this thread's pixel vector
+    // skip rows: registers -> exchange buffer
 #pragma unroll
     for (int k = 0; k < Q4; ++k) {
         const int i = threadIdx.x + 256 * k;
@@ -395,26 +420,33 @@ __global__ __launch_bounds__(256) void k_upfuse(UpFuseArgs a, int tiles_x, int t
         *reinterpret_cast<float4*>(stg + px * LDT + 4 * (i - px * Q4)) = skc[k];
     }
     __syncthreads();
-    float sk[E];
-#pragma unroll
-    for (int k = 0; k < Q4; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(stg + threadIdx.x * LDT + 4 * k);
-        sk[4 * k] = v.x; sk[4 * k + 1] = v.y; sk[4 * k + 2] = v.z; sk[4 * k + 3] = v.w;
-    }
+    gemm_half(1);
     __syncthreads();
-    if (a.t_save) stage_out(tt, a.t_save);
-    float o[E];
+    // t rows (up path): this thread's pixel vector -> exchange buffer
 #pragma unroll
-    for (int n = 0; n < E; ++n) {
-        float v = 0.f;
+    for (int k = 0; k < Q4; ++k) *reinterpret_cast<float4*>(stg + threadIdx.x * LDT + 4 * k) = make_float4(tt[4 * k], tt[4 * k + 1], tt[4 * k + 2], tt[4 * k + 3]);
+    __syncthreads();
+    if (a.t_save) rows_out(a.t_save);
+    gemm_half(0);
+    __syncthreads();
+    // output rows: accumulator layout (lane (r, g): pixels 4g + v, channel r) -> exchange buffer
 #pragma unroll
-        for (int k = 0; k < E; ++k) v += sFw[n * 2 * E + k] * tt[k];
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int k = 0; k < E; ++k) v += sFw[n * 2 * E + E + k] * sk[k];
-        o[n] = v + sFb[E + n];
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) stg[(64 * wave_ + 16 * mt + 4 * g_ + v) * LDT + nt * 16 + r_] = acc[mt][nt][v];
+    __syncthreads();
+    rows_out(a.y);
+    if (a.g && inimg) {
+        float o[E];
+#pragma unroll
+        for (int k = 0; k < Q4; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(stg + threadIdx.x * LDT + 4 * k);
+            o[4 * k] = v.x; o[4 * k + 1] = v.y; o[4 * k + 2] = v.z; o[4 * k + 3] = v.w;
+        }
+        emit_g<E>(o, a.n1g, a.n1b, a.g, b, (long)oy * a.W + ox, (long)a.H * a.W);
     }
-    stage_out(o, a.y);
-    if (a.g && inimg) emit_g<E>(o, a.n1g, a.n1b, a.g, b, (long)oy * a.W + ox, (long)a.H * a.W);
 }
 
 int launch_upfuse(int E, const UpFuseArgs& a, hipStream_t s) {
