@@ -142,11 +142,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 
     // h2 of halo rows [ya, ya + nr) x columns [x0 - 1, x0 + 17) -> ring   (nr = 2: strip prologue, 8: one step).
     // pre / pre_in: chunk 0's x vector, fetched by the caller ahead of time.
-    auto compute_rows = [&](int ya, int nr, float4 pre, bool pre_in) {
+    // after_first: run right behind the consumption of the prefetched chunk-0 vector.  gfx950 counts loads AND stores in one in-order
+    // counter, and with the exec-masked branches around them the compiler waits with vmcnt(0) there: anything issued before that point
+    // (the step's residual-row loads, which need the whole step to land) would be waited for on the spot.
+    auto compute_rows = [&](int ya, int nr, float4 pre, bool pre_in, auto&& after_first) {
         const int npx = nr * HX, nchunks = (npx + CH - 1) / CH;
         __syncthreads();                 // the previous phase's readers of the aliased region (gelu(h3) pieces) are done
         STAMP(1);
         ln_store(0, pre, pre_in);
+        after_first();
         STAMP(2);
         __syncthreads();
         STAMP(3);
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         float4 pre;
         bool pin;
         ln_fetch(Y0 - 1, 2 * HX, 0, pre, pin);
-        compute_rows(Y0 - 1, 2, pre, pin);
+        compute_rows(Y0 - 1, 2, pre, pin, [] {});
     }
     float4 pre;
     bool pin;
@@ -248,16 +252,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     stamp_on = (y0 == Y0 + 2 * TY) && strip == 0;
 #endif
     STAMP(0);
-    // the residual rows of the epilogue are requested first: their HBM round trip hides under the whole step.
-    // wave w owns tile rows 2 w and 2 w + 1; lane (r, g): pixel x0 + r, channels 4 g .. 4 g + 3
+    // the residual rows of the epilogue are requested early (right behind the first wait of the step, see compute_rows): their HBM
+    // round trip hides under the whole step.  wave w owns tile rows 2 w and 2 w + 1; lane (r, g): pixel x0 + r, channels 4 g .. 4 g + 3
     float4 xres[2];
+    compute_rows(y0 + 1, TY, pre, pin, [&] {
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-        const int y = y0 + 2 * wave + ch, x = x0 + r;
-        xres[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y < Yend && x < w) xres[ch] = *reinterpret_cast<const float4*>(a2.x + ((b * h + y) * (long)w + x) * E + 4 * g);
-    }
-    compute_rows(y0 + 1, TY, pre, pin);
+        for (int ch = 0; ch < 2; ++ch) {
+            const int y = y0 + 2 * wave + ch, x = x0 + r;
+            xres[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y < Yend && x < w) xres[ch] = *reinterpret_cast<const float4*>(a2.x + ((b * h + y) * (long)w + x) * E + 4 * g);
+        }
+    });
     if (y0 + TY < Yend) ln_fetch(y0 + TY + 1, TY * HX, 0, pre, pin);   // next step's first chunk: in flight during P2
     float wq[4][9], bq[4];
     {
