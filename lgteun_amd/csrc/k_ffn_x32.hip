@@ -135,10 +135,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (lq == 0) sMask[slot][lpx] = m_;
     };
 
-    auto compute_rows = [&](int ya, int nr, float4 pre, bool pre_in) {
+    // after_first: runs right behind the consumption of the prefetched chunk-0 vector (the compiler's wait there is vmcnt(0): loads issued
+    // before it would be waited for on the spot -- k_ffn_x.hip)
+    auto compute_rows = [&](int ya, int nr, float4 pre, bool pre_in, auto&& after_first) {
         const int npx = nr * HX, nchunks = (npx + CH - 1) / CH;
         __syncthreads();                 // the previous phase's readers of the aliased region (gelu(h3) pieces) are done
         ln_store(0, pre, pre_in);
+        after_first();
         __syncthreads();
         const int ring0 = ((ya - Y0 + 1) % RING) * HX;
         for (int c = 0; c < nchunks; ++c) {
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float4 pre;
         bool pin;
         ln_fetch(Y0 - 1, 2 * HX, 0, pre, pin);
-        compute_rows(Y0 - 1, 2, pre, pin);
+        compute_rows(Y0 - 1, 2, pre, pin, [] {});
     }
     float4 pre;
     bool pin;
@@ -235,15 +238,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // wave w owns tile row w; lane (r, g): pixel x0 + r, output channels 16 mb + 4 g .. + 3 (mb = 0, 1)
     const int ty = wave;
     float4 xres[2];
-    {
+    compute_rows(y0 + 1, TY, pre, pin, [&] {
         const int y = y0 + ty, x = x0 + r;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             xres[mb] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (y < Yend && x < w) xres[mb] = *reinterpret_cast<const float4*>(a2.x + ((b * h + y) * (long)w + x) * E + 16 * mb + 4 * g);
         }
-    }
-    compute_rows(y0 + 1, TY, pre, pin);
+    });
     if (y0 + TY < Yend) ln_fetch(y0 + TY + 1, TY * HX, 0, pre, pin);   // next step's first chunk: in flight during the output phase
     // ---- output phase: per K-half: dw3x3 over the ring + GELU -> pieces -> GEMM3 partial ; then bias + residual -> y (+ planar LN half)
     {
