@@ -1,7 +1,9 @@
 // Backward of the pixelwise / resampling kernels (k_pixel.hip) for gfx950: data module (D, DT, R, RT, eta),
 // LGT tail / patch_embed / down / up+fusion.  Autograd of reference models/unlg_former.py:29-37,58-61 and
-// models/common/LGT.py:64-88,280-281,294-295,302-303.  Small parameter gradients (a few floats per tensor) are
-// reduced per workgroup and added with float atomics; all 1x1-conv weight gradients go through k_wgrad.hip.
+// models/common/LGT.py:64-88,280-281,294-295,302-303.  Small parameter gradients (a few floats per tensor) leave every workgroup as a
+// partial row and are summed in a fixed order by the deferred reduce launch (bwd_kernels.h: no float atomics, bitwise reproducible);
+// the tail's and patch_embed's own 1x1-conv weight gradients are accumulated in their backward kernels, the other 1x1 convs' go
+// through k_wgrad.hip.  Kernels whose traffic is NHWC rows use lane = (pixel, channel quad); planar ones one lane per pixel.
 #include <string.h>
 
 #include "kernels.h"
