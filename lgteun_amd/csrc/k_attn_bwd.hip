@@ -221,10 +221,13 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                 }
                 if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
-            float* co = a.cat + p * E + hd * D;
-            float* dq_o = a.dqkv + p * DQLD + hd * D;
+            float4* co = reinterpret_cast<float4*>(a.cat + p * E + hd * D);      // 16-byte stores (as scalar loops the two possibly
+            float4* dq_o = reinterpret_cast<float4*>(a.dqkv + p * DQLD + hd * D);  // aliasing destinations compiled to 2 D dword stores)
 #pragma unroll
-            for (int c = 0; c < D; ++c) { co[c] = O[c]; dq_o[c] = dqh[c] * scale; }
+            for (int c4 = 0; c4 < D / 4; ++c4) {
+                co[c4] = make_float4(O[4 * c4], O[4 * c4 + 1], O[4 * c4 + 2], O[4 * c4 + 3]);
+                dq_o[c4] = make_float4(dqh[4 * c4] * scale, dqh[4 * c4 + 1] * scale, dqh[4 * c4 + 2] * scale, dqh[4 * c4 + 3] * scale);
+            }
             sSt[lane * 4 + 0] = mx;
             sSt[lane * 4 + 1] = inv;
             sSt[lane * 4 + 2] = Dv;
@@ -262,10 +265,13 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                     dkh[4 * c4] += dS * qi[c4].x; dkh[4 * c4 + 1] += dS * qi[c4].y; dkh[4 * c4 + 2] += dS * qi[c4].z; dkh[4 * c4 + 3] += dS * qi[c4].w;
                 }
             }
-            float* dk_o = a.dqkv + p * DQLD + HC + hd * D;
-            float* dv_o = a.dqkv + p * DQLD + 2 * HC + hd * D;
+            float4* dk_o = reinterpret_cast<float4*>(a.dqkv + p * DQLD + HC + hd * D);
+            float4* dv_o = reinterpret_cast<float4*>(a.dqkv + p * DQLD + 2 * HC + hd * D);
 #pragma unroll
-            for (int c = 0; c < D; ++c) { dk_o[c] = dkh[c]; dv_o[c] = dvh[c]; }
+            for (int c4 = 0; c4 < D / 4; ++c4) {
+                dk_o[c4] = make_float4(dkh[4 * c4], dkh[4 * c4 + 1], dkh[4 * c4 + 2], dkh[4 * c4 + 3]);
+                dv_o[c4] = make_float4(dvh[4 * c4], dvh[4 * c4 + 1], dvh[4 * c4 + 2], dvh[4 * c4 + 3]);
+            }
         }
     }
     __syncthreads();
