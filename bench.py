@@ -181,6 +181,9 @@ def main():
     C, K, H, B_PER_GPU, label = CONFIGS[args.config]
     E, P0 = 4 * C, H * H
 
+    if os.environ.get('LG_BENCH_WATCHDOG'):   # diagnostic: dump every thread's Python stack and exit if the run takes longer than N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['LG_BENCH_WATCHDOG']), exit=True)
     from lgteun_amd import ddp
     rank, world, local_rank = ddp.env_world()
     if world != args.gpus:
