@@ -212,9 +212,17 @@ def main():
     sched = torch.optim.lr_scheduler.StepLR(opt, step_size=25900, gamma=0.85)              # :86, stepped every iteration
     ms, pan, gt = synth_batch(B_PER_GPU, rank, device)
 
+    trace = os.environ.get('LG_BENCH_TRACE')   # diagnostic: per-step wall time of every rank (synchronises each step)
+    nstep = [0]
+
     def step():
+        t_ = time.perf_counter()
         eng.train_step(ms, pan, gt, opt)
         sched.step()
+        if trace:
+            torch.cuda.synchronize()
+            nstep[0] += 1
+            print(f'[rank {rank}] step {nstep[0]} {1e3 * (time.perf_counter() - t_):.1f} ms', file=sys.stderr, flush=True)
 
     def timed(fn, n_warm, n):
         for _ in range(n_warm):

@@ -52,6 +52,13 @@ class GradBuckets:
 
     def start(self, flat_grad, which):
         a, b = self.ranges[which]
+        # gloo on device tensors (the N-ranks-on-one-GPU rehearsal of bench.py / tests, never the production transport) runs its
+        # collectives on host threads that copy through pinned memory: with two of them outstanding beside a stream that keeps
+        # receiving work, a 4-rank rehearsal stalled for seconds and then for good (every rank in finish(); blocking collectives: fine).
+        # RCCL collectives are stream-ordered and stay asynchronous.  LG_DDP_SYNC=1 forces the blocking form for any backend.
+        if os.environ.get('LG_DDP_SYNC') == '1' or (flat_grad.is_cuda and dist.get_backend(self.group) == 'gloo'):
+            dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group)
+            return
         w = dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append(w)
 
