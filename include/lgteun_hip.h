@@ -126,6 +126,11 @@ int lg_prof_read(double* total_ms, int64_t* launches);
 void lg_prof_disable(void);
 const char* lg_kernel_name(int32_t kernel_id);
 
+/* The dropout the LGMixers apply in train mode (nn.Dropout(0.1) behind proj, LGT.py:197-198,215): out[i] = 0 or 1/0.9 = the factor of
+ * element i (= pixel * e + channel, NHWC) of block `blk` of stage `stage` under `seed` -- a counter hash, so forward and backward draw the
+ * same mask without storing it, and an integrator can reproduce it.  n elements from index `first`; out is a device pointer. */
+int lg_dropout_mask(uint64_t seed, int32_t stage, int32_t blk, int64_t first, int64_t n, float* out, void* stream);
+
 /* ---- per-op entry points (unit-tested against the oracle; same kernels the orchestrators launch) ---- */
 /* bmu.sampling_ bicubic (basic_module_unformer_v2.py:21-23): mode 0: x0.5, 1: x2, 2: x4.  x [planes,hi,wi]. */
 int lg_op_resample(const float* x, float* y, int32_t planes, int32_t hi, int32_t wi, int32_t mode, void* stream);

@@ -54,6 +54,7 @@ SIGNATURES = {
                             c_void_p]),
     'lg_op_block': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_int32,
                               c_void_p]),
+    'lg_dropout_mask': (c_int32, [c_uint64, c_int32, c_int32, c_int64, c_int64, c_void_p, c_void_p]),
     'lg_prof_enable': (c_int32, [c_int32, c_int32]),
     'lg_prof_reset': (c_int32, []),
     'lg_prof_pause': (None, [c_int32]),

@@ -511,6 +511,18 @@ extern "C" int lg_op_lgt_bwd(const lg_plan* plan, const float* params, float* gr
 // ------------------------------------------------------------------------------------------------
 // 16-byte accesses, four of them in flight per thread, and at most 256 workgroups: every workgroup ends in one float atomic on the
 // loss scalar, and those serialise in L2 (the 1024-workgroup scalar-load form spent its 21 us there and in load latency)
+__global__ __launch_bounds__(256) void k_dropout_mask(uint64_t seed, long first, long n, float* __restrict__ out) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) out[i] = dropout_scale(seed, (uint64_t)(first + i));
+}
+extern "C" int lg_dropout_mask(uint64_t seed, int32_t stage, int32_t blk, int64_t first, int64_t n, float* out, void* stream) {
+    if (!out || n < 0 || first < 0 || stage < 0 || stage >= LG_MAX_K || blk < 0 || blk > 4) { lg_set_error("dropout_mask: invalid argument"); return -1; }
+    if (n == 0) return 0;
+    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    k_dropout_mask<<<grid, 256, 0, (hipStream_t)stream>>>(mix_seed(seed, stage, blk), first, n, out);
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void k_l1(const float* __restrict__ out, const float* __restrict__ gt, float* __restrict__ dout,
                                             float* loss_accum, long n, float inv_n, float gscale) {
     float part = 0.f;

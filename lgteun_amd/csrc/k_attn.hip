@@ -116,6 +116,16 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
 #pragma unroll
                 for (int k = 0; k < E / 4; ++k) xres[k] = reinterpret_cast<const float4*>(a.x + p * E)[k];
             }
+            // dropout keep-bits of this pixel's E outputs, drawn here (one register across the softmax) rather than in the epilogue, where
+            // the hash temporaries pushed the kernel over the three-waves-per-SIMD register budget
+            uint32_t keep[(E + 31) / 32];
+#pragma unroll
+            for (int n = 0; n < (E + 31) / 32; ++n) keep[n] = 0xffffffffu;
+            if (a.dropout) {
+#pragma unroll
+                for (int n = 0; n < E; ++n)
+                    if (dropout_scale(a.seed, (uint64_t)(p * E + n)) == 0.0f) keep[n >> 5] &= ~(1u << (n & 31));
+            }
             float o1[HC];
 #pragma unroll
             for (int hd = 0; hd < 2; ++hd) {
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
 #pragma unroll
                     for (int k = 0; k < HC; ++k) v += sWproj[n * E + HC + k] * o2[k];
                     v += sBias[3 * HC + n];
-                    if (a.dropout) v *= dropout_scale(a.seed, (uint64_t)(p * E + n));
+                    v = (keep[n >> 5] >> (n & 31)) & 1u ? (a.dropout ? v * (1.0f / 0.9f) : v) : 0.0f;
                     o[u] = v;
                 }
                 const float4 xr = PRE ? xres[n4] : reinterpret_cast<const float4*>(a.x + p * E)[n4];

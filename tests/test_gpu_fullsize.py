@@ -187,3 +187,48 @@ def test_deferred_dead_stage_forwards_change_nothing(drop):
     assert np.allclose(res[0][0], res[1][0], rtol=1e-6, atol=0)   # the logged loss scalar is summed with float atomics (order varies)
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
     assert float(res[1][1].abs().max()) > 0
+
+
+def _dropout_mask_numpy(seed, stage, blk, first, n):
+    """numpy restatement of csrc/common.h mix_seed + dropout_scale (test infrastructure only)"""
+    M = (1 << 64) - 1
+    z = (seed + 0x9E3779B97F4A7C15 * (stage * 8 + blk + 1)) & M
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    z ^= z >> 31
+    idx = np.arange(first, first + n, dtype=np.uint64)
+    x = (idx + np.uint64(z & 0xffffffff)).astype(np.uint32)
+    x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d)
+    x ^= np.uint32(z >> 32) ^ (idx >> np.uint64(32)).astype(np.uint32)
+    x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b)
+    x ^= x >> np.uint32(16)
+    return np.where(x < np.uint32(429496730), np.float32(0), np.float32(1.0 / 0.9))
+
+
+def test_dropout_mask_rate_independence_and_restatement():
+    """lg_dropout_mask exposes the counter-hash mask of the LGMixer dropout: it equals the numpy restatement bit for bit, drops 10 % of
+    the elements (within 4 sigma, per seed / stage / block and per channel position), neighbouring elements and neighbouring seeds are
+    uncorrelated, and indices beyond 2^32 are well defined"""
+    from lgteun_amd import _lib
+    from lgteun_amd.engine import _ptr, _stream_ptr
+    lib = _lib.lib()
+    n = 1 << 20
+    out = torch.empty(n, device='cuda')
+    masks = {}
+    for seed, stage, blk, first in ((1234, 0, 0, 0), (1235, 0, 0, 0), (1234, 3, 4, 0), (2 ** 63 + 77, 1, 2, 0), (1234, 0, 0, (1 << 33) + 5)):
+        _lib.check(lib.lg_dropout_mask(seed, stage, blk, first, n, _ptr(out), _stream_ptr()), 'lg_dropout_mask')
+        got = out.cpu().numpy()
+        np.testing.assert_array_equal(got, _dropout_mask_numpy(seed, stage, blk, first, n))
+        drop = got == 0
+        sigma = (0.1 * 0.9 / n) ** 0.5
+        assert abs(drop.mean() - 0.1) < 4 * sigma, drop.mean()
+        per_ch = drop.reshape(-1, 16).mean(0)                      # every channel position of an e = 16 pixel
+        assert np.abs(per_ch - 0.1).max() < 4.5 * sigma * 4, per_ch
+        assert abs(np.corrcoef(drop[:-1], drop[1:])[0, 1]) < 5e-3      # neighbours
+        assert abs(np.corrcoef(drop[:-16], drop[16:])[0, 1]) < 5e-3    # same channel of the next pixel
+        masks[(seed, stage, blk, first)] = drop
+    keys = list(masks)
+    for i in range(len(keys)):
+        for j in range(i + 1, len(keys)):
+            assert abs(np.corrcoef(masks[keys[i]], masks[keys[j]])[0, 1]) < 5e-3, (keys[i], keys[j])
+    assert lib.lg_dropout_mask(1, 0, 7, 0, 4, _ptr(out), _stream_ptr()) != 0     # block index out of range
