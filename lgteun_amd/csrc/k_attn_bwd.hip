@@ -14,10 +14,11 @@
 #include "bwd_kernels.h"
 
 template <int HC, int NW>
-__global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nwin, int ngroups) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HC == 32 ? 1 : 2))) void k_attn_bwd_core(AttnBwdArgs a, int nwin, int ngroups) {
     // blockIdx.y = head: the two heads of a window are independent, so each workgroup keeps only one head's pos_emb /
     // dpos / K,V,Q,dO tiles in LDS -> half the LDS, twice the waves per CU.
     constexpr int E = 2 * HC, D = HC / 2;
+    constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
     constexpr int Y1LD = (HC + 15) / 16 * 16, DQLD = (3 * HC + 15) / 16 * 16;  // wgrad operands are padded to 16 columns
     constexpr int PW = 4 * 64 * D + 64 * 4;       // floats of LDS per wave
     constexpr int PLD = 65;                       // padded pos_emb row: conflict-free for lane = query AND lane = key
@@ -26,14 +27,28 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
     float* sPos = smem;                    // [64 i][65]  pos_emb[hd][i][j]
     float* sDpos = smem + 64 * PLD;        // [64 i][65]  accumulated dS
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* sK = smem + 2 * 64 * PLD + wave * PW;   // [64][D]
+    // per-wave tiles, CHANNEL-major [c][token]: a 16-byte broadcast read is one channel of FOUR tokens, so both passes run their
+    // inner products as packed fp32 over token pairs (v_pk_fma_f32, the lane's own operand splat by op_sel) -- k_attn.hip has the details
+    float* sK = smem + 2 * 64 * PLD + wave * PW;   // [D][64]
     float* sV = sK + 64 * D;
-    float* sQ = sV + 64 * D;
+    float* sQ = sV + 64 * D;               // q * scale * log2(e): scores live in the log2 domain (softmax = exp2(s - max))
     float* sDO = sQ + 64 * D;
-    float* sSt = sDO + 64 * D;             // [64][4]  row max, 1/row sum, D_i
+    float* sSt = sDO + 64 * D;             // [3][64]  row max (log2 domain), 1/row sum, D_i
+    // tokens per LDS broadcast: four (16 bytes) at D = 4; two (8 bytes) for the wider heads, whose register budget does not hold 4 x D
+    // values of two operands per group
+    constexpr int TG = D == 4 ? 4 : 2, NP = TG / 2, NG = 64 / TG;
+    auto ld_tokens = [&](const float* tile, int c, int g, lg_v2f (&out)[NP]) {
+        if constexpr (TG == 4) {
+            const float4 v = reinterpret_cast<const float4*>(tile)[c * 16 + g];
+            out[0] = (lg_v2f){v.x, v.y}; out[NP - 1] = (lg_v2f){v.z, v.w};
+        } else {
+            const float2 v = reinterpret_cast<const float2*>(tile)[c * 32 + g];
+            out[0] = (lg_v2f){v.x, v.y};
+        }
+    };
     for (int i = threadIdx.x; i < 64 * 64; i += NW * 64) {
         const int ii = i >> 6, j = i & 63;
-        sPos[ii * PLD + j] = a.pos[hd * 64 * 64 + i];
+        sPos[ii * PLD + j] = a.pos[hd * 64 * 64 + i] * LOG2E;
         sDpos[ii * PLD + j] = 0.f;
     }
     // this head's slices of to_qkv (rows hd*D + c of each third) and of proj^T, once per workgroup: read as LDS broadcasts in the
@@ -57,9 +72,9 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
     const float scale = (float)(1.0 / sqrt((double)D));
     // pos_emb gradient: in pass 2 lane j owns column j of dS, so dpos[hd][i][j] accumulates in 64 registers across all the
     // windows of this wave (LDS float atomics here cost more than the rest of the kernel)
-    float dpacc[64];
+    lg_v2f dpacc[32];
 #pragma unroll
-    for (int i = 0; i < 64; ++i) dpacc[i] = 0.f;
+    for (int i = 0; i < 32; ++i) dpacc[i] = (lg_v2f){0.f, 0.f};
 
     // pixel of this lane in window `win` (row-major windows, row-major tokens)
     auto pixel_of = [&](int win, long& b, long& s) -> long {
@@ -122,9 +137,9 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                         vk += sWq[(D + c) * HC + k] * y1[k];
                         vv += sWq[(2 * D + c) * HC + k] * y1[k];
                     }
-                    sQ[lane * D + c] = (vq + sBq[c]) * scale;
-                    sK[lane * D + c] = vk + sBq[D + c];
-                    sV[lane * D + c] = vv + sBq[2 * D + c];
+                    sQ[c * 64 + lane] = (vq + sBq[c]) * (scale * LOG2E);
+                    sK[c * 64 + lane] = vk + sBq[D + c];
+                    sV[c * 64 + lane] = vv + sBq[2 * D + c];
                 }
             }
             {
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                     float acc = 0.f;
 #pragma unroll
                     for (int n = 0; n < E; ++n) acc += sWp[k * E + n] * dym[n];
-                    sDO[lane * D + k] = acc;
+                    sDO[k * 64 + lane] = acc;
                 }
                 if (hd == 0) {   // global-mixer half of the proj input, and the zero padding of the dqkv rows
                     float* co = a.cat + p * E;
@@ -157,70 +172,92 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();   // per-wave tiles: no workgroup barrier needed
         if (active) {
-            // ---------------- pass 1: lane = query i
+            // ---------------- pass 1: lane = query i, packed over KEY pairs
             float q[D], dOi[D];
 #pragma unroll
-            for (int c = 0; c < D; ++c) { q[c] = sQ[lane * D + c]; dOi[c] = sDO[lane * D + c]; }
+            for (int c = 0; c < D; ++c) { q[c] = sQ[c * 64 + lane]; dOi[c] = sDO[c * 64 + lane]; }
             const float* prow = sPos + lane * PLD;
-            const float4* kh = reinterpret_cast<const float4*>(sK);   // rows as 16-byte LDS broadcasts
-            const float4* vh = reinterpret_cast<const float4*>(sV);
-            float sc[64];
+            lg_v2f sc[32];
             float mx = -3.0e38f;
 #pragma unroll
-            for (int j = 0; j < 64; ++j) {
-                float t = prow[j];
+            for (int g = 0; g < NG; ++g) {
+                lg_v2f sp[NP];
 #pragma unroll
-                for (int c4 = 0; c4 < D / 4; ++c4) {
-                    const float4 kv = kh[j * (D / 4) + c4];
-                    t += q[4 * c4] * kv.x + q[4 * c4 + 1] * kv.y + q[4 * c4 + 2] * kv.z + q[4 * c4 + 3] * kv.w;
+                for (int u = 0; u < NP; ++u) sp[u] = (lg_v2f){prow[TG * g + 2 * u], prow[TG * g + 2 * u + 1]};
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    lg_v2f kv[NP];
+                    ld_tokens(sK, c, g, kv);
+                    const lg_v2f qq = (lg_v2f){q[c], q[c]};
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) sp[u] = qq * kv[u] + sp[u];
                 }
-                sc[j] = t;
-                mx = fmaxf(mx, t);
-                if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) { sc[NP * g + u] = sp[u]; mx = fmaxf(mx, fmaxf(sp[u].x, sp[u].y)); }
+                if ((TG * (g + 1)) % 8 == 0) __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("" ::: "memory");
-            float l = 0.f;
+            lg_v2f l2 = (lg_v2f){0.f, 0.f};
+            const lg_v2f mx2 = (lg_v2f){mx, mx};
 #pragma unroll
-            for (int j = 0; j < 64; ++j) { sc[j] = __expf(sc[j] - mx); l += sc[j]; }
-            const float inv = __builtin_amdgcn_rcpf(l);
-            float O[D];
+            for (int g = 0; g < 32; ++g) {
+                const lg_v2f t = sc[g] - mx2;
+                sc[g] = (lg_v2f){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                l2 += sc[g];
+            }
+            const float inv = __builtin_amdgcn_rcpf(l2.x + l2.y);
+            const lg_v2f inv2 = (lg_v2f){inv, inv};
+            lg_v2f O2[D];   // (even keys, odd keys) partials
 #pragma unroll
-            for (int c = 0; c < D; ++c) O[c] = 0.f;
+            for (int c = 0; c < D; ++c) O2[c] = (lg_v2f){0.f, 0.f};
             // D_i = sum_j P_ij dP_ij = dO_i . O_i  (dP_ij = dO_i . v_j): no second pass over V for it
 #pragma unroll
-            for (int j = 0; j < 64; ++j) {
-                sc[j] *= inv;
+            for (int g = 0; g < NG; ++g) {
 #pragma unroll
-                for (int c4 = 0; c4 < D / 4; ++c4) {
-                    const float4 vv = vh[j * (D / 4) + c4];
-                    O[4 * c4] += sc[j] * vv.x; O[4 * c4 + 1] += sc[j] * vv.y; O[4 * c4 + 2] += sc[j] * vv.z; O[4 * c4 + 3] += sc[j] * vv.w;
+                for (int u = 0; u < NP; ++u) sc[NP * g + u] *= inv2;
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    lg_v2f vv[NP];
+                    ld_tokens(sV, c, g, vv);
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) O2[c] = sc[NP * g + u] * vv[u] + O2[c];
                 }
-                if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                if ((TG * (g + 1)) % 8 == 0) __builtin_amdgcn_sched_barrier(0);
             }
+            float O[D];
             float Dv = 0.f;
 #pragma unroll
-            for (int c = 0; c < D; ++c) Dv += dOi[c] * O[c];
-            asm volatile("" ::: "memory");   // re-read K_j / V_j from LDS below instead of keeping 64 x 2D values live
+            for (int c = 0; c < D; ++c) { O[c] = O2[c].x + O2[c].y; Dv += dOi[c] * O[c]; }
+            asm volatile("" ::: "memory");   // re-read K / V from LDS below instead of keeping 64 x 2D values live
+            const lg_v2f Dv2 = (lg_v2f){Dv, Dv};
+            lg_v2f dq2[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) dq2[c] = (lg_v2f){0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                lg_v2f dP[NP], kv[D][NP];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) dP[u] = (lg_v2f){0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    lg_v2f vv[NP];
+                    ld_tokens(sV, c, g, vv);
+                    ld_tokens(sK, c, g, kv[c]);
+                    const lg_v2f dd = (lg_v2f){dOi[c], dOi[c]};
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) dP[u] = dd * vv[u] + dP[u];
+                }
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const lg_v2f dS = sc[NP * g + u] * (dP[u] - Dv2);
+#pragma unroll
+                    for (int c = 0; c < D; ++c) dq2[c] = dS * kv[c][u] + dq2[c];
+                }
+                if ((TG * (g + 1)) % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+            }
             float dqh[D];
 #pragma unroll
-            for (int c = 0; c < D; ++c) dqh[c] = 0.f;
-#pragma unroll
-            for (int j = 0; j < 64; ++j) {
-                float dP = 0.f;
-                float4 kv[D / 4];
-#pragma unroll
-                for (int c4 = 0; c4 < D / 4; ++c4) {
-                    const float4 vv = vh[j * (D / 4) + c4];
-                    kv[c4] = kh[j * (D / 4) + c4];
-                    dP += dOi[4 * c4] * vv.x + dOi[4 * c4 + 1] * vv.y + dOi[4 * c4 + 2] * vv.z + dOi[4 * c4 + 3] * vv.w;
-                }
-                const float dS = sc[j] * (dP - Dv);
-#pragma unroll
-                for (int c4 = 0; c4 < D / 4; ++c4) {
-                    dqh[4 * c4] += dS * kv[c4].x; dqh[4 * c4 + 1] += dS * kv[c4].y; dqh[4 * c4 + 2] += dS * kv[c4].z; dqh[4 * c4 + 3] += dS * kv[c4].w;
-                }
-                if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int c = 0; c < D; ++c) dqh[c] = dq2[c].x + dq2[c].y;
             float4* co = reinterpret_cast<float4*>(a.cat + p * E + hd * D);      // 16-byte stores (as scalar loops the two possibly
             float4* dq_o = reinterpret_cast<float4*>(a.dqkv + p * DQLD + hd * D);  // aliasing destinations compiled to 2 D dword stores)
 #pragma unroll
@@ -228,43 +265,54 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
                 co[c4] = make_float4(O[4 * c4], O[4 * c4 + 1], O[4 * c4 + 2], O[4 * c4 + 3]);
                 dq_o[c4] = make_float4(dqh[4 * c4] * scale, dqh[4 * c4 + 1] * scale, dqh[4 * c4 + 2] * scale, dqh[4 * c4 + 3] * scale);
             }
-            sSt[lane * 4 + 0] = mx;
-            sSt[lane * 4 + 1] = inv;
-            sSt[lane * 4 + 2] = Dv;
+            sSt[lane] = mx;
+            sSt[64 + lane] = inv;
+            sSt[128 + lane] = Dv;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();   // per-wave tiles: no workgroup barrier needed
         if (active) {
-            // ---------------- pass 2: lane = key j
-            float kj[D], vj[D], dkh[D], dvh[D];
+            // ---------------- pass 2: lane = key j, packed over QUERY pairs
+            float kj[D], vj[D];
+            lg_v2f dk2[D], dv2[D];
 #pragma unroll
-            for (int c = 0; c < D; ++c) { kj[c] = sK[lane * D + c]; vj[c] = sV[lane * D + c]; dkh[c] = 0.f; dvh[c] = 0.f; }
+            for (int c = 0; c < D; ++c) { kj[c] = sK[c * 64 + lane]; vj[c] = sV[c * 64 + lane]; dk2[c] = (lg_v2f){0.f, 0.f}; dv2[c] = (lg_v2f){0.f, 0.f}; }
             const float* pcol = sPos + lane;
-            const float4* qh = reinterpret_cast<const float4*>(sQ);
-            const float4* doh = reinterpret_cast<const float4*>(sDO);
-            const float4* st = reinterpret_cast<const float4*>(sSt);
 #pragma unroll
-            for (int i = 0; i < 64; ++i) {
-                float t = pcol[i * PLD], dP = 0.f;
-                float4 qi[D / 4], doi[D / 4];
+            for (int g = 0; g < NG; ++g) {
+                lg_v2f t[NP], dP[NP], qi[D][NP], doi[D][NP];
 #pragma unroll
-                for (int c4 = 0; c4 < D / 4; ++c4) {
-                    qi[c4] = qh[i * (D / 4) + c4];
-                    doi[c4] = doh[i * (D / 4) + c4];
-                    t += qi[c4].x * kj[4 * c4] + qi[c4].y * kj[4 * c4 + 1] + qi[c4].z * kj[4 * c4 + 2] + qi[c4].w * kj[4 * c4 + 3];
-                    dP += doi[c4].x * vj[4 * c4] + doi[c4].y * vj[4 * c4 + 1] + doi[c4].z * vj[4 * c4 + 2] + doi[c4].w * vj[4 * c4 + 3];
+                for (int u = 0; u < NP; ++u) { t[u] = (lg_v2f){pcol[(TG * g + 2 * u) * PLD], pcol[(TG * g + 2 * u + 1) * PLD]}; dP[u] = (lg_v2f){0.f, 0.f}; }
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    ld_tokens(sQ, c, g, qi[c]);
+                    ld_tokens(sDO, c, g, doi[c]);
+                    const lg_v2f kk = (lg_v2f){kj[c], kj[c]}, vv = (lg_v2f){vj[c], vj[c]};
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) { t[u] = kk * qi[c][u] + t[u]; dP[u] = vv * doi[c][u] + dP[u]; }
                 }
-                const float4 sv = st[i];
-                const float P = __expf(t - sv.x) * sv.y;
-                const float dS = P * (dP - sv.z);
-                dpacc[i] += dS;
-                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                lg_v2f smx[NP], sinv[NP], sdv[NP];   // row max (log2 domain), 1 / row sum, D_i of the TG queries
+                ld_tokens(sSt, 0, g, smx);
+                ld_tokens(sSt, 1, g, sinv);
+                ld_tokens(sSt, 2, g, sdv);
+                lg_v2f P[NP], dS[NP];
 #pragma unroll
-                for (int c4 = 0; c4 < D / 4; ++c4) {
-                    dvh[4 * c4] += P * doi[c4].x; dvh[4 * c4 + 1] += P * doi[c4].y; dvh[4 * c4 + 2] += P * doi[c4].z; dvh[4 * c4 + 3] += P * doi[c4].w;
-                    dkh[4 * c4] += dS * qi[c4].x; dkh[4 * c4 + 1] += dS * qi[c4].y; dkh[4 * c4 + 2] += dS * qi[c4].z; dkh[4 * c4 + 3] += dS * qi[c4].w;
+                for (int u = 0; u < NP; ++u) {
+                    const lg_v2f e = t[u] - smx[u];
+                    P[u] = (lg_v2f){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} * sinv[u];
+                    dS[u] = P[u] * (dP[u] - sdv[u]);
+                    dpacc[NP * g + u] += dS[u];
+                }
+                if ((TG * (g + 1)) % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) { dv2[c] = P[u] * doi[c][u] + dv2[c]; dk2[c] = dS[u] * qi[c][u] + dk2[c]; }
                 }
             }
+            float dkh[D], dvh[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) { dkh[c] = (dk2[c].x + dk2[c].y) * LN2; dvh[c] = dv2[c].x + dv2[c].y; }   // sQ carries log2(e)
             float4* dk_o = reinterpret_cast<float4*>(a.dqkv + p * DQLD + HC + hd * D);
             float4* dv_o = reinterpret_cast<float4*>(a.dqkv + p * DQLD + 2 * HC + hd * D);
 #pragma unroll
@@ -278,7 +326,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_bwd_core(AttnBwdArgs a, int nw
     for (int w = 0; w < NW; ++w) {   // waves take turns (fixed order): sDpos[i][j] += this wave's column sums
         if (wave == w) {
 #pragma unroll
-            for (int i = 0; i < 64; ++i) sDpos[i * PLD + lane] += dpacc[i];
+            for (int i = 0; i < 64; ++i) sDpos[i * PLD + lane] += (i & 1) ? dpacc[i >> 1].y : dpacc[i >> 1].x;
         }
         __syncthreads();
     }
