@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     });
     if (y0 + TY < Yend) ln_fetch(y0 + TY + 1, TY * HX, 0, pre, pin);   // next step's first chunk: in flight during P2
     float wq[4][9], bq[4];
+    lg_v2f wq01[9], wq23[9];   // the taps as channel PAIRS: the depthwise sum runs on v_pk_fma_f32 (18 instead of 36 instructions per pixel quad)
     {
         const float* tp = a2.dww + 36 * q;
         asm volatile("" : "+v"(tp));            // keep the loads inside the step loop (not hoisted back into 40 live registers)
@@ -282,6 +283,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         asm volatile("" : "+v"(bp));
         const float4 bv = *reinterpret_cast<const float4*>(bp);
         bq[0] = bv.x; bq[1] = bv.y; bq[2] = bv.z; bq[3] = bv.w;
+#pragma unroll
+        for (int kk = 0; kk < 9; ++kk) { wq01[kk] = (lg_v2f){wq[0][kk], wq[1][kk]}; wq23[kk] = (lg_v2f){wq[2][kk], wq[3][kk]}; }
     }
     // ---- P2: per wave, 2 tile rows of 16 pixels: dw3x3 over the ring + GELU -> pieces -> GEMM3 -> bias + residual -> y (+ planar LN half)
     {
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll(SAVE == 1 ? LG_XS_SAVE_UNROLL : 4)
             for (int it = 0; it < 4; ++it) {
                 const int tx = (lane >> 4) + 4 * it;
-                float4 acc = make_float4(bq[0], bq[1], bq[2], bq[3]);
+                lg_v2f acc01 = (lg_v2f){bq[0], bq[1]}, acc23 = (lg_v2f){bq[2], bq[3]};
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     int sl = sbase + ty + dy;
@@ -301,10 +304,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) {
                         const float4 v = *reinterpret_cast<const float4*>(ring + (sl * HX + tx + dx) * LDR + 4 * q);
-                        acc.x += wq[0][dy * 3 + dx] * v.x; acc.y += wq[1][dy * 3 + dx] * v.y;
-                        acc.z += wq[2][dy * 3 + dx] * v.z; acc.w += wq[3][dy * 3 + dx] * v.w;
+                        acc01 = wq01[dy * 3 + dx] * (lg_v2f){v.x, v.y} + acc01;
+                        acc23 = wq23[dy * 3 + dx] * (lg_v2f){v.z, v.w} + acc23;
                     }
                 }
+                const float4 acc = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
                 float av[4];
                 if (SAVE == 1) {
                     lg_v2f a01, a23, g01, g23;

@@ -44,12 +44,27 @@ __device__ __forceinline__ Split3 split3(float v) {
 // one dword = the bf16 (high halves) of two fp32 patterns: `lo` in bits 0..15, `hi` in bits 16..31   (one v_perm_b32)
 __device__ __forceinline__ uint32_t pack_hi16(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 
+// two values at once: the residual subtractions as packed fp32 (v_pk_add_f32 with neg: the same IEEE subtraction, so the pieces are bit
+// for bit those of split3) -- 6 instead of 8 instructions per pair before the packing permutes
+typedef float sb_v2f __attribute__((ext_vector_type(2)));
+struct Split3x2 {
+    u32x2_t p1, p2, p3;
+};
+__device__ __forceinline__ Split3x2 split3_pair(sb_v2f v) {
+    Split3x2 s;
+    s.p1 = __builtin_bit_cast(u32x2_t, v);
+    const sb_v2f r1 = v - __builtin_bit_cast(sb_v2f, s.p1 & 0xffff0000u);
+    s.p2 = __builtin_bit_cast(u32x2_t, r1);
+    const sb_v2f r2 = r1 - __builtin_bit_cast(sb_v2f, s.p2 & 0xffff0000u);
+    s.p3 = __builtin_bit_cast(u32x2_t, r2);
+    return s;
+}
 // four consecutive-k values -> the 8-byte fragment of each piece
 __device__ __forceinline__ void split3_x4(const float (&v)[4], u32x2_t& q1, u32x2_t& q2, u32x2_t& q3) {
-    const Split3 a = split3(v[0]), b = split3(v[1]), c = split3(v[2]), d = split3(v[3]);
-    q1 = (u32x2_t){pack_hi16(a.p1, b.p1), pack_hi16(c.p1, d.p1)};
-    q2 = (u32x2_t){pack_hi16(a.p2, b.p2), pack_hi16(c.p2, d.p2)};
-    q3 = (u32x2_t){pack_hi16(a.p3, b.p3), pack_hi16(c.p3, d.p3)};
+    const Split3x2 ab = split3_pair((sb_v2f){v[0], v[1]}), cd = split3_pair((sb_v2f){v[2], v[3]});
+    q1 = (u32x2_t){pack_hi16(ab.p1.x, ab.p1.y), pack_hi16(cd.p1.x, cd.p1.y)};
+    q2 = (u32x2_t){pack_hi16(ab.p2.x, ab.p2.y), pack_hi16(cd.p2.x, cd.p2.y)};
+    q3 = (u32x2_t){pack_hi16(ab.p3.x, ab.p3.y), pack_hi16(cd.p3.x, cd.p3.y)};
 }
 
 // weight fragments, split once per workgroup.  W: fp32 [rows][K] row-major, this wave's 16 rows start at W.
