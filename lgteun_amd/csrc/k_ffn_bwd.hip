@@ -66,11 +66,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((E == 16 ||
     for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int k = 0; k < 9; ++k) wq[u][k] = a.dww[(c0 + 4 * q + u) * 9 + k];
-    float pw[4][10];
+    // taps and gradient partials as channel PAIRS: phase P2 runs on v_pk_fma_f32 (38 instead of 76 vector instructions per pixel quad)
+    lg_v2f wq01[9], wq23[9], pw01[10], pw23[10];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int k = 0; k < 9; ++k) { wq01[k] = (lg_v2f){wq[0][k], wq[1][k]}; wq23[k] = (lg_v2f){wq[2][k], wq[3][k]}; }
 #pragma unroll
-        for (int k = 0; k < 10; ++k) pw[u][k] = 0.f;
+    for (int k = 0; k < 10; ++k) { pw01[k] = (lg_v2f){0.f, 0.f}; pw23[k] = (lg_v2f){0.f, 0.f}; }
     const int ntiles = a.B * tiles_x * tiles_y;
     constexpr int NDY = MH * (E / 4) / 256;             // dy halo tile: float4 items per thread
     constexpr int NG3 = (NH * CQ + 255) / 256;          // h2 / g3 halo tile: float4 items per thread
@@ -193,21 +194,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((E == 16 ||
         const int y = y0 + ty, x = x0 + tx;
         if (y >= h || x >= w) continue;
         const float4 gc = *reinterpret_cast<const float4*>(bufG + ((ty + 1) * HX + tx + 1) * LDG + 4 * q);
-        pw[0][9] += gc.x; pw[1][9] += gc.y; pw[2][9] += gc.z; pw[3][9] += gc.w;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const lg_v2f gc01 = (lg_v2f){gc.x, gc.y}, gc23 = (lg_v2f){gc.z, gc.w};
+        pw01[9] += gc01; pw23[9] += gc23;
+        lg_v2f acc01 = (lg_v2f){0.f, 0.f}, acc23 = (lg_v2f){0.f, 0.f};
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 // forward: h3(y',x') += w[dy][dx] * h2(y'+dy-1, x'+dx-1)  ->  h2(y,x) feeds h3(y-dy+1, x-dx+1)
                 const float4 gv = *reinterpret_cast<const float4*>(bufG + ((ty + 2 - dy) * HX + tx + 2 - dx) * LDG + 4 * q);
-                acc.x += wq[0][dy * 3 + dx] * gv.x; acc.y += wq[1][dy * 3 + dx] * gv.y;
-                acc.z += wq[2][dy * 3 + dx] * gv.z; acc.w += wq[3][dy * 3 + dx] * gv.w;
+                acc01 = wq01[dy * 3 + dx] * (lg_v2f){gv.x, gv.y} + acc01;
+                acc23 = wq23[dy * 3 + dx] * (lg_v2f){gv.z, gv.w} + acc23;
                 const float4 hv = *reinterpret_cast<const float4*>(bufH + ((ty + dy) * HX + tx + dx) * LDG + 4 * q);
-                pw[0][dy * 3 + dx] += gc.x * hv.x; pw[1][dy * 3 + dx] += gc.y * hv.y;
-                pw[2][dy * 3 + dx] += gc.z * hv.z; pw[3][dy * 3 + dx] += gc.w * hv.w;
+                pw01[dy * 3 + dx] = gc01 * (lg_v2f){hv.x, hv.y} + pw01[dy * 3 + dx];
+                pw23[dy * 3 + dx] = gc23 * (lg_v2f){hv.z, hv.w} + pw23[dy * 3 + dx];
             }
-        HS<BF>::st4(a.dh2, ((b * h + y) * (long)w + x) * N1 + c0 + 4 * q, acc);
+        HS<BF>::st4(a.dh2, ((b * h + y) * (long)w + x) * N1 + c0 + 4 * q, make_float4(acc01.x, acc01.y, acc23.x, acc23.y));
     }
     }   // tiles of this workgroup
     const int tile_id = blockIdx.x;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((E == 16 ||
     for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int k = 0; k < 10; ++k) {
-            float v = pw[u][k];
+            float v = u == 0 ? pw01[k].x : (u == 1 ? pw01[k].y : (u == 2 ? pw23[k].x : pw23[k].y));
 #pragma unroll
             for (int off = CQ; off < 64; off <<= 1) v += __shfl_xor(v, off);
             if (lane < CQ) red[(wave * CQ + q) * 40 + u * 10 + k] = v;
