@@ -25,6 +25,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef LG_WGRAD_WGS
 #define LG_WGRAD_WGS 512
 #endif
+#ifndef LG_WGRAD_INTERLEAVE
+#define LG_WGRAD_INTERLEAVE 1   // 0: one contiguous pixel range per wave (A/B: the 16-wide blocks run 35 -> 31.5 us interleaved, the 64 x 64 ones the same)
+#endif
 __host__ __device__ constexpr int wgrad_batch(int nt, int kt, bool vec) { return vec ? LG_WGRAD_VEC_U : (nt + kt <= 2 ? 16 : (nt + kt <= 4 ? 8 : 4)); }
 
 // XGELU: the stored X is a pre-activation and the conv input is gelu(X) (feed_forward's second and third 1x1 convs when the forward
@@ -37,9 +40,18 @@ __global__ __launch_bounds__(256) void k_wgrad_t(WgradArgs a, int k_blocks, long
     const int nb = blockIdx.y / k_blocks, kb = blockIdx.y - nb * k_blocks;
     const int n0 = nb * NB, k0 = kb * KB;
     const long slice = (long)blockIdx.x * 4 + wave;
+#if LG_WGRAD_INTERLEAVE
+    // batches of 4 U pixels dealt round-robin to the waves of the grid: at any moment the whole grid reads ONE contiguous window of the
+    // operands (all HBM channels), instead of 2 048 streams that all sit at the same offset of their own 64 KiB-aligned chunk
+    const long p_stride = (long)gridDim.x * 4 * (4 * U);
+    const long p_begin = slice * (4 * U);
+    const long p_end = a.P;
+#else
+    const long p_stride = 4 * U;
     const long p_begin = slice * px_per_wave;
     long p_end = p_begin + px_per_wave;
     if (p_end > a.P) p_end = a.P;
+#endif
     f32x4 acc[NT][KT];
     float bsum[NT];
 #pragma unroll
@@ -87,9 +99,9 @@ __global__ __launch_bounds__(256) void k_wgrad_t(WgradArgs a, int k_blocks, long
         float yc[U][NT], xc[U][KT];
         fetch(p_begin, yc, xc);
 #pragma unroll 1
-        for (long p = p_begin; p < p_end; p += 4 * U) {
+        for (long p = p_begin; p < p_end; p += p_stride) {
             float yn[U][NT], xn[U][KT];
-            fetch(p + 4 * U, yn, xn);   // next batch in flight under this batch's MFMAs (past the slice end: cached, unused)
+            fetch(p + p_stride, yn, xn);   // next batch in flight under this batch's MFMAs (past the slice end: cached, unused)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
