@@ -129,7 +129,7 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
         const char* impl = getenv("LG_FFN_IMPL");
         p->ffn_tile = !impl ? 0 : (!strcmp(impl, "strip") ? 1 : (!strcmp(impl, "tile") ? 2 : (!strcmp(impl, "xp") ? 3 : 0)));
         const char* sv = getenv("LG_FFN_SAVE");
-        p->save3 = (sv && !strcmp(sv, "3")) ? 1 : 0;
+        p->save3 = (sv && !strcmp(sv, "5")) ? 0 : 1;   // default: pre-activation saves; "5": the five-tensor form (A/B)
     }
     p->off = (int64_t*)malloc(sizeof(int64_t) * n_offsets);
     memcpy(p->off, offsets, sizeof(int64_t) * n_offsets);

@@ -191,7 +191,10 @@ struct Ffn1BwdArgs {
 };
 #define FFN1_BWD_WGS 512   // persistent grid cap of k_ffn1_bwd
 inline bool ffn1_bwd_fuses_w1(int e) { return e <= 32; }
-inline bool ffn1_bwd_fuses_w2(int e, int pre) { return pre && e == 16; }
+#ifndef LG_FW2
+#define LG_FW2 0   // 1: k_ffn1_bwd accumulates dW2 itself in the pre-activation mode (64 extra f32 MFMAs per chunk: 7.51 ms against 7.43 with dW2 from k_wgrad_t, gelu evaluated on its X operand)
+#endif
+inline bool ffn1_bwd_fuses_w2(int e, int pre) { return LG_FW2 && pre && e == 16; }
 int launch_ffn1_bwd(int e, const Ffn1BwdArgs& a, hipStream_t s);
 int launch_ffn1_bwd_x32(const Ffn1BwdArgs& a, const float* w1, void* wsplit, hipStream_t s);   // k_ffn1_bwd_x32.hip
 int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[cols][rows]

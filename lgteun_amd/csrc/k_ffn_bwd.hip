@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 2
     // FW2 (pre-activation saves, e = 16): gelu(h1) is evaluated here for gelu'(h1) anyway, so dW2 = sum_p dh2 (x) gelu(h1) and db2 are
     // accumulated in this kernel too: the rows of all four waves (dh2 in bufD, gelu(h1) in bufA) are the operands, wave w owns the
     // output rows n = 4 i + w (tile t of a float4 at column 4r = channel 4r + t, as in k_wgrad_t's VEC layout)
-    constexpr bool FW2 = PRE && E == 16;
+    constexpr bool FW2 = PRE && E == 16 && LG_FW2;
     float* bufA_all = w2l + N1 * LDH;            // [4][MW][LDH] gelu(h1) rows (FW2)
     float* bufA = bufA_all + wave * (MW * LDH);
     f32x4 acc2[FW2 ? 4 : 1];

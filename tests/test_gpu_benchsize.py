@@ -102,6 +102,33 @@ def test_split_backward_is_bitwise_the_whole_backward(C, h, K, B):
     assert float(whole[a0:b0].abs().max()) > 0
 
 
+def test_both_ffn_save_modes_give_the_same_step(monkeypatch):
+    """The live stage's e = 16 FFN half-blocks either save gelu / gelu' (five 4e-wide tensors per block, the backward evaluates no GELU)
+    or the three pre-activations h1 / h2 / h3 (LG_FFN_SAVE, read at plan creation; 40 % less saved-activation traffic, the backward
+    re-evaluates GELU with the forward's own function).  Same forward bit for bit; gradients equal to rounding (dW2 / dW3 see gelu(h)
+    through the scalar evaluation of k_wgrad_t instead of the forward's packed one)."""
+    from gpu_helpers import make_module
+    from lgteun_amd._lib import LG_FLAG_FAITHFUL, LG_FLAG_SAVE
+    ms, pan, gt = (T(a).cuda() for a in dw.make_inputs(3, 4, 32, 32, seed=5, kind='dn'))
+    res = {}
+    for mode in ('5', '3'):
+        monkeypatch.setenv('LG_FFN_SAVE', mode)
+        net = make_module(4, 2)
+        eng = net.engine()
+        out, saved = eng.forward_raw(ms, pan, LG_FLAG_FAITHFUL | LG_FLAG_SAVE, 0)
+        dout = torch.sign(out - gt) / out.numel()
+        g = torch.zeros_like(eng.gflat)
+        eng.backward_raw(saved, dout, g, LG_FLAG_FAITHFUL | LG_FLAG_SAVE, 0)
+        res[mode] = (out.clone(), g.clone(), eng)
+    assert torch.equal(res['5'][0], res['3'][0])
+    g5, g3, eng = res['5'][1], res['3'][1], res['5'][2]
+    assert not torch.equal(g5, torch.zeros_like(g5))
+    for i in eng.live_idx:
+        o, n = eng.offsets[i], eng.params[i].numel()
+        a, b = g5[o:o + n].double(), g3[o:o + n].double()
+        assert float((a - b).norm()) <= 2e-6 * float(a.norm()) + 1e-12, eng.names[i]
+
+
 def test_two_autograd_graphs_keep_their_own_activations():
     """two forwards with the same batch size before either backward (summed / consistency losses): each graph
     owns its saved activations, so the gradients equal those of the two graphs run one after the other"""
