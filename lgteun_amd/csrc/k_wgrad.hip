@@ -109,10 +109,19 @@ __global__ __launch_bounds__(256) void k_wgrad_t(WgradArgs a, int k_blocks, long
                 float yv[NT], xv[KT];
 #pragma unroll
                 for (int i = 0; i < NT; ++i) { yv[i] = yc[u][i] * (VEC ? rm : rm * ym[i]); bsum[i] += yv[i]; }
+                if constexpr (XGELU && KT % 2 == 0) {   // gelu on operand PAIRS (packed fp32, the forward's own gelu2_f): half the vector instructions
 #pragma unroll
-                for (int j = 0; j < KT; ++j) {
-                    const float xg = XGELU ? gelu_f(xc[u][j]) : xc[u][j];
-                    xv[j] = VEC ? xg : xg * xm[j];
+                    for (int j = 0; j < KT; j += 2) {
+                        const lg_v2f gp = gelu2_f((lg_v2f){xc[u][j], xc[u][j + 1]});
+                        xv[j] = VEC ? gp.x : gp.x * xm[j];
+                        xv[j + 1] = VEC ? gp.y : gp.y * xm[j + 1];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KT; ++j) {
+                        const float xg = XGELU ? gelu_f(xc[u][j]) : xc[u][j];
+                        xv[j] = VEC ? xg : xg * xm[j];
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
