@@ -223,20 +223,9 @@ __device__ __forceinline__ float lane_group_sum(float v) {
 }
 // counter-hash RNG for dropout (keep probability 0.9, nn.Dropout(0.1) of LGT.py:197): element idx is dropped when a 32-bit hash of its
 // counter falls below 0.1 * 2^32.  The hash is a two-round multiply-xorshift keyed by both halves of the 64-bit per-(stage, block) seed:
-// 2 quarter-rate 32-bit multiplies per element against the 10 of the 64-bit splitmix it replaces (LG_DROPOUT64 keeps that one for A/B).
+// 2 quarter-rate 32-bit multiplies per element against the 10 of the 64-bit splitmix it replaced (8.5 % of k_attn).
 // Forward and backward call the same function, so the masks agree by construction.
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx) {
-#ifdef LG_ABL_DROPOUT
-    return 1.0f / 0.9f;
-#endif
-#ifdef LG_DROPOUT64
-    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    float u = (float)(z >> 40) * (1.0f / 16777216.0f);
-    return u < 0.1f ? 0.0f : (1.0f / 0.9f);
-#endif
     uint32_t x = (uint32_t)idx + (uint32_t)seed;
     x ^= x >> 16; x *= 0x7feb352du;
     x ^= (uint32_t)(seed >> 32) ^ (uint32_t)(idx >> 32);
