@@ -116,10 +116,12 @@ def test_both_ffn_save_modes_give_the_same_step(monkeypatch):
         net = make_module(4, 2)
         eng = net.engine()
         out, saved = eng.forward_raw(ms, pan, LG_FLAG_FAITHFUL | LG_FLAG_SAVE, 0)
+        ws_sum = float(saved[1].view(torch.uint8)[::4093].double().sum())   # fingerprint of the saved activations (the modes keep different tensors)
         dout = torch.sign(out - gt) / out.numel()
         g = torch.zeros_like(eng.gflat)
         eng.backward_raw(saved, dout, g, LG_FLAG_FAITHFUL | LG_FLAG_SAVE, 0)
-        res[mode] = (out.clone(), g.clone(), eng)
+        res[mode] = (out.clone(), g.clone(), eng, ws_sum)
+    assert res['5'][3] != res['3'][3]          # the switch was honoured: the workspaces hold different things
     assert torch.equal(res['5'][0], res['3'][0])
     g5, g3, eng = res['5'][1], res['3'][1], res['5'][2]
     assert not torch.equal(g5, torch.zeros_like(g5))
