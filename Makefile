@@ -2,13 +2,19 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := lgteun_amd/csrc
-SRCS  := $(CSRC)/api.hip $(CSRC)/k_pixel.hip $(CSRC)/k_fft.hip $(CSRC)/k_attn.hip $(CSRC)/k_ffn.hip $(CSRC)/k_ffn_x.hip $(CSRC)/k_ffn_x32.hip $(CSRC)/k_ffn_xp.hip $(CSRC)/k_ffn_x64.hip $(CSRC)/k_bwd.hip $(CSRC)/k_bwd_pixel.hip $(CSRC)/k_wgrad.hip $(CSRC)/k_ffn_bwd.hip $(CSRC)/k_ffn1_bwd_x32.hip $(CSRC)/k_attn_bwd.hip
+SRCS  := $(CSRC)/api.hip $(CSRC)/k_pixel.hip $(CSRC)/k_fft.hip $(CSRC)/k_attn.hip $(CSRC)/k_ffn.hip $(CSRC)/k_ffn_x.hip $(CSRC)/k_ffn_x32.hip $(CSRC)/k_ffn_x64.hip $(CSRC)/k_bwd.hip $(CSRC)/k_bwd_pixel.hip $(CSRC)/k_wgrad.hip $(CSRC)/k_ffn_bwd.hip $(CSRC)/k_ffn1_bwd_x32.hip $(CSRC)/k_attn_bwd.hip
+# A/B-only kernels stay out of the product library: `make AB=1` adds k_ffn_xp (LG_FFN_IMPL=xp: the software-pipelined variant of the
+# fused FFN forward, bitwise the same results, measured 2.5 % slower)
+ifdef AB
+SRCS  += $(CSRC)/k_ffn_xp.hip
+ABFLAGS := -DLG_BUILD_AB=1
+endif
 OBJS  := $(SRCS:.hip=.o)
 LIB   := lgteun_amd/_lgteun_hip.so
 # -fno-slp-vectorize: the SLP vectoriser turns scalar fp32 chains into v_pk_mul_f32 / v_pk_add_f32 pairs; packed fp32 issues at
 # half rate on gfx950 and the pairing blocks mul+add -> fma contraction (k_attn: 3140 VALU instructions, 502 of them packed,
 # vs 3099 unpacked).  Measured on one box, alternating runs: 9.28 -> 9.10 ms/step fp32, 8.96 -> 8.68 bf16 mode.
-FLAGS := -O3 -std=c++17 -fno-slp-vectorize -fPIC -fvisibility=hidden --offload-arch=$(ARCH) -Wall -Wno-unused-function -Wno-unused-value
+FLAGS := -O3 -std=c++17 -fno-slp-vectorize -fPIC -fvisibility=hidden --offload-arch=$(ARCH) -Wall -Wno-unused-function -Wno-unused-value $(ABFLAGS)
 
 all: $(LIB)
 

@@ -45,8 +45,17 @@ E, P0 = 4 * C, H * H
 
 PROF_EVERY = 4   # live HIP-event timing of the roofline kernel: every 4th step of the timed region
 # kernels that make up the "ffn" launch slot (lg_kernel_id LG_K_FFN2): the fused feed_forward half-block, all variants
-FFN_KERNELS = ('k_ffn_xs', 'k_ffn_x32', 'k_ffn_strip', 'k_ffn_fused')
-PMC_SUMMARIES = {c: os.path.join(ROOT, 'profiles', f'r02_bench_{n}_pmc_hbm.csv') for c, n in (('c2', 'bs32'), ('c3', 'c3'), ('c5', 'c5'))}
+FFN_KERNELS = ('k_ffn_xs', 'k_ffn_x32', 'k_ffn_strip', 'k_ffn_fused', 'k_ffn1_x64', 'k_ffn2_x64')
+
+
+def _newest_summary(name):
+    """profiles/rNN_bench_<name>_pmc_hbm.csv of the latest round that committed one"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_bench_{name}_pmc_hbm.csv')))
+    return found[-1] if found else None
+
+
+PMC_SUMMARIES = {c: _newest_summary(n) for c, n in (('c2', 'bs32'), ('c3', 'c3'), ('c5', 'c5'))}
 
 
 def traffic_from_profile(kernel, config='c2'):
@@ -58,11 +67,15 @@ def traffic_from_profile(kernel, config='c2'):
     if not names or not path or not os.path.exists(path):
         return None
     num = den = 0.0
+    pair = 0          # e = 64: the half-block is two launches (k_ffn1_x64 + k_ffn2_x64) timed as ONE slot -> bytes add, launches do not
     for r in csv.DictReader(open(path)):
         if any(n in r['Kernel_Name'] for n in names):
             num += float(r['HBM_bytes_per_launch']) * int(r['launches'])
+            if 'k_ffn1_x64' in r['Kernel_Name']:
+                pair += int(r['launches'])
             den += int(r['launches'])
-    return int(num / den) if den else None
+    den -= pair
+    return int(num / den) if den > 0 else None
 
 
 def synth_batch(B, rank, device):
@@ -181,11 +194,15 @@ def main():
     C, K, H, B_PER_GPU, label = CONFIGS[args.config]
     E, P0 = 4 * C, H * H
 
-    if os.environ.get('LG_BENCH_WATCHDOG'):   # diagnostic: dump every thread's Python stack and exit if the run takes longer than N seconds
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ['LG_BENCH_WATCHDOG']), exit=True)
     from lgteun_amd import ddp
     rank, world, local_rank = ddp.env_world()
+    # watchdog: a stalled rank dumps every thread's Python stack and exits non-zero instead of sitting in a collective until the
+    # launcher's time limit kills it without a trace.  Armed by default for multi-rank runs (600 s covers RCCL's first-collective
+    # set-up plus the whole run many times over); LG_BENCH_WATCHDOG=N overrides, 0 disables.
+    wd = int(os.environ.get('LG_BENCH_WATCHDOG', '600' if world > 1 else '0'))
+    if wd > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
     if world != args.gpus:
         if args.gpus != 1 or world != 1:
             print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run', file=sys.stderr)
@@ -329,7 +346,9 @@ def main():
         else:
             roof = dict(bound='hbm', achieved=round(ach_gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(f_hbm, 4))
         pmc_path = PMC_SUMMARIES.get(args.config)
-        roof.update(traffic=traffic_from_profile(args.prof_kernel, args.config),
+        # `bound` names the ROOF the fraction is taken against (contract: hbm | mfma); `limiter` says what the counters show the kernel
+        # is actually held by (profiles/r0N_sq_counters_*): the vector ALU's instruction issue, not either roof
+        roof.update(limiter='valu-issue' if args.prof_kernel == 'ffn' else None, traffic=traffic_from_profile(args.prof_kernel, args.config),
                     traffic_source=os.path.relpath(pmc_path, ROOT) if pmc_path and os.path.exists(pmc_path) else None,
                     kernel=L.lg_kernel_name(kid).decode(), launches=int(n_l.value), timed_every_n_steps=PROF_EVERY,
                     avg_launch_us=round(avg_us, 2), algorithmic_bytes_per_launch=int(byts), algorithmic_flops_per_launch=int(flops),

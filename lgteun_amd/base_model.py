@@ -51,7 +51,13 @@ class Base_model:
         self.switch_dict = {}
         self.loss_module = get_loss_module(full_cfg=cfg, logger=logger)
         self.last_iter = 0
+        self.rank, self.world = 0, 1      # one process per GPU: set_cuda() reads them from torch.distributed
         self.timer = Timer()
+
+    def _barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
 
     def add_module(self, module_name, module, switch=True):
         assert isinstance(module, nn.Module)
@@ -71,6 +77,7 @@ class Base_model:
         dev = torch.device('cuda', torch.cuda.current_device())
         import torch.distributed as dist
         ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.rank, self.world = (dist.get_rank(), dist.get_world_size()) if ddp else (0, 1)
         for name in self.module_dict:
             self.module_dict[name] = self.module_dict[name].to(dev)
             if ddp and hasattr(self.module_dict[name], 'attach_ddp'):
@@ -83,8 +90,25 @@ class Base_model:
             src = checkpoint[module_name]
             module.load_state_dict(src.state_dict() if hasattr(src, 'state_dict') else src)
 
-    def load_checkpoint(self, path):
-        checkpoint = torch.load(path, weights_only=False)
+    def _read_checkpoint(self, path, allow_pickle):
+        """plain-tensor checkpoints (what save() writes; what tools/convert_checkpoint.py makes of a reference-era file) load with
+        `weights_only=True`: nothing in the file is executed.  The reference's own format -- whole pickled module objects,
+        base_model.py:362-368 -- runs code from the file while loading, so it is read only when the caller says the file is
+        trusted: `allow_pickle=True` or `cfg.allow_pickled_checkpoint = True`."""
+        if allow_pickle is None:
+            allow_pickle = bool(self.cfg.get('allow_pickled_checkpoint', False))
+        try:
+            return torch.load(path, map_location='cpu', weights_only=True)
+        except Exception as e:  # noqa: BLE001  (torch raises UnpicklingError for anything beyond tensors / containers)
+            if not allow_pickle:
+                raise RuntimeError(
+                    f'{path} is not a plain-tensor checkpoint (the reference pickles whole module objects). Convert it once with '
+                    'tools/convert_checkpoint.py, or pass allow_pickle=True / set cfg.allow_pickled_checkpoint for a file you '
+                    f'trust.  ({type(e).__name__}: {str(e)[:200]})') from e
+        return torch.load(path, map_location='cpu', weights_only=False)
+
+    def load_checkpoint(self, path, allow_pickle=None):
+        checkpoint = self._read_checkpoint(path, allow_pickle)
         self.last_iter = checkpoint['iter_num']
         self._load_modules(checkpoint)
         self._resume_optim = checkpoint.get('optim')     # checkpoints of this build carry it; restored by set_optim()
@@ -92,8 +116,8 @@ class Base_model:
             if name in self.optim_dict:
                 self.optim_dict[name].load_state_dict(st)
 
-    def load_pretrained(self, path):
-        self._load_modules(torch.load(path, weights_only=False))
+    def load_pretrained(self, path, allow_pickle=None):
+        self._load_modules(self._read_checkpoint(path, allow_pickle))
 
     def set_optim(self):
         from .engine import FusedAdam
@@ -154,7 +178,7 @@ class Base_model:
                     break
 
     def print_train_log(self, iter_id, loss_res, log_freq=10):
-        if iter_id % log_freq == 0 and self.logger is not None:
+        if iter_id % log_freq == 0 and self.logger is not None and self.rank == 0:
             avg_iter_time = self.timer.since_last_check() / log_freq
             remain_time = avg_iter_time * (self.cfg.max_iter - iter_id)
             self.logger.info(f'===> training iteration[{iter_id}/{self.cfg.max_iter}] '
@@ -183,6 +207,7 @@ class Base_model:
         names = ['PSNR', 'SSIM', 'Q', 'SAM', 'ERGAS'] if ref else []
         denorm = bool(self.cfg.get('norm_input', False))
         out_dir = osp.join(self.test_out1 if ref else self.test_out0, f'iter_{iter_id}')
+        save = save and self.rank == 0     # one process per GPU: every rank evaluates, ONE writes the files (the reference is one process)
         if save:
             mkdir_or_exist(out_dir)
 
@@ -209,18 +234,30 @@ class Base_model:
                 self.eval_results.setdefault(f'{name}_mean', []).append(round(float(res[:, k].mean()), 4))
                 self.eval_results.setdefault(f'{name}_std', []).append(round(float(res[:, k].std()), 4))
                 latest[name] = (float(res[:, k].mean()), float(res[:, k].std()))
-            if self.logger is not None:
+            if self.logger is not None and self.rank == 0:
                 self.logger.info(f'iter {iter_id} low-resolution eval: {latest}')
+        elif not ref and self.logger is not None and self.rank == 0:
+            self.logger.info(f'iter {iter_id} full-resolution pass: no-reference indices (D_lambda / D_s / QNR) are not computed by this build')
+        self._barrier()                    # no rank runs ahead of the files rank 0 is writing
         return latest
 
     def save(self, iter_id):
-        """reference pickles whole module objects + iter_num (base_model.py:354-369); additionally stores the
-        optimizer state (absent in the reference)."""
-        mkdir_or_exist(self.train_out)
+        """`train_out/model_iter_N.pth` like the reference (base_model.py:354-369), written by rank 0 only, holding plain tensors:
+        {module name: state_dict, 'iter_num', 'optim': optimizer state (absent in the reference)} -- loadable with
+        `weights_only=True`.  `cfg.pickle_modules = True` writes the reference's own format instead (whole pickled module
+        objects), for tools that expect it; such a file needs `allow_pickle` to be read back."""
         path = osp.join(self.train_out, f'model_iter_{iter_id}.pth')
-        ckpt = {'iter_num': iter_id}
-        for name, module in self.module_dict.items():
-            ckpt[name] = module.module if hasattr(module, 'module') else module
-        ckpt['optim'] = {k: v.state_dict() for k, v in self.optim_dict.items()}
-        torch.save(ckpt, path)
+        if self.rank == 0:
+            mkdir_or_exist(self.train_out)
+            ckpt = {'iter_num': iter_id}
+            pickled = bool(self.cfg.get('pickle_modules', False))
+            for name, module in self.module_dict.items():
+                core = module.module if hasattr(module, 'module') else module
+                ckpt[name] = core if pickled else {k: v.detach().cpu() for k, v in core.state_dict().items()}
+            ckpt['optim'] = {k: v.state_dict() for k, v in self.optim_dict.items()}
+            tmp = path + '.tmp'
+            torch.save(ckpt, tmp)
+            import os
+            os.replace(tmp, path)          # readers never see a half-written file
+        self._barrier()
         return path

@@ -1199,7 +1199,12 @@ int launch_ffn_fused(int e, const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t 
     // e = 16: the strip kernel on the bf16 matrix pipe in fp32-equivalent split arithmetic (k_ffn_x.hip); for A/B runs the plan's
     // switch (env LG_FFN_IMPL = strip | tile | xp, read at plan creation) selects the f32-MFMA strip kernel (1), the per-tile kernel (2)
     // it replaced, or the software-pipelined variant k_ffn_xp (3: same results bit for bit, measured 2.5 % slower)
-    if (e == 16) return a1.tile16 == 2 ? launch_ffn_fused_t<16>(a1, a2, s) : (a1.tile16 == 1 ? launch_ffn_strip(a1, a2, s) : (a1.tile16 == 3 ? launch_ffn_xp(a1, a2, s) : launch_ffn_xs(a1, a2, s)));
+#ifdef LG_BUILD_AB
+    if (e == 16 && a1.tile16 == 3) return launch_ffn_xp(a1, a2, s);
+#else
+    if (e == 16 && a1.tile16 == 3) { lg_set_error("LG_FFN_IMPL=xp: k_ffn_xp is an A/B kernel, build the library with `make AB=1`"); return -2; }
+#endif
+    if (e == 16) return a1.tile16 == 2 ? launch_ffn_fused_t<16>(a1, a2, s) : (a1.tile16 == 1 ? launch_ffn_strip(a1, a2, s) : launch_ffn_xs(a1, a2, s));
     if (e == 32) return (a1.tile16 == 0 && a1.wsplit) ? launch_ffn_x32(a1, a2, s) : launch_ffn_fused_t<32>(a1, a2, s);
     if (e == 64 && a1.tile16 == 0 && a1.wsplit && a1.h2) return launch_ffn_x64(a1, a2, s);   // two kernels, split-bf16 GEMMs
     return LG_FFN_NOT_FUSED;

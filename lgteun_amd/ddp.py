@@ -1,9 +1,20 @@
 """Batch-sharded data parallelism for the LGTEUN hot path: one process per GPU, torch.distributed (backend "nccl" is RCCL
 over xGMI on ROCm; "gloo" on CPU for tests).  Replaces the reference's single-process nn.DataParallel
 (models/base/base_model.py:91-100).  The path shards naturally: samples are independent, the only batch
-reduction is the L1 mean, so each rank computes its share of the GLOBAL-mean gradient and the flat live-gradient
-ranges are SUM-all-reduced -- two buckets: the last stage's LGT (ready first, reduced while the K data-step backwards
-still run) and the shared data-module + eta tensors (a few hundred bytes)."""
+reduction is the L1 mean, so each rank computes its share of the GLOBAL-mean gradient and the flat gradient buffer is
+SUM-all-reduced.
+
+Default: ONE collective per step over the span of the flat gradient buffer that covers every live range, issued in stream
+order behind the backward (`dist.all_reduce`, not async: RCCL enqueues it on its own stream and makes the compute stream wait
+-- no host block; gloo blocks the host until its worker thread is done).  The same call for every backend, so the path the
+2-rank tests cover is the path an 8-GPU RCCL run takes.  The live gradients are 0.4 MB (C=4) ... 1.1 MB (C=8) inside a
+1.6 ... 8.6 MB buffer whose dead-stage slots are zero: the collective is latency-bound (tens of microseconds of a 7.5 ms
+step), so reducing the zeros along costs less than packing the two live ranges would.
+
+Opt-in (`LG_DDP_OVERLAP=1` / `GradBuckets(..., overlap=True)`): two asynchronous buckets -- the last stage's LGT, reduced
+while the K data-step backwards still run, and the shared data-module + eta tensors.  It buys < 1 % of a step and is the
+form that stalled a 4-ranks-on-one-GPU gloo rehearsal in round 2, so it stays off until an 8-GPU
+RCCL run has shown it."""
 import os
 
 import torch
@@ -42,32 +53,32 @@ def broadcast_flat(flat, src=0, group=None):
         dist.broadcast(flat, src=src, group=group)
 
 
-class GradBuckets:
-    """SUM all-reduce of the live ranges of a flat gradient buffer.  `ranges` = [(a0,b0) shared+eta, (a1,b1) last LGT]."""
+def overlap_requested():
+    return os.environ.get('LG_DDP_OVERLAP', '0') == '1'
 
-    def __init__(self, ranges, group=None):
+
+class GradBuckets:
+    """SUM all-reduce of the live part of a flat gradient buffer.  `ranges` = the live ranges, in the reference's graph
+    [(a0, b0) shared + eta, (a1, b1) last stage's LGT]; in 'chained' mode [(0, total)]."""
+
+    def __init__(self, ranges, group=None, overlap=None):
         self.ranges = list(ranges)
         self.group = group
+        self.overlap = overlap_requested() if overlap is None else bool(overlap)
+        self.span = (min(a for a, _ in self.ranges), max(b for _, b in self.ranges))
         self._pending = []
 
+    # ---- default: one stream-ordered collective --------------------------------------------------
+    def all_reduce(self, flat_grad):
+        a, b = self.span
+        dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group)
+
+    # ---- opt-in overlap: one asynchronous collective per live range -------------------------------
     def start(self, flat_grad, which):
         a, b = self.ranges[which]
-        # gloo on device tensors (the N-ranks-on-one-GPU rehearsal of bench.py / tests, never the production transport) runs its
-        # collectives on host threads that copy through pinned memory: with two of them outstanding beside a stream that keeps
-        # receiving work, a 4-rank rehearsal stalled for seconds and then for good (every rank in finish(); blocking collectives: fine).
-        # RCCL collectives are stream-ordered and stay asynchronous.  LG_DDP_SYNC=1 forces the blocking form for any backend.
-        if os.environ.get('LG_DDP_SYNC') == '1' or (flat_grad.is_cuda and dist.get_backend(self.group) == 'gloo'):
-            dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group)
-            return
-        w = dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending.append(w)
+        self._pending.append(dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
-        for w in self._pending:
+        pending, self._pending = self._pending, []
+        for w in pending:
             w.wait()
-        self._pending = []
-
-    def all_reduce(self, flat_grad):
-        for i in range(len(self.ranges)):
-            self.start(flat_grad, i)
-        self.finish()

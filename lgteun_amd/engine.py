@@ -114,8 +114,6 @@ class Engine:
         self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
         self._ranges_dev = {ch: torch.tensor([v for r in rg for v in r], dtype=torch.int64, device=dev)
                             for ch, (_, rg) in self._live.items()}
-        self._first_ptr = self.params[0].data_ptr()
-        self._last_ptr = self.params[-1].data_ptr()
         self._plans = {}
         self._ws = {}
         self._ws_pool = {}             # autograd path: released training workspaces by (plan, B, train), see _WsLease
@@ -153,17 +151,30 @@ class Engine:
     def max_range(self):
         return max(b - a for a, b in self.live_ranges)
 
-    def attach_ddp(self, group=None):
-        """join a torch.distributed group: broadcast rank-0 weights, reduce the live gradient ranges every step"""
+    def attach_ddp(self, group=None, broadcast=True):
+        """join a torch.distributed group: reduce the flat gradient buffer every step.  broadcast=True (an explicit
+        `module.attach_ddp()`): rank-0 weights go to every rank -- a COLLECTIVE, so every rank of the group must make the call.
+        broadcast=False (an engine rebuilt under an attached module, e.g. after `.to()`): no communication; the ranks' weights
+        were made equal by the first attachment and identical updates keep them equal."""
         import torch.distributed as dist
         from .ddp import GradBuckets, broadcast_flat
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.process_group = group
         if self.world > 1:
-            broadcast_flat(self.flat, 0, group)
+            if broadcast:
+                broadcast_flat(self.flat, 0, group)
             self.buckets = {ch: GradBuckets(rg, group) for ch, (_, rg) in self._live.items()}
         return self
+
+    def global_loss(self):
+        """the GLOBAL-mean loss of the last train_step as a Python float (host sync; under DDP one scalar all-reduce: `_loss`
+        holds this rank's share of the global mean).  For the logging cadence only."""
+        t = self._loss.clone()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group)
+        return float(t.item())
 
     def _check_attached(self):
         """a process group with more than one rank exists but this engine never joined it: every rank would train on its own
@@ -178,7 +189,10 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------
     def valid(self):
-        return (self.params[0].data_ptr() == self._first_ptr and self.params[-1].data_ptr() == self._last_ptr)
+        """every parameter is still the view into the flat buffer it was given (a caller that re-assigns one tensor's `.data`,
+        `.to()`, a re-created parameter: the kernels would read stale weights) -- 492 pointer compares at K = 4, ~50 us"""
+        flat_ptr = self.flat.data_ptr()
+        return all(p.data_ptr() == flat_ptr + 4 * o for p, o in zip(self.params, self.offsets))
 
     def __del__(self):
         try:
@@ -303,24 +317,24 @@ class Engine:
         n_local = out.numel()
         check(self.lib.lg_l1_loss(_ptr(out), _ptr(gt), _ptr(dout), _ptr(self._loss), n_local, n_local * self.world,
                                   float(loss_weight), _stream_ptr()), 'lg_l1_loss')
-        if self.world > 1 and flags & LG_FLAG_CHAINED:
-            # every tensor is live and the LGT / data-step backwards interleave: one all-reduce of the whole flat buffer
-            self.backward_raw(saved, dout, self.gflat, flags, seed)
-            self.buckets[True].all_reduce(self.gflat)
-        elif self.world > 1 or defer:
-            # bucket 1 (last stage's LGT) is reduced over RCCL while the K data-step backwards still run
-            bk = self.buckets[False] if self.world > 1 else None
+        bk = self.buckets[bool(flags & LG_FLAG_CHAINED)] if self.world > 1 else None
+        overlap = bool(bk is not None and bk.overlap and not (flags & LG_FLAG_CHAINED))
+        if defer or overlap:
+            # two backward calls: the dead-stage forwards (side stream) and / or the opt-in asynchronous bucket of the last stage's
+            # LGT start behind the LGT backward and run beside the K data-step backwards
             self.backward_raw(saved, dout, self.gflat, flags | LG_FLAG_BWD_LGT, seed)
             if defer:
                 self._dead_forward(saved, flags, seed)
-            if bk:
+            if overlap:
                 bk.start(self.gflat, 1)
             self.backward_raw(saved, dout, self.gflat, flags | LG_FLAG_BWD_DATA, seed)
-            if bk:
+            if overlap:
                 bk.start(self.gflat, 0)
                 bk.finish()
         else:
             self.backward_raw(saved, dout, self.gflat, flags, seed)
+        if bk is not None and not overlap:
+            bk.all_reduce(self.gflat)      # default: ONE stream-ordered collective behind the whole backward (ddp.py)
         optim.step_flat(self)
         if defer:
             torch.cuda.current_stream().wait_stream(self._side_stream)   # the step ends when its dead-stage work has ended
@@ -353,7 +367,8 @@ class _WsLease:
 
     def __del__(self):
         try:
-            self._pool.append(self.ws)
+            if not self._pool:             # one spare buffer per (plan, B, train); extras go back to the allocator
+                self._pool.append(self.ws)
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
 

@@ -121,17 +121,20 @@ class Pansharpening(nn.Module):
         if self._engine is None or not self._engine.valid():
             self._engine = Engine(self)
             if self._ddp is not None:  # the data-parallel attachment belongs to the module, not to one Engine object
-                self._engine.attach_ddp(self._ddp[0])
+                # no broadcast here: a rebuild may happen on one rank only (a collective would hang) and must not overwrite what
+                # the ranks loaded; call attach_ddp() again on EVERY rank to re-synchronise the weights
+                self._engine.attach_ddp(self._ddp[0], broadcast=False)
         return self._engine
 
     def attach_ddp(self, group=None):
         """join a torch.distributed process group (one process per GPU; backend nccl = RCCL over xGMI): rank-0 weights are
-        broadcast and every train step / autograd backward all-reduces the live gradient ranges.  Replaces the reference's
-        nn.DataParallel wrap (models/base/base_model.py:91-100)."""
+        broadcast and every train step / autograd backward all-reduces the flat gradient buffer.  A COLLECTIVE call: every rank
+        of the group makes it (again after loading weights on one rank only).  Replaces the reference's nn.DataParallel wrap
+        (models/base/base_model.py:91-100)."""
+        self._ddp = None
+        eng = self.engine()            # (re)built without an attachment
         self._ddp = (group,)
-        if self._engine is not None and self._engine.valid():
-            return self._engine.attach_ddp(group)
-        return self.engine()
+        return eng.attach_ddp(group, broadcast=True)
 
     def canonical_names(self):
         return canonical_names(self.in_channels, self.stage)
@@ -172,7 +175,7 @@ class UnlgFormer(Base_model):
             loss_t = core.engine().train_step(input_batch['input_lr'], input_batch['input_pan'], input_batch['target'],
                                               G_optim, loss_weight=w)
             if iter_id % log_freq == 0:
-                v = float(loss_t.item())
+                v = core.engine().global_loss()        # all ranks: under DDP `loss_t` is this rank's share of the global mean
                 self.print_train_log(iter_id, dict(rec_loss=v / w if w else 0.0, full_loss=v), log_freq)
             return
         output = G(input_batch['input_lr'], input_batch['input_pan'])

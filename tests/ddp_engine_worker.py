@@ -70,9 +70,65 @@ def main():
             res['unattached_raised'] = np.array(0)
         except RuntimeError as e:
             res['unattached_raised'] = np.array(int('attach_ddp' in str(e)))
+    res.update(runner_check(outdir, rank, world, ms, pan, gt))
     np.savez(os.path.join(outdir, f'rank{rank}.npz'), **res)
     dist.barrier()
     dist.destroy_process_group()
+
+
+class _ListLogger:
+    def __init__(self):
+        self.lines = []
+
+    def info(self, msg):
+        self.lines.append(str(msg))
+
+    error = warning = info
+
+
+def runner_check(outdir, rank, world, ms, pan, gt):
+    """the reference-style RUNNER on two ranks (Base_model.train / save / test; reference models/base/base_model.py:164-204,354-369
+    under one process per GPU instead of nn.DataParallel): ONE rank writes the checkpoint and the fused images, every rank waits for
+    the files, the logged loss is the GLOBAL mean, and the written checkpoint loads back with weights_only=True"""
+    import lgteun_amd
+    from lgteun_amd import ddp
+    from lgteun_amd.compat import Config
+    a, b = ddp.shard_bounds(B_GLOBAL, rank, world)
+    work = os.path.join(outdir, 'runner')
+    batch = dict(input_lr=ms[a:b] * 2047.5, input_pan=pan[a:b] * 2047.5, target=gt[a:b] * 2047.5, image_id=[f'r{rank}_{i}' for i in range(b - a)])
+    cfg = Config(dict(ms_chans=C, work_dir=work, datas='GF-2', cuda=True, max_iter=2, bit_depth=11, norm_input=True,
+                      save_freq=1, eval_freq=-1, test_freq=-1, loss_cfg={'rec_loss': dict(type='l1', w=1.)},
+                      optim_cfg={'core_module': dict(type='Adam', betas=(0.9, 0.999), lr=1.5e-3)},
+                      sched_cfg=dict(step_size=2, gamma=0.85), model_cfg={'core_module': dict(stage=K)}))
+    log = _ListLogger()
+    torch.manual_seed(100 + rank)                       # different initial weights per rank: set_cuda() must broadcast rank 0's
+    runner = lgteun_amd.build_model('UnlgFormer', cfg, log, [batch], [batch], [batch])
+    runner.set_cuda()
+    runner.set_optim()
+    runner.set_sched()
+    runner.optim_dict['core_module'].dropout = False
+    out = {'runner_rank': np.array(runner.rank), 'runner_world': np.array(runner.world)}
+    runner.train_iter(iter_id=10, input_batch=lgteun_amd.base_model.data_normalize(batch, 11), log_freq=10)   # logs on rank 0
+    eng = runner.module_dict['core_module'].engine()
+    out['runner_local_loss'] = np.array(float(eng._loss.item()))
+    out['runner_global_loss'] = np.array(eng.global_loss())
+    logged = [ln for ln in log.lines if ln.startswith('full loss')]
+    out['runner_logged_loss'] = np.array(float(logged[-1].split(':')[1]) if logged else -1.0)
+    path = runner.save(iter_id=1)                       # rank 0 writes, everyone returns behind the barrier
+    out['runner_ckpt_exists'] = np.array(int(os.path.exists(path)))
+    out['runner_tmp_left'] = np.array(int(os.path.exists(path + '.tmp')))
+    ck = torch.load(path, map_location='cpu', weights_only=True)
+    out['runner_ckpt_iter'] = np.array(int(ck['iter_num']))
+    w_now = torch.cat([v.detach().reshape(-1).cpu() for v in runner.module_dict['core_module'].state_dict().values()])
+    w_ck = torch.cat([v.reshape(-1) for v in ck['core_module'].values()])
+    out['runner_ckpt_equal'] = np.array(int(torch.equal(w_now, w_ck)))
+    runner.test(iter_id=1, save=True, ref=True)         # every rank evaluates; only rank 0 writes TIFFs
+    d = os.path.join(work, 'GF-2', 'test_out1', 'iter_1')
+    out['runner_tifs'] = np.array(sorted(os.listdir(d)) if os.path.isdir(d) else [])
+    r2 = lgteun_amd.build_model('UnlgFormer', cfg, _ListLogger(), [batch], [batch], [batch])
+    r2.load_checkpoint(path)                            # plain-tensor checkpoint: loads without executing anything from the file
+    out['runner_reload_iter'] = np.array(int(r2.last_iter))
+    return out
 
 
 if __name__ == '__main__':

@@ -154,3 +154,51 @@ def test_reference_config_file_builds_the_model(tmp_path):
     assert getattr(opt, 'is_fused_lgteun', False) and opt.param_groups[0]['lr'] == 1.5e-3 and opt.param_groups[0]['betas'] == (0.9, 0.999)
     assert runner.sched_dict['core_module'].step_size == cfg.step and runner.sched_dict['core_module'].gamma == 0.85
     assert runner.train_out.endswith('/WV-3/train_out')
+
+
+def test_checkpoints_are_plain_tensors_and_pickled_ones_need_consent(tmp_path):
+    """Base_model.save writes {module: state_dict, iter_num, optim} that `weights_only=True` loads (nothing in the file is executed);
+    the reference's own format -- whole pickled module objects, base_model.py:362-368 -- is written only with cfg.pickle_modules and
+    read back only with explicit consent (allow_pickle / cfg.allow_pickled_checkpoint); losses: unknown types end the run like
+    the reference (losses.py:34), zero-weight losses are dropped (:229)"""
+    import logging
+    import lgteun_amd
+    from lgteun_amd.compat import Config
+    from lgteun_amd.losses import get_loss_module
+
+    def mk(**extra):
+        cfg = Config(dict(ms_chans=4, work_dir=str(tmp_path), datas='GF-2', loss_cfg={'rec_loss': dict(type='l1', w=1.)},
+                          model_cfg={'core_module': dict(stage=1)}, **extra))
+        return lgteun_amd.build_model('UnlgFormer', cfg, logging.getLogger('ck'), None, None, None)
+    torch.manual_seed(5)
+    a = mk()
+    path = a.save(iter_id=9)
+    ck = torch.load(path, weights_only=True)
+    assert ck['iter_num'] == 9 and set(ck) == {'iter_num', 'core_module', 'optim'}
+    b = mk()
+    b.load_checkpoint(path)
+    assert b.last_iter == 9
+    for (k, v), (k2, v2) in zip(a.module_dict['core_module'].state_dict().items(), b.module_dict['core_module'].state_dict().items()):
+        assert k == k2 and torch.equal(v, v2)
+    # the reference's format
+    c = mk(pickle_modules=True)
+    p2 = c.save(iter_id=11)
+    with pytest.raises(RuntimeError, match='convert_checkpoint'):
+        mk().load_checkpoint(p2)
+    d = mk()
+    d.load_checkpoint(p2, allow_pickle=True)
+    assert d.last_iter == 11
+    e = mk(allow_pickled_checkpoint=True)
+    e.load_pretrained(p2)
+    for (k, v), (_, v2) in zip(c.module_dict['core_module'].state_dict().items(), e.module_dict['core_module'].state_dict().items()):
+        assert torch.equal(v, v2), k
+    # loss factory
+    assert set(get_loss_module(Config(dict(loss_cfg={'rec_loss': dict(type='l2', w=0.5)})), None)) == {'rec_loss'}
+    assert get_loss_module(Config(dict(loss_cfg={'rec_loss': dict(type='l1', w=0.0)})), None) == {}
+    with pytest.raises(SystemExit):
+        get_loss_module(Config(dict(loss_cfg={'rec_loss': dict(type='huber', w=1.0)})), None)
+    with pytest.raises(SystemExit):
+        get_loss_module(Config(dict(loss_cfg={'QNR_loss': dict(w=1.0)})), None)
+    m = get_loss_module(Config(dict(loss_cfg={'rec_loss': dict(type='l1', w=1.0)})), None)['rec_loss']
+    x, y = torch.tensor([1.0, 3.0]), torch.tensor([0.0, 1.0])
+    assert m.get_type() == 'l1' and float(m(out=x, gt=y)) == 1.5

@@ -1,6 +1,7 @@
 """N > 1 path on CPU: world_size-2 gloo run of the DDP bucket logic (lgteun_amd.ddp + the flat live-range layout).
 Each rank computes ITS SHARE of the global-mean L1 gradient with the oracle on its batch shard, scatters it into the flat
-gradient buffer at the engine's offsets and SUM-all-reduces the two live ranges; the result must equal the single-process
+gradient buffer at the engine's offsets and SUM-all-reduces it -- the default single stream-ordered collective, and the opt-in
+form with two asynchronous buckets outstanding at once; the result must equal the single-process
 gradient on the concatenated batch (SURVEY 8e equivalence test), and dead-stage slots must stay untouched."""
 import os
 import socket
@@ -36,7 +37,7 @@ def _flat_grads(P, ms, pan, gt, n_global, mode='faithful'):
     return flat, live_ranges, float(loss)
 
 
-def _worker(rank, world, port, q, mode):
+def _worker(rank, world, port, q, mode, overlap):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
     from lgteun_amd import ddp
@@ -53,13 +54,19 @@ def _worker(rank, world, port, q, mode):
     before = wflat.clone()
     ddp.broadcast_flat(wflat, 0)
     assert torch.equal(wflat, before)
-    buckets = ddp.GradBuckets(ranges)
-    if mode == 'chained':
-        buckets.all_reduce(flat)
-    else:
-        buckets.start(flat, 1)       # LGT bucket first (overlaps the data-step backward on the GPU path)
+    buckets = ddp.GradBuckets(ranges, overlap=overlap)
+    assert buckets.overlap == overlap
+    if overlap:
+        # opt-in form (LG_DDP_OVERLAP=1): two ASYNCHRONOUS collectives outstanding at once, the LGT bucket first (on the GPU path it
+        # overlaps the data-step backwards), then unrelated work, then finish()
+        buckets.start(flat, 1)
         buckets.start(flat, 0)
+        assert len(buckets._pending) == 2
+        _ = torch.ones(1000).sum()
         buckets.finish()
+        assert not buckets._pending
+    else:
+        buckets.all_reduce(flat)     # the default: ONE stream-ordered collective over the span of the live ranges (Engine.train_step)
     lt = torch.tensor([loss], dtype=torch.float64)
     dist.all_reduce(lt)
     if rank == 0:
@@ -68,14 +75,14 @@ def _worker(rank, world, port, q, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('mode', ['faithful', 'chained'])
-def test_two_rank_gradients_equal_single_process(mode):
+@pytest.mark.parametrize('mode,overlap', [('faithful', False), ('faithful', True), ('chained', False)])
+def test_two_rank_gradients_equal_single_process(mode, overlap):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     got, loss2 = q.get(timeout=300)
@@ -112,3 +119,5 @@ def test_shard_bounds_and_layout():
     offs, total, live_idx, ranges = flat_layout(names, [int(np.prod(shapes[n])) if len(shapes[n]) else 1 for n in names], 4)
     assert all(o % 4 == 0 for o in offs) and len(live_idx) == 12 + 4 + 119
     assert ranges[0][0] == 0 and ranges[1][1] == total and ranges[0][1] <= ranges[1][0]
+    assert ddp.GradBuckets(ranges).span == (0, total)          # the default bucket: one span over every live range
+    assert ddp.GradBuckets(ranges).overlap is False            # two asynchronous buckets are opt-in (LG_DDP_OVERLAP=1)

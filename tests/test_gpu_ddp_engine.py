@@ -48,3 +48,24 @@ def test_two_rank_engine_train_step_equals_single_process(request):
     w, ws = r0['weights'], r0['single_weights']
     assert _rel(w[a1:b1], ws[a1:b1]) < 1e-4 and _rel(w[a0:b0], ws[a0:b0]) < 1e-4
     assert np.array_equal(w[b0:a1], ws[b0:a1])                  # dead stages untouched by Adam on every path
+
+
+def test_two_rank_runner_writes_once_and_logs_the_global_loss(request):
+    """the reference-style runner under one process per GPU: rank 0 alone writes `train_out/model_iter_N.pth` and the
+    fused TIFFs, the other rank returns behind a barrier and finds the finished file; the checkpoint holds plain tensors
+    (weights_only=True) equal to the live weights; the logged `full loss` is the GLOBAL mean, not one rank's 1/world share"""
+    job = getattr(request.config, '_lgteun_ddp_job', None)
+    assert job is not None
+    outdir, procs, logs = job
+    for p in procs:
+        assert p.wait(timeout=900) == 0, ''.join(open(f).read()[-3000:] for f in logs)
+    r0, r1 = (np.load(f'{outdir}/rank{r}.npz') for r in (0, 1))
+    assert (int(r0['runner_rank']), int(r1['runner_rank'])) == (0, 1) and int(r0['runner_world']) == 2
+    for r in (r0, r1):
+        assert int(r['runner_ckpt_exists']) == 1 and int(r['runner_tmp_left']) == 0
+        assert int(r['runner_ckpt_iter']) == 1 and int(r['runner_ckpt_equal']) == 1 and int(r['runner_reload_iter']) == 1
+    g = float(r0['runner_global_loss'])
+    assert abs(g - float(r1['runner_global_loss'])) < 1e-7
+    assert abs(float(r0['runner_local_loss']) + float(r1['runner_local_loss']) - g) < 1e-6
+    assert abs(float(r0['runner_logged_loss']) - g) < 1e-5 and float(r1['runner_logged_loss']) == -1.0   # rank 0 logs, the global mean
+    assert list(r0['runner_tifs']) == ['r0_0_mul_hat.tif', 'r0_1_mul_hat.tif']                           # rank 1 wrote nothing

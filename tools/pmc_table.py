@@ -15,7 +15,7 @@ for r in rows:
     acc[k][r['Counter_Name']] += float(r['Counter_Value'])
     launches[k].add(r['Dispatch_Id'])
 names = sorted({c for k in acc for c in acc[k]})
-print('kernel'.ljust(48), 'n'.rjust(5), *[c[-18:].rjust(19) for c in names])
+print('kernel'.ljust(84), 'n'.rjust(5), *[c[-18:].rjust(19) for c in names])
 for k in sorted(acc, key=lambda k: -sum(acc[k].values())):
     n = len(launches[k])
-    print(k[:48].ljust(48), str(n).rjust(5), *[f'{acc[k][c] / n:19.0f}' for c in names])
+    print(k[:84].ljust(84), str(n).rjust(5), *[f'{acc[k][c] / n:19.0f}' for c in names])
