@@ -129,7 +129,7 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
         const char* impl = getenv("LG_FFN_IMPL");
         p->ffn_tile = !impl ? 0 : (!strcmp(impl, "strip") ? 1 : (!strcmp(impl, "tile") ? 2 : (!strcmp(impl, "xp") ? 3 : 0)));
         const char* sv = getenv("LG_FFN_SAVE");
-        p->save3 = (sv && !strcmp(sv, "5")) ? 0 : 1;   // default: pre-activation saves; "5": the five-tensor form (A/B)
+        p->save_mode = !sv ? 2 : (!strcmp(sv, "5") ? 5 : (!strcmp(sv, "3") ? 3 : 2));   // common.h: lg_plan::save_mode
     }
     p->off = (int64_t*)malloc(sizeof(int64_t) * n_offsets);
     memcpy(p->off, offsets, sizeof(int64_t) * n_offsets);
@@ -211,7 +211,7 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     int rc;
     Ffn1Args a1;
     const bool pre = pl->ffn_saves_preact(bb.e);   // h1 / h3 go to the a1 / a3 slots, nothing to g1 / g3
-    a1.x = bb.xmid; a1.a1s = (flags & LG_FLAG_SAVE) ? bb.a1 : nullptr; a1.g1s = ((flags & LG_FLAG_SAVE) && !pre) ? bb.g1 : nullptr; a1.h2 = bb.h2;
+    a1.x = bb.xmid; a1.a1s = ((flags & LG_FLAG_SAVE) && !pl->ffn_bwd_x(bb.e)) ? bb.a1 : nullptr; a1.g1s = ((flags & LG_FLAG_SAVE) && !pre) ? bb.g1 : nullptr; a1.h2 = bb.h2;
     a1.ln2g = P + pl->blk(stage, j, B_LN2G); a1.ln2b = P + pl->blk(stage, j, B_LN2B);
     a1.w1 = P + pl->blk(stage, j, B_W1); a1.b1 = P + pl->blk(stage, j, B_B1);
     a1.w2 = P + pl->blk(stage, j, B_W2); a1.b2 = P + pl->blk(stage, j, B_B2);

@@ -32,12 +32,14 @@ struct lg_plan {
     lg_config cfg;
     int n_offsets;
     int ffn_tile;  // A/B switch read ONCE at plan creation (env LG_FFN_IMPL = strip | tile): the f32-MFMA fused FFN kernels instead of the split-bf16 ones
-    int save3;     // A/B switch read ONCE at plan creation (env LG_FFN_SAVE = 5 turns it off), see ffn_saves_preact
-    // true (default): the live stage's e = 16 FFN half-blocks save the PRE-ACTIVATIONS h1, h2, h3 (in the a1 / h2 / a3 slots) and the
-    // backward re-evaluates gelu / gelu' with the forward's own functions; false: they save gelu(h1), gelu'(h1), h2, gelu(h3), gelu'(h3)
-    // (five tensors) and the backward evaluates no GELU.  Measured on one box: the same step time (7.44 ms either
-    // way), the saving launch 179 -> 146 us, 40 % less saved-activation traffic and 270 MB less workspace per block.
-    bool ffn_saves_preact(int e) const { return e == 16 && cfg.precision == 0 && ffn_tile == 0 && save3; }
+    int save_mode; // A/B switch read ONCE at plan creation (env LG_FFN_SAVE = 5 | 3 | 2, default 2): what the live stage's e = 16 FFN half-blocks
+    // keep for the backward.  2 (default): the pre-activations h2, h3 -- h1 is re-computed from x by k_ffn1_bwd_xs (k_ffn_bwd_x.hip), which
+    // also forms dW1 / dW2 on the bf16 matrix pipe; 3: h1, h2, h3 (round 2's default: k_ffn1_bwd<16> + k_wgrad_t re-evaluate gelu / gelu');
+    // 5: gelu(h1), gelu'(h1), h2, gelu(h3), gelu'(h3) (GELU-free backward; the only form of the other widths and of precision = 'bf16').
+    // In modes 2 / 3 the tensors sit in the a1 / h2 / a3 slots (workspace.h) and the g1 / g3 slots stay unused.
+    bool ffn_e16_split() const { return cfg.precision == 0 && ffn_tile == 0; }
+    bool ffn_saves_preact(int e) const { return e == 16 && ffn_e16_split() && save_mode != 5; }
+    bool ffn_bwd_x(int e) const { return e == 16 && ffn_e16_split() && save_mode == 2; }   // h1 not saved; backward through k_ffn1_bwd_xs
     int64_t* off;  // host copy of offsets
     int64_t shared(int s) const { return off[s]; }
     int64_t eta(int i) const { return off[S_NSHARED + i]; }

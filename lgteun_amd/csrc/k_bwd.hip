@@ -106,6 +106,20 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
     fd.d_dww = G + pl->blk(st, j, B_DWW); fd.d_dwb = G + pl->blk(st, j, B_DWB);
     fd.B = B; fd.h = fb.h; fd.w = fb.w; fd.hbf = hbf; fd.pre = pre;
     RC(launch_ffn_dw_bwd(e, fd, s));
+    if (pl->ffn_bwd_x(e)) {
+        // h1 was not saved: one pass over dh2 re-computes it and yields dx, the LayerNorm gradients, dW1 / db1 and dW2 / db2
+        Ffn1BwdXArgs fx;
+        fx.dh2 = bb.dh2; fx.x = fb.xmid; fx.dy = dy; fx.dx = tmp;
+        fx.w1 = P + pl->blk(st, j, B_W1); fx.b1 = P + pl->blk(st, j, B_B1); fx.w2t = bb.w2t[j]; fx.w1t = bb.w1t[j];
+        fx.ln2g = P + pl->blk(st, j, B_LN2G); fx.ln2b = P + pl->blk(st, j, B_LN2B);
+        fx.slab = bb.rq.take((size_t)FFN1_BWD_WGS * FFN1_BWD_X_ROW);
+        if (!fx.slab) return -3;
+        fx.d_w1 = G + pl->blk(st, j, B_W1); fx.d_b1 = G + pl->blk(st, j, B_B1); fx.d_w2 = G + pl->blk(st, j, B_W2); fx.d_b2 = G + pl->blk(st, j, B_B2);
+        fx.d_ln2g = G + pl->blk(st, j, B_LN2G); fx.d_ln2b = G + pl->blk(st, j, B_LN2B);
+        fx.P = Pn;
+        RC(launch_ffn1_bwd_xs(fx, s));
+        return wgrad(dy, e, fb.a3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 0, hbf, bb, s, pre);
+    }
     Ffn1BwdArgs f1;
     f1.dh2 = bb.dh2; f1.g1 = pre ? fb.a1 : fb.g1; f1.x = fb.xmid; f1.dy = dy; f1.dh1 = bb.dh1; f1.y2 = bb.y2; f1.dx = tmp;
     f1.w2t = bb.w2t[j]; f1.w1t = bb.w1t[j];

@@ -1,0 +1,294 @@
+// k_ffn1_bwd_xs: the pixelwise half of the feed_forward backward at e = 16 (reference models/common/LGT.py:91-109 with the pre_norm /
+// residual wrappers :45-61) with EVERYTHING that hangs off dh2 in one pass, on the bf16 matrix pipe in fp32-equivalent split
+// arithmetic (split_bf16.h):
+//
+//     h1  = W1 LN(x) + b1                 (re-computed: the forward no longer saves it)
+//     dh1 = (W2^T dh2) * gelu'(h1)
+//     dx  = dy + LN^T (W1^T dh1)          + d gamma, d beta of the LayerNorm
+//     dW2 += dh2 (x) gelu(h1),  db2 += dh2,  dW1 += dh1 (x) LN(x),  db1 += dh1        (pixel sums)
+//
+// It replaces k_ffn1_bwd<16> (f32 MFMA: 101 us, reads dh2 + h1 + x + dy) AND the 64 x 64 weight-gradient launch k_wgrad_t<4,4>
+// (f32 MFMA: 68 us, reads dh2 + h1 again): dh2 is read once, h1 never (profiles/r03_*).
+//
+// Orientation: PIXELS ride on the A side of the MFMA, weights on the B side, so a lane ends up with one hidden CHANNEL (column r
+// of the wave's 16-channel block) for four consecutive PIXELS (rows 4 g .. 4 g + 3).  That is exactly the operand layout of the
+// weight-gradient products, whose K dimension is the pixel axis: gelu(h1) and dh1 go from the accumulator registers straight
+// into dW2's B operand and dW1's A operand (v_mfma_f32_16x16x16_bf16, k = 4 g + j) without touching LDS.  The operands that do
+// live in LDS ([pixel][channel] images of the bf16 pieces of dh2 and LN(x)) are read by rows for the data GEMMs and by columns
+// (ds_read_b64_tr_b16, the hardware transpose read) for the weight gradients: one image serves both.
+// Wave w owns hidden channels [16 w, 16 w + 16): its dW1 rows, its dW2 columns and its K = 16 slice of W1^T dh1, whose four
+// partial sums meet in LDS in front of the LayerNorm backward.
+//
+// Tile = 64 pixels, persistent workgroups deal tiles round-robin, next tile's operands in flight in registers.
+// LDS 55 KB (two workgroups per CU): D2 pieces [3][64][72] bf16 | LN(x) pieces [3][64][16] | per-wave dh1^T [4][3][16][16] |
+// W1^T dh1 partials [4][64][16] fp32.
+#include "kernels.h"
+#include "bwd_kernels.h"
+#include "split_bf16.h"
+
+namespace {
+
+constexpr int E = 16, N1 = 64, NPX = 64, LDP = 72;
+constexpr int D2_PIECE = NPX * LDP;          // halves
+constexpr int XN_PIECE = NPX * E;            // halves
+constexpr int D1T_PIECE = 16 * 16;           // halves, per wave and piece
+constexpr size_t OFF_XN = (size_t)3 * D2_PIECE * 2;
+constexpr size_t OFF_D1T = OFF_XN + (size_t)3 * XN_PIECE * 2;
+constexpr size_t OFF_RED = OFF_D1T + (size_t)4 * 3 * D1T_PIECE * 2;
+constexpr size_t LDS_BYTES = OFF_RED + (size_t)4 * NPX * E * 4;
+static_assert(OFF_XN % 16 == 0 && OFF_D1T % 16 == 0 && OFF_RED % 16 == 0, "16-byte aligned LDS regions");
+
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    return v;
+}
+__device__ __forceinline__ bf16x8_t lds_x8(const uint16_t* p) { return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(p)); }
+__device__ __forceinline__ s16x4_t lds_x4(const uint16_t* p) { return __builtin_bit_cast(s16x4_t, *reinterpret_cast<const u32x2_t*>(p)); }
+// transposed read: the 16 lanes of a group hand in the addresses of a 4-row x 16-column block of 16-bit elements (lane 4 q + p: row q,
+// columns 4 p .. 4 p + 3) and lane i gets column i of the four rows
+__device__ __forceinline__ s16x4_t lds_tr4(const uint16_t* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p);
+}
+// the six piece products of a fp32-equivalent 16x16x16 block: a, b = the three bf16 pieces of each operand (small terms first)
+__device__ __forceinline__ void mfma6_16(f32x4_t& acc, const s16x4_t (&a)[3], const s16x4_t (&b)[3]) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[0], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma6_32(f32x4_t& acc, const bf16x8_t (&a)[3], const bf16x8_t (&b)[3]) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void split4(const float (&v)[4], s16x4_t (&p)[3]) {
+    u32x2_t q1, q2, q3;
+    split3_x4(v, q1, q2, q3);
+    p[0] = __builtin_bit_cast(s16x4_t, q1); p[1] = __builtin_bit_cast(s16x4_t, q2); p[2] = __builtin_bit_cast(s16x4_t, q3);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn1_bwd_xs(Ffn1BwdXArgs a, long ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint16_t* D2 = reinterpret_cast<uint16_t*>(smem_raw);                 // [3][NPX][LDP]   bf16 pieces of dh2
+    uint16_t* XN = reinterpret_cast<uint16_t*>(smem_raw + OFF_XN);        // [3][NPX][E]     bf16 pieces of LN(x)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    uint16_t* D1T = reinterpret_cast<uint16_t*>(smem_raw + OFF_D1T) + wave * 3 * D1T_PIECE;   // [3][16 ch][16 px] of this wave
+    float* red = reinterpret_cast<float*>(smem_raw + OFF_RED);            // [4 waves][NPX][E]
+
+    // ---- weights of this wave's hidden-channel block, split once, register-resident
+    const WFrag16 w1f = load_wfrag16(a.w1 + (size_t)(wave * 16) * E, E, 0);            // [n = 16 w + r][k = 4 g ..]: B of h1 = LN(x) W1^T
+    const WFrag32 w2f0 = load_wfrag32(a.w2t + (size_t)(wave * 16) * N1, N1, 0);        // [n' = 16 w + r][n = 8 g ..]: B of da1 = dh2 W2
+    const WFrag32 w2f1 = load_wfrag32(a.w2t + (size_t)(wave * 16) * N1, N1, 1);
+    const WFrag16 w1tf = load_wfrag16(a.w1t, N1, wave * 16);                           // [k = r][n = 16 w + 4 g ..]: A of W1^T dh1 (K slice)
+    const float b1s = a.b1[wave * 16 + r];
+    // LayerNorm role: thread = (pixel t / 4, channel quad t % 4)
+    const int lpx = threadIdx.x >> 2, lq = threadIdx.x & 3;
+    const float4 lng = *reinterpret_cast<const float4*>(a.ln2g + 4 * lq), lnb = *reinterpret_cast<const float4*>(a.ln2b + 4 * lq);
+    // loader role: thread = (pixel t / 16 + 16 it, channel quad t % 16)
+    const int dq = threadIdx.x & 15, dpx = threadIdx.x >> 4;
+
+    f32x4_t acc2[4], acc1 = (f32x4_t){0.f, 0.f, 0.f, 0.f};   // dW2[16 nb + 4 g + v][16 w + r], dW1[16 w + 4 g + v][r]
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) acc2[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float bs1 = 0.f;                                          // db1[16 w + r], this lane's pixels
+    float4 bs2 = make_float4(0.f, 0.f, 0.f, 0.f);             // db2[4 dq ..], this thread's pixels
+    float4 pg = make_float4(0.f, 0.f, 0.f, 0.f), pb = pg;     // d gamma / d beta [4 lq ..], this thread's pixels
+
+    float4 d2n[4], xnx, dyn;
+    auto issue = [&](long tile_) {
+        const long p0 = tile_ * NPX;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) d2n[it] = *reinterpret_cast<const float4*>(a.dh2 + (p0 + dpx + 16 * it) * N1 + 4 * dq);
+        xnx = *reinterpret_cast<const float4*>(a.x + (p0 + lpx) * E + 4 * lq);
+        dyn = *reinterpret_cast<const float4*>(a.dy + (p0 + lpx) * E + 4 * lq);
+    };
+    if ((long)blockIdx.x < ntiles) issue(blockIdx.x);
+
+#pragma unroll 1
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long p0 = tile * NPX;
+        // ---- loader: dh2 -> pieces -> D2 ; LN(x) -> pieces -> XN (the previous tile's readers of both are behind its second barrier)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const float4 d = d2n[it];
+            bs2.x += d.x; bs2.y += d.y; bs2.z += d.z; bs2.w += d.w;
+            const float v[4] = {d.x, d.y, d.z, d.w};
+            u32x2_t q1, q2, q3;
+            split3_x4(v, q1, q2, q3);
+            uint16_t* dst = D2 + (dpx + 16 * it) * LDP + 4 * dq;
+            *reinterpret_cast<u32x2_t*>(dst) = q1;
+            *reinterpret_cast<u32x2_t*>(dst + D2_PIECE) = q2;
+            *reinterpret_cast<u32x2_t*>(dst + 2 * D2_PIECE) = q3;
+        }
+        const float4 xv = xnx, dyv = dyn;
+        const float mu = quad_sum((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / E);
+        const float c0 = xv.x - mu, c1 = xv.y - mu, c2 = xv.z - mu, c3 = xv.w - mu;
+        const float rstd = __builtin_amdgcn_rsqf(quad_sum((c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3)) * (1.0f / E) + LG_EPS);
+        const float xh[4] = {c0 * rstd, c1 * rstd, c2 * rstd, c3 * rstd};
+        {
+            const float yv[4] = {xh[0] * lng.x + lnb.x, xh[1] * lng.y + lnb.y, xh[2] * lng.z + lnb.z, xh[3] * lng.w + lnb.w};
+            u32x2_t q1, q2, q3;
+            split3_x4(yv, q1, q2, q3);
+            uint16_t* dst = XN + lpx * E + 4 * lq;
+            *reinterpret_cast<u32x2_t*>(dst) = q1;
+            *reinterpret_cast<u32x2_t*>(dst + XN_PIECE) = q2;
+            *reinterpret_cast<u32x2_t*>(dst + 2 * XN_PIECE) = q3;
+        }
+        if (tile + (long)gridDim.x < ntiles) issue(tile + gridDim.x);   // next tile's operands: in flight during the GEMM phase
+        __syncthreads();
+
+        // ---- GEMM phase: four blocks of 16 pixels; this wave's 16 hidden channels
+#pragma unroll 1
+        for (int pbk = 0; pbk < NPX / 16; ++pbk) {
+            // h1[px 4 g + v][ch 16 w + r] = LN(x) W1^T + b1
+            s16x4_t xa[3];
+            {
+                const uint16_t* p = XN + (pbk * 16 + r) * E + 4 * g;
+                xa[0] = lds_x4(p); xa[1] = lds_x4(p + XN_PIECE); xa[2] = lds_x4(p + 2 * XN_PIECE);
+            }
+            f32x4_t h1 = (f32x4_t){b1s, b1s, b1s, b1s};
+            mfma6_16(h1, xa, w1f.p);
+            // da1 = dh2 W2 (K = 64 as two 32-deep blocks)
+            f32x4_t da = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            {
+                const uint16_t* p = D2 + (pbk * 16 + r) * LDP + 8 * g;
+                const bf16x8_t d0[3] = {lds_x8(p), lds_x8(p + D2_PIECE), lds_x8(p + 2 * D2_PIECE)};
+                mfma6_32(da, d0, w2f0.p);
+                const bf16x8_t d1[3] = {lds_x8(p + 32), lds_x8(p + 32 + D2_PIECE), lds_x8(p + 32 + 2 * D2_PIECE)};
+                mfma6_32(da, d1, w2f1.p);
+            }
+            // gelu(h1), gelu'(h1) with one exponential for both; dh1 = da1 * gelu'(h1)
+            lg_v2f a01, a23, g01, g23;
+            gelu2_both_f((lg_v2f){h1[0], h1[1]}, a01, g01);
+            gelu2_both_f((lg_v2f){h1[2], h1[3]}, a23, g23);
+            const float a1v[4] = {a01.x, a01.y, a23.x, a23.y};
+            const float d1v[4] = {da[0] * g01.x, da[1] * g01.y, da[2] * g23.x, da[3] * g23.y};
+            bs1 += (d1v[0] + d1v[1]) + (d1v[2] + d1v[3]);
+            s16x4_t a1p[3], d1p[3];
+            split4(a1v, a1p);
+            split4(d1v, d1p);
+            // dW1[16 w + .][.] += dh1^T LN(x): A = dh1 from the registers (K = the lane's four pixels), B = LN(x) read by columns
+            {
+                const uint16_t* p = XN + (pbk * 16 + 4 * g + (r >> 2)) * E + 4 * (r & 3);
+                const s16x4_t xt[3] = {lds_tr4(p), lds_tr4(p + XN_PIECE), lds_tr4(p + 2 * XN_PIECE)};
+                mfma6_16(acc1, d1p, xt);
+            }
+            // dW2[.][16 w + .] += dh2^T gelu(h1): A = dh2 read by columns, B = gelu(h1) from the registers
+            {
+                const uint16_t* p = D2 + (pbk * 16 + 4 * g + (r >> 2)) * LDP + 4 * (r & 3);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const s16x4_t dt[3] = {lds_tr4(p + 16 * nb), lds_tr4(p + 16 * nb + D2_PIECE), lds_tr4(p + 16 * nb + 2 * D2_PIECE)};
+                    mfma6_16(acc2[nb], dt, a1p);
+                }
+            }
+            // this wave's K = 16 slice of W1^T dh1: dh1 -> [channel][pixel] in the wave's own LDS region, read back by columns as the B operand
+            {
+                uint16_t* dst = D1T + r * 16 + 4 * g;
+                *reinterpret_cast<u32x2_t*>(dst) = __builtin_bit_cast(u32x2_t, d1p[0]);
+                *reinterpret_cast<u32x2_t*>(dst + D1T_PIECE) = __builtin_bit_cast(u32x2_t, d1p[1]);
+                *reinterpret_cast<u32x2_t*>(dst + 2 * D1T_PIECE) = __builtin_bit_cast(u32x2_t, d1p[2]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint16_t* p = D1T + (4 * g + (r >> 2)) * 16 + 4 * (r & 3);
+                const s16x4_t dtp[3] = {lds_tr4(p), lds_tr4(p + D1T_PIECE), lds_tr4(p + 2 * D1T_PIECE)};
+                f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                mfma6_16(o, w1tf.p, dtp);             // o[v] = (W1^T dh1)[out channel 4 g + v][pixel r], hidden channels 16 w .. 16 w + 15 only
+                __builtin_amdgcn_wave_barrier();      // D1T is rewritten by the next pixel block
+                *reinterpret_cast<float4*>(red + ((size_t)wave * NPX + pbk * 16 + r) * E + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        __syncthreads();
+
+        // ---- LayerNorm backward + residual (thread = pixel lpx, channels 4 lq ..): sum of the four K slices, then the usual two moments
+        {
+            const float* rp = red + (size_t)lpx * E + 4 * lq;
+            const float4 s0 = *reinterpret_cast<const float4*>(rp), s1 = *reinterpret_cast<const float4*>(rp + NPX * E);
+            const float4 s2 = *reinterpret_cast<const float4*>(rp + 2 * NPX * E), s3 = *reinterpret_cast<const float4*>(rp + 3 * NPX * E);
+            const float dl[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
+            pg.x += dl[0] * xh[0]; pg.y += dl[1] * xh[1]; pg.z += dl[2] * xh[2]; pg.w += dl[3] * xh[3];
+            pb.x += dl[0]; pb.y += dl[1]; pb.z += dl[2]; pb.w += dl[3];
+            const float dxh[4] = {dl[0] * lng.x, dl[1] * lng.y, dl[2] * lng.z, dl[3] * lng.w};
+            const float m1 = quad_sum((dxh[0] + dxh[1]) + (dxh[2] + dxh[3])) * (1.0f / E);
+            const float m2 = quad_sum((dxh[0] * xh[0] + dxh[1] * xh[1]) + (dxh[2] * xh[2] + dxh[3] * xh[3])) * (1.0f / E);
+            *reinterpret_cast<float4*>(a.dx + (p0 + lpx) * E + 4 * lq) =
+                make_float4(dyv.x + rstd * (dxh[0] - m1 - xh[0] * m2), dyv.y + rstd * (dxh[1] - m1 - xh[1] * m2),
+                            dyv.z + rstd * (dxh[2] - m1 - xh[2] * m2), dyv.w + rstd * (dxh[3] - m1 - xh[3] * m2));
+        }
+        // (the next tile's loader writes D2 / XN, which this tile's GEMM phase finished reading before the barrier above; `red` is
+        // rewritten only behind the next tile's first barrier)
+    }
+
+    // ---- this workgroup's partial sums -> its slab row [dW2 64x64 | db2 64 | dW1 64x16 | db1 64 | d gamma 16 | d beta 16]
+    float* row = a.slab + (size_t)blockIdx.x * FFN1_BWD_X_ROW;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) row[(16 * nb + 4 * g + v) * N1 + 16 * wave + r] = acc2[nb][v];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) row[FFN1_BWD_X_W1 + (16 * wave + 4 * g + v) * E + r] = acc1[v];
+    {
+        float s = bs1;
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (g == 0) row[FFN1_BWD_X_B1 + 16 * wave + r] = s;
+    }
+    __syncthreads();                     // every wave is done with the tile loop's LDS
+    float* sc = reinterpret_cast<float*>(smem_raw);   // [16][64] db2 partials | [64][16] d gamma | [64][16] d beta
+    *reinterpret_cast<float4*>(sc + dpx * N1 + 4 * dq) = bs2;
+    *reinterpret_cast<float4*>(sc + 16 * N1 + lpx * E + 4 * lq) = pg;
+    *reinterpret_cast<float4*>(sc + 16 * N1 + NPX * E + lpx * E + 4 * lq) = pb;
+    __syncthreads();
+    if (threadIdx.x < N1) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += sc[k * N1 + threadIdx.x];
+        row[FFN1_BWD_X_B2 + threadIdx.x] = s;
+    } else if (threadIdx.x < N1 + 2 * E) {
+        const int i = threadIdx.x - N1, which = i / E, c = i % E;
+        const float* src = sc + 16 * N1 + which * NPX * E + c;
+        float s = 0.f;
+        for (int k = 0; k < NPX; ++k) s += src[k * E];
+        row[(which ? FFN1_BWD_X_LB : FFN1_BWD_X_LG) + c] = s;
+    }
+}
+
+}   // namespace
+
+int launch_ffn1_bwd_xs(const Ffn1BwdXArgs& a, hipStream_t s) {
+    ProfScope prof__(LG_K_FFN1_BWD, s);
+    if (a.P <= 0 || a.P % NPX) { lg_set_error("ffn1_bwd_xs: pixel count %ld is not a multiple of %d", a.P, NPX); return -2; }
+    if (!a.dh2 || !a.x || !a.dy || !a.dx || !a.slab || !a.w1 || !a.w1t || !a.w2t || !a.b1 || !a.ln2g || !a.ln2b) { lg_set_error("ffn1_bwd_xs: null argument"); return -2; }
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn1_bwd_xs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) { lg_set_error("ffn1_bwd_xs: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_once.done();
+    }
+    const long ntiles = a.P / NPX;
+    const int grid = (int)(ntiles < FFN1_BWD_WGS ? ntiles : FFN1_BWD_WGS);
+    k_ffn1_bwd_xs<<<grid, 256, LDS_BYTES, s>>>(a, ntiles);
+    LG_CHECK_LAUNCH();
+    // the slab rows, summed in a fixed order by the deferred reduce launch
+    ReduceJob j;
+    j.dst2 = nullptr; j.nslices = grid; j.slice_stride = FFN1_BWD_X_ROW;
+    auto job = [&](int off, float* dst, int rows, int cols) {
+        j.slab = a.slab + off; j.dst = dst; j.rows = rows; j.cols = cols; j.row_stride = cols; j.ld = cols; j.rows_valid = rows; j.cols_valid = cols;
+        return launch_reduce_job(j, s);
+    };
+    int rc = job(0, a.d_w2, N1, N1);
+    if (!rc) rc = job(FFN1_BWD_X_B2, a.d_b2, 1, N1);
+    if (!rc) rc = job(FFN1_BWD_X_W1, a.d_w1, N1, E);
+    if (!rc) rc = job(FFN1_BWD_X_B1, a.d_b1, 1, N1);
+    if (!rc) rc = job(FFN1_BWD_X_LG, a.d_ln2g, 1, E);
+    if (!rc) rc = job(FFN1_BWD_X_LB, a.d_ln2b, 1, E);
+    return rc;
+}

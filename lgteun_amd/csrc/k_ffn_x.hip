@@ -60,7 +60,7 @@ __device__ __forceinline__ s16x4_t lds_x4(const uint16_t* p) { return __builtin_
 
 // SAVE: 0 nothing; 1 gelu(h1), gelu'(h1), h2, gelu(h3), gelu'(h3) (GELU-free backward: the precision = 'bf16' layout);
 // 2 the PRE-ACTIVATIONS h1, h2, h3 only (three tensors instead of five: the backward kernels re-evaluate gelu / gelu' from
-// them, bwd_kernels.h `pre`)
+// them, bwd_kernels.h `pre`); 3 h2 and h3 only (the backward re-computes h1 from x: k_ffn1_bwd_xs)
 template <int SAVE, int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn_xs(Ffn1Args a1, Ffn2Args a2, int tiles_x, int strips_y, int nstrips,
                                                                                        int SH) {
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                         HS<BF>::st4(a2.g3s, o, make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
                 } else {
-                    if (SAVE == 2) {
+                    if (SAVE >= 2) {
                         const int y = y0 + ty, x = x0 + tx;
                         if (y < Yend && x < w) HS<BF>::st4(a2.a3s, ((b * h + y) * (long)w + x) * N1 + 4 * q, acc);
                     }
@@ -390,6 +390,7 @@ int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ffn_xs<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn_xs: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -402,13 +403,16 @@ int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     const int strips_y = (a2.h + SH - 1) / SH;
     const int nstrips = a2.B * tiles_x * strips_y;
     const int grid = nstrips < 512 ? nstrips : 512;
-    const bool save = a1.a1s != nullptr;
+    const bool save = a1.h2 != nullptr;           // h2 leaves the chip only for the backward
     const bool pre = save && a1.g1s == nullptr;   // pre-activation saves (h1 in a1s, h3 in a3s)
-    if (pre && (a1.hbf || !a2.a3s || a2.g3s || !a1.h2)) { lg_set_error("ffn_xs: pre-activation saves need fp32 storage and h1 / h2 / h3 slots"); return -2; }
+    const bool noh1 = pre && a1.a1s == nullptr;   // ... without h1 (the backward re-computes it)
+    if (save && !pre && !a1.a1s) { lg_set_error("ffn_xs: the five-tensor save needs the gelu(h1) slot"); return -2; }
+    if (pre && (a1.hbf || !a2.a3s || a2.g3s)) { lg_set_error("ffn_xs: pre-activation saves need fp32 storage and h2 / h3 slots"); return -2; }
     if (a1.hbf) {   // precision = 'bf16': plain bf16 operands, bf16 storage of the saved tensors
         if (save) k_ffn_xs<1, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
         else k_ffn_xs<0, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
-    } else if (pre) k_ffn_xs<2, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    } else if (noh1) k_ffn_xs<3, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    else if (pre) k_ffn_xs<2, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
     else if (save) k_ffn_xs<1, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
     else k_ffn_xs<0, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
     LG_CHECK_LAUNCH();

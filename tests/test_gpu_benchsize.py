@@ -102,16 +102,16 @@ def test_split_backward_is_bitwise_the_whole_backward(C, h, K, B):
     assert float(whole[a0:b0].abs().max()) > 0
 
 
-def test_both_ffn_save_modes_give_the_same_step(monkeypatch):
-    """The live stage's e = 16 FFN half-blocks either save gelu / gelu' (five 4e-wide tensors per block, the backward evaluates no GELU)
-    or the three pre-activations h1 / h2 / h3 (LG_FFN_SAVE, read at plan creation; 40 % less saved-activation traffic, the backward
-    re-evaluates GELU with the forward's own function).  Same forward bit for bit; gradients equal to rounding (dW2 / dW3 see gelu(h)
-    through the scalar evaluation of k_wgrad_t instead of the forward's packed one)."""
+def test_all_ffn_save_modes_give_the_same_step(monkeypatch):
+    """The live stage's e = 16 FFN half-blocks keep, for the backward (LG_FFN_SAVE, read at plan creation): '5' gelu / gelu' of both hidden
+    tensors + h2 (five 4e-wide tensors per block, the backward evaluates no GELU); '3' the pre-activations h1 / h2 / h3 (the backward
+    re-evaluates GELU with the forward's own function); '2' (default) h2 / h3 only -- h1 is re-computed from x by k_ffn1_bwd_xs, which
+    also forms dx, dW1 and dW2 on the bf16 matrix pipe in split arithmetic.  Same forward bit for bit; gradients equal to rounding."""
     from gpu_helpers import make_module
     from lgteun_amd._lib import LG_FLAG_FAITHFUL, LG_FLAG_SAVE
     ms, pan, gt = (T(a).cuda() for a in dw.make_inputs(3, 4, 32, 32, seed=5, kind='dn'))
     res = {}
-    for mode in ('5', '3'):
+    for mode in ('5', '3', '2'):
         monkeypatch.setenv('LG_FFN_SAVE', mode)
         net = make_module(4, 2)
         eng = net.engine()
@@ -122,13 +122,15 @@ def test_both_ffn_save_modes_give_the_same_step(monkeypatch):
         eng.backward_raw(saved, dout, g, LG_FLAG_FAITHFUL | LG_FLAG_SAVE, 0)
         res[mode] = (out.clone(), g.clone(), eng, ws_sum)
     assert res['5'][3] != res['3'][3]          # the switch was honoured: the workspaces hold different things
-    assert torch.equal(res['5'][0], res['3'][0])
-    g5, g3, eng = res['5'][1], res['3'][1], res['5'][2]
+    assert torch.equal(res['5'][0], res['3'][0]) and torch.equal(res['5'][0], res['2'][0])
+    g5, eng = res['5'][1], res['5'][2]
     assert not torch.equal(g5, torch.zeros_like(g5))
-    for i in eng.live_idx:
-        o, n = eng.offsets[i], eng.params[i].numel()
-        a, b = g5[o:o + n].double(), g3[o:o + n].double()
-        assert float((a - b).norm()) <= 2e-6 * float(a.norm()) + 1e-12, eng.names[i]
+    for mode in ('3', '2'):
+        gm = res[mode][1]
+        for i in eng.live_idx:
+            o, n = eng.offsets[i], eng.params[i].numel()
+            a, b = g5[o:o + n].double(), gm[o:o + n].double()
+            assert float((a - b).norm()) <= 2e-6 * float(a.norm()) + 1e-12, (mode, eng.names[i], float((a - b).norm()), float(a.norm()))
 
 
 def test_two_autograd_graphs_keep_their_own_activations():
