@@ -218,6 +218,25 @@ struct Ffn1BwdXArgs {
 #define FFN1_BWD_X_LB 5264
 #define FFN1_BWD_X_ROW 5280
 int launch_ffn1_bwd_xs(const Ffn1BwdXArgs& a, hipStream_t s);
+// e = 16, fp32 storage (k_ffn_dwbwd_x.hip): the strip-walking spatial half -- dh3 in an LDS ring, dh2 out, depthwise gradients AND
+// dW3 / db3 in the same pass; replaces k_ffn_dw_bwd<16> + the 16 x 64 k_wgrad_t launch
+struct FfnDwBwdXArgs {
+    const float* dy;   // [B,h,w,16]
+    const float* h3;   // [B,h,w,64] saved pre-activation of the second GELU
+    const float* h2;   // [B,h,w,64] saved
+    float* dh2;        // [B,h,w,64] out
+    const float* w3t;  // [64][16] transposed W3
+    const float* dww;  // [64,1,3,3]
+    float* slab;       // FFN_DW_BWD_X_WGS rows of FFN_DW_BWD_X_ROW floats (per-workgroup partial sums)
+    float *d_dww, *d_dwb, *d_w3, *d_b3;   // accumulated (+=) by the deferred reduce launch
+    int B, h, w;
+};
+#define FFN_DW_BWD_X_WGS 512
+#define FFN_DW_BWD_X_DB 576
+#define FFN_DW_BWD_X_W3 640
+#define FFN_DW_BWD_X_B3 1664
+#define FFN_DW_BWD_X_ROW 1680
+int launch_ffn_dw_bwd_xs(const FfnDwBwdXArgs& a, hipStream_t s);
 int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[cols][rows]
 int launch_transpose3(const float* const* src, float* const* dst, const int* rows, const int* cols, int njobs, hipStream_t s);
 

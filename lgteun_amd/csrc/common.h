@@ -37,6 +37,8 @@ struct lg_plan {
     // also forms dW1 / dW2 on the bf16 matrix pipe; 3: h1, h2, h3 (round 2's default: k_ffn1_bwd<16> + k_wgrad_t re-evaluate gelu / gelu');
     // 5: gelu(h1), gelu'(h1), h2, gelu(h3), gelu'(h3) (GELU-free backward; the only form of the other widths and of precision = 'bf16').
     // In modes 2 / 3 the tensors sit in the a1 / h2 / a3 slots (workspace.h) and the g1 / g3 slots stay unused.
+    int dwbwd_tile; // A/B switch read ONCE at plan creation (env LG_FFN_DWBWD=tile): round 2's tile kernel k_ffn_dw_bwd<16> + k_wgrad_t for dW3
+                    // instead of the strip-walking k_ffn_dw_bwd_xs
     bool ffn_e16_split() const { return cfg.precision == 0 && ffn_tile == 0; }
     bool ffn_saves_preact(int e) const { return e == 16 && ffn_e16_split() && save_mode != 5; }
     bool ffn_bwd_x(int e) const { return e == 16 && ffn_e16_split() && save_mode == 2; }   // h1 not saved; backward through k_ffn1_bwd_xs

@@ -98,6 +98,27 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
     const int hbf = pl->cfg.precision == 1 ? 1 : 0;   // bf16 storage of the hidden / saved FFN tensors
     const int pre = pl->ffn_saves_preact(e) ? 1 : 0;  // fb.a1 / fb.a3 hold h1 / h3 (fb.g1 / fb.g3 unused): GELU re-evaluated where needed
     const long Pn = (long)B * fb.h * fb.w;
+    if (pl->ffn_bwd_x(e) && !pl->dwbwd_tile) {
+        // two launches per half-block: the strip-walking spatial half (dh3 in LDS -> dh2, depthwise gradients, dW3 / db3) and the pixelwise
+        // half (h1 re-computed, dx, LayerNorm gradients, dW1 / db1, dW2 / db2); dh2 is the only tensor between them
+        FfnDwBwdXArgs fk;
+        fk.dy = dy; fk.h3 = fb.a3; fk.h2 = fb.h2; fk.dh2 = bb.dh2; fk.w3t = bb.w3t[j]; fk.dww = P + pl->blk(st, j, B_DWW);
+        fk.slab = bb.rq.take((size_t)FFN_DW_BWD_X_WGS * FFN_DW_BWD_X_ROW);
+        if (!fk.slab) return -3;
+        fk.d_dww = G + pl->blk(st, j, B_DWW); fk.d_dwb = G + pl->blk(st, j, B_DWB); fk.d_w3 = G + pl->blk(st, j, B_W3); fk.d_b3 = G + pl->blk(st, j, B_B3);
+        fk.B = B; fk.h = fb.h; fk.w = fb.w;
+        RC(launch_ffn_dw_bwd_xs(fk, s));
+        Ffn1BwdXArgs fx;
+        fx.dh2 = bb.dh2; fx.x = fb.xmid; fx.dy = dy; fx.dx = tmp;
+        fx.w1 = P + pl->blk(st, j, B_W1); fx.b1 = P + pl->blk(st, j, B_B1); fx.w2t = bb.w2t[j]; fx.w1t = bb.w1t[j];
+        fx.ln2g = P + pl->blk(st, j, B_LN2G); fx.ln2b = P + pl->blk(st, j, B_LN2B);
+        fx.slab = bb.rq.take((size_t)FFN1_BWD_WGS * FFN1_BWD_X_ROW);
+        if (!fx.slab) return -3;
+        fx.d_w1 = G + pl->blk(st, j, B_W1); fx.d_b1 = G + pl->blk(st, j, B_B1); fx.d_w2 = G + pl->blk(st, j, B_W2); fx.d_b2 = G + pl->blk(st, j, B_B2);
+        fx.d_ln2g = G + pl->blk(st, j, B_LN2G); fx.d_ln2b = G + pl->blk(st, j, B_LN2B);
+        fx.P = Pn;
+        return launch_ffn1_bwd_xs(fx, s);
+    }
     FfnDwBwdArgs fd;
     fd.dy = dy; fd.g3 = pre ? fb.a3 : fb.g3; fd.h2 = fb.h2; fd.dh2 = bb.dh2; fd.w3t = bb.w3t[j]; fd.dww = P + pl->blk(st, j, B_DWW);
     fd.slab_w = bb.rq.take(ffn_dw_bwd_slab_floats(e, B, fb.h, fb.w));

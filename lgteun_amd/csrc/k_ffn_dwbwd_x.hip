@@ -1,0 +1,318 @@
+// k_ffn_dw_bwd_xs: the spatial half of the feed_forward backward at e = 16 (reference models/common/LGT.py:91-109: net.4, the second
+// GELU and the depthwise 3x3 of net.2), as a STRIP WALK like the forward's k_ffn_xs:
+//
+//     dh3 = (W3^T dy) * gelu'(h3)          on the halo pixels, kept in a 10-row fp32 LDS ring (never stored)
+//     dh2 = dw3x3^T dh3                    -> HBM, the one tensor k_ffn1_bwd_xs reads
+//     d dww[c][k] += h2(q) dh3(q - off_k),  d dwb[c] += dh3,  dW3 += dy (x) gelu(h3),  db3 += dy        (pixel sums)
+//
+// A workgroup walks DOWN a 16-column strip in 8-row steps; a step computes dh3 only on its 8 NEW halo rows (8 x 18 = 144 pixels,
+// three chunks of 48), so dy and h3 are read 1.125 x instead of the 1.40 x of the tile kernel it replaces (k_ffn_dw_bwd<16>), h2 is
+// read exactly once (the tap products use the centre pixel's h2 against the NEIGHBOURS' dh3: d dww[c][k] = sum_q h2(q) dh3(q - off_k),
+// the same neighbour value that dh2 needs), and the weight gradient of net.4 comes out of the same pass on the bf16 matrix pipe in
+// split arithmetic (split_bf16.h) -- k_wgrad_t<1,4> and its second read of dy / h3 are gone.
+// GEMM (W3^T dy): weights on the A side, pixels on the B side, wave w = hidden channels [16 w, 16 w + 16): a lane holds four
+// consecutive channels of one pixel, so h3 arrives and dh3 leaves as 16-byte accesses.  dW3: the pixel axis is the K dimension; dy^T
+// is read by columns from the chunk's dy image (ds_read_b64_tr_b16), gelu(h3) goes through a 1.5 KB per-wave [pixel][channel] image.
+// LDS 65 KB (two workgroups per CU): ring [10][18][68] fp32 | dy pieces [2][3][48][16] bf16 | per-wave gelu(h3) pieces [4][3][16][16].
+#include "kernels.h"
+#include "bwd_kernels.h"
+#include "split_bf16.h"
+
+namespace {
+
+constexpr int E = 16, N1 = 64, TX = 16, HX = 18, TY = 8, RING = 10, LDR = 68, CH = 48, CQ = 16;
+constexpr int DY_PIECE = CH * E;             // halves
+constexpr int DY_SLOT = 3 * DY_PIECE;
+constexpr int A3_PIECE = 16 * 16;            // halves, per wave and piece
+constexpr size_t OFF_DY = (size_t)RING * HX * LDR * 4;
+constexpr size_t OFF_A3 = OFF_DY + (size_t)2 * DY_SLOT * 2;
+constexpr size_t LDS_BYTES = OFF_A3 + (size_t)4 * 3 * A3_PIECE * 2;
+static_assert(OFF_DY % 16 == 0 && OFF_A3 % 16 == 0, "16-byte aligned LDS regions");
+static_assert((size_t)(4 * CQ * 40 + 4 * E) * 4 <= OFF_DY, "the end-of-kernel reduction rows alias the ring");
+
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+__device__ __forceinline__ s16x4_t lds_x4(const uint16_t* p) { return __builtin_bit_cast(s16x4_t, *reinterpret_cast<const u32x2_t*>(p)); }
+__device__ __forceinline__ s16x4_t lds_tr4(const uint16_t* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p); }
+__device__ __forceinline__ void mfma6_16(f32x4_t& acc, const s16x4_t (&a)[3], const s16x4_t (&b)[3]) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[0], acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn_dw_bwd_xs(FfnDwBwdXArgs a, int tiles_x, int strips_y, int nstrips, int SH) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* ring = reinterpret_cast<float*>(smem_raw);                          // [RING*HX][LDR] dh3
+    uint16_t* DY = reinterpret_cast<uint16_t*>(smem_raw + OFF_DY);             // [2][3][CH][E]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    uint16_t* A3 = reinterpret_cast<uint16_t*>(smem_raw + OFF_A3) + wave * 3 * A3_PIECE;   // [3][16 px][16 ch] of this wave
+    const int h = a.h, w = a.w;
+    const int c0 = wave * 16 + 4 * g;                 // first of the lane's four hidden channels after the GEMM
+    const WFrag16 w3f = load_wfrag16(a.w3t + (size_t)(wave * 16) * E, E, 0);   // W3^T rows [16 w, 16 w + 16)
+    const int q = lane % CQ;                          // P2: lane = (pixel slot lane / 16, channel quad q)
+    const int lpx = threadIdx.x >> 2, lq = threadIdx.x & 3;                    // dy role: thread t < 192 = (chunk pixel t / 4, channel quad t % 4)
+    const bool dy_thread = threadIdx.x < 4 * CH;
+
+    // gradient partials of the depthwise taps / bias of the lane's four P2 channels, as channel PAIRS (v_pk_fma_f32)
+    lg_v2f pw01[10], pw23[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { pw01[k] = (lg_v2f){0.f, 0.f}; pw23[k] = (lg_v2f){0.f, 0.f}; }
+    f32x4_t acc3 = (f32x4_t){0.f, 0.f, 0.f, 0.f};     // dW3[4 g + v][16 w + r]
+    float4 sb3 = make_float4(0.f, 0.f, 0.f, 0.f);     // db3[4 lq ..], this thread's own pixels
+
+#pragma unroll 1
+    for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+    int t = strip;
+    const int tx_i = t % tiles_x;
+    t /= tiles_x;
+    const int sy = t % strips_y;
+    const long b = t / strips_y;
+    const int x0 = tx_i * TX, Y0 = sy * SH, Yend = min(Y0 + SH, h);
+
+    // dy vector of halo pixel m of the row block starting at ya (zeros outside the image / beyond npx); own: the pixel belongs to THIS strip
+    auto dy_fetch = [&](int ya, int npx, int c, float4& dv, bool& own) {
+        const int m = c * CH + lpx;
+        const int hy = m / HX, hx = m - hy * HX;
+        const int y = ya + hy, x = x0 + hx - 1;
+        const bool in = dy_thread && (m < npx) && y >= 0 && y < h && x >= 0 && x < w;
+        own = in && hx >= 1 && hx <= TX && y >= Y0 && y < Yend;
+        dv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) dv = *reinterpret_cast<const float4*>(a.dy + ((b * h + y) * (long)w + x) * E + 4 * lq);
+    };
+    auto dy_store = [&](int slot, const float4& dv, bool own) {
+        if (!dy_thread) return;
+        if (own) { sb3.x += dv.x; sb3.y += dv.y; sb3.z += dv.z; sb3.w += dv.w; }
+        const float v[4] = {dv.x, dv.y, dv.z, dv.w};
+        u32x2_t q1, q2, q3;
+        split3_x4(v, q1, q2, q3);
+        uint16_t* dst = DY + slot * DY_SLOT + lpx * E + 4 * lq;
+        *reinterpret_cast<u32x2_t*>(dst) = q1;
+        *reinterpret_cast<u32x2_t*>(dst + DY_PIECE) = q2;
+        *reinterpret_cast<u32x2_t*>(dst + 2 * DY_PIECE) = q3;
+    };
+    // h3 of the lane's pixel / channels in chunk c (zeros outside the image / beyond npx)
+    auto h3_fetch = [&](int ya, int npx, int c, float4 (&hv)[3]) {
+#pragma unroll
+        for (int pb = 0; pb < 3; ++pb) {
+            const int m = c * CH + pb * 16 + r;
+            const int hy = m / HX, hx = m - hy * HX;
+            const int y = ya + hy, x = x0 + hx - 1;
+            hv[pb] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < npx && y >= 0 && y < h && x >= 0 && x < w) hv[pb] = *reinterpret_cast<const float4*>(a.h3 + ((b * h + y) * (long)w + x) * N1 + c0);
+        }
+    };
+
+    // dh3 of halo rows [ya, ya + nr) x columns [x0 - 1, x0 + 17) -> ring (nr = 2: strip prologue, 8: one step)
+    // in_last: run at the top of the LAST chunk, where no next-chunk operands are in flight (registers and load slots are free)
+    auto compute_rows = [&](int ya, int nr, float4 pre, bool pre_own, auto&& in_last) {
+        const int npx = nr * HX, nchunks = (npx + CH - 1) / CH;
+        float4 h3c[3], h3n[3];
+        h3_fetch(ya, npx, 0, h3c);
+        dy_store(0, pre, pre_own);
+        __syncthreads();                 // also: the previous phase (P2) is done reading the ring rows this call overwrites
+        const int ring0 = ((ya - Y0 + 1) % RING) * HX;
+        for (int c = 0; c < nchunks; ++c) {
+            const int slot = c & 1;
+            const bool more = c + 1 < nchunks;
+            float4 ndv;
+            bool nown = false;
+            if (more) { dy_fetch(ya, npx, c + 1, ndv, nown); h3_fetch(ya, npx, c + 1, h3n); }
+            else in_last();
+            const uint16_t* dyb = DY + slot * DY_SLOT;
+#pragma unroll
+            for (int pb = 0; pb < 3; ++pb) {
+                const int m = c * CH + pb * 16 + r;
+                const int hy = m / HX, hx = m - hy * HX;
+                const int y = ya + hy, x = x0 + hx - 1;
+                const bool own = m < npx && hx >= 1 && hx <= TX && x < w && y >= Y0 && y < Yend;
+                // (W3^T dy)[16 w + 4 g + v][pixel r]
+                f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                {
+                    const uint16_t* p = dyb + (pb * 16 + r) * E + 4 * g;
+                    const s16x4_t xb[3] = {lds_x4(p), lds_x4(p + DY_PIECE), lds_x4(p + 2 * DY_PIECE)};
+                    mfma6_16(acc, w3f.p, xb);
+                }
+                lg_v2f a01, a23, g01, g23;
+                gelu2_both_f((lg_v2f){h3c[pb].x, h3c[pb].y}, a01, g01);
+                gelu2_both_f((lg_v2f){h3c[pb].z, h3c[pb].w}, a23, g23);
+                // dh3 (0 outside the image: dy is 0 there) -> ring
+                int rp = ring0 + m;
+                rp = rp >= RING * HX ? rp - RING * HX : rp;
+                if (m < npx) *reinterpret_cast<float4*>(ring + rp * LDR + c0) = make_float4(acc[0] * g01.x, acc[1] * g01.y, acc[2] * g23.x, acc[3] * g23.y);
+                // gelu(h3) of the strip's OWN pixels (every pixel of the image belongs to exactly one strip) -> the wave's [pixel][channel] image
+                const float mk = own ? 1.0f : 0.0f;
+                const float av[4] = {a01.x * mk, a01.y * mk, a23.x * mk, a23.y * mk};
+                u32x2_t q1, q2, q3;
+                split3_x4(av, q1, q2, q3);
+                uint16_t* dst = A3 + r * 16 + 4 * g;
+                *reinterpret_cast<u32x2_t*>(dst) = q1;
+                *reinterpret_cast<u32x2_t*>(dst + A3_PIECE) = q2;
+                *reinterpret_cast<u32x2_t*>(dst + 2 * A3_PIECE) = q3;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // dW3[.][16 w + .] += dy^T gelu(h3): both operands read by columns (K = the 16 pixels of the block)
+                {
+                    const uint16_t* pa = dyb + (pb * 16 + 4 * g + (r >> 2)) * E + 4 * (r & 3);
+                    const s16x4_t dt[3] = {lds_tr4(pa), lds_tr4(pa + DY_PIECE), lds_tr4(pa + 2 * DY_PIECE)};
+                    const uint16_t* pbp = A3 + (4 * g + (r >> 2)) * 16 + 4 * (r & 3);
+                    const s16x4_t at[3] = {lds_tr4(pbp), lds_tr4(pbp + A3_PIECE), lds_tr4(pbp + 2 * A3_PIECE)};
+                    mfma6_16(acc3, dt, at);
+                }
+                __builtin_amdgcn_wave_barrier();      // the wave's image is rewritten by the next pixel block
+            }
+            if (more) {
+                dy_store(slot ^ 1, ndv, nown);
+#pragma unroll
+                for (int pb = 0; pb < 3; ++pb) h3c[pb] = h3n[pb];
+            }
+            __syncthreads();   // dy slot c + 1 complete; the readers of slot c are done before chunk c + 2 rewrites it; after the last chunk: ring rows complete
+        }
+    };
+
+    {
+        float4 pre;
+        bool pown;
+        dy_fetch(Y0 - 1, 2 * HX, 0, pre, pown);
+        compute_rows(Y0 - 1, 2, pre, pown, [] {});
+    }
+#pragma unroll 1
+    for (int y0 = Y0; y0 < Yend; y0 += TY) {
+        // h2 of the step's output pixels (wave w: tile rows 2 w, 2 w + 1; lane: pixel x0 + lane / 16 + 4 it, channels 4 q ..), item
+        // i = 4 ch + it: the first one is requested during the last chunk of the halo pass, item i + 1 while item i is worked on
+        auto h2_fetch = [&](int i) {
+            const int y = y0 + 2 * wave + (i >> 2), x = x0 + (lane >> 4) + 4 * (i & 3);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y < Yend && x < w) v = *reinterpret_cast<const float4*>(a.h2 + ((b * h + y) * (long)w + x) * N1 + 4 * q);
+            return v;
+        };
+        float4 h2n;
+        {
+            float4 pre;
+            bool pown;
+            dy_fetch(y0 + 1, TY * HX, 0, pre, pown);
+            compute_rows(y0 + 1, TY, pre, pown, [&] { h2n = h2_fetch(0); });
+        }
+        // the depthwise taps of the lane's four channels as channel pairs: 36 contiguous floats, re-read (L1 / L2 hits) per step instead of
+        // pinning 36 VGPRs through the halo pass
+        lg_v2f wq01[9], wq23[9];
+        {
+            const float* tp = a.dww + 36 * q;
+            asm volatile("" : "+v"(tp));            // keep the loads inside the step loop
+            float t36[36];
+#pragma unroll
+            for (int k4 = 0; k4 < 9; ++k4) {
+                const float4 v = *reinterpret_cast<const float4*>(tp + 4 * k4);
+                t36[4 * k4] = v.x; t36[4 * k4 + 1] = v.y; t36[4 * k4 + 2] = v.z; t36[4 * k4 + 3] = v.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { wq01[k] = (lg_v2f){t36[k], t36[9 + k]}; wq23[k] = (lg_v2f){t36[18 + k], t36[27 + k]}; }
+        }
+        // ---- P2: dh2 = dw^T dh3 and the depthwise weight / bias gradient partials
+        const int sbase = (y0 - Y0) % RING;            // ring slot of row y0 - 1
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {
+            const int ty = 2 * wave + (i >> 2), tx = (lane >> 4) + 4 * (i & 3);
+            const int y = y0 + ty, x = x0 + tx;
+            const bool ok = y < Yend && x < w;
+            const float4 hc = h2n;
+            if (i < 7) h2n = h2_fetch(i + 1);
+            const lg_v2f h01 = (lg_v2f){hc.x, hc.y}, h23 = (lg_v2f){hc.z, hc.w};   // 0 where !ok
+            lg_v2f acc01 = (lg_v2f){0.f, 0.f}, acc23 = (lg_v2f){0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                // forward: h3(p) += w[dy][dx] h2(p + (dy-1, dx-1))  ->  h2(q) meets dh3(q - (dy-1, dx-1)) in both sums
+                int sl = sbase + ty + 2 - dy;
+                sl = sl >= RING ? sl - RING : sl;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float4 gv = *reinterpret_cast<const float4*>(ring + (sl * HX + tx + 2 - dx) * LDR + 4 * q);
+                    const lg_v2f g01 = (lg_v2f){gv.x, gv.y}, g23 = (lg_v2f){gv.z, gv.w};
+                    acc01 = wq01[dy * 3 + dx] * g01 + acc01;
+                    acc23 = wq23[dy * 3 + dx] * g23 + acc23;
+                    pw01[dy * 3 + dx] = h01 * g01 + pw01[dy * 3 + dx];
+                    pw23[dy * 3 + dx] = h23 * g23 + pw23[dy * 3 + dx];
+                    if (dy == 1 && dx == 1) {
+                        const float mk = ok ? 1.0f : 0.0f;
+                        pw01[9] = g01 * mk + pw01[9];
+                        pw23[9] = g23 * mk + pw23[9];
+                    }
+                }
+            }
+            if (ok) *reinterpret_cast<float4*>(a.dh2 + ((b * h + y) * (long)w + x) * N1 + 4 * q) = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
+        }
+    }   // steps of the strip
+    __syncthreads();   // the last step's P2 readers of the ring are done before the next strip's prologue writes it
+    }   // strips of this workgroup
+
+    // ---- this workgroup's partial sums -> its slab row [d dww 64x9 | d dwb 64 | dW3 16x64 | db3 16]
+    float* row = a.slab + (size_t)blockIdx.x * FFN_DW_BWD_X_ROW;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) row[FFN_DW_BWD_X_W3 + (4 * g + v) * N1 + 16 * wave + r] = acc3[v];
+    float* red = ring;    // [4 waves][16 quads][40] | [4 waves][16]: the ring is dead (barrier at the end of the last strip)
+    // depthwise partials: lanes with the same q (four per wave) hold the same channels
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            float v = u == 0 ? pw01[k].x : (u == 1 ? pw01[k].y : (u == 2 ? pw23[k].x : pw23[k].y));
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < CQ) red[(wave * CQ + q) * 40 + u * 10 + k] = v;
+        }
+    // db3: dy threads with the same lq hold the same channels (48 per quad, in waves 0 .. 2)
+    {
+        float4 s = sb3;
+#pragma unroll
+        for (int off = 4; off < 64; off <<= 1) {
+            s.x += __shfl_xor(s.x, off); s.y += __shfl_xor(s.y, off); s.z += __shfl_xor(s.z, off); s.w += __shfl_xor(s.w, off);
+        }
+        if (lane < 4) *reinterpret_cast<float4*>(red + 4 * CQ * 40 + wave * E + 4 * lane) = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CQ * 40; i += 256) {
+        const float v = (red[i] + red[CQ * 40 + i]) + (red[2 * CQ * 40 + i] + red[3 * CQ * 40 + i]);
+        const int qq = i / 40, rem = i - qq * 40, u = rem / 10, k = rem - u * 10;
+        const int c = 4 * qq + u;
+        if (k < 9) row[c * 9 + k] = v;
+        else row[FFN_DW_BWD_X_DB + c] = v;
+    }
+    if (threadIdx.x < E) {
+        const float* s = red + 4 * CQ * 40 + threadIdx.x;
+        row[FFN_DW_BWD_X_B3 + threadIdx.x] = (s[0] + s[E]) + (s[2 * E] + s[3 * E]);
+    }
+}
+
+}   // namespace
+
+int launch_ffn_dw_bwd_xs(const FfnDwBwdXArgs& a, hipStream_t s) {
+    ProfScope prof__(LG_K_FFN2_BWD, s);
+    if (!a.dy || !a.h3 || !a.h2 || !a.dh2 || !a.w3t || !a.dww || !a.slab) { lg_set_error("ffn_dw_bwd_xs: null argument"); return -2; }
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd_xs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) { lg_set_error("ffn_dw_bwd_xs: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_once.done();
+    }
+    const int tiles_x = (a.w + 15) / 16;
+    // strip height as in the forward: the tallest multiple of 8 rows that still yields >= 512 strips (two resident workgroups per CU), at least 16
+    int SH = (a.h + 7) / 8 * 8;
+    while (SH > 16 && (long)a.B * tiles_x * ((a.h + SH - 1) / SH) < 512) SH = (SH / 2 + 7) / 8 * 8;
+    const int strips_y = (a.h + SH - 1) / SH;
+    const int nstrips = a.B * tiles_x * strips_y;
+    const int grid = nstrips < FFN_DW_BWD_X_WGS ? nstrips : FFN_DW_BWD_X_WGS;
+    k_ffn_dw_bwd_xs<<<grid, 256, LDS_BYTES, s>>>(a, tiles_x, strips_y, nstrips, SH);
+    LG_CHECK_LAUNCH();
+    ReduceJob j;
+    j.dst2 = nullptr; j.nslices = grid; j.slice_stride = FFN_DW_BWD_X_ROW;
+    auto job = [&](int off, float* dst, int rows, int cols) {
+        j.slab = a.slab + off; j.dst = dst; j.rows = rows; j.cols = cols; j.row_stride = cols; j.ld = cols; j.rows_valid = rows; j.cols_valid = cols;
+        return launch_reduce_job(j, s);
+    };
+    int rc = job(0, a.d_dww, N1, 9);
+    if (!rc) rc = job(FFN_DW_BWD_X_DB, a.d_dwb, 1, N1);
+    if (!rc) rc = job(FFN_DW_BWD_X_W3, a.d_w3, E, N1);
+    if (!rc) rc = job(FFN_DW_BWD_X_B3, a.d_b3, 1, E);
+    return rc;
+}

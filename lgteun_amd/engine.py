@@ -416,6 +416,9 @@ class FusedAdam(torch.optim.Optimizer):
     def step_flat(self, engine):
         if self._state is None or self._state['exp_avg'].numel() != engine.total:
             self._state = dict(exp_avg=torch.zeros_like(engine.flat), exp_avg_sq=torch.zeros_like(engine.flat))
+        elif self._state['exp_avg'].device != engine.flat.device or not self._state['exp_avg'].is_contiguous():
+            # moments restored from a checkpoint (loaded to the host): the kernel takes device pointers
+            self._state = {k: v.to(engine.flat.device).contiguous() for k, v in self._state.items()}
         self._step += 1
         g = self.param_groups[0]
         engine.adam(self._state, self._step, g['lr'], g['betas'], g['eps'])

@@ -269,7 +269,11 @@ def test_runner_train_eval_save_load_roundtrip(tmp_path):
     runner2.set_optim()
     o1, o2 = runner.optim_dict['core_module'], runner2.optim_dict['core_module']
     assert o2._step == o1._step == 6
-    assert torch.equal(o2._state['exp_avg'], o1._state['exp_avg']) and torch.equal(o2._state['exp_avg_sq'], o1._state['exp_avg_sq'])
+    assert torch.equal(o2._state['exp_avg'].cpu(), o1._state['exp_avg'].cpu()) and torch.equal(o2._state['exp_avg_sq'].cpu(), o1._state['exp_avg_sq'].cpu())
+    # ... and the restored moments (loaded to the host) move to the device with the first fused step
+    runner2.set_sched()
+    runner2.train_iter(iter_id=7, input_batch=lgteun_amd.base_model.data_normalize({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in loader[0].items()}, 11))
+    assert o2._step == 7 and o2._state['exp_avg'].is_cuda
     # the full-resolution pass runs the model and writes the fused images when asked (its no-reference indices are out of scope)
     runner2.test_data_loader0 = loader[:1]
     assert runner2.test(iter_id=6, save=True, ref=False) == {}
