@@ -12,8 +12,8 @@
 // split arithmetic (split_bf16.h) -- k_wgrad_t<1,4> and its second read of dy / h3 are gone.
 // GEMM (W3^T dy): weights on the A side, pixels on the B side, wave w = hidden channels [16 w, 16 w + 16): a lane holds four
 // consecutive channels of one pixel, so h3 arrives and dh3 leaves as 16-byte accesses.  dW3: the pixel axis is the K dimension; dy^T
-// is read by columns from the chunk's dy image (ds_read_b64_tr_b16), gelu(h3) goes through a 1.5 KB per-wave [pixel][channel] image.
-// LDS 65 KB (two workgroups per CU): ring [10][18][68] fp32 | dy pieces [2][3][48][16] bf16 | per-wave gelu(h3) pieces [4][3][16][16].
+// is read by columns from the chunk's dy image (ds_read_b64_tr_b16), gelu(h3) goes through a 4.5 KB per-wave [pixel][channel] image of the chunk.
+// LDS 77 KB (two workgroups per CU): ring [10][18][68] fp32 | dy pieces [2][3][48][16] bf16 | per-wave gelu(h3) pieces [4][3][48][16].
 #include "kernels.h"
 #include "bwd_kernels.h"
 #include "split_bf16.h"
@@ -23,7 +23,7 @@ namespace {
 constexpr int E = 16, N1 = 64, TX = 16, HX = 18, TY = 8, RING = 10, LDR = 68, CH = 48, CQ = 16;
 constexpr int DY_PIECE = CH * E;             // halves
 constexpr int DY_SLOT = 3 * DY_PIECE;
-constexpr int A3_PIECE = 16 * 16;            // halves, per wave and piece
+constexpr int A3_PIECE = CH * 16;            // halves, per wave and piece: the chunk's 48 pixels x the wave's 16 channels
 constexpr size_t OFF_DY = (size_t)RING * HX * LDR * 4;
 constexpr size_t OFF_A3 = OFF_DY + (size_t)2 * DY_SLOT * 2;
 constexpr size_t LDS_BYTES = OFF_A3 + (size_t)4 * 3 * A3_PIECE * 2;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     float* ring = reinterpret_cast<float*>(smem_raw);                          // [RING*HX][LDR] dh3
     uint16_t* DY = reinterpret_cast<uint16_t*>(smem_raw + OFF_DY);             // [2][3][CH][E]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-    uint16_t* A3 = reinterpret_cast<uint16_t*>(smem_raw + OFF_A3) + wave * 3 * A3_PIECE;   // [3][16 px][16 ch] of this wave
+    uint16_t* A3 = reinterpret_cast<uint16_t*>(smem_raw + OFF_A3) + wave * 3 * A3_PIECE;   // [3][48 px][16 ch] of this wave
     const int h = a.h, w = a.w;
     const int c0 = wave * 16 + 4 * g;                 // first of the lane's four hidden channels after the GEMM
     const WFrag16 w3f = load_wfrag16(a.w3t + (size_t)(wave * 16) * E, E, 0);   // W3^T rows [16 w, 16 w + 16)
@@ -146,21 +146,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 const float av[4] = {a01.x * mk, a01.y * mk, a23.x * mk, a23.y * mk};
                 u32x2_t q1, q2, q3;
                 split3_x4(av, q1, q2, q3);
-                uint16_t* dst = A3 + r * 16 + 4 * g;
+                uint16_t* dst = A3 + (pb * 16 + r) * 16 + 4 * g;
                 *reinterpret_cast<u32x2_t*>(dst) = q1;
                 *reinterpret_cast<u32x2_t*>(dst + A3_PIECE) = q2;
                 *reinterpret_cast<u32x2_t*>(dst + 2 * A3_PIECE) = q3;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                // dW3[.][16 w + .] += dy^T gelu(h3): both operands read by columns (K = the 16 pixels of the block)
-                {
-                    const uint16_t* pa = dyb + (pb * 16 + 4 * g + (r >> 2)) * E + 4 * (r & 3);
-                    const s16x4_t dt[3] = {lds_tr4(pa), lds_tr4(pa + DY_PIECE), lds_tr4(pa + 2 * DY_PIECE)};
-                    const uint16_t* pbp = A3 + (4 * g + (r >> 2)) * 16 + 4 * (r & 3);
-                    const s16x4_t at[3] = {lds_tr4(pbp), lds_tr4(pbp + A3_PIECE), lds_tr4(pbp + 2 * A3_PIECE)};
-                    mfma6_16(acc3, dt, at);
-                }
-                __builtin_amdgcn_wave_barrier();      // the wave's image is rewritten by the next pixel block
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // dW3[.][16 w + .] += dy^T gelu(h3): both operands read by columns (K = the chunk's 48 pixels); off the critical path of the ring
+#pragma unroll
+            for (int pb = 0; pb < 3; ++pb) {
+                const uint16_t* pa = dyb + (pb * 16 + 4 * g + (r >> 2)) * E + 4 * (r & 3);
+                const s16x4_t dt[3] = {lds_tr4(pa), lds_tr4(pa + DY_PIECE), lds_tr4(pa + 2 * DY_PIECE)};
+                const uint16_t* pbp = A3 + (pb * 16 + 4 * g + (r >> 2)) * 16 + 4 * (r & 3);
+                const s16x4_t at[3] = {lds_tr4(pbp), lds_tr4(pbp + A3_PIECE), lds_tr4(pbp + 2 * A3_PIECE)};
+                mfma6_16(acc3, dt, at);
             }
             if (more) {
                 dy_store(slot ^ 1, ndv, nown);
@@ -180,19 +180,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll 1
     for (int y0 = Y0; y0 < Yend; y0 += TY) {
         // h2 of the step's output pixels (wave w: tile rows 2 w, 2 w + 1; lane: pixel x0 + lane / 16 + 4 it, channels 4 q ..), item
-        // i = 4 ch + it: the first one is requested during the last chunk of the halo pass, item i + 1 while item i is worked on
+        // i = 4 ch + it.  An HBM round trip is longer than one P2 item, so four vectors are kept in flight: items 0 .. 3 are requested at
+        // the top of the LAST chunk of the halo pass, item i + 4 while item i is worked on (a rolled loop over a rotating register set:
+        // the unrolled forms of this loop spill)
         auto h2_fetch = [&](int i) {
             const int y = y0 + 2 * wave + (i >> 2), x = x0 + (lane >> 4) + 4 * (i & 3);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (y < Yend && x < w) v = *reinterpret_cast<const float4*>(a.h2 + ((b * h + y) * (long)w + x) * N1 + 4 * q);
             return v;
         };
-        float4 h2n;
+        float4 h2a, h2b, h2c, h2d;
         {
             float4 pre;
             bool pown;
             dy_fetch(y0 + 1, TY * HX, 0, pre, pown);
-            compute_rows(y0 + 1, TY, pre, pown, [&] { h2n = h2_fetch(0); });
+            compute_rows(y0 + 1, TY, pre, pown, [&] { h2a = h2_fetch(0); h2b = h2_fetch(1); h2c = h2_fetch(2); h2d = h2_fetch(3); });
         }
         // the depthwise taps of the lane's four channels as channel pairs: 36 contiguous floats, re-read (L1 / L2 hits) per step instead of
         // pinning 36 VGPRs through the halo pass
@@ -216,8 +218,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             const int ty = 2 * wave + (i >> 2), tx = (lane >> 4) + 4 * (i & 3);
             const int y = y0 + ty, x = x0 + tx;
             const bool ok = y < Yend && x < w;
-            const float4 hc = h2n;
-            if (i < 7) h2n = h2_fetch(i + 1);
+            const float4 hc = h2a;
+            h2a = h2b; h2b = h2c; h2c = h2d;
+            if (i < 4) h2d = h2_fetch(i + 4);
             const lg_v2f h01 = (lg_v2f){hc.x, hc.y}, h23 = (lg_v2f){hc.z, hc.w};   // 0 where !ok
             lg_v2f acc01 = (lg_v2f){0.f, 0.f}, acc23 = (lg_v2f){0.f, 0.f};
 #pragma unroll
