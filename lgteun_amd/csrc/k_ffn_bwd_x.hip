@@ -26,6 +26,18 @@
 #include "bwd_kernels.h"
 #include "split_bf16.h"
 
+// In-kernel phase stamps (diagnostic build only, -DLG_STAMPS: tools/build_stamps.sh + tools/bwd_stamps.py): the four waves of workgroup 0
+// write s_memtime at the phase boundaries of their third tile; no stamp executes in the product build.
+#ifdef LG_STAMPS
+__device__ unsigned long long g_kb_stamps[4 * 16];
+#define STAMP(i) do { if (blockIdx.x == 0 && lane == 0 && stamp_on) g_kb_stamps[wave * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" __attribute__((visibility("default"))) int lg_debug_kb_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_kb_stamps), sizeof(g_kb_stamps));
+}
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int E = 16, N1 = 64, NPX = 64, LDP = 72;
@@ -39,6 +51,10 @@ constexpr size_t LDS_BYTES = OFF_RED + (size_t)4 * NPX * E * 4;
 static_assert(OFF_XN % 16 == 0 && OFF_D1T % 16 == 0 && OFF_RED % 16 == 0, "16-byte aligned LDS regions");
 
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+#ifndef LG_KB_FENCE
+#define LG_KB_FENCE 1
+#endif
+#define KB_FENCE() do { if (LG_KB_FENCE) __builtin_amdgcn_sched_barrier(0); } while (0)
 
 __device__ __forceinline__ float quad_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
@@ -115,6 +131,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll 1
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long p0 = tile * NPX;
+#ifdef LG_STAMPS
+        const bool stamp_on = tile == (long)blockIdx.x + 2 * (long)gridDim.x;
+#endif
+        STAMP(0);
         // ---- loader: dh2 -> pieces -> D2 ; LN(x) -> pieces -> XN (the previous tile's readers of both are behind its second barrier)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -143,29 +163,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             *reinterpret_cast<u32x2_t*>(dst + 2 * XN_PIECE) = q3;
         }
         if (tile + (long)gridDim.x < ntiles) issue(tile + gridDim.x);   // next tile's operands: in flight during the GEMM phase
+        STAMP(1);
         __syncthreads();
+        STAMP(2);
 
         // ---- GEMM phase: four blocks of 16 pixels; this wave's 16 hidden channels
 #pragma unroll 1
         for (int pbk = 0; pbk < NPX / 16; ++pbk) {
-            // h1[px 4 g + v][ch 16 w + r] = LN(x) W1^T + b1
+            // The phases below are kept apart by scheduling fences (KB_FENCE): on gfx950 a wave that alternates MFMAs and vector
+            // instructions runs slower than the sum of the two (tools/micro/mfma_valu_overlap.hip: 482 + 525 us alone, 1178 us interleaved
+            // in one wave, 650 us with the two kinds of work in different waves of the SIMD) -- bursts of one kind per wave let the OTHER
+            // resident wave's vector work run under this wave's matrix work.
+            // ---- operands of the two data GEMMs
             s16x4_t xa[3];
             {
                 const uint16_t* p = XN + (pbk * 16 + r) * E + 4 * g;
                 xa[0] = lds_x4(p); xa[1] = lds_x4(p + XN_PIECE); xa[2] = lds_x4(p + 2 * XN_PIECE);
             }
+            const uint16_t* pd = D2 + (pbk * 16 + r) * LDP + 8 * g;
+            const bf16x8_t d0[3] = {lds_x8(pd), lds_x8(pd + D2_PIECE), lds_x8(pd + 2 * D2_PIECE)};
+            const bf16x8_t d1[3] = {lds_x8(pd + 32), lds_x8(pd + 32 + D2_PIECE), lds_x8(pd + 32 + 2 * D2_PIECE)};
+            KB_FENCE();
+            // ---- h1[px 4 g + v][ch 16 w + r] = LN(x) W1^T + b1 ; da1 = dh2 W2 (K = 64 as two 32-deep blocks)
             f32x4_t h1 = (f32x4_t){b1s, b1s, b1s, b1s};
             mfma6_16(h1, xa, w1f.p);
-            // da1 = dh2 W2 (K = 64 as two 32-deep blocks)
             f32x4_t da = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            {
-                const uint16_t* p = D2 + (pbk * 16 + r) * LDP + 8 * g;
-                const bf16x8_t d0[3] = {lds_x8(p), lds_x8(p + D2_PIECE), lds_x8(p + 2 * D2_PIECE)};
-                mfma6_32(da, d0, w2f0.p);
-                const bf16x8_t d1[3] = {lds_x8(p + 32), lds_x8(p + 32 + D2_PIECE), lds_x8(p + 32 + 2 * D2_PIECE)};
-                mfma6_32(da, d1, w2f1.p);
-            }
-            // gelu(h1), gelu'(h1) with one exponential for both; dh1 = da1 * gelu'(h1)
+            mfma6_32(da, d0, w2f0.p);
+            mfma6_32(da, d1, w2f1.p);
+            KB_FENCE();
+            // ---- gelu(h1), gelu'(h1) with one exponential for both; dh1 = da1 * gelu'(h1); pieces; the column reads of the weight-gradient operands
             lg_v2f a01, a23, g01, g23;
             gelu2_both_f((lg_v2f){h1[0], h1[1]}, a01, g01);
             gelu2_both_f((lg_v2f){h1[2], h1[3]}, a23, g23);
@@ -175,21 +201,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             s16x4_t a1p[3], d1p[3];
             split4(a1v, a1p);
             split4(d1v, d1p);
-            // dW1[16 w + .][.] += dh1^T LN(x): A = dh1 from the registers (K = the lane's four pixels), B = LN(x) read by columns
-            {
-                const uint16_t* p = XN + (pbk * 16 + 4 * g + (r >> 2)) * E + 4 * (r & 3);
-                const s16x4_t xt[3] = {lds_tr4(p), lds_tr4(p + XN_PIECE), lds_tr4(p + 2 * XN_PIECE)};
-                mfma6_16(acc1, d1p, xt);
-            }
-            // dW2[.][16 w + .] += dh2^T gelu(h1): A = dh2 read by columns, B = gelu(h1) from the registers
-            {
-                const uint16_t* p = D2 + (pbk * 16 + 4 * g + (r >> 2)) * LDP + 4 * (r & 3);
+            const uint16_t* px = XN + (pbk * 16 + 4 * g + (r >> 2)) * E + 4 * (r & 3);
+            const s16x4_t xt[3] = {lds_tr4(px), lds_tr4(px + XN_PIECE), lds_tr4(px + 2 * XN_PIECE)};
+            const uint16_t* pt = D2 + (pbk * 16 + 4 * g + (r >> 2)) * LDP + 4 * (r & 3);
+            s16x4_t dt[4][3];
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    const s16x4_t dt[3] = {lds_tr4(p + 16 * nb), lds_tr4(p + 16 * nb + D2_PIECE), lds_tr4(p + 16 * nb + 2 * D2_PIECE)};
-                    mfma6_16(acc2[nb], dt, a1p);
-                }
-            }
+            for (int nb = 0; nb < 4; ++nb) { dt[nb][0] = lds_tr4(pt + 16 * nb); dt[nb][1] = lds_tr4(pt + 16 * nb + D2_PIECE); dt[nb][2] = lds_tr4(pt + 16 * nb + 2 * D2_PIECE); }
+            KB_FENCE();
+            // ---- dW1[16 w + .][.] += dh1^T LN(x) (A = dh1 from the registers, B = LN(x) read by columns);
+            //      dW2[.][16 w + .] += dh2^T gelu(h1) (A = dh2 read by columns, B = gelu(h1) from the registers)
+            mfma6_16(acc1, d1p, xt);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) mfma6_16(acc2[nb], dt[nb], a1p);
+            KB_FENCE();
             // this wave's K = 16 slice of W1^T dh1: dh1 -> [channel][pixel] in the wave's own LDS region, read back by columns as the B operand
             {
                 uint16_t* dst = D1T + r * 16 + 4 * g;
@@ -206,7 +230,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 *reinterpret_cast<float4*>(red + ((size_t)wave * NPX + pbk * 16 + r) * E + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
+        STAMP(3);
         __syncthreads();
+        STAMP(4);
 
         // ---- LayerNorm backward + residual (thread = pixel lpx, channels 4 lq ..): sum of the four K slices, then the usual two moments
         {
@@ -223,6 +249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 make_float4(dyv.x + rstd * (dxh[0] - m1 - xh[0] * m2), dyv.y + rstd * (dxh[1] - m1 - xh[1] * m2),
                             dyv.z + rstd * (dxh[2] - m1 - xh[2] * m2), dyv.w + rstd * (dxh[3] - m1 - xh[3] * m2));
         }
+        STAMP(5);
         // (the next tile's loader writes D2 / XN, which this tile's GEMM phase finished reading before the barrier above; `red` is
         // rewritten only behind the next tile's first barrier)
     }

@@ -18,6 +18,17 @@
 #include "bwd_kernels.h"
 #include "split_bf16.h"
 
+// In-kernel phase stamps (diagnostic build only, -DLG_STAMPS: tools/build_stamps.sh + tools/bwd_stamps.py)
+#ifdef LG_STAMPS
+__device__ unsigned long long g_ka_stamps[4 * 16];
+#define STAMP(i) do { if (blockIdx.x == 0 && lane == 0 && stamp_on) g_ka_stamps[wave * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" __attribute__((visibility("default"))) int lg_debug_ka_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ka_stamps), sizeof(g_ka_stamps));
+}
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int E = 16, N1 = 64, TX = 16, HX = 18, TY = 8, RING = 10, LDR = 68, CH = 48, CQ = 16;
@@ -70,20 +81,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int sy = t % strips_y;
     const long b = t / strips_y;
     const int x0 = tx_i * TX, Y0 = sy * SH, Yend = min(Y0 + SH, h);
+#ifdef LG_STAMPS
+    bool stamp_on = false;
+#endif
 
-    // dy vector of halo pixel m of the row block starting at ya (zeros outside the image / beyond npx); own: the pixel belongs to THIS strip
-    auto dy_fetch = [&](int ya, int npx, int c, float4& dv, bool& own) {
+    // Every global load below is UNCONDITIONAL, from a clamped (always valid) address, and masked afterwards by a select: a load inside an
+    // exec-masked branch makes the compiler wait with vmcnt(0) at the join (loads and stores share ONE in-order counter on gfx950), which
+    // turns every prefetch into a full HBM round trip on the spot (in-kernel stamps, profiles/r03_ffn_bwd_phase_stamps.txt).
+    // dy vector of halo pixel m of the row block starting at ya; in: inside the image, own: the pixel belongs to THIS strip
+    auto dy_fetch = [&](int ya, int npx, int c, float4& dv, bool& in, bool& own) {
         const int m = c * CH + lpx;
         const int hy = m / HX, hx = m - hy * HX;
         const int y = ya + hy, x = x0 + hx - 1;
-        const bool in = dy_thread && (m < npx) && y >= 0 && y < h && x >= 0 && x < w;
+        in = dy_thread && (m < npx) && y >= 0 && y < h && x >= 0 && x < w;
         own = in && hx >= 1 && hx <= TX && y >= Y0 && y < Yend;
-        dv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in) dv = *reinterpret_cast<const float4*>(a.dy + ((b * h + y) * (long)w + x) * E + 4 * lq);
+        dv = *reinterpret_cast<const float4*>(a.dy + ((b * h + clampi(y, 0, h - 1)) * (long)w + clampi(x, 0, w - 1)) * E + 4 * lq);
     };
-    auto dy_store = [&](int slot, const float4& dv, bool own) {
-        if (!dy_thread) return;
+    auto dy_store = [&](int slot, const float4& dvr, bool in, bool own) {
+        const float4 dv = make_float4(in ? dvr.x : 0.f, in ? dvr.y : 0.f, in ? dvr.z : 0.f, in ? dvr.w : 0.f);   // dy = 0 outside the image: so is dh3
         if (own) { sb3.x += dv.x; sb3.y += dv.y; sb3.z += dv.z; sb3.w += dv.w; }
+        if (!dy_thread) return;          // wave 3 holds no dy vectors
         const float v[4] = {dv.x, dv.y, dv.z, dv.w};
         u32x2_t q1, q2, q3;
         split3_x4(v, q1, q2, q3);
@@ -92,33 +109,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         *reinterpret_cast<u32x2_t*>(dst + DY_PIECE) = q2;
         *reinterpret_cast<u32x2_t*>(dst + 2 * DY_PIECE) = q3;
     };
-    // h3 of the lane's pixel / channels in chunk c (zeros outside the image / beyond npx)
-    auto h3_fetch = [&](int ya, int npx, int c, float4 (&hv)[3]) {
+    // h3 of the lane's pixel / channels in chunk c.  No mask: outside the image dy = 0 makes dh3 = 0 whatever gelu'(h3) is, and gelu(h3)
+    // enters dW3 only for the strip's own pixels
+    auto h3_fetch = [&](int ya, int c, float4 (&hv)[3]) {
 #pragma unroll
         for (int pb = 0; pb < 3; ++pb) {
             const int m = c * CH + pb * 16 + r;
             const int hy = m / HX, hx = m - hy * HX;
-            const int y = ya + hy, x = x0 + hx - 1;
-            hv[pb] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < npx && y >= 0 && y < h && x >= 0 && x < w) hv[pb] = *reinterpret_cast<const float4*>(a.h3 + ((b * h + y) * (long)w + x) * N1 + c0);
+            const int y = clampi(ya + hy, 0, h - 1), x = clampi(x0 + hx - 1, 0, w - 1);
+            hv[pb] = *reinterpret_cast<const float4*>(a.h3 + ((b * h + y) * (long)w + x) * N1 + c0);
         }
     };
 
     // dh3 of halo rows [ya, ya + nr) x columns [x0 - 1, x0 + 17) -> ring (nr = 2: strip prologue, 8: one step)
     // in_last: run at the top of the LAST chunk, where no next-chunk operands are in flight (registers and load slots are free)
-    auto compute_rows = [&](int ya, int nr, float4 pre, bool pre_own, auto&& in_last) {
+    // pre / pre_in / pre_own, h3c: chunk 0's dy vector and h3 vectors, requested by the caller ahead of time
+    auto compute_rows = [&](int ya, int nr, float4 pre, bool pre_in, bool pre_own, float4 (&h3c)[3], auto&& in_last) {
         const int npx = nr * HX, nchunks = (npx + CH - 1) / CH;
-        float4 h3c[3], h3n[3];
-        h3_fetch(ya, npx, 0, h3c);
-        dy_store(0, pre, pre_own);
+        float4 h3n[3];
+        dy_store(0, pre, pre_in, pre_own);
+        STAMP(1);
         __syncthreads();                 // also: the previous phase (P2) is done reading the ring rows this call overwrites
+        STAMP(2);
         const int ring0 = ((ya - Y0 + 1) % RING) * HX;
         for (int c = 0; c < nchunks; ++c) {
             const int slot = c & 1;
             const bool more = c + 1 < nchunks;
             float4 ndv;
-            bool nown = false;
-            if (more) { dy_fetch(ya, npx, c + 1, ndv, nown); h3_fetch(ya, npx, c + 1, h3n); }
+            bool nin = false, nown = false;
+            if (more) { dy_fetch(ya, npx, c + 1, ndv, nin, nown); h3_fetch(ya, c + 1, h3n); }
             else in_last();
             const uint16_t* dyb = DY + slot * DY_SLOT;
 #pragma unroll
@@ -163,39 +182,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 mfma6_16(acc3, dt, at);
             }
             if (more) {
-                dy_store(slot ^ 1, ndv, nown);
+                dy_store(slot ^ 1, ndv, nin, nown);
 #pragma unroll
                 for (int pb = 0; pb < 3; ++pb) h3c[pb] = h3n[pb];
             }
+            STAMP(3 + 2 * c);
             __syncthreads();   // dy slot c + 1 complete; the readers of slot c are done before chunk c + 2 rewrites it; after the last chunk: ring rows complete
+            STAMP(4 + 2 * c);
         }
     };
 
-    {
-        float4 pre;
-        bool pown;
-        dy_fetch(Y0 - 1, 2 * HX, 0, pre, pown);
-        compute_rows(Y0 - 1, 2, pre, pown, [] {});
-    }
+    float4 pre, h3p[3];
+    bool pin, pown;
+    dy_fetch(Y0 - 1, 2 * HX, 0, pre, pin, pown);
+    h3_fetch(Y0 - 1, 0, h3p);
+    // the first step's chunk-0 operands are requested at the top of the prologue's only chunk, the next step's before P2 (below): an HBM
+    // round trip under a whole phase instead of in front of it
+    float4 npre, nh3[3];
+    bool npin = false, npown = false;
+    compute_rows(Y0 - 1, 2, pre, pin, pown, h3p, [&] { dy_fetch(Y0 + 1, TY * HX, 0, npre, npin, npown); h3_fetch(Y0 + 1, 0, nh3); });
 #pragma unroll 1
     for (int y0 = Y0; y0 < Yend; y0 += TY) {
+#ifdef LG_STAMPS
+        stamp_on = (y0 == Y0 + 2 * TY) && strip == 0;
+#endif
+        STAMP(0);
         // h2 of the step's output pixels (wave w: tile rows 2 w, 2 w + 1; lane: pixel x0 + lane / 16 + 4 it, channels 4 q ..), item
         // i = 4 ch + it.  An HBM round trip is longer than one P2 item, so four vectors are kept in flight: items 0 .. 3 are requested at
-        // the top of the LAST chunk of the halo pass, item i + 4 while item i is worked on (a rolled loop over a rotating register set:
-        // the unrolled forms of this loop spill)
+        // the top of the LAST chunk of the halo pass, item i + 4 while item i is worked on.  Every output pixel of a step is inside the
+        // image (launcher: h % 8 == 0, w % 16 == 0).
         auto h2_fetch = [&](int i) {
             const int y = y0 + 2 * wave + (i >> 2), x = x0 + (lane >> 4) + 4 * (i & 3);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (y < Yend && x < w) v = *reinterpret_cast<const float4*>(a.h2 + ((b * h + y) * (long)w + x) * N1 + 4 * q);
-            return v;
+            return *reinterpret_cast<const float4*>(a.h2 + ((b * h + y) * (long)w + x) * N1 + 4 * q);
         };
         float4 h2a, h2b, h2c, h2d;
-        {
-            float4 pre;
-            bool pown;
-            dy_fetch(y0 + 1, TY * HX, 0, pre, pown);
-            compute_rows(y0 + 1, TY, pre, pown, [&] { h2a = h2_fetch(0); h2b = h2_fetch(1); h2c = h2_fetch(2); h2d = h2_fetch(3); });
-        }
+        pre = npre; pin = npin; pown = npown;
+#pragma unroll
+        for (int pb = 0; pb < 3; ++pb) h3p[pb] = nh3[pb];
+        compute_rows(y0 + 1, TY, pre, pin, pown, h3p, [&] { h2a = h2_fetch(0); h2b = h2_fetch(1); h2c = h2_fetch(2); h2d = h2_fetch(3); });
         // the depthwise taps of the lane's four channels as channel pairs: 36 contiguous floats, re-read (L1 / L2 hits) per step instead of
         // pinning 36 VGPRs through the halo pass
         lg_v2f wq01[9], wq23[9];
@@ -212,16 +236,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             for (int k = 0; k < 9; ++k) { wq01[k] = (lg_v2f){t36[k], t36[9 + k]}; wq23[k] = (lg_v2f){t36[18 + k], t36[27 + k]}; }
         }
         // ---- P2: dh2 = dw^T dh3 and the depthwise weight / bias gradient partials
+        // next step's chunk-0 operands (clamped addresses: harmless behind the strip's last step), requested BEHIND the taps and the first
+        // h2 vectors: the wait counter is in-order, a wait for the taps would otherwise wait for these HBM loads as well
+        __builtin_amdgcn_sched_barrier(0);
+        dy_fetch(y0 + TY + 1, TY * HX, 0, npre, npin, npown);
+        h3_fetch(y0 + TY + 1, 0, nh3);
+        STAMP(9);
         const int sbase = (y0 - Y0) % RING;            // ring slot of row y0 - 1
-#pragma unroll 1
-        for (int i = 0; i < 8; ++i) {
-            const int ty = 2 * wave + (i >> 2), tx = (lane >> 4) + 4 * (i & 3);
+        // one output pixel quad: hreg holds its h2 vector and is re-loaded with the vector of the item four places on (no register
+        // rotation: a rotating set needs its moves in front of the loop's back edge, i.e. a wait for the load issued in the same iteration)
+        auto item = [&](int ch, int it, float4& hreg) {
+            const int ty = 2 * wave + ch, tx = (lane >> 4) + 4 * it;
             const int y = y0 + ty, x = x0 + tx;
-            const bool ok = y < Yend && x < w;
-            const float4 hc = h2a;
-            h2a = h2b; h2b = h2c; h2c = h2d;
-            if (i < 4) h2d = h2_fetch(i + 4);
-            const lg_v2f h01 = (lg_v2f){hc.x, hc.y}, h23 = (lg_v2f){hc.z, hc.w};   // 0 where !ok
+            const float4 hc = hreg;
+            {
+                const int yn = y0 + 2 * wave + 1;      // ch = 0: the same pixel column one tile row down; ch = 1: the repeat is an L2 hit nobody waits for
+                hreg = *reinterpret_cast<const float4*>(a.h2 + ((b * h + yn) * (long)w + x) * N1 + 4 * q);
+            }
+            const lg_v2f h01 = (lg_v2f){hc.x, hc.y}, h23 = (lg_v2f){hc.z, hc.w};
             lg_v2f acc01 = (lg_v2f){0.f, 0.f}, acc23 = (lg_v2f){0.f, 0.f};
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
@@ -236,15 +268,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     acc23 = wq23[dy * 3 + dx] * g23 + acc23;
                     pw01[dy * 3 + dx] = h01 * g01 + pw01[dy * 3 + dx];
                     pw23[dy * 3 + dx] = h23 * g23 + pw23[dy * 3 + dx];
-                    if (dy == 1 && dx == 1) {
-                        const float mk = ok ? 1.0f : 0.0f;
-                        pw01[9] = g01 * mk + pw01[9];
-                        pw23[9] = g23 * mk + pw23[9];
-                    }
+                    if (dy == 1 && dx == 1) { pw01[9] += g01; pw23[9] += g23; }
                 }
             }
-            if (ok) *reinterpret_cast<float4*>(a.dh2 + ((b * h + y) * (long)w + x) * N1 + 4 * q) = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
+            *reinterpret_cast<float4*>(a.dh2 + ((b * h + y) * (long)w + x) * N1 + 4 * q) = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
+            __builtin_amdgcn_sched_barrier(0);      // one item at a time: interleaved items need more registers than there are
+        };
+#pragma unroll 1
+        for (int ch = 0; ch < 2; ++ch) {
+            item(ch, 0, h2a);
+            item(ch, 1, h2b);
+            item(ch, 2, h2c);
+            item(ch, 3, h2d);
         }
+        STAMP(10);
     }   // steps of the strip
     __syncthreads();   // the last step's P2 readers of the ring are done before the next strip's prologue writes it
     }   // strips of this workgroup
@@ -298,6 +335,7 @@ int launch_ffn_dw_bwd_xs(const FfnDwBwdXArgs& a, hipStream_t s) {
         if (e != hipSuccess) { lg_set_error("ffn_dw_bwd_xs: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
+    if ((a.h & 7) || (a.w & 15)) { lg_set_error("ffn_dw_bwd_xs: h must be a multiple of 8 and w of 16 (got %d x %d)", a.h, a.w); return -2; }
     const int tiles_x = (a.w + 15) / 16;
     // strip height as in the forward: the tallest multiple of 8 rows that still yields >= 512 strips (two resident workgroups per CU), at least 16
     int SH = (a.h + 7) / 8 * 8;
