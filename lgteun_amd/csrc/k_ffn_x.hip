@@ -36,6 +36,9 @@ extern "C" __attribute__((visibility("default"))) int lg_debug_ffn_stamps(unsign
 #define STAMP(i) do { } while (0)
 #endif
 
+#ifndef LG_XS_UNCOND
+#define LG_XS_UNCOND 0   // 1: unconditional clamped x loads (the cure of k_ffn_dw_bwd_xs's vmcnt(0) waits); measured here: 114.6 vs 112.2 us per launch, off
+#endif
 #ifndef LG_XS_SAVE_UNROLL
 #define LG_XS_SAVE_UNROLL 1
 #endif
@@ -117,8 +120,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         const int hy = m / HX, hx = m - hy * HX;
         const int y = ya + hy, x = x0 + hx - 1;
         in = ln_thread && (m < npx) && y >= 0 && y < h && x >= 0 && x < w;
+#if LG_XS_UNCOND
+        // unconditional, from a clamped (always valid) address: a load inside an exec-masked branch makes the compiler wait with vmcnt(0) at
+        // the join, i.e. for every load in flight (k_ffn_dwbwd_x.hip; profiles/r03_ffn_bwd_phase_stamps.txt).  ln_store masks the result.
+        xv = *reinterpret_cast<const float4*>(a1.x + ((b * h + clampi(y, 0, h - 1)) * (long)w + clampi(x, 0, w - 1)) * E + 4 * lq);
+#else
         xv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (in) xv = *reinterpret_cast<const float4*>(a1.x + ((b * h + y) * (long)w + x) * E + 4 * lq);
+#endif
     };
     // LayerNorm of the fetched vector over its 16 channels (4 lanes of a quad), split into pieces -> XA[slot]
     auto ln_store = [&](int slot, const float4& xv, bool in) {
@@ -259,8 +268,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
             const int y = y0 + 2 * wave + ch, x = x0 + r;
+#if LG_XS_UNCOND
+            xres[ch] = *reinterpret_cast<const float4*>(a2.x + ((b * h + min(y, h - 1)) * (long)w + min(x, w - 1)) * E + 4 * g);
+#else
             xres[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (y < Yend && x < w) xres[ch] = *reinterpret_cast<const float4*>(a2.x + ((b * h + y) * (long)w + x) * E + 4 * g);
+#endif
         }
     });
     if (y0 + TY < Yend) ln_fetch(y0 + TY + 1, TY * HX, 0, pre, pin);   // next step's first chunk: in flight during P2
