@@ -200,7 +200,8 @@ int launch_ffn1_bwd_x32(const Ffn1BwdArgs& a, const float* w1, void* wsplit, hip
 // e = 16, fp32 storage (k_ffn_bwd_x.hip): everything that hangs off dh2 in ONE pass on the bf16 matrix pipe (split arithmetic) --
 // h1 re-computed from x, dx, LayerNorm gradients, dW1 / db1 AND dW2 / db2; replaces k_ffn1_bwd<16> + the 64 x 64 k_wgrad_t launch
 struct Ffn1BwdXArgs {
-    const float* dh2;  // [P,64]
+    const void* dh2;   // [P,64]  (hidden storage: fp32, or bf16 when hbf)
+    int hbf;           // 1: precision = 'bf16' (plain bf16 products, dh2 stored as bf16)
     const float* x;    // [P,16] block mid activation (LN2 input)
     const float* dy;   // [P,16] grad wrt block output (residual path)
     float* dx;         // [P,16]
@@ -222,9 +223,10 @@ int launch_ffn1_bwd_xs(const Ffn1BwdXArgs& a, hipStream_t s);
 // dW3 / db3 in the same pass; replaces k_ffn_dw_bwd<16> + the 16 x 64 k_wgrad_t launch
 struct FfnDwBwdXArgs {
     const float* dy;   // [B,h,w,16]
-    const float* h3;   // [B,h,w,64] saved pre-activation of the second GELU
-    const float* h2;   // [B,h,w,64] saved
-    float* dh2;        // [B,h,w,64] out
+    const void* h3;    // [B,h,w,64] saved pre-activation of the second GELU   (hidden storage: fp32, or bf16 when hbf)
+    const void* h2;    // [B,h,w,64] saved                                      (hidden storage)
+    void* dh2;         // [B,h,w,64] out                                        (hidden storage)
+    int hbf;           // 1: precision = 'bf16' (plain bf16 products, bf16 storage of h2 / h3 / dh2)
     const float* w3t;  // [64][16] transposed W3
     const float* dww;  // [64,1,3,3]
     float* slab;       // FFN_DW_BWD_X_WGS rows of FFN_DW_BWD_X_ROW floats (per-workgroup partial sums)

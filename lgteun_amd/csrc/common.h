@@ -39,9 +39,9 @@ struct lg_plan {
     // In modes 2 / 3 the tensors sit in the a1 / h2 / a3 slots (workspace.h) and the g1 / g3 slots stay unused.
     int dwbwd_tile; // A/B switch read ONCE at plan creation (env LG_FFN_DWBWD=tile): round 2's tile kernel k_ffn_dw_bwd<16> + k_wgrad_t for dW3
                     // instead of the strip-walking k_ffn_dw_bwd_xs
-    bool ffn_e16_split() const { return cfg.precision == 0 && ffn_tile == 0; }
-    bool ffn_saves_preact(int e) const { return e == 16 && ffn_e16_split() && save_mode != 5; }
-    bool ffn_bwd_x(int e) const { return e == 16 && ffn_e16_split() && save_mode == 2; }   // h1 not saved; backward through k_ffn1_bwd_xs
+    // precision = 'bf16' (plain bf16 MFMA, bf16 storage of the saved tensors) knows modes 2 and 5 only (3 falls back to 5)
+    bool ffn_bwd_x(int e) const { return e == 16 && ffn_tile == 0 && save_mode == 2; }   // h1 not saved; backward through k_ffn_dw_bwd_xs + k_ffn1_bwd_xs
+    bool ffn_saves_preact(int e) const { return e == 16 && ffn_tile == 0 && (save_mode == 2 || (save_mode == 3 && cfg.precision == 0)); }
     int64_t* off;  // host copy of offsets
     int64_t shared(int s) const { return off[s]; }
     int64_t eta(int i) const { return off[S_NSHARED + i]; }

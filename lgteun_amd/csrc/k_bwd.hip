@@ -98,7 +98,7 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
     const int hbf = pl->cfg.precision == 1 ? 1 : 0;   // bf16 storage of the hidden / saved FFN tensors
     const int pre = pl->ffn_saves_preact(e) ? 1 : 0;  // fb.a1 / fb.a3 hold h1 / h3 (fb.g1 / fb.g3 unused): GELU re-evaluated where needed
     const long Pn = (long)B * fb.h * fb.w;
-    if (pl->ffn_bwd_x(e) && !pl->dwbwd_tile) {
+    if (pl->ffn_bwd_x(e) && (!pl->dwbwd_tile || hbf)) {
         // two launches per half-block: the strip-walking spatial half (dh3 in LDS -> dh2, depthwise gradients, dW3 / db3) and the pixelwise
         // half (h1 re-computed, dx, LayerNorm gradients, dW1 / db1, dW2 / db2); dh2 is the only tensor between them
         FfnDwBwdXArgs fk;
@@ -106,7 +106,7 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         fk.slab = bb.rq.take((size_t)FFN_DW_BWD_X_WGS * FFN_DW_BWD_X_ROW);
         if (!fk.slab) return -3;
         fk.d_dww = G + pl->blk(st, j, B_DWW); fk.d_dwb = G + pl->blk(st, j, B_DWB); fk.d_w3 = G + pl->blk(st, j, B_W3); fk.d_b3 = G + pl->blk(st, j, B_B3);
-        fk.B = B; fk.h = fb.h; fk.w = fb.w;
+        fk.B = B; fk.h = fb.h; fk.w = fb.w; fk.hbf = hbf;
         RC(launch_ffn_dw_bwd_xs(fk, s));
         Ffn1BwdXArgs fx;
         fx.dh2 = bb.dh2; fx.x = fb.xmid; fx.dy = dy; fx.dx = tmp;
@@ -116,7 +116,7 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         if (!fx.slab) return -3;
         fx.d_w1 = G + pl->blk(st, j, B_W1); fx.d_b1 = G + pl->blk(st, j, B_B1); fx.d_w2 = G + pl->blk(st, j, B_W2); fx.d_b2 = G + pl->blk(st, j, B_B2);
         fx.d_ln2g = G + pl->blk(st, j, B_LN2G); fx.d_ln2b = G + pl->blk(st, j, B_LN2B);
-        fx.P = Pn;
+        fx.P = Pn; fx.hbf = hbf;
         return launch_ffn1_bwd_xs(fx, s);
     }
     FfnDwBwdArgs fd;
@@ -137,7 +137,7 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         if (!fx.slab) return -3;
         fx.d_w1 = G + pl->blk(st, j, B_W1); fx.d_b1 = G + pl->blk(st, j, B_B1); fx.d_w2 = G + pl->blk(st, j, B_W2); fx.d_b2 = G + pl->blk(st, j, B_B2);
         fx.d_ln2g = G + pl->blk(st, j, B_LN2G); fx.d_ln2b = G + pl->blk(st, j, B_LN2B);
-        fx.P = Pn;
+        fx.P = Pn; fx.hbf = hbf;
         RC(launch_ffn1_bwd_xs(fx, s));
         return wgrad(dy, e, fb.a3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 0, hbf, bb, s, pre);
     }

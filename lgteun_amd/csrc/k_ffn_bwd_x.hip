@@ -25,6 +25,7 @@
 #include "kernels.h"
 #include "bwd_kernels.h"
 #include "split_bf16.h"
+#include "hstore.h"
 
 // In-kernel phase stamps (diagnostic build only, -DLG_STAMPS: tools/build_stamps.sh + tools/bwd_stamps.py): the four waves of workgroup 0
 // write s_memtime at the phase boundaries of their third tile; no stamp executes in the product build.
@@ -85,13 +86,27 @@ __device__ __forceinline__ void mfma6_32(f32x4_t& acc, const bf16x8_t (&a)[3], c
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
 }
+// NP = 3: the six piece products (fp32-equivalent); NP = 1 (precision = 'bf16'): one product of round-to-nearest bf16 operands
+template <int NP>
+__device__ __forceinline__ void mfmaN_16(f32x4_t& acc, const s16x4_t (&a)[3], const s16x4_t (&b)[3]) {
+    if (NP == 3) mfma6_16(acc, a, b);
+    else acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[0], acc, 0, 0, 0);
+}
+template <int NP>
+__device__ __forceinline__ void mfmaN_32(f32x4_t& acc, const bf16x8_t (&a)[3], const bf16x8_t (&b)[3]) {
+    if (NP == 3) mfma6_32(acc, a, b);
+    else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+template <int NP>
 __device__ __forceinline__ void split4(const float (&v)[4], s16x4_t (&p)[3]) {
     u32x2_t q1, q2, q3;
-    split3_x4(v, q1, q2, q3);
+    split_x4<NP>(v, q1, q2, q3);
     p[0] = __builtin_bit_cast(s16x4_t, q1); p[1] = __builtin_bit_cast(s16x4_t, q2); p[2] = __builtin_bit_cast(s16x4_t, q3);
 }
 
+template <int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn1_bwd_xs(Ffn1BwdXArgs a, long ntiles) {
+    constexpr bool BF = (NP == 1);   // plain-bf16 mode: dh2 is stored as bf16 (hstore.h) and is its own (single) piece
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint16_t* D2 = reinterpret_cast<uint16_t*>(smem_raw);                 // [3][NPX][LDP]   bf16 pieces of dh2
     uint16_t* XN = reinterpret_cast<uint16_t*>(smem_raw + OFF_XN);        // [3][NPX][E]     bf16 pieces of LN(x)
@@ -100,10 +115,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     float* red = reinterpret_cast<float*>(smem_raw + OFF_RED);            // [4 waves][NPX][E]
 
     // ---- weights of this wave's hidden-channel block, split once, register-resident
-    const WFrag16 w1f = load_wfrag16(a.w1 + (size_t)(wave * 16) * E, E, 0);            // [n = 16 w + r][k = 4 g ..]: B of h1 = LN(x) W1^T
-    const WFrag32 w2f0 = load_wfrag32(a.w2t + (size_t)(wave * 16) * N1, N1, 0);        // [n' = 16 w + r][n = 8 g ..]: B of da1 = dh2 W2
-    const WFrag32 w2f1 = load_wfrag32(a.w2t + (size_t)(wave * 16) * N1, N1, 1);
-    const WFrag16 w1tf = load_wfrag16(a.w1t, N1, wave * 16);                           // [k = r][n = 16 w + 4 g ..]: A of W1^T dh1 (K slice)
+    const WFrag16 w1f = NP == 3 ? load_wfrag16(a.w1 + (size_t)(wave * 16) * E, E, 0) : load_wfrag16_rne(a.w1 + (size_t)(wave * 16) * E, E, 0);            // [n = 16 w + r][k = 4 g ..]: B of h1 = LN(x) W1^T
+    const WFrag32 w2f0 = NP == 3 ? load_wfrag32(a.w2t + (size_t)(wave * 16) * N1, N1, 0) : load_wfrag32_rne(a.w2t + (size_t)(wave * 16) * N1, N1, 0);        // [n' = 16 w + r][n = 8 g ..]: B of da1 = dh2 W2
+    const WFrag32 w2f1 = NP == 3 ? load_wfrag32(a.w2t + (size_t)(wave * 16) * N1, N1, 1) : load_wfrag32_rne(a.w2t + (size_t)(wave * 16) * N1, N1, 1);
+    const WFrag16 w1tf = NP == 3 ? load_wfrag16(a.w1t, N1, wave * 16) : load_wfrag16_rne(a.w1t, N1, wave * 16);                           // [k = r][n = 16 w + 4 g ..]: A of W1^T dh1 (K slice)
     const float b1s = a.b1[wave * 16 + r];
     // LayerNorm role: thread = (pixel t / 4, channel quad t % 4)
     const int lpx = threadIdx.x >> 2, lq = threadIdx.x & 3;
@@ -118,11 +133,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     float4 bs2 = make_float4(0.f, 0.f, 0.f, 0.f);             // db2[4 dq ..], this thread's pixels
     float4 pg = make_float4(0.f, 0.f, 0.f, 0.f), pb = pg;     // d gamma / d beta [4 lq ..], this thread's pixels
 
-    float4 d2n[4], xnx, dyn;
+    typename HS<BF>::raw4 d2n[4];    // raw bits: widened when they leave the prefetch registers
+    float4 xnx, dyn;
     auto issue = [&](long tile_) {
         const long p0 = tile_ * NPX;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) d2n[it] = *reinterpret_cast<const float4*>(a.dh2 + (p0 + dpx + 16 * it) * N1 + 4 * dq);
+        for (int it = 0; it < 4; ++it) d2n[it] = HS<BF>::ldraw(a.dh2, (p0 + dpx + 16 * it) * N1 + 4 * dq);
         xnx = *reinterpret_cast<const float4*>(a.x + (p0 + lpx) * E + 4 * lq);
         dyn = *reinterpret_cast<const float4*>(a.dy + (p0 + lpx) * E + 4 * lq);
     };
@@ -138,15 +154,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         // ---- loader: dh2 -> pieces -> D2 ; LN(x) -> pieces -> XN (the previous tile's readers of both are behind its second barrier)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const float4 d = d2n[it];
+            const float4 d = HS<BF>::widen(d2n[it]);
             bs2.x += d.x; bs2.y += d.y; bs2.z += d.z; bs2.w += d.w;
-            const float v[4] = {d.x, d.y, d.z, d.w};
-            u32x2_t q1, q2, q3;
-            split3_x4(v, q1, q2, q3);
             uint16_t* dst = D2 + (dpx + 16 * it) * LDP + 4 * dq;
-            *reinterpret_cast<u32x2_t*>(dst) = q1;
-            *reinterpret_cast<u32x2_t*>(dst + D2_PIECE) = q2;
-            *reinterpret_cast<u32x2_t*>(dst + 2 * D2_PIECE) = q3;
+            if constexpr (BF) {
+                *reinterpret_cast<u32x2_t*>(dst) = __builtin_bit_cast(u32x2_t, d2n[it]);   // the stored bf16 values ARE the operand
+            } else {
+                const float v[4] = {d.x, d.y, d.z, d.w};
+                u32x2_t q1, q2, q3;
+                split3_x4(v, q1, q2, q3);
+                *reinterpret_cast<u32x2_t*>(dst) = q1;
+                *reinterpret_cast<u32x2_t*>(dst + D2_PIECE) = q2;
+                *reinterpret_cast<u32x2_t*>(dst + 2 * D2_PIECE) = q3;
+            }
         }
         const float4 xv = xnx, dyv = dyn;
         const float mu = quad_sum((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / E);
@@ -156,11 +176,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         {
             const float yv[4] = {xh[0] * lng.x + lnb.x, xh[1] * lng.y + lnb.y, xh[2] * lng.z + lnb.z, xh[3] * lng.w + lnb.w};
             u32x2_t q1, q2, q3;
-            split3_x4(yv, q1, q2, q3);
+            split_x4<NP>(yv, q1, q2, q3);
             uint16_t* dst = XN + lpx * E + 4 * lq;
             *reinterpret_cast<u32x2_t*>(dst) = q1;
-            *reinterpret_cast<u32x2_t*>(dst + XN_PIECE) = q2;
-            *reinterpret_cast<u32x2_t*>(dst + 2 * XN_PIECE) = q3;
+            if (NP == 3) {
+                *reinterpret_cast<u32x2_t*>(dst + XN_PIECE) = q2;
+                *reinterpret_cast<u32x2_t*>(dst + 2 * XN_PIECE) = q3;
+            }
         }
         if (tile + (long)gridDim.x < ntiles) issue(tile + gridDim.x);   // next tile's operands: in flight during the GEMM phase
         STAMP(1);
@@ -178,18 +200,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             s16x4_t xa[3];
             {
                 const uint16_t* p = XN + (pbk * 16 + r) * E + 4 * g;
-                xa[0] = lds_x4(p); xa[1] = lds_x4(p + XN_PIECE); xa[2] = lds_x4(p + 2 * XN_PIECE);
+                xa[0] = lds_x4(p);
+                if (NP == 3) { xa[1] = lds_x4(p + XN_PIECE); xa[2] = lds_x4(p + 2 * XN_PIECE); } else { xa[1] = xa[0]; xa[2] = xa[0]; }
             }
             const uint16_t* pd = D2 + (pbk * 16 + r) * LDP + 8 * g;
-            const bf16x8_t d0[3] = {lds_x8(pd), lds_x8(pd + D2_PIECE), lds_x8(pd + 2 * D2_PIECE)};
-            const bf16x8_t d1[3] = {lds_x8(pd + 32), lds_x8(pd + 32 + D2_PIECE), lds_x8(pd + 32 + 2 * D2_PIECE)};
+            bf16x8_t d0[3], d1[3];
+            d0[0] = lds_x8(pd); d1[0] = lds_x8(pd + 32);
+            if (NP == 3) { d0[1] = lds_x8(pd + D2_PIECE); d0[2] = lds_x8(pd + 2 * D2_PIECE); d1[1] = lds_x8(pd + 32 + D2_PIECE); d1[2] = lds_x8(pd + 32 + 2 * D2_PIECE); }
+            else { d0[1] = d0[0]; d0[2] = d0[0]; d1[1] = d1[0]; d1[2] = d1[0]; }
             KB_FENCE();
             // ---- h1[px 4 g + v][ch 16 w + r] = LN(x) W1^T + b1 ; da1 = dh2 W2 (K = 64 as two 32-deep blocks)
             f32x4_t h1 = (f32x4_t){b1s, b1s, b1s, b1s};
-            mfma6_16(h1, xa, w1f.p);
+            mfmaN_16<NP>(h1, xa, w1f.p);
             f32x4_t da = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            mfma6_32(da, d0, w2f0.p);
-            mfma6_32(da, d1, w2f1.p);
+            mfmaN_32<NP>(da, d0, w2f0.p);
+            mfmaN_32<NP>(da, d1, w2f1.p);
             KB_FENCE();
             // ---- gelu(h1), gelu'(h1) with one exponential for both; dh1 = da1 * gelu'(h1); pieces; the column reads of the weight-gradient operands
             lg_v2f a01, a23, g01, g23;
@@ -199,33 +224,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             const float d1v[4] = {da[0] * g01.x, da[1] * g01.y, da[2] * g23.x, da[3] * g23.y};
             bs1 += (d1v[0] + d1v[1]) + (d1v[2] + d1v[3]);
             s16x4_t a1p[3], d1p[3];
-            split4(a1v, a1p);
-            split4(d1v, d1p);
+            split4<NP>(a1v, a1p);
+            split4<NP>(d1v, d1p);
             const uint16_t* px = XN + (pbk * 16 + 4 * g + (r >> 2)) * E + 4 * (r & 3);
-            const s16x4_t xt[3] = {lds_tr4(px), lds_tr4(px + XN_PIECE), lds_tr4(px + 2 * XN_PIECE)};
+            s16x4_t xt[3];
+            xt[0] = lds_tr4(px);
+            if (NP == 3) { xt[1] = lds_tr4(px + XN_PIECE); xt[2] = lds_tr4(px + 2 * XN_PIECE); } else { xt[1] = xt[0]; xt[2] = xt[0]; }
             const uint16_t* pt = D2 + (pbk * 16 + 4 * g + (r >> 2)) * LDP + 4 * (r & 3);
             s16x4_t dt[4][3];
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) { dt[nb][0] = lds_tr4(pt + 16 * nb); dt[nb][1] = lds_tr4(pt + 16 * nb + D2_PIECE); dt[nb][2] = lds_tr4(pt + 16 * nb + 2 * D2_PIECE); }
+            for (int nb = 0; nb < 4; ++nb) {
+                dt[nb][0] = lds_tr4(pt + 16 * nb);
+                if (NP == 3) { dt[nb][1] = lds_tr4(pt + 16 * nb + D2_PIECE); dt[nb][2] = lds_tr4(pt + 16 * nb + 2 * D2_PIECE); } else { dt[nb][1] = dt[nb][0]; dt[nb][2] = dt[nb][0]; }
+            }
             KB_FENCE();
             // ---- dW1[16 w + .][.] += dh1^T LN(x) (A = dh1 from the registers, B = LN(x) read by columns);
             //      dW2[.][16 w + .] += dh2^T gelu(h1) (A = dh2 read by columns, B = gelu(h1) from the registers)
-            mfma6_16(acc1, d1p, xt);
+            mfmaN_16<NP>(acc1, d1p, xt);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) mfma6_16(acc2[nb], dt[nb], a1p);
+            for (int nb = 0; nb < 4; ++nb) mfmaN_16<NP>(acc2[nb], dt[nb], a1p);
             KB_FENCE();
             // this wave's K = 16 slice of W1^T dh1: dh1 -> [channel][pixel] in the wave's own LDS region, read back by columns as the B operand
             {
                 uint16_t* dst = D1T + r * 16 + 4 * g;
                 *reinterpret_cast<u32x2_t*>(dst) = __builtin_bit_cast(u32x2_t, d1p[0]);
-                *reinterpret_cast<u32x2_t*>(dst + D1T_PIECE) = __builtin_bit_cast(u32x2_t, d1p[1]);
-                *reinterpret_cast<u32x2_t*>(dst + 2 * D1T_PIECE) = __builtin_bit_cast(u32x2_t, d1p[2]);
+                if (NP == 3) {
+                    *reinterpret_cast<u32x2_t*>(dst + D1T_PIECE) = __builtin_bit_cast(u32x2_t, d1p[1]);
+                    *reinterpret_cast<u32x2_t*>(dst + 2 * D1T_PIECE) = __builtin_bit_cast(u32x2_t, d1p[2]);
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const uint16_t* p = D1T + (4 * g + (r >> 2)) * 16 + 4 * (r & 3);
-                const s16x4_t dtp[3] = {lds_tr4(p), lds_tr4(p + D1T_PIECE), lds_tr4(p + 2 * D1T_PIECE)};
+                s16x4_t dtp[3];
+                dtp[0] = lds_tr4(p);
+                if (NP == 3) { dtp[1] = lds_tr4(p + D1T_PIECE); dtp[2] = lds_tr4(p + 2 * D1T_PIECE); } else { dtp[1] = dtp[0]; dtp[2] = dtp[0]; }
                 f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                mfma6_16(o, w1tf.p, dtp);             // o[v] = (W1^T dh1)[out channel 4 g + v][pixel r], hidden channels 16 w .. 16 w + 15 only
+                mfmaN_16<NP>(o, w1tf.p, dtp);             // o[v] = (W1^T dh1)[out channel 4 g + v][pixel r], hidden channels 16 w .. 16 w + 15 only
                 __builtin_amdgcn_wave_barrier();      // D1T is rewritten by the next pixel block
                 *reinterpret_cast<float4*>(red + ((size_t)wave * NPX + pbk * 16 + r) * E + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
             }
@@ -296,13 +330,15 @@ int launch_ffn1_bwd_xs(const Ffn1BwdXArgs& a, hipStream_t s) {
     if (!a.dh2 || !a.x || !a.dy || !a.dx || !a.slab || !a.w1 || !a.w1t || !a.w2t || !a.b1 || !a.ln2g || !a.ln2b) { lg_set_error("ffn1_bwd_xs: null argument"); return -2; }
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn1_bwd_xs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn1_bwd_xs<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1_bwd_xs<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) { lg_set_error("ffn1_bwd_xs: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
     const long ntiles = a.P / NPX;
     const int grid = (int)(ntiles < FFN1_BWD_WGS ? ntiles : FFN1_BWD_WGS);
-    k_ffn1_bwd_xs<<<grid, 256, LDS_BYTES, s>>>(a, ntiles);
+    if (a.hbf) k_ffn1_bwd_xs<1><<<grid, 256, LDS_BYTES, s>>>(a, ntiles);      // precision = 'bf16': plain bf16 operands, dh2 stored as bf16
+    else k_ffn1_bwd_xs<3><<<grid, 256, LDS_BYTES, s>>>(a, ntiles);
     LG_CHECK_LAUNCH();
     // the slab rows, summed in a fixed order by the deferred reduce launch
     ReduceJob j;

@@ -17,6 +17,7 @@
 #include "kernels.h"
 #include "bwd_kernels.h"
 #include "split_bf16.h"
+#include "hstore.h"
 
 // In-kernel phase stamps (diagnostic build only, -DLG_STAMPS: tools/build_stamps.sh + tools/bwd_stamps.py)
 #ifdef LG_STAMPS
@@ -53,7 +54,16 @@ __device__ __forceinline__ void mfma6_16(f32x4_t& acc, const s16x4_t (&a)[3], co
     acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[0], acc, 0, 0, 0);
 }
 
+template <int NP>
+__device__ __forceinline__ void mfmaN_16(f32x4_t& acc, const s16x4_t (&a)[3], const s16x4_t (&b)[3]) {
+    if (NP == 3) mfma6_16(acc, a, b);
+    else acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[0], acc, 0, 0, 0);
+}
+
+// NP = 3: fp32 storage of h2 / h3 / dh2, fp32-equivalent split products; NP = 1 (precision = 'bf16'): bf16 storage (hstore.h), plain bf16 products
+template <int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn_dw_bwd_xs(FfnDwBwdXArgs a, int tiles_x, int strips_y, int nstrips, int SH) {
+    constexpr bool BF = (NP == 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* ring = reinterpret_cast<float*>(smem_raw);                          // [RING*HX][LDR] dh3
     uint16_t* DY = reinterpret_cast<uint16_t*>(smem_raw + OFF_DY);             // [2][3][CH][E]
@@ -61,7 +71,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     uint16_t* A3 = reinterpret_cast<uint16_t*>(smem_raw + OFF_A3) + wave * 3 * A3_PIECE;   // [3][48 px][16 ch] of this wave
     const int h = a.h, w = a.w;
     const int c0 = wave * 16 + 4 * g;                 // first of the lane's four hidden channels after the GEMM
-    const WFrag16 w3f = load_wfrag16(a.w3t + (size_t)(wave * 16) * E, E, 0);   // W3^T rows [16 w, 16 w + 16)
+    const WFrag16 w3f = NP == 3 ? load_wfrag16(a.w3t + (size_t)(wave * 16) * E, E, 0) : load_wfrag16_rne(a.w3t + (size_t)(wave * 16) * E, E, 0);   // W3^T rows [16 w, 16 w + 16)
     const int q = lane % CQ;                          // P2: lane = (pixel slot lane / 16, channel quad q)
     const int lpx = threadIdx.x >> 2, lq = threadIdx.x & 3;                    // dy role: thread t < 192 = (chunk pixel t / 4, channel quad t % 4)
     const bool dy_thread = threadIdx.x < 4 * CH;
@@ -103,30 +113,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         if (!dy_thread) return;          // wave 3 holds no dy vectors
         const float v[4] = {dv.x, dv.y, dv.z, dv.w};
         u32x2_t q1, q2, q3;
-        split3_x4(v, q1, q2, q3);
+        split_x4<NP>(v, q1, q2, q3);
         uint16_t* dst = DY + slot * DY_SLOT + lpx * E + 4 * lq;
         *reinterpret_cast<u32x2_t*>(dst) = q1;
-        *reinterpret_cast<u32x2_t*>(dst + DY_PIECE) = q2;
-        *reinterpret_cast<u32x2_t*>(dst + 2 * DY_PIECE) = q3;
+        if (NP == 3) {
+            *reinterpret_cast<u32x2_t*>(dst + DY_PIECE) = q2;
+            *reinterpret_cast<u32x2_t*>(dst + 2 * DY_PIECE) = q3;
+        }
     };
     // h3 of the lane's pixel / channels in chunk c.  No mask: outside the image dy = 0 makes dh3 = 0 whatever gelu'(h3) is, and gelu(h3)
     // enters dW3 only for the strip's own pixels
-    auto h3_fetch = [&](int ya, int c, float4 (&hv)[3]) {
+    auto h3_fetch = [&](int ya, int c, typename HS<BF>::raw4 (&hv)[3]) {
 #pragma unroll
         for (int pb = 0; pb < 3; ++pb) {
             const int m = c * CH + pb * 16 + r;
             const int hy = m / HX, hx = m - hy * HX;
             const int y = clampi(ya + hy, 0, h - 1), x = clampi(x0 + hx - 1, 0, w - 1);
-            hv[pb] = *reinterpret_cast<const float4*>(a.h3 + ((b * h + y) * (long)w + x) * N1 + c0);
+            hv[pb] = HS<BF>::ldraw(a.h3, ((b * h + y) * (long)w + x) * N1 + c0);
         }
     };
 
     // dh3 of halo rows [ya, ya + nr) x columns [x0 - 1, x0 + 17) -> ring (nr = 2: strip prologue, 8: one step)
     // in_last: run at the top of the LAST chunk, where no next-chunk operands are in flight (registers and load slots are free)
     // pre / pre_in / pre_own, h3c: chunk 0's dy vector and h3 vectors, requested by the caller ahead of time
-    auto compute_rows = [&](int ya, int nr, float4 pre, bool pre_in, bool pre_own, float4 (&h3c)[3], auto&& in_last) {
+    auto compute_rows = [&](int ya, int nr, float4 pre, bool pre_in, bool pre_own, typename HS<BF>::raw4 (&h3c)[3], auto&& in_last) {
         const int npx = nr * HX, nchunks = (npx + CH - 1) / CH;
-        float4 h3n[3];
+        typename HS<BF>::raw4 h3n[3];
         dy_store(0, pre, pre_in, pre_own);
         STAMP(1);
         __syncthreads();                 // also: the previous phase (P2) is done reading the ring rows this call overwrites
@@ -150,12 +162,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
                 {
                     const uint16_t* p = dyb + (pb * 16 + r) * E + 4 * g;
-                    const s16x4_t xb[3] = {lds_x4(p), lds_x4(p + DY_PIECE), lds_x4(p + 2 * DY_PIECE)};
-                    mfma6_16(acc, w3f.p, xb);
+                    s16x4_t xb[3];
+                    xb[0] = lds_x4(p);
+                    if (NP == 3) { xb[1] = lds_x4(p + DY_PIECE); xb[2] = lds_x4(p + 2 * DY_PIECE); } else { xb[1] = xb[0]; xb[2] = xb[0]; }
+                    mfmaN_16<NP>(acc, w3f.p, xb);
                 }
                 lg_v2f a01, a23, g01, g23;
-                gelu2_both_f((lg_v2f){h3c[pb].x, h3c[pb].y}, a01, g01);
-                gelu2_both_f((lg_v2f){h3c[pb].z, h3c[pb].w}, a23, g23);
+                const float4 h3v = HS<BF>::widen(h3c[pb]);
+                gelu2_both_f((lg_v2f){h3v.x, h3v.y}, a01, g01);
+                gelu2_both_f((lg_v2f){h3v.z, h3v.w}, a23, g23);
                 // dh3 (0 outside the image: dy is 0 there) -> ring
                 int rp = ring0 + m;
                 rp = rp >= RING * HX ? rp - RING * HX : rp;
@@ -164,11 +179,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 const float mk = own ? 1.0f : 0.0f;
                 const float av[4] = {a01.x * mk, a01.y * mk, a23.x * mk, a23.y * mk};
                 u32x2_t q1, q2, q3;
-                split3_x4(av, q1, q2, q3);
+                split_x4<NP>(av, q1, q2, q3);
                 uint16_t* dst = A3 + (pb * 16 + r) * 16 + 4 * g;
                 *reinterpret_cast<u32x2_t*>(dst) = q1;
-                *reinterpret_cast<u32x2_t*>(dst + A3_PIECE) = q2;
-                *reinterpret_cast<u32x2_t*>(dst + 2 * A3_PIECE) = q3;
+                if (NP == 3) {
+                    *reinterpret_cast<u32x2_t*>(dst + A3_PIECE) = q2;
+                    *reinterpret_cast<u32x2_t*>(dst + 2 * A3_PIECE) = q3;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -176,10 +193,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int pb = 0; pb < 3; ++pb) {
                 const uint16_t* pa = dyb + (pb * 16 + 4 * g + (r >> 2)) * E + 4 * (r & 3);
-                const s16x4_t dt[3] = {lds_tr4(pa), lds_tr4(pa + DY_PIECE), lds_tr4(pa + 2 * DY_PIECE)};
                 const uint16_t* pbp = A3 + (pb * 16 + 4 * g + (r >> 2)) * 16 + 4 * (r & 3);
-                const s16x4_t at[3] = {lds_tr4(pbp), lds_tr4(pbp + A3_PIECE), lds_tr4(pbp + 2 * A3_PIECE)};
-                mfma6_16(acc3, dt, at);
+                s16x4_t dt[3], at[3];
+                dt[0] = lds_tr4(pa); at[0] = lds_tr4(pbp);
+                if (NP == 3) { dt[1] = lds_tr4(pa + DY_PIECE); dt[2] = lds_tr4(pa + 2 * DY_PIECE); at[1] = lds_tr4(pbp + A3_PIECE); at[2] = lds_tr4(pbp + 2 * A3_PIECE); }
+                else { dt[1] = dt[0]; dt[2] = dt[0]; at[1] = at[0]; at[2] = at[0]; }
+                mfmaN_16<NP>(acc3, dt, at);
             }
             if (more) {
                 dy_store(slot ^ 1, ndv, nin, nown);
@@ -192,13 +211,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         }
     };
 
-    float4 pre, h3p[3];
+    float4 pre;
+    typename HS<BF>::raw4 h3p[3];
     bool pin, pown;
     dy_fetch(Y0 - 1, 2 * HX, 0, pre, pin, pown);
     h3_fetch(Y0 - 1, 0, h3p);
     // the first step's chunk-0 operands are requested at the top of the prologue's only chunk, the next step's before P2 (below): an HBM
     // round trip under a whole phase instead of in front of it
-    float4 npre, nh3[3];
+    float4 npre;
+    typename HS<BF>::raw4 nh3[3];
     bool npin = false, npown = false;
     compute_rows(Y0 - 1, 2, pre, pin, pown, h3p, [&] { dy_fetch(Y0 + 1, TY * HX, 0, npre, npin, npown); h3_fetch(Y0 + 1, 0, nh3); });
 #pragma unroll 1
@@ -213,9 +234,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         // image (launcher: h % 8 == 0, w % 16 == 0).
         auto h2_fetch = [&](int i) {
             const int y = y0 + 2 * wave + (i >> 2), x = x0 + (lane >> 4) + 4 * (i & 3);
-            return *reinterpret_cast<const float4*>(a.h2 + ((b * h + y) * (long)w + x) * N1 + 4 * q);
+            return HS<BF>::ldraw(a.h2, ((b * h + y) * (long)w + x) * N1 + 4 * q);
         };
-        float4 h2a, h2b, h2c, h2d;
+        typename HS<BF>::raw4 h2a, h2b, h2c, h2d;
         pre = npre; pin = npin; pown = npown;
 #pragma unroll
         for (int pb = 0; pb < 3; ++pb) h3p[pb] = nh3[pb];
@@ -245,13 +266,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         const int sbase = (y0 - Y0) % RING;            // ring slot of row y0 - 1
         // one output pixel quad: hreg holds its h2 vector and is re-loaded with the vector of the item four places on (no register
         // rotation: a rotating set needs its moves in front of the loop's back edge, i.e. a wait for the load issued in the same iteration)
-        auto item = [&](int ch, int it, float4& hreg) {
+        auto item = [&](int ch, int it, typename HS<BF>::raw4& hreg) {
             const int ty = 2 * wave + ch, tx = (lane >> 4) + 4 * it;
             const int y = y0 + ty, x = x0 + tx;
-            const float4 hc = hreg;
+            const float4 hc = HS<BF>::widen(hreg);
             {
                 const int yn = y0 + 2 * wave + 1;      // ch = 0: the same pixel column one tile row down; ch = 1: the repeat is an L2 hit nobody waits for
-                hreg = *reinterpret_cast<const float4*>(a.h2 + ((b * h + yn) * (long)w + x) * N1 + 4 * q);
+                hreg = HS<BF>::ldraw(a.h2, ((b * h + yn) * (long)w + x) * N1 + 4 * q);
             }
             const lg_v2f h01 = (lg_v2f){hc.x, hc.y}, h23 = (lg_v2f){hc.z, hc.w};
             lg_v2f acc01 = (lg_v2f){0.f, 0.f}, acc23 = (lg_v2f){0.f, 0.f};
@@ -271,7 +292,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     if (dy == 1 && dx == 1) { pw01[9] += g01; pw23[9] += g23; }
                 }
             }
-            *reinterpret_cast<float4*>(a.dh2 + ((b * h + y) * (long)w + x) * N1 + 4 * q) = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
+            HS<BF>::st4(a.dh2, ((b * h + y) * (long)w + x) * N1 + 4 * q, make_float4(acc01.x, acc01.y, acc23.x, acc23.y));
             __builtin_amdgcn_sched_barrier(0);      // one item at a time: interleaved items need more registers than there are
         };
 #pragma unroll 1
@@ -331,7 +352,8 @@ int launch_ffn_dw_bwd_xs(const FfnDwBwdXArgs& a, hipStream_t s) {
     if (!a.dy || !a.h3 || !a.h2 || !a.dh2 || !a.w3t || !a.dww || !a.slab) { lg_set_error("ffn_dw_bwd_xs: null argument"); return -2; }
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd_xs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd_xs<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd_xs<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) { lg_set_error("ffn_dw_bwd_xs: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
@@ -343,7 +365,8 @@ int launch_ffn_dw_bwd_xs(const FfnDwBwdXArgs& a, hipStream_t s) {
     const int strips_y = (a.h + SH - 1) / SH;
     const int nstrips = a.B * tiles_x * strips_y;
     const int grid = nstrips < FFN_DW_BWD_X_WGS ? nstrips : FFN_DW_BWD_X_WGS;
-    k_ffn_dw_bwd_xs<<<grid, 256, LDS_BYTES, s>>>(a, tiles_x, strips_y, nstrips, SH);
+    if (a.hbf) k_ffn_dw_bwd_xs<1><<<grid, 256, LDS_BYTES, s>>>(a, tiles_x, strips_y, nstrips, SH);   // precision = 'bf16'
+    else k_ffn_dw_bwd_xs<3><<<grid, 256, LDS_BYTES, s>>>(a, tiles_x, strips_y, nstrips, SH);
     LG_CHECK_LAUNCH();
     ReduceJob j;
     j.dst2 = nullptr; j.nslices = grid; j.slice_stride = FFN_DW_BWD_X_ROW;

@@ -406,6 +406,7 @@ int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) { lg_set_error("ffn_xs: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
@@ -420,9 +421,11 @@ int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     const bool pre = save && a1.g1s == nullptr;   // pre-activation saves (h1 in a1s, h3 in a3s)
     const bool noh1 = pre && a1.a1s == nullptr;   // ... without h1 (the backward re-computes it)
     if (save && !pre && !a1.a1s) { lg_set_error("ffn_xs: the five-tensor save needs the gelu(h1) slot"); return -2; }
-    if (pre && (a1.hbf || !a2.a3s || a2.g3s)) { lg_set_error("ffn_xs: pre-activation saves need fp32 storage and h2 / h3 slots"); return -2; }
+    if (pre && (!a2.a3s || a2.g3s)) { lg_set_error("ffn_xs: pre-activation saves need the h2 / h3 slots"); return -2; }
+    if (pre && a1.hbf && !noh1) { lg_set_error("ffn_xs: bf16 storage keeps h2 / h3 (mode 2) or the five tensors (mode 5)"); return -2; }
     if (a1.hbf) {   // precision = 'bf16': plain bf16 operands, bf16 storage of the saved tensors
-        if (save) k_ffn_xs<1, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+        if (noh1) k_ffn_xs<3, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+        else if (save) k_ffn_xs<1, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
         else k_ffn_xs<0, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
     } else if (noh1) k_ffn_xs<3, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
     else if (pre) k_ffn_xs<2, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
