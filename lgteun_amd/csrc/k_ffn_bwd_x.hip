@@ -86,10 +86,27 @@ __device__ __forceinline__ void mfma6_32(f32x4_t& acc, const bf16x8_t (&a)[3], c
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
 }
+__device__ __forceinline__ bf16x8_t cat8(s16x4_t lo, s16x4_t hi) {
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// The six piece products of a 16-deep block as THREE 32-deep MFMAs: two piece products share one instruction, their operands
+// concatenated along K (slots 0..3 of a lane = one piece pair, 4..7 = another; both operands use the same order, and any order of K is a
+// sum).  v_mfma_f32_16x16x16_bf16 costs the matrix pipe what the 32-deep form costs (16 busy cycles each, profiles/r03_sq_counters_*),
+// so this halves the pipe time of every K = 16 product: a1 b3 + a3 b1 | a2 b2 + a2 b1 | a1 b2 + a1 b1   (small terms first).
+#ifndef LG_KB_PAIR
+#define LG_KB_PAIR 1
+#endif
+__device__ __forceinline__ void mfma3_16(f32x4_t& acc, const s16x4_t (&a)[3], const s16x4_t (&b)[3]) {
+    const bf16x8_t b31 = cat8(b[2], b[0]), b21 = cat8(b[1], b[0]);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(a[0], a[2]), b31, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(a[1], a[1]), b21, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(a[0], a[0]), b21, acc, 0, 0, 0);
+}
 // NP = 3: the six piece products (fp32-equivalent); NP = 1 (precision = 'bf16'): one product of round-to-nearest bf16 operands
 template <int NP>
 __device__ __forceinline__ void mfmaN_16(f32x4_t& acc, const s16x4_t (&a)[3], const s16x4_t (&b)[3]) {
-    if (NP == 3) mfma6_16(acc, a, b);
+    if (NP == 3) { if (LG_KB_PAIR) mfma3_16(acc, a, b); else mfma6_16(acc, a, b); }
     else acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[0], acc, 0, 0, 0);
 }
 template <int NP>

@@ -54,9 +54,20 @@ __device__ __forceinline__ void mfma6_16(f32x4_t& acc, const s16x4_t (&a)[3], co
     acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[0], acc, 0, 0, 0);
 }
 
+__device__ __forceinline__ bf16x8_t cat8(s16x4_t lo, s16x4_t hi) {
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// the six piece products as three 32-deep MFMAs, two products per instruction (k_ffn_bwd_x.hip: mfma3_16)
+__device__ __forceinline__ void mfma3_16(f32x4_t& acc, const s16x4_t (&a)[3], const s16x4_t (&b)[3]) {
+    const bf16x8_t b31 = cat8(b[2], b[0]), b21 = cat8(b[1], b[0]);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(a[0], a[2]), b31, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(a[1], a[1]), b21, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(a[0], a[0]), b21, acc, 0, 0, 0);
+}
 template <int NP>
 __device__ __forceinline__ void mfmaN_16(f32x4_t& acc, const s16x4_t (&a)[3], const s16x4_t (&b)[3]) {
-    if (NP == 3) mfma6_16(acc, a, b);
+    if (NP == 3) mfma3_16(acc, a, b);
     else acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[0], acc, 0, 0, 0);
 }
 

@@ -110,7 +110,26 @@ __device__ __forceinline__ void mfma_split32(f32x4_t& acc, const WFrag32& w, bf1
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[1], x1, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[0], x1, acc, 0, 0, 0);
 }
+// K = 16 blocks: v_mfma_f32_16x16x16_bf16 costs the matrix pipe what the 32-deep form costs (16 busy cycles each), so two piece products
+// share one 32-deep instruction, their operands concatenated along K:  w1 x3 + w3 x1 | w2 x2 + w2 x1 | w1 x2 + w1 x1  (small terms first)
+#ifndef LG_SPLIT16_PAIR
+#define LG_SPLIT16_PAIR 1
+#endif
+__device__ __forceinline__ bf16x8_t sb_cat8(s16x4_t lo, s16x4_t hi) {
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ void mfma_split16_pair(f32x4_t& acc, const WFrag16& w, s16x4_t x1, s16x4_t x2, s16x4_t x3) {
+    const bf16x8_t x31 = sb_cat8(x3, x1), x21 = sb_cat8(x2, x1);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_cat8(w.p[0], w.p[2]), x31, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_cat8(w.p[1], w.p[1]), x21, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb_cat8(w.p[0], w.p[0]), x21, acc, 0, 0, 0);
+}
 __device__ __forceinline__ void mfma_split16(f32x4_t& acc, const WFrag16& w, s16x4_t x1, s16x4_t x2, s16x4_t x3) {
+#if LG_SPLIT16_PAIR
+    mfma_split16_pair(acc, w, x1, x2, x3);
+    return;
+#endif
     acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.p[0], x3, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.p[2], x1, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.p[1], x2, acc, 0, 0, 0);
