@@ -13,7 +13,7 @@
 // GEMM (W3^T dy): weights on the A side, pixels on the B side, wave w = hidden channels [16 w, 16 w + 16): a lane holds four
 // consecutive channels of one pixel, so h3 arrives and dh3 leaves as 16-byte accesses.  dW3: the pixel axis is the K dimension; dy^T
 // is read by columns from the chunk's dy image (ds_read_b64_tr_b16), gelu(h3) goes through a 4.5 KB per-wave [pixel][channel] image of the chunk.
-// LDS 77 KB (two workgroups per CU): ring [10][18][68] fp32 | dy pieces [2][3][48][16] bf16 | per-wave gelu(h3) pieces [4][3][48][16].
+// LDS 79 KB (two workgroups per CU): ring [10][18][68] fp32 | dy pieces [2][3][48][16] bf16 | per-wave gelu(h3) pieces [4][3][48][16] | depthwise taps [64][9] fp32.
 #include "kernels.h"
 #include "bwd_kernels.h"
 #include "split_bf16.h"
@@ -38,8 +38,9 @@ constexpr int DY_SLOT = 3 * DY_PIECE;
 constexpr int A3_PIECE = CH * 16;            // halves, per wave and piece: the chunk's 48 pixels x the wave's 16 channels
 constexpr size_t OFF_DY = (size_t)RING * HX * LDR * 4;
 constexpr size_t OFF_A3 = OFF_DY + (size_t)2 * DY_SLOT * 2;
-constexpr size_t LDS_BYTES = OFF_A3 + (size_t)4 * 3 * A3_PIECE * 2;
-static_assert(OFF_DY % 16 == 0 && OFF_A3 % 16 == 0, "16-byte aligned LDS regions");
+constexpr size_t OFF_TAPS = OFF_A3 + (size_t)4 * 3 * A3_PIECE * 2;
+constexpr size_t LDS_BYTES = OFF_TAPS + (size_t)N1 * 9 * 4;
+static_assert(OFF_DY % 16 == 0 && OFF_A3 % 16 == 0 && OFF_TAPS % 16 == 0, "16-byte aligned LDS regions");
 static_assert((size_t)(4 * CQ * 40 + 4 * E) * 4 <= OFF_DY, "the end-of-kernel reduction rows alias the ring");
 
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
@@ -58,6 +59,9 @@ __device__ __forceinline__ bf16x8_t cat8(s16x4_t lo, s16x4_t hi) {
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
     return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
+#ifndef LG_KA_PAIR
+#define LG_KA_PAIR 0   // measured in THIS kernel (VALU / LDS bound, matrix pipe 10 % busy): the operand concatenation costs 133.7 vs 119.5 us per launch; off
+#endif
 // the six piece products as three 32-deep MFMAs, two products per instruction (k_ffn_bwd_x.hip: mfma3_16)
 __device__ __forceinline__ void mfma3_16(f32x4_t& acc, const s16x4_t (&a)[3], const s16x4_t (&b)[3]) {
     const bf16x8_t b31 = cat8(b[2], b[0]), b21 = cat8(b[1], b[0]);
@@ -67,7 +71,7 @@ __device__ __forceinline__ void mfma3_16(f32x4_t& acc, const s16x4_t (&a)[3], co
 }
 template <int NP>
 __device__ __forceinline__ void mfmaN_16(f32x4_t& acc, const s16x4_t (&a)[3], const s16x4_t (&b)[3]) {
-    if (NP == 3) mfma3_16(acc, a, b);
+    if (NP == 3) { if (LG_KA_PAIR) mfma3_16(acc, a, b); else mfma6_16(acc, a, b); }
     else acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[0], acc, 0, 0, 0);
 }
 
@@ -87,6 +91,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int lpx = threadIdx.x >> 2, lq = threadIdx.x & 3;                    // dy role: thread t < 192 = (chunk pixel t / 4, channel quad t % 4)
     const bool dy_thread = threadIdx.x < 4 * CH;
 
+    // the depthwise taps [64][9], once per workgroup in LDS: re-read per step from there (from L1 / L2 the wait for them sat behind every
+    // HBM load in flight -- one in-order counter -- 1.9 k ticks of a 24 k-tick step, profiles/r03_ffn_bwd_phase_stamps.txt)
+    float* sTaps = reinterpret_cast<float*>(smem_raw + OFF_TAPS);
+    for (int i = threadIdx.x; i < N1 * 9; i += 256) sTaps[i] = a.dww[i];
     // gradient partials of the depthwise taps / bias of the lane's four P2 channels, as channel PAIRS (v_pk_fma_f32)
     lg_v2f pw01[10], pw23[10];
 #pragma unroll
@@ -252,12 +260,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int pb = 0; pb < 3; ++pb) h3p[pb] = nh3[pb];
         compute_rows(y0 + 1, TY, pre, pin, pown, h3p, [&] { h2a = h2_fetch(0); h2b = h2_fetch(1); h2c = h2_fetch(2); h2d = h2_fetch(3); });
-        // the depthwise taps of the lane's four channels as channel pairs: 36 contiguous floats, re-read (L1 / L2 hits) per step instead of
-        // pinning 36 VGPRs through the halo pass
+        // the depthwise taps of the lane's four channels as channel pairs: 36 contiguous floats from LDS per step instead of 36 VGPRs pinned
+        // through the halo pass
         lg_v2f wq01[9], wq23[9];
         {
-            const float* tp = a.dww + 36 * q;
-            asm volatile("" : "+v"(tp));            // keep the loads inside the step loop
+            const float* tp = sTaps + 36 * q;
             float t36[36];
 #pragma unroll
             for (int k4 = 0; k4 < 9; ++k4) {
@@ -267,9 +274,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int k = 0; k < 9; ++k) { wq01[k] = (lg_v2f){t36[k], t36[9 + k]}; wq23[k] = (lg_v2f){t36[18 + k], t36[27 + k]}; }
         }
-        // ---- P2: dh2 = dw^T dh3 and the depthwise weight / bias gradient partials
-        // next step's chunk-0 operands (clamped addresses: harmless behind the strip's last step), requested BEHIND the taps and the first
-        // h2 vectors: the wait counter is in-order, a wait for the taps would otherwise wait for these HBM loads as well
+        // next step's chunk-0 operands (clamped addresses: harmless behind the strip's last step), requested BEHIND the first h2 vectors: the
+        // wait counter is in-order
         __builtin_amdgcn_sched_barrier(0);
         dy_fetch(y0 + TY + 1, TY * HX, 0, npre, npin, npown);
         h3_fetch(y0 + TY + 1, 0, nh3);
