@@ -3,13 +3,11 @@
 k_ffn_strip<SAVE>, the e=32 fused FFN and the e=64 pair with their backwards), BASELINE configs[4]'s shape (C=8, 256x256 PAN,
 K=8: split-FFT forward AND backward) and two PAN sizes that are not powers of two (Bluestein mixer; pinned directly against the
 reference, not through the oracle).  Plus the two-call backward the data-parallel step uses.  Dropout off."""
-import re
-
 import numpy as np
 import pytest
 import torch
 
-from conftest import load_gold
+from conftest import GOLD, load_gold
 from helpers import rel_l2
 from oracle import detweights as dw
 
@@ -55,20 +53,32 @@ def test_train_step_vs_reference_gradients(manifest, name, mode):
     err = (num / den) ** 0.5
     # gate: global relative L2 1e-3; for scale, the reference's own fp32 gradients are m['grad_rel_fp32_vs_fp64'] off its fp64 ones
     assert err < 1e-3, (err, m['grad_rel_fp32_vs_fp64'])
-    # per tensor, on the tensor's own scale (floored at 2e-5).  Allowance: 3e-2, or 3x the reference's OWN fp32-vs-fp64 error on that
-    # tensor where that is larger (`self_err`: sums that cancel to ~1e-5 -- FFT-mixer amplitude biases -- are known to a few per cent
-    # only in the reference's fp32 itself; measured by tools/gen_goldens.py on the reference)
-    # The noise is a property of the parameter KIND, not of one tensor's single draw: the reference's fp32 conv_amp biases of this golden are
-    # 0.08 % ... 7.2 % off their fp64 values depending on the block, so a tensor's allowance uses the largest self_err among the tensors
-    # of its kind (same name with the block position stripped).  A different but equally valid fp32 summation order (e.g. the LayerNorm
-    # statistics of a producing kernel) moves these cancelling sums by that much.
-    self_err = dict(zip(sorted(grads), g['self_err']))
-    kind = lambda k: re.sub(r'^prior_module\.\d+\.((encoder_layers|decoder_layers)\.\d+\.\d+|bottleneck)\.blocks\.\d+\.', 'block.', k)
-    kind_err = {}
-    for k in grads:
-        kind_err[kind(k)] = max(kind_err.get(kind(k), 0.0), float(self_err[k]))
-    worst = max((float(np.abs(v - g[k.replace('.', '/')]).max() / max(float(np.abs(g[k.replace('.', '/')]).max()), 2e-5))
-                 / max(3e-2, 3.0 * kind_err[kind(k)]), k) for k, v in grads.items())
+    # per tensor, on the tensor's own scale (floored at 2e-5): 3e-2 against the reference's fp32 gradient -- for every tensor except the
+    # KINDS whose L1 gradients are sums that cancel to ~1e-5 of their terms (the FFT mixer's amplitude / phase biases, pos_emb): those are
+    # known to 0.1 % ... 6 % only in the reference's fp32 ITSELF, so an fp32 golden cannot tell "as noisy as the reference" from "wrong".
+    # For them the reference's fp64 gradients (tests/golden/grad64_*.npz, tools/gen_goldens.py --only-r3) are the truth, and the gate is a
+    # statement about distance to it, per kind as a relative L2 over all the kind's tensors: IN NO CASE is this build further from fp64
+    # than the reference's own fp32 is in ITS worst case of the five goldens (profiles/r03_grad_vs_fp64.txt: in three of the five cases
+    # this build is 1.2 ... 8 x closer to fp64 than the reference's fp32, in grad_c8_k4_p128 the reference's fp32 happens to be 9 ... 40 x
+    # closer than its own typical -- the noise is a property of the kind, not of one draw).
+    kinds = ('global_mixer.conv_amp.0.bias', 'global_mixer.conv_pha.0.bias', 'local_mixer.pos_emb')
+
+    def kind_dist(case, kd, get):
+        g64c = np.load(f'{GOLD}/grad64_{case[5:]}.npz')
+        ks = [k[4:] for k in g64c.files if k.endswith(kd.replace('.', '/'))]
+        den = sum(float((g64c['g64/' + k] ** 2).sum()) for k in ks) ** 0.5
+        return sum(float(((get(k).astype(np.float64) - g64c['g64/' + k]) ** 2).sum()) for k in ks) ** 0.5 / den
+    cases = ['grad_c4_k4_p128', 'grad_c8_k4_p128', 'grad_c4_k2_p80x48', 'grad_c4_k2_p208x176', 'grad_c8_k8_p256']
+    report = {}
+    for kd in kinds:
+        ref_worst = max(kind_dist(c, kd, (lambda gc: (lambda k: gc[k]))(load_gold(c))) for c in cases)
+        ours = kind_dist(name, kd, lambda k: grads[k.replace('/', '.')])
+        ref_here = kind_dist(name, kd, lambda k: g[k])
+        report[kd] = (ours, ref_here, ref_worst)
+        assert ours <= ref_worst, (kd, ours, ref_here, ref_worst)
+    print(name, mode, {k: tuple(f'{v:.2e}' for v in r) for k, r in report.items()})
+    worst = max((float(np.abs(v - g[k.replace('.', '/')]).max() / max(float(np.abs(g[k.replace('.', '/')]).max()), 2e-5)) / 3e-2, k)
+                for k, v in grads.items() if not k.endswith(kinds))
     assert worst[0] < 1.0, worst
     a, b = eng.live_ranges[0][1], eng.live_ranges[1][0]
     assert float(eng.gflat[a:b].abs().max()) == 0.0            # dead-stage slots of the flat gradient buffer: never written

@@ -81,9 +81,38 @@ def round2(R, manifest):
               'grad fp32-vs-fp64', manifest[cs['name']]['grad_rel_fp32_vs_fp64'], flush=True)
 
 
+R3_KINDS = ('global_mixer.conv_amp.0.bias', 'global_mixer.conv_pha.0.bias', 'global_mixer.conv_amp.0.weight', 'global_mixer.conv_pha.0.weight',
+            'local_mixer.pos_emb')
+
+
+def round3(R, manifest):
+    """Round-3 fixtures: the reference's fp64 AND fp32 gradients of the parameter kinds whose L1 gradients are cancelling sums (the FFT
+    mixer's per-channel amplitude / phase scale + bias, pos_emb) for the five round-2 cases -> tests/golden/grad64_<case>.npz.  With them
+    the train-step test states these kinds' error as a distance to fp64 next to the reference's own fp32 distance, instead of an
+    allowance derived from the fp32 golden alone.  The round-2 files are left byte-identical."""
+    for name in ('grad_c4_k4_p128', 'grad_c8_k4_p128', 'grad_c4_k2_p80x48', 'grad_c4_k2_p208x176', 'grad_c8_k8_p256'):
+        cs = manifest[name]
+        C, K, B, h, w = cs['C'], cs['K'], cs['B'], cs['h'], cs['w']
+        ms, pan, gt = dw.make_inputs(B, C, h, w, seed=cs['seed'], kind=cs['kind'])
+        out = {}
+        for dt, tag in ((torch.float64, 'g64'), (torch.float32, 'g32')):
+            net, _ = build_ref(R, C, K, dtype=dt)
+            loss = torch.nn.L1Loss()(net(t(ms, dt), t(pan, dt)), t(gt, dt))
+            loss.backward()
+            for k, p in net.named_parameters():
+                if p.grad is not None and k.endswith(R3_KINDS):
+                    out[tag + '/' + k.replace('.', '/')] = p.grad.numpy().astype(np.float64)
+        old = np.load(os.path.join(GOLD, name + '.npz'))
+        for k in [k for k in out if k.startswith('g32/')]:       # the fp32 run is the one the round-2 file already holds
+            assert np.array_equal(out[k].astype(np.float32), old[k[4:]]), k
+        np.savez_compressed(os.path.join(GOLD, 'grad64_' + name[5:] + '.npz'), **{k: v for k, v in out.items() if k.startswith('g64/')})
+        print('grad64_' + name[5:], len([k for k in out if k.startswith('g64/')]), 'tensors', flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--check', action='store_true')
+    ap.add_argument('--only-r3', action='store_true', help='write only the round-3 fixtures (fp64 gradients of the cancelling-sum kinds)')
     ap.add_argument('--only-r2', action='store_true', help='write only the round-2 fixtures (bench-size / configs[4] / non-pow2 '
                                                             'gradients); the manifest is merged, round-1 files are left alone')
     args = ap.parse_args()
@@ -92,6 +121,11 @@ def main():
     torch.set_num_threads(8)
     R = import_reference()
     manifest = {}
+    if args.only_r3:
+        with open(os.path.join(GOLD, 'manifest.json')) as f:
+            manifest = json.load(f)
+        round3(R, manifest)
+        return
     if args.only_r2:
         with open(os.path.join(GOLD, 'manifest.json')) as f:
             manifest = json.load(f)
