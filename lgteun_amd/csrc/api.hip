@@ -218,7 +218,7 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     a1.w1 = P + pl->blk(stage, j, B_W1); a1.b1 = P + pl->blk(stage, j, B_B1);
     a1.w2 = P + pl->blk(stage, j, B_W2); a1.b2 = P + pl->blk(stage, j, B_B2);
     a1.P = (long)B * bb.h * bb.w;
-    a1.hbf = pl->cfg.precision == 1 ? 1 : 0;
+    a1.hbf = pl->hidden_bf16(bb.e) ? 1 : 0;
     a1.tile16 = pl->ffn_tile;
     a1.wsplit = wsplit;
     Ffn2Args a2;

@@ -39,6 +39,10 @@ struct lg_plan {
     // In modes 2 / 3 the tensors sit in the a1 / h2 / a3 slots (workspace.h) and the g1 / g3 slots stay unused.
     int dwbwd_tile; // A/B switch read ONCE at plan creation (env LG_FFN_DWBWD=tile): round 2's tile kernel k_ffn_dw_bwd<16> + k_wgrad_t for dW3
                     // instead of the strip-walking k_ffn_dw_bwd_xs
+    // precision = 'bf16' applies where a plain-bf16 kernel exists: e = 16 and e = 32.  The e = 64 half-blocks (level 1 of the 8-band net) have
+    // only the round-1 f32-MFMA pair in that form (436 + 372 us against 123 + 95 us for the split-bf16 k_ffn_x64 pair), so they run the
+    // default kernels with fp32 storage in both modes -- 'bf16' is never slower than the default (c3 / c5)
+    bool hidden_bf16(int e) const { return cfg.precision == 1 && e != 64; }
     // precision = 'bf16' (plain bf16 MFMA, bf16 storage of the saved tensors) knows modes 2 and 5 only (3 falls back to 5)
     bool ffn_bwd_x(int e) const { return e == 16 && ffn_tile == 0 && save_mode == 2; }   // h1 not saved; backward through k_ffn_dw_bwd_xs + k_ffn1_bwd_xs
     bool ffn_saves_preact(int e) const { return e == 16 && ffn_tile == 0 && (save_mode == 2 || (save_mode == 3 && cfg.precision == 0)); }

@@ -95,7 +95,7 @@ static int ffn_transposes(const lg_plan* pl, const float* P, int st, int j0, int
 static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int j, const BlockBufs& fb, BwdBufs& bb, const float* dy,
                         float* tmp, int B, hipStream_t s) {
     const int e = fb.e, n1 = 4 * e;
-    const int hbf = pl->cfg.precision == 1 ? 1 : 0;   // bf16 storage of the hidden / saved FFN tensors
+    const int hbf = pl->hidden_bf16(e) ? 1 : 0;       // bf16 storage of the hidden / saved FFN tensors
     const int pre = pl->ffn_saves_preact(e) ? 1 : 0;  // fb.a1 / fb.a3 hold h1 / h3 (fb.g1 / fb.g3 unused): GELU re-evaluated where needed
     const long Pn = (long)B * fb.h * fb.w;
     if (pl->ffn_bwd_x(e) && (!pl->dwbwd_tile || hbf)) {
