@@ -197,28 +197,25 @@ inline bool ffn1_bwd_fuses_w1(int e) { return e <= 32; }
 inline bool ffn1_bwd_fuses_w2(int e, int pre) { return LG_FW2 && pre && e == 16; }
 int launch_ffn1_bwd(int e, const Ffn1BwdArgs& a, hipStream_t s);
 int launch_ffn1_bwd_x32(const Ffn1BwdArgs& a, const float* w1, void* wsplit, hipStream_t s);   // k_ffn1_bwd_x32.hip
-// e = 16, fp32 storage (k_ffn_bwd_x.hip): everything that hangs off dh2 in ONE pass on the bf16 matrix pipe (split arithmetic) --
-// h1 re-computed from x, dx, LayerNorm gradients, dW1 / db1 AND dW2 / db2; replaces k_ffn1_bwd<16> + the 64 x 64 k_wgrad_t launch
+// e = 16 | 32 (k_ffn_bwd_x.hip): everything that hangs off dh2 in ONE pass on the bf16 matrix pipe (split arithmetic) --
+// h1 re-computed from x, dx, LayerNorm gradients, dW1 / db1 AND dW2 / db2; replaces k_ffn1_bwd<16> / k_ffn1_bwd_x32 + the 4e x 4e k_wgrad_t launches
+// (N1 = 4 e below)
 struct Ffn1BwdXArgs {
-    const void* dh2;   // [P,64]  (hidden storage: fp32, or bf16 when hbf)
+    const void* dh2;   // [P,N1]  (hidden storage: fp32, or bf16 when hbf)
     int hbf;           // 1: precision = 'bf16' (plain bf16 products, dh2 stored as bf16)
-    const float* x;    // [P,16] block mid activation (LN2 input)
-    const float* dy;   // [P,16] grad wrt block output (residual path)
-    float* dx;         // [P,16]
-    const float *w1, *b1;      // forward W1 [64][16], b1 [64]
-    const float *w2t, *w1t;    // W2^T [64][64], W1^T [16][64]
+    const float* x;    // [P,e] block mid activation (LN2 input)
+    const float* dy;   // [P,e] grad wrt block output (residual path)
+    float* dx;         // [P,e]
+    const float *w1, *b1;      // forward W1 [N1][e], b1 [N1]
+    const float *w2t, *w1t;    // W2^T [N1][N1], W1^T [e][N1]
     const float *ln2g, *ln2b;
-    float* slab;       // FFN1_BWD_WGS rows of FFN1_BWD_X_ROW floats (per-workgroup partial sums)
+    float* slab;       // ffn1_bwd_x_slab_floats(e) floats (per-workgroup partial sums)
     float *d_w1, *d_b1, *d_w2, *d_b2, *d_ln2g, *d_ln2b;   // accumulated (+=) by the deferred reduce launch
     long P;            // multiple of 64
 };
-#define FFN1_BWD_X_B2 4096
-#define FFN1_BWD_X_W1 4160
-#define FFN1_BWD_X_B1 5184
-#define FFN1_BWD_X_LG 5248
-#define FFN1_BWD_X_LB 5264
-#define FFN1_BWD_X_ROW 5280
-int launch_ffn1_bwd_xs(const Ffn1BwdXArgs& a, hipStream_t s);
+inline int ffn1_bwd_x_wgs(int e) { return e == 16 ? 512 : 256; }   // persistent grid: two workgroups per CU at e = 16 (55 KB of LDS), one at e = 32 (139 KB)
+size_t ffn1_bwd_x_slab_floats(int e);                               // floats of Ffn1BwdXArgs::slab
+int launch_ffn1_bwd_xs(int e, const Ffn1BwdXArgs& a, hipStream_t s);   // e = 16 | 32
 // e = 16, fp32 storage (k_ffn_dwbwd_x.hip): the strip-walking spatial half -- dh3 in an LDS ring, dh2 out, depthwise gradients AND
 // dW3 / db3 in the same pass; replaces k_ffn_dw_bwd<16> + the 16 x 64 k_wgrad_t launch
 struct FfnDwBwdXArgs {

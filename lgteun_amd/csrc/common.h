@@ -44,6 +44,9 @@ struct lg_plan {
     // default kernels with fp32 storage in both modes -- 'bf16' is never slower than the default (c3 / c5)
     bool hidden_bf16(int e) const { return cfg.precision == 1 && e != 64; }
     // precision = 'bf16' (plain bf16 MFMA, bf16 storage of the saved tensors) knows modes 2 and 5 only (3 falls back to 5)
+    int bwd32_old; // A/B switch read ONCE at plan creation (env LG_FFN_BWD32=xs turns it off): 1 = k_ffn1_bwd_x32 + k_wgrad_t at e = 32 (default);
+                   // 0 = k_ffn1_bwd_xs<32>, the e = 16 kernel's template at 8 waves / one workgroup per CU -- correct, but slower there
+    bool ffn1_bwd_x32(int e) const { return e == 32 && ffn_tile == 0 && !bwd32_old; }
     bool ffn_bwd_x(int e) const { return e == 16 && ffn_tile == 0 && save_mode == 2; }   // h1 not saved; backward through k_ffn_dw_bwd_xs + k_ffn1_bwd_xs
     bool ffn_saves_preact(int e) const { return e == 16 && ffn_tile == 0 && (save_mode == 2 || (save_mode == 3 && cfg.precision == 0)); }
     int64_t* off;  // host copy of offsets

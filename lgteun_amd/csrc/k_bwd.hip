@@ -44,6 +44,11 @@ static void carve_bwd(const lg_plan* plan, int B, void* base, BwdBufs& bb) {
     // arena: one block's worth of slabs (dw-conv partials + the three FFN weight gradients + the small ones) between flushes;
     // take() flushes by itself if a configuration needs more
     if (sl3 > sl) sl = sl3;
+    for (size_t e = E; e <= 2 * E; e *= 2)   // slab rows of the fused FFN backward kernels (k_ffn_bwd_x.hip, k_ffn_dwbwd_x.hip)
+        if (e == 16 || e == 32) {
+            if (ffn1_bwd_x_slab_floats((int)e) > sl) sl = ffn1_bwd_x_slab_floats((int)e);
+        }
+    if ((size_t)FFN_DW_BWD_X_WGS * FFN_DW_BWD_X_ROW > sl) sl = (size_t)FFN_DW_BWD_X_WGS * FFN_DW_BWD_X_ROW;
     bb.slab_cap = 4 * sl;
     bb.slab_arena = cv.take(bb.slab_cap);
     bb.dt = cv.take(P0 * E); bb.dskip = cv.take(P0 * E); bb.v = cv.take(P1 * E); bb.du = cv.take(P1 * E);
@@ -112,12 +117,12 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         fx.dh2 = bb.dh2; fx.x = fb.xmid; fx.dy = dy; fx.dx = tmp;
         fx.w1 = P + pl->blk(st, j, B_W1); fx.b1 = P + pl->blk(st, j, B_B1); fx.w2t = bb.w2t[j]; fx.w1t = bb.w1t[j];
         fx.ln2g = P + pl->blk(st, j, B_LN2G); fx.ln2b = P + pl->blk(st, j, B_LN2B);
-        fx.slab = bb.rq.take((size_t)FFN1_BWD_WGS * FFN1_BWD_X_ROW);
+        fx.slab = bb.rq.take(ffn1_bwd_x_slab_floats(e));
         if (!fx.slab) return -3;
         fx.d_w1 = G + pl->blk(st, j, B_W1); fx.d_b1 = G + pl->blk(st, j, B_B1); fx.d_w2 = G + pl->blk(st, j, B_W2); fx.d_b2 = G + pl->blk(st, j, B_B2);
         fx.d_ln2g = G + pl->blk(st, j, B_LN2G); fx.d_ln2b = G + pl->blk(st, j, B_LN2B);
         fx.P = Pn; fx.hbf = hbf;
-        return launch_ffn1_bwd_xs(fx, s);
+        return launch_ffn1_bwd_xs(e, fx, s);
     }
     FfnDwBwdArgs fd;
     fd.dy = dy; fd.g3 = pre ? fb.a3 : fb.g3; fd.h2 = fb.h2; fd.dh2 = bb.dh2; fd.w3t = bb.w3t[j]; fd.dww = P + pl->blk(st, j, B_DWW);
@@ -127,18 +132,19 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
     fd.d_dww = G + pl->blk(st, j, B_DWW); fd.d_dwb = G + pl->blk(st, j, B_DWB);
     fd.B = B; fd.h = fb.h; fd.w = fb.w; fd.hbf = hbf; fd.pre = pre;
     RC(launch_ffn_dw_bwd(e, fd, s));
-    if (pl->ffn_bwd_x(e)) {
-        // h1 was not saved: one pass over dh2 re-computes it and yields dx, the LayerNorm gradients, dW1 / db1 and dW2 / db2
+    if (pl->ffn_bwd_x(e) || pl->ffn1_bwd_x32(e)) {
+        // one pass over dh2 re-computes h1 and yields dx, the LayerNorm gradients, dW1 / db1 and dW2 / db2 (e = 16: h1 was not saved; e = 32:
+        // the saved gelu(h1) / gelu'(h1) are simply not read)
         Ffn1BwdXArgs fx;
         fx.dh2 = bb.dh2; fx.x = fb.xmid; fx.dy = dy; fx.dx = tmp;
         fx.w1 = P + pl->blk(st, j, B_W1); fx.b1 = P + pl->blk(st, j, B_B1); fx.w2t = bb.w2t[j]; fx.w1t = bb.w1t[j];
         fx.ln2g = P + pl->blk(st, j, B_LN2G); fx.ln2b = P + pl->blk(st, j, B_LN2B);
-        fx.slab = bb.rq.take((size_t)FFN1_BWD_WGS * FFN1_BWD_X_ROW);
+        fx.slab = bb.rq.take(ffn1_bwd_x_slab_floats(e));
         if (!fx.slab) return -3;
         fx.d_w1 = G + pl->blk(st, j, B_W1); fx.d_b1 = G + pl->blk(st, j, B_B1); fx.d_w2 = G + pl->blk(st, j, B_W2); fx.d_b2 = G + pl->blk(st, j, B_B2);
         fx.d_ln2g = G + pl->blk(st, j, B_LN2G); fx.d_ln2b = G + pl->blk(st, j, B_LN2B);
         fx.P = Pn; fx.hbf = hbf;
-        RC(launch_ffn1_bwd_xs(fx, s));
+        RC(launch_ffn1_bwd_xs(e, fx, s));
         return wgrad(dy, e, fb.a3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 0, hbf, bb, s, pre);
     }
     Ffn1BwdArgs f1;

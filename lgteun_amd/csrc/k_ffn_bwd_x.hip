@@ -20,8 +20,9 @@
 // partial sums meet in LDS in front of the LayerNorm backward.
 //
 // Tile = 64 pixels, persistent workgroups deal tiles round-robin, next tile's operands in flight in registers.
-// LDS 55 KB (two workgroups per CU): D2 pieces [3][64][72] bf16 | LN(x) pieces [3][64][16] | per-wave dh1^T [4][3][16][16] |
-// W1^T dh1 partials [4][64][16] fp32.
+// e = 16: 4 waves, LDS 55 KB (two workgroups per CU): D2 pieces [3][64][72] bf16 | LN(x) pieces [3][64][16] | per-wave dh1^T [4][3][16][16] |
+// W1^T dh1 partials [4][64][16] fp32.  e = 32 (round 3: level 1 of the 4-band net, level 0 of the 8-band net): the same kernel with 8 waves
+// (N1 / 16 hidden-channel blocks), 139 KB, one workgroup per CU; it replaces k_ffn1_bwd_x32 + the 128 x 128 k_wgrad_t launches.
 #include "kernels.h"
 #include "bwd_kernels.h"
 #include "split_bf16.h"
@@ -41,15 +42,22 @@ extern "C" __attribute__((visibility("default"))) int lg_debug_kb_stamps(unsigne
 
 namespace {
 
-constexpr int E = 16, N1 = 64, NPX = 64, LDP = 72;
-constexpr int D2_PIECE = NPX * LDP;          // halves
-constexpr int XN_PIECE = NPX * E;            // halves
-constexpr int D1T_PIECE = 16 * 16;           // halves, per wave and piece
-constexpr size_t OFF_XN = (size_t)3 * D2_PIECE * 2;
-constexpr size_t OFF_D1T = OFF_XN + (size_t)3 * XN_PIECE * 2;
-constexpr size_t OFF_RED = OFF_D1T + (size_t)4 * 3 * D1T_PIECE * 2;
-constexpr size_t LDS_BYTES = OFF_RED + (size_t)4 * NPX * E * 4;
-static_assert(OFF_XN % 16 == 0 && OFF_D1T % 16 == 0 && OFF_RED % 16 == 0, "16-byte aligned LDS regions");
+constexpr int NPX = 64;
+template <int E>
+struct KB {
+    static constexpr int N1 = 4 * E, NW = N1 / 16, NT = 64 * NW, LDP = N1 + 8, LPP = E / 4;
+    static constexpr int D2_PIECE = NPX * LDP;      // halves
+    static constexpr int XN_PIECE = NPX * E;        // halves
+    static constexpr int D1T_PIECE = 16 * 16;       // halves, per wave and piece
+    static constexpr size_t OFF_XN = (size_t)3 * D2_PIECE * 2;
+    static constexpr size_t OFF_D1T = OFF_XN + (size_t)3 * XN_PIECE * 2;
+    static constexpr size_t OFF_RED = OFF_D1T + (size_t)NW * 3 * D1T_PIECE * 2;
+    static constexpr size_t LDS_BYTES = OFF_RED + (size_t)NW * NPX * E * 4;
+    // slab row of a workgroup: [dW2 N1 x N1 | db2 N1 | dW1 N1 x E | db1 N1 | d gamma E | d beta E]
+    static constexpr int R_B2 = N1 * N1, R_W1 = R_B2 + N1, R_B1 = R_W1 + N1 * E, R_LG = R_B1 + N1, R_LB = R_LG + E, ROW = R_LB + E;
+    static_assert(OFF_XN % 16 == 0 && OFF_D1T % 16 == 0 && OFF_RED % 16 == 0, "16-byte aligned LDS regions");
+    static_assert(NT / (N1 / 4) == 16 && NT / LPP == NPX, "loader / LayerNorm thread maps");
+};
 
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 #ifndef LG_KB_FENCE
@@ -121,31 +129,65 @@ __device__ __forceinline__ void split4(const float (&v)[4], s16x4_t (&p)[3]) {
     p[0] = __builtin_bit_cast(s16x4_t, q1); p[1] = __builtin_bit_cast(s16x4_t, q2); p[2] = __builtin_bit_cast(s16x4_t, q3);
 }
 
+// generic K block of the data GEMMs: 16-deep (e = 16: K = e) or 32-deep
 template <int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn1_bwd_xs(Ffn1BwdXArgs a, long ntiles) {
-    constexpr bool BF = (NP == 1);   // plain-bf16 mode: dh2 is stored as bf16 (hstore.h) and is its own (single) piece
+__device__ __forceinline__ void ld3_x4(const uint16_t* p, int piece, s16x4_t (&o)[3]) {
+    o[0] = lds_x4(p);
+    if (NP == 3) { o[1] = lds_x4(p + piece); o[2] = lds_x4(p + 2 * piece); } else { o[1] = o[0]; o[2] = o[0]; }
+}
+template <int NP>
+__device__ __forceinline__ void ld3_x8(const uint16_t* p, int piece, bf16x8_t (&o)[3]) {
+    o[0] = lds_x8(p);
+    if (NP == 3) { o[1] = lds_x8(p + piece); o[2] = lds_x8(p + 2 * piece); } else { o[1] = o[0]; o[2] = o[0]; }
+}
+template <int NP>
+__device__ __forceinline__ void ld3_tr(const uint16_t* p, int piece, s16x4_t (&o)[3]) {
+    o[0] = lds_tr4(p);
+    if (NP == 3) { o[1] = lds_tr4(p + piece); o[2] = lds_tr4(p + 2 * piece); } else { o[1] = o[0]; o[2] = o[0]; }
+}
+template <int NP>
+__device__ __forceinline__ WFrag32 wfrag32(const float* W, int K, int kb) { return NP == 3 ? load_wfrag32(W, K, kb) : load_wfrag32_rne(W, K, kb); }
+template <int NP>
+__device__ __forceinline__ WFrag16 wfrag16(const float* W, int K, int k0) { return NP == 3 ? load_wfrag16(W, K, k0) : load_wfrag16_rne(W, K, k0); }
+
+template <int E, int NP>
+__global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn1_bwd_xs(Ffn1BwdXArgs a, long ntiles) {
+    using C = KB<E>;
+    constexpr int N1 = C::N1, NW = C::NW, NT = C::NT, LDP = C::LDP, LPP = C::LPP, D2_PIECE = C::D2_PIECE, XN_PIECE = C::XN_PIECE, D1T_PIECE = C::D1T_PIECE;
+    constexpr int KB2 = N1 / 32;       // 32-deep K blocks of dh2 W2
+    constexpr int NE = E / 16;         // 16-wide blocks of the e-channel axis (columns of dW1, rows of W1^T dh1)
+    constexpr bool BF = (NP == 1);     // plain-bf16 mode: dh2 is stored as bf16 (hstore.h) and is its own (single) piece
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint16_t* D2 = reinterpret_cast<uint16_t*>(smem_raw);                 // [3][NPX][LDP]   bf16 pieces of dh2
-    uint16_t* XN = reinterpret_cast<uint16_t*>(smem_raw + OFF_XN);        // [3][NPX][E]     bf16 pieces of LN(x)
+    uint16_t* D2 = reinterpret_cast<uint16_t*>(smem_raw);                    // [3][NPX][LDP]   bf16 pieces of dh2
+    uint16_t* XN = reinterpret_cast<uint16_t*>(smem_raw + C::OFF_XN);        // [3][NPX][E]     bf16 pieces of LN(x)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-    uint16_t* D1T = reinterpret_cast<uint16_t*>(smem_raw + OFF_D1T) + wave * 3 * D1T_PIECE;   // [3][16 ch][16 px] of this wave
-    float* red = reinterpret_cast<float*>(smem_raw + OFF_RED);            // [4 waves][NPX][E]
+    uint16_t* D1T = reinterpret_cast<uint16_t*>(smem_raw + C::OFF_D1T) + wave * 3 * D1T_PIECE;   // [3][16 ch][16 px] of this wave
+    float* red = reinterpret_cast<float*>(smem_raw + C::OFF_RED);            // [NW waves][NPX][E]
 
     // ---- weights of this wave's hidden-channel block, split once, register-resident
-    const WFrag16 w1f = NP == 3 ? load_wfrag16(a.w1 + (size_t)(wave * 16) * E, E, 0) : load_wfrag16_rne(a.w1 + (size_t)(wave * 16) * E, E, 0);            // [n = 16 w + r][k = 4 g ..]: B of h1 = LN(x) W1^T
-    const WFrag32 w2f0 = NP == 3 ? load_wfrag32(a.w2t + (size_t)(wave * 16) * N1, N1, 0) : load_wfrag32_rne(a.w2t + (size_t)(wave * 16) * N1, N1, 0);        // [n' = 16 w + r][n = 8 g ..]: B of da1 = dh2 W2
-    const WFrag32 w2f1 = NP == 3 ? load_wfrag32(a.w2t + (size_t)(wave * 16) * N1, N1, 1) : load_wfrag32_rne(a.w2t + (size_t)(wave * 16) * N1, N1, 1);
-    const WFrag16 w1tf = NP == 3 ? load_wfrag16(a.w1t, N1, wave * 16) : load_wfrag16_rne(a.w1t, N1, wave * 16);                           // [k = r][n = 16 w + 4 g ..]: A of W1^T dh1 (K slice)
-    const float b1s = a.b1[wave * 16 + r];
-    // LayerNorm role: thread = (pixel t / 4, channel quad t % 4)
-    const int lpx = threadIdx.x >> 2, lq = threadIdx.x & 3;
-    const float4 lng = *reinterpret_cast<const float4*>(a.ln2g + 4 * lq), lnb = *reinterpret_cast<const float4*>(a.ln2b + 4 * lq);
-    // loader role: thread = (pixel t / 16 + 16 it, channel quad t % 16)
-    const int dq = threadIdx.x & 15, dpx = threadIdx.x >> 4;
-
-    f32x4_t acc2[4], acc1 = (f32x4_t){0.f, 0.f, 0.f, 0.f};   // dW2[16 nb + 4 g + v][16 w + r], dW1[16 w + 4 g + v][r]
+    // W1 rows [16 w, 16 w + 16) (B of h1 = LN(x) W1^T): one 16-deep block at e = 16, one 32-deep block at e = 32
+    WFrag16 w1f16;
+    WFrag32 w1f32;
+    if constexpr (E == 16) w1f16 = wfrag16<NP>(a.w1 + (size_t)(wave * 16) * E, E, 0);
+    else w1f32 = wfrag32<NP>(a.w1 + (size_t)(wave * 16) * E, E, 0);
+    WFrag32 w2f[KB2];                  // W2^T rows [16 w, 16 w + 16) (B of da1 = dh2 W2)
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) acc2[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < KB2; ++kb) w2f[kb] = wfrag32<NP>(a.w2t + (size_t)(wave * 16) * N1, N1, kb);
+    WFrag16 w1tf[NE];                  // W1^T [16 rb + r][16 w + 4 g ..] (A of this wave's K = 16 slice of W1^T dh1)
+#pragma unroll
+    for (int rb = 0; rb < NE; ++rb) w1tf[rb] = wfrag16<NP>(a.w1t + (size_t)(rb * 16) * N1, N1, wave * 16);
+    const float b1s = a.b1[wave * 16 + r];
+    // LayerNorm role: thread = (pixel t / (e/4), channel quad t % (e/4))
+    const int lpx = threadIdx.x / LPP, lq = threadIdx.x % LPP;
+    const float4 lng = *reinterpret_cast<const float4*>(a.ln2g + 4 * lq), lnb = *reinterpret_cast<const float4*>(a.ln2b + 4 * lq);
+    // loader role: thread = (pixel t / (N1/4) + 16 it, channel quad t % (N1/4))
+    const int dq = threadIdx.x % (N1 / 4), dpx = threadIdx.x / (N1 / 4);
+
+    f32x4_t acc2[NW], acc1[NE];        // dW2[16 nb + 4 g + v][16 w + r], dW1[16 w + 4 g + v][16 cb + r]
+#pragma unroll
+    for (int nb = 0; nb < NW; ++nb) acc2[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cb = 0; cb < NE; ++cb) acc1[cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     float bs1 = 0.f;                                          // db1[16 w + r], this lane's pixels
     float4 bs2 = make_float4(0.f, 0.f, 0.f, 0.f);             // db2[4 dq ..], this thread's pixels
     float4 pg = make_float4(0.f, 0.f, 0.f, 0.f), pb = pg;     // d gamma / d beta [4 lq ..], this thread's pixels
@@ -186,9 +228,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             }
         }
         const float4 xv = xnx, dyv = dyn;
-        const float mu = quad_sum((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / E);
+        const float mu = lane_group_sum<LPP>((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / E);
         const float c0 = xv.x - mu, c1 = xv.y - mu, c2 = xv.z - mu, c3 = xv.w - mu;
-        const float rstd = __builtin_amdgcn_rsqf(quad_sum((c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3)) * (1.0f / E) + LG_EPS);
+        const float rstd = __builtin_amdgcn_rsqf(lane_group_sum<LPP>((c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3)) * (1.0f / E) + LG_EPS);
         const float xh[4] = {c0 * rstd, c1 * rstd, c2 * rstd, c3 * rstd};
         {
             const float yv[4] = {xh[0] * lng.x + lnb.x, xh[1] * lng.y + lnb.y, xh[2] * lng.z + lnb.z, xh[3] * lng.w + lnb.w};
@@ -212,28 +254,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             // The phases below are kept apart by scheduling fences (KB_FENCE): on gfx950 a wave that alternates MFMAs and vector
             // instructions runs slower than the sum of the two (tools/micro/mfma_valu_overlap.hip: 482 + 525 us alone, 1178 us interleaved
             // in one wave, 650 us with the two kinds of work in different waves of the SIMD) -- bursts of one kind per wave let the OTHER
-            // resident wave's vector work run under this wave's matrix work.
-            // ---- operands of the two data GEMMs
-            s16x4_t xa[3];
-            {
-                const uint16_t* p = XN + (pbk * 16 + r) * E + 4 * g;
-                xa[0] = lds_x4(p);
-                if (NP == 3) { xa[1] = lds_x4(p + XN_PIECE); xa[2] = lds_x4(p + 2 * XN_PIECE); } else { xa[1] = xa[0]; xa[2] = xa[0]; }
-            }
-            const uint16_t* pd = D2 + (pbk * 16 + r) * LDP + 8 * g;
-            bf16x8_t d0[3], d1[3];
-            d0[0] = lds_x8(pd); d1[0] = lds_x8(pd + 32);
-            if (NP == 3) { d0[1] = lds_x8(pd + D2_PIECE); d0[2] = lds_x8(pd + 2 * D2_PIECE); d1[1] = lds_x8(pd + 32 + D2_PIECE); d1[2] = lds_x8(pd + 32 + 2 * D2_PIECE); }
-            else { d0[1] = d0[0]; d0[2] = d0[0]; d1[1] = d1[0]; d1[2] = d1[0]; }
-            KB_FENCE();
-            // ---- h1[px 4 g + v][ch 16 w + r] = LN(x) W1^T + b1 ; da1 = dh2 W2 (K = 64 as two 32-deep blocks)
+            // resident wave's vector work run under this wave's matrix work.  (Measured here: no difference, 101.3 vs 101.5 us; kept.)
+            // ---- h1[px 4 g + v][ch 16 w + r] = LN(x) W1^T + b1 ; da1 = dh2 W2 (K = N1 in 32-deep blocks)
             f32x4_t h1 = (f32x4_t){b1s, b1s, b1s, b1s};
-            mfmaN_16<NP>(h1, xa, w1f.p);
+            if constexpr (E == 16) {
+                s16x4_t xa[3];
+                ld3_x4<NP>(XN + (pbk * 16 + r) * E + 4 * g, XN_PIECE, xa);
+                KB_FENCE();
+                mfmaN_16<NP>(h1, xa, w1f16.p);
+            } else {
+                bf16x8_t xa[3];
+                ld3_x8<NP>(XN + (pbk * 16 + r) * E + 8 * g, XN_PIECE, xa);
+                KB_FENCE();
+                mfmaN_32<NP>(h1, xa, w1f32.p);
+            }
             f32x4_t da = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            mfmaN_32<NP>(da, d0, w2f0.p);
-            mfmaN_32<NP>(da, d1, w2f1.p);
+            {
+                const uint16_t* pd = D2 + (pbk * 16 + r) * LDP + 8 * g;
+#pragma unroll
+                for (int kb = 0; kb < KB2; ++kb) {
+                    bf16x8_t dk[3];
+                    ld3_x8<NP>(pd + 32 * kb, D2_PIECE, dk);
+                    mfmaN_32<NP>(da, dk, w2f[kb].p);
+                }
+            }
             KB_FENCE();
-            // ---- gelu(h1), gelu'(h1) with one exponential for both; dh1 = da1 * gelu'(h1); pieces; the column reads of the weight-gradient operands
+            // ---- gelu(h1), gelu'(h1) with one exponential for both; dh1 = da1 * gelu'(h1); pieces
             lg_v2f a01, a23, g01, g23;
             gelu2_both_f((lg_v2f){h1[0], h1[1]}, a01, g01);
             gelu2_both_f((lg_v2f){h1[2], h1[3]}, a23, g23);
@@ -243,23 +289,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             s16x4_t a1p[3], d1p[3];
             split4<NP>(a1v, a1p);
             split4<NP>(d1v, d1p);
-            const uint16_t* px = XN + (pbk * 16 + 4 * g + (r >> 2)) * E + 4 * (r & 3);
-            s16x4_t xt[3];
-            xt[0] = lds_tr4(px);
-            if (NP == 3) { xt[1] = lds_tr4(px + XN_PIECE); xt[2] = lds_tr4(px + 2 * XN_PIECE); } else { xt[1] = xt[0]; xt[2] = xt[0]; }
-            const uint16_t* pt = D2 + (pbk * 16 + 4 * g + (r >> 2)) * LDP + 4 * (r & 3);
-            s16x4_t dt[4][3];
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                dt[nb][0] = lds_tr4(pt + 16 * nb);
-                if (NP == 3) { dt[nb][1] = lds_tr4(pt + 16 * nb + D2_PIECE); dt[nb][2] = lds_tr4(pt + 16 * nb + 2 * D2_PIECE); } else { dt[nb][1] = dt[nb][0]; dt[nb][2] = dt[nb][0]; }
-            }
             KB_FENCE();
             // ---- dW1[16 w + .][.] += dh1^T LN(x) (A = dh1 from the registers, B = LN(x) read by columns);
             //      dW2[.][16 w + .] += dh2^T gelu(h1) (A = dh2 read by columns, B = gelu(h1) from the registers)
-            mfmaN_16<NP>(acc1, d1p, xt);
+            {
+                const uint16_t* px = XN + (pbk * 16 + 4 * g + (r >> 2)) * E + 4 * (r & 3);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) mfmaN_16<NP>(acc2[nb], dt[nb], a1p);
+                for (int cb = 0; cb < NE; ++cb) {
+                    s16x4_t xt[3];
+                    ld3_tr<NP>(px + 16 * cb, XN_PIECE, xt);
+                    mfmaN_16<NP>(acc1[cb], d1p, xt);
+                }
+                const uint16_t* pt = D2 + (pbk * 16 + 4 * g + (r >> 2)) * LDP + 4 * (r & 3);
+#pragma unroll
+                for (int nb = 0; nb < NW; ++nb) {
+                    s16x4_t dt[3];
+                    ld3_tr<NP>(pt + 16 * nb, D2_PIECE, dt);
+                    mfmaN_16<NP>(acc2[nb], dt, a1p);
+                }
+            }
             KB_FENCE();
             // this wave's K = 16 slice of W1^T dh1: dh1 -> [channel][pixel] in the wave's own LDS region, read back by columns as the B operand
             {
@@ -271,31 +319,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const uint16_t* p = D1T + (4 * g + (r >> 2)) * 16 + 4 * (r & 3);
                 s16x4_t dtp[3];
-                dtp[0] = lds_tr4(p);
-                if (NP == 3) { dtp[1] = lds_tr4(p + D1T_PIECE); dtp[2] = lds_tr4(p + 2 * D1T_PIECE); } else { dtp[1] = dtp[0]; dtp[2] = dtp[0]; }
-                f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                mfmaN_16<NP>(o, w1tf.p, dtp);             // o[v] = (W1^T dh1)[out channel 4 g + v][pixel r], hidden channels 16 w .. 16 w + 15 only
+                ld3_tr<NP>(D1T + (4 * g + (r >> 2)) * 16 + 4 * (r & 3), D1T_PIECE, dtp);
+#pragma unroll
+                for (int rb = 0; rb < NE; ++rb) {
+                    f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    mfmaN_16<NP>(o, w1tf[rb].p, dtp);     // o[v] = (W1^T dh1)[out channel 16 rb + 4 g + v][pixel r], hidden channels 16 w .. 16 w + 15 only
+                    *reinterpret_cast<float4*>(red + ((size_t)wave * NPX + pbk * 16 + r) * E + 16 * rb + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
+                }
                 __builtin_amdgcn_wave_barrier();      // D1T is rewritten by the next pixel block
-                *reinterpret_cast<float4*>(red + ((size_t)wave * NPX + pbk * 16 + r) * E + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
         STAMP(3);
         __syncthreads();
         STAMP(4);
 
-        // ---- LayerNorm backward + residual (thread = pixel lpx, channels 4 lq ..): sum of the four K slices, then the usual two moments
+        // ---- LayerNorm backward + residual (thread = pixel lpx, channels 4 lq ..): sum of the NW K slices, then the usual two moments
         {
             const float* rp = red + (size_t)lpx * E + 4 * lq;
-            const float4 s0 = *reinterpret_cast<const float4*>(rp), s1 = *reinterpret_cast<const float4*>(rp + NPX * E);
-            const float4 s2 = *reinterpret_cast<const float4*>(rp + 2 * NPX * E), s3 = *reinterpret_cast<const float4*>(rp + 3 * NPX * E);
-            const float dl[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
+            float dl[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w2 = 0; w2 < NW; w2 += 2) {
+                const float4 s0 = *reinterpret_cast<const float4*>(rp + (size_t)w2 * NPX * E), s1 = *reinterpret_cast<const float4*>(rp + (size_t)(w2 + 1) * NPX * E);
+                dl[0] += s0.x + s1.x; dl[1] += s0.y + s1.y; dl[2] += s0.z + s1.z; dl[3] += s0.w + s1.w;
+            }
             pg.x += dl[0] * xh[0]; pg.y += dl[1] * xh[1]; pg.z += dl[2] * xh[2]; pg.w += dl[3] * xh[3];
             pb.x += dl[0]; pb.y += dl[1]; pb.z += dl[2]; pb.w += dl[3];
             const float dxh[4] = {dl[0] * lng.x, dl[1] * lng.y, dl[2] * lng.z, dl[3] * lng.w};
-            const float m1 = quad_sum((dxh[0] + dxh[1]) + (dxh[2] + dxh[3])) * (1.0f / E);
-            const float m2 = quad_sum((dxh[0] * xh[0] + dxh[1] * xh[1]) + (dxh[2] * xh[2] + dxh[3] * xh[3])) * (1.0f / E);
+            const float m1 = lane_group_sum<LPP>((dxh[0] + dxh[1]) + (dxh[2] + dxh[3])) * (1.0f / E);
+            const float m2 = lane_group_sum<LPP>((dxh[0] * xh[0] + dxh[1] * xh[1]) + (dxh[2] * xh[2] + dxh[3] * xh[3])) * (1.0f / E);
             *reinterpret_cast<float4*>(a.dx + (p0 + lpx) * E + 4 * lq) =
                 make_float4(dyv.x + rstd * (dxh[0] - m1 - xh[0] * m2), dyv.y + rstd * (dxh[1] - m1 - xh[1] * m2),
                             dyv.z + rstd * (dxh[2] - m1 - xh[2] * m2), dyv.w + rstd * (dxh[3] - m1 - xh[3] * m2));
@@ -305,22 +357,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         // rewritten only behind the next tile's first barrier)
     }
 
-    // ---- this workgroup's partial sums -> its slab row [dW2 64x64 | db2 64 | dW1 64x16 | db1 64 | d gamma 16 | d beta 16]
-    float* row = a.slab + (size_t)blockIdx.x * FFN1_BWD_X_ROW;
+    // ---- this workgroup's partial sums -> its slab row [dW2 N1 x N1 | db2 N1 | dW1 N1 x e | db1 N1 | d gamma e | d beta e]
+    float* row = a.slab + (size_t)blockIdx.x * C::ROW;
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+    for (int nb = 0; nb < NW; ++nb)
 #pragma unroll
         for (int v = 0; v < 4; ++v) row[(16 * nb + 4 * g + v) * N1 + 16 * wave + r] = acc2[nb][v];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) row[FFN1_BWD_X_W1 + (16 * wave + 4 * g + v) * E + r] = acc1[v];
+    for (int cb = 0; cb < NE; ++cb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) row[C::R_W1 + (16 * wave + 4 * g + v) * E + 16 * cb + r] = acc1[cb][v];
     {
         float s = bs1;
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        if (g == 0) row[FFN1_BWD_X_B1 + 16 * wave + r] = s;
+        if (g == 0) row[C::R_B1 + 16 * wave + r] = s;
     }
     __syncthreads();                     // every wave is done with the tile loop's LDS
-    float* sc = reinterpret_cast<float*>(smem_raw);   // [16][64] db2 partials | [64][16] d gamma | [64][16] d beta
+    float* sc = reinterpret_cast<float*>(smem_raw);   // [16][N1] db2 partials | [NPX][e] d gamma | [NPX][e] d beta
     *reinterpret_cast<float4*>(sc + dpx * N1 + 4 * dq) = bs2;
     *reinterpret_cast<float4*>(sc + 16 * N1 + lpx * E + 4 * lq) = pg;
     *reinterpret_cast<float4*>(sc + 16 * N1 + NPX * E + lpx * E + 4 * lq) = pb;
@@ -329,46 +383,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += sc[k * N1 + threadIdx.x];
-        row[FFN1_BWD_X_B2 + threadIdx.x] = s;
+        row[C::R_B2 + threadIdx.x] = s;
     } else if (threadIdx.x < N1 + 2 * E) {
         const int i = threadIdx.x - N1, which = i / E, c = i % E;
         const float* src = sc + 16 * N1 + which * NPX * E + c;
         float s = 0.f;
         for (int k = 0; k < NPX; ++k) s += src[k * E];
-        row[(which ? FFN1_BWD_X_LB : FFN1_BWD_X_LG) + c] = s;
+        row[(which ? C::R_LB : C::R_LG) + c] = s;
     }
 }
 
-}   // namespace
-
-int launch_ffn1_bwd_xs(const Ffn1BwdXArgs& a, hipStream_t s) {
-    ProfScope prof__(LG_K_FFN1_BWD, s);
-    if (a.P <= 0 || a.P % NPX) { lg_set_error("ffn1_bwd_xs: pixel count %ld is not a multiple of %d", a.P, NPX); return -2; }
-    if (!a.dh2 || !a.x || !a.dy || !a.dx || !a.slab || !a.w1 || !a.w1t || !a.w2t || !a.b1 || !a.ln2g || !a.ln2b) { lg_set_error("ffn1_bwd_xs: null argument"); return -2; }
+template <int E>
+int launch_t(const Ffn1BwdXArgs& a, hipStream_t s) {
+    using C = KB<E>;
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn1_bwd_xs<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1_bwd_xs<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn1_bwd_xs<E, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1_bwd_xs<E, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
         if (e != hipSuccess) { lg_set_error("ffn1_bwd_xs: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
     const long ntiles = a.P / NPX;
-    const int grid = (int)(ntiles < FFN1_BWD_WGS ? ntiles : FFN1_BWD_WGS);
-    if (a.hbf) k_ffn1_bwd_xs<1><<<grid, 256, LDS_BYTES, s>>>(a, ntiles);      // precision = 'bf16': plain bf16 operands, dh2 stored as bf16
-    else k_ffn1_bwd_xs<3><<<grid, 256, LDS_BYTES, s>>>(a, ntiles);
+    const int cap = ffn1_bwd_x_wgs(E);
+    const int grid = (int)(ntiles < cap ? ntiles : cap);
+    if (a.hbf) k_ffn1_bwd_xs<E, 1><<<grid, C::NT, C::LDS_BYTES, s>>>(a, ntiles);      // precision = 'bf16': plain bf16 operands, dh2 stored as bf16
+    else k_ffn1_bwd_xs<E, 3><<<grid, C::NT, C::LDS_BYTES, s>>>(a, ntiles);
     LG_CHECK_LAUNCH();
     // the slab rows, summed in a fixed order by the deferred reduce launch
     ReduceJob j;
-    j.dst2 = nullptr; j.nslices = grid; j.slice_stride = FFN1_BWD_X_ROW;
+    j.dst2 = nullptr; j.nslices = grid; j.slice_stride = C::ROW;
     auto job = [&](int off, float* dst, int rows, int cols) {
         j.slab = a.slab + off; j.dst = dst; j.rows = rows; j.cols = cols; j.row_stride = cols; j.ld = cols; j.rows_valid = rows; j.cols_valid = cols;
         return launch_reduce_job(j, s);
     };
-    int rc = job(0, a.d_w2, N1, N1);
-    if (!rc) rc = job(FFN1_BWD_X_B2, a.d_b2, 1, N1);
-    if (!rc) rc = job(FFN1_BWD_X_W1, a.d_w1, N1, E);
-    if (!rc) rc = job(FFN1_BWD_X_B1, a.d_b1, 1, N1);
-    if (!rc) rc = job(FFN1_BWD_X_LG, a.d_ln2g, 1, E);
-    if (!rc) rc = job(FFN1_BWD_X_LB, a.d_ln2b, 1, E);
+    int rc = job(0, a.d_w2, C::N1, C::N1);
+    if (!rc) rc = job(C::R_B2, a.d_b2, 1, C::N1);
+    if (!rc) rc = job(C::R_W1, a.d_w1, C::N1, E);
+    if (!rc) rc = job(C::R_B1, a.d_b1, 1, C::N1);
+    if (!rc) rc = job(C::R_LG, a.d_ln2g, 1, E);
+    if (!rc) rc = job(C::R_LB, a.d_ln2b, 1, E);
     return rc;
+}
+
+}   // namespace
+
+size_t ffn1_bwd_x_slab_floats(int e) { return (size_t)ffn1_bwd_x_wgs(e) * (e == 16 ? KB<16>::ROW : KB<32>::ROW); }
+
+int launch_ffn1_bwd_xs(int e, const Ffn1BwdXArgs& a, hipStream_t s) {
+    ProfScope prof__(LG_K_FFN1_BWD, s);
+    if (e != 16 && e != 32) { lg_set_error("ffn1_bwd_xs: e=%d unsupported", e); return -1; }
+    if (a.P <= 0 || a.P % NPX) { lg_set_error("ffn1_bwd_xs: pixel count %ld is not a multiple of %d", a.P, NPX); return -2; }
+    if (!a.dh2 || !a.x || !a.dy || !a.dx || !a.slab || !a.w1 || !a.w1t || !a.w2t || !a.b1 || !a.ln2g || !a.ln2b) { lg_set_error("ffn1_bwd_xs: null argument"); return -2; }
+    return e == 16 ? launch_t<16>(a, s) : launch_t<32>(a, s);
 }
