@@ -23,7 +23,7 @@ for r in rows[lo:hi]:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     gap = (s - prev_end) / 1e3 if prev_end is not None else 0.0
     prev_end = max(e, prev_end or e)
-    nm = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '').replace('(anonymous namespace)::', '')
+    nm = re.sub(r'\(.*', '', r['Kernel_Name'].replace('(anonymous namespace)::', '')).replace('void ', '')
     print('%8.1f us  gap %6.1f  %s' % ((e - s) / 1e3, gap, nm[:70]))
     tot += e - s
 print('launches', hi - lo, 'kernel time %.3f ms' % (tot / 1e6), 'span %.3f ms' % ((int(rows[hi-1]['End_Timestamp']) - int(rows[lo]['Start_Timestamp'])) / 1e6))
