@@ -59,6 +59,9 @@ __device__ __forceinline__ bf16x8_t cat8(s16x4_t lo, s16x4_t hi) {
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
     return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
+#ifndef LG_KA_SLIDE
+#define LG_KA_SLIDE 1
+#endif
 #ifndef LG_KA_PAIR
 #define LG_KA_PAIR 0   // measured in THIS kernel (VALU / LDS bound, matrix pipe 10 % busy): the operand concatenation costs 133.7 vs 119.5 us per launch; off
 #endif
@@ -252,7 +255,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         // the top of the LAST chunk of the halo pass, item i + 4 while item i is worked on.  Every output pixel of a step is inside the
         // image (launcher: h % 8 == 0, w % 16 == 0).
         auto h2_fetch = [&](int i) {
+#if LG_KA_SLIDE
+            const int y = y0 + 2 * wave + (i >> 2), x = x0 + 4 * (lane >> 4) + (i & 3);
+#else
             const int y = y0 + 2 * wave + (i >> 2), x = x0 + (lane >> 4) + 4 * (i & 3);
+#endif
             return HS<BF>::ldraw(a.h2, ((b * h + y) * (long)w + x) * N1 + 4 * q);
         };
         typename HS<BF>::raw4 h2a, h2b, h2c, h2d;
@@ -281,8 +288,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         h3_fetch(y0 + TY + 1, 0, nh3);
         STAMP(9);
         const int sbase = (y0 - Y0) % RING;            // ring slot of row y0 - 1
-        // one output pixel quad: hreg holds its h2 vector and is re-loaded with the vector of the item four places on (no register
-        // rotation: a rotating set needs its moves in front of the loop's back edge, i.e. a wait for the load issued in the same iteration)
+        // A lane works on FOUR CONSECUTIVE pixels of a tile row (x0 + 4 (lane / 16) + it) and slides a 3 x 3 window of dh3 vectors over
+        // them: item `it` needs ring columns it .. it + 2, so a row of four items reads 6 x 3 vectors instead of 4 x 9 -- the P2 phase was
+        // LDS-read bound (profiles/r03_ffn_bwd_phase_stamps.txt).  hreg holds an item's h2 vector and is re-loaded with the vector of the
+        // item one tile row down (no register rotation: a rotating set needs its moves in front of the loop's back edge, i.e. a wait for the
+        // load issued in the same iteration).
+#if LG_KA_SLIDE
+        auto row4 = [&](int ch) {
+            const int ty = 2 * wave + ch, y = y0 + ty, txb = 4 * (lane >> 4);
+            const float* rrow[3];
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {       // ring row ty + rr (relative to row y0 - 1) meets tap dy = 2 - rr
+                int sl = sbase + ty + rr;
+                sl = sl >= RING ? sl - RING : sl;
+                rrow[rr] = ring + (sl * HX + txb) * LDR + 4 * q;
+            }
+            float4 col[6][3];
+            auto ldcol = [&](int c) {
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) col[c][rr] = *reinterpret_cast<const float4*>(rrow[rr] + c * LDR);
+            };
+            ldcol(0); ldcol(1); ldcol(2);
+            auto item = [&](int it, typename HS<BF>::raw4& hreg) {
+                if (it < 3) ldcol(it + 3);          // the next item's new column: requested under this item's arithmetic
+                const int x = x0 + txb + it;
+                const float4 hc = HS<BF>::widen(hreg);
+                hreg = HS<BF>::ldraw(a.h2, ((b * h + y0 + 2 * wave + 1) * (long)w + x) * N1 + 4 * q);   // ch = 0: one tile row down; ch = 1: a repeat nobody waits for
+                const lg_v2f h01 = (lg_v2f){hc.x, hc.y}, h23 = (lg_v2f){hc.z, hc.w};
+                lg_v2f acc01 = (lg_v2f){0.f, 0.f}, acc23 = (lg_v2f){0.f, 0.f};
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        // forward: h3(p) += w[dy][dx] h2(p + (dy-1, dx-1))  ->  h2(q) meets dh3(q - (dy-1, dx-1)) in both sums: halo column
+                        // tx + 2 - dx = tx + cc, ring row ty + 2 - dy = ty + rr
+                        const int k = (2 - rr) * 3 + (2 - cc);
+                        const float4 gv = col[it + cc][rr];
+                        const lg_v2f g01 = (lg_v2f){gv.x, gv.y}, g23 = (lg_v2f){gv.z, gv.w};
+                        acc01 = wq01[k] * g01 + acc01;
+                        acc23 = wq23[k] * g23 + acc23;
+                        pw01[k] = h01 * g01 + pw01[k];
+                        pw23[k] = h23 * g23 + pw23[k];
+                        if (k == 4) { pw01[9] += g01; pw23[9] += g23; }
+                    }
+                HS<BF>::st4(a.dh2, ((b * h + y) * (long)w + x) * N1 + 4 * q, make_float4(acc01.x, acc01.y, acc23.x, acc23.y));
+                __builtin_amdgcn_sched_barrier(0);      // one item at a time: interleaved items need more registers than there are
+            };
+            item(0, h2a); item(1, h2b); item(2, h2c); item(3, h2d);
+        };
+#pragma unroll 1
+        for (int ch = 0; ch < 2; ++ch) row4(ch);
+#else
         auto item = [&](int ch, int it, typename HS<BF>::raw4& hreg) {
             const int ty = 2 * wave + ch, tx = (lane >> 4) + 4 * it;
             const int y = y0 + ty, x = x0 + tx;
@@ -319,6 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             item(ch, 2, h2c);
             item(ch, 3, h2d);
         }
+#endif
         STAMP(10);
     }   // steps of the strip
     __syncthreads();   // the last step's P2 readers of the ring are done before the next strip's prologue writes it
