@@ -1,8 +1,8 @@
 """Runner counterpart of reference models/base/base_model.py restricted to the hot path's callers:
 add_module :56, set_cuda :91 (one process per GPU + RCCL instead of nn.DataParallel), load_checkpoint :102,
 set_optim :116 (Adam -> fused HIP Adam), set_sched :137 (StepLR stepped EVERY iteration :197-199),
-train :164, test :267 (reference-based indices PSNR / SSIM / Q / SAM / ERGAS; the no-reference QNR family is out of scope,
-SURVEY section 2), save :354 (same `train_out/` location; optimizer state added)."""
+train :164, test :267 (reference-based indices PSNR / SSIM / Q / SAM / ERGAS on the reduced-resolution set, the no-reference
+D_lambda / D_s / QNR on the full-resolution set), save :354 (same `train_out/` location; optimizer state added)."""
 import os.path as osp
 
 import numpy as np
@@ -195,16 +195,15 @@ class Base_model:
     @torch.no_grad()
     def test(self, iter_id, save=False, ref=True):
         """evaluation (base_model.py:267-352).  ref=True: reduced-resolution set, PSNR / SSIM / Q / SAM / ERGAS against the target,
-        `<metric>_mean` / `<metric>_std` lists in self.eval_results like the reference.  ref=False: the full-resolution set runs
-        through the model (and is saved when asked), but its no-reference indices D_lambda / D_s / QNR are not computed -- that
-        metric family is out of this build's scope.  Inputs are always normalised; arrays are brought back
+        `<metric>_mean` / `<metric>_std` lists in self.eval_results like the reference.  ref=False: the full-resolution set, no target:
+        D_lambda / D_s / QNR from the fused image, the PAN and the MS input (lgteun_amd/metrics.py: parity-unpinned).  Inputs are always normalised; arrays are brought back
         to digital numbers before the metrics / the TIFF writer only with cfg.norm_input (base_model.py:296,311-316)."""
         from .dataset import save_image
         loader = self.test_data_loader1 if ref else self.test_data_loader0
         for module in self.module_dict.values():
             module.eval()
         dev = next(iter(self.module_dict.values())).parameters().__next__().device
-        names = ['PSNR', 'SSIM', 'Q', 'SAM', 'ERGAS'] if ref else []
+        names = ['PSNR', 'SSIM', 'Q', 'SAM', 'ERGAS'] if ref else ['D_lambda', 'D_s', 'QNR']
         denorm = bool(self.cfg.get('norm_input', False))
         out_dir = osp.join(self.test_out1 if ref else self.test_out0, f'iter_{iter_id}')
         save = save and self.rank == 0     # one process per GPU: every rank evaluates, ONE writes the files (the reference is one process)
@@ -222,6 +221,9 @@ class Base_model:
             if ref:
                 gt = to_np(input_batch['target'])
                 res.extend(mtc.ref_evaluate(out[i], gt[i]) for i in range(out.shape[0]))
+            else:                                                # full-resolution set: no target (base_model.py:330-334)
+                pan_np, lr_np = to_np(input_batch['input_pan']), to_np(input_batch['input_lr'])
+                res.extend(mtc.no_ref_evaluate(out[i], pan_np[i], lr_np[i]) for i in range(out.shape[0]))
             if save:
                 for i, image_id in enumerate(input_batch['image_id']):
                     # [C, H, W] for the writer (the reference hands its HWC array to a CHW writer, base_model.py:336: a
@@ -235,9 +237,7 @@ class Base_model:
                 self.eval_results.setdefault(f'{name}_std', []).append(round(float(res[:, k].std()), 4))
                 latest[name] = (float(res[:, k].mean()), float(res[:, k].std()))
             if self.logger is not None and self.rank == 0:
-                self.logger.info(f'iter {iter_id} low-resolution eval: {latest}')
-        elif not ref and self.logger is not None and self.rank == 0:
-            self.logger.info(f'iter {iter_id} full-resolution pass: no-reference indices (D_lambda / D_s / QNR) are not computed by this build')
+                self.logger.info(f"iter {iter_id} {'low' if ref else 'full'}-resolution eval: {latest}")
         self._barrier()                    # no rank runs ahead of the files rank 0 is writing
         return latest
 

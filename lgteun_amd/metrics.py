@@ -16,7 +16,11 @@ Parity status: PSNR / SAM / ERGAS are pinned by values the reference itself prod
 SSIM / Q call cv2.filter2D in the reference and cv2 is not installed in the build image, so they are PARITY-UNPINNED: they
 are checked against brute-force evaluations of the definitions above only (tests/test_metrics_cpu.py).  Restricting the
 average to fully covered windows makes the result independent of any border rule.
-The no-reference indices (D_lambda, D_s, QNR) are outside the scope of this build.
+The no-reference family of the full-resolution pass (`no_ref_evaluate`: D_lambda, D_s, QNR; Alparone et al., 2008) is written from the
+published definitions as well: Q on 32 x 32 windows, the PAN image brought to MS resolution by a Gaussian low-pass whose gain at the MS
+Nyquist frequency is the sensor's MTF value, then decimation.  The reference builds that filter with a 2-D window method on top of cv2 /
+scipy.ndimage and a per-satellite table; this is the separable Gaussian of the same MTF gain, so the family is PARITY-UNPINNED like SSIM / Q
+and is checked against brute-force evaluations of its definitions only.
 """
 import numpy as np
 from numpy.lib.stride_tricks import sliding_window_view
@@ -24,6 +28,7 @@ from numpy.lib.stride_tricks import sliding_window_view
 PEAK = 2047.5
 _TINY = np.finfo(np.float64).eps
 SSIM_TAPS, SSIM_SIGMA, Q_BLOCK, ERGAS_RATIO = 11, 1.5, 8, 4
+QNR_BLOCK, MTF_TAPS, MTF_GAIN_PAN = 32, 41, 0.15
 
 
 def _as_pair(a, b):
@@ -121,3 +126,66 @@ def qindex(img1, img2, block_size=Q_BLOCK):
 def ref_evaluate(pred, gt):
     """the five reference-based indices in the order of the reference's result tables: PSNR, SSIM, Q, SAM, ERGAS"""
     return [psnr(pred, gt), ssim(pred, gt), qindex(pred, gt), sam(pred, gt), ergas(pred, gt)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# no-reference indices of the full-resolution pass (reference models/base/metrics.py:290-408, `no_ref_evaluate`)
+# ---------------------------------------------------------------------------------------------------------------------
+def mtf_taps(gain_at_nyquist, ratio=ERGAS_RATIO, n=MTF_TAPS):
+    """n samples of the Gaussian low-pass whose FREQUENCY response has the value `gain_at_nyquist` at the Nyquist frequency of the
+    coarser grid (1 / (2 ratio) cycles per fine pixel): H(f) = exp(-2 pi^2 s^2 f^2) for a spatial Gaussian of standard deviation s"""
+    if not 0.0 < gain_at_nyquist < 1.0:
+        raise ValueError('the MTF gain at Nyquist lies in (0, 1)')
+    f_nyq = 1.0 / (2.0 * ratio)
+    sigma = np.sqrt(-np.log(gain_at_nyquist) / (2.0 * np.pi ** 2 * f_nyq ** 2))
+    return gaussian_taps(n, sigma)
+
+
+def mtf_degrade(img, gain_at_nyquist=MTF_GAIN_PAN, ratio=ERGAS_RATIO):
+    """(H, W[, bands]) -> (H / ratio, W / ratio[, bands]): separable MTF-matched low-pass (edges replicated), then every ratio-th sample"""
+    x = np.asarray(img, dtype=np.float64)
+    taps = mtf_taps(gain_at_nyquist, ratio)
+    half = taps.size // 2
+    pad = [(half, half), (half, half)] + [(0, 0)] * (x.ndim - 2)
+    xp = np.pad(x, pad, mode='edge')
+    rows = np.tensordot(sliding_window_view(xp, taps.size, axis=0), taps, axes=([-1], [0]))
+    full = np.tensordot(sliding_window_view(rows, taps.size, axis=1), taps, axes=([-1], [0]))
+    return full[::ratio, ::ratio]
+
+
+def d_lambda(fused, ms, block_size=QNR_BLOCK, p=1):
+    """spectral distortion: how much the inter-band Q indices of the fused image differ from those of the MS image,
+    ( mean over band pairs l < r of |Q(F_l, F_r) - Q(M_l, M_r)|^p )^(1/p)"""
+    f, m = np.asarray(fused, np.float64), np.asarray(ms, np.float64)
+    if f.ndim != 3 or m.ndim != 3 or f.shape[2] != m.shape[2] or f.shape[2] < 2:
+        raise ValueError('fused and MS images are (H, W, bands) with the same number (>= 2) of bands')
+    nb = f.shape[2]
+    bs_m = min(block_size, min(m.shape[:2]))
+    diffs = [abs(_q_band(f[..., l], f[..., r], block_size) - _q_band(m[..., l], m[..., r], bs_m)) ** p
+             for l in range(nb) for r in range(l + 1, nb)]
+    return float(np.mean(diffs) ** (1.0 / p))
+
+
+def d_s(fused, ms, pan, pan_lr=None, block_size=QNR_BLOCK, q=1, ratio=ERGAS_RATIO, gain_at_nyquist=MTF_GAIN_PAN):
+    """spatial distortion: ( mean over bands of |Q(F_l, P) - Q(M_l, P_lr)|^q )^(1/q); P_lr = the PAN image at MS resolution
+    (MTF-matched low-pass + decimation unless given)"""
+    f, m, pn = np.asarray(fused, np.float64), np.asarray(ms, np.float64), np.asarray(pan, np.float64).squeeze()
+    if pn.ndim != 2 or f.shape[:2] != pn.shape:
+        raise ValueError('PAN is (H, W) at the fused image\'s resolution')
+    plr = mtf_degrade(pn, gain_at_nyquist, ratio) if pan_lr is None else np.asarray(pan_lr, np.float64).squeeze()
+    if plr.shape != m.shape[:2]:
+        raise ValueError(f'low-resolution PAN {plr.shape} does not match the MS image {m.shape[:2]}')
+    bs_lr = min(block_size, min(plr.shape))        # the reference's tables use the SAME window at both resolutions (metrics.py:325,329)
+    diffs = [abs(_q_band(f[..., l], pn, block_size) - _q_band(m[..., l], plr, bs_lr)) ** q for l in range(f.shape[2])]
+    return float(np.mean(diffs) ** (1.0 / q))
+
+
+def qnr(fused, ms, pan, pan_lr=None, alpha=1, beta=1, **kw):
+    """quality with no reference: (1 - D_lambda)^alpha (1 - D_s)^beta, 1 for a fusion without spectral or spatial distortion"""
+    return float((1.0 - d_lambda(fused, ms, kw.get('block_size', QNR_BLOCK))) ** alpha * (1.0 - d_s(fused, ms, pan, pan_lr, **kw)) ** beta)
+
+
+def no_ref_evaluate(pred, pan, ms):
+    """the three no-reference indices in the order of the reference's result tables: D_lambda, D_s, QNR"""
+    dl, ds = d_lambda(pred, ms), d_s(pred, ms, pan)
+    return [dl, ds, (1.0 - dl) * (1.0 - ds)]

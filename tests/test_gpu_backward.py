@@ -274,9 +274,11 @@ def test_runner_train_eval_save_load_roundtrip(tmp_path):
     runner2.set_sched()
     runner2.train_iter(iter_id=7, input_batch=lgteun_amd.base_model.data_normalize({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in loader[0].items()}, 11))
     assert o2._step == 7 and o2._state['exp_avg'].is_cuda
-    # the full-resolution pass runs the model and writes the fused images when asked (its no-reference indices are out of scope)
+    # the full-resolution pass runs the model, writes the fused images when asked and reports the no-reference indices
     runner2.test_data_loader0 = loader[:1]
-    assert runner2.test(iter_id=6, save=True, ref=False) == {}
+    nr = runner2.test(iter_id=6, save=True, ref=False)
+    assert set(nr) == {'D_lambda', 'D_s', 'QNR'} and 0.0 <= nr['QNR'][0] <= 1.0
+    assert runner2.eval_results['QNR_mean'][-1] == round(nr['QNR'][0], 4)
     assert (tmp_path / 'GF-2' / 'test_out0' / 'iter_6' / 'a0_mul_hat.tif').exists()
 
 

@@ -71,4 +71,46 @@ def test_psnr_sam_ergas_properties():
         mtc.sam(a[..., 0], b[..., 0])          # a spectral angle needs bands
     with pytest.raises(ValueError):
         mtc.qindex(a, b, 1)
-    assert not hasattr(mtc, 'qnr')               # the no-reference family is out of scope
+
+
+def test_no_reference_indices_follow_their_definitions():
+    """D_lambda / D_s / QNR (Alparone et al. 2008; reference models/base/metrics.py:290-408 `no_ref_evaluate`), written from the
+    definitions: checked against brute-force evaluations on small images (parity-unpinned like SSIM / Q: the reference's MTF filter
+    needs cv2 / scipy.ndimage tables that are not in the image)"""
+    from lgteun_amd import metrics as mtc
+    rng = np.random.default_rng(7)
+    H = 64
+    fused = rng.uniform(100, 1800, (H, H, 4))
+    pan = fused.mean(axis=2) + rng.normal(0, 20, (H, H))
+    ms = mtc.mtf_degrade(fused, 0.3) + rng.normal(0, 5, (H // 4, H // 4, 4))
+
+    def q_brute(x, y, bs):          # universal image quality index, mean over every fully covered window
+        vals = []
+        for i in range(x.shape[0] - bs + 1):
+            for j in range(x.shape[1] - bs + 1):
+                a, b = x[i:i + bs, j:j + bs].ravel(), y[i:i + bs, j:j + bs].ravel()
+                ma, mb = a.mean(), b.mean()
+                va, vb, cab = ((a - ma) ** 2).mean(), ((b - mb) ** 2).mean(), ((a - ma) * (b - mb)).mean()
+                vals.append((2 * ma * mb / (ma * ma + mb * mb)) * (2 * cab / (va + vb)))
+        return float(np.mean(vals))
+    bs = 32
+    pairs = [(l, r) for l in range(4) for r in range(l + 1, 4)]
+    dl = np.mean([abs(q_brute(fused[..., l], fused[..., r], bs) - q_brute(ms[..., l], ms[..., r], 16)) for l, r in pairs])
+    assert abs(mtc.d_lambda(fused, ms, bs) - dl) < 1e-10
+    plr = mtc.mtf_degrade(pan)
+    ds = np.mean([abs(q_brute(fused[..., l], pan, bs) - q_brute(ms[..., l], plr, 16)) for l in range(4)])
+    assert abs(mtc.d_s(fused, ms, pan, block_size=bs) - ds) < 1e-10
+    got = mtc.no_ref_evaluate(fused, pan, ms)
+    assert abs(got[0] - dl) < 1e-10 and abs(got[1] - ds) < 1e-10 and abs(got[2] - (1 - dl) * (1 - ds)) < 1e-12
+    assert abs(mtc.qnr(fused, ms, pan) - got[2]) < 1e-12
+    # a fusion whose inter-band and band-to-PAN similarities are those of the inputs has no distortion: QNR = 1
+    same = np.repeat(np.repeat(ms, 4, axis=0), 4, axis=1)
+    assert mtc.d_lambda(same, same, 8) == 0.0
+    # the MTF low-pass: unit DC gain, the prescribed gain at the coarse grid's Nyquist frequency, decimation by the ratio
+    taps = mtc.mtf_taps(0.15, 4)
+    f = 1.0 / 8.0
+    gain = abs(np.sum(taps * np.exp(-2j * np.pi * f * (np.arange(taps.size) - taps.size // 2))))
+    assert abs(taps.sum() - 1) < 1e-12 and abs(gain - 0.15) < 2e-3
+    assert mtc.mtf_degrade(np.full((32, 48), 5.0)).shape == (8, 12) and np.allclose(mtc.mtf_degrade(np.full((32, 48), 5.0)), 5.0)
+    with pytest.raises(ValueError):
+        mtc.d_s(fused, ms, pan[:-4])
