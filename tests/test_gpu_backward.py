@@ -299,3 +299,55 @@ def test_gradients_are_bitwise_reproducible(C, H):
     eng.train_step(ms, pan, gt, opt)
     assert torch.equal(g1, eng.gflat)
     assert float(g1.abs().max()) > 0
+
+
+@pytest.mark.parametrize('B,h,w', [(1, 16, 16), (3, 80, 48), (2, 48, 208), (1, 128, 128)])
+def test_ffn_backward_kernels_at_awkward_shapes(B, h, w):
+    """the round-3 e = 16 FFN backward pair (k_ffn_dw_bwd_xs: strip walk with an LDS ring of dh3; k_ffn1_bwd_xs: h1 re-computed, dx and all
+    weight gradients on the bf16 pipe in split arithmetic) in isolation against the fp64 oracle at sizes that exercise their edges: one
+    strip step only, strips that end inside a step, rectangular planes, an odd batch, a multi-step strip walk"""
+    from gpu_helpers import Ops, make_module
+    C = 4
+    net = make_module(C, 1)
+    ops = Ops(net, h, w)
+    e = 4 * C
+    rng = np.random.default_rng(1000 + h + w)
+    x = T(rng.standard_normal((B, h, w, e)).astype(np.float32))
+    dy = T(rng.standard_normal((B, h, w, e)).astype(np.float32))
+    P64 = det_params(C, 1, dtype=torch.float64, requires_grad=True)
+    want_dx, want_g = _oracle_block(P64, C, 0, 2, x.double(), dy.double())
+    got_dx, flat = ops.block_bwd(0, 0, 2, x.cuda(), dy.cuda())
+    assert rel_l2(got_dx.cpu(), want_dx) < 2e-5, rel_l2(got_dx.cpu(), want_dx)
+    assert len(want_g) == 10                                       # W1 b1 W2 b2 dww dwb W3 b3 + the LayerNorm pair
+    for k, g in want_g.items():
+        got = ops.grad_of(flat, k).cpu().numpy()
+        ref = g.numpy()
+        assert float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)) < 2e-4, (k, float(np.abs(got - ref).max() / np.abs(ref).max()))
+
+
+@pytest.mark.parametrize('env', [{'LG_FFN_DWBWD': 'tile'}, {'LG_FFN_SAVE': '3'}, {'LG_FFN_BWD32': 'xs'}])
+def test_ffn_backward_ab_paths_agree_with_the_default(env, monkeypatch):
+    """the A/B switches of the FFN backward (round 2's tile kernel + weight-gradient launch; the three-tensor save mode; the e = 32
+    instance of k_ffn1_bwd_xs) give the default path's gradients to rounding on a whole train step (C = 4: e = 16 at level 0, e = 32 at
+    level 1)"""
+    from gpu_helpers import make_module
+    from lgteun_amd import FusedAdam
+    ms, pan, gt = (T(a).cuda() for a in dw.make_inputs(2, 4, 16, 16, seed=11, kind='smooth'))
+
+    def grads():
+        net = make_module(4, 2)
+        opt = FusedAdam(net.parameters(), lr=0.0)
+        opt.dropout = False
+        eng = net.engine()
+        eng.train_step(ms, pan, gt, opt)
+        return eng.gflat.clone(), eng
+    for k in env:
+        monkeypatch.delenv(k, raising=False)
+    g0, eng = grads()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)                                   # read once per plan: a fresh module builds a fresh plan
+    g1, _ = grads()
+    for i in eng.live_idx:
+        o, n = eng.offsets[i], eng.params[i].numel()
+        a, b = g0[o:o + n].double(), g1[o:o + n].double()
+        assert float((a - b).norm()) <= 5e-6 * float(a.norm()) + 1e-12, (env, eng.names[i], float((a - b).norm()), float(a.norm()))
