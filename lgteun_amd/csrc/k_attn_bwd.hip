@@ -441,21 +441,30 @@ __global__ __launch_bounds__(256) void k_attn_bwd_epi(AttnBwdArgs a, long total)
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
     const long hw = (long)a.h * a.w;
-    for (long p = (long)blockIdx.x * PPW + slot; p < total; p += (long)gridDim.x * PPW) {   // total is a multiple of PPW (launcher)
+    // The operands of a pixel group are requested ONE GROUP AHEAD into a second, statically named register set (A / B alternate: a
+    // rotating set would need its moves in front of the back edge, i.e. a wait for the loads issued in the same iteration): the kernel
+    // runs two waves per SIMD, too few to hide an HBM round trip per iteration by occupancy.  Every load is unconditional (the planar
+    // dg channel is clamped for the attention-half lanes, whose value is not used).
+    struct Ops4 { float4 x4, dy4; float2 dq2[R / 2]; float dgv[4]; };
+    auto issue = [&](long p, Ops4& o) {
         const long b = p / hw, s = p - b * hw;
-        const float4 x4 = *reinterpret_cast<const float4*>(a.x + p * E + 4 * q);
-        const float4 dy4 = *reinterpret_cast<const float4*>(a.dy + p * E + 4 * q);
+        o.x4 = *reinterpret_cast<const float4*>(a.x + p * E + 4 * q);
+        o.dy4 = *reinterpret_cast<const float4*>(a.dy + p * E + 4 * q);
+#pragma unroll
+        for (int r2 = 0; r2 < R / 2; ++r2) o.dq2[r2] = *reinterpret_cast<const float2*>(a.dqkv + p * DQLD + R * q + 2 * r2);
+        const int cg = attn_half ? 0 : 4 * q - HC;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o.dgv[u] = a.dg[(b * HC + cg + u) * hw + s];
+    };
+    const long stride = (long)gridDim.x * PPW;
+    auto body = [&](long p, const Ops4& o) {
+        const float4 x4 = o.x4, dy4 = o.dy4;
         float dq[R];
 #pragma unroll
-        for (int r2 = 0; r2 < R / 2; ++r2) {
-            const float2 v = *reinterpret_cast<const float2*>(a.dqkv + p * DQLD + R * q + 2 * r2);
-            dq[2 * r2] = v.x; dq[2 * r2 + 1] = v.y;
-        }
-        float dgv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!attn_half) {
+        for (int r2 = 0; r2 < R / 2; ++r2) { dq[2 * r2] = o.dq2[r2].x; dq[2 * r2 + 1] = o.dq2[r2].y; }
+        float dgv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) dgv[u] = a.dg[(b * HC + (4 * q + u - HC)) * hw + s];
-        }
+        for (int u = 0; u < 4; ++u) dgv[u] = attn_half ? 0.f : o.dgv[u];
         // LayerNorm statistics over the pixel's E channels
         const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
         const float mu = lane_group_sum<LPP>((xv[0] + xv[1]) + (xv[2] + xv[3])) * (1.0f / E);
@@ -511,6 +520,20 @@ __global__ __launch_bounds__(256) void k_attn_bwd_epi(AttnBwdArgs a, long total)
                 acc[8 + R * HC + r] += dq[r];
             }
             __builtin_amdgcn_wave_barrier();     // ex is rewritten by the next pixel group
+        }
+    };
+    {
+        Ops4 oa, ob;
+        long p = (long)blockIdx.x * PPW + slot;          // total is a multiple of PPW (launcher): a group is whole or absent
+        if (p < total) issue(p, oa);
+        while (p < total) {
+            const long p1 = p + stride, p2 = p1 + stride;
+            issue(p1 < total ? p1 : p, ob);             // clamped: a repeat of the current group when there is no next one
+            body(p, oa);
+            if (p1 >= total) break;
+            issue(p2 < total ? p2 : p1, oa);
+            body(p1, ob);
+            p = p2;
         }
     }
     // lanes with equal q hold partials of the same outputs: across the wave, then the 4 waves in LDS (fixed order)
