@@ -131,6 +131,8 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
         const char* sv = getenv("LG_FFN_SAVE");
         const char* b32 = getenv("LG_FFN_BWD32");
         p->bwd32_old = (b32 && !strcmp(b32, "xs")) ? 0 : 1;   // default: the round-2 pair (k_ffn1_bwd_xs<32>: parity-green, measured 375 us against 203 + 121 us at C = 8)
+        const char* ab = getenv("LG_ATTN_BWD");
+        p->attn_bwd_old = (ab && !strcmp(ab, "old")) ? 1 : 0;
         const char* dwb = getenv("LG_FFN_DWBWD");
         p->dwbwd_tile = (dwb && !strcmp(dwb, "tile")) ? 1 : 0;
         p->save_mode = !sv ? 2 : (!strcmp(sv, "5") ? 5 : (!strcmp(sv, "3") ? 3 : 2));   // common.h: lg_plan::save_mode

@@ -294,3 +294,40 @@ constexpr bool attn_bwd_fuses_qkv(int e) { return LG_ATTN_FUSE_QKV && e == 16; }
 inline size_t attn_bwd_part_floats(int e) { return (size_t)PIXEL_PART_WGS * 2 * e + (attn_bwd_fuses_qkv(e) ? (size_t)1024 * ((3 * e / 2) * (e / 2) + 3 * e / 2) : 0); }
 int attn_bwd_grid(int e, int B, int h, int w);
 int launch_attn_bwd(int e, const AttnBwdArgs& a, hipStream_t s);
+
+// ---- round 4: the whole local-mixer half-block backward in one kernel (k_attn_bwd_f.hip; e = 16) ----
+// k_proj_o2_bwd_k runs first (the FFT-mixer backward needs do2): do2, ONE dropout keep-bit word per pixel instead of the masked copy of
+// dy, and the proj bias gradient; then k_attn_bwd_f: flash passes, to_qkv^T, LayerNorm backward, dx and every parameter gradient of the
+// half-block (pos_emb, to_qkv, proj, LayerNorm) without a pixel-sized intermediate in HBM.
+struct ProjO2BwdKArgs {
+    const float* dy;   // [P,e] grad wrt the mixer half-block output
+    float* do2;        // [B,e/2,h,w] planar grad wrt the global-mixer output
+    uint32_t* keep;    // [P] out: dropout keep bits (bit n = channel n kept); null = no dropout
+    const float* projw;
+    float* slab;       // PROJ_O2_K_WGS rows of e floats: proj bias gradient partials
+    float* d_projb;    // += by the deferred reduce launch
+    int HW;
+    long total;
+    uint64_t seed;
+};
+#define PROJ_O2_K_WGS 1024
+int launch_proj_o2_bwd_k(int e, const ProjO2BwdKArgs& a, hipStream_t s);
+struct AttnBwdFArgs {
+    const float* x;        // [P,e] block input
+    const float* dy;       // [P,e] grad wrt the mixer half-block output (unmasked)
+    const uint32_t* keep;  // [P] dropout keep bits written by k_proj_o2_bwd_k; null = no dropout
+    const float* o2;       // planar global-mixer output (proj input, for the proj weight gradient)
+    const float* dg;       // planar grad wrt LN1(x)[e/2:] (FFT-mixer backward)
+    float* dx;             // [P,e]
+    const float* pos;      // [2,64,64]
+    const float *ln1g, *ln1b, *qkvw, *qkvb, *projw;
+    float* slab;           // ATTN_BWD_F_WGS rows of ATTN_BWD_F_ROW floats: per-workgroup partial sums
+    float *d_pos, *d_qkvw, *d_qkvb, *d_projw, *d_ln1g, *d_ln1b;   // += by the deferred reduce launch
+    int B, h, w;
+};
+#define ATTN_BWD_F_WGS 256
+#define ATTN_BWD_F_WQ 8192            // row: pos_emb [2][64][64] | dWqkv [24][8] | dbqkv [24] | dWproj [16][16] | d gamma [16] | d beta [16]
+#define ATTN_BWD_F_ROW (8192 + 192 + 24 + 256 + 32)
+inline bool attn_bwd_fused(int e) { return e == 16; }
+int attn_bwd_f_grid(int B, int h, int w);
+int launch_attn_bwd_f(int e, const AttnBwdFArgs& a, hipStream_t s);

@@ -44,6 +44,7 @@ struct lg_plan {
     // default kernels with fp32 storage in both modes -- 'bf16' is never slower than the default (c3 / c5)
     bool hidden_bf16(int e) const { return cfg.precision == 1 && e != 64; }
     // precision = 'bf16' (plain bf16 MFMA, bf16 storage of the saved tensors) knows modes 2 and 5 only (3 falls back to 5)
+    int attn_bwd_old; // A/B switch: 1 = round 3's k_attn_bwd_core + k_attn_bwd_epi + k_wgrad_t at e = 16 instead of k_attn_bwd_f
     int bwd32_old; // A/B switch read ONCE at plan creation (env LG_FFN_BWD32=xs turns it off): 1 = k_ffn1_bwd_x32 + k_wgrad_t at e = 32 (default);
                    // 0 = k_ffn1_bwd_xs<32>, the e = 16 kernel's template at 8 waves / one workgroup per CU -- correct, but slower there
     bool ffn1_bwd_x32(int e) const { return e == 32 && ffn_tile == 0 && !bwd32_old; }

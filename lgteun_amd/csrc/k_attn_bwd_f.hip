@@ -1,0 +1,599 @@
+// Backward of the local-mixer half-block in ONE kernel (round 4; e = 16: the four level-0 blocks of the 4-band net) -- autograd of reference
+// models/common/LGT.py:112-146 (local_mixer), 183-219 (LGMixer: concat / proj / dropout), 45-61 (pre_norm, residual).
+//
+// Round 2/3 ran this as k_attn_bwd_core (one workgroup per window group AND head: dq / dk / dv "pieces" and the proj input to HBM, 235 MB)
+// -> k_attn_bwd_epi (reads them back: to_qkv^T, LayerNorm backward, dx; 185 MB) -> k_wgrad_t (proj weight gradient: dym and cat once
+// more), 184 + ~20 us and ~570 MB per level-0 block against a unit of ~135 MB (read x, dy, o2, dg; write dx).  Here nothing between
+// the flash passes and dx leaves the chip:
+//   * one workgroup = 8 waves = 4 windows x 2 heads (wave = (window slot, head)): the 64 pos_emb-gradient accumulators of a head stay
+//     in the registers of that head's wave across all windows, exactly as before (they are why ONE wave cannot carry both heads);
+//   * prologue and epilogue are split between the two waves of a window by TOKENS, not by head: lane = (token, channel half), each
+//     wave takes 32 tokens.  x / dy are read once per window (not once per head), LayerNorm sums are one DPP step, q / k / v of BOTH
+//     heads come out of the pair of lanes of a token (lane c computes head c) and go into the two waves' channel-major K / V / Q / dO
+//     tiles; the to_qkv^T partial sums of the two heads meet in LDS, the LayerNorm backward and dx are formed by the same lanes that
+//     read x, the global-mixer half (dg) joins there;
+//   * every weight gradient that is a sum over pixels of an outer product runs on the matrix pipe with the TOKEN axis as K
+//     (v_mfma_f32_16x16x4_f32: exact fp32 products, the same arithmetic as k_wgrad_t): dWqkv / dbqkv of a head = dqkv_h^T [12 x 64] .
+//     [y1 | 1] [64 x 9] (16 MFMAs per window and wave, the bias through a column of ones), dWproj = dym^T [16 x 32] . cat [32 x 16]
+//     (8 MFMAs; the two waves split the tokens).  The accumulators are 8 registers for the whole kernel; the 48 + 16 per-lane
+//     accumulators of k_attn_bwd_epi<16,true> are gone;
+//   * LayerNorm gamma / beta gradients: 16 per-lane sums in lane-owned LDS slots (two 16-byte read-modify-writes per window);
+//   * dropout: k_proj_o2_bwd_k (which has to run in front of the FFT-mixer backward anyway) stores ONE keep-bit word per pixel instead of
+//     the masked copy of dy (2 MB instead of 33.5 MB written and read back), and sums the proj bias gradient on the way.
+// Three workgroup barriers per window group (tiles complete / partial sums complete / LDS free for the next group).
+#include "kernels.h"
+#include "bwd_kernels.h"
+#include "mfma.h"
+
+namespace {
+constexpr int F_HC = 8, F_E = 16, F_D = 4, F_NS = 4, F_NW = 8;
+constexpr int F_PLD = 65;                       // padded pos_emb row: conflict-free for lane = query AND lane = key
+constexpr int F_Y1LD = 12;                      // [y1 (8) | 1 | 0 0 0] per token: B operand of the to_qkv weight-gradient product
+constexpr int F_QLD = 12;                       // staged dqkv rows of one head per token: A operand
+constexpr int F_WPS = 68;                       // lane-half stride of the dO weights (two lane-dependent addresses on different banks)
+// LDS map (floats)
+constexpr int F_OFF_WQ = 2 * 64 * F_PLD;        // [2 heads][12 rows = q c | k c | v c][8]
+constexpr int F_OFF_BQ = F_OFF_WQ + 192;        // [2][12] (+ pad)
+constexpr int F_OFF_WP = F_OFF_BQ + 32;         // [2 halves][8 n][8 = head * 4 + k], half stride F_WPS
+constexpr int F_OFF_LN = F_OFF_WP + 144;        // gamma[16] | beta[16]
+constexpr int F_OFF_WAVE = F_OFF_LN + 32;
+constexpr int F_PW = 2752;                      // per wave: K | V | Q | dO [4][64] each, stats [3][64], to_qkv^T partial [64][8], slots [4][64] float4
+constexpr int F_T_K = 0, F_T_V = 256, F_T_Q = 512, F_T_DO = 768, F_T_ST = 1024, F_T_PART = 1216, F_T_SLOT = 1728;
+constexpr int F_OFF_SLOT = F_OFF_WAVE + F_NW * F_PW;
+constexpr int F_PS = 1920;                      // per window slot: y1 image [64][12], cat image [64][16], (mu, rstd) [64][2]
+constexpr int F_S_Y1 = 0, F_S_CAT = 768, F_S_MR = 1792;
+constexpr int F_LDS_FLOATS = F_OFF_SLOT + F_NS * F_PS;
+static_assert(F_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+static_assert(F_OFF_WAVE % 4 == 0 && F_PW % 4 == 0 && F_PS % 4 == 0, "16-byte alignment of the LDS regions");
+
+__device__ __forceinline__ float dpp_xor1(float v) {   // the other lane of the token's pair
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_even(float v) {   // the even lane's value on both lanes of the pair
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xA0, 0xF, 0xF, true));   // quad_perm [0,0,2,2]
+}
+}  // namespace
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k_attn_bwd_f(AttnBwdFArgs a, int nwin, int ngroups) {
+    constexpr int HC = F_HC, E = F_E, D = F_D, PLD = F_PLD;
+    constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ws = wave >> 1, hd = wave & 1;
+    float* const sPosH = smem + hd * 64 * PLD;                 // pos_emb[hd][i][j] * log2(e)
+    float* const sWq = smem + F_OFF_WQ;
+    float* const sBq = smem + F_OFF_BQ;
+    float* const sWp = smem + F_OFF_WP;
+    float* const sLn = smem + F_OFF_LN;
+    float* const mine = smem + F_OFF_WAVE + wave * F_PW;       // this wave's region
+    float* const sK = mine + F_T_K;
+    float* const sV = mine + F_T_V;
+    float* const sQ = mine + F_T_Q;
+    float* const sDO = mine + F_T_DO;
+    float* const sSt = mine + F_T_ST;
+    float* const sSlot = mine + F_T_SLOT;
+    float* const slotw = smem + F_OFF_SLOT + ws * F_PS;        // this window slot's images
+    float* const sY1 = slotw + F_S_Y1;
+    float* const sCat = slotw + F_S_CAT;
+    float* const sMr = slotw + F_S_MR;
+
+    // ---- staging, once per workgroup
+    for (int i = threadIdx.x; i < 2 * 64 * 64; i += 512) {
+        const int h = i >> 12, ii = (i >> 6) & 63, j = i & 63;
+        smem[h * 64 * PLD + ii * PLD + j] = a.pos[i] * LOG2E;
+    }
+    if (threadIdx.x < 192) {   // sWq[h][third * 4 + c][k] = qkvw[third * HC + h * D + c][k]
+        const int h = threadIdx.x / 96, r = (threadIdx.x % 96) >> 3, k = threadIdx.x & 7;
+        sWq[threadIdx.x] = a.qkvw[((r >> 2) * HC + h * D + (r & 3)) * HC + k];
+    }
+    if (threadIdx.x < 24) {
+        const int h = threadIdx.x / 12, r = threadIdx.x % 12;
+        sBq[threadIdx.x] = a.qkvb[(r >> 2) * HC + h * D + (r & 3)];
+    }
+    if (threadIdx.x >= 256 && threadIdx.x < 256 + 128) {   // sWp[c][u][hk] = projw[HC * c + u][hk]   (hk = head * 4 + k: the attention columns of proj)
+        const int i = threadIdx.x - 256, c = i >> 6, u = (i >> 3) & 7, hk = i & 7;
+        sWp[c * F_WPS + u * 8 + hk] = a.projw[(HC * c + u) * E + hk];
+    }
+    if (threadIdx.x >= 448 && threadIdx.x < 448 + 32) {
+        const int i = threadIdx.x - 448;
+        sLn[i] = i < 16 ? a.ln1g[i] : a.ln1b[i - 16];
+    }
+    {   // LayerNorm-gradient slots of this lane
+        float4* sl = reinterpret_cast<float4*>(sSlot);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sl[v * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int nwx = a.w >> 3, nwy = a.h >> 3;
+    const long hw = (long)a.h * a.w;
+    const float scale = 0.5f;   // D^-1/2, D = 4
+    // pos_emb gradient: in pass 2 lane j owns column j of dS of THIS wave's head, accumulated in 64 registers across all windows
+    lg_v2f dpacc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) dpacc[i] = (lg_v2f){0.f, 0.f};
+    f32x4 accq = {0.f, 0.f, 0.f, 0.f};   // dWqkv / dbqkv of this head: D[row = third * 4 + c][col = k | 8 = bias]
+    f32x4 accp = {0.f, 0.f, 0.f, 0.f};   // dWproj partial: D[n][k]
+    const int mr = lane & 15, mg = lane >> 4;   // MFMA operand coordinates of this lane
+    // lane = (token of this wave's half of the window, channel half) in the prologue and the epilogue
+    const int tk = 32 * hd + (lane >> 1), ch = lane & 1;
+    __syncthreads();
+
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int win = grp * F_NS + ws;
+        const bool active = win < nwin;
+        // pixel of (window, token tk): plane index bT, offset in the plane sT, NHWC pixel pT.  Computed again in the epilogue rather than
+        // kept across the flash passes (6 registers at the kernel's peak)
+        auto pixel_of = [&](long& bT, long& sT) -> long {
+            const int wx = win % nwx, rr = win / nwx, wy = rr % nwy;
+            bT = rr / nwy;
+            sT = (long)(wy * 8 + (tk >> 3)) * a.w + wx * 8 + (tk & 7);
+            return bT * hw + sT;
+        };
+        if (active) {
+            long bT, sT;
+            const long pT = pixel_of(bT, sT);
+            // ---------------- prologue: lane = (token tk, channel half ch)
+            const float4* xs = reinterpret_cast<const float4*>(a.x + pT * E + HC * ch);
+            const float4* ds = reinterpret_cast<const float4*>(a.dy + pT * E + HC * ch);
+            const float4 x0 = xs[0], x1 = xs[1], d0 = ds[0], d1 = ds[1];
+            const uint32_t kw = a.keep ? a.keep[pT] : 0xffffffffu;
+            float xh[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            float sm = ((xh[0] + xh[1]) + (xh[2] + xh[3])) + ((xh[4] + xh[5]) + (xh[6] + xh[7]));
+            sm += dpp_xor1(sm);
+            const float mu = sm * (1.0f / E);
+            float vs = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { xh[u] -= mu; vs += xh[u] * xh[u]; }
+            vs += dpp_xor1(vs);
+            const float rstd = __builtin_amdgcn_rsqf(vs * (1.0f / E) + LG_EPS);
+            float y1[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y1[k] = dpp_even(xh[k] * rstd * sLn[k] + sLn[16 + k]);   // LN1(x)[:8] of the token on both lanes
+            // q, k, v of head `ch` for this token -> that head's wave tiles (channel-major [c][token])
+            float* const tile = smem + F_OFF_WAVE + (2 * ws + ch) * F_PW;
+            const float4* wq4 = reinterpret_cast<const float4*>(sWq + ch * 96);
+#pragma unroll
+            for (int r = 0; r < 12; ++r) {
+                const float4 wa = wq4[2 * r], wb = wq4[2 * r + 1];
+                float acc = sBq[ch * 12 + r];
+                acc += wa.x * y1[0]; acc += wa.y * y1[1]; acc += wa.z * y1[2]; acc += wa.w * y1[3];
+                acc += wb.x * y1[4]; acc += wb.y * y1[5]; acc += wb.z * y1[6]; acc += wb.w * y1[7];
+                if (r < 4) tile[F_T_Q + r * 64 + tk] = acc * (scale * LOG2E);   // scores live in the log2 domain
+                else if (r < 8) tile[F_T_K + (r - 4) * 64 + tk] = acc;
+                else tile[F_T_V + (r - 8) * 64 + tk] = acc;
+            }
+            // dO = (proj^T dym)[attention columns]: this lane's 8 channels of dym against both heads, then the pair adds up
+            const float dyv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            float pr[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pr[k] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float dm = ((kw >> (8 * ch + u)) & 1u) ? (a.keep ? dyv[u] * (1.0f / 0.9f) : dyv[u]) : 0.0f;
+                const float4 wa = *reinterpret_cast<const float4*>(sWp + ch * F_WPS + u * 8);
+                const float4 wb = *reinterpret_cast<const float4*>(sWp + ch * F_WPS + u * 8 + 4);
+                pr[0] += wa.x * dm; pr[1] += wa.y * dm; pr[2] += wa.z * dm; pr[3] += wa.w * dm;
+                pr[4] += wb.x * dm; pr[5] += wb.y * dm; pr[6] += wb.z * dm; pr[7] += wb.w * dm;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float send = ch ? pr[k] : pr[4 + k];     // what the other lane keeps
+                const float keepv = ch ? pr[4 + k] : pr[k];
+                tile[F_T_DO + k * 64 + tk] = keepv + dpp_xor1(send);
+            }
+            // y1 image of the window (B operand of the to_qkv weight-gradient product; column 8 = 1 carries the bias gradient)
+            float4* y4 = reinterpret_cast<float4*>(sY1 + tk * F_Y1LD);
+            if (ch == 0) {
+                y4[0] = make_float4(y1[0], y1[1], y1[2], y1[3]);
+                y4[1] = make_float4(y1[4], y1[5], y1[6], y1[7]);
+                *reinterpret_cast<float2*>(sMr + 2 * tk) = make_float2(mu, rstd);
+            } else {
+                y4[2] = make_float4(1.f, 0.f, 0.f, 0.f);
+            }
+        }
+        __syncthreads();   // B1: the tiles of every wave are complete
+        float dqkv[12];
+        if (active) {
+            // ---------------- pass 1: lane = query i, packed over KEY pairs (as k_attn_bwd_core)
+            float q[D], dOi[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) { q[c] = sQ[c * 64 + lane]; dOi[c] = sDO[c * 64 + lane]; }
+            const float* prow = sPosH + lane * PLD;
+            lg_v2f sc[32];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                lg_v2f sp0 = (lg_v2f){prow[4 * g], prow[4 * g + 1]}, sp1 = (lg_v2f){prow[4 * g + 2], prow[4 * g + 3]};
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    const float4 kv = reinterpret_cast<const float4*>(sK)[c * 16 + g];
+                    const lg_v2f qq = (lg_v2f){q[c], q[c]};
+                    sp0 = qq * (lg_v2f){kv.x, kv.y} + sp0;
+                    sp1 = qq * (lg_v2f){kv.z, kv.w} + sp1;
+                }
+                sc[2 * g] = sp0; sc[2 * g + 1] = sp1;
+                mx = fmaxf(mx, fmaxf(fmaxf(sp0.x, sp0.y), fmaxf(sp1.x, sp1.y)));
+                if (g & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("" ::: "memory");
+            lg_v2f l2 = (lg_v2f){0.f, 0.f};
+            const lg_v2f mx2 = (lg_v2f){mx, mx};
+#pragma unroll
+            for (int g = 0; g < 32; ++g) {
+                const lg_v2f t = sc[g] - mx2;
+                sc[g] = (lg_v2f){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                l2 += sc[g];
+            }
+            const float inv = __builtin_amdgcn_rcpf(l2.x + l2.y);
+            const lg_v2f inv2 = (lg_v2f){inv, inv};
+            lg_v2f O2[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) O2[c] = (lg_v2f){0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                sc[2 * g] *= inv2; sc[2 * g + 1] *= inv2;
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    const float4 vv = reinterpret_cast<const float4*>(sV)[c * 16 + g];
+                    O2[c] = sc[2 * g] * (lg_v2f){vv.x, vv.y} + O2[c];
+                    O2[c] = sc[2 * g + 1] * (lg_v2f){vv.z, vv.w} + O2[c];
+                }
+                if (g & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            float O[D];
+            float Dv = 0.f;   // D_i = sum_j P_ij dP_ij = dO_i . O_i
+#pragma unroll
+            for (int c = 0; c < D; ++c) { O[c] = O2[c].x + O2[c].y; Dv += dOi[c] * O[c]; }
+            asm volatile("" ::: "memory");   // re-read K / V from LDS below instead of keeping 64 x 2D values live
+            const lg_v2f Dv2 = (lg_v2f){Dv, Dv};
+            lg_v2f dq2[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) dq2[c] = (lg_v2f){0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                lg_v2f dP0 = (lg_v2f){0.f, 0.f}, dP1 = (lg_v2f){0.f, 0.f};
+                float4 kv[D];
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    const float4 vv = reinterpret_cast<const float4*>(sV)[c * 16 + g];
+                    kv[c] = reinterpret_cast<const float4*>(sK)[c * 16 + g];
+                    const lg_v2f dd = (lg_v2f){dOi[c], dOi[c]};
+                    dP0 = dd * (lg_v2f){vv.x, vv.y} + dP0;
+                    dP1 = dd * (lg_v2f){vv.z, vv.w} + dP1;
+                }
+                const lg_v2f dS0 = sc[2 * g] * (dP0 - Dv2), dS1 = sc[2 * g + 1] * (dP1 - Dv2);
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    dq2[c] = dS0 * (lg_v2f){kv[c].x, kv[c].y} + dq2[c];
+                    dq2[c] = dS1 * (lg_v2f){kv[c].z, kv[c].w} + dq2[c];
+                }
+                if (g & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int c = 0; c < D; ++c) dqkv[c] = (dq2[c].x + dq2[c].y) * scale;
+            // this head's attention output into the window's cat image (proj input: B operand of the proj weight-gradient product)
+            *reinterpret_cast<float4*>(sCat + lane * E + D * hd) = make_float4(O[0], O[1], O[2], O[3]);
+            sSt[lane] = mx;
+            sSt[64 + lane] = inv;
+            sSt[128 + lane] = Dv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the row statistics are this wave's own
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (active) {
+            // ---------------- pass 2: lane = key j, packed over QUERY pairs
+            float kj[D], vj[D];
+            lg_v2f dk2[D], dv2[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) { kj[c] = sK[c * 64 + lane]; vj[c] = sV[c * 64 + lane]; dk2[c] = (lg_v2f){0.f, 0.f}; dv2[c] = (lg_v2f){0.f, 0.f}; }
+            const float* pcol = sPosH + lane;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                lg_v2f t0 = (lg_v2f){pcol[(4 * g) * PLD], pcol[(4 * g + 1) * PLD]}, t1 = (lg_v2f){pcol[(4 * g + 2) * PLD], pcol[(4 * g + 3) * PLD]};
+                lg_v2f dP0 = (lg_v2f){0.f, 0.f}, dP1 = (lg_v2f){0.f, 0.f};
+                float4 qi[D], doi[D];
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    qi[c] = reinterpret_cast<const float4*>(sQ)[c * 16 + g];
+                    doi[c] = reinterpret_cast<const float4*>(sDO)[c * 16 + g];
+                    const lg_v2f kk = (lg_v2f){kj[c], kj[c]}, vv = (lg_v2f){vj[c], vj[c]};
+                    t0 = kk * (lg_v2f){qi[c].x, qi[c].y} + t0;
+                    t1 = kk * (lg_v2f){qi[c].z, qi[c].w} + t1;
+                    dP0 = vv * (lg_v2f){doi[c].x, doi[c].y} + dP0;
+                    dP1 = vv * (lg_v2f){doi[c].z, doi[c].w} + dP1;
+                }
+                const float4 smx = reinterpret_cast<const float4*>(sSt)[g];
+                const float4 sinv = reinterpret_cast<const float4*>(sSt)[16 + g];
+                const float4 sdv = reinterpret_cast<const float4*>(sSt)[32 + g];
+                const lg_v2f e0 = t0 - (lg_v2f){smx.x, smx.y}, e1 = t1 - (lg_v2f){smx.z, smx.w};
+                const lg_v2f P0 = (lg_v2f){__builtin_amdgcn_exp2f(e0.x), __builtin_amdgcn_exp2f(e0.y)} * (lg_v2f){sinv.x, sinv.y};
+                const lg_v2f P1 = (lg_v2f){__builtin_amdgcn_exp2f(e1.x), __builtin_amdgcn_exp2f(e1.y)} * (lg_v2f){sinv.z, sinv.w};
+                const lg_v2f dS0 = P0 * (dP0 - (lg_v2f){sdv.x, sdv.y}), dS1 = P1 * (dP1 - (lg_v2f){sdv.z, sdv.w});
+                dpacc[2 * g] += dS0;
+                dpacc[2 * g + 1] += dS1;
+                if (g & 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    dv2[c] = P0 * (lg_v2f){doi[c].x, doi[c].y} + dv2[c];
+                    dv2[c] = P1 * (lg_v2f){doi[c].z, doi[c].w} + dv2[c];
+                    dk2[c] = dS0 * (lg_v2f){qi[c].x, qi[c].y} + dk2[c];
+                    dk2[c] = dS1 * (lg_v2f){qi[c].z, qi[c].w} + dk2[c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < D; ++c) { dqkv[4 + c] = (dk2[c].x + dk2[c].y) * LN2; dqkv[8 + c] = dv2[c].x + dv2[c].y; }   // sQ carries log2(e)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // every lane is done with the wave's K / V / Q / dO tiles: they become the dqkv image
+        if (active) {
+            // ---------------- E1: lane = token: this head's share of to_qkv^T dqkv, and its to_qkv weight gradient on the matrix pipe
+            float pt[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pt[k] = 0.f;
+            const float4* wq4 = reinterpret_cast<const float4*>(sWq + hd * 96);
+#pragma unroll
+            for (int r = 0; r < 12; ++r) {
+                const float4 wa = wq4[2 * r], wb = wq4[2 * r + 1];
+                pt[0] += wa.x * dqkv[r]; pt[1] += wa.y * dqkv[r]; pt[2] += wa.z * dqkv[r]; pt[3] += wa.w * dqkv[r];
+                pt[4] += wb.x * dqkv[r]; pt[5] += wb.y * dqkv[r]; pt[6] += wb.z * dqkv[r]; pt[7] += wb.w * dqkv[r];
+            }
+            float4* pp = reinterpret_cast<float4*>(mine + F_T_PART + lane * 8);
+            pp[0] = make_float4(pt[0], pt[1], pt[2], pt[3]);
+            pp[1] = make_float4(pt[4], pt[5], pt[6], pt[7]);
+            float4* st = reinterpret_cast<float4*>(mine + lane * F_QLD);   // dqkv image [token][12] over the (dead) tiles
+            st[0] = make_float4(dqkv[0], dqkv[1], dqkv[2], dqkv[3]);
+            st[1] = make_float4(dqkv[4], dqkv[5], dqkv[6], dqkv[7]);
+            st[2] = make_float4(dqkv[8], dqkv[9], dqkv[10], dqkv[11]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (active) {
+            // dW_h[r][k] += sum_tokens dqkv[token][r] * [y1 | 1][token][k]: token 4 s + mg is the MFMA's k index of lane (mr, mg)
+            const bool live = mr < 12;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int tok = 4 * s + mg;
+                float av = mine[tok * F_QLD + mr], bv = sY1[tok * F_Y1LD + mr];
+                av = live ? av : 0.f;
+                bv = live ? bv : 0.f;
+                accq = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accq, 0, 0, 0);
+            }
+        }
+        __syncthreads();   // B2: both heads' partial sums and attention outputs of the window are in LDS
+        if (active) {
+            // ---------------- E3: lane = (token tk, channel half ch): join the halves, LayerNorm backward, dx; proj weight gradient
+            long bT, sT;
+            const long pT = pixel_of(bT, sT);
+            const float4* xs = reinterpret_cast<const float4*>(a.x + pT * E + HC * ch);
+            const float4* ds = reinterpret_cast<const float4*>(a.dy + pT * E + HC * ch);
+            const float4 x0 = xs[0], x1 = xs[1], d0 = ds[0], d1 = ds[1];
+            const uint32_t kw = a.keep ? a.keep[pT] : 0xffffffffu;
+            float dgv[8], o2v[4];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dgv[k] = a.dg[(bT * HC + k) * hw + sT];           // both lanes of the pair ask for the same address
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o2v[k] = a.o2[(bT * HC + 4 * ch + k) * hw + sT];   // lane ch stages o2 channels [4 ch, 4 ch + 4)
+            const float2 mrs = *reinterpret_cast<const float2*>(sMr + 2 * tk);
+            const float mu = mrs.x, rstd = mrs.y;
+            const float4* pa = reinterpret_cast<const float4*>(smem + F_OFF_WAVE + (2 * ws) * F_PW + F_T_PART + tk * 8);
+            const float4* pb = reinterpret_cast<const float4*>(smem + F_OFF_WAVE + (2 * ws + 1) * F_PW + F_T_PART + tk * 8);
+            const float4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+            const float att[8] = {a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w, a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w};
+            const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            const float dyv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            float xh[8], dyf[8], gg[8];
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                xh[u] = (xv[u] - mu) * rstd;
+                dyf[u] = ch ? dgv[u] : att[u];
+                gg[u] = dyf[u] * sLn[8 * ch + u];
+                m1 += gg[u];
+                m2 += gg[u] * xh[u];
+            }
+            m1 += dpp_xor1(m1);
+            m2 += dpp_xor1(m2);
+            m1 *= (1.0f / E);
+            m2 *= (1.0f / E);
+            float4* dxo = reinterpret_cast<float4*>(a.dx + pT * E + HC * ch);   // residual with the UNMASKED upstream gradient
+            dxo[0] = make_float4(dyv[0] + rstd * (gg[0] - m1 - xh[0] * m2), dyv[1] + rstd * (gg[1] - m1 - xh[1] * m2),
+                                 dyv[2] + rstd * (gg[2] - m1 - xh[2] * m2), dyv[3] + rstd * (gg[3] - m1 - xh[3] * m2));
+            dxo[1] = make_float4(dyv[4] + rstd * (gg[4] - m1 - xh[4] * m2), dyv[5] + rstd * (gg[5] - m1 - xh[5] * m2),
+                                 dyv[6] + rstd * (gg[6] - m1 - xh[6] * m2), dyv[7] + rstd * (gg[7] - m1 - xh[7] * m2));
+            {   // d gamma / d beta of this lane's 8 channels: lane-owned slots
+                float4* sl = reinterpret_cast<float4*>(sSlot);
+                float4 s0 = sl[lane], s1 = sl[64 + lane], s2 = sl[128 + lane], s3 = sl[192 + lane];
+                s0.x += dyf[0] * xh[0]; s0.y += dyf[1] * xh[1]; s0.z += dyf[2] * xh[2]; s0.w += dyf[3] * xh[3];
+                s1.x += dyf[4] * xh[4]; s1.y += dyf[5] * xh[5]; s1.z += dyf[6] * xh[6]; s1.w += dyf[7] * xh[7];
+                s2.x += dyf[0]; s2.y += dyf[1]; s2.z += dyf[2]; s2.w += dyf[3];
+                s3.x += dyf[4]; s3.y += dyf[5]; s3.z += dyf[6]; s3.w += dyf[7];
+                sl[lane] = s0; sl[64 + lane] = s1; sl[128 + lane] = s2; sl[192 + lane] = s3;
+            }
+            // dym image [32 tokens of this wave][16] over the tiles (the dqkv image was consumed in front of B2), o2 into the cat image
+            float dm[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dm[u] = ((kw >> (8 * ch + u)) & 1u) ? (a.keep ? dyv[u] * (1.0f / 0.9f) : dyv[u]) : 0.0f;
+            float4* dst = reinterpret_cast<float4*>(mine + (lane >> 1) * E + HC * ch);
+            dst[0] = make_float4(dm[0], dm[1], dm[2], dm[3]);
+            dst[1] = make_float4(dm[4], dm[5], dm[6], dm[7]);
+            *reinterpret_cast<float4*>(sCat + tk * E + HC + 4 * ch) = make_float4(o2v[0], o2v[1], o2v[2], o2v[3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (active) {
+            // dWproj[n][k] += sum over this wave's 32 tokens of dym[token][n] * cat[token][k]
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int tl = 4 * s + mg;
+                accp = __builtin_amdgcn_mfma_f32_16x16x4f32(mine[tl * E + mr], sCat[(32 * hd + tl) * E + mr], accp, 0, 0, 0);
+            }
+        }
+        __syncthreads();   // B3: tiles and images are free for the next window group
+    }
+
+    // ---------------- write-out: one slab row per workgroup, summed over the workgroups by the deferred reduce launch
+    float* const row = a.slab + (size_t)blockIdx.x * ATTN_BWD_F_ROW;
+    float* const sRed = smem;                 // pos_emb is dead: [8 waves][32] LayerNorm sums | [8][256] accq | [8][256] accp
+    {
+        const float4* sl = reinterpret_cast<const float4*>(sSlot);
+        const float4 s0 = sl[lane], s1 = sl[64 + lane], s2 = sl[128 + lane], s3 = sl[192 + lane];
+        float v[16] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w, s3.x, s3.y, s3.z, s3.w};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+#pragma unroll
+            for (int off = 2; off < 64; off <<= 1) v[i] += __shfl_xor(v[i], off);   // lanes of equal parity = equal channel half
+        }
+        if (lane < 2) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { sRed[wave * 32 + 8 * lane + u] = v[u]; sRed[wave * 32 + 16 + 8 * lane + u] = v[8 + u]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // accumulator element i of lane (mr, mg) = D[4 mg + i][mr]
+            sRed[256 + wave * 256 + (4 * mg + i) * 16 + mr] = accq[i];
+            sRed[256 + 2048 + wave * 256 + (4 * mg + i) * 16 + mr] = accp[i];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ATTN_BWD_F_ROW - ATTN_BWD_F_WQ; i += 512) {
+        float v = 0.f;
+        if (i < 192 + 24) {          // dWqkv [24][8] | dbqkv [24]: the four waves of the row's head
+            const int rowq = i < 192 ? i >> 3 : i - 192, k = i < 192 ? (i & 7) : 8;
+            const int third = rowq / HC, h = (rowq % HC) / D, c = rowq % D;
+#pragma unroll
+            for (int s4 = 0; s4 < F_NS; ++s4) v += sRed[256 + (2 * s4 + h) * 256 + (third * 4 + c) * 16 + k];
+        } else if (i < 192 + 24 + 256) {   // dWproj [16][16]
+            const int j = i - 216;
+#pragma unroll
+            for (int w8 = 0; w8 < F_NW; ++w8) v += sRed[256 + 2048 + w8 * 256 + j];
+        } else {                     // d gamma [16] | d beta [16]
+            const int j = i - 472;
+#pragma unroll
+            for (int w8 = 0; w8 < F_NW; ++w8) v += sRed[w8 * 32 + j];
+        }
+        row[ATTN_BWD_F_WQ + i] = v;
+    }
+    // pos_emb gradient of this workgroup: the four waves of a head add their column sums in a fixed order (over the per-wave regions)
+    float* const sDp = smem + F_OFF_WAVE + hd * 64 * PLD;
+    for (int turn = 0; turn < F_NS; ++turn) {
+        __syncthreads();
+        if (ws == turn) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                const float v = (i & 1) ? dpacc[i >> 1].y : dpacc[i >> 1].x;
+                if (turn == 0) sDp[i * PLD + lane] = v;
+                else sDp[i * PLD + lane] += v;
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * 64 * 64; idx += 512)
+        row[idx] = smem[F_OFF_WAVE + (idx >> 12) * 64 * PLD + ((idx >> 6) & 63) * PLD + (idx & 63)];
+}
+
+// ------------------------------------------------------------------------------------------------
+// proj backward towards the global-mixer half, in front of the FFT-mixer backward: do2[b,c,y,x] = sum_n projw[n][e/2+c] dym[p][n] with
+// dym = dropout mask * dy.  Writes ONE keep-bit word per pixel (bit n = channel n kept) for k_attn_bwd_f instead of dym, and sums the
+// proj bias gradient db[n] = sum_p dym[p][n] on the way (one partial row per workgroup).  One lane per pixel: the planar output wants it.
+// ------------------------------------------------------------------------------------------------
+template <int E>
+__global__ __launch_bounds__(256) void k_proj_o2_bwd_k(ProjO2BwdKArgs a) {
+    constexpr int HC = E / 2;
+    __shared__ float sProj[E * HC];   // [n][c] = projw[n][HC + c]
+    __shared__ float red[4][E];
+    for (int i = threadIdx.x; i < E * HC; i += 256) sProj[i] = a.projw[(i / HC) * E + HC + (i % HC)];
+    __syncthreads();
+    float db[E];
+#pragma unroll
+    for (int n = 0; n < E; ++n) db[n] = 0.f;
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < a.total; p += (long)gridDim.x * 256L) {
+        const long b = p / a.HW, s = p - b * a.HW;
+        float dy[E];
+        const float4* src = reinterpret_cast<const float4*>(a.dy + p * E);
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k) {
+            const float4 v = src[k];
+            dy[4 * k] = v.x; dy[4 * k + 1] = v.y; dy[4 * k + 2] = v.z; dy[4 * k + 3] = v.w;
+        }
+        if (a.keep) {
+            uint32_t kw = 0;
+#pragma unroll
+            for (int n = 0; n < E; ++n) {
+                const bool kept = dropout_scale(a.seed, (uint64_t)(p * E + n)) != 0.0f;
+                kw |= kept ? (1u << n) : 0u;
+                dy[n] = kept ? dy[n] * (1.0f / 0.9f) : 0.0f;
+            }
+            a.keep[p] = kw;
+        }
+#pragma unroll
+        for (int n = 0; n < E; ++n) db[n] += dy[n];
+#pragma unroll
+        for (int c = 0; c < HC; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int n = 0; n < E; ++n) acc += sProj[n * HC + c] * dy[n];
+            a.do2[(b * HC + c) * a.HW + s] = acc;
+        }
+    }
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+#pragma unroll
+    for (int n = 0; n < E; ++n) {
+        float v = db[n];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (ln == 0) red[wv][n] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < E) a.slab[(size_t)blockIdx.x * E + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+int attn_bwd_f_grid(int B, int h, int w) {
+    const int nwin = B * (h / 8) * (w / 8);
+    const int ngroups = (nwin + F_NS - 1) / F_NS;
+    return ngroups < ATTN_BWD_F_WGS ? ngroups : ATTN_BWD_F_WGS;   // one resident workgroup (8 waves, 150 KB of LDS) per CU
+}
+
+int launch_attn_bwd_f(int e, const AttnBwdFArgs& a, hipStream_t s) {
+    ProfScope prof__(LG_K_ATTN_BWD, s);
+    if (e != 16) { lg_set_error("attn_bwd_f: e=%d unsupported", e); return -1; }
+    if ((a.h & 7) || (a.w & 7)) { lg_set_error("attn_bwd_f: h,w must be multiples of 8"); return -2; }
+    if (!a.slab || !a.d_pos || !a.d_qkvw || !a.d_qkvb || !a.d_projw || !a.d_ln1g || !a.d_ln1b) { lg_set_error("attn_bwd_f: null destination"); return -2; }
+    const int nwin = a.B * (a.h / 8) * (a.w / 8);
+    const int ngroups = (nwin + F_NS - 1) / F_NS;
+    const size_t lds = (size_t)F_LDS_FLOATS * sizeof(float);
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
+        hipError_t er = hipFuncSetAttribute((const void*)k_attn_bwd_f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (er != hipSuccess) { lg_set_error("attn_bwd_f: hipFuncSetAttribute: %s", hipGetErrorString(er)); return (int)er; }
+        attr_once.done();
+    }
+    const int grid = attn_bwd_f_grid(a.B, a.h, a.w);
+    k_attn_bwd_f<<<grid, 512, lds, s>>>(a, nwin, ngroups);
+    LG_CHECK_LAUNCH();
+    // partial rows -> gradients (+=), in the block's deferred reduce launch
+    ReduceJob j;
+    j.dst2 = nullptr; j.nslices = grid; j.slice_stride = ATTN_BWD_F_ROW;
+    auto job = [&](int off, float* dst, int rows, int cols) {
+        j.slab = a.slab + off; j.dst = dst; j.rows = rows; j.cols = cols; j.row_stride = cols; j.ld = cols; j.rows_valid = rows; j.cols_valid = cols;
+        return launch_reduce_job(j, s);
+    };
+    int rc = job(0, a.d_pos, 1, 2 * 64 * 64);
+    if (!rc) rc = job(ATTN_BWD_F_WQ, a.d_qkvw, 3 * F_HC, F_HC);
+    if (!rc) rc = job(ATTN_BWD_F_WQ + 192, a.d_qkvb, 1, 3 * F_HC);
+    if (!rc) rc = job(ATTN_BWD_F_WQ + 216, a.d_projw, F_E, F_E);
+    if (!rc) rc = job(ATTN_BWD_F_WQ + 472, a.d_ln1g, 1, F_E);
+    if (!rc) rc = job(ATTN_BWD_F_WQ + 488, a.d_ln1b, 1, F_E);
+    return rc;
+}
+
+int launch_proj_o2_bwd_k(int e, const ProjO2BwdKArgs& a, hipStream_t s) {
+    if (e != 16) { lg_set_error("proj_o2_bwd_k: e=%d unsupported", e); return -1; }
+    const long nb = (a.total + 255) / 256;
+    const int grid = (int)(nb < PROJ_O2_K_WGS ? nb : PROJ_O2_K_WGS);
+    k_proj_o2_bwd_k<16><<<grid, 256, 0, s>>>(a);
+    LG_CHECK_LAUNCH();
+    ReduceJob j;
+    j.slab = a.slab; j.dst = a.d_projb; j.dst2 = nullptr; j.nslices = grid; j.slice_stride = e;
+    j.rows = 1; j.cols = e; j.row_stride = e; j.ld = e; j.rows_valid = 1; j.cols_valid = e;
+    return launch_reduce_job(j, s);
+}

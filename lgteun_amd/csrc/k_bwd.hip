@@ -197,6 +197,30 @@ static int mixer_half_bwd(const lg_plan* pl, const float* P, float* G, int st, i
     const int e = fb.e, hc = e / 2;
     const long Pn = (long)B * fb.h * fb.w;
     const int drop = (flags & LG_FLAG_DROPOUT) ? 1 : 0;
+    if (attn_bwd_fused(e) && !pl->attn_bwd_old) {
+        // round 4: three launches per half-block -- proj^T towards the global mixer (+ dropout keep bits, proj bias gradient), the FFT-mixer
+        // backward, and ONE kernel for everything else (flash passes, to_qkv^T, LayerNorm backward, dx, every parameter gradient)
+        uint32_t* keep = drop ? reinterpret_cast<uint32_t*>(bb.dym) : nullptr;
+        ProjO2BwdKArgs pk;
+        pk.dy = tmp; pk.do2 = bb.do2; pk.keep = keep; pk.projw = P + pl->blk(st, j, B_PROJW);
+        pk.slab = bb.rq.take((size_t)PROJ_O2_K_WGS * e);
+        if (!pk.slab) return -3;
+        pk.d_projb = G + pl->blk(st, j, B_PROJB); pk.HW = fb.h * fb.w; pk.total = Pn; pk.seed = mix_seed(seed, st, j);
+        RC(launch_proj_o2_bwd_k(e, pk, s));
+        float* fpart = bb.rq.take(fft_bwd_part_floats(B * hc, fb.h, fb.w));
+        if (!fpart) return -3;
+        RC(fft_bwd_call(pl, P, G, st, j, fb, bb.do2, bb.dg, B, s, bb.fft_scratch, fpart));
+        AttnBwdFArgs af;
+        af.x = fb.xin; af.dy = tmp; af.keep = keep; af.o2 = fb.o2; af.dg = bb.dg; af.dx = dx_out;
+        af.pos = P + pl->blk(st, j, B_POS);
+        af.ln1g = P + pl->blk(st, j, B_LN1G); af.ln1b = P + pl->blk(st, j, B_LN1B);
+        af.qkvw = P + pl->blk(st, j, B_QKVW); af.qkvb = P + pl->blk(st, j, B_QKVB); af.projw = P + pl->blk(st, j, B_PROJW);
+        af.slab = bb.dpos_slab;   // 512 * 8192 floats: untouched until the block's flush
+        af.d_pos = G + pl->blk(st, j, B_POS); af.d_qkvw = G + pl->blk(st, j, B_QKVW); af.d_qkvb = G + pl->blk(st, j, B_QKVB);
+        af.d_projw = G + pl->blk(st, j, B_PROJW); af.d_ln1g = G + pl->blk(st, j, B_LN1G); af.d_ln1b = G + pl->blk(st, j, B_LN1B);
+        af.B = B; af.h = fb.h; af.w = fb.w;
+        return launch_attn_bwd_f(e, af, s);
+    }
     ProjO2BwdArgs po;
     po.dy = tmp; po.do2 = bb.do2; po.dym = drop ? bb.dym : nullptr; po.projw = P + pl->blk(st, j, B_PROJW);
     po.HW = fb.h * fb.w; po.total = Pn; po.dropout = drop; po.seed = mix_seed(seed, st, j);

@@ -351,3 +351,58 @@ def test_ffn_backward_ab_paths_agree_with_the_default(env, monkeypatch):
         o, n = eng.offsets[i], eng.params[i].numel()
         a, b = g0[o:o + n].double(), g1[o:o + n].double()
         assert float((a - b).norm()) <= 5e-6 * float(a.norm()) + 1e-12, (env, eng.names[i], float((a - b).norm()), float(a.norm()))
+
+
+@pytest.mark.parametrize('drop', [False, True])
+def test_fused_attention_backward_agrees_with_the_round3_path(drop, monkeypatch):
+    """k_attn_bwd_f (round 4: the local-mixer half-block backward in one kernel, dropout through one keep-bit word per pixel written by
+    k_proj_o2_bwd_k) against round 3's k_attn_bwd_core + k_attn_bwd_epi + k_wgrad_t on a whole train step, with and without dropout
+    (same counter seed: the two paths must apply the same mask): every live gradient tensor to rounding"""
+    from gpu_helpers import make_module
+    from lgteun_amd.engine import LG_FLAG_DROPOUT, LG_FLAG_SAVE, LG_FLAG_FAITHFUL
+    ms, pan, gt = (T(a).cuda() for a in dw.make_inputs(3, 4, 16, 24, seed=12, kind='smooth'))
+    flags = (LG_FLAG_DROPOUT if drop else 0) | LG_FLAG_SAVE | LG_FLAG_FAITHFUL
+    gen = torch.Generator(device='cpu').manual_seed(6)
+
+    def grads():
+        net = make_module(4, 2)
+        eng = net.engine()
+        y, saved = eng.forward_raw(ms, pan, flags, seed=4321)
+        r = torch.randn(y.shape, generator=torch.Generator(device='cpu').manual_seed(6)).cuda()
+        g = torch.zeros_like(eng.flat)
+        eng.backward_raw(saved, r, g, flags, seed=4321)
+        return g, eng
+    monkeypatch.delenv('LG_ATTN_BWD', raising=False)
+    g1, eng = grads()
+    monkeypatch.setenv('LG_ATTN_BWD', 'old')                       # read once per plan: a fresh module builds a fresh plan
+    g0, _ = grads()
+    assert float(g0.abs().max()) > 0
+    for i in eng.live_idx:
+        o, n = eng.offsets[i], eng.params[i].numel()
+        a, b = g0[o:o + n].double(), g1[o:o + n].double()
+        tol = 2e-4 if eng.names[i].endswith(('pos_emb', 'conv_amp.0.bias', 'conv_pha.0.bias')) else 2e-5   # the cancelling sums
+        assert float((a - b).norm()) <= tol * float(a.norm()) + 1e-10, (drop, eng.names[i], float((a - b).norm()), float(a.norm()))
+
+
+@pytest.mark.parametrize('B,h,w', [(1, 16, 16), (1, 16, 32), (3, 16, 48), (5, 32, 32), (5, 128, 128)])
+def test_mixer_backward_kernel_at_awkward_shapes(B, h, w):
+    """the fused local-mixer backward in isolation against the fp64 oracle at sizes that exercise its edges: one window group (a single workgroup), two,
+    rectangular planes with an odd batch, and more window groups (320) than resident workgroups (256: some walk two groups)"""
+    from gpu_helpers import Ops, make_module
+    C = 4
+    net = make_module(C, 1)
+    ops = Ops(net, h, w)
+    e = 4 * C
+    rng = np.random.default_rng(2000 + h + w)
+    x = T(rng.standard_normal((B, h, w, e)).astype(np.float32))
+    dy = T(rng.standard_normal((B, h, w, e)).astype(np.float32))
+    P64 = det_params(C, 1, dtype=torch.float64, requires_grad=True)
+    want_dx, want_g = _oracle_block(P64, C, 0, 1, x.double(), dy.double())
+    got_dx, flat = ops.block_bwd(0, 0, 1, x.cuda(), dy.cuda())
+    assert rel_l2(got_dx.cpu(), want_dx) < 1e-4, rel_l2(got_dx.cpu(), want_dx)
+    assert len(want_g) == 11, sorted(want_g)     # pos_emb, to_qkv w/b, conv_amp w/b, conv_pha w/b, proj w/b, LayerNorm pair
+    for k, g in want_g.items():
+        got = ops.grad_of(flat, k).cpu().numpy()
+        ref = g.numpy()
+        err = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+        assert err < (2e-3 if 'global_mixer' in k else 1e-4), (k, err)

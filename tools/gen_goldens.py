@@ -109,18 +109,66 @@ def round3(R, manifest):
         print('grad64_' + name[5:], len([k for k in out if k.startswith('g64/')]), 'tensors', flush=True)
 
 
+def round4(R, manifest):
+    """Round-4 fixture: how well the REFERENCE'S OWN fp32 arithmetic knows the cancelling-sum gradient kinds -> tests/golden/gradnoise.json.
+    For each of the five cases and kinds: (a) `ref_vs_fp64`, the distance of the reference's fp32 gradients to its fp64 gradients (relative
+    L2 over the kind's live tensors; the number round 3's gate was built on), and (b) `ref_spread`, how far the reference's fp32 gradients
+    MOVE when every input value is nudged to a neighbouring float (4 draws of random +-1 ulp on ms and pan, seeded), on the same scale.
+    (b) is 5 ... 40 x (a) in the cases where (a) is small: the network is piecewise continuous (torch.angle's branch cut, abs() of the irfft2
+    output) and these kinds cancel to ~1e-5 of their terms, so one fp32 evaluation lands anywhere in a band of width (b) around the fp64
+    value and a small (a) is a lucky draw, not a property of the arithmetic.  The gate of tests/test_gpu_benchsize.py is per case
+    3 x max(a, rms of b)."""
+    out = {}
+    for name in ('grad_c4_k4_p128', 'grad_c8_k4_p128', 'grad_c4_k2_p80x48', 'grad_c4_k2_p208x176', 'grad_c8_k8_p256'):
+        cs = manifest[name]
+        C, K, B, h, w = cs['C'], cs['K'], cs['B'], cs['h'], cs['w']
+        ms, pan, gt = dw.make_inputs(B, C, h, w, seed=cs['seed'], kind=cs['kind'])
+        g64 = np.load(os.path.join(GOLD, 'grad64_' + name[5:] + '.npz'))
+
+        def grads32(ms_, pan_):
+            net, _ = build_ref(R, C, K, dtype=torch.float32)
+            loss = torch.nn.L1Loss()(net(t(ms_), t(pan_)), t(gt))
+            loss.backward()
+            return {k: p.grad.numpy().astype(np.float64) for k, p in net.named_parameters() if p.grad is not None and k.endswith(R3_KINDS)}
+
+        def nudge(a, rng):
+            up = rng.integers(0, 2, a.shape).astype(bool)
+            return np.where(up, np.nextafter(a, np.float32(4.0)), np.nextafter(a, np.float32(-4.0))).astype(np.float32)
+
+        base = grads32(ms, pan)
+        rng = np.random.default_rng(1000 + cs['seed'])
+        runs = [grads32(nudge(ms, rng), nudge(pan, rng)) for _ in range(4)]
+        out[name] = {}
+        for kd in R3_KINDS:
+            ks = [k for k in base if k.endswith(kd)]
+            t64 = {k: g64['g64/' + k.replace('.', '/')] for k in ks}
+            den = sum(float((t64[k] ** 2).sum()) for k in ks) ** 0.5
+            ref = sum(float(((base[k] - t64[k]) ** 2).sum()) for k in ks) ** 0.5 / den
+            sp = [sum(float(((r[k] - base[k]) ** 2).sum()) for k in ks) ** 0.5 / den for r in runs]
+            out[name][kd] = dict(ref_vs_fp64=ref, ref_spread=sp, ref_spread_rms=float(np.sqrt(np.mean(np.square(sp)))))
+            print(name, kd.ljust(34), f'ref32-vs-fp64 {ref:.3e}   spread under +-1 ulp inputs', ' '.join(f'{v:.3e}' for v in sp), flush=True)
+    with open(os.path.join(GOLD, 'gradnoise.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--check', action='store_true')
     ap.add_argument('--only-r3', action='store_true', help='write only the round-3 fixtures (fp64 gradients of the cancelling-sum kinds)')
     ap.add_argument('--only-r2', action='store_true', help='write only the round-2 fixtures (bench-size / configs[4] / non-pow2 '
                                                             'gradients); the manifest is merged, round-1 files are left alone')
+    ap.add_argument('--only-r4', action='store_true', help='write only the round-4 fixture (the reference fp32 gradients\' own noise band)')
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = import_reference()
     manifest = {}
+    if args.only_r4:
+        with open(os.path.join(GOLD, 'manifest.json')) as f:
+            manifest = json.load(f)
+        round4(R, manifest)
+        return
     if args.only_r3:
         with open(os.path.join(GOLD, 'manifest.json')) as f:
             manifest = json.load(f)
@@ -259,6 +307,8 @@ def main():
     round2(R, manifest)
     with open(os.path.join(GOLD, 'manifest.json'), 'w') as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
+    round3(R, manifest)
+    round4(R, manifest)
     print('wrote', GOLD)
 
 
