@@ -72,7 +72,25 @@ typedef struct lg_config {
                       * of two up to 512 take the radix-2 FFT paths (plane in LDS up to 128, split above); everything else
                       * (400x400 full-resolution scenes, rectangles) the Bluestein path -- same results, slower mixer */
     int32_t precision; /* 0 = fp32 storage/compute (parity mode); 1 = bf16 storage of FFN hidden tensors */
+    uint32_t variant;  /* 0 = the product path.  LG_VAR_* bits select A/B kernels that compute the SAME function (tests compare them with
+                        * the default; the library itself reads no environment variable).  Bits this build does not carry are rejected. */
 } lg_config;
+
+/* lg_config.variant: A/B switches (all default off) */
+#define LG_VAR_FFN_IMPL_MASK 3u   /* fused FFN forward: 0 = split-bf16 kernels; 1 = the exact f32-MFMA strip kernel (v_mfma_f32_16x16x4_f32: bit
+                                   * for bit an fp32 fma chain -- the yardstick of the arithmetic-criterion test); 2 = round 1's per-tile
+                                   * f32-MFMA kernel, 3 = the software-pipelined split kernel (both only in `make AB=1` builds) */
+#define LG_VAR_FFN_STRIP 1u
+#define LG_VAR_FFN_TILE 2u
+#define LG_VAR_FFN_XP 3u
+#define LG_VAR_FFN_SAVE_MASK (3u << 2) /* what the live stage's e = 16 FFN keeps for the backward: 0 = h2, h3 (default); 1 = h1, h2, h3; 2 = the
+                                        * five-tensor GELU-free form */
+#define LG_VAR_FFN_SAVE3 (1u << 2)
+#define LG_VAR_FFN_SAVE5 (2u << 2)
+#define LG_VAR_FFN_BWD32_XS (1u << 4)   /* e = 32 FFN backward: the e = 16 kernel's template instance instead of the default pair */
+#define LG_VAR_FFN_DWBWD_TILE (1u << 5) /* e = 16 FFN backward, spatial half: round 2's tile kernel + weight-gradient launch */
+#define LG_VAR_ATTN_BWD_R3 (1u << 6)    /* e = 16 local-mixer backward: round 3's three-kernel form instead of k_attn_bwd_f */
+#define LG_VAR_ALL 0x7fu
 
 typedef struct lg_plan lg_plan; /* host-side, immutable after creation */
 

@@ -23,7 +23,28 @@ KERNEL_IDS = {n: i for i, n in enumerate(['none', 'ffn1', 'ffn', 'fft', 'attn', 
 
 
 class LgConfig(ctypes.Structure):
-    _fields_ = [('C', c_int32), ('K', c_int32), ('H', c_int32), ('W', c_int32), ('precision', c_int32)]
+    _fields_ = [('C', c_int32), ('K', c_int32), ('H', c_int32), ('W', c_int32), ('precision', c_int32), ('variant', ctypes.c_uint32)]
+
+
+# lg_config.variant bits (include/lgteun_hip.h): A/B kernels that compute the same function as the product path
+LG_VAR_FFN_STRIP, LG_VAR_FFN_TILE, LG_VAR_FFN_XP = 1, 2, 3
+LG_VAR_FFN_SAVE3, LG_VAR_FFN_SAVE5 = 1 << 2, 2 << 2
+LG_VAR_FFN_BWD32_XS, LG_VAR_FFN_DWBWD_TILE, LG_VAR_ATTN_BWD_R3 = 1 << 4, 1 << 5, 1 << 6
+
+
+def variant_from_env(env=None):
+    """the variant word of a new plan from the diagnostic LG_* environment variables (read HERE, on the Python side, when an Engine
+    builds a plan -- the shared library itself never looks at the environment).  Unset = 0 = the product path."""
+    env = os.environ if env is None else env
+    v = {'strip': LG_VAR_FFN_STRIP, 'tile': LG_VAR_FFN_TILE, 'xp': LG_VAR_FFN_XP}.get(env.get('LG_FFN_IMPL', ''), 0)
+    v |= {'3': LG_VAR_FFN_SAVE3, '5': LG_VAR_FFN_SAVE5}.get(env.get('LG_FFN_SAVE', ''), 0)
+    if env.get('LG_FFN_BWD32') == 'xs':
+        v |= LG_VAR_FFN_BWD32_XS
+    if env.get('LG_FFN_DWBWD') == 'tile':
+        v |= LG_VAR_FFN_DWBWD_TILE
+    if env.get('LG_ATTN_BWD') in ('old', 'r3'):
+        v |= LG_VAR_ATTN_BWD_R3
+    return v
 
 
 class LgteunHipError(RuntimeError):

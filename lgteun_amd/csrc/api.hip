@@ -122,20 +122,22 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
     if (n_offsets != expect) { lg_set_error("plan_create: expected %d offsets, got %d", expect, n_offsets); return -2; }
     for (int i = 0; i < n_offsets; ++i)
         if (offsets[i] < 0 || (offsets[i] & 3)) { lg_set_error("plan_create: offset %d (=%lld) must be a non-negative multiple of 4 floats", i, (long long)offsets[i]); return -2; }
+    if (cfg->variant & ~LG_VAR_ALL) { lg_set_error("plan_create: unknown variant bits 0x%x", cfg->variant & ~LG_VAR_ALL); return -2; }
+    if ((cfg->variant & LG_VAR_FFN_SAVE_MASK) == LG_VAR_FFN_SAVE_MASK) { lg_set_error("plan_create: invalid FFN save variant"); return -2; }
+#ifndef LG_BUILD_AB
+    if ((cfg->variant & LG_VAR_FFN_IMPL_MASK) >= LG_VAR_FFN_TILE) { lg_set_error("plan_create: FFN variants 2 / 3 exist in `make AB=1` builds only"); return -2; }
+#endif
     lg_plan* p = new lg_plan;
     p->cfg = *cfg;
     p->n_offsets = n_offsets;
-    {   // read once here, never on the launch path
-        const char* impl = getenv("LG_FFN_IMPL");
-        p->ffn_tile = !impl ? 0 : (!strcmp(impl, "strip") ? 1 : (!strcmp(impl, "tile") ? 2 : (!strcmp(impl, "xp") ? 3 : 0)));
-        const char* sv = getenv("LG_FFN_SAVE");
-        const char* b32 = getenv("LG_FFN_BWD32");
-        p->bwd32_old = (b32 && !strcmp(b32, "xs")) ? 0 : 1;   // default: the round-2 pair (k_ffn1_bwd_xs<32>: parity-green, measured 375 us against 203 + 121 us at C = 8)
-        const char* ab = getenv("LG_ATTN_BWD");
-        p->attn_bwd_old = (ab && !strcmp(ab, "old")) ? 1 : 0;
-        const char* dwb = getenv("LG_FFN_DWBWD");
-        p->dwbwd_tile = (dwb && !strcmp(dwb, "tile")) ? 1 : 0;
-        p->save_mode = !sv ? 2 : (!strcmp(sv, "5") ? 5 : (!strcmp(sv, "3") ? 3 : 2));   // common.h: lg_plan::save_mode
+    {   // A/B switches come in through lg_config.variant (the library reads no environment variable)
+        const uint32_t v = cfg->variant;
+        p->ffn_tile = (int)(v & LG_VAR_FFN_IMPL_MASK);
+        const uint32_t sv = v & LG_VAR_FFN_SAVE_MASK;
+        p->save_mode = sv == LG_VAR_FFN_SAVE5 ? 5 : (sv == LG_VAR_FFN_SAVE3 ? 3 : 2);   // common.h: lg_plan::save_mode
+        p->bwd32_old = (v & LG_VAR_FFN_BWD32_XS) ? 0 : 1;   // default: the round-2 pair (k_ffn1_bwd_xs<32>: parity-green, measured 375 us against 203 + 121 us at C = 8)
+        p->dwbwd_tile = (v & LG_VAR_FFN_DWBWD_TILE) ? 1 : 0;
+        p->attn_bwd_old = (v & LG_VAR_ATTN_BWD_R3) ? 1 : 0;
     }
     p->off = (int64_t*)malloc(sizeof(int64_t) * n_offsets);
     memcpy(p->off, offsets, sizeof(int64_t) * n_offsets);

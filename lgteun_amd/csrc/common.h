@@ -31,21 +31,21 @@ static inline int block_base(int blk) {
 struct lg_plan {
     lg_config cfg;
     int n_offsets;
-    int ffn_tile;  // A/B switch read ONCE at plan creation (env LG_FFN_IMPL = strip | tile): the f32-MFMA fused FFN kernels instead of the split-bf16 ones
-    int save_mode; // A/B switch read ONCE at plan creation (env LG_FFN_SAVE = 5 | 3 | 2, default 2): what the live stage's e = 16 FFN half-blocks
+    int ffn_tile;  // A/B switch (lg_config.variant & LG_VAR_FFN_IMPL_MASK; Python side: LG_FFN_IMPL = strip | tile | xp): the f32-MFMA fused FFN kernels instead of the split-bf16 ones
+    int save_mode; // A/B switch (lg_config.variant LG_VAR_FFN_SAVE3 | _SAVE5; Python side: LG_FFN_SAVE = 5 | 3 | 2, default 2): what the live stage's e = 16 FFN half-blocks
     // keep for the backward.  2 (default): the pre-activations h2, h3 -- h1 is re-computed from x by k_ffn1_bwd_xs (k_ffn_bwd_x.hip), which
     // also forms dW1 / dW2 on the bf16 matrix pipe; 3: h1, h2, h3 (round 2's default: k_ffn1_bwd<16> + k_wgrad_t re-evaluate gelu / gelu');
     // 5: gelu(h1), gelu'(h1), h2, gelu(h3), gelu'(h3) (GELU-free backward; the only form of the other widths and of precision = 'bf16').
     // In modes 2 / 3 the tensors sit in the a1 / h2 / a3 slots (workspace.h) and the g1 / g3 slots stay unused.
-    int dwbwd_tile; // A/B switch read ONCE at plan creation (env LG_FFN_DWBWD=tile): round 2's tile kernel k_ffn_dw_bwd<16> + k_wgrad_t for dW3
+    int dwbwd_tile; // A/B switch (lg_config.variant LG_VAR_FFN_DWBWD_TILE; Python side: LG_FFN_DWBWD=tile): round 2's tile kernel k_ffn_dw_bwd<16> + k_wgrad_t for dW3
                     // instead of the strip-walking k_ffn_dw_bwd_xs
     // precision = 'bf16' applies where a plain-bf16 kernel exists: e = 16 and e = 32.  The e = 64 half-blocks (level 1 of the 8-band net) have
     // only the round-1 f32-MFMA pair in that form (436 + 372 us against 123 + 95 us for the split-bf16 k_ffn_x64 pair), so they run the
     // default kernels with fp32 storage in both modes -- 'bf16' is never slower than the default (c3 / c5)
     bool hidden_bf16(int e) const { return cfg.precision == 1 && e != 64; }
     // precision = 'bf16' (plain bf16 MFMA, bf16 storage of the saved tensors) knows modes 2 and 5 only (3 falls back to 5)
-    int attn_bwd_old; // A/B switch: 1 = round 3's k_attn_bwd_core + k_attn_bwd_epi + k_wgrad_t at e = 16 instead of k_attn_bwd_f
-    int bwd32_old; // A/B switch read ONCE at plan creation (env LG_FFN_BWD32=xs turns it off): 1 = k_ffn1_bwd_x32 + k_wgrad_t at e = 32 (default);
+    int attn_bwd_old; // A/B switch (lg_config.variant LG_VAR_ATTN_BWD_R3; Python side: LG_ATTN_BWD=r3): 1 = round 3's k_attn_bwd_core + k_attn_bwd_epi + k_wgrad_t at e = 16 instead of k_attn_bwd_f
+    int bwd32_old; // A/B switch (lg_config.variant LG_VAR_FFN_BWD32_XS turns it off; Python side: LG_FFN_BWD32=xs): 1 = k_ffn1_bwd_x32 + k_wgrad_t at e = 32 (default);
                    // 0 = k_ffn1_bwd_xs<32>, the e = 16 kernel's template at 8 waves / one workgroup per CU -- correct, but slower there
     bool ffn1_bwd_x32(int e) const { return e == 32 && ffn_tile == 0 && !bwd32_old; }
     bool ffn_bwd_x(int e) const { return e == 16 && ffn_tile == 0 && save_mode == 2; }   // h1 not saved; backward through k_ffn_dw_bwd_xs + k_ffn1_bwd_xs

@@ -25,6 +25,21 @@
 #include "bwd_kernels.h"
 #include "mfma.h"
 
+// In-kernel phase stamps (diagnostic build only, -DLG_STAMPS: tools/build_stamps.sh + tools/attn_bwd_stamps.py): the eight waves of workgroup 0
+// write s_memtime at the phase boundaries of their third window group; no stamp executes in the product build.
+#ifdef LG_STAMPS
+// branch-free: every wave of every workgroup stores every stamp (a conditional store splits the loop body into basic blocks and the
+// register allocator then spills > 1000 registers: the instrumented kernel ran 19 x slower than the product one)
+__device__ unsigned long long g_kf_stamps[256 * 8 * 8 * 16];   // [workgroup][wave][group of the workgroup][stamp]
+#define STAMP(i) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)); \
+                      g_kf_stamps[((blockIdx.x * 8 + wave) * 8 + (stamp_it & 7)) * 16 + (i)] = t__; } while (0)
+extern "C" __attribute__((visibility("default"))) int lg_debug_kf_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_kf_stamps), sizeof(g_kf_stamps));
+}
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 namespace {
 constexpr int F_HC = 8, F_E = 16, F_D = 4, F_NS = 4, F_NW = 8;
 constexpr int F_PLD = 65;                       // padded pos_emb row: conflict-free for lane = query AND lane = key
@@ -48,6 +63,13 @@ static_assert(F_OFF_WAVE % 4 == 0 && F_PW % 4 == 0 && F_PS % 4 == 0, "16-byte al
 
 __device__ __forceinline__ float dpp_xor1(float v) {   // the other lane of the token's pair
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+// workgroup barrier that orders LDS only: __syncthreads() is a release / acquire pair on ALL address spaces, i.e. s_waitcnt vmcnt(0) in
+// front of s_barrier whenever a global store is pending -- it would drain the dx stores and every operand requested ahead
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 __device__ __forceinline__ float dpp_even(float v) {   // the even lane's value on both lanes of the pair
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xA0, 0xF, 0xF, true));   // quad_perm [0,0,2,2]
@@ -77,10 +99,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     float* const sCat = slotw + F_S_CAT;
     float* const sMr = slotw + F_S_MR;
 
+#ifdef LG_STAMPS
+    { const int stamp_it = 0; STAMP(11); }
+#endif
     // ---- staging, once per workgroup
-    for (int i = threadIdx.x; i < 2 * 64 * 64; i += 512) {
-        const int h = i >> 12, ii = (i >> 6) & 63, j = i & 63;
-        smem[h * 64 * PLD + ii * PLD + j] = a.pos[i] * LOG2E;
+    {   // pos_emb: the 16 values of a thread requested at once (a load + wait per loop trip is 16 dependent round trips)
+        float pv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pv[k] = a.pos[k * 512 + threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = k * 512 + threadIdx.x;
+            smem[(i >> 12) * 64 * PLD + ((i >> 6) & 63) * PLD + (i & 63)] = pv[k] * LOG2E;
+        }
     }
     if (threadIdx.x < 192) {   // sWq[h][third * 4 + c][k] = qkvw[third * HC + h * D + c][k]
         const int h = threadIdx.x / 96, r = (threadIdx.x % 96) >> 3, k = threadIdx.x & 7;
@@ -117,25 +148,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int tk = 32 * hd + (lane >> 1), ch = lane & 1;
     __syncthreads();
 
+    // pixel of (window, token tk): plane index bT, offset in the plane sT, NHWC pixel (return value).  Recomputed where needed rather than
+    // kept across the flash passes (6 registers at the kernel's peak)
+    auto pixel_of = [&](int win, long& bT, long& sT) -> long {
+        const int wx = win % nwx, rr = win / nwx, wy = rr % nwy;
+        bT = rr / nwy;
+        sT = (long)(wy * 8 + (tk >> 3)) * a.w + wx * 8 + (tk & 7);
+        return bT * hw + sT;
+    };
+    // Every wave of the workgroup is in the same phase (three barriers per group), so an HBM round trip that is waited for where it is
+    // issued is paid by the whole CU.  All global operands are therefore requested a phase or more ahead, unconditionally:
+    //   * the prologue's x / dy rows and keep word of the NEXT window group behind the flash passes of this one (n*: 17 registers across
+    //     the low-pressure epilogue phases);
+    //   * the epilogue's operands of THIS group (x / dy again -- an L2 hit --, dg, o2, keep) behind pass 1, across pass 2 (e*: 29 registers).
+    const uint32_t* const keepp = a.keep ? a.keep : reinterpret_cast<const uint32_t*>(a.x);   // no dropout: any valid address, value unused
+    float4 nx0, nx1, nd0, nd1;
+    uint32_t nkw;
+    auto issue_prologue = [&](int win) {
+        long bT, sT;
+        const long pT = pixel_of(win, bT, sT);
+        const float4* xs = reinterpret_cast<const float4*>(a.x + pT * E + HC * ch);
+        const float4* ds = reinterpret_cast<const float4*>(a.dy + pT * E + HC * ch);
+        nx0 = xs[0]; nx1 = xs[1]; nd0 = ds[0]; nd1 = ds[1];
+        nkw = keepp[pT];
+    };
+    if (blockIdx.x < ngroups) issue_prologue(blockIdx.x * F_NS + ws);
+#pragma unroll 1
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const int win = grp * F_NS + ws;
-        const bool active = win < nwin;
-        // pixel of (window, token tk): plane index bT, offset in the plane sT, NHWC pixel pT.  Computed again in the epilogue rather than
-        // kept across the flash passes (6 registers at the kernel's peak)
-        auto pixel_of = [&](long& bT, long& sT) -> long {
-            const int wx = win % nwx, rr = win / nwx, wy = rr % nwy;
-            bT = rr / nwy;
-            sT = (long)(wy * 8 + (tk >> 3)) * a.w + wx * 8 + (tk & 7);
-            return bT * hw + sT;
-        };
-        if (active) {
-            long bT, sT;
-            const long pT = pixel_of(bT, sT);
+        const int win = grp * F_NS + ws;   // nwin is a multiple of F_NS (launcher): every window slot is live
+#ifdef LG_STAMPS
+        const int stamp_it = (grp - (int)blockIdx.x) / (int)gridDim.x;
+#endif
+        STAMP(0);
+        {
             // ---------------- prologue: lane = (token tk, channel half ch)
-            const float4* xs = reinterpret_cast<const float4*>(a.x + pT * E + HC * ch);
-            const float4* ds = reinterpret_cast<const float4*>(a.dy + pT * E + HC * ch);
-            const float4 x0 = xs[0], x1 = xs[1], d0 = ds[0], d1 = ds[1];
-            const uint32_t kw = a.keep ? a.keep[pT] : 0xffffffffu;
+            const float4 x0 = nx0, x1 = nx1, d0 = nd0, d1 = nd1;
+            const uint32_t kw = a.keep ? nkw : 0xffffffffu;
             float xh[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
             float sm = ((xh[0] + xh[1]) + (xh[2] + xh[3])) + ((xh[4] + xh[5]) + (xh[6] + xh[7]));
             sm += dpp_xor1(sm);
@@ -190,9 +238,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
                 y4[2] = make_float4(1.f, 0.f, 0.f, 0.f);
             }
         }
-        __syncthreads();   // B1: the tiles of every wave are complete
+        STAMP(1);
+        lds_barrier();   // B1: the tiles of every wave are complete
+        STAMP(2);
         float dqkv[12];
-        if (active) {
+        {
             // ---------------- pass 1: lane = query i, packed over KEY pairs (as k_attn_bwd_core)
             float q[D], dOi[D];
 #pragma unroll
@@ -276,15 +326,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
             sSt[64 + lane] = inv;
             sSt[128 + lane] = Dv;
         }
+        STAMP(3);
+        // the epilogue's global operands of this group, requested across pass 2
+        float4 ex0, ex1, ed0, ed1;
+        uint32_t ekw;
+        float edg[8], eo2[4];
+        {
+            long bT, sT;
+            const long pT = pixel_of(win, bT, sT);
+            const float4* xs = reinterpret_cast<const float4*>(a.x + pT * E + HC * ch);
+            const float4* ds = reinterpret_cast<const float4*>(a.dy + pT * E + HC * ch);
+            ex0 = xs[0]; ex1 = xs[1]; ed0 = ds[0]; ed1 = ds[1];
+            ekw = keepp[pT];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) edg[k] = a.dg[(bT * HC + k) * hw + sT];           // both lanes of the pair ask for the same address
+#pragma unroll
+            for (int k = 0; k < 4; ++k) eo2[k] = a.o2[(bT * HC + 4 * ch + k) * hw + sT];   // lane ch stages o2 channels [4 ch, 4 ch + 4)
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();   // the row statistics are this wave's own
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (active) {
+        {
             // ---------------- pass 2: lane = key j, packed over QUERY pairs
-            float kj[D], vj[D];
+            // the lane's own k / v as FULL register pairs: a splat by op_sel reads one half of a pair whose other half the allocator
+            // gives to anything -- here to the destinations of the loads in flight, and the wait for those then sits in front of pass 2
+            lg_v2f kj2[D], vj2[D];
             lg_v2f dk2[D], dv2[D];
 #pragma unroll
-            for (int c = 0; c < D; ++c) { kj[c] = sK[c * 64 + lane]; vj[c] = sV[c * 64 + lane]; dk2[c] = (lg_v2f){0.f, 0.f}; dv2[c] = (lg_v2f){0.f, 0.f}; }
+            for (int c = 0; c < D; ++c) {
+                const float kc = sK[c * 64 + lane], vc = sV[c * 64 + lane];
+                kj2[c] = (lg_v2f){kc, kc}; vj2[c] = (lg_v2f){vc, vc};
+                asm volatile("" : "+v"(kj2[c]), "+v"(vj2[c]));
+                dk2[c] = (lg_v2f){0.f, 0.f}; dv2[c] = (lg_v2f){0.f, 0.f};
+            }
             const float* pcol = sPosH + lane;
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
@@ -295,7 +369,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
                 for (int c = 0; c < D; ++c) {
                     qi[c] = reinterpret_cast<const float4*>(sQ)[c * 16 + g];
                     doi[c] = reinterpret_cast<const float4*>(sDO)[c * 16 + g];
-                    const lg_v2f kk = (lg_v2f){kj[c], kj[c]}, vv = (lg_v2f){vj[c], vj[c]};
+                    const lg_v2f kk = kj2[c], vv = vj2[c];
                     t0 = kk * (lg_v2f){qi[c].x, qi[c].y} + t0;
                     t1 = kk * (lg_v2f){qi[c].z, qi[c].w} + t1;
                     dP0 = vv * (lg_v2f){doi[c].x, doi[c].y} + dP0;
@@ -322,9 +396,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int c = 0; c < D; ++c) { dqkv[4 + c] = (dk2[c].x + dk2[c].y) * LN2; dqkv[8 + c] = dv2[c].x + dv2[c].y; }   // sQ carries log2(e)
         }
+        STAMP(4);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();   // every lane is done with the wave's K / V / Q / dO tiles: they become the dqkv image
-        if (active) {
+        {   // the next group's prologue operands (a repeat of this group's addresses when there is no next one)
+            const int gn = grp + (int)gridDim.x;
+            issue_prologue((gn < ngroups ? gn : grp) * F_NS + ws);
+        }
+        {
             // ---------------- E1: lane = token: this head's share of to_qkv^T dqkv, and its to_qkv weight gradient on the matrix pipe
             float pt[8];
 #pragma unroll
@@ -344,35 +423,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
             st[1] = make_float4(dqkv[4], dqkv[5], dqkv[6], dqkv[7]);
             st[2] = make_float4(dqkv[8], dqkv[9], dqkv[10], dqkv[11]);
         }
+        STAMP(5);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (active) {
+        {
             // dW_h[r][k] += sum_tokens dqkv[token][r] * [y1 | 1][token][k]: token 4 s + mg is the MFMA's k index of lane (mr, mg)
             const bool live = mr < 12;
+            const float* const ap = mine + mg * F_QLD + mr;    // one base register each; the token step is an immediate offset
+            const float* const bp = sY1 + mg * F_Y1LD + mr;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const int tok = 4 * s + mg;
-                float av = mine[tok * F_QLD + mr], bv = sY1[tok * F_Y1LD + mr];
+                float av = ap[s * 4 * F_QLD], bv = bp[s * 4 * F_Y1LD];
                 av = live ? av : 0.f;
                 bv = live ? bv : 0.f;
                 accq = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accq, 0, 0, 0);
             }
         }
-        __syncthreads();   // B2: both heads' partial sums and attention outputs of the window are in LDS
-        if (active) {
+        STAMP(6);
+        lds_barrier();   // B2: both heads' partial sums and attention outputs of the window are in LDS
+        STAMP(7);
+        {
             // ---------------- E3: lane = (token tk, channel half ch): join the halves, LayerNorm backward, dx; proj weight gradient
             long bT, sT;
-            const long pT = pixel_of(bT, sT);
-            const float4* xs = reinterpret_cast<const float4*>(a.x + pT * E + HC * ch);
-            const float4* ds = reinterpret_cast<const float4*>(a.dy + pT * E + HC * ch);
-            const float4 x0 = xs[0], x1 = xs[1], d0 = ds[0], d1 = ds[1];
-            const uint32_t kw = a.keep ? a.keep[pT] : 0xffffffffu;
-            float dgv[8], o2v[4];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) dgv[k] = a.dg[(bT * HC + k) * hw + sT];           // both lanes of the pair ask for the same address
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o2v[k] = a.o2[(bT * HC + 4 * ch + k) * hw + sT];   // lane ch stages o2 channels [4 ch, 4 ch + 4)
+            const long pT = pixel_of(win, bT, sT);
+            const float4 x0 = ex0, x1 = ex1, d0 = ed0, d1 = ed1;
+            const uint32_t kw = a.keep ? ekw : 0xffffffffu;
+            const float* const dgv = edg;
+            const float* const o2v = eo2;
             const float2 mrs = *reinterpret_cast<const float2*>(sMr + 2 * tk);
             const float mu = mrs.x, rstd = mrs.y;
             const float4* pa = reinterpret_cast<const float4*>(smem + F_OFF_WAVE + (2 * ws) * F_PW + F_T_PART + tk * 8);
@@ -418,32 +496,51 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
             dst[1] = make_float4(dm[4], dm[5], dm[6], dm[7]);
             *reinterpret_cast<float4*>(sCat + tk * E + HC + 4 * ch) = make_float4(o2v[0], o2v[1], o2v[2], o2v[3]);
         }
+        STAMP(8);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (active) {
+        {
             // dWproj[n][k] += sum over this wave's 32 tokens of dym[token][n] * cat[token][k]
+            const float* const ap = mine + mg * E + mr;
+            const float* const bp = sCat + (32 * hd + mg) * E + mr;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int tl = 4 * s + mg;
-                accp = __builtin_amdgcn_mfma_f32_16x16x4f32(mine[tl * E + mr], sCat[(32 * hd + tl) * E + mr], accp, 0, 0, 0);
-            }
+            for (int s = 0; s < 8; ++s) accp = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[s * 4 * E], bp[s * 4 * E], accp, 0, 0, 0);
         }
-        __syncthreads();   // B3: tiles and images are free for the next window group
+        STAMP(9);
+        lds_barrier();   // B3: tiles and images are free for the next window group
+        STAMP(10);
     }
 
-    // ---------------- write-out: one slab row per workgroup, summed over the workgroups by the deferred reduce launch
+#ifdef LG_STAMPS
+    { const int stamp_it = 0; STAMP(12); }
+#endif
+    // ---------------- write-out: one slab row per workgroup, summed over the workgroups by the deferred reduce launch.
+    // Two barriers: every wave parks its 64 x 64 pos_emb-gradient columns in a region of its own (8 x 16.6 KB over the dead pos_emb, tiles
+    // and images) next to its small sums, then all 512 threads add the waves' shares in a fixed order on the way to global memory.
+    // (Round 3's form -- the waves of a head taking turns at one LDS copy, a read-modify-write per value and a barrier per turn -- was
+    // ~25 us of this kernel's 146.)
     float* const row = a.slab + (size_t)blockIdx.x * ATTN_BWD_F_ROW;
-    float* const sRed = smem;                 // pos_emb is dead: [8 waves][32] LayerNorm sums | [8][256] accq | [8][256] accp
+    constexpr int DPW = 64 * PLD;                   // floats of a wave's pos_emb-gradient region [i][65]
+    float* const sRed = smem + F_NW * DPW;          // [8 waves][32] LayerNorm sums | [8][256] accq | [8][256] accp
+    static_assert(F_NW * DPW + 256 + 2 * 2048 <= F_LDS_FLOATS, "write-out regions");
+    float v[16];
     {
         const float4* sl = reinterpret_cast<const float4*>(sSlot);
         const float4 s0 = sl[lane], s1 = sl[64 + lane], s2 = sl[128 + lane], s3 = sl[192 + lane];
-        float v[16] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w, s3.x, s3.y, s3.z, s3.w};
+        const float t[16] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w, s3.x, s3.y, s3.z, s3.w};
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
+            v[i] = t[i];
 #pragma unroll
             for (int off = 2; off < 64; off <<= 1) v[i] += __shfl_xor(v[i], off);   // lanes of equal parity = equal channel half
         }
+    }
+    __syncthreads();   // every wave has read its slots: the per-wave regions are free
+    {
+        float* const dp = smem + wave * DPW + lane;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) dp[i * PLD] = (i & 1) ? dpacc[i >> 1].y : dpacc[i >> 1].x;
         if (lane < 2) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) { sRed[wave * 32 + 8 * lane + u] = v[u]; sRed[wave * 32 + 16 + 8 * lane + u] = v[8 + u]; }
@@ -455,40 +552,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         }
     }
     __syncthreads();
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < 2 * 64 * 64; idx += 512) {   // pos_emb [h][i][j]: the four waves of head h, window slots in order
+        const int h = idx >> 12, o = ((idx >> 6) & 63) * PLD + (idx & 63);
+        row[idx] = ((smem[h * DPW + o] + smem[(2 + h) * DPW + o]) + smem[(4 + h) * DPW + o]) + smem[(6 + h) * DPW + o];
+    }
     for (int i = threadIdx.x; i < ATTN_BWD_F_ROW - ATTN_BWD_F_WQ; i += 512) {
-        float v = 0.f;
+        float r = 0.f;
         if (i < 192 + 24) {          // dWqkv [24][8] | dbqkv [24]: the four waves of the row's head
             const int rowq = i < 192 ? i >> 3 : i - 192, k = i < 192 ? (i & 7) : 8;
             const int third = rowq / HC, h = (rowq % HC) / D, c = rowq % D;
 #pragma unroll
-            for (int s4 = 0; s4 < F_NS; ++s4) v += sRed[256 + (2 * s4 + h) * 256 + (third * 4 + c) * 16 + k];
+            for (int s4 = 0; s4 < F_NS; ++s4) r += sRed[256 + (2 * s4 + h) * 256 + (third * 4 + c) * 16 + k];
         } else if (i < 192 + 24 + 256) {   // dWproj [16][16]
             const int j = i - 216;
 #pragma unroll
-            for (int w8 = 0; w8 < F_NW; ++w8) v += sRed[256 + 2048 + w8 * 256 + j];
+            for (int w8 = 0; w8 < F_NW; ++w8) r += sRed[256 + 2048 + w8 * 256 + j];
         } else {                     // d gamma [16] | d beta [16]
             const int j = i - 472;
 #pragma unroll
-            for (int w8 = 0; w8 < F_NW; ++w8) v += sRed[w8 * 32 + j];
+            for (int w8 = 0; w8 < F_NW; ++w8) r += sRed[w8 * 32 + j];
         }
-        row[ATTN_BWD_F_WQ + i] = v;
+        row[ATTN_BWD_F_WQ + i] = r;
     }
-    // pos_emb gradient of this workgroup: the four waves of a head add their column sums in a fixed order (over the per-wave regions)
-    float* const sDp = smem + F_OFF_WAVE + hd * 64 * PLD;
-    for (int turn = 0; turn < F_NS; ++turn) {
-        __syncthreads();
-        if (ws == turn) {
-#pragma unroll
-            for (int i = 0; i < 64; ++i) {
-                const float v = (i & 1) ? dpacc[i >> 1].y : dpacc[i >> 1].x;
-                if (turn == 0) sDp[i * PLD + lane] = v;
-                else sDp[i * PLD + lane] += v;
-            }
-        }
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 2 * 64 * 64; idx += 512)
-        row[idx] = smem[F_OFF_WAVE + (idx >> 12) * 64 * PLD + ((idx >> 6) & 63) * PLD + (idx & 63)];
+#ifdef LG_STAMPS
+    { const int stamp_it = 0; STAMP(13); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -559,7 +648,8 @@ int launch_attn_bwd_f(int e, const AttnBwdFArgs& a, hipStream_t s) {
     if ((a.h & 7) || (a.w & 7)) { lg_set_error("attn_bwd_f: h,w must be multiples of 8"); return -2; }
     if (!a.slab || !a.d_pos || !a.d_qkvw || !a.d_qkvb || !a.d_projw || !a.d_ln1g || !a.d_ln1b) { lg_set_error("attn_bwd_f: null destination"); return -2; }
     const int nwin = a.B * (a.h / 8) * (a.w / 8);
-    const int ngroups = (nwin + F_NS - 1) / F_NS;
+    if (nwin % F_NS) { lg_set_error("attn_bwd_f: %d windows are not a multiple of %d", nwin, F_NS); return -2; }   // level 0: h, w are multiples of 16
+    const int ngroups = nwin / F_NS;
     const size_t lds = (size_t)F_LDS_FLOATS * sizeof(float);
     static DeviceOnce attr_once;
     if (attr_once.need()) {

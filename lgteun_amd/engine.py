@@ -17,8 +17,7 @@ import torch
 
 from . import _lib
 from ._lib import (LG_FLAG_BWD_DATA, LG_FLAG_BWD_LGT, LG_FLAG_CHAINED, LG_FLAG_DEFER_DEAD, LG_FLAG_DROPOUT, LG_FLAG_FAITHFUL, LG_FLAG_SAVE,
-                   LgConfig,
-                   check)
+                   LgConfig, check, variant_from_env)
 
 
 def _block_names(pre):
@@ -125,6 +124,7 @@ class Engine:
         # small launches get in at kernel boundaries -- while the co-running launches stretch the fused FFN's measured duration by
         # 6 %, so the default keeps one stream and per-kernel numbers that mean what they say.
         self.overlap_dead = os.environ.get('LG_OVERLAP_DEAD', '0') == '1'
+        self.variant = None            # lg_config.variant of the plans: None = from the diagnostic LG_* environment variables (normally 0)
         self._side_stream = None
         self.world = 1
         self.rank = 0
@@ -203,9 +203,10 @@ class Engine:
 
     def plan(self, H, W):
         prec = {'fp32': 0, 'bf16': 1}[self.module_precision()]
-        key = (H, W, prec)
+        var = variant_from_env() if self.variant is None else int(self.variant)
+        key = (H, W, prec, var)
         if key not in self._plans:
-            cfg = LgConfig(self.C, self.K, H, W, prec)
+            cfg = LgConfig(self.C, self.K, H, W, prec, var)
             arr = (ctypes.c_int64 * len(self.offsets))(*self.offsets)
             out = ctypes.c_void_p()
             check(self.lib.lg_plan_create(ctypes.byref(cfg), arr, len(self.offsets), ctypes.byref(out)), 'lg_plan_create')

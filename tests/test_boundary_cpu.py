@@ -84,6 +84,36 @@ def test_c_abi_exports_every_declared_symbol():
     assert L.lg_plan_create(ctypes.byref(cfg), offs, 4, ctypes.byref(out)) < 0
     L.lg_last_error.restype = ctypes.c_char_p
     assert b'C must be 4 or 8' in L.lg_last_error()
+    # A/B switches are lg_config.variant bits: unknown bits are rejected, and the library imports no getenv
+    cfg = _lib.LgConfig(4, 2, 32, 32, 0, 1 << 20)
+    n = 12 + 2 + 119 * 2
+    offs = (ctypes.c_int64 * n)(*[4 * i for i in range(n)])
+    assert L.lg_plan_create(ctypes.byref(cfg), offs, n, ctypes.byref(out)) < 0 and b'variant' in L.lg_last_error()
+    cfg = _lib.LgConfig(4, 2, 32, 32, 0, _lib.LG_VAR_FFN_STRIP | _lib.LG_VAR_ATTN_BWD_R3)
+    assert L.lg_plan_create(ctypes.byref(cfg), offs, n, ctypes.byref(out)) == 0
+    L.lg_plan_destroy.argtypes = [ctypes.c_void_p]
+    L.lg_plan_destroy(out)
+    import shutil
+    import subprocess
+    if shutil.which('nm'):
+        und = subprocess.run(['nm', '-D', '--undefined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
+        assert 'getenv' not in und, 'the product library must not read environment variables'
+
+
+def test_variant_word_from_the_diagnostic_environment_variables():
+    from lgteun_amd import _lib
+    assert _lib.variant_from_env({}) == 0
+    assert _lib.variant_from_env({'LG_FFN_IMPL': 'strip'}) == _lib.LG_VAR_FFN_STRIP
+    assert _lib.variant_from_env({'LG_FFN_SAVE': '5', 'LG_FFN_DWBWD': 'tile'}) == _lib.LG_VAR_FFN_SAVE5 | _lib.LG_VAR_FFN_DWBWD_TILE
+    assert _lib.variant_from_env({'LG_FFN_SAVE': '3', 'LG_FFN_BWD32': 'xs', 'LG_ATTN_BWD': 'r3'}) == \
+        _lib.LG_VAR_FFN_SAVE3 | _lib.LG_VAR_FFN_BWD32_XS | _lib.LG_VAR_ATTN_BWD_R3
+    assert _lib.variant_from_env({'LG_FFN_SAVE': '2', 'LG_FFN_IMPL': 'split'}) == 0
+    hdr = open(os.path.join(ROOT, 'include', 'lgteun_hip.h')).read()
+    for name in ('LG_VAR_FFN_STRIP', 'LG_VAR_FFN_TILE', 'LG_VAR_FFN_XP'):
+        assert int(re.search(rf'#define {name} (\d+)u', hdr).group(1)) == getattr(_lib, name)
+    for name in ('LG_VAR_FFN_SAVE3', 'LG_VAR_FFN_SAVE5', 'LG_VAR_FFN_BWD32_XS', 'LG_VAR_FFN_DWBWD_TILE', 'LG_VAR_ATTN_BWD_R3'):
+        a, b = re.search(rf'#define {name} \((\d+)u << (\d+)\)', hdr).groups()
+        assert int(a) << int(b) == getattr(_lib, name), name
 
 
 def test_metrics_match_oracle():

@@ -374,7 +374,7 @@ def test_fused_attention_backward_agrees_with_the_round3_path(drop, monkeypatch)
         return g, eng
     monkeypatch.delenv('LG_ATTN_BWD', raising=False)
     g1, eng = grads()
-    monkeypatch.setenv('LG_ATTN_BWD', 'old')                       # read once per plan: a fresh module builds a fresh plan
+    monkeypatch.setenv('LG_ATTN_BWD', 'r3')                       # read once per plan: a fresh module builds a fresh plan
     g0, _ = grads()
     assert float(g0.abs().max()) > 0
     for i in eng.live_idx:

@@ -54,28 +54,35 @@ def test_train_step_vs_reference_gradients(manifest, name, mode):
     # gate: global relative L2 1e-3; for scale, the reference's own fp32 gradients are m['grad_rel_fp32_vs_fp64'] off its fp64 ones
     assert err < 1e-3, (err, m['grad_rel_fp32_vs_fp64'])
     # per tensor, on the tensor's own scale (floored at 2e-5): 3e-2 against the reference's fp32 gradient -- for every tensor except the
-    # KINDS whose L1 gradients are sums that cancel to ~1e-5 of their terms (the FFT mixer's amplitude / phase biases, pos_emb): those are
-    # known to 0.1 % ... 6 % only in the reference's fp32 ITSELF, so an fp32 golden cannot tell "as noisy as the reference" from "wrong".
-    # For them the reference's fp64 gradients (tests/golden/grad64_*.npz, tools/gen_goldens.py --only-r3) are the truth, and the gate is a
-    # statement about distance to it, per kind as a relative L2 over all the kind's tensors: IN NO CASE is this build further from fp64
-    # than the reference's own fp32 is in ITS worst case of the five goldens (profiles/r03_grad_vs_fp64.txt: in three of the five cases
-    # this build is 1.2 ... 8 x closer to fp64 than the reference's fp32, in grad_c8_k4_p128 the reference's fp32 happens to be 9 ... 40 x
-    # closer than its own typical -- the noise is a property of the kind, not of one draw).
-    kinds = ('global_mixer.conv_amp.0.bias', 'global_mixer.conv_pha.0.bias', 'local_mixer.pos_emb')
-
-    def kind_dist(case, kd, get):
-        g64c = np.load(f'{GOLD}/grad64_{case[5:]}.npz')
-        ks = [k[4:] for k in g64c.files if k.endswith(kd.replace('.', '/'))]
-        den = sum(float((g64c['g64/' + k] ** 2).sum()) for k in ks) ** 0.5
-        return sum(float(((get(k).astype(np.float64) - g64c['g64/' + k]) ** 2).sum()) for k in ks) ** 0.5 / den
-    cases = ['grad_c4_k4_p128', 'grad_c8_k4_p128', 'grad_c4_k2_p80x48', 'grad_c4_k2_p208x176', 'grad_c8_k8_p256']
+    # five KINDS whose L1 gradients are sums that cancel to ~1e-5 of their terms (the FFT mixer's amplitude / phase scale + bias, pos_emb).
+    # An fp32 golden cannot judge those: tests/golden/gradnoise.json (tools/gen_goldens.py --only-r4, the reference itself) records that
+    # the reference's OWN fp32 gradients of these kinds move by 0.1 % ... 9 % when its inputs are nudged by one ulp -- the network is
+    # piecewise continuous (torch.angle's branch cut, abs() behind irfft2), so one fp32 evaluation lands anywhere in that band around
+    # the fp64 value, and a case where the reference's fp32 happens to sit 10 x closer (grad_c8_k4_p128) is a lucky draw
+    # (profiles/r04_grad_vs_fp64.txt).  The truth is the reference's fp64 gradient (grad64_*.npz); the gate is PER CASE (VERDICT r3
+    # item 3): per kind (relative L2 over the kind's live tensors) this build is no further from fp64 than 3 x the larger of
+    # (a) the reference's own fp32 distance in THIS case and (b) the reference's own largest one-ulp spread in THIS case; per tensor of
+    # these kinds, on the tensor's own scale, 5 x the same two numbers of that tensor.
+    import json
+    kinds = ('global_mixer.conv_amp.0.bias', 'global_mixer.conv_pha.0.bias', 'global_mixer.conv_amp.0.weight', 'global_mixer.conv_pha.0.weight',
+             'local_mixer.pos_emb')
+    with open(f'{GOLD}/gradnoise.json') as f:
+        noise = json.load(f)[name]
+    g64c = np.load(f'{GOLD}/grad64_{name[5:]}.npz')
     report = {}
     for kd in kinds:
-        ref_worst = max(kind_dist(c, kd, (lambda gc: (lambda k: gc[k]))(load_gold(c))) for c in cases)
-        ours = kind_dist(name, kd, lambda k: grads[k.replace('/', '.')])
-        ref_here = kind_dist(name, kd, lambda k: g[k])
-        report[kd] = (ours, ref_here, ref_worst)
-        assert ours <= ref_worst, (kd, ours, ref_here, ref_worst)
+        ks = [k for k in grads if k.endswith(kd)]
+        t64 = {k: g64c['g64/' + k.replace('.', '/')] for k in ks}
+        den = sum(float((t64[k] ** 2).sum()) for k in ks) ** 0.5
+        ours = sum(float(((grads[k].astype(np.float64) - t64[k]) ** 2).sum()) for k in ks) ** 0.5 / den
+        nk = noise[kd]
+        bound = 3.0 * max(nk['ref_vs_fp64'], max(nk['ref_spread']))
+        report[kd] = (ours, nk['ref_vs_fp64'], max(nk['ref_spread']))
+        assert ours <= bound, (name, kd, ours, nk)
+        for k in ks:
+            nt = noise['tensors'][k]
+            e_t = float(((grads[k].astype(np.float64) - t64[k]) ** 2).sum()) ** 0.5 / float((t64[k] ** 2).sum()) ** 0.5
+            assert e_t <= 5.0 * max(nt['ref_vs_fp64'], max(nt['ref_spread'])), (name, k, e_t, nt)
     print(name, mode, {k: tuple(f'{v:.2e}' for v in r) for k, r in report.items()})
     worst = max((float(np.abs(v - g[k.replace('.', '/')]).max() / max(float(np.abs(g[k.replace('.', '/')]).max()), 2e-5)) / 3e-2, k)
                 for k, v in grads.items() if not k.endswith(kinds))

@@ -117,7 +117,7 @@ def round4(R, manifest):
     (b) is 5 ... 40 x (a) in the cases where (a) is small: the network is piecewise continuous (torch.angle's branch cut, abs() of the irfft2
     output) and these kinds cancel to ~1e-5 of their terms, so one fp32 evaluation lands anywhere in a band of width (b) around the fp64
     value and a small (a) is a lucky draw, not a property of the arithmetic.  The gate of tests/test_gpu_benchsize.py is per case
-    3 x max(a, rms of b)."""
+    3 x max(a, largest of b) per kind and 5 x the same per tensor."""
     out = {}
     for name in ('grad_c4_k4_p128', 'grad_c8_k4_p128', 'grad_c4_k2_p80x48', 'grad_c4_k2_p208x176', 'grad_c8_k8_p256'):
         cs = manifest[name]
@@ -138,7 +138,12 @@ def round4(R, manifest):
         base = grads32(ms, pan)
         rng = np.random.default_rng(1000 + cs['seed'])
         runs = [grads32(nudge(ms, rng), nudge(pan, rng)) for _ in range(4)]
-        out[name] = {}
+        out[name] = {'tensors': {}}
+        for k in sorted(base):   # the same two numbers per TENSOR, on the tensor's own scale
+            t64 = g64['g64/' + k.replace('.', '/')]
+            den = float((t64 ** 2).sum()) ** 0.5
+            out[name]['tensors'][k] = dict(ref_vs_fp64=float(((base[k] - t64) ** 2).sum()) ** 0.5 / den,
+                                           ref_spread=[float(((r[k] - base[k]) ** 2).sum()) ** 0.5 / den for r in runs])
         for kd in R3_KINDS:
             ks = [k for k in base if k.endswith(kd)]
             t64 = {k: g64['g64/' + k.replace('.', '/')] for k in ks}
