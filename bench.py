@@ -78,13 +78,53 @@ def traffic_from_profile(kernel, config='c2'):
     return int(num / den) if den > 0 else None
 
 
-def synth_batch(B, rank, device):
+def synth_batch(B, rank, device, c=None, h=None):
     """integer DN in [0,2047] / 2047.5 (reference dataset/utils.py:232-249, bit_depth 11); seed configs/unlg_former.py:66"""
+    c, h = c or C, h or H
     g = torch.Generator().manual_seed(19971118 + rank)
 
     def dn(*shape):
         return (torch.randint(0, 2048, shape, generator=g).float() / 2047.5).to(device)
-    return dn(B, C, H // 4, H // 4), dn(B, 1, H, H), dn(B, C, H, H)
+    return dn(B, c, h // 4, h // 4), dn(B, 1, h, h), dn(B, c, h, h)
+
+
+# what the SQ counters of a committed profile show the roofline kernel to be held by -- per (config, kernel), with the file that says so.
+# No entry = no counters were taken for that kernel in that config: the label is then None rather than a guess (ADVICE r3).
+LIMITERS = {('c2', 'ffn'): ('valu-issue', 'profiles/r03_sq_counters_step.txt')}
+
+
+def side_config(name, device, n_steps):
+    """side measurement (NOT `value`): the train step of another BASELINE config on a fresh module -- pairs/s, ms per step and the
+    average launch of its fused FFN forward (HIP events on every launch of the timed steps), so that the driver's record carries the
+    8-band configs next to the headline"""
+    import lgteun_amd
+    from lgteun_amd import _lib
+    from lgteun_amd.compat import Config
+    c, k, h, b, label = CONFIGS[name]
+    torch.manual_seed(19971118)
+    net = lgteun_amd.Pansharpening(Config(ms_chans=c), None, stage=k).to(device)
+    net.train()
+    eng = net.engine()
+    opt = lgteun_amd.FusedAdam(net.parameters(), lr=1.5e-3, betas=(0.9, 0.999))
+    ms, pan, gt = synth_batch(b, 0, device, c, h)
+    L = _lib.lib()
+    for _ in range(3):
+        eng.train_step(ms, pan, gt, opt)
+    _lib.check(L.lg_prof_enable(_lib.KERNEL_IDS['ffn'], 64 * (n_steps + 1)), 'lg_prof_enable')
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n_steps):
+        eng.train_step(ms, pan, gt, opt)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / n_steps
+    tot_ms, n_l = ctypes.c_double(), ctypes.c_int64()
+    _lib.check(L.lg_prof_read(ctypes.byref(tot_ms), ctypes.byref(n_l)), 'lg_prof_read')
+    L.lg_prof_disable()
+    del net, eng, opt
+    torch.cuda.empty_cache()
+    return dict(value=round(b / dt, 2), unit='image-pairs/sec', ms_per_step=round(dt * 1e3, 3), steps=n_steps, workload=label, mode='faithful',
+                dropout=True, ffn_avg_launch_us=round(tot_ms.value / max(n_l.value, 1) * 1e3, 2), ffn_launches=int(n_l.value),
+                note='fresh module, HIP events on every fused-FFN launch of the timed steps (event pairs cost ~1 % of a step)')
 
 
 def algorithmic_per_launch(kernel, B):
@@ -332,6 +372,11 @@ def main():
         net.mode = args.mode
         net.train()
 
+    # fourth side measurement: BASELINE configs[2] and configs[4] at their single-GPU shapes (8 bands), fresh modules
+    others = None
+    if side and args.config == 'c2' and args.mode == 'faithful' and args.precision == 'fp32':
+        others = {name: side_config(name, device, 10) for name in ('c3', 'c5')}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = B_PER_GPU * world * args.steps / elapsed
@@ -348,7 +393,9 @@ def main():
         pmc_path = PMC_SUMMARIES.get(args.config)
         # `bound` names the ROOF the fraction is taken against (contract: hbm | mfma); `limiter` says what the counters show the kernel
         # is actually held by (profiles/r0N_sq_counters_*): the vector ALU's instruction issue, not either roof
-        roof.update(limiter='valu-issue' if args.prof_kernel == 'ffn' else None, traffic=traffic_from_profile(args.prof_kernel, args.config),
+        lim = LIMITERS.get((args.config, args.prof_kernel))
+        roof.update(limiter=lim[0] if lim and os.path.exists(os.path.join(ROOT, lim[1])) else None, limiter_source=lim[1] if lim else None,
+                    traffic=traffic_from_profile(args.prof_kernel, args.config),
                     traffic_source=os.path.relpath(pmc_path, ROOT) if pmc_path and os.path.exists(pmc_path) else None,
                     kernel=L.lg_kernel_name(kid).decode(), launches=int(n_l.value), timed_every_n_steps=PROF_EVERY,
                     avg_launch_us=round(avg_us, 2), algorithmic_bytes_per_launch=int(byts), algorithmic_flops_per_launch=int(flops),
@@ -376,6 +423,9 @@ def main():
             out['bf16_mode'] = bf16
         if evalf is not None:
             out['eval_forward'] = dict(unit='eval image-pairs/sec', batch=B_PER_GPU, **evalf)
+        if others is not None:
+            out['c3_mode'] = others['c3']
+            out['c5_mode'] = others['c5']
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(host_cores(), args.config)
         print(json.dumps(out), flush=True)

@@ -97,14 +97,20 @@ class Base_model:
         trusted: `allow_pickle=True` or `cfg.allow_pickled_checkpoint = True`."""
         if allow_pickle is None:
             allow_pickle = bool(self.cfg.get('allow_pickled_checkpoint', False))
+        import pickle
         try:
             return torch.load(path, map_location='cpu', weights_only=True)
-        except Exception as e:  # noqa: BLE001  (torch raises UnpicklingError for anything beyond tensors / containers)
+        except (pickle.UnpicklingError, RuntimeError) as e:   # what torch raises for anything beyond tensors / containers; a missing or
+            if isinstance(e, RuntimeError) and 'weights_only' not in str(e).lower() and 'unsupported' not in str(e).lower() \
+                    and 'global' not in str(e).lower():        # unreadable file (OSError, EOFError, a corrupt archive) is NOT a reason to unpickle
+                raise
             if not allow_pickle:
                 raise RuntimeError(
                     f'{path} is not a plain-tensor checkpoint (the reference pickles whole module objects). Convert it once with '
                     'tools/convert_checkpoint.py, or pass allow_pickle=True / set cfg.allow_pickled_checkpoint for a file you '
                     f'trust.  ({type(e).__name__}: {str(e)[:200]})') from e
+        if self.logger is not None:
+            self.logger.warning(f'{path}: not a plain-tensor checkpoint, unpickling it as allowed by allow_pickle / cfg.allow_pickled_checkpoint')
         return torch.load(path, map_location='cpu', weights_only=False)
 
     def load_checkpoint(self, path, allow_pickle=None):
@@ -206,15 +212,23 @@ class Base_model:
         names = ['PSNR', 'SSIM', 'Q', 'SAM', 'ERGAS'] if ref else ['D_lambda', 'D_s', 'QNR']
         denorm = bool(self.cfg.get('norm_input', False))
         out_dir = osp.join(self.test_out1 if ref else self.test_out0, f'iter_{iter_id}')
-        save = save and self.rank == 0     # one process per GPU: every rank evaluates, ONE writes the files (the reference is one process)
+        # one process per GPU: the evaluation set is SPLIT over the ranks (the reference is one process).  A loader built with this rank's
+        # ShardedSampler (dataset.build_loader(rank, world)) or declared so with cfg.eval_sharded already yields this rank's share; of any
+        # other loader (the same on every rank) rank r takes batches r, r + world, ...  Every rank writes the fused images of ITS share,
+        # the per-image metric rows of all ranks are gathered in rank order before the mean / std.
         if save:
             mkdir_or_exist(out_dir)
+        from .dataset import ShardedSampler
+        inner = getattr(loader, 'loader', loader)
+        sharded = self.world > 1 and (bool(self.cfg.get('eval_sharded', False)) or isinstance(getattr(inner, 'sampler', None), ShardedSampler))
 
         def to_np(t):   # [b c h w] -> [b h w c]
             t = data_denormalize(t, self.cfg.bit_depth) if denorm else t
             return t.permute(0, 2, 3, 1).cpu().numpy()
         res = []
-        for input_batch in (loader or []):
+        for bi, input_batch in enumerate(loader or []):
+            if self.world > 1 and not sharded and bi % self.world != self.rank:
+                continue
             input_batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in input_batch.items()}
             input_batch = data_normalize(input_batch, self.cfg.bit_depth)
             out = to_np(self.get_model_output(input_batch))
@@ -230,6 +244,11 @@ class Base_model:
                     # transposed file; not reproduced)
                     save_image(osp.join(out_dir, f'{image_id}_mul_hat.tif'), np.moveaxis(out[i], -1, 0))
         latest = {}
+        if self.world > 1:
+            import torch.distributed as dist
+            rows = [None] * self.world
+            dist.all_gather_object(rows, [list(map(float, r)) for r in res])
+            res = [r for part in rows for r in part]
         if res:
             res = np.array(res)
             for k, name in enumerate(names):
@@ -238,7 +257,7 @@ class Base_model:
                 latest[name] = (float(res[:, k].mean()), float(res[:, k].std()))
             if self.logger is not None and self.rank == 0:
                 self.logger.info(f"iter {iter_id} {'low' if ref else 'full'}-resolution eval: {latest}")
-        self._barrier()                    # no rank runs ahead of the files rank 0 is writing
+        self._barrier()                    # no rank runs ahead of files another rank is still writing
         return latest
 
     def save(self, iter_id):

@@ -324,6 +324,7 @@ struct AttnBwdFArgs {
     float* slab;           // ATTN_BWD_F_WGS rows of ATTN_BWD_F_ROW floats: per-workgroup partial sums
     float *d_pos, *d_qkvw, *d_qkvb, *d_projw, *d_ln1g, *d_ln1b;   // += by the deferred reduce launch
     int B, h, w;
+    unsigned rcp_nwx, rcp_nwy;   // filled by the launcher: 2^32 / (w / 8) + 1, 2^32 / (h / 8) + 1
 };
 #define ATTN_BWD_F_WGS 256
 #define ATTN_BWD_F_WQ 8192            // row: pos_emb [2][64][64] | dWqkv [24][8] | dbqkv [24] | dWproj [16][16] | d gamma [16] | d beta [16]

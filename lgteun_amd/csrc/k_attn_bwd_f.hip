@@ -30,7 +30,7 @@
 #ifdef LG_STAMPS
 // branch-free: every wave of every workgroup stores every stamp (a conditional store splits the loop body into basic blocks and the
 // register allocator then spills > 1000 registers: the instrumented kernel ran 19 x slower than the product one)
-__device__ unsigned long long g_kf_stamps[256 * 8 * 8 * 16];   // [workgroup][wave][group of the workgroup][stamp]
+__device__ unsigned long long g_kf_stamps[512 * 8 * 8 * 16];   // [workgroup][wave][group of the workgroup][stamp]
 #define STAMP(i) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)); \
                       g_kf_stamps[((blockIdx.x * 8 + wave) * 8 + (stamp_it & 7)) * 16 + (i)] = t__; } while (0)
 extern "C" __attribute__((visibility("default"))) int lg_debug_kf_stamps(unsigned long long* host) {
@@ -41,8 +41,14 @@ extern "C" __attribute__((visibility("default"))) int lg_debug_kf_stamps(unsigne
 #endif
 
 namespace {
-constexpr int F_HC = 8, F_E = 16, F_D = 4, F_NS = 4, F_NW = 8;
-constexpr int F_PLD = 65;                       // padded pos_emb row: conflict-free for lane = query AND lane = key
+#ifndef LG_ATTNF_NS
+#define LG_ATTNF_NS 4   // window slots per workgroup: 4 = one 8-wave workgroup per CU (155 KB of LDS); 2 = 4-wave workgroups, TWO per CU (81 KB each), so that
+                        // one workgroup's prologue / epilogue could run beside the other's flash passes -- measured 142.8 vs 135.8 us: the kernel is
+                        // vector-issue bound in EVERY phase (stamps: a window group costs 33 k ticks either way), decoupling the phases buys nothing
+#endif
+constexpr int F_HC = 8, F_E = 16, F_D = 4, F_NS = LG_ATTNF_NS, F_NW = 2 * F_NS, F_NT = 64 * F_NW;
+constexpr int F_PLD = 68;                       // padded pos_emb row (16-byte aligned): lane = query reads its row as 16-byte pieces, lane = key a column;
+                                                // both conflict-free (68 = 4 mod 64: the 16 lanes of a ds_read_b128 group sit 4 banks apart)
 constexpr int F_Y1LD = 12;                      // [y1 (8) | 1 | 0 0 0] per token: B operand of the to_qkv weight-gradient product
 constexpr int F_QLD = 12;                       // staged dqkv rows of one head per token: A operand
 constexpr int F_WPS = 68;                       // lane-half stride of the dO weights (two lane-dependent addresses on different banks)
@@ -52,13 +58,16 @@ constexpr int F_OFF_BQ = F_OFF_WQ + 192;        // [2][12] (+ pad)
 constexpr int F_OFF_WP = F_OFF_BQ + 32;         // [2 halves][8 n][8 = head * 4 + k], half stride F_WPS
 constexpr int F_OFF_LN = F_OFF_WP + 144;        // gamma[16] | beta[16]
 constexpr int F_OFF_WAVE = F_OFF_LN + 32;
-constexpr int F_PW = 2752;                      // per wave: K | V | Q | dO [4][64] each, stats [3][64], to_qkv^T partial [64][8], slots [4][64] float4
+constexpr int F_PW = 1856;                      // per wave: K | V | Q | dO [4][64] each, stats [3][64], to_qkv^T partial [64][8], LayerNorm-gradient slots [4 rows][2 halves][16]
 constexpr int F_T_K = 0, F_T_V = 256, F_T_Q = 512, F_T_DO = 768, F_T_ST = 1024, F_T_PART = 1216, F_T_SLOT = 1728;
 constexpr int F_OFF_SLOT = F_OFF_WAVE + F_NW * F_PW;
 constexpr int F_PS = 1920;                      // per window slot: y1 image [64][12], cat image [64][16], (mu, rstd) [64][2]
 constexpr int F_S_Y1 = 0, F_S_CAT = 768, F_S_MR = 1792;
-constexpr int F_LDS_FLOATS = F_OFF_SLOT + F_NS * F_PS;
-static_assert(F_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+constexpr int F_LOOP_FLOATS = F_OFF_SLOT + F_NS * F_PS;
+constexpr int F_DPW = 64 * 65;                  // write-out: a wave's pos_emb-gradient columns [i][65] ...
+constexpr int F_OUT_FLOATS = F_NW * F_DPW + F_NW * (32 + 512);   // ... + its LayerNorm sums [32] and the two MFMA accumulators [256] each
+constexpr int F_LDS_FLOATS = F_LOOP_FLOATS > F_OUT_FLOATS ? F_LOOP_FLOATS : F_OUT_FLOATS;
+static_assert(F_LDS_FLOATS * 4 <= (F_NS == 2 ? 80 : 160) * 1024, "LDS budget: two workgroups per CU at F_NS = 2");
 static_assert(F_OFF_WAVE % 4 == 0 && F_PW % 4 == 0 && F_PS % 4 == 0, "16-byte alignment of the LDS regions");
 
 __device__ __forceinline__ float dpp_xor1(float v) {   // the other lane of the token's pair
@@ -71,12 +80,20 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+// sum over the 8 lanes of a 16-lane row that share this lane's parity (= the row's 8 tokens of one channel half): xor 2, then rotations by
+// 4 and 8 inside the row; every lane of the class ends up with the sum
+__device__ __forceinline__ float row8_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));   // row_ror:8
+    return v;
+}
 __device__ __forceinline__ float dpp_even(float v) {   // the even lane's value on both lanes of the pair
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xA0, 0xF, 0xF, true));   // quad_perm [0,0,2,2]
 }
 }  // namespace
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k_attn_bwd_f(AttnBwdFArgs a, int nwin, int ngroups) {
+__global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void k_attn_bwd_f(AttnBwdFArgs a, int nwin, int ngroups) {
     constexpr int HC = F_HC, E = F_E, D = F_D, PLD = F_PLD;
     constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -103,13 +120,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     { const int stamp_it = 0; STAMP(11); }
 #endif
     // ---- staging, once per workgroup
-    {   // pos_emb: the 16 values of a thread requested at once (a load + wait per loop trip is 16 dependent round trips)
-        float pv[16];
+    {   // pos_emb: all values of a thread requested at once (a load + wait per loop trip is 16 - 32 dependent round trips)
+        constexpr int NPV = 2 * 64 * 64 / F_NT;
+        float pv[NPV];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) pv[k] = a.pos[k * 512 + threadIdx.x];
+        for (int k = 0; k < NPV; ++k) pv[k] = a.pos[k * F_NT + threadIdx.x];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int i = k * 512 + threadIdx.x;
+        for (int k = 0; k < NPV; ++k) {
+            const int i = k * F_NT + threadIdx.x;
             smem[(i >> 12) * 64 * PLD + ((i >> 6) & 63) * PLD + (i & 63)] = pv[k] * LOG2E;
         }
     }
@@ -121,19 +139,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         const int h = threadIdx.x / 12, r = threadIdx.x % 12;
         sBq[threadIdx.x] = a.qkvb[(r >> 2) * HC + h * D + (r & 3)];
     }
-    if (threadIdx.x >= 256 && threadIdx.x < 256 + 128) {   // sWp[c][u][hk] = projw[HC * c + u][hk]   (hk = head * 4 + k: the attention columns of proj)
-        const int i = threadIdx.x - 256, c = i >> 6, u = (i >> 3) & 7, hk = i & 7;
+    if (threadIdx.x < 128) {   // sWp[c][u][hk] = projw[HC * c + u][hk]   (hk = head * 4 + k: the attention columns of proj)
+        const int i = threadIdx.x, c = i >> 6, u = (i >> 3) & 7, hk = i & 7;
         sWp[c * F_WPS + u * 8 + hk] = a.projw[(HC * c + u) * E + hk];
     }
-    if (threadIdx.x >= 448 && threadIdx.x < 448 + 32) {
-        const int i = threadIdx.x - 448;
+    if (threadIdx.x >= 192 && threadIdx.x < 192 + 32) {
+        const int i = threadIdx.x - 192;
         sLn[i] = i < 16 ? a.ln1g[i] : a.ln1b[i - 16];
     }
-    {   // LayerNorm-gradient slots of this lane
-        float4* sl = reinterpret_cast<float4*>(sSlot);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) sl[v * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    // LayerNorm gamma / beta gradient slots: the 8 lanes of a 16-lane row that hold one channel half pre-sum their 8 tokens with three DPP
+    // steps and share ONE slot of 16 floats (every one of them writes the same sum to it: 512 bytes per wave instead of 4 KB)
+    float* const myslot = sSlot + ((lane >> 4) * 2 + (lane & 1)) * 16;
+    sSlot[lane] = 0.f;
+    sSlot[64 + lane] = 0.f;
     const int nwx = a.w >> 3, nwy = a.h >> 3;
     const long hw = (long)a.h * a.w;
     const float scale = 0.5f;   // D^-1/2, D = 4
@@ -151,8 +169,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     // pixel of (window, token tk): plane index bT, offset in the plane sT, NHWC pixel (return value).  Recomputed where needed rather than
     // kept across the flash passes (6 registers at the kernel's peak)
     auto pixel_of = [&](int win, long& bT, long& sT) -> long {
-        const int wx = win % nwx, rr = win / nwx, wy = rr % nwy;
-        bT = rr / nwy;
+        // divisions by the window counts through host-made reciprocals (exact for win < 2^24 and counts < 256: launcher)
+        const int rr = (int)__umulhi((unsigned)win, a.rcp_nwx), wx = win - rr * nwx;
+        const int bi = (int)__umulhi((unsigned)rr, a.rcp_nwy), wy = rr - bi * nwy;
+        bT = bi;
         sT = (long)(wy * 8 + (tk >> 3)) * a.w + wx * 8 + (tk & 7);
         return bT * hw + sT;
     };
@@ -252,7 +272,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
             float mx = -3.0e38f;
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                lg_v2f sp0 = (lg_v2f){prow[4 * g], prow[4 * g + 1]}, sp1 = (lg_v2f){prow[4 * g + 2], prow[4 * g + 3]};
+                const float4 pr4 = reinterpret_cast<const float4*>(prow)[g];
+                lg_v2f sp0 = (lg_v2f){pr4.x, pr4.y}, sp1 = (lg_v2f){pr4.z, pr4.w};
 #pragma unroll
                 for (int c = 0; c < D; ++c) {
                     const float4 kv = reinterpret_cast<const float4*>(sK)[c * 16 + g];
@@ -478,14 +499,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
                                  dyv[2] + rstd * (gg[2] - m1 - xh[2] * m2), dyv[3] + rstd * (gg[3] - m1 - xh[3] * m2));
             dxo[1] = make_float4(dyv[4] + rstd * (gg[4] - m1 - xh[4] * m2), dyv[5] + rstd * (gg[5] - m1 - xh[5] * m2),
                                  dyv[6] + rstd * (gg[6] - m1 - xh[6] * m2), dyv[7] + rstd * (gg[7] - m1 - xh[7] * m2));
-            {   // d gamma / d beta of this lane's 8 channels: lane-owned slots
-                float4* sl = reinterpret_cast<float4*>(sSlot);
-                float4 s0 = sl[lane], s1 = sl[64 + lane], s2 = sl[128 + lane], s3 = sl[192 + lane];
-                s0.x += dyf[0] * xh[0]; s0.y += dyf[1] * xh[1]; s0.z += dyf[2] * xh[2]; s0.w += dyf[3] * xh[3];
-                s1.x += dyf[4] * xh[4]; s1.y += dyf[5] * xh[5]; s1.z += dyf[6] * xh[6]; s1.w += dyf[7] * xh[7];
-                s2.x += dyf[0]; s2.y += dyf[1]; s2.z += dyf[2]; s2.w += dyf[3];
-                s3.x += dyf[4]; s3.y += dyf[5]; s3.z += dyf[6]; s3.w += dyf[7];
-                sl[lane] = s0; sl[64 + lane] = s1; sl[128 + lane] = s2; sl[192 + lane] = s3;
+            {   // d gamma / d beta of this lane's 8 channels: summed over the row's 8 tokens of this channel half, then into the row's slot
+                float gs[16];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { gs[u] = row8_sum(dyf[u] * xh[u]); gs[8 + u] = row8_sum(dyf[u]); }
+                float4* sl = reinterpret_cast<float4*>(myslot);
+                float4 s0 = sl[0], s1 = sl[1], s2 = sl[2], s3 = sl[3];
+                s0.x += gs[0]; s0.y += gs[1]; s0.z += gs[2]; s0.w += gs[3];
+                s1.x += gs[4]; s1.y += gs[5]; s1.z += gs[6]; s1.w += gs[7];
+                s2.x += gs[8]; s2.y += gs[9]; s2.z += gs[10]; s2.w += gs[11];
+                s3.x += gs[12]; s3.y += gs[13]; s3.z += gs[14]; s3.w += gs[15];
+                sl[0] = s0; sl[1] = s1; sl[2] = s2; sl[3] = s3;
             }
             // dym image [32 tokens of this wave][16] over the tiles (the dqkv image was consumed in front of B2), o2 into the cat image
             float dm[8];
@@ -517,57 +541,50 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 #endif
     // ---------------- write-out: one slab row per workgroup, summed over the workgroups by the deferred reduce launch.
     // Two barriers: every wave parks its 64 x 64 pos_emb-gradient columns in a region of its own (8 x 16.6 KB over the dead pos_emb, tiles
-    // and images) next to its small sums, then all 512 threads add the waves' shares in a fixed order on the way to global memory.
+    // and images) next to its small sums, then all threads add the waves' shares in a fixed order on the way to global memory.
     // (Round 3's form -- the waves of a head taking turns at one LDS copy, a read-modify-write per value and a barrier per turn -- was
     // ~25 us of this kernel's 146.)
     float* const row = a.slab + (size_t)blockIdx.x * ATTN_BWD_F_ROW;
-    constexpr int DPW = 64 * PLD;                   // floats of a wave's pos_emb-gradient region [i][65]
-    float* const sRed = smem + F_NW * DPW;          // [8 waves][32] LayerNorm sums | [8][256] accq | [8][256] accp
-    static_assert(F_NW * DPW + 256 + 2 * 2048 <= F_LDS_FLOATS, "write-out regions");
-    float v[16];
-    {
-        const float4* sl = reinterpret_cast<const float4*>(sSlot);
-        const float4 s0 = sl[lane], s1 = sl[64 + lane], s2 = sl[128 + lane], s3 = sl[192 + lane];
-        const float t[16] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w, s3.x, s3.y, s3.z, s3.w};
+    constexpr int DPW = F_DPW, OLD = 65;            // floats of a wave's pos_emb-gradient region [i][65]
+    float* const sRed = smem + F_NW * DPW;          // [waves][32] LayerNorm sums | [waves][256] accq | [waves][256] accp
+    float v[16];   // lanes 0 / 1: the wave's d gamma (8) | d beta (8) sums of channel half 0 / 1 over its four rows
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            v[i] = t[i];
-#pragma unroll
-            for (int off = 2; off < 64; off <<= 1) v[i] += __shfl_xor(v[i], off);   // lanes of equal parity = equal channel half
-        }
-    }
+    for (int i = 0; i < 16; ++i) v[i] = ((sSlot[(lane & 1) * 16 + i] + sSlot[(2 + (lane & 1)) * 16 + i]) + sSlot[(4 + (lane & 1)) * 16 + i]) + sSlot[(6 + (lane & 1)) * 16 + i];
     __syncthreads();   // every wave has read its slots: the per-wave regions are free
     {
         float* const dp = smem + wave * DPW + lane;
 #pragma unroll
-        for (int i = 0; i < 64; ++i) dp[i * PLD] = (i & 1) ? dpacc[i >> 1].y : dpacc[i >> 1].x;
+        for (int i = 0; i < 64; ++i) dp[i * OLD] = (i & 1) ? dpacc[i >> 1].y : dpacc[i >> 1].x;
         if (lane < 2) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) { sRed[wave * 32 + 8 * lane + u] = v[u]; sRed[wave * 32 + 16 + 8 * lane + u] = v[8 + u]; }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {   // accumulator element i of lane (mr, mg) = D[4 mg + i][mr]
-            sRed[256 + wave * 256 + (4 * mg + i) * 16 + mr] = accq[i];
-            sRed[256 + 2048 + wave * 256 + (4 * mg + i) * 16 + mr] = accp[i];
+            sRed[32 * F_NW + wave * 256 + (4 * mg + i) * 16 + mr] = accq[i];
+            sRed[32 * F_NW + 256 * F_NW + wave * 256 + (4 * mg + i) * 16 + mr] = accp[i];
         }
     }
     __syncthreads();
 #pragma unroll 4
-    for (int idx = threadIdx.x; idx < 2 * 64 * 64; idx += 512) {   // pos_emb [h][i][j]: the four waves of head h, window slots in order
-        const int h = idx >> 12, o = ((idx >> 6) & 63) * PLD + (idx & 63);
-        row[idx] = ((smem[h * DPW + o] + smem[(2 + h) * DPW + o]) + smem[(4 + h) * DPW + o]) + smem[(6 + h) * DPW + o];
+    for (int idx = threadIdx.x; idx < 2 * 64 * 64; idx += F_NT) {   // pos_emb [h][i][j]: the waves of head h, window slots in order
+        const int h = idx >> 12, o = ((idx >> 6) & 63) * OLD + (idx & 63);
+        float r = smem[h * DPW + o];
+#pragma unroll
+        for (int s4 = 1; s4 < F_NS; ++s4) r += smem[(2 * s4 + h) * DPW + o];
+        row[idx] = r;
     }
-    for (int i = threadIdx.x; i < ATTN_BWD_F_ROW - ATTN_BWD_F_WQ; i += 512) {
+    for (int i = threadIdx.x; i < ATTN_BWD_F_ROW - ATTN_BWD_F_WQ; i += F_NT) {
         float r = 0.f;
         if (i < 192 + 24) {          // dWqkv [24][8] | dbqkv [24]: the four waves of the row's head
             const int rowq = i < 192 ? i >> 3 : i - 192, k = i < 192 ? (i & 7) : 8;
             const int third = rowq / HC, h = (rowq % HC) / D, c = rowq % D;
 #pragma unroll
-            for (int s4 = 0; s4 < F_NS; ++s4) r += sRed[256 + (2 * s4 + h) * 256 + (third * 4 + c) * 16 + k];
+            for (int s4 = 0; s4 < F_NS; ++s4) r += sRed[32 * F_NW + (2 * s4 + h) * 256 + (third * 4 + c) * 16 + k];
         } else if (i < 192 + 24 + 256) {   // dWproj [16][16]
             const int j = i - 216;
 #pragma unroll
-            for (int w8 = 0; w8 < F_NW; ++w8) r += sRed[256 + 2048 + w8 * 256 + j];
+            for (int w8 = 0; w8 < F_NW; ++w8) r += sRed[32 * F_NW + 256 * F_NW + w8 * 256 + j];
         } else {                     // d gamma [16] | d beta [16]
             const int j = i - 472;
 #pragma unroll
@@ -639,7 +656,7 @@ __global__ __launch_bounds__(256) void k_proj_o2_bwd_k(ProjO2BwdKArgs a) {
 int attn_bwd_f_grid(int B, int h, int w) {
     const int nwin = B * (h / 8) * (w / 8);
     const int ngroups = (nwin + F_NS - 1) / F_NS;
-    return ngroups < ATTN_BWD_F_WGS ? ngroups : ATTN_BWD_F_WGS;   // one resident workgroup (8 waves, 150 KB of LDS) per CU
+    return ngroups < ATTN_BWD_F_WGS ? ngroups : ATTN_BWD_F_WGS;   // the resident workgroups: two per CU (4 waves, 80 KB of LDS each)
 }
 
 int launch_attn_bwd_f(int e, const AttnBwdFArgs& a, hipStream_t s) {
@@ -658,7 +675,11 @@ int launch_attn_bwd_f(int e, const AttnBwdFArgs& a, hipStream_t s) {
         attr_once.done();
     }
     const int grid = attn_bwd_f_grid(a.B, a.h, a.w);
-    k_attn_bwd_f<<<grid, 512, lds, s>>>(a, nwin, ngroups);
+    if (nwin >= (1 << 24) || a.w / 8 >= 256 || a.h / 8 >= 256) { lg_set_error("attn_bwd_f: %d windows of a %d x %d plane are out of range", nwin, a.h, a.w); return -2; }
+    AttnBwdFArgs ak = a;
+    ak.rcp_nwx = (unsigned)((1ull << 32) / (unsigned)(a.w / 8)) + 1u;   // floor(n / d) = umulhi(n, 2^32 / d + 1) for n d < 2^32
+    ak.rcp_nwy = (unsigned)((1ull << 32) / (unsigned)(a.h / 8)) + 1u;
+    k_attn_bwd_f<<<grid, F_NT, lds, s>>>(ak, nwin, ngroups);
     LG_CHECK_LAUNCH();
     // partial rows -> gradients (+=), in the block's deferred reduce launch
     ReduceJob j;

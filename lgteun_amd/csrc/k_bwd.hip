@@ -29,7 +29,7 @@ static void carve_bwd(const lg_plan* plan, int B, void* base, BwdBufs& bb) {
     bb.y2 = cv.take(P0 * E); bb.do2 = cv.take(P0 * E / 2); bb.dg = cv.take(P0 * E / 2);
     bb.dym = cv.take(P0 * E); bb.cat = cv.take(P0 * E); bb.y1 = cv.take(P0 * 16 > P0 * E / 2 ? P0 * 16 : P0 * E / 2);
     bb.dqkv = cv.take(P0 * 2 * E);
-    bb.dpos_slab = cv.take((size_t)512 * 2 * 64 * 64);
+    bb.dpos_slab = cv.take((size_t)ATTN_BWD_F_WGS * ATTN_BWD_F_ROW > (size_t)512 * 2 * 64 * 64 ? (size_t)ATTN_BWD_F_WGS * ATTN_BWD_F_ROW : (size_t)512 * 2 * 64 * 64);
     for (int j = 0; j < 5; ++j) { bb.w3t[j] = cv.take(8 * E * 2 * E); bb.w2t[j] = cv.take(8 * E * 8 * E); bb.w1t[j] = cv.take(8 * E * 2 * E); }
     bb.wsp = cv.take(ffn_wsplit_bytes(32) / sizeof(float));   // pre-split W2^T / W1^T fragments of k_ffn1_bwd_x32 (e = 32 blocks)
     size_t sl = wgrad_slab_floats((int)(8 * E), (int)(8 * E), (long)P0);
@@ -215,7 +215,7 @@ static int mixer_half_bwd(const lg_plan* pl, const float* P, float* G, int st, i
         af.pos = P + pl->blk(st, j, B_POS);
         af.ln1g = P + pl->blk(st, j, B_LN1G); af.ln1b = P + pl->blk(st, j, B_LN1B);
         af.qkvw = P + pl->blk(st, j, B_QKVW); af.qkvb = P + pl->blk(st, j, B_QKVB); af.projw = P + pl->blk(st, j, B_PROJW);
-        af.slab = bb.dpos_slab;   // 512 * 8192 floats: untouched until the block's flush
+        af.slab = bb.dpos_slab;   // ATTN_BWD_F_WGS rows: untouched until the block's flush
         af.d_pos = G + pl->blk(st, j, B_POS); af.d_qkvw = G + pl->blk(st, j, B_QKVW); af.d_qkvb = G + pl->blk(st, j, B_QKVB);
         af.d_projw = G + pl->blk(st, j, B_PROJW); af.d_ln1g = G + pl->blk(st, j, B_LN1G); af.d_ln1b = G + pl->blk(st, j, B_LN1B);
         af.B = B; af.h = fb.h; af.w = fb.w;

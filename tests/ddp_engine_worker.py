@@ -96,7 +96,7 @@ def runner_check(outdir, rank, world, ms, pan, gt):
     a, b = ddp.shard_bounds(B_GLOBAL, rank, world)
     work = os.path.join(outdir, 'runner')
     batch = dict(input_lr=ms[a:b] * 2047.5, input_pan=pan[a:b] * 2047.5, target=gt[a:b] * 2047.5, image_id=[f'r{rank}_{i}' for i in range(b - a)])
-    cfg = Config(dict(ms_chans=C, work_dir=work, datas='GF-2', cuda=True, max_iter=2, bit_depth=11, norm_input=True,
+    cfg = Config(dict(ms_chans=C, work_dir=work, datas='GF-2', cuda=True, max_iter=2, bit_depth=11, norm_input=True, eval_sharded=True,
                       save_freq=1, eval_freq=-1, test_freq=-1, loss_cfg={'rec_loss': dict(type='l1', w=1.)},
                       optim_cfg={'core_module': dict(type='Adam', betas=(0.9, 0.999), lr=1.5e-3)},
                       sched_cfg=dict(step_size=2, gamma=0.85), model_cfg={'core_module': dict(stage=K)}))
@@ -122,7 +122,9 @@ def runner_check(outdir, rank, world, ms, pan, gt):
     w_now = torch.cat([v.detach().reshape(-1).cpu() for v in runner.module_dict['core_module'].state_dict().values()])
     w_ck = torch.cat([v.reshape(-1) for v in ck['core_module'].values()])
     out['runner_ckpt_equal'] = np.array(int(torch.equal(w_now, w_ck)))
-    runner.test(iter_id=1, save=True, ref=True)         # every rank evaluates; only rank 0 writes TIFFs
+    runner.test(iter_id=1, save=True, ref=True)         # every rank evaluates ITS share (cfg.eval_sharded: the loaders are per-rank shards) and writes its TIFFs
+    out['runner_eval_psnr'] = np.array(runner.eval_results['PSNR_mean'][-1])
+    out['runner_eval_n'] = np.array(len(runner.eval_results['PSNR_mean']))
     d = os.path.join(work, 'GF-2', 'test_out1', 'iter_1')
     out['runner_tifs'] = np.array(sorted(os.listdir(d)) if os.path.isdir(d) else [])
     r2 = lgteun_amd.build_model('UnlgFormer', cfg, _ListLogger(), [batch], [batch], [batch])

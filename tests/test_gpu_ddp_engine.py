@@ -68,4 +68,7 @@ def test_two_rank_runner_writes_once_and_logs_the_global_loss(request):
     assert abs(g - float(r1['runner_global_loss'])) < 1e-7
     assert abs(float(r0['runner_local_loss']) + float(r1['runner_local_loss']) - g) < 1e-6
     assert abs(float(r0['runner_logged_loss']) - g) < 1e-5 and float(r1['runner_logged_loss']) == -1.0   # rank 0 logs, the global mean
-    assert list(r0['runner_tifs']) == ['r0_0_mul_hat.tif', 'r0_1_mul_hat.tif']                           # rank 1 wrote nothing
+    # the evaluation set is split over the ranks: every rank writes the fused images of its share, the metric rows are gathered
+    assert list(r1['runner_tifs']) == ['r0_0_mul_hat.tif', 'r0_1_mul_hat.tif', 'r1_0_mul_hat.tif', 'r1_1_mul_hat.tif'] or \
+        list(r0['runner_tifs']) == ['r0_0_mul_hat.tif', 'r0_1_mul_hat.tif', 'r1_0_mul_hat.tif', 'r1_1_mul_hat.tif']
+    assert float(r0['runner_eval_psnr']) == float(r1['runner_eval_psnr']) and float(r0['runner_eval_psnr']) > 0   # mean over ALL images, on both ranks

@@ -26,16 +26,17 @@ tot, n = ctypes.c_double(), ctypes.c_int64()
 L.lg_prof_read(ctypes.byref(tot), ctypes.byref(n))
 L.lg_prof_disable()
 print(f'k_attn_bwd_f by HIP events (this build): {1e3 * tot.value / max(n.value, 1):.1f} us per launch, {n.value} launch(es)')
-N = 256 * 8 * 8 * 16
+N = 512 * 8 * 8 * 16
 buf = (ctypes.c_ulonglong * N)()
 f = L.lg_debug_kf_stamps
 f.restype = ctypes.c_int
 assert f(buf) == 0
-st = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8, 8, 16).astype(np.int64)   # [workgroup][wave][group][stamp]
+st = np.frombuffer(buf, dtype=np.uint64).reshape(512, 8, 8, 16).astype(np.int64)   # [workgroup][wave][group][stamp]
+st = st[st[:, 0, 0, 11] > 0][:, :(4 if st[0, 4, 0, 11] == 0 else 8)]             # the workgroups / waves that ran
 names = {1: 'prologue (LN, qkv, dO -> tiles)', 2: 'barrier B1', 3: 'pass 1 (lane = query)', 4: 'epilogue loads issued + pass 2 (lane = key)',
          5: 'next loads issued + E1: to_qkv^T partial, image', 6: 'to_qkv weight-gradient MFMAs', 7: 'barrier B2', 8: 'E3: LN backward, dx, slots, images',
          9: 'proj weight-gradient MFMAs', 10: 'barrier B3'}
-print('k_attn_bwd_f, s_memtime ticks (~2.3 GHz) per phase, mean over the 256 workgroups; columns = waves (window slot, head)')
+print('k_attn_bwd_f, s_memtime ticks (~2.3 GHz) per phase, mean over the workgroups; columns = waves (window slot, head)')
 for it in (0, 3, 7):
     print(f' window group {it} of the workgroup')
     for i in range(1, 11):
