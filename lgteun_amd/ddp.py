@@ -54,7 +54,11 @@ def broadcast_flat(flat, src=0, group=None):
 
 
 def overlap_requested():
-    return os.environ.get('LG_DDP_OVERLAP', '0') == '1'
+    """LG_DDP_OVERLAP = 1: two asynchronous buckets (both outstanding behind the data-step backwards); = serial: the same two-bucket
+    ordering (LGT backward -> LGT bucket -> data-step backwards -> shared bucket -> Adam) with the first bucket waited for before the
+    second is started -- at most ONE outstanding work, the form that is known to complete on every transport"""
+    v = os.environ.get('LG_DDP_OVERLAP', '0')
+    return 'serial' if v == 'serial' else v == '1'
 
 
 class GradBuckets:
@@ -64,7 +68,9 @@ class GradBuckets:
     def __init__(self, ranges, group=None, overlap=None):
         self.ranges = list(ranges)
         self.group = group
-        self.overlap = overlap_requested() if overlap is None else bool(overlap)
+        ov = overlap_requested() if overlap is None else overlap
+        self.overlap = bool(ov)
+        self.serial = ov == 'serial'      # the LGT bucket is waited for in front of the shared bucket (one outstanding work at a time)
         self.span = (min(a for a, _ in self.ranges), max(b for _, b in self.ranges))
         self._pending = []
 

@@ -330,6 +330,8 @@ class Engine:
                 bk.start(self.gflat, 1)
             self.backward_raw(saved, dout, self.gflat, flags | LG_FLAG_BWD_DATA, seed)
             if overlap:
+                if bk.serial:
+                    bk.finish()            # the LGT bucket's result is in before the shared bucket starts
                 bk.start(self.gflat, 0)
                 bk.finish()
         else:

@@ -54,6 +54,20 @@ def main():
     net.attach_ddp()
     res = run(net, ms[a:b].contiguous(), pan[a:b].contiguous(), gt[a:b].contiguous(), STEPS)
     res['world'] = np.array(net.engine().world)
+    # the two-bucket ordering north_star names (LGT backward -> LGT bucket -> K data-step backwards -> shared bucket -> Adam; reference
+    # base_model.py:91-100 reduces implicitly) on DEVICE tensors, in the form with one outstanding work at a time:
+    # same weights, same shard, same step -> the flat gradient must be bitwise the default path's
+    net2 = make_module(C, K, salt=0)
+    net2.attach_ddp()
+    e2 = net2.engine()
+    res['overlap_default_gflat'] = run(net2, ms[a:b].contiguous(), pan[a:b].contiguous(), gt[a:b].contiguous(), 1)['gflat0']
+    net3 = make_module(C, K, salt=0)
+    net3.attach_ddp()
+    e3 = net3.engine()
+    for bk in e3.buckets.values():
+        bk.overlap, bk.serial = True, True
+    res['overlap_serial_gflat'] = run(net3, ms[a:b].contiguous(), pan[a:b].contiguous(), gt[a:b].contiguous(), 1)['gflat0']
+    res['overlap_serial_weights_equal'] = np.array(int(torch.equal(e2.flat, e3.flat)))
     # the attachment survives a rebuilt engine (.to() re-creates the parameters)
     net.to('cuda:0')
     res['world_after_to'] = np.array(net.engine().world)

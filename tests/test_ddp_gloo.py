@@ -55,7 +55,7 @@ def _worker(rank, world, port, q, mode, overlap):
     ddp.broadcast_flat(wflat, 0)
     assert torch.equal(wflat, before)
     buckets = ddp.GradBuckets(ranges, overlap=overlap)
-    assert buckets.overlap == overlap
+    assert buckets.overlap == bool(overlap) and buckets.serial == (overlap == 'serial')
     if overlap:
         # opt-in form (LG_DDP_OVERLAP=1): two ASYNCHRONOUS collectives outstanding at once, the LGT bucket first (on the GPU path it
         # overlaps the data-step backwards), then unrelated work, then finish()
@@ -75,7 +75,7 @@ def _worker(rank, world, port, q, mode, overlap):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('mode,overlap', [('faithful', False), ('faithful', True), ('chained', False)])
+@pytest.mark.parametrize('mode,overlap', [('faithful', False), ('faithful', True), ('faithful', 'serial'), ('chained', False)])
 def test_two_rank_gradients_equal_single_process(mode, overlap):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))

@@ -48,6 +48,12 @@ def test_two_rank_engine_train_step_equals_single_process(request):
     w, ws = r0['weights'], r0['single_weights']
     assert _rel(w[a1:b1], ws[a1:b1]) < 1e-4 and _rel(w[a0:b0], ws[a0:b0]) < 1e-4
     assert np.array_equal(w[b0:a1], ws[b0:a1])                  # dead stages untouched by Adam on every path
+    # the two-bucket ordering (LGT backward -> LGT bucket -> data-step backwards -> shared bucket -> Adam) on device tensors, one
+    # outstanding work at a time: bitwise the default single-collective path, on both ranks
+    for r in (r0, r1):
+        assert np.array_equal(r['overlap_serial_gflat'], r['overlap_default_gflat']) and np.abs(r['overlap_serial_gflat']).max() > 0
+        assert int(r['overlap_serial_weights_equal']) == 1
+    assert np.array_equal(r0['overlap_serial_gflat'], r1['overlap_serial_gflat'])
 
 
 def test_two_rank_runner_writes_once_and_logs_the_global_loss(request):
