@@ -228,7 +228,7 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     a1.tile16 = pl->ffn_tile;
     a1.wsplit = wsplit;
     Ffn2Args a2;
-    a2.h2 = bb.h2; a2.x = bb.xmid; a2.a3s = (flags & LG_FLAG_SAVE) ? bb.a3 : nullptr; a2.g3s = ((flags & LG_FLAG_SAVE) && !pre) ? bb.g3 : nullptr; a2.y = bb.xout;
+    a2.h2 = bb.h2; a2.x = bb.xmid; a2.a3s = (flags & LG_FLAG_SAVE) ? bb.a3 : nullptr; a2.g3s = ((flags & LG_FLAG_SAVE) && !pre && !pl->ffn_dw_x32(bb.e)) ? bb.g3 : nullptr; a2.y = bb.xout;   // g3s null with a3s set: a3 receives the PRE-activation h3
     a2.g = g_next;
     a2.dww = P + pl->blk(stage, j, B_DWW); a2.dwb = P + pl->blk(stage, j, B_DWB);
     a2.w3 = P + pl->blk(stage, j, B_W3); a2.b3 = P + pl->blk(stage, j, B_B3);

@@ -216,7 +216,7 @@ struct Ffn1BwdXArgs {
 inline int ffn1_bwd_x_wgs(int e) { return e == 16 ? 512 : 256; }   // persistent grid: two workgroups per CU at e = 16 (55 KB of LDS), one at e = 32 (139 KB)
 size_t ffn1_bwd_x_slab_floats(int e);                               // floats of Ffn1BwdXArgs::slab
 int launch_ffn1_bwd_xs(int e, const Ffn1BwdXArgs& a, hipStream_t s);   // e = 16 | 32
-// e = 16, fp32 storage (k_ffn_dwbwd_x.hip): the strip-walking spatial half -- dh3 in an LDS ring, dh2 out, depthwise gradients AND
+// e = 16 | 32 (k_ffn_dwbwd_x.hip): the strip-walking spatial half -- dh3 in an LDS ring, dh2 out, depthwise gradients AND
 // dW3 / db3 in the same pass; replaces k_ffn_dw_bwd<16> + the 16 x 64 k_wgrad_t launch
 struct FfnDwBwdXArgs {
     const float* dy;   // [B,h,w,16]
@@ -224,18 +224,21 @@ struct FfnDwBwdXArgs {
     const void* h2;    // [B,h,w,64] saved                                      (hidden storage)
     void* dh2;         // [B,h,w,64] out                                        (hidden storage)
     int hbf;           // 1: precision = 'bf16' (plain bf16 products, bf16 storage of h2 / h3 / dh2)
-    const float* w3t;  // [64][16] transposed W3
-    const float* dww;  // [64,1,3,3]
+    const float* w3t;  // [4e][e] transposed W3
+    const float* dww;  // [4e,1,3,3]
     float* slab;       // FFN_DW_BWD_X_WGS rows of FFN_DW_BWD_X_ROW floats (per-workgroup partial sums)
     float *d_dww, *d_dwb, *d_w3, *d_b3;   // accumulated (+=) by the deferred reduce launch
     int B, h, w;
 };
-#define FFN_DW_BWD_X_WGS 512
+#define FFN_DW_BWD_X_WGS 512      // e = 16: two resident workgroups per CU
 #define FFN_DW_BWD_X_DB 576
 #define FFN_DW_BWD_X_W3 640
 #define FFN_DW_BWD_X_B3 1664
 #define FFN_DW_BWD_X_ROW 1680
-int launch_ffn_dw_bwd_xs(const FfnDwBwdXArgs& a, hipStream_t s);
+#define FFN_DW_BWD_X32_ROW 5408   // e = 32: [d dww 128 x 9 | d dwb 128 | dW3 32 x 128 | db3 32], one workgroup (8 waves) per CU
+inline int ffn_dw_bwd_x_wgs(int e) { return e == 16 ? FFN_DW_BWD_X_WGS : 256; }
+inline size_t ffn_dw_bwd_x_slab_floats(int e) { return e == 16 ? (size_t)FFN_DW_BWD_X_WGS * FFN_DW_BWD_X_ROW : (size_t)256 * FFN_DW_BWD_X32_ROW; }
+int launch_ffn_dw_bwd_xs(int e, const FfnDwBwdXArgs& a, hipStream_t s);   // e = 16 | 32
 int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[cols][rows]
 int launch_transpose3(const float* const* src, float* const* dst, const int* rows, const int* cols, int njobs, hipStream_t s);
 

@@ -48,6 +48,9 @@ struct lg_plan {
     int bwd32_old; // A/B switch (lg_config.variant LG_VAR_FFN_BWD32_XS turns it off; Python side: LG_FFN_BWD32=xs): 1 = k_ffn1_bwd_x32 + k_wgrad_t at e = 32 (default);
                    // 0 = k_ffn1_bwd_xs<32>, the e = 16 kernel's template at 8 waves / one workgroup per CU -- correct, but slower there
     bool ffn1_bwd_x32(int e) const { return e == 32 && ffn_tile == 0 && !bwd32_old; }
+    // e = 32 (round 4): the spatial half through the strip-walking k_ffn_dw_bwd_xs<32> (dW3 / db3 included): the forward saves the PRE-activation h3
+    // in the a3 slot and nothing in g3; the pixelwise half stays k_ffn1_bwd_x32 + the 128 x 128 weight-gradient launch on the saved gelu(h1) / gelu'(h1)
+    bool ffn_dw_x32(int e) const { return e == 32 && ffn_tile == 0 && !dwbwd_tile && !ffn1_bwd_x32(32); }
     bool ffn_bwd_x(int e) const { return e == 16 && ffn_tile == 0 && save_mode == 2; }   // h1 not saved; backward through k_ffn_dw_bwd_xs + k_ffn1_bwd_xs
     bool ffn_saves_preact(int e) const { return e == 16 && ffn_tile == 0 && (save_mode == 2 || (save_mode == 3 && cfg.precision == 0)); }
     int64_t* off;  // host copy of offsets

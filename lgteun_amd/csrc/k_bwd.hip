@@ -48,7 +48,8 @@ static void carve_bwd(const lg_plan* plan, int B, void* base, BwdBufs& bb) {
         if (e == 16 || e == 32) {
             if (ffn1_bwd_x_slab_floats((int)e) > sl) sl = ffn1_bwd_x_slab_floats((int)e);
         }
-    if ((size_t)FFN_DW_BWD_X_WGS * FFN_DW_BWD_X_ROW > sl) sl = (size_t)FFN_DW_BWD_X_WGS * FFN_DW_BWD_X_ROW;
+    if (ffn_dw_bwd_x_slab_floats(16) > sl) sl = ffn_dw_bwd_x_slab_floats(16);
+    if (ffn_dw_bwd_x_slab_floats(32) > sl) sl = ffn_dw_bwd_x_slab_floats(32);
     bb.slab_cap = 4 * sl;
     bb.slab_arena = cv.take(bb.slab_cap);
     bb.dt = cv.take(P0 * E); bb.dskip = cv.take(P0 * E); bb.v = cv.take(P1 * E); bb.du = cv.take(P1 * E);
@@ -108,11 +109,11 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         // half (h1 re-computed, dx, LayerNorm gradients, dW1 / db1, dW2 / db2); dh2 is the only tensor between them
         FfnDwBwdXArgs fk;
         fk.dy = dy; fk.h3 = fb.a3; fk.h2 = fb.h2; fk.dh2 = bb.dh2; fk.w3t = bb.w3t[j]; fk.dww = P + pl->blk(st, j, B_DWW);
-        fk.slab = bb.rq.take((size_t)FFN_DW_BWD_X_WGS * FFN_DW_BWD_X_ROW);
+        fk.slab = bb.rq.take(ffn_dw_bwd_x_slab_floats(e));
         if (!fk.slab) return -3;
         fk.d_dww = G + pl->blk(st, j, B_DWW); fk.d_dwb = G + pl->blk(st, j, B_DWB); fk.d_w3 = G + pl->blk(st, j, B_W3); fk.d_b3 = G + pl->blk(st, j, B_B3);
         fk.B = B; fk.h = fb.h; fk.w = fb.w; fk.hbf = hbf;
-        RC(launch_ffn_dw_bwd_xs(fk, s));
+        RC(launch_ffn_dw_bwd_xs(e, fk, s));
         Ffn1BwdXArgs fx;
         fx.dh2 = bb.dh2; fx.x = fb.xmid; fx.dy = dy; fx.dx = tmp;
         fx.w1 = P + pl->blk(st, j, B_W1); fx.b1 = P + pl->blk(st, j, B_B1); fx.w2t = bb.w2t[j]; fx.w1t = bb.w1t[j];
@@ -124,14 +125,28 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         fx.P = Pn; fx.hbf = hbf;
         return launch_ffn1_bwd_xs(e, fx, s);
     }
-    FfnDwBwdArgs fd;
-    fd.dy = dy; fd.g3 = pre ? fb.a3 : fb.g3; fd.h2 = fb.h2; fd.dh2 = bb.dh2; fd.w3t = bb.w3t[j]; fd.dww = P + pl->blk(st, j, B_DWW);
-    fd.slab_w = bb.rq.take(ffn_dw_bwd_slab_floats(e, B, fb.h, fb.w));
-    if (!fd.slab_w) return -3;
-    fd.slab_b = fd.slab_w + ffn_dw_bwd_slab_floats(e, B, fb.h, fb.w) / 10 * 9;
-    fd.d_dww = G + pl->blk(st, j, B_DWW); fd.d_dwb = G + pl->blk(st, j, B_DWB);
-    fd.B = B; fd.h = fb.h; fd.w = fb.w; fd.hbf = hbf; fd.pre = pre;
-    RC(launch_ffn_dw_bwd(e, fd, s));
+    const bool dwx32 = pl->ffn_dw_x32(e);
+    if (dwx32) {
+        // e = 32: the strip-walking spatial half (dh3 in an LDS ring -> dh2; depthwise gradients, dW3 / db3 in the same pass) on the saved
+        // pre-activation h3; the pixelwise half below is round 2's k_ffn1_bwd_x32 + the 128 x 128 weight-gradient launch
+        FfnDwBwdXArgs fk;
+        fk.dy = dy; fk.h3 = fb.a3; fk.h2 = fb.h2; fk.dh2 = bb.dh2; fk.w3t = bb.w3t[j]; fk.dww = P + pl->blk(st, j, B_DWW);
+        fk.slab = bb.rq.take(ffn_dw_bwd_x_slab_floats(e));
+        if (!fk.slab) return -3;
+        fk.d_dww = G + pl->blk(st, j, B_DWW); fk.d_dwb = G + pl->blk(st, j, B_DWB); fk.d_w3 = G + pl->blk(st, j, B_W3); fk.d_b3 = G + pl->blk(st, j, B_B3);
+        fk.B = B; fk.h = fb.h; fk.w = fb.w; fk.hbf = hbf;
+        RC(launch_ffn_dw_bwd_xs(e, fk, s));
+    }
+    if (!dwx32) {
+        FfnDwBwdArgs fd;
+        fd.dy = dy; fd.g3 = pre ? fb.a3 : fb.g3; fd.h2 = fb.h2; fd.dh2 = bb.dh2; fd.w3t = bb.w3t[j]; fd.dww = P + pl->blk(st, j, B_DWW);
+        fd.slab_w = bb.rq.take(ffn_dw_bwd_slab_floats(e, B, fb.h, fb.w));
+        if (!fd.slab_w) return -3;
+        fd.slab_b = fd.slab_w + ffn_dw_bwd_slab_floats(e, B, fb.h, fb.w) / 10 * 9;
+        fd.d_dww = G + pl->blk(st, j, B_DWW); fd.d_dwb = G + pl->blk(st, j, B_DWB);
+        fd.B = B; fd.h = fb.h; fd.w = fb.w; fd.hbf = hbf; fd.pre = pre;
+        RC(launch_ffn_dw_bwd(e, fd, s));
+    }
     if (pl->ffn_bwd_x(e) || pl->ffn1_bwd_x32(e)) {
         // one pass over dh2 re-computes h1 and yields dx, the LayerNorm gradients, dW1 / db1 and dW2 / db2 (e = 16: h1 was not saved; e = 32:
         // the saved gelu(h1) / gelu'(h1) are simply not read)
@@ -174,7 +189,7 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
     if (!ffn1_bwd_fuses_w1(e))
         RC(wgrad(bb.dh1, n1, bb.y2, e, G + pl->blk(st, j, B_W1), e, G + pl->blk(st, j, B_B1), Pn, n1, e, n1, e, hbf, 0, bb, s));
     // last: dh2's two readers run right behind its producer (Infinity Cache), this one only needs the saved gelu(h3) and dy
-    RC(wgrad(dy, e, fb.a3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 0, hbf, bb, s, pre));
+    if (!dwx32) RC(wgrad(dy, e, fb.a3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 0, hbf, bb, s, pre));
     return 0;
 }
 

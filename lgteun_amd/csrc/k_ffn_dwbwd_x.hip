@@ -1,5 +1,5 @@
-// k_ffn_dw_bwd_xs: the spatial half of the feed_forward backward at e = 16 (reference models/common/LGT.py:91-109: net.4, the second
-// GELU and the depthwise 3x3 of net.2), as a STRIP WALK like the forward's k_ffn_xs:
+// k_ffn_dw_bwd_xs<E>: the spatial half of the feed_forward backward at e = 16 and (round 4) e = 32 (reference models/common/LGT.py:91-109:
+// net.4, the second GELU and the depthwise 3x3 of net.2), as a STRIP WALK like the forward's k_ffn_xs / k_ffn_x32:
 //
 //     dh3 = (W3^T dy) * gelu'(h3)          on the halo pixels, kept in a 10-row fp32 LDS ring (never stored)
 //     dh2 = dw3x3^T dh3                    -> HBM, the one tensor k_ffn1_bwd_xs reads
@@ -14,6 +14,11 @@
 // consecutive channels of one pixel, so h3 arrives and dh3 leaves as 16-byte accesses.  dW3: the pixel axis is the K dimension; dy^T
 // is read by columns from the chunk's dy image (ds_read_b64_tr_b16), gelu(h3) goes through a 4.5 KB per-wave [pixel][channel] image of the chunk.
 // LDS 79 KB (two workgroups per CU): ring [10][18][68] fp32 | dy pieces [2][3][48][16] bf16 | per-wave gelu(h3) pieces [4][3][48][16] | depthwise taps [64][9] fp32.
+// e = 32 (hidden width 128: level 0 of the 8-band net, level 1 of the 4-band net): the same walk with EIGHT waves (wave w = hidden channels
+// [16 w, 16 w + 16)), one 512-thread workgroup per CU, 151 KB: ring [10][18][132] | dy pieces [2][3][48][32] | gelu(h3) pieces [8][3][48][16] | taps
+// [128][9]; W3^T dy is one 32-deep block per piece product, dW3 two 16-row tiles per wave, and in the depthwise phase a wave owns ONE tile row
+// and a lane slides its 3 x 3 window over EIGHT consecutive pixels (30 ring reads per 8 outputs).  It replaces k_ffn_dw_bwd<32> (channel-split
+// tiles: 1.40 x read amplification, h2 read twice) and the 32 x 128 k_wgrad_t launch with its second pass over dy and gelu(h3).
 #include "kernels.h"
 #include "bwd_kernels.h"
 #include "split_bf16.h"
@@ -32,16 +37,27 @@ extern "C" __attribute__((visibility("default"))) int lg_debug_ka_stamps(unsigne
 
 namespace {
 
-constexpr int E = 16, N1 = 64, TX = 16, HX = 18, TY = 8, RING = 10, LDR = 68, CH = 48, CQ = 16;
-constexpr int DY_PIECE = CH * E;             // halves
-constexpr int DY_SLOT = 3 * DY_PIECE;
+constexpr int TX = 16, HX = 18, TY = 8, RING = 10, CH = 48;
 constexpr int A3_PIECE = CH * 16;            // halves, per wave and piece: the chunk's 48 pixels x the wave's 16 channels
-constexpr size_t OFF_DY = (size_t)RING * HX * LDR * 4;
-constexpr size_t OFF_A3 = OFF_DY + (size_t)2 * DY_SLOT * 2;
-constexpr size_t OFF_TAPS = OFF_A3 + (size_t)4 * 3 * A3_PIECE * 2;
-constexpr size_t LDS_BYTES = OFF_TAPS + (size_t)N1 * 9 * 4;
-static_assert(OFF_DY % 16 == 0 && OFF_A3 % 16 == 0 && OFF_TAPS % 16 == 0, "16-byte aligned LDS regions");
-static_assert((size_t)(4 * CQ * 40 + 4 * E) * 4 <= OFF_DY, "the end-of-kernel reduction rows alias the ring");
+template <int E_>
+struct KA {
+    static constexpr int E = E_, N1 = 4 * E, NW = N1 / 16, NT = 64 * NW, LDR = N1 + 4, CQ = N1 / 4, LQ = E / 4;
+    static constexpr int DY_PIECE = CH * E;      // halves
+    static constexpr int DY_SLOT = 3 * DY_PIECE;
+    static constexpr size_t OFF_DY = (size_t)RING * HX * LDR * 4;
+    static constexpr size_t OFF_A3 = OFF_DY + (size_t)2 * DY_SLOT * 2;
+    static constexpr size_t OFF_TAPS = OFF_A3 + (size_t)NW * 3 * A3_PIECE * 2;
+    static constexpr size_t LDS_BYTES = OFF_TAPS + (size_t)N1 * 9 * 4;
+    // slab row of a workgroup: [d dww N1 x 9 | d dwb N1 | dW3 E x N1 | db3 E]
+    static constexpr int R_DB = N1 * 9, R_W3 = N1 * 10, R_B3 = R_W3 + E * N1, ROW = R_B3 + E;
+    static constexpr int LGW = 64 / CQ, PPL = TX / LGW, RPW = TY / NW;   // P2: lane groups per wave (4 | 2), consecutive pixels of a tile row per lane (4 | 8), tile rows per wave (2 | 1)
+    static_assert(OFF_DY % 16 == 0 && OFF_A3 % 16 == 0 && OFF_TAPS % 16 == 0, "16-byte aligned LDS regions");
+    static_assert((size_t)(NW * CQ * 40 + NW * E) * 4 <= OFF_DY, "the end-of-kernel reduction rows alias the ring");
+    static_assert(CH * LQ <= NT, "one dy vector per thread and chunk");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+static_assert(KA<16>::R_DB == FFN_DW_BWD_X_DB && KA<16>::R_W3 == FFN_DW_BWD_X_W3 && KA<16>::R_B3 == FFN_DW_BWD_X_B3 && KA<16>::ROW == FFN_DW_BWD_X_ROW, "slab row (bwd_kernels.h)");
+static_assert(KA<32>::ROW == FFN_DW_BWD_X32_ROW, "slab row (bwd_kernels.h)");
 
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 __device__ __forceinline__ s16x4_t lds_x4(const uint16_t* p) { return __builtin_bit_cast(s16x4_t, *reinterpret_cast<const u32x2_t*>(p)); }
@@ -59,9 +75,6 @@ __device__ __forceinline__ bf16x8_t cat8(s16x4_t lo, s16x4_t hi) {
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
     return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
-#ifndef LG_KA_SLIDE
-#define LG_KA_SLIDE 1
-#endif
 #ifndef LG_KA_PAIR
 #define LG_KA_PAIR 0   // measured in THIS kernel (VALU / LDS bound, matrix pipe 10 % busy): the operand concatenation costs 133.7 vs 119.5 us per launch; off
 #endif
@@ -78,31 +91,42 @@ __device__ __forceinline__ void mfmaN_16(f32x4_t& acc, const s16x4_t (&a)[3], co
     else acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[0], acc, 0, 0, 0);
 }
 
+__device__ __forceinline__ bf16x8_t lds_x8(const uint16_t* p) { return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(p)); }
+
 // NP = 3: fp32 storage of h2 / h3 / dh2, fp32-equivalent split products; NP = 1 (precision = 'bf16'): bf16 storage (hstore.h), plain bf16 products
-template <int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn_dw_bwd_xs(FfnDwBwdXArgs a, int tiles_x, int strips_y, int nstrips, int SH) {
+template <int E, int NP>
+__global__ __launch_bounds__(KA<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn_dw_bwd_xs(FfnDwBwdXArgs a, int tiles_x, int strips_y, int nstrips, int SH) {
+    using C = KA<E>;
+    constexpr int N1 = C::N1, NW = C::NW, NT = C::NT, LDR = C::LDR, CQ = C::CQ, LQ = C::LQ, DY_PIECE = C::DY_PIECE, DY_SLOT = C::DY_SLOT;
+    constexpr int LGW = C::LGW, PPL = C::PPL, RPW = C::RPW, NM = E / 16;
     constexpr bool BF = (NP == 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* ring = reinterpret_cast<float*>(smem_raw);                          // [RING*HX][LDR] dh3
-    uint16_t* DY = reinterpret_cast<uint16_t*>(smem_raw + OFF_DY);             // [2][3][CH][E]
+    uint16_t* DY = reinterpret_cast<uint16_t*>(smem_raw + C::OFF_DY);          // [2][3][CH][E]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-    uint16_t* A3 = reinterpret_cast<uint16_t*>(smem_raw + OFF_A3) + wave * 3 * A3_PIECE;   // [3][48 px][16 ch] of this wave
+    uint16_t* A3 = reinterpret_cast<uint16_t*>(smem_raw + C::OFF_A3) + wave * 3 * A3_PIECE;   // [3][48 px][16 ch] of this wave
     const int h = a.h, w = a.w;
     const int c0 = wave * 16 + 4 * g;                 // first of the lane's four hidden channels after the GEMM
-    const WFrag16 w3f = NP == 3 ? load_wfrag16(a.w3t + (size_t)(wave * 16) * E, E, 0) : load_wfrag16_rne(a.w3t + (size_t)(wave * 16) * E, E, 0);   // W3^T rows [16 w, 16 w + 16)
-    const int q = lane % CQ;                          // P2: lane = (pixel slot lane / 16, channel quad q)
-    const int lpx = threadIdx.x >> 2, lq = threadIdx.x & 3;                    // dy role: thread t < 192 = (chunk pixel t / 4, channel quad t % 4)
-    const bool dy_thread = threadIdx.x < 4 * CH;
+    // W3^T rows [16 w, 16 w + 16): one 16-deep block at e = 16, one 32-deep block at e = 32
+    WFrag16 w3f16;
+    WFrag32 w3f32;
+    if constexpr (E == 16) w3f16 = NP == 3 ? load_wfrag16(a.w3t + (size_t)(wave * 16) * E, E, 0) : load_wfrag16_rne(a.w3t + (size_t)(wave * 16) * E, E, 0);
+    else w3f32 = NP == 3 ? load_wfrag32(a.w3t + (size_t)(wave * 16) * E, E, 0) : load_wfrag32_rne(a.w3t + (size_t)(wave * 16) * E, E, 0);
+    const int q = lane % CQ, lgrp = lane / CQ;        // P2: lane = (lane group, channel quad q)
+    const int lpx = threadIdx.x / LQ, lq = threadIdx.x % LQ;                   // dy role: thread t < CH * LQ = (chunk pixel t / LQ, channel quad t % LQ)
+    const bool dy_thread = threadIdx.x < LQ * CH;
 
-    // the depthwise taps [64][9], once per workgroup in LDS: re-read per step from there (from L1 / L2 the wait for them sat behind every
+    // the depthwise taps [N1][9], once per workgroup in LDS: re-read per step from there (from L1 / L2 the wait for them sat behind every
     // HBM load in flight -- one in-order counter -- 1.9 k ticks of a 24 k-tick step, profiles/r03_ffn_bwd_phase_stamps.txt)
-    float* sTaps = reinterpret_cast<float*>(smem_raw + OFF_TAPS);
-    for (int i = threadIdx.x; i < N1 * 9; i += 256) sTaps[i] = a.dww[i];
+    float* sTaps = reinterpret_cast<float*>(smem_raw + C::OFF_TAPS);
+    for (int i = threadIdx.x; i < N1 * 9; i += NT) sTaps[i] = a.dww[i];
     // gradient partials of the depthwise taps / bias of the lane's four P2 channels, as channel PAIRS (v_pk_fma_f32)
     lg_v2f pw01[10], pw23[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) { pw01[k] = (lg_v2f){0.f, 0.f}; pw23[k] = (lg_v2f){0.f, 0.f}; }
-    f32x4_t acc3 = (f32x4_t){0.f, 0.f, 0.f, 0.f};     // dW3[4 g + v][16 w + r]
+    f32x4_t acc3[NM];                                 // dW3[16 mt + 4 g + v][16 w + r]
+#pragma unroll
+    for (int mt = 0; mt < NM; ++mt) acc3[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     float4 sb3 = make_float4(0.f, 0.f, 0.f, 0.f);     // db3[4 lq ..], this thread's own pixels
 
 #pragma unroll 1
@@ -132,7 +156,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     auto dy_store = [&](int slot, const float4& dvr, bool in, bool own) {
         const float4 dv = make_float4(in ? dvr.x : 0.f, in ? dvr.y : 0.f, in ? dvr.z : 0.f, in ? dvr.w : 0.f);   // dy = 0 outside the image: so is dh3
         if (own) { sb3.x += dv.x; sb3.y += dv.y; sb3.z += dv.z; sb3.w += dv.w; }
-        if (!dy_thread) return;          // wave 3 holds no dy vectors
+        if (!dy_thread) return;          // the last wave(s) hold no dy vectors
         const float v[4] = {dv.x, dv.y, dv.z, dv.w};
         u32x2_t q1, q2, q3;
         split_x4<NP>(v, q1, q2, q3);
@@ -182,12 +206,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 const bool own = m < npx && hx >= 1 && hx <= TX && x < w && y >= Y0 && y < Yend;
                 // (W3^T dy)[16 w + 4 g + v][pixel r]
                 f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                {
+                if constexpr (E == 16) {
                     const uint16_t* p = dyb + (pb * 16 + r) * E + 4 * g;
                     s16x4_t xb[3];
                     xb[0] = lds_x4(p);
                     if (NP == 3) { xb[1] = lds_x4(p + DY_PIECE); xb[2] = lds_x4(p + 2 * DY_PIECE); } else { xb[1] = xb[0]; xb[2] = xb[0]; }
-                    mfmaN_16<NP>(acc, w3f.p, xb);
+                    mfmaN_16<NP>(acc, w3f16.p, xb);
+                } else {
+                    const uint16_t* p = dyb + (pb * 16 + r) * E + 8 * g;
+                    const bf16x8_t x1 = lds_x8(p);
+                    bf16x8_t x2 = x1, x3 = x1;
+                    if (NP == 3) { x2 = lds_x8(p + DY_PIECE); x3 = lds_x8(p + 2 * DY_PIECE); }
+                    mfma_np32<NP>(acc, w3f32, x1, x2, x3);
                 }
                 lg_v2f a01, a23, g01, g23;
                 const float4 h3v = HS<BF>::widen(h3c[pb]);
@@ -214,13 +244,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             // dW3[.][16 w + .] += dy^T gelu(h3): both operands read by columns (K = the chunk's 48 pixels); off the critical path of the ring
 #pragma unroll
             for (int pb = 0; pb < 3; ++pb) {
-                const uint16_t* pa = dyb + (pb * 16 + 4 * g + (r >> 2)) * E + 4 * (r & 3);
                 const uint16_t* pbp = A3 + (pb * 16 + 4 * g + (r >> 2)) * 16 + 4 * (r & 3);
-                s16x4_t dt[3], at[3];
-                dt[0] = lds_tr4(pa); at[0] = lds_tr4(pbp);
-                if (NP == 3) { dt[1] = lds_tr4(pa + DY_PIECE); dt[2] = lds_tr4(pa + 2 * DY_PIECE); at[1] = lds_tr4(pbp + A3_PIECE); at[2] = lds_tr4(pbp + 2 * A3_PIECE); }
-                else { dt[1] = dt[0]; dt[2] = dt[0]; at[1] = at[0]; at[2] = at[0]; }
-                mfmaN_16<NP>(acc3, dt, at);
+                s16x4_t at[3];
+                at[0] = lds_tr4(pbp);
+                if (NP == 3) { at[1] = lds_tr4(pbp + A3_PIECE); at[2] = lds_tr4(pbp + 2 * A3_PIECE); } else { at[1] = at[0]; at[2] = at[0]; }
+#pragma unroll
+                for (int mt = 0; mt < NM; ++mt) {
+                    const uint16_t* pa = dyb + (pb * 16 + 4 * g + (r >> 2)) * E + 16 * mt + 4 * (r & 3);
+                    s16x4_t dt[3];
+                    dt[0] = lds_tr4(pa);
+                    if (NP == 3) { dt[1] = lds_tr4(pa + DY_PIECE); dt[2] = lds_tr4(pa + 2 * DY_PIECE); } else { dt[1] = dt[0]; dt[2] = dt[0]; }
+                    mfmaN_16<NP>(acc3[mt], dt, at);
+                }
             }
             if (more) {
                 dy_store(slot ^ 1, ndv, nin, nown);
@@ -250,23 +285,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         stamp_on = (y0 == Y0 + 2 * TY) && strip == 0;
 #endif
         STAMP(0);
-        // h2 of the step's output pixels (wave w: tile rows 2 w, 2 w + 1; lane: pixel x0 + lane / 16 + 4 it, channels 4 q ..), item
-        // i = 4 ch + it.  An HBM round trip is longer than one P2 item, so four vectors are kept in flight: items 0 .. 3 are requested at
-        // the top of the LAST chunk of the halo pass, item i + 4 while item i is worked on.  Every output pixel of a step is inside the
-        // image (launcher: h % 8 == 0, w % 16 == 0).
-        auto h2_fetch = [&](int i) {
-#if LG_KA_SLIDE
-            const int y = y0 + 2 * wave + (i >> 2), x = x0 + 4 * (lane >> 4) + (i & 3);
-#else
-            const int y = y0 + 2 * wave + (i >> 2), x = x0 + (lane >> 4) + 4 * (i & 3);
-#endif
-            return HS<BF>::ldraw(a.h2, ((b * h + y) * (long)w + x) * N1 + 4 * q);
-        };
+        // h2 of the step's output pixels: wave w owns tile rows RPW w .. RPW w + RPW - 1, a lane the PPL consecutive pixels
+        // x0 + PPL lgrp + it of a row, channels 4 q ..  An HBM round trip is longer than one P2 item, so four vectors are kept in flight:
+        // items 0 .. 3 are requested at the top of the LAST chunk of the halo pass, the item four places on while item i is worked on.
+        // Every output pixel of a step is inside the image (launcher: h % 8 == 0, w % 16 == 0).
+        const int yrow0 = y0 + RPW * wave, xl0 = x0 + PPL * lgrp;
+        auto h2_at = [&](int y, int x) { return HS<BF>::ldraw(a.h2, ((b * h + y) * (long)w + x) * N1 + 4 * q); };
         typename HS<BF>::raw4 h2a, h2b, h2c, h2d;
         pre = npre; pin = npin; pown = npown;
 #pragma unroll
         for (int pb = 0; pb < 3; ++pb) h3p[pb] = nh3[pb];
-        compute_rows(y0 + 1, TY, pre, pin, pown, h3p, [&] { h2a = h2_fetch(0); h2b = h2_fetch(1); h2c = h2_fetch(2); h2d = h2_fetch(3); });
+        compute_rows(y0 + 1, TY, pre, pin, pown, h3p, [&] { h2a = h2_at(yrow0, xl0); h2b = h2_at(yrow0, xl0 + 1); h2c = h2_at(yrow0, xl0 + 2); h2d = h2_at(yrow0, xl0 + 3); });
         // the depthwise taps of the lane's four channels as channel pairs: 36 contiguous floats from LDS per step instead of 36 VGPRs pinned
         // through the halo pass
         lg_v2f wq01[9], wq23[9];
@@ -288,14 +317,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         h3_fetch(y0 + TY + 1, 0, nh3);
         STAMP(9);
         const int sbase = (y0 - Y0) % RING;            // ring slot of row y0 - 1
-        // A lane works on FOUR CONSECUTIVE pixels of a tile row (x0 + 4 (lane / 16) + it) and slides a 3 x 3 window of dh3 vectors over
-        // them: item `it` needs ring columns it .. it + 2, so a row of four items reads 6 x 3 vectors instead of 4 x 9 -- the P2 phase was
-        // LDS-read bound (profiles/r03_ffn_bwd_phase_stamps.txt).  hreg holds an item's h2 vector and is re-loaded with the vector of the
-        // item one tile row down (no register rotation: a rotating set needs its moves in front of the loop's back edge, i.e. a wait for the
-        // load issued in the same iteration).
-#if LG_KA_SLIDE
-        auto row4 = [&](int ch) {
-            const int ty = 2 * wave + ch, y = y0 + ty, txb = 4 * (lane >> 4);
+        // A lane works on PPL CONSECUTIVE pixels of a tile row and slides a 3 x 3 window of dh3 vectors over them: item `it` needs ring
+        // columns it .. it + 2, so a row of PPL items reads (PPL + 2) x 3 vectors instead of PPL x 9 -- the P2 phase was LDS-read bound
+        // (profiles/r03_ffn_bwd_phase_stamps.txt).  hreg holds an item's h2 vector and is re-loaded with the vector of the item four places
+        // on in the lane's walk (no register rotation: a rotating set needs its moves in front of the loop's back edge, i.e. a wait for
+        // the load issued in the same iteration).
+        auto rowN = [&](int ch) {
+            const int ty = RPW * wave + ch, y = y0 + ty, txb = PPL * lgrp;
             const float* rrow[3];
 #pragma unroll
             for (int rr = 0; rr < 3; ++rr) {       // ring row ty + rr (relative to row y0 - 1) meets tap dy = 2 - rr
@@ -303,17 +331,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 sl = sl >= RING ? sl - RING : sl;
                 rrow[rr] = ring + (sl * HX + txb) * LDR + 4 * q;
             }
-            float4 col[6][3];
+            float4 col[4][3];                      // the window in a ring of four column slots: item `it` reads slots it .. it + 2 (mod 4)
             auto ldcol = [&](int c) {
 #pragma unroll
-                for (int rr = 0; rr < 3; ++rr) col[c][rr] = *reinterpret_cast<const float4*>(rrow[rr] + c * LDR);
+                for (int rr = 0; rr < 3; ++rr) col[c & 3][rr] = *reinterpret_cast<const float4*>(rrow[rr] + c * LDR);
             };
             ldcol(0); ldcol(1); ldcol(2);
             auto item = [&](int it, typename HS<BF>::raw4& hreg) {
-                if (it < 3) ldcol(it + 3);          // the next item's new column: requested under this item's arithmetic
+                if (it + 1 < PPL) ldcol(it + 3);    // the next item's new column, into the slot this item does not read: requested under its arithmetic
                 const int x = x0 + txb + it;
                 const float4 hc = HS<BF>::widen(hreg);
-                hreg = HS<BF>::ldraw(a.h2, ((b * h + y0 + 2 * wave + 1) * (long)w + x) * N1 + 4 * q);   // ch = 0: one tile row down; ch = 1: a repeat nobody waits for
+                {   // the item four places on: same row while it lasts, then the lane's next row (clamped to the step: a repeat nobody waits for)
+                    const int nit = it + 4, ny = nit < PPL ? y : (ch + 1 < RPW ? y + 1 : y), nx = x0 + txb + (nit < PPL ? nit : nit - PPL);
+                    hreg = h2_at(ny, nx);
+                }
                 const lg_v2f h01 = (lg_v2f){hc.x, hc.y}, h23 = (lg_v2f){hc.z, hc.w};
                 lg_v2f acc01 = (lg_v2f){0.f, 0.f}, acc23 = (lg_v2f){0.f, 0.f};
 #pragma unroll
@@ -323,7 +354,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                         // forward: h3(p) += w[dy][dx] h2(p + (dy-1, dx-1))  ->  h2(q) meets dh3(q - (dy-1, dx-1)) in both sums: halo column
                         // tx + 2 - dx = tx + cc, ring row ty + 2 - dy = ty + rr
                         const int k = (2 - rr) * 3 + (2 - cc);
-                        const float4 gv = col[it + cc][rr];
+                        const float4 gv = col[(it + cc) & 3][rr];
                         const lg_v2f g01 = (lg_v2f){gv.x, gv.y}, g23 = (lg_v2f){gv.z, gv.w};
                         acc01 = wq01[k] * g01 + acc01;
                         acc23 = wq23[k] * g23 + acc23;
@@ -335,122 +366,101 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 __builtin_amdgcn_sched_barrier(0);      // one item at a time: interleaved items need more registers than there are
             };
             item(0, h2a); item(1, h2b); item(2, h2c); item(3, h2d);
+            if constexpr (PPL == 8) { item(4, h2a); item(5, h2b); item(6, h2c); item(7, h2d); }
         };
 #pragma unroll 1
-        for (int ch = 0; ch < 2; ++ch) row4(ch);
-#else
-        auto item = [&](int ch, int it, typename HS<BF>::raw4& hreg) {
-            const int ty = 2 * wave + ch, tx = (lane >> 4) + 4 * it;
-            const int y = y0 + ty, x = x0 + tx;
-            const float4 hc = HS<BF>::widen(hreg);
-            {
-                const int yn = y0 + 2 * wave + 1;      // ch = 0: the same pixel column one tile row down; ch = 1: the repeat is an L2 hit nobody waits for
-                hreg = HS<BF>::ldraw(a.h2, ((b * h + yn) * (long)w + x) * N1 + 4 * q);
-            }
-            const lg_v2f h01 = (lg_v2f){hc.x, hc.y}, h23 = (lg_v2f){hc.z, hc.w};
-            lg_v2f acc01 = (lg_v2f){0.f, 0.f}, acc23 = (lg_v2f){0.f, 0.f};
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                // forward: h3(p) += w[dy][dx] h2(p + (dy-1, dx-1))  ->  h2(q) meets dh3(q - (dy-1, dx-1)) in both sums
-                int sl = sbase + ty + 2 - dy;
-                sl = sl >= RING ? sl - RING : sl;
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float4 gv = *reinterpret_cast<const float4*>(ring + (sl * HX + tx + 2 - dx) * LDR + 4 * q);
-                    const lg_v2f g01 = (lg_v2f){gv.x, gv.y}, g23 = (lg_v2f){gv.z, gv.w};
-                    acc01 = wq01[dy * 3 + dx] * g01 + acc01;
-                    acc23 = wq23[dy * 3 + dx] * g23 + acc23;
-                    pw01[dy * 3 + dx] = h01 * g01 + pw01[dy * 3 + dx];
-                    pw23[dy * 3 + dx] = h23 * g23 + pw23[dy * 3 + dx];
-                    if (dy == 1 && dx == 1) { pw01[9] += g01; pw23[9] += g23; }
-                }
-            }
-            HS<BF>::st4(a.dh2, ((b * h + y) * (long)w + x) * N1 + 4 * q, make_float4(acc01.x, acc01.y, acc23.x, acc23.y));
-            __builtin_amdgcn_sched_barrier(0);      // one item at a time: interleaved items need more registers than there are
-        };
-#pragma unroll 1
-        for (int ch = 0; ch < 2; ++ch) {
-            item(ch, 0, h2a);
-            item(ch, 1, h2b);
-            item(ch, 2, h2c);
-            item(ch, 3, h2d);
-        }
-#endif
+        for (int ch = 0; ch < RPW; ++ch) rowN(ch);
         STAMP(10);
     }   // steps of the strip
     __syncthreads();   // the last step's P2 readers of the ring are done before the next strip's prologue writes it
     }   // strips of this workgroup
 
-    // ---- this workgroup's partial sums -> its slab row [d dww 64x9 | d dwb 64 | dW3 16x64 | db3 16]
-    float* row = a.slab + (size_t)blockIdx.x * FFN_DW_BWD_X_ROW;
+    // ---- this workgroup's partial sums -> its slab row [d dww N1 x 9 | d dwb N1 | dW3 E x N1 | db3 E]
+    float* row = a.slab + (size_t)blockIdx.x * C::ROW;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) row[FFN_DW_BWD_X_W3 + (4 * g + v) * N1 + 16 * wave + r] = acc3[v];
-    float* red = ring;    // [4 waves][16 quads][40] | [4 waves][16]: the ring is dead (barrier at the end of the last strip)
-    // depthwise partials: lanes with the same q (four per wave) hold the same channels
+    for (int mt = 0; mt < NM; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) row[C::R_W3 + (16 * mt + 4 * g + v) * N1 + 16 * wave + r] = acc3[mt][v];
+    float* red = ring;    // [NW waves][CQ quads][40] | [NW waves][E]: the ring is dead (barrier at the end of the last strip)
+    // depthwise partials: lanes with the same q (LGW per wave) hold the same channels
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int k = 0; k < 10; ++k) {
             float v = u == 0 ? pw01[k].x : (u == 1 ? pw01[k].y : (u == 2 ? pw23[k].x : pw23[k].y));
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
+#pragma unroll
+            for (int off = CQ; off < 64; off <<= 1) v += __shfl_xor(v, off);
             if (lane < CQ) red[(wave * CQ + q) * 40 + u * 10 + k] = v;
         }
-    // db3: dy threads with the same lq hold the same channels (48 per quad, in waves 0 .. 2)
+    // db3: dy threads with the same lq hold the same channels
     {
-        float4 s = sb3;
+        float4 s4 = sb3;
 #pragma unroll
-        for (int off = 4; off < 64; off <<= 1) {
-            s.x += __shfl_xor(s.x, off); s.y += __shfl_xor(s.y, off); s.z += __shfl_xor(s.z, off); s.w += __shfl_xor(s.w, off);
+        for (int off = LQ; off < 64; off <<= 1) {
+            s4.x += __shfl_xor(s4.x, off); s4.y += __shfl_xor(s4.y, off); s4.z += __shfl_xor(s4.z, off); s4.w += __shfl_xor(s4.w, off);
         }
-        if (lane < 4) *reinterpret_cast<float4*>(red + 4 * CQ * 40 + wave * E + 4 * lane) = s;
+        if (lane < LQ) *reinterpret_cast<float4*>(red + NW * CQ * 40 + wave * E + 4 * lane) = s4;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < CQ * 40; i += 256) {
-        const float v = (red[i] + red[CQ * 40 + i]) + (red[2 * CQ * 40 + i] + red[3 * CQ * 40 + i]);
+    for (int i = threadIdx.x; i < CQ * 40; i += NT) {
+        float v = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < NW; ++w8) v += red[w8 * CQ * 40 + i];
         const int qq = i / 40, rem = i - qq * 40, u = rem / 10, k = rem - u * 10;
         const int c = 4 * qq + u;
         if (k < 9) row[c * 9 + k] = v;
-        else row[FFN_DW_BWD_X_DB + c] = v;
+        else row[C::R_DB + c] = v;
     }
     if (threadIdx.x < E) {
-        const float* s = red + 4 * CQ * 40 + threadIdx.x;
-        row[FFN_DW_BWD_X_B3 + threadIdx.x] = (s[0] + s[E]) + (s[2 * E] + s[3 * E]);
+        const float* sp = red + NW * CQ * 40 + threadIdx.x;
+        float v = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < NW; ++w8) v += sp[w8 * E];
+        row[C::R_B3 + threadIdx.x] = v;
     }
 }
 
-}   // namespace
-
-int launch_ffn_dw_bwd_xs(const FfnDwBwdXArgs& a, hipStream_t s) {
-    ProfScope prof__(LG_K_FFN2_BWD, s);
-    if (!a.dy || !a.h3 || !a.h2 || !a.dh2 || !a.w3t || !a.dww || !a.slab) { lg_set_error("ffn_dw_bwd_xs: null argument"); return -2; }
+template <int E>
+static int launch_dw_t(const FfnDwBwdXArgs& a, hipStream_t s) {
+    using C = KA<E>;
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd_xs<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd_xs<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd_xs<E, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_dw_bwd_xs<E, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
         if (e != hipSuccess) { lg_set_error("ffn_dw_bwd_xs: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
-    if ((a.h & 7) || (a.w & 15)) { lg_set_error("ffn_dw_bwd_xs: h must be a multiple of 8 and w of 16 (got %d x %d)", a.h, a.w); return -2; }
     const int tiles_x = (a.w + 15) / 16;
-    // strip height as in the forward: the tallest multiple of 8 rows that still yields >= 512 strips (two resident workgroups per CU), at least 16
+    // strip height as in the forward: the tallest multiple of 8 rows that still yields one strip per resident workgroup (512 at e = 16: two per
+    // CU; 256 at e = 32), at least 16
+    const int wgs = ffn_dw_bwd_x_wgs(E);
     int SH = (a.h + 7) / 8 * 8;
-    while (SH > 16 && (long)a.B * tiles_x * ((a.h + SH - 1) / SH) < 512) SH = (SH / 2 + 7) / 8 * 8;
+    while (SH > 16 && (long)a.B * tiles_x * ((a.h + SH - 1) / SH) < wgs) SH = (SH / 2 + 7) / 8 * 8;
     const int strips_y = (a.h + SH - 1) / SH;
     const int nstrips = a.B * tiles_x * strips_y;
-    const int grid = nstrips < FFN_DW_BWD_X_WGS ? nstrips : FFN_DW_BWD_X_WGS;
-    if (a.hbf) k_ffn_dw_bwd_xs<1><<<grid, 256, LDS_BYTES, s>>>(a, tiles_x, strips_y, nstrips, SH);   // precision = 'bf16'
-    else k_ffn_dw_bwd_xs<3><<<grid, 256, LDS_BYTES, s>>>(a, tiles_x, strips_y, nstrips, SH);
+    const int grid = nstrips < wgs ? nstrips : wgs;
+    if (a.hbf) k_ffn_dw_bwd_xs<E, 1><<<grid, C::NT, C::LDS_BYTES, s>>>(a, tiles_x, strips_y, nstrips, SH);   // precision = 'bf16'
+    else k_ffn_dw_bwd_xs<E, 3><<<grid, C::NT, C::LDS_BYTES, s>>>(a, tiles_x, strips_y, nstrips, SH);
     LG_CHECK_LAUNCH();
     ReduceJob j;
-    j.dst2 = nullptr; j.nslices = grid; j.slice_stride = FFN_DW_BWD_X_ROW;
+    j.dst2 = nullptr; j.nslices = grid; j.slice_stride = C::ROW;
     auto job = [&](int off, float* dst, int rows, int cols) {
         j.slab = a.slab + off; j.dst = dst; j.rows = rows; j.cols = cols; j.row_stride = cols; j.ld = cols; j.rows_valid = rows; j.cols_valid = cols;
         return launch_reduce_job(j, s);
     };
-    int rc = job(0, a.d_dww, N1, 9);
-    if (!rc) rc = job(FFN_DW_BWD_X_DB, a.d_dwb, 1, N1);
-    if (!rc) rc = job(FFN_DW_BWD_X_W3, a.d_w3, E, N1);
-    if (!rc) rc = job(FFN_DW_BWD_X_B3, a.d_b3, 1, E);
+    int rc = job(0, a.d_dww, C::N1, 9);
+    if (!rc) rc = job(C::R_DB, a.d_dwb, 1, C::N1);
+    if (!rc) rc = job(C::R_W3, a.d_w3, E, C::N1);
+    if (!rc) rc = job(C::R_B3, a.d_b3, 1, E);
     return rc;
+}
+
+}   // namespace
+
+int launch_ffn_dw_bwd_xs(int e, const FfnDwBwdXArgs& a, hipStream_t s) {
+    ProfScope prof__(LG_K_FFN2_BWD, s);
+    if (e != 16 && e != 32) { lg_set_error("ffn_dw_bwd_xs: e=%d unsupported", e); return -1; }
+    if (!a.dy || !a.h3 || !a.h2 || !a.dh2 || !a.w3t || !a.dww || !a.slab) { lg_set_error("ffn_dw_bwd_xs: null argument"); return -2; }
+    if ((a.h & 7) || (a.w & 15)) { lg_set_error("ffn_dw_bwd_xs: h must be a multiple of 8 and w of 16 (got %d x %d)", a.h, a.w); return -2; }
+    return e == 16 ? launch_dw_t<16>(a, s) : launch_dw_t<32>(a, s);
 }

@@ -300,8 +300,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int y = y0 + ty, x = x0 + tx;
                     if (y < Yend && x < w) {
                         const long off = ((b * h + y) * (long)w + x) * N1 + 4 * qc;
-                        HS<BF>::st4(a2.a3s, off, make_float4(av[0], av[1], av[2], av[3]));
-                        HS<BF>::st4(a2.g3s, off, make_float4(g01.x, g01.y, g23.x, g23.y));
+                        if (a2.g3s) {   // five-tensor form: gelu(h3), gelu'(h3)
+                            HS<BF>::st4(a2.a3s, off, make_float4(av[0], av[1], av[2], av[3]));
+                            HS<BF>::st4(a2.g3s, off, make_float4(g01.x, g01.y, g23.x, g23.y));
+                        } else {        // k_ffn_dw_bwd_xs<32> re-evaluates both from the pre-activation
+                            HS<BF>::st4(a2.a3s, off, acc);
+                        }
                     }
                 } else {
                     const lg_v2f a01 = gelu2_f((lg_v2f){acc.x, acc.y}), a23 = gelu2_f((lg_v2f){acc.z, acc.w});

@@ -301,13 +301,14 @@ def test_gradients_are_bitwise_reproducible(C, H):
     assert float(g1.abs().max()) > 0
 
 
+@pytest.mark.parametrize('C', [4, 8])
 @pytest.mark.parametrize('B,h,w', [(1, 16, 16), (3, 80, 48), (2, 48, 208), (1, 128, 128)])
-def test_ffn_backward_kernels_at_awkward_shapes(B, h, w):
-    """the round-3 e = 16 FFN backward pair (k_ffn_dw_bwd_xs: strip walk with an LDS ring of dh3; k_ffn1_bwd_xs: h1 re-computed, dx and all
-    weight gradients on the bf16 pipe in split arithmetic) in isolation against the fp64 oracle at sizes that exercise their edges: one
-    strip step only, strips that end inside a step, rectangular planes, an odd batch, a multi-step strip walk"""
+def test_ffn_backward_kernels_at_awkward_shapes(C, B, h, w):
+    """the e = 16 FFN backward pair (k_ffn_dw_bwd_xs<16>: strip walk with an LDS ring of dh3; k_ffn1_bwd_xs: h1 re-computed, dx and all
+    weight gradients on the bf16 pipe in split arithmetic) and, with 8 bands, the e = 32 path (round 4: k_ffn_dw_bwd_xs<32>, the same walk
+    with eight waves, + k_ffn1_bwd_x32) in isolation against the fp64 oracle at sizes that exercise their edges: one strip step only,
+    strips that end inside a step, rectangular planes, an odd batch, a multi-step strip walk"""
     from gpu_helpers import Ops, make_module
-    C = 4
     net = make_module(C, 1)
     ops = Ops(net, h, w)
     e = 4 * C
