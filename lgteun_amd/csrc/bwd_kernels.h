@@ -235,9 +235,8 @@ struct FfnDwBwdXArgs {
 #define FFN_DW_BWD_X_W3 640
 #define FFN_DW_BWD_X_B3 1664
 #define FFN_DW_BWD_X_ROW 1680
-#define FFN_DW_BWD_X32_ROW 5408   // e = 32: [d dww 128 x 9 | d dwb 128 | dW3 32 x 128 | db3 32], one workgroup (8 waves) per CU
-inline int ffn_dw_bwd_x_wgs(int e) { return e == 16 ? FFN_DW_BWD_X_WGS : 256; }
-inline size_t ffn_dw_bwd_x_slab_floats(int e) { return e == 16 ? (size_t)FFN_DW_BWD_X_WGS * FFN_DW_BWD_X_ROW : (size_t)256 * FFN_DW_BWD_X32_ROW; }
+#define FFN_DW_BWD_X32_ROW 2720   // e = 32: [d dww 64 x 9 | d dwb 64 | dW3 32 x 64 | db3 32] per channel half; 256 workgroups per half
+inline size_t ffn_dw_bwd_x_slab_floats(int e) { return (size_t)FFN_DW_BWD_X_WGS * (e == 16 ? FFN_DW_BWD_X_ROW : FFN_DW_BWD_X32_ROW); }
 int launch_ffn_dw_bwd_xs(int e, const FfnDwBwdXArgs& a, hipStream_t s);   // e = 16 | 32
 int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[cols][rows]
 int launch_transpose3(const float* const* src, float* const* dst, const int* rows, const int* cols, int njobs, hipStream_t s);

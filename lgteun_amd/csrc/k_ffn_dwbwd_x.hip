@@ -14,11 +14,14 @@
 // consecutive channels of one pixel, so h3 arrives and dh3 leaves as 16-byte accesses.  dW3: the pixel axis is the K dimension; dy^T
 // is read by columns from the chunk's dy image (ds_read_b64_tr_b16), gelu(h3) goes through a 4.5 KB per-wave [pixel][channel] image of the chunk.
 // LDS 79 KB (two workgroups per CU): ring [10][18][68] fp32 | dy pieces [2][3][48][16] bf16 | per-wave gelu(h3) pieces [4][3][48][16] | depthwise taps [64][9] fp32.
-// e = 32 (hidden width 128: level 0 of the 8-band net, level 1 of the 4-band net): the same walk with EIGHT waves (wave w = hidden channels
-// [16 w, 16 w + 16)), one 512-thread workgroup per CU, 151 KB: ring [10][18][132] | dy pieces [2][3][48][32] | gelu(h3) pieces [8][3][48][16] | taps
-// [128][9]; W3^T dy is one 32-deep block per piece product, dW3 two 16-row tiles per wave, and in the depthwise phase a wave owns ONE tile row
-// and a lane slides its 3 x 3 window over EIGHT consecutive pixels (30 ring reads per 8 outputs).  It replaces k_ffn_dw_bwd<32> (channel-split
-// tiles: 1.40 x read amplification, h2 read twice) and the 32 x 128 k_wgrad_t launch with its second pass over dy and gelu(h3).
+// e = 32 (hidden width 128: level 0 of the 8-band net, level 1 of the 4-band net; round 4): everything behind W3^T dy is per hidden CHANNEL, so
+// the 128 channels are two independent halves of 64: blockIdx.y = half, each half IS the e = 16 walk (four waves, two workgroups per CU, 74 KB:
+// the gelu(h3) image is per 16-pixel block there) on channels [64 half, 64 half + 64) of h3 / h2 / dh2, with K = 32 in W3^T dy (one 32-deep block
+// per piece product) and two 16-row tiles of dW3 per wave; dy is read by both halves (the second read is an L2 hit).  A first form with EIGHT
+// waves in one 151 KB workgroup per CU ran 384 us against 314 + 52 for the kernels it replaces: every wave of the CU in the same phase, nothing
+// beside the barriers, 66 spilled registers whose scratch traffic waits for the prefetches (one in-order counter) -- stamps: 56 k ticks per step
+// against 2 x 12.5 k.  It replaces k_ffn_dw_bwd<32> (channel-split tiles: 1.40 x read amplification, h2 read twice) and the 32 x 128 k_wgrad_t
+// launch with its second pass over dy and gelu(h3).
 #include "kernels.h"
 #include "bwd_kernels.h"
 #include "split_bf16.h"
@@ -26,7 +29,7 @@
 
 // In-kernel phase stamps (diagnostic build only, -DLG_STAMPS: tools/build_stamps.sh + tools/bwd_stamps.py)
 #ifdef LG_STAMPS
-__device__ unsigned long long g_ka_stamps[4 * 16];
+__device__ unsigned long long g_ka_stamps[8 * 16];
 #define STAMP(i) do { if (blockIdx.x == 0 && lane == 0 && stamp_on) g_ka_stamps[wave * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" __attribute__((visibility("default"))) int lg_debug_ka_stamps(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ka_stamps), sizeof(g_ka_stamps));
@@ -38,23 +41,22 @@ extern "C" __attribute__((visibility("default"))) int lg_debug_ka_stamps(unsigne
 namespace {
 
 constexpr int TX = 16, HX = 18, TY = 8, RING = 10, CH = 48;
-constexpr int A3_PIECE = CH * 16;            // halves, per wave and piece: the chunk's 48 pixels x the wave's 16 channels
+constexpr int NH = 64, NW = 4, NT = 256, LDR = NH + 4, CQ = NH / 4;   // hidden channels / waves / threads of a workgroup, ring row, channel quads
+constexpr int A3_PIECE = 16 * 16;            // halves, per wave and piece: one 16-pixel block x the wave's 16 channels
 template <int E_>
 struct KA {
-    static constexpr int E = E_, N1 = 4 * E, NW = N1 / 16, NT = 64 * NW, LDR = N1 + 4, CQ = N1 / 4, LQ = E / 4;
+    static constexpr int E = E_, N1 = 4 * E, NHALF = N1 / NH, LQ = E / 4, NV = (CH * LQ + NT - 1) / NT;   // NV: dy vectors per thread and chunk
     static constexpr int DY_PIECE = CH * E;      // halves
     static constexpr int DY_SLOT = 3 * DY_PIECE;
     static constexpr size_t OFF_DY = (size_t)RING * HX * LDR * 4;
     static constexpr size_t OFF_A3 = OFF_DY + (size_t)2 * DY_SLOT * 2;
     static constexpr size_t OFF_TAPS = OFF_A3 + (size_t)NW * 3 * A3_PIECE * 2;
-    static constexpr size_t LDS_BYTES = OFF_TAPS + (size_t)N1 * 9 * 4;
-    // slab row of a workgroup: [d dww N1 x 9 | d dwb N1 | dW3 E x N1 | db3 E]
-    static constexpr int R_DB = N1 * 9, R_W3 = N1 * 10, R_B3 = R_W3 + E * N1, ROW = R_B3 + E;
-    static constexpr int LGW = 64 / CQ, PPL = TX / LGW, RPW = TY / NW;   // P2: lane groups per wave (4 | 2), consecutive pixels of a tile row per lane (4 | 8), tile rows per wave (2 | 1)
+    static constexpr size_t LDS_BYTES = OFF_TAPS + (size_t)NH * 9 * 4;
+    // slab row of a workgroup: [d dww 64 x 9 | d dwb 64 | dW3 E x 64 | db3 E]  (its channel half)
+    static constexpr int R_DB = NH * 9, R_W3 = NH * 10, R_B3 = R_W3 + E * NH, ROW = R_B3 + E;
     static_assert(OFF_DY % 16 == 0 && OFF_A3 % 16 == 0 && OFF_TAPS % 16 == 0, "16-byte aligned LDS regions");
     static_assert((size_t)(NW * CQ * 40 + NW * E) * 4 <= OFF_DY, "the end-of-kernel reduction rows alias the ring");
-    static_assert(CH * LQ <= NT, "one dy vector per thread and chunk");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 };
 static_assert(KA<16>::R_DB == FFN_DW_BWD_X_DB && KA<16>::R_W3 == FFN_DW_BWD_X_W3 && KA<16>::R_B3 == FFN_DW_BWD_X_B3 && KA<16>::ROW == FFN_DW_BWD_X_ROW, "slab row (bwd_kernels.h)");
 static_assert(KA<32>::ROW == FFN_DW_BWD_X32_ROW, "slab row (bwd_kernels.h)");
@@ -95,31 +97,35 @@ __device__ __forceinline__ bf16x8_t lds_x8(const uint16_t* p) { return __builtin
 
 // NP = 3: fp32 storage of h2 / h3 / dh2, fp32-equivalent split products; NP = 1 (precision = 'bf16'): bf16 storage (hstore.h), plain bf16 products
 template <int E, int NP>
-__global__ __launch_bounds__(KA<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn_dw_bwd_xs(FfnDwBwdXArgs a, int tiles_x, int strips_y, int nstrips, int SH) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn_dw_bwd_xs(FfnDwBwdXArgs a, int tiles_x, int strips_y, int nstrips, int SH) {
     using C = KA<E>;
-    constexpr int N1 = C::N1, NW = C::NW, NT = C::NT, LDR = C::LDR, CQ = C::CQ, LQ = C::LQ, DY_PIECE = C::DY_PIECE, DY_SLOT = C::DY_SLOT;
-    constexpr int LGW = C::LGW, PPL = C::PPL, RPW = C::RPW, NM = E / 16;
+    constexpr int N1 = C::N1, LQ = C::LQ, NV = C::NV, DY_PIECE = C::DY_PIECE, DY_SLOT = C::DY_SLOT;
+    constexpr int PPL = 4, RPW = 2, NM = E / 16;       // P2: consecutive pixels of a tile row per lane, tile rows per wave; 16-row tiles of dW3
     constexpr bool BF = (NP == 1);
+    const int hoff = blockIdx.y * NH;                  // this workgroup's channel half [hoff, hoff + 64) of the N1 hidden channels
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* ring = reinterpret_cast<float*>(smem_raw);                          // [RING*HX][LDR] dh3
     uint16_t* DY = reinterpret_cast<uint16_t*>(smem_raw + C::OFF_DY);          // [2][3][CH][E]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     uint16_t* A3 = reinterpret_cast<uint16_t*>(smem_raw + C::OFF_A3) + wave * 3 * A3_PIECE;   // [3][48 px][16 ch] of this wave
     const int h = a.h, w = a.w;
-    const int c0 = wave * 16 + 4 * g;                 // first of the lane's four hidden channels after the GEMM
+    const int c0 = wave * 16 + 4 * g;                 // first of the lane's four hidden channels after the GEMM (local to the half)
     // W3^T rows [16 w, 16 w + 16): one 16-deep block at e = 16, one 32-deep block at e = 32
     WFrag16 w3f16;
     WFrag32 w3f32;
-    if constexpr (E == 16) w3f16 = NP == 3 ? load_wfrag16(a.w3t + (size_t)(wave * 16) * E, E, 0) : load_wfrag16_rne(a.w3t + (size_t)(wave * 16) * E, E, 0);
-    else w3f32 = NP == 3 ? load_wfrag32(a.w3t + (size_t)(wave * 16) * E, E, 0) : load_wfrag32_rne(a.w3t + (size_t)(wave * 16) * E, E, 0);
+    if constexpr (E == 16) w3f16 = NP == 3 ? load_wfrag16(a.w3t + (size_t)(hoff + wave * 16) * E, E, 0) : load_wfrag16_rne(a.w3t + (size_t)(hoff + wave * 16) * E, E, 0);
+    else w3f32 = NP == 3 ? load_wfrag32(a.w3t + (size_t)(hoff + wave * 16) * E, E, 0) : load_wfrag32_rne(a.w3t + (size_t)(hoff + wave * 16) * E, E, 0);
     const int q = lane % CQ, lgrp = lane / CQ;        // P2: lane = (lane group, channel quad q)
-    const int lpx = threadIdx.x / LQ, lq = threadIdx.x % LQ;                   // dy role: thread t < CH * LQ = (chunk pixel t / LQ, channel quad t % LQ)
-    const bool dy_thread = threadIdx.x < LQ * CH;
+    // dy role: vector v of thread t = (chunk pixel, channel quad) number t + 256 v of the chunk's CH * LQ (192 at e = 16: one per thread; 384 at
+    // e = 32: threads 0 .. 127 carry a second one)
+    const int lq = threadIdx.x % LQ;                                           // 256 % LQ == 0: the same quad for every vector of a thread
+    auto dy_px = [&](int v) { return (threadIdx.x + NT * v) / LQ; };
+    auto dy_has = [&](int v) { return threadIdx.x + NT * v < LQ * CH; };
 
     // the depthwise taps [N1][9], once per workgroup in LDS: re-read per step from there (from L1 / L2 the wait for them sat behind every
     // HBM load in flight -- one in-order counter -- 1.9 k ticks of a 24 k-tick step, profiles/r03_ffn_bwd_phase_stamps.txt)
     float* sTaps = reinterpret_cast<float*>(smem_raw + C::OFF_TAPS);
-    for (int i = threadIdx.x; i < N1 * 9; i += NT) sTaps[i] = a.dww[i];
+    for (int i = threadIdx.x; i < NH * 9; i += NT) sTaps[i] = a.dww[hoff * 9 + i];
     // gradient partials of the depthwise taps / bias of the lane's four P2 channels, as channel PAIRS (v_pk_fma_f32)
     lg_v2f pw01[10], pw23[10];
 #pragma unroll
@@ -145,26 +151,35 @@ __global__ __launch_bounds__(KA<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
     // exec-masked branch makes the compiler wait with vmcnt(0) at the join (loads and stores share ONE in-order counter on gfx950), which
     // turns every prefetch into a full HBM round trip on the spot (in-kernel stamps, profiles/r03_ffn_bwd_phase_stamps.txt).
     // dy vector of halo pixel m of the row block starting at ya; in: inside the image, own: the pixel belongs to THIS strip
-    auto dy_fetch = [&](int ya, int npx, int c, float4& dv, bool& in, bool& own) {
-        const int m = c * CH + lpx;
-        const int hy = m / HX, hx = m - hy * HX;
-        const int y = ya + hy, x = x0 + hx - 1;
-        in = dy_thread && (m < npx) && y >= 0 && y < h && x >= 0 && x < w;
-        own = in && hx >= 1 && hx <= TX && y >= Y0 && y < Yend;
-        dv = *reinterpret_cast<const float4*>(a.dy + ((b * h + clampi(y, 0, h - 1)) * (long)w + clampi(x, 0, w - 1)) * E + 4 * lq);
+    struct DyVec { float4 dv[NV]; bool in[NV], own[NV]; };
+    auto dy_fetch = [&](int ya, int npx, int c, DyVec& d) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int m = c * CH + dy_px(v);
+            const int hy = m / HX, hx = m - hy * HX;
+            const int y = ya + hy, x = x0 + hx - 1;
+            d.in[v] = dy_has(v) && (m < npx) && y >= 0 && y < h && x >= 0 && x < w;
+            d.own[v] = d.in[v] && hx >= 1 && hx <= TX && y >= Y0 && y < Yend;
+            d.dv[v] = *reinterpret_cast<const float4*>(a.dy + ((b * h + clampi(y, 0, h - 1)) * (long)w + clampi(x, 0, w - 1)) * E + 4 * lq);
+        }
     };
-    auto dy_store = [&](int slot, const float4& dvr, bool in, bool own) {
-        const float4 dv = make_float4(in ? dvr.x : 0.f, in ? dvr.y : 0.f, in ? dvr.z : 0.f, in ? dvr.w : 0.f);   // dy = 0 outside the image: so is dh3
-        if (own) { sb3.x += dv.x; sb3.y += dv.y; sb3.z += dv.z; sb3.w += dv.w; }
-        if (!dy_thread) return;          // the last wave(s) hold no dy vectors
-        const float v[4] = {dv.x, dv.y, dv.z, dv.w};
-        u32x2_t q1, q2, q3;
-        split_x4<NP>(v, q1, q2, q3);
-        uint16_t* dst = DY + slot * DY_SLOT + lpx * E + 4 * lq;
-        *reinterpret_cast<u32x2_t*>(dst) = q1;
-        if (NP == 3) {
-            *reinterpret_cast<u32x2_t*>(dst + DY_PIECE) = q2;
-            *reinterpret_cast<u32x2_t*>(dst + 2 * DY_PIECE) = q3;
+    auto dy_store = [&](int slot, const DyVec& d) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float4 dvr = d.dv[v];
+            const bool in = d.in[v];
+            const float4 dv = make_float4(in ? dvr.x : 0.f, in ? dvr.y : 0.f, in ? dvr.z : 0.f, in ? dvr.w : 0.f);   // dy = 0 outside the image: so is dh3
+            if (d.own[v]) { sb3.x += dv.x; sb3.y += dv.y; sb3.z += dv.z; sb3.w += dv.w; }
+            if (!dy_has(v)) continue;        // the last wave(s) hold no (second) dy vector
+            const float vv[4] = {dv.x, dv.y, dv.z, dv.w};
+            u32x2_t q1, q2, q3;
+            split_x4<NP>(vv, q1, q2, q3);
+            uint16_t* dst = DY + slot * DY_SLOT + dy_px(v) * E + 4 * lq;
+            *reinterpret_cast<u32x2_t*>(dst) = q1;
+            if (NP == 3) {
+                *reinterpret_cast<u32x2_t*>(dst + DY_PIECE) = q2;
+                *reinterpret_cast<u32x2_t*>(dst + 2 * DY_PIECE) = q3;
+            }
         }
     };
     // h3 of the lane's pixel / channels in chunk c.  No mask: outside the image dy = 0 makes dh3 = 0 whatever gelu'(h3) is, and gelu(h3)
@@ -175,17 +190,17 @@ __global__ __launch_bounds__(KA<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
             const int m = c * CH + pb * 16 + r;
             const int hy = m / HX, hx = m - hy * HX;
             const int y = clampi(ya + hy, 0, h - 1), x = clampi(x0 + hx - 1, 0, w - 1);
-            hv[pb] = HS<BF>::ldraw(a.h3, ((b * h + y) * (long)w + x) * N1 + c0);
+            hv[pb] = HS<BF>::ldraw(a.h3, ((b * h + y) * (long)w + x) * N1 + hoff + c0);
         }
     };
 
     // dh3 of halo rows [ya, ya + nr) x columns [x0 - 1, x0 + 17) -> ring (nr = 2: strip prologue, 8: one step)
     // in_last: run at the top of the LAST chunk, where no next-chunk operands are in flight (registers and load slots are free)
     // pre / pre_in / pre_own, h3c: chunk 0's dy vector and h3 vectors, requested by the caller ahead of time
-    auto compute_rows = [&](int ya, int nr, float4 pre, bool pre_in, bool pre_own, typename HS<BF>::raw4 (&h3c)[3], auto&& in_last) {
+    auto compute_rows = [&](int ya, int nr, const DyVec& pre, typename HS<BF>::raw4 (&h3c)[3], auto&& in_last) {
         const int npx = nr * HX, nchunks = (npx + CH - 1) / CH;
         typename HS<BF>::raw4 h3n[3];
-        dy_store(0, pre, pre_in, pre_own);
+        dy_store(0, pre);
         STAMP(1);
         __syncthreads();                 // also: the previous phase (P2) is done reading the ring rows this call overwrites
         STAMP(2);
@@ -193,9 +208,8 @@ __global__ __launch_bounds__(KA<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
         for (int c = 0; c < nchunks; ++c) {
             const int slot = c & 1;
             const bool more = c + 1 < nchunks;
-            float4 ndv;
-            bool nin = false, nown = false;
-            if (more) { dy_fetch(ya, npx, c + 1, ndv, nin, nown); h3_fetch(ya, c + 1, h3n); }
+            DyVec nd;
+            if (more) { dy_fetch(ya, npx, c + 1, nd); h3_fetch(ya, c + 1, h3n); }
             else in_last();
             const uint16_t* dyb = DY + slot * DY_SLOT;
 #pragma unroll
@@ -228,37 +242,38 @@ __global__ __launch_bounds__(KA<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
                 rp = rp >= RING * HX ? rp - RING * HX : rp;
                 if (m < npx) *reinterpret_cast<float4*>(ring + rp * LDR + c0) = make_float4(acc[0] * g01.x, acc[1] * g01.y, acc[2] * g23.x, acc[3] * g23.y);
                 // gelu(h3) of the strip's OWN pixels (every pixel of the image belongs to exactly one strip) -> the wave's [pixel][channel] image
+                // of THIS 16-pixel block, consumed right away by dW3[.][16 w + .] += dy^T gelu(h3): both operands read by columns (K = the
+                // block's 16 pixels); off the critical path of the ring
                 const float mk = own ? 1.0f : 0.0f;
                 const float av[4] = {a01.x * mk, a01.y * mk, a23.x * mk, a23.y * mk};
                 u32x2_t q1, q2, q3;
                 split_x4<NP>(av, q1, q2, q3);
-                uint16_t* dst = A3 + (pb * 16 + r) * 16 + 4 * g;
+                uint16_t* dst = A3 + r * 16 + 4 * g;
                 *reinterpret_cast<u32x2_t*>(dst) = q1;
                 if (NP == 3) {
                     *reinterpret_cast<u32x2_t*>(dst + A3_PIECE) = q2;
                     *reinterpret_cast<u32x2_t*>(dst + 2 * A3_PIECE) = q3;
                 }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // dW3[.][16 w + .] += dy^T gelu(h3): both operands read by columns (K = the chunk's 48 pixels); off the critical path of the ring
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const uint16_t* pbp = A3 + (4 * g + (r >> 2)) * 16 + 4 * (r & 3);
+                    s16x4_t at[3];
+                    at[0] = lds_tr4(pbp);
+                    if (NP == 3) { at[1] = lds_tr4(pbp + A3_PIECE); at[2] = lds_tr4(pbp + 2 * A3_PIECE); } else { at[1] = at[0]; at[2] = at[0]; }
 #pragma unroll
-            for (int pb = 0; pb < 3; ++pb) {
-                const uint16_t* pbp = A3 + (pb * 16 + 4 * g + (r >> 2)) * 16 + 4 * (r & 3);
-                s16x4_t at[3];
-                at[0] = lds_tr4(pbp);
-                if (NP == 3) { at[1] = lds_tr4(pbp + A3_PIECE); at[2] = lds_tr4(pbp + 2 * A3_PIECE); } else { at[1] = at[0]; at[2] = at[0]; }
-#pragma unroll
-                for (int mt = 0; mt < NM; ++mt) {
-                    const uint16_t* pa = dyb + (pb * 16 + 4 * g + (r >> 2)) * E + 16 * mt + 4 * (r & 3);
-                    s16x4_t dt[3];
-                    dt[0] = lds_tr4(pa);
-                    if (NP == 3) { dt[1] = lds_tr4(pa + DY_PIECE); dt[2] = lds_tr4(pa + 2 * DY_PIECE); } else { dt[1] = dt[0]; dt[2] = dt[0]; }
-                    mfmaN_16<NP>(acc3[mt], dt, at);
+                    for (int mt = 0; mt < NM; ++mt) {
+                        const uint16_t* pa = dyb + (pb * 16 + 4 * g + (r >> 2)) * E + 16 * mt + 4 * (r & 3);
+                        s16x4_t dt[3];
+                        dt[0] = lds_tr4(pa);
+                        if (NP == 3) { dt[1] = lds_tr4(pa + DY_PIECE); dt[2] = lds_tr4(pa + 2 * DY_PIECE); } else { dt[1] = dt[0]; dt[2] = dt[0]; }
+                        mfmaN_16<NP>(acc3[mt], dt, at);
+                    }
                 }
+                __builtin_amdgcn_wave_barrier();   // the image is rewritten by the next block
             }
             if (more) {
-                dy_store(slot ^ 1, ndv, nin, nown);
+                dy_store(slot ^ 1, nd);
 #pragma unroll
                 for (int pb = 0; pb < 3; ++pb) h3c[pb] = h3n[pb];
             }
@@ -268,17 +283,15 @@ __global__ __launch_bounds__(KA<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
         }
     };
 
-    float4 pre;
+    DyVec pre;
     typename HS<BF>::raw4 h3p[3];
-    bool pin, pown;
-    dy_fetch(Y0 - 1, 2 * HX, 0, pre, pin, pown);
+    dy_fetch(Y0 - 1, 2 * HX, 0, pre);
     h3_fetch(Y0 - 1, 0, h3p);
     // the first step's chunk-0 operands are requested at the top of the prologue's only chunk, the next step's before P2 (below): an HBM
     // round trip under a whole phase instead of in front of it
-    float4 npre;
+    DyVec npre;
     typename HS<BF>::raw4 nh3[3];
-    bool npin = false, npown = false;
-    compute_rows(Y0 - 1, 2, pre, pin, pown, h3p, [&] { dy_fetch(Y0 + 1, TY * HX, 0, npre, npin, npown); h3_fetch(Y0 + 1, 0, nh3); });
+    compute_rows(Y0 - 1, 2, pre, h3p, [&] { dy_fetch(Y0 + 1, TY * HX, 0, npre); h3_fetch(Y0 + 1, 0, nh3); });
 #pragma unroll 1
     for (int y0 = Y0; y0 < Yend; y0 += TY) {
 #ifdef LG_STAMPS
@@ -290,12 +303,12 @@ __global__ __launch_bounds__(KA<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
         // items 0 .. 3 are requested at the top of the LAST chunk of the halo pass, the item four places on while item i is worked on.
         // Every output pixel of a step is inside the image (launcher: h % 8 == 0, w % 16 == 0).
         const int yrow0 = y0 + RPW * wave, xl0 = x0 + PPL * lgrp;
-        auto h2_at = [&](int y, int x) { return HS<BF>::ldraw(a.h2, ((b * h + y) * (long)w + x) * N1 + 4 * q); };
+        auto h2_at = [&](int y, int x) { return HS<BF>::ldraw(a.h2, ((b * h + y) * (long)w + x) * N1 + hoff + 4 * q); };
         typename HS<BF>::raw4 h2a, h2b, h2c, h2d;
-        pre = npre; pin = npin; pown = npown;
+        pre = npre;
 #pragma unroll
         for (int pb = 0; pb < 3; ++pb) h3p[pb] = nh3[pb];
-        compute_rows(y0 + 1, TY, pre, pin, pown, h3p, [&] { h2a = h2_at(yrow0, xl0); h2b = h2_at(yrow0, xl0 + 1); h2c = h2_at(yrow0, xl0 + 2); h2d = h2_at(yrow0, xl0 + 3); });
+        compute_rows(y0 + 1, TY, pre, h3p, [&] { h2a = h2_at(yrow0, xl0); h2b = h2_at(yrow0, xl0 + 1); h2c = h2_at(yrow0, xl0 + 2); h2d = h2_at(yrow0, xl0 + 3); });
         // the depthwise taps of the lane's four channels as channel pairs: 36 contiguous floats from LDS per step instead of 36 VGPRs pinned
         // through the halo pass
         lg_v2f wq01[9], wq23[9];
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(KA<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
         // next step's chunk-0 operands (clamped addresses: harmless behind the strip's last step), requested BEHIND the first h2 vectors: the
         // wait counter is in-order
         __builtin_amdgcn_sched_barrier(0);
-        dy_fetch(y0 + TY + 1, TY * HX, 0, npre, npin, npown);
+        dy_fetch(y0 + TY + 1, TY * HX, 0, npre);
         h3_fetch(y0 + TY + 1, 0, nh3);
         STAMP(9);
         const int sbase = (y0 - Y0) % RING;            // ring slot of row y0 - 1
@@ -362,11 +375,10 @@ __global__ __launch_bounds__(KA<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
                         pw23[k] = h23 * g23 + pw23[k];
                         if (k == 4) { pw01[9] += g01; pw23[9] += g23; }
                     }
-                HS<BF>::st4(a.dh2, ((b * h + y) * (long)w + x) * N1 + 4 * q, make_float4(acc01.x, acc01.y, acc23.x, acc23.y));
+                HS<BF>::st4(a.dh2, ((b * h + y) * (long)w + x) * N1 + hoff + 4 * q, make_float4(acc01.x, acc01.y, acc23.x, acc23.y));
                 __builtin_amdgcn_sched_barrier(0);      // one item at a time: interleaved items need more registers than there are
             };
             item(0, h2a); item(1, h2b); item(2, h2c); item(3, h2d);
-            if constexpr (PPL == 8) { item(4, h2a); item(5, h2b); item(6, h2c); item(7, h2d); }
         };
 #pragma unroll 1
         for (int ch = 0; ch < RPW; ++ch) rowN(ch);
@@ -375,12 +387,12 @@ __global__ __launch_bounds__(KA<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
     __syncthreads();   // the last step's P2 readers of the ring are done before the next strip's prologue writes it
     }   // strips of this workgroup
 
-    // ---- this workgroup's partial sums -> its slab row [d dww N1 x 9 | d dwb N1 | dW3 E x N1 | db3 E]
-    float* row = a.slab + (size_t)blockIdx.x * C::ROW;
+    // ---- this workgroup's partial sums -> its slab row [d dww 64 x 9 | d dwb 64 | dW3 E x 64 | db3 E] of its channel half
+    float* row = a.slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * C::ROW;
 #pragma unroll
     for (int mt = 0; mt < NM; ++mt)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) row[C::R_W3 + (16 * mt + 4 * g + v) * N1 + 16 * wave + r] = acc3[mt][v];
+        for (int v = 0; v < 4; ++v) row[C::R_W3 + (16 * mt + 4 * g + v) * NH + 16 * wave + r] = acc3[mt][v];
     float* red = ring;    // [NW waves][CQ quads][40] | [NW waves][E]: the ring is dead (barrier at the end of the last strip)
     // depthwise partials: lanes with the same q (LGW per wave) hold the same channels
 #pragma unroll
@@ -431,27 +443,33 @@ static int launch_dw_t(const FfnDwBwdXArgs& a, hipStream_t s) {
         attr_once.done();
     }
     const int tiles_x = (a.w + 15) / 16;
-    // strip height as in the forward: the tallest multiple of 8 rows that still yields one strip per resident workgroup (512 at e = 16: two per
-    // CU; 256 at e = 32), at least 16
-    const int wgs = ffn_dw_bwd_x_wgs(E);
+    // strip height as in the forward: the tallest multiple of 8 rows that still yields a strip per resident workgroup (512 = two per CU; at
+    // e = 32 the two channel halves share them), at least 16
+    const int wgs = FFN_DW_BWD_X_WGS / C::NHALF;
     int SH = (a.h + 7) / 8 * 8;
     while (SH > 16 && (long)a.B * tiles_x * ((a.h + SH - 1) / SH) < wgs) SH = (SH / 2 + 7) / 8 * 8;
     const int strips_y = (a.h + SH - 1) / SH;
     const int nstrips = a.B * tiles_x * strips_y;
-    const int grid = nstrips < wgs ? nstrips : wgs;
-    if (a.hbf) k_ffn_dw_bwd_xs<E, 1><<<grid, C::NT, C::LDS_BYTES, s>>>(a, tiles_x, strips_y, nstrips, SH);   // precision = 'bf16'
-    else k_ffn_dw_bwd_xs<E, 3><<<grid, C::NT, C::LDS_BYTES, s>>>(a, tiles_x, strips_y, nstrips, SH);
+    const int gx = nstrips < wgs ? nstrips : wgs;
+    const dim3 grid(gx, C::NHALF);
+    if (a.hbf) k_ffn_dw_bwd_xs<E, 1><<<grid, NT, C::LDS_BYTES, s>>>(a, tiles_x, strips_y, nstrips, SH);   // precision = 'bf16'
+    else k_ffn_dw_bwd_xs<E, 3><<<grid, NT, C::LDS_BYTES, s>>>(a, tiles_x, strips_y, nstrips, SH);
     LG_CHECK_LAUNCH();
+    // the slab rows of each channel half, summed in a fixed order by the deferred reduce launch
     ReduceJob j;
-    j.dst2 = nullptr; j.nslices = grid; j.slice_stride = C::ROW;
-    auto job = [&](int off, float* dst, int rows, int cols) {
-        j.slab = a.slab + off; j.dst = dst; j.rows = rows; j.cols = cols; j.row_stride = cols; j.ld = cols; j.rows_valid = rows; j.cols_valid = cols;
-        return launch_reduce_job(j, s);
-    };
-    int rc = job(0, a.d_dww, C::N1, 9);
-    if (!rc) rc = job(C::R_DB, a.d_dwb, 1, C::N1);
-    if (!rc) rc = job(C::R_W3, a.d_w3, E, C::N1);
-    if (!rc) rc = job(C::R_B3, a.d_b3, 1, E);
+    j.dst2 = nullptr; j.nslices = gx; j.slice_stride = C::ROW;
+    int rc = 0;
+    for (int half = 0; half < C::NHALF && !rc; ++half) {
+        const float* base = a.slab + (size_t)half * gx * C::ROW;
+        auto job = [&](int off, float* dst, int rows, int cols, int ld) {
+            j.slab = base + off; j.dst = dst; j.rows = rows; j.cols = cols; j.row_stride = cols; j.ld = ld; j.rows_valid = rows; j.cols_valid = cols;
+            return launch_reduce_job(j, s);
+        };
+        rc = job(0, a.d_dww + (size_t)half * NH * 9, NH, 9, 9);
+        if (!rc) rc = job(C::R_DB, a.d_dwb + half * NH, 1, NH, NH);
+        if (!rc) rc = job(C::R_W3, a.d_w3 + half * NH, E, NH, C::N1);
+        if (!rc && half == 0) rc = job(C::R_B3, a.d_b3, 1, E, E);     // db3 = sum of dy: every half sums it, one is used
+    }
     return rc;
 }
 
