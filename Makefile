@@ -5,12 +5,17 @@ CSRC  := lgteun_amd/csrc
 SRCS  := $(CSRC)/api.hip $(CSRC)/k_pixel.hip $(CSRC)/k_fft.hip $(CSRC)/k_attn.hip $(CSRC)/k_ffn.hip $(CSRC)/k_ffn_x.hip $(CSRC)/k_ffn_x32.hip $(CSRC)/k_ffn_x64.hip $(CSRC)/k_bwd.hip $(CSRC)/k_bwd_pixel.hip $(CSRC)/k_wgrad.hip $(CSRC)/k_ffn_bwd.hip $(CSRC)/k_ffn_bwd_x.hip $(CSRC)/k_ffn_dwbwd_x.hip $(CSRC)/k_ffn1_bwd_x32.hip $(CSRC)/k_attn_bwd.hip $(CSRC)/k_attn_bwd_f.hip
 # A/B-only kernels stay out of the product library: `make AB=1` adds k_ffn_xp (LG_FFN_IMPL=xp: the software-pipelined variant of the
 # fused FFN forward, bitwise the same results, measured 2.5 % slower)
+# (AB objects get their own suffix, so a product build never links objects compiled with the other flag set and vice versa)
 ifdef AB
 SRCS  += $(CSRC)/k_ffn_xp.hip
 ABFLAGS := -DLG_BUILD_AB=1
-endif
-OBJS  := $(SRCS:.hip=.o)
+OSUF  := .ab.o
+LIB   := lgteun_amd/_lgteun_hip_ab.so   # use it with LGTEUN_HIP_LIB=$PWD/lgteun_amd/_lgteun_hip_ab.so
+else
+OSUF  := .o
 LIB   := lgteun_amd/_lgteun_hip.so
+endif
+OBJS  := $(SRCS:.hip=$(OSUF))
 # -fno-slp-vectorize: the SLP vectoriser turns scalar fp32 chains into v_pk_mul_f32 / v_pk_add_f32 pairs; packed fp32 issues at
 # half rate on gfx950 and the pairing blocks mul+add -> fma contraction (k_attn: 3140 VALU instructions, 502 of them packed,
 # vs 3099 unpacked).  Measured on one box, alternating runs: 9.28 -> 9.10 ms/step fp32, 8.96 -> 8.68 bf16 mode.
@@ -19,7 +24,7 @@ FLAGS := -O3 -std=c++17 -fno-slp-vectorize -fPIC -fvisibility=hidden --offload-a
 all: $(LIB)
 
 # prerequisites come from the compiler (-MMD writes one .d file per object: every header a source includes, hstore.h too)
-$(CSRC)/%.o: $(CSRC)/%.hip
+$(CSRC)/%$(OSUF): $(CSRC)/%.hip
 	$(HIPCC) $(FLAGS) -MMD -MP -c $< -o $@
 
 -include $(OBJS:.o=.d)
@@ -28,5 +33,5 @@ $(LIB): $(OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
 
 clean:
-	rm -f $(OBJS) $(OBJS:.o=.d) $(LIB)
+	rm -f $(CSRC)/*.o $(CSRC)/*.d $(LIB)
 .PHONY: all clean

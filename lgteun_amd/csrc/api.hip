@@ -126,6 +126,8 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
     if ((cfg->variant & LG_VAR_FFN_SAVE_MASK) == LG_VAR_FFN_SAVE_MASK) { lg_set_error("plan_create: invalid FFN save variant"); return -2; }
 #ifndef LG_BUILD_AB
     if ((cfg->variant & LG_VAR_FFN_IMPL_MASK) >= LG_VAR_FFN_TILE) { lg_set_error("plan_create: FFN variants 2 / 3 exist in `make AB=1` builds only"); return -2; }
+    if (cfg->variant & LG_VAR_FFN_BWD32_XS) { lg_set_error("plan_create: LG_VAR_FFN_BWD32_XS (k_ffn1_bwd_xs<32>) exists in `make AB=1` builds only"); return -2; }
+    if (cfg->precision == 1 && (cfg->variant & LG_VAR_FFN_IMPL_MASK)) { lg_set_error("plan_create: precision = 1 with an FFN variant exists in `make AB=1` builds only"); return -2; }
 #endif
     lg_plan* p = new lg_plan;
     p->cfg = *cfg;
@@ -228,7 +230,7 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     a1.tile16 = pl->ffn_tile;
     a1.wsplit = wsplit;
     Ffn2Args a2;
-    a2.h2 = bb.h2; a2.x = bb.xmid; a2.a3s = (flags & LG_FLAG_SAVE) ? bb.a3 : nullptr; a2.g3s = ((flags & LG_FLAG_SAVE) && !pre && !pl->ffn_dw_x32(bb.e)) ? bb.g3 : nullptr; a2.y = bb.xout;   // g3s null with a3s set: a3 receives the PRE-activation h3
+    a2.h2 = bb.h2; a2.x = bb.xmid; a2.a3s = (flags & LG_FLAG_SAVE) ? bb.a3 : nullptr; a2.g3s = ((flags & LG_FLAG_SAVE) && !pre && !pl->ffn_dw_x32(bb.e, bb.h, bb.w)) ? bb.g3 : nullptr; a2.y = bb.xout;   // g3s null with a3s set: a3 receives the PRE-activation h3
     a2.g = g_next;
     a2.dww = P + pl->blk(stage, j, B_DWW); a2.dwb = P + pl->blk(stage, j, B_DWB);
     a2.w3 = P + pl->blk(stage, j, B_W3); a2.b3 = P + pl->blk(stage, j, B_B3);

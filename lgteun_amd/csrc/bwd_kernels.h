@@ -215,6 +215,7 @@ struct Ffn1BwdXArgs {
 };
 inline int ffn1_bwd_x_wgs(int e) { return e == 16 ? 512 : 256; }   // persistent grid: two workgroups per CU at e = 16 (55 KB of LDS), one at e = 32 (139 KB)
 size_t ffn1_bwd_x_slab_floats(int e);                               // floats of Ffn1BwdXArgs::slab
+bool ffn1_bwd_x32_built();                                          // the e = 32 instance is compiled (make AB=1)
 int launch_ffn1_bwd_xs(int e, const Ffn1BwdXArgs& a, hipStream_t s);   // e = 16 | 32
 // e = 16 | 32 (k_ffn_dwbwd_x.hip): the strip-walking spatial half -- dh3 in an LDS ring, dh2 out, depthwise gradients AND
 // dW3 / db3 in the same pass; replaces k_ffn_dw_bwd<16> + the 16 x 64 k_wgrad_t launch

@@ -44,8 +44,8 @@ static void carve_bwd(const lg_plan* plan, int B, void* base, BwdBufs& bb) {
     // arena: one block's worth of slabs (dw-conv partials + the three FFN weight gradients + the small ones) between flushes;
     // take() flushes by itself if a configuration needs more
     if (sl3 > sl) sl = sl3;
-    for (size_t e = E; e <= 2 * E; e *= 2)   // slab rows of the fused FFN backward kernels (k_ffn_bwd_x.hip, k_ffn_dwbwd_x.hip)
-        if (e == 16 || e == 32) {
+    for (size_t e = E; e <= 2 * E; e *= 2)   // slab rows of the fused FFN backward kernels (k_ffn_bwd_x.hip, k_ffn_dwbwd_x.hip): only of the paths this plan runs
+        if ((e == 16 && plan->ffn_bwd_x(16)) || (e == 32 && plan->ffn1_bwd_x32(32))) {
             if (ffn1_bwd_x_slab_floats((int)e) > sl) sl = ffn1_bwd_x_slab_floats((int)e);
         }
     if (ffn_dw_bwd_x_slab_floats(16) > sl) sl = ffn_dw_bwd_x_slab_floats(16);
@@ -125,7 +125,7 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         fx.P = Pn; fx.hbf = hbf;
         return launch_ffn1_bwd_xs(e, fx, s);
     }
-    const bool dwx32 = pl->ffn_dw_x32(e);
+    const bool dwx32 = pl->ffn_dw_x32(e, fb.h, fb.w);
     if (dwx32) {
         // e = 32: the strip-walking spatial half (dh3 in an LDS ring -> dh2; depthwise gradients, dW3 / db3 in the same pass) on the saved
         // pre-activation h3; the pixelwise half below is round 2's k_ffn1_bwd_x32 + the 128 x 128 weight-gradient launch

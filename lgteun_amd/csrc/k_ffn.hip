@@ -1192,9 +1192,15 @@ static int launch_ffn_fused_bf_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStre
 // returns LG_FFN_NOT_FUSED if the fused kernels do not cover this size (caller falls back to k_ffn1 + k_ffn2)
 int launch_ffn_fused(int e, const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     if (a1.hbf) {   // throughput mode: bf16 matrix cores for the three GEMMs
-        if (e == 16) return a1.tile16 == 0 ? launch_ffn_xs(a1, a2, s) : launch_ffn_fused_bf_t<16>(a1, a2, s);   // k_ffn_xs<., NP = 1>
-        if (e == 32) return (a1.tile16 == 0 && a1.wsplit) ? launch_ffn_x32(a1, a2, s) : launch_ffn_fused_bf_t<32>(a1, a2, s);   // k_ffn_x32<., NP = 1>
-        return LG_FFN_NOT_FUSED;
+#ifdef LG_BUILD_AB   // round 1's bf16 tile kernels: A/B builds only (lg_plan_create rejects precision = 1 with an FFN variant otherwise)
+        if (e == 16 && a1.tile16 != 0) return launch_ffn_fused_bf_t<16>(a1, a2, s);
+        if (e == 32 && (a1.tile16 != 0 || !a1.wsplit)) return launch_ffn_fused_bf_t<32>(a1, a2, s);
+#endif
+        if (e == 16 && a1.tile16 == 0) return launch_ffn_xs(a1, a2, s);                 // k_ffn_xs<., NP = 1>
+        if (e == 32 && a1.tile16 == 0 && a1.wsplit) return launch_ffn_x32(a1, a2, s);   // k_ffn_x32<., NP = 1>
+        if (e == 64) return LG_FFN_NOT_FUSED;
+        lg_set_error("ffn: precision = 1 with an FFN variant needs a `make AB=1` build");
+        return -2;
     }
     // e = 16: the strip kernel on the bf16 matrix pipe in fp32-equivalent split arithmetic (k_ffn_x.hip); for A/B runs the plan's
     // switch (env LG_FFN_IMPL = strip | tile | xp, read at plan creation) selects the f32-MFMA strip kernel (1), the per-tile kernel (2)
@@ -1204,7 +1210,10 @@ int launch_ffn_fused(int e, const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t 
 #else
     if (e == 16 && a1.tile16 == 3) { lg_set_error("LG_FFN_IMPL=xp: k_ffn_xp is an A/B kernel, build the library with `make AB=1`"); return -2; }
 #endif
-    if (e == 16) return a1.tile16 == 2 ? launch_ffn_fused_t<16>(a1, a2, s) : (a1.tile16 == 1 ? launch_ffn_strip(a1, a2, s) : launch_ffn_xs(a1, a2, s));
+#ifdef LG_BUILD_AB
+    if (e == 16 && a1.tile16 == 2) return launch_ffn_fused_t<16>(a1, a2, s);   // round 1's per-tile kernel at e = 16: A/B builds only
+#endif
+    if (e == 16) return a1.tile16 == 1 ? launch_ffn_strip(a1, a2, s) : launch_ffn_xs(a1, a2, s);
     if (e == 32) return (a1.tile16 == 0 && a1.wsplit) ? launch_ffn_x32(a1, a2, s) : launch_ffn_fused_t<32>(a1, a2, s);
     if (e == 64 && a1.tile16 == 0 && a1.wsplit && a1.h2) return launch_ffn_x64(a1, a2, s);   // two kernels, split-bf16 GEMMs
     return LG_FFN_NOT_FUSED;

@@ -60,6 +60,9 @@ struct KB {
 };
 
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+#ifndef LG_KB_STAGGER
+#define LG_KB_STAGGER 0
+#endif
 #ifndef LG_KB_FENCE
 #define LG_KB_FENCE 1
 #endif
@@ -247,6 +250,11 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
         STAMP(1);
         __syncthreads();
         STAMP(2);
+#if LG_KB_STAGGER
+        // e = 32: the two waves of a SIMD (w and w + 4) leave the barrier together and would run their matrix bursts and their vector
+        // bursts at the same time; half a block of delay for the second lets one wave's MFMAs run under the other's GELU / splitting
+        if (NW == 8 && wave >= 4) __builtin_amdgcn_s_sleep(LG_KB_STAGGER);
+#endif
 
         // ---- GEMM phase: four blocks of 16 pixels; this wave's 16 hidden channels
 #pragma unroll 1
@@ -428,11 +436,22 @@ int launch_t(const Ffn1BwdXArgs& a, hipStream_t s) {
 }   // namespace
 
 size_t ffn1_bwd_x_slab_floats(int e) { return (size_t)ffn1_bwd_x_wgs(e) * (e == 16 ? KB<16>::ROW : KB<32>::ROW); }
+bool ffn1_bwd_x32_built() {
+#ifdef LG_BUILD_AB
+    return true;
+#else
+    return false;
+#endif
+}
 
 int launch_ffn1_bwd_xs(int e, const Ffn1BwdXArgs& a, hipStream_t s) {
     ProfScope prof__(LG_K_FFN1_BWD, s);
     if (e != 16 && e != 32) { lg_set_error("ffn1_bwd_xs: e=%d unsupported", e); return -1; }
     if (a.P <= 0 || a.P % NPX) { lg_set_error("ffn1_bwd_xs: pixel count %ld is not a multiple of %d", a.P, NPX); return -2; }
     if (!a.dh2 || !a.x || !a.dy || !a.dx || !a.slab || !a.w1 || !a.w1t || !a.w2t || !a.b1 || !a.ln2g || !a.ln2b) { lg_set_error("ffn1_bwd_xs: null argument"); return -2; }
-    return e == 16 ? launch_t<16>(a, s) : launch_t<32>(a, s);
+#ifdef LG_BUILD_AB   // the e = 32 instance (one 8-wave workgroup per CU: correct, slower than k_ffn1_bwd_x32 + k_wgrad_t): A/B builds only
+    if (e == 32) return launch_t<32>(a, s);
+#endif
+    if (e != 16) { lg_set_error("ffn1_bwd_xs: the e = 32 instance exists in `make AB=1` builds only"); return -2; }
+    return launch_t<16>(a, s);
 }

@@ -347,7 +347,13 @@ def test_ffn_backward_ab_paths_agree_with_the_default(env, monkeypatch):
     g0, eng = grads()
     for k, v in env.items():
         monkeypatch.setenv(k, v)                                   # read once per plan: a fresh module builds a fresh plan
-    g1, _ = grads()
+    from lgteun_amd._lib import LgteunHipError
+    try:
+        g1, _ = grads()
+    except LgteunHipError as e:
+        if 'AB=1' in str(e):
+            pytest.skip('this variant is compiled into `make AB=1` builds only')
+        raise
     for i in eng.live_idx:
         o, n = eng.offsets[i], eng.params[i].numel()
         a, b = g0[o:o + n].double(), g1[o:o + n].double()

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build/stamps
-FLAGS="-O3 -std=c++17 -fno-slp-vectorize -fPIC -fvisibility=hidden --offload-arch=gfx950 -DLG_STAMPS -Wno-unused-value -Wno-unused-function"
+FLAGS="-O3 -std=c++17 -fno-slp-vectorize -fPIC -fvisibility=hidden --offload-arch=gfx950 -DLG_STAMPS -DLG_BUILD_AB=1 $STAMP_FLAGS -Wno-unused-value -Wno-unused-function"
 OBJS=""
 for f in lgteun_amd/csrc/*.hip; do
   o=build/stamps/$(basename ${f%.hip}).o
