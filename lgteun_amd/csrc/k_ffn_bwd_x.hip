@@ -60,6 +60,9 @@ struct KB {
 };
 
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+#ifndef LG_KB_DACHAINS
+#define LG_KB_DACHAINS 0
+#endif
 #ifndef LG_KB_STAGGER
 #define LG_KB_STAGGER 0
 #endif
@@ -279,12 +282,27 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
             f32x4_t da = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             {
                 const uint16_t* pd = D2 + (pbk * 16 + r) * LDP + 8 * g;
+#if LG_KB_DACHAINS
+                // K = N1 as independent accumulation chains (one per 32-deep block), summed at the end: a chain of 6 KB2 dependent MFMAs
+                // otherwise
+                f32x4_t dak[KB2];
+#pragma unroll
+                for (int kb = 0; kb < KB2; ++kb) {
+                    dak[kb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    bf16x8_t dk[3];
+                    ld3_x8<NP>(pd + 32 * kb, D2_PIECE, dk);
+                    mfmaN_32<NP>(dak[kb], dk, w2f[kb].p);
+                }
+#pragma unroll
+                for (int kb = 0; kb < KB2; ++kb) da += dak[kb];
+#else
 #pragma unroll
                 for (int kb = 0; kb < KB2; ++kb) {
                     bf16x8_t dk[3];
                     ld3_x8<NP>(pd + 32 * kb, D2_PIECE, dk);
                     mfmaN_32<NP>(da, dk, w2f[kb].p);
                 }
+#endif
             }
             KB_FENCE();
             // ---- gelu(h1), gelu'(h1) with one exponential for both; dh1 = da1 * gelu'(h1); pieces

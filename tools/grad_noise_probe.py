@@ -64,7 +64,7 @@ def main():
             den = float((t64 ** 2).sum()) ** 0.5
             ref = float(((g32[k.replace('.', '/')].astype(np.float64) - t64) ** 2).sum()) ** 0.5 / den
             mm = BLK.match(k)
-            print((mm.group(1) + '.' + mm.group(2)).ljust(34), kd[0][13:].ljust(32), f'{ref:10.2e}',
+            print((mm.group(1) + '.' + mm.group(2)).ljust(34), kd[0].split('.', 1)[1].ljust(32), f'{ref:10.2e}',
                   *[f'{float(((g[k] - t64) ** 2).sum()) ** 0.5 / den:18.2e}' for _, g in runs])
         # per channel of the phase weights: a single flipped angle() bin shows up as ONE channel of ONE block
         print(f'-- {name}: conv_pha.0.weight per channel, |ours - fp64| / max|fp64| of the tensor (default switch), reference fp32 beside it')
