@@ -73,8 +73,10 @@ static_assert(F_OFF_WAVE % 4 == 0 && F_PW % 4 == 0 && F_PS % 4 == 0, "16-byte al
 __device__ __forceinline__ float dpp_xor1(float v) {   // the other lane of the token's pair
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
 }
-// workgroup barrier that orders LDS only: __syncthreads() is a release / acquire pair on ALL address spaces, i.e. s_waitcnt vmcnt(0) in
-// front of s_barrier whenever a global store is pending -- it would drain the dx stores and every operand requested ahead
+// workgroup barrier that orders LDS only: the operands requested ahead and the dx stores must stay in flight across it.  (On this toolchain
+// __syncthreads() compiles to the same s_waitcnt lgkmcnt(0) + s_barrier as long as no LDS-DMA is pending -- checked in the assembly; what
+// did drain the loads in the first version was the reload of a spilled register next to a barrier: scratch traffic shares the in-order
+// vector-memory counter.  The explicit form states the intent and does not depend on that.)
 __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
