@@ -19,7 +19,7 @@ def _flat_grad(net, ms, pan, gt):
     return loss, eng.gflat.clone()
 
 
-@pytest.mark.parametrize('C,K,B,h', [(4, 4, 32, 32), (8, 4, 32, 32)])      # BASELINE configs[1] and configs[2]
+@pytest.mark.parametrize('C,K,B,h', [(4, 4, 32, 32), (8, 4, 32, 32), (8, 8, 16, 64)])      # BASELINE configs[1], configs[2] and configs[4] at its per-GPU batch (16 pairs of 256x256)
 def test_gradient_is_linear_in_the_batch(C, K, B, h):
     """mean-L1 gradient of B pairs == mean of the gradients of its two halves: what batch-sharded DDP relies on"""
     from gpu_helpers import make_module

@@ -145,3 +145,29 @@ def test_chained_mode_is_the_same_functions_composed_the_intended_way():
     assert torch.equal(orc.forward(P, ms, pan, 1, mode='chained'), orc.forward(P, ms, pan, 1, mode='faithful'))
     with pytest.raises(ValueError):
         orc.forward(P, ms, pan, K, mode='intended')
+
+
+def test_reference_noise_band_fixture_covers_every_case_kind_and_tensor(manifest):
+    """tests/golden/gradnoise.json (tools/gen_goldens.py --only-r4, the reference itself): for each of the five bench-size / odd-size cases the
+    reference's own fp32 distance to its fp64 gradients and its spread under +-1-ulp input nudges, per kind and per live tensor of the
+    cancelling-sum kinds -- the numbers the per-case gate of tests/test_gpu_benchsize.py is built on"""
+    import json
+    import os
+    from conftest import GOLD
+    noise = json.load(open(os.path.join(GOLD, 'gradnoise.json')))
+    kinds = ('global_mixer.conv_amp.0.bias', 'global_mixer.conv_pha.0.bias', 'global_mixer.conv_amp.0.weight', 'global_mixer.conv_pha.0.weight',
+             'local_mixer.pos_emb')
+    assert sorted(noise) == sorted(['grad_c4_k4_p128', 'grad_c8_k4_p128', 'grad_c4_k2_p80x48', 'grad_c4_k2_p208x176', 'grad_c8_k8_p256'])
+    for name, entry in noise.items():
+        g64 = np.load(os.path.join(GOLD, 'grad64_' + name[5:] + '.npz'))
+        tensors = {k[4:].replace('/', '.') for k in g64.files}
+        assert set(entry['tensors']) == tensors and len(tensors) == 25          # 5 blocks x 5 kinds of the live LGT
+        assert all(k.startswith(f"prior_module.{manifest[name]['K'] - 1}.") for k in tensors)
+        for kd in kinds:
+            e = entry[kd]
+            assert 0 < e['ref_vs_fp64'] < 0.2 and len(e['ref_spread']) == 4 and all(0 < v < 0.2 for v in e['ref_spread'])
+        for t in entry['tensors'].values():
+            assert 0 <= t['ref_vs_fp64'] < 1.0 and len(t['ref_spread']) == 4
+    # the finding the gate rests on: where the reference's fp32 sits unusually close to fp64, its own one-ulp spread is an order of magnitude larger
+    e = noise['grad_c8_k4_p128']['global_mixer.conv_pha.0.weight']
+    assert max(e['ref_spread']) > 20 * e['ref_vs_fp64']
