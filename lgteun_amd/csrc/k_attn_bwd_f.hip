@@ -40,6 +40,11 @@ extern "C" __attribute__((visibility("default"))) int lg_debug_kf_stamps(unsigne
 #define STAMP(i) do { } while (0)
 #endif
 
+#ifndef LG_ATTNF_SB
+#define LG_ATTNF_SB 2   // a scheduling fence behind every LG_ATTNF_SB-th key / query group of the flash passes (0: none).  Same-box A/B of the kernel's
+                        // average launch: none 140.5 us, every group 123.3, every 2nd 122.9 (kept), every 4th 128.9, every 8th 130.3
+#endif
+#define PASS_FENCE(g) do { if (LG_ATTNF_SB && ((g) % LG_ATTNF_SB) == LG_ATTNF_SB - 1) __builtin_amdgcn_sched_barrier(0); } while (0)
 namespace {
 #ifndef LG_ATTNF_NS
 #define LG_ATTNF_NS 4   // window slots per workgroup: 4 = one 8-wave workgroup per CU (155 KB of LDS); 2 = 4-wave workgroups, TWO per CU (81 KB each), so that
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
                 }
                 sc[2 * g] = sp0; sc[2 * g + 1] = sp1;
                 mx = fmaxf(mx, fmaxf(fmaxf(sp0.x, sp0.y), fmaxf(sp1.x, sp1.y)));
-                if (g & 1) __builtin_amdgcn_sched_barrier(0);
+                PASS_FENCE(g);
             }
             asm volatile("" ::: "memory");
             lg_v2f l2 = (lg_v2f){0.f, 0.f};
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
                     O2[c] = sc[2 * g] * (lg_v2f){vv.x, vv.y} + O2[c];
                     O2[c] = sc[2 * g + 1] * (lg_v2f){vv.z, vv.w} + O2[c];
                 }
-                if (g & 1) __builtin_amdgcn_sched_barrier(0);
+                PASS_FENCE(g);
             }
             float O[D];
             float Dv = 0.f;   // D_i = sum_j P_ij dP_ij = dO_i . O_i
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
                     dq2[c] = dS0 * (lg_v2f){kv[c].x, kv[c].y} + dq2[c];
                     dq2[c] = dS1 * (lg_v2f){kv[c].z, kv[c].w} + dq2[c];
                 }
-                if (g & 1) __builtin_amdgcn_sched_barrier(0);
+                PASS_FENCE(g);
             }
 #pragma unroll
             for (int c = 0; c < D; ++c) dqkv[c] = (dq2[c].x + dq2[c].y) * scale;
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
                 const lg_v2f dS0 = P0 * (dP0 - (lg_v2f){sdv.x, sdv.y}), dS1 = P1 * (dP1 - (lg_v2f){sdv.z, sdv.w});
                 dpacc[2 * g] += dS0;
                 dpacc[2 * g + 1] += dS1;
-                if (g & 1) __builtin_amdgcn_sched_barrier(0);
+                PASS_FENCE(g);
 #pragma unroll
                 for (int c = 0; c < D; ++c) {
                     dv2[c] = P0 * (lg_v2f){doi[c].x, doi[c].y} + dv2[c];
