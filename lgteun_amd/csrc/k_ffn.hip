@@ -1203,7 +1203,7 @@ int launch_ffn_fused(int e, const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t 
         return -2;
     }
     // e = 16: the strip kernel on the bf16 matrix pipe in fp32-equivalent split arithmetic (k_ffn_x.hip); for A/B runs the plan's
-    // switch (env LG_FFN_IMPL = strip | tile | xp, read at plan creation) selects the f32-MFMA strip kernel (1), the per-tile kernel (2)
+    // switch (lg_config.variant & LG_VAR_FFN_IMPL_MASK) selects the f32-MFMA strip kernel (1), the per-tile kernel (2: `make AB=1` builds)
     // it replaced, or the software-pipelined variant k_ffn_xp (3: same results bit for bit, measured 2.5 % slower)
 #ifdef LG_BUILD_AB
     if (e == 16 && a1.tile16 == 3) return launch_ffn_xp(a1, a2, s);

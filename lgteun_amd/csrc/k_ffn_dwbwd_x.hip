@@ -77,6 +77,9 @@ __device__ __forceinline__ bf16x8_t cat8(s16x4_t lo, s16x4_t hi) {
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
     return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
+#ifndef LG_KA_ITEMFENCE
+#define LG_KA_ITEMFENCE 1   // P2: a scheduling fence behind every LG_KA_ITEMFENCE-th item (0: none)
+#endif
 #ifndef LG_KA_PAIR
 #define LG_KA_PAIR 0   // measured in THIS kernel (VALU / LDS bound, matrix pipe 10 % busy): the operand concatenation costs 133.7 vs 119.5 us per launch; off
 #endif
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void k_
                         if (k == 4) { pw01[9] += g01; pw23[9] += g23; }
                     }
                 HS<BF>::st4(a.dh2, ((b * h + y) * (long)w + x) * N1 + hoff + 4 * q, make_float4(acc01.x, acc01.y, acc23.x, acc23.y));
-                __builtin_amdgcn_sched_barrier(0);      // one item at a time: interleaved items need more registers than there are
+                if (LG_KA_ITEMFENCE && ((it + 1) % LG_KA_ITEMFENCE) == 0) __builtin_amdgcn_sched_barrier(0);   // one item at a time: interleaved items need more registers than there are
             };
             item(0, h2a); item(1, h2b); item(2, h2c); item(3, h2d);
         };
