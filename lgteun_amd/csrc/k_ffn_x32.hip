@@ -17,12 +17,22 @@
 
 namespace {
 
-constexpr int E = 32, N1 = 128, TX = 16, HX = 18, TY = 8, RING = 10, LDR = 132, CH = 48;
-constexpr int A2_HALVES = 3 * CH * N1;           // 18432 halves (36,864 B), rows of 256 B, swizzled
-constexpr int XA_SLOT = 3 * CH * E;              // 4608 halves per slot
+#ifndef LG_X32_ALT
+#define LG_X32_ALT 0   // 1 (round-4 experiment, parity-green, NOT kept): 32-pixel chunks, TWO gelu(h1) images; the two wave groups of the workgroup (waves
+                       // 0 .. 3 / 4 .. 7 = the two waves of every SIMD) run GEMM2 of chunk c and GEMM1 + GELU of chunk c + 1 in OPPOSITE order, so
+                       // that one wave's matrix burst could run under the other's vector burst, and a chunk costs one barrier.  Same-box A/B at c3
+                       // (average launch of the fused FFN, all variants): 316.6 us against 280.5 for round 2's form (48-pixel chunks, every wave in
+                       // the same phase, two barriers per chunk) -- with ONE wave of a SIMD in GEMM2 its two dependent accumulation chains do not
+                       // fill the matrix pipe (six chains of two waves did), and five chunks per step pay the pipeline's fill and drain
+#endif
+constexpr int E = 32, N1 = 128, TX = 16, HX = 18, TY = 8, RING = 10, LDR = 132, CH = LG_X32_ALT ? 32 : 48, NPB = CH / 16;
+constexpr int NA2 = LG_X32_ALT ? 2 : 1;          // gelu(h1) images
+constexpr int A2_HALVES = 3 * CH * N1;           // halves per image (CH = 48: 36,864 B; 32: 24,576 B), rows of 256 B, swizzled
+constexpr int XA_SLOT = 3 * CH * E;              // halves per LN(x) slot
 constexpr int G3_WAVE = 3 * 16 * 64;             // 3072 halves per wave (one K-half), rows of 128 B, swizzled
-constexpr size_t LDS_BYTES = (size_t)RING * HX * LDR * 4 + (size_t)(A2_HALVES + 2 * XA_SLOT) * 2;
-static_assert(8 * G3_WAVE <= A2_HALVES + 2 * XA_SLOT, "gelu(h3) pieces must fit in the aliased region");
+constexpr size_t LDS_BYTES = (size_t)RING * HX * LDR * 4 + (size_t)(NA2 * A2_HALVES + 2 * XA_SLOT) * 2;
+static_assert(8 * G3_WAVE <= NA2 * A2_HALVES + 2 * XA_SLOT, "gelu(h3) pieces must fit in the aliased region");
+static_assert(LDS_BYTES + 4096 <= 160 * 1024, "LDS budget (dynamic + the static parameter / mask arrays)");
 constexpr int NF_W1 = 8, NF_W2 = 32, NF_W3 = 8;  // 16 x 32 fragments: W1 [128][32], W2 [128][128], W3 [32][128]
 
 __device__ __forceinline__ bf16x8_t lds_x8(const uint16_t* p) { return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(p)); }
@@ -65,13 +75,13 @@ template <bool SAVE, int NP>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ffn_x32(Ffn1Args a1, Ffn2Args a2, const u32x4_t* __restrict__ wsp, int tiles_x, int strips_y, int nstrips, int SH) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* ring = reinterpret_cast<float*>(smem_raw);                                   // [RING*HX][LDR]
-    uint16_t* A2 = reinterpret_cast<uint16_t*>(smem_raw + (size_t)RING * HX * LDR * 4);   // [3][CH][N1], chunk-swizzled
-    uint16_t* XA = A2 + A2_HALVES;                                                      // [2][3][CH][E]
+    uint16_t* A2 = reinterpret_cast<uint16_t*>(smem_raw + (size_t)RING * HX * LDR * 4);   // [NA2][3][CH][N1], chunk-swizzled
+    uint16_t* XA = A2 + NA2 * A2_HALVES;                                                // [2][3][CH][E]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     uint16_t* G3 = A2 + wave * G3_WAVE;                                                 // [3][16][64], aliases A2 / XA
     const int h = a2.h, w = a2.w;
     __shared__ __attribute__((aligned(16))) float sPar[5 * E];
-    __shared__ __attribute__((aligned(16))) float sMask[2][CH];
+    __shared__ __attribute__((aligned(16))) float sMask[4][CH];   // halo-pixel masks of up to four chunks in flight (slot = chunk & 3; round 2's form uses two)
     float* sLn2g = sPar;            float* sLn2b = sPar + E;
     float* sN1g = sPar + 2 * E;     float* sN1b = sPar + 3 * E;
     float* sB3 = sPar + 4 * E;
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) w2f[kb] = ld_wfrag(wsp, NF_W1 + wave * 4 + kb);
     const u32x4_t* w3p = wsp + (size_t)(NF_W1 + NF_W2) * 3 * 64;             // W3 fragments (mb, kb): f = mb * 4 + kb
-    // LayerNorm phase: thread t < 384 = (chunk pixel t / 8, channel quad t % 8)
+    // LayerNorm phase: thread t < 8 CH = (chunk pixel t / 8, channel quad t % 8)
     const int lpx = threadIdx.x >> 3, lq = threadIdx.x & 7;
     const bool ln_thread = threadIdx.x < 8 * CH;
     // depthwise phase: lane = (pixel slot lane / 16, channel quad q16 of the current K-half)
@@ -113,8 +123,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         xv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (in) xv = *reinterpret_cast<const float4*>(a1.x + ((b * h + y) * (long)w + x) * E + 4 * lq);
     };
-    // LayerNorm over the 32 channels of a pixel = 8 consecutive lanes; pieces -> XA[slot]
-    auto ln_store = [&](int slot, const float4& xv, bool in) {
+    // LayerNorm over the 32 channels of a pixel = 8 consecutive lanes; pieces -> XA[slot], halo mask -> sMask[mslot]
+    auto ln_store = [&](int slot, int mslot, const float4& xv, bool in) {
         if (!ln_thread) return;
         float s = quad_sum((xv.x + xv.y) + (xv.z + xv.w));
         s += __shfl_xor(s, 4);
@@ -132,15 +142,139 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         *reinterpret_cast<u32x2_t*>(dst) = q1;
         *reinterpret_cast<u32x2_t*>(dst + CH * E) = q2;
         *reinterpret_cast<u32x2_t*>(dst + 2 * CH * E) = q3;
-        if (lq == 0) sMask[slot][lpx] = m_;
+        if (lq == 0) sMask[mslot][lpx] = m_;
+    };
+    // ---- the two stages of a chunk.  stage1: GEMM1 (K = 32: h1[16 w .. +15][CH pixels] = W1 LN(x)) + GELU + split -> gelu(h1) image `img`;
+    //      stage2: GEMM2 (K = 128: h2 = W2 gelu(h1)) from image `img` -> masked -> ring (+ saves)
+    auto stage1 = [&](int ya, int npx, int c, int xslot, int img) {
+        f32x4_t acc[NPB];
+        const uint16_t* xa = XA + xslot * XA_SLOT + r * E + 8 * g;
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb) {
+            acc[pb] = (f32x4_t){b1v.x, b1v.y, b1v.z, b1v.w};
+            const uint16_t* p = xa + pb * 16 * E;
+            mfma_np32<NP>(acc[pb], w1f, lds_x8(p), lds_x8(p + CH * E), lds_x8(p + 2 * CH * E));
+        }
+        // GELU, split, -> image: logical 16-byte chunk 2 w + g / 2 of the pixel's row, stored at chunk ^ (pixel & 15)
+        uint16_t* A2i = A2 + img * A2_HALVES;
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb) {
+            float av[4];
+            if (SAVE) {
+                const int m = c * CH + pb * 16 + r;
+                const int hy = m / HX, hx = m - hy * HX;
+                const int y = ya + hy, x = x0 + hx - 1;
+                const bool inner = m < npx && hx >= 1 && hx <= TX && x < w && y >= Y0 && y < Yend;
+                const long prow = ((b * h + y) * (long)w + x) * N1 + c0;
+                lg_v2f a01, a23, g01, g23;
+                gelu2_both_f((lg_v2f){acc[pb][0], acc[pb][1]}, a01, g01);
+                gelu2_both_f((lg_v2f){acc[pb][2], acc[pb][3]}, a23, g23);
+                av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
+                if (inner) {
+                    HS<BF>::st4(a1.a1s, prow, make_float4(av[0], av[1], av[2], av[3]));
+                    HS<BF>::st4(a1.g1s, prow, make_float4(g01.x, g01.y, g23.x, g23.y));
+                }
+            } else {
+                const lg_v2f a01 = gelu2_f((lg_v2f){acc[pb][0], acc[pb][1]}), a23 = gelu2_f((lg_v2f){acc[pb][2], acc[pb][3]});
+                av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
+            }
+            u32x2_t q1, q2, q3;
+            split_x4<NP>(av, q1, q2, q3);
+            const int px = pb * 16 + r;
+            uint16_t* dst = A2i + px * N1 + (((2 * wave + (g >> 1)) ^ (px & 15)) << 3) + 4 * (g & 1);
+            *reinterpret_cast<u32x2_t*>(dst) = q1;
+            *reinterpret_cast<u32x2_t*>(dst + CH * N1) = q2;
+            *reinterpret_cast<u32x2_t*>(dst + 2 * CH * N1) = q3;
+        }
+    };
+    auto stage2 = [&](int ya, int npx, int c, int mslot, int img, int ring0) {
+        f32x4_t acc[NPB];
+        const uint16_t* A2i = A2 + img * A2_HALVES;
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb) {
+            acc[pb] = (f32x4_t){b2v.x, b2v.y, b2v.z, b2v.w};
+            const int px = pb * 16 + r;
+            const uint16_t* row = A2i + px * N1;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const uint16_t* p = row + (((4 * kb + g) ^ (px & 15)) << 3);
+                mfma_np32<NP>(acc[pb], w2f[kb], lds_x8(p), lds_x8(p + CH * N1), lds_x8(p + 2 * CH * N1));
+            }
+        }
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb) {
+            const int m = c * CH + pb * 16 + r;
+            const float mk = sMask[mslot][pb * 16 + r];
+            const float4 hh = make_float4(acc[pb][0] * mk, acc[pb][1] * mk, acc[pb][2] * mk, acc[pb][3] * mk);
+            if (SAVE) {
+                const int hy = m / HX, hx = m - hy * HX;
+                const int y = ya + hy, x = x0 + hx - 1;
+                const bool inner = m < npx && hx >= 1 && hx <= TX && x < w && y >= Y0 && y < Yend;
+                if (inner) HS<BF>::st4(a1.h2, ((b * h + y) * (long)w + x) * N1 + c0, hh);
+            }
+            int rp = ring0 + m;
+            rp = rp >= RING * HX ? rp - RING * HX : rp;
+            if (m < npx) *reinterpret_cast<float4*>(ring + rp * LDR + c0) = hh;
+        }
     };
 
+#if LG_X32_ALT
+    // dh.. h2 of halo rows [ya, ya + nr) -> ring.  pre0 / pre1: the x vectors of chunks 0 and 1, requested by the caller ahead of time.
+    // after_first: runs right behind the consumption of the prefetched vectors (the compiler's wait there is vmcnt(0): loads issued before it
+    // would be waited for on the spot -- k_ffn_x.hip).
+    // Chunk pipeline: image c & 1 holds gelu(h1) of chunk c.  In iteration c the waves of group A (0 .. 3) run stage2(c) and THEN stage1(c + 1),
+    // the waves of group B (4 .. 7) the other way round: the two waves of a SIMD (w and w + 4) are never in the same kind of burst, GEMM2's 48
+    // MFMAs of one run under the other's GELU / splitting, and a chunk ends in ONE barrier.  LN(x) of chunk c + 2 is normalised in iteration c
+    // (its slot c & 1 was read by stage1(c) in iteration c - 1; its mask slot (c + 2) & 3 is not the one stage2(c) reads).
+    auto compute_rows = [&](int ya, int nr, float4 pre0, bool pin0, float4 pre1, bool pin1, auto&& after_first) {
+        const int npx = nr * HX, nchunks = (npx + CH - 1) / CH;
+        const bool grpA = wave < 4;
+        __syncthreads();                 // the previous phase's readers of the aliased region (gelu(h3) pieces) are done
+        ln_store(0, 0, pre0, pin0);
+        if (nchunks > 1) ln_store(1, 1, pre1, pin1);
+        after_first();
+        float4 nx;
+        bool nin = false;
+        if (nchunks > 2) ln_fetch(ya, npx, 2, nx, nin);
+        __syncthreads();
+        stage1(ya, npx, 0, 0, 0);
+        __syncthreads();
+        const int ring0 = ((ya - Y0 + 1) % RING) * HX;
+        for (int c = 0; c < nchunks; ++c) {
+            const bool more1 = c + 1 < nchunks, more2 = c + 2 < nchunks;
+            if (grpA) {
+                stage2(ya, npx, c, c & 3, c & 1, ring0);
+                if (more1) stage1(ya, npx, c + 1, (c + 1) & 1, (c + 1) & 1);
+            } else {
+                if (more1) stage1(ya, npx, c + 1, (c + 1) & 1, (c + 1) & 1);
+                stage2(ya, npx, c, c & 3, c & 1, ring0);
+            }
+            if (more2) {
+                ln_store(c & 1, (c + 2) & 3, nx, nin);
+                if (c + 3 < nchunks) ln_fetch(ya, npx, c + 3, nx, nin);
+            }
+            __syncthreads();
+        }
+    };
+
+    {
+        float4 pre0, pre1;
+        bool pin0, pin1;
+        ln_fetch(Y0 - 1, 2 * HX, 0, pre0, pin0);
+        ln_fetch(Y0 - 1, 2 * HX, 1, pre1, pin1);
+        compute_rows(Y0 - 1, 2, pre0, pin0, pre1, pin1, [] {});
+    }
+    float4 pre, pre1;
+    bool pin, pin1;
+    ln_fetch(Y0 + 1, TY * HX, 0, pre, pin);
+    ln_fetch(Y0 + 1, TY * HX, 1, pre1, pin1);
+#else
     // after_first: runs right behind the consumption of the prefetched chunk-0 vector (the compiler's wait there is vmcnt(0): loads issued
     // before it would be waited for on the spot -- k_ffn_x.hip)
-    auto compute_rows = [&](int ya, int nr, float4 pre, bool pre_in, auto&& after_first) {
+    auto compute_rows = [&](int ya, int nr, float4 pre, bool pre_in, float4, bool, auto&& after_first) {
         const int npx = nr * HX, nchunks = (npx + CH - 1) / CH;
         __syncthreads();                 // the previous phase's readers of the aliased region (gelu(h3) pieces) are done
-        ln_store(0, pre, pre_in);
+        ln_store(0, 0, pre, pre_in);
         after_first();
         __syncthreads();
         const int ring0 = ((ya - Y0 + 1) % RING) * HX;
@@ -150,76 +284,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             bool nin = false;
             const bool more = c + 1 < nchunks;
             if (more) ln_fetch(ya, npx, c + 1, nx, nin);
-            long prow[3];
-            bool inner[3];
-            if (SAVE) {
-#pragma unroll
-                for (int pb = 0; pb < 3; ++pb) {
-                    const int m = c * CH + pb * 16 + r;
-                    const int hy = m / HX, hx = m - hy * HX;
-                    const int y = ya + hy, x = x0 + hx - 1;
-                    inner[pb] = m < npx && hx >= 1 && hx <= TX && x < w && y >= Y0 && y < Yend;
-                    prow[pb] = ((b * h + y) * (long)w + x) * N1 + c0;
-                }
-            }
-            // ---- GEMM1 (K = 32): h1[16 w .. +15][48 pixels] = W1 LN(x)
-            f32x4_t acc[3];
-            const uint16_t* xa = XA + slot * XA_SLOT + r * E + 8 * g;
-#pragma unroll
-            for (int pb = 0; pb < 3; ++pb) {
-                acc[pb] = (f32x4_t){b1v.x, b1v.y, b1v.z, b1v.w};
-                const uint16_t* p = xa + pb * 16 * E;
-                mfma_np32<NP>(acc[pb], w1f, lds_x8(p), lds_x8(p + CH * E), lds_x8(p + 2 * CH * E));
-            }
-            // ---- GELU, split, -> A2: logical 16-byte chunk 2 w + g / 2 of the pixel's row, stored at chunk ^ (pixel & 15)
-#pragma unroll
-            for (int pb = 0; pb < 3; ++pb) {
-                float av[4];
-                if (SAVE) {
-                    lg_v2f a01, a23, g01, g23;
-                    gelu2_both_f((lg_v2f){acc[pb][0], acc[pb][1]}, a01, g01);
-                    gelu2_both_f((lg_v2f){acc[pb][2], acc[pb][3]}, a23, g23);
-                    av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
-                    if (inner[pb]) {
-                        HS<BF>::st4(a1.a1s, prow[pb], make_float4(av[0], av[1], av[2], av[3]));
-                        HS<BF>::st4(a1.g1s, prow[pb], make_float4(g01.x, g01.y, g23.x, g23.y));
-                    }
-                } else {
-                    const lg_v2f a01 = gelu2_f((lg_v2f){acc[pb][0], acc[pb][1]}), a23 = gelu2_f((lg_v2f){acc[pb][2], acc[pb][3]});
-                    av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
-                }
-                u32x2_t q1, q2, q3;
-                split_x4<NP>(av, q1, q2, q3);
-                const int px = pb * 16 + r;
-                uint16_t* dst = A2 + px * N1 + (((2 * wave + (g >> 1)) ^ (px & 15)) << 3) + 4 * (g & 1);
-                *reinterpret_cast<u32x2_t*>(dst) = q1;
-                *reinterpret_cast<u32x2_t*>(dst + CH * N1) = q2;
-                *reinterpret_cast<u32x2_t*>(dst + 2 * CH * N1) = q3;
-            }
+            stage1(ya, npx, c, slot, 0);
             __syncthreads();
-            // ---- GEMM2 (K = 128): h2[16 w .. +15][48 pixels] = W2 gelu(h1)
-#pragma unroll
-            for (int pb = 0; pb < 3; ++pb) {
-                acc[pb] = (f32x4_t){b2v.x, b2v.y, b2v.z, b2v.w};
-                const int px = pb * 16 + r;
-                const uint16_t* row = A2 + px * N1;
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    const uint16_t* p = row + (((4 * kb + g) ^ (px & 15)) << 3);
-                    mfma_np32<NP>(acc[pb], w2f[kb], lds_x8(p), lds_x8(p + CH * N1), lds_x8(p + 2 * CH * N1));
-                }
-            }
-            if (more) ln_store(slot ^ 1, nx, nin);
-#pragma unroll
-            for (int pb = 0; pb < 3; ++pb) {
-                const int m = c * CH + pb * 16 + r;
-                const float mk = sMask[slot][pb * 16 + r];
-                const float4 hh = make_float4(acc[pb][0] * mk, acc[pb][1] * mk, acc[pb][2] * mk, acc[pb][3] * mk);
-                if (SAVE && inner[pb]) HS<BF>::st4(a1.h2, prow[pb], hh);
-                int rp = ring0 + m;
-                rp = rp >= RING * HX ? rp - RING * HX : rp;
-                if (m < npx) *reinterpret_cast<float4*>(ring + rp * LDR + c0) = hh;
-            }
+            stage2(ya, npx, c, slot, 0, ring0);     // (the ring stores follow ln_store in round 2's order; the order of the two is free)
+            if (more) ln_store(slot ^ 1, slot ^ 1, nx, nin);
             __syncthreads();
         }
     };
@@ -228,17 +296,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float4 pre;
         bool pin;
         ln_fetch(Y0 - 1, 2 * HX, 0, pre, pin);
-        compute_rows(Y0 - 1, 2, pre, pin, [] {});
+        compute_rows(Y0 - 1, 2, pre, pin, pre, pin, [] {});
     }
-    float4 pre;
-    bool pin;
+    float4 pre, pre1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool pin, pin1 = false;
     ln_fetch(Y0 + 1, TY * HX, 0, pre, pin);
+#endif
 #pragma unroll 1
     for (int y0 = Y0; y0 < Yend; y0 += TY) {
     // wave w owns tile row w; lane (r, g): pixel x0 + r, output channels 16 mb + 4 g .. + 3 (mb = 0, 1)
     const int ty = wave;
     float4 xres[2];
-    compute_rows(y0 + 1, TY, pre, pin, [&] {
+    compute_rows(y0 + 1, TY, pre, pin, pre1, pin1, [&] {
         const int y = y0 + ty, x = x0 + r;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
@@ -246,7 +315,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (y < Yend && x < w) xres[mb] = *reinterpret_cast<const float4*>(a2.x + ((b * h + y) * (long)w + x) * E + 16 * mb + 4 * g);
         }
     });
-    if (y0 + TY < Yend) ln_fetch(y0 + TY + 1, TY * HX, 0, pre, pin);   // next step's first chunk: in flight during the output phase
+    if (y0 + TY < Yend) {   // next step's first chunk(s): in flight during the output phase
+        ln_fetch(y0 + TY + 1, TY * HX, 0, pre, pin);
+        if (LG_X32_ALT) ln_fetch(y0 + TY + 1, TY * HX, 1, pre1, pin1);
+    }
     // ---- output phase: per K-half: dw3x3 over the ring + GELU -> pieces -> GEMM3 partial ; then bias + residual -> y (+ planar LN half)
     {
         const int sbase = (y0 - Y0) % RING;            // ring slot of row y0 - 1
