@@ -10,6 +10,7 @@
 //     fragment order into the caller's workspace, so the kernel's weight loads are coalesced 16-byte reads and W3 (96 VGPRs if
 //     resident) is simply re-read per K-half from L1 / L2.
 // The f32-MFMA kernel it replaces (k_ffn_fused<32>) ran one wave per SIMD at MFMA cycles + VALU cycles.
+#include <type_traits>
 #include "kernels.h"
 
 #include "hstore.h"
@@ -21,7 +22,7 @@ namespace {
 #define LG_X32_ALT 0   // 1 (round-4 experiment, parity-green, NOT kept): 32-pixel chunks, TWO gelu(h1) images; the two wave groups of the workgroup (waves
                        // 0 .. 3 / 4 .. 7 = the two waves of every SIMD) run GEMM2 of chunk c and GEMM1 + GELU of chunk c + 1 in OPPOSITE order, so
                        // that one wave's matrix burst could run under the other's vector burst, and a chunk costs one barrier.  Same-box A/B at c3
-                       // (average launch of the fused FFN, all variants): 316.6 us against 280.5 for round 2's form (48-pixel chunks, every wave in
+                       // (average launch of the fused FFN, all variants): 316.6 us (310.5 with the chunk loop unrolled and the x vectors requested two chunks ahead) against 280.5 - 282 for round 2's form (48-pixel chunks, every wave in
                        // the same phase, two barriers per chunk) -- with ONE wave of a SIMD in GEMM2 its two dependent accumulation chains do not
                        // fill the matrix pipe (six chains of two waves did), and five chunks per step pay the pipeline's fill and drain
 #endif
@@ -226,22 +227,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the waves of group B (4 .. 7) the other way round: the two waves of a SIMD (w and w + 4) are never in the same kind of burst, GEMM2's 48
     // MFMAs of one run under the other's GELU / splitting, and a chunk ends in ONE barrier.  LN(x) of chunk c + 2 is normalised in iteration c
     // (its slot c & 1 was read by stage1(c) in iteration c - 1; its mask slot (c + 2) & 3 is not the one stage2(c) reads).
-    auto compute_rows = [&](int ya, int nr, float4 pre0, bool pin0, float4 pre1, bool pin1, auto&& after_first) {
-        const int npx = nr * HX, nchunks = (npx + CH - 1) / CH;
-        const bool grpA = wave < 4;
+    auto compute_rows = [&](int ya, auto nr_c, float4 pre0, bool pin0, float4 pre1, bool pin1, auto&& after_first) {
+        constexpr int nr = decltype(nr_c)::value, npx = nr * HX, nchunks = (npx + CH - 1) / CH;   // compile-time: the chunk loop unrolls, so the
+        const bool grpA = wave < 4;                                                                 // prefetch registers have static names
         __syncthreads();                 // the previous phase's readers of the aliased region (gelu(h3) pieces) are done
         ln_store(0, 0, pre0, pin0);
         if (nchunks > 1) ln_store(1, 1, pre1, pin1);
         after_first();
-        float4 nx;
-        bool nin = false;
-        if (nchunks > 2) ln_fetch(ya, npx, 2, nx, nin);
+        // x vectors of chunks 2 .. nchunks - 1: requested TWO chunks ahead (chunk k's vector is normalised at the end of iteration k - 2)
+        float4 nxv[nchunks > 2 ? nchunks - 2 : 1];
+        bool ninv[nchunks > 2 ? nchunks - 2 : 1];
+        if (nchunks > 2) ln_fetch(ya, npx, 2, nxv[0], ninv[0]);
+        if (nchunks > 3) ln_fetch(ya, npx, 3, nxv[1], ninv[1]);
         __syncthreads();
         stage1(ya, npx, 0, 0, 0);
         __syncthreads();
         const int ring0 = ((ya - Y0 + 1) % RING) * HX;
+#pragma unroll
         for (int c = 0; c < nchunks; ++c) {
             const bool more1 = c + 1 < nchunks, more2 = c + 2 < nchunks;
+            if (c + 4 < nchunks) ln_fetch(ya, npx, c + 4, nxv[c + 2], ninv[c + 2]);
             if (grpA) {
                 stage2(ya, npx, c, c & 3, c & 1, ring0);
                 if (more1) stage1(ya, npx, c + 1, (c + 1) & 1, (c + 1) & 1);
@@ -249,10 +254,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (more1) stage1(ya, npx, c + 1, (c + 1) & 1, (c + 1) & 1);
                 stage2(ya, npx, c, c & 3, c & 1, ring0);
             }
-            if (more2) {
-                ln_store(c & 1, (c + 2) & 3, nx, nin);
-                if (c + 3 < nchunks) ln_fetch(ya, npx, c + 3, nx, nin);
-            }
+            if (more2) ln_store(c & 1, (c + 2) & 3, nxv[c], ninv[c]);
             __syncthreads();
         }
     };
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         bool pin0, pin1;
         ln_fetch(Y0 - 1, 2 * HX, 0, pre0, pin0);
         ln_fetch(Y0 - 1, 2 * HX, 1, pre1, pin1);
-        compute_rows(Y0 - 1, 2, pre0, pin0, pre1, pin1, [] {});
+        compute_rows(Y0 - 1, std::integral_constant<int, 2>{}, pre0, pin0, pre1, pin1, [] {});
     }
     float4 pre, pre1;
     bool pin, pin1;
@@ -271,7 +273,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #else
     // after_first: runs right behind the consumption of the prefetched chunk-0 vector (the compiler's wait there is vmcnt(0): loads issued
     // before it would be waited for on the spot -- k_ffn_x.hip)
-    auto compute_rows = [&](int ya, int nr, float4 pre, bool pre_in, float4, bool, auto&& after_first) {
+    auto compute_rows = [&](int ya, auto nr_c, float4 pre, bool pre_in, float4, bool, auto&& after_first) {
+        constexpr int nr = decltype(nr_c)::value;
         const int npx = nr * HX, nchunks = (npx + CH - 1) / CH;
         __syncthreads();                 // the previous phase's readers of the aliased region (gelu(h3) pieces) are done
         ln_store(0, 0, pre, pre_in);
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float4 pre;
         bool pin;
         ln_fetch(Y0 - 1, 2 * HX, 0, pre, pin);
-        compute_rows(Y0 - 1, 2, pre, pin, pre, pin, [] {});
+        compute_rows(Y0 - 1, std::integral_constant<int, 2>{}, pre, pin, pre, pin, [] {});
     }
     float4 pre, pre1 = make_float4(0.f, 0.f, 0.f, 0.f);
     bool pin, pin1 = false;
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // wave w owns tile row w; lane (r, g): pixel x0 + r, output channels 16 mb + 4 g .. + 3 (mb = 0, 1)
     const int ty = wave;
     float4 xres[2];
-    compute_rows(y0 + 1, TY, pre, pin, pre1, pin1, [&] {
+    compute_rows(y0 + 1, std::integral_constant<int, TY>{}, pre, pin, pre1, pin1, [&] {
         const int y = y0 + ty, x = x0 + r;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
