@@ -18,16 +18,42 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a, int nwin, int nquads) 
     float* sK = smem + 2 * 64 * 64;           // [4][64][HC]
     float* sV = sK + 4 * 64 * HC;             // [4][64][HC]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 2 * 64 * 64; i += 256) sPos[i] = a.posT[i] * LOG2E;   // scores live in the log2 domain: softmax = exp2(s - max)
     // weights of the block, once per (persistent) workgroup: read as LDS broadcasts in the window loop (as dependent vector
     // loads they were ~60 load instructions with waits per window)
     __shared__ __attribute__((aligned(16))) float sWqkv[3 * HC * HC];
     __shared__ __attribute__((aligned(16))) float sWproj[E * E];
     __shared__ float sBias[3 * HC + E + 2 * HC];   // qkv bias | proj bias | ln1 gamma, beta (local half)
-    for (int i = threadIdx.x; i < 3 * HC * HC; i += 256) sWqkv[i] = a.qkvw[i];
-    for (int i = threadIdx.x; i < E * E; i += 256) sWproj[i] = a.projw[i];
-    for (int i = threadIdx.x; i < 3 * HC + E + 2 * HC; i += 256)
-        sBias[i] = i < 3 * HC ? a.qkvb[i] : (i < 3 * HC + E ? a.projb[i - 3 * HC] : (i < 4 * HC + E ? a.ln1g[i - 3 * HC - E] : a.ln1b[i - 4 * HC - E]));
+    {
+        // Staging: EVERY value of a thread is requested before the first one is stored (unconditional loads from clamped indices).  As five
+        // loops with a load, a wait and a store per trip -- the small ones inside exec-masked branches, whose joins wait with vmcnt(0) -- the
+        // workgroups of the launch, which all start together, sat through ~8 dependent L2 round trips before their first window (round 4)
+        constexpr int NQ = (3 * HC * HC + 255) / 256, NPJ = (E * E + 255) / 256, NB = 3 * HC + E + 2 * HC;
+        float pv[32], wq[NQ], wp[NPJ], bv[4];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) pv[k] = a.posT[k * 256 + threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) wq[k] = a.qkvw[min(k * 256 + (int)threadIdx.x, 3 * HC * HC - 1)];
+#pragma unroll
+        for (int k = 0; k < NPJ; ++k) wp[k] = a.projw[min(k * 256 + (int)threadIdx.x, E * E - 1)];
+        {
+            const int i = threadIdx.x;
+            bv[0] = a.qkvb[min(i, 3 * HC - 1)];
+            bv[1] = a.projb[clampi(i - 3 * HC, 0, E - 1)];
+            bv[2] = a.ln1g[clampi(i - 3 * HC - E, 0, HC - 1)];
+            bv[3] = a.ln1b[clampi(i - 4 * HC - E, 0, HC - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) sPos[k * 256 + threadIdx.x] = pv[k] * LOG2E;   // scores live in the log2 domain: softmax = exp2(s - max)
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) if (k * 256 + (int)threadIdx.x < 3 * HC * HC) sWqkv[k * 256 + threadIdx.x] = wq[k];
+#pragma unroll
+        for (int k = 0; k < NPJ; ++k) if (k * 256 + (int)threadIdx.x < E * E) sWproj[k * 256 + threadIdx.x] = wp[k];
+        static_assert(NB <= 256, "one bias value per thread");
+        if ((int)threadIdx.x < NB) {
+            const int i = threadIdx.x;
+            sBias[i] = i < 3 * HC ? bv[0] : (i < 3 * HC + E ? bv[1] : (i < 4 * HC + E ? bv[2] : bv[3]));
+        }
+    }
     const int nwx = a.w >> 3, nwy = a.h >> 3;
     const float scale = (float)(1.0 / sqrt((double)D)) * LOG2E;
     float* myK = sK + wave * 64 * HC;
