@@ -255,4 +255,17 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx) {
 __device__ __forceinline__ void lds_stage(float* dst, const float* __restrict__ src, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
+// Several small arrays at once, with EVERY load in flight before the first store: one lds_stage call after another is one dependent L2 round
+// trip after another (each loop's load sits in an exec-masked branch, whose join waits with vmcnt(0)) -- 3 to 5 of them at the start of
+// kernels that run 12 - 40 us.  Counts are compile-time; loads are unconditional from clamped indices; NT = the block size.
+template <int NT, int N>
+__device__ __forceinline__ void lds_stage_ld(float (&v)[(N + NT - 1) / NT], const float* __restrict__ src) {
+#pragma unroll
+    for (int k = 0; k < (N + NT - 1) / NT; ++k) { const int i = k * NT + (int)threadIdx.x; v[k] = src[i < N ? i : N - 1]; }
+}
+template <int NT, int N>
+__device__ __forceinline__ void lds_stage_st(float* dst, const float (&v)[(N + NT - 1) / NT]) {
+#pragma unroll
+    for (int k = 0; k < (N + NT - 1) / NT; ++k) { const int i = k * NT + (int)threadIdx.x; if (i < N) dst[i] = v[k]; }
+}
 #endif  // __HIPCC__

@@ -192,9 +192,17 @@ __global__ __launch_bounds__(256) void k_down(DownArgs a) {
     static_assert(NO == 8, "eight outputs per lane");
     __shared__ float sW[2 * E * E], sB[2 * E], sNg[2 * E], sNb[2 * E];
     __shared__ __attribute__((aligned(16))) float ux[PPW * LDU];
-    lds_stage(sW, a.w, 2 * E * E);
-    lds_stage(sB, a.b, 2 * E);
-    if (a.g) { lds_stage(sNg, a.n1g, 2 * E); lds_stage(sNb, a.n1b, 2 * E); }
+    {   // all four arrays requested before the first store (common.h: lds_stage_ld / _st); absent LayerNorm vectors: a valid dummy source
+        float vw[(2 * E * E + 255) / 256], vb[1], vg[1], vn[1];
+        lds_stage_ld<256, 2 * E * E>(vw, a.w);
+        lds_stage_ld<256, 2 * E>(vb, a.b);
+        lds_stage_ld<256, 2 * E>(vg, a.g ? a.n1g : a.b);
+        lds_stage_ld<256, 2 * E>(vn, a.g ? a.n1b : a.b);
+        lds_stage_st<256, 2 * E * E>(sW, vw);
+        lds_stage_st<256, 2 * E>(sB, vb);
+        lds_stage_st<256, 2 * E>(sNg, vg);
+        lds_stage_st<256, 2 * E>(sNb, vn);
+    }
     __syncthreads();
     const int q = threadIdx.x % LPP, slot = threadIdx.x / LPP;
     const int ho = a.H / 2, wo = a.W / 2;
@@ -294,9 +302,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     __shared__ float4 srcb[NS * Q];                          // [NS][2E] level-1 pixels
     __shared__ __attribute__((aligned(16))) float vb[NS * LDV];   // [NS][E] up-conv of them (no bias)
     __shared__ float sFw[E * 2 * E], sFb[2 * E];   // fusion weight | up bias, fusion bias (synchronised by the barriers below)
-    lds_stage(sFw, a.fw, E * 2 * E);
-    lds_stage(sFb, a.upb, E);
-    lds_stage(sFb + E, a.fb, E);
+    {   // all three arrays requested before the first store
+        float vw[(E * 2 * E + 255) / 256], vu[1], vf[1];
+        lds_stage_ld<256, E * 2 * E>(vw, a.fw);
+        lds_stage_ld<256, E>(vu, a.upb);
+        lds_stage_ld<256, E>(vf, a.fb);
+        lds_stage_st<256, E * 2 * E>(sFw, vw);
+        lds_stage_st<256, E>(sFb, vu);
+        lds_stage_st<256, E>(sFb + E, vf);
+    }
     const int hi = a.H / 2, wi = a.W / 2;
     int t = blockIdx.x;
     const int tx_i = t % tiles_x;
@@ -467,8 +481,13 @@ int launch_upfuse(int E, const UpFuseArgs& a, hipStream_t s) {
 template <int C, int E>
 __global__ __launch_bounds__(256) void k_tail(TailArgs a) {
     __shared__ float sW[C * E], sB[C];
-    lds_stage(sW, a.w, C * E);
-    lds_stage(sB, a.b, C);
+    {
+        float vw[(C * E + 255) / 256], vb[1];
+        lds_stage_ld<256, C * E>(vw, a.w);
+        lds_stage_ld<256, C>(vb, a.b);
+        lds_stage_st<256, C * E>(sW, vw);
+        lds_stage_st<256, C>(sB, vb);
+    }
     __syncthreads();
     long p = blockIdx.x * 256L + threadIdx.x;
     if (p >= a.total) return;
