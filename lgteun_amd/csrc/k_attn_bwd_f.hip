@@ -127,32 +127,33 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
     { const int stamp_it = 0; STAMP(11); }
 #endif
     // ---- staging, once per workgroup
-    {   // pos_emb: all values of a thread requested at once (a load + wait per loop trip is 16 - 32 dependent round trips)
+    {   // every staged value of a thread is requested before the first one is stored (a load + wait per loop trip, or per exec-masked `if`, is a
+        // dependent L2 round trip each: 16 + 4 of them in the first version), unconditionally from clamped indices
         constexpr int NPV = 2 * 64 * 64 / F_NT;
         float pv[NPV];
 #pragma unroll
         for (int k = 0; k < NPV; ++k) pv[k] = a.pos[k * F_NT + threadIdx.x];
+        const int t = threadIdx.x;
+        // sWq[h][third * 4 + c][k] = qkvw[third * HC + h * D + c][k]   (t < 192)
+        const int tq = t < 192 ? t : 191, hq = tq / 96, rq = (tq % 96) >> 3, kq = tq & 7;
+        const float vwq = a.qkvw[((rq >> 2) * HC + hq * D + (rq & 3)) * HC + kq];
+        const int tb = t < 24 ? t : 23, hb = tb / 12, rb = tb % 12;
+        const float vbq = a.qkvb[(rb >> 2) * HC + hb * D + (rb & 3)];
+        // sWp[c][u][hk] = projw[HC * c + u][hk]   (hk = head * 4 + k: the attention columns of proj; t < 128)
+        const int tp = t < 128 ? t : 127, cp = tp >> 6, up = (tp >> 3) & 7, hkp = tp & 7;
+        const float vwp = a.projw[(HC * cp + up) * E + hkp];
+        const int tl = t < 32 ? t : 31;
+        const float vlg = a.ln1g[tl & 15], vlb = a.ln1b[tl & 15];
+        const float vln = tl < 16 ? vlg : vlb;
 #pragma unroll
         for (int k = 0; k < NPV; ++k) {
             const int i = k * F_NT + threadIdx.x;
             smem[(i >> 12) * 64 * PLD + ((i >> 6) & 63) * PLD + (i & 63)] = pv[k] * LOG2E;
         }
-    }
-    if (threadIdx.x < 192) {   // sWq[h][third * 4 + c][k] = qkvw[third * HC + h * D + c][k]
-        const int h = threadIdx.x / 96, r = (threadIdx.x % 96) >> 3, k = threadIdx.x & 7;
-        sWq[threadIdx.x] = a.qkvw[((r >> 2) * HC + h * D + (r & 3)) * HC + k];
-    }
-    if (threadIdx.x < 24) {
-        const int h = threadIdx.x / 12, r = threadIdx.x % 12;
-        sBq[threadIdx.x] = a.qkvb[(r >> 2) * HC + h * D + (r & 3)];
-    }
-    if (threadIdx.x < 128) {   // sWp[c][u][hk] = projw[HC * c + u][hk]   (hk = head * 4 + k: the attention columns of proj)
-        const int i = threadIdx.x, c = i >> 6, u = (i >> 3) & 7, hk = i & 7;
-        sWp[c * F_WPS + u * 8 + hk] = a.projw[(HC * c + u) * E + hk];
-    }
-    if (threadIdx.x >= 192 && threadIdx.x < 192 + 32) {
-        const int i = threadIdx.x - 192;
-        sLn[i] = i < 16 ? a.ln1g[i] : a.ln1b[i - 16];
+        if (t < 192) sWq[t] = vwq;
+        if (t < 24) sBq[t] = vbq;
+        if (t < 128) sWp[cp * F_WPS + up * 8 + hkp] = vwp;
+        if (t < 32) sLn[t] = vln;
     }
     // LayerNorm gamma / beta gradient slots: the 8 lanes of a 16-lane row that hold one channel half pre-sum their 8 tokens with three DPP
     // steps and share ONE slot of 16 floats (every one of them writes the same sum to it: 512 bytes per wave instead of 4 KB)
