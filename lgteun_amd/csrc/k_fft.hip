@@ -217,6 +217,9 @@ __device__ __forceinline__ void half_bin(int it, int n, int lg, int& q, int& p, 
 
 // LG = log2(n) is a template parameter: every shift / mask / stride of the (force-inlined) passes becomes an immediate and the
 // stage loops unroll -- about a third of the butterfly loops' instructions were runtime index arithmetic
+// threads of the in-LDS mixer kernels for a 2^LG-point side (launch_fftmix / launch_fftmix_bwd use the same function)
+__host__ __device__ constexpr int fft_threads(int lg) { return lg >= 7 ? 1024 : (lg >= 6 ? 512 : 256); }
+
 template <int LG>
 __global__ void k_fftmix(FftArgs a) {
     extern __shared__ float2 smem2[];
@@ -231,10 +234,21 @@ __global__ void k_fftmix(FftArgs a) {
         float ang = 2.0f * (float)k / (float)n;
         tw[k] = make_float2(cospif(ang), 0.0f - sinpif(ang));
     }
-    for (int i = threadIdx.x * 4; i < n * n; i += blockDim.x * 4) {   // 16-byte global loads (n >= 8: a quad never straddles rows)
-        const float4 v = *reinterpret_cast<const float4*>(g + i);
-        float2* d = buf + (i >> lg) * LD + (i & (n - 1));
-        d[0] = make_float2(v.x, 0.0f); d[1] = make_float2(v.y, 0.0f); d[2] = make_float2(v.z, 0.0f); d[3] = make_float2(v.w, 0.0f);
+    {   // 16-byte global loads (n >= 8: a quad never straddles rows), ALL of a thread's requested before the first is stored: as a loop over
+        // blockDim the plane came in as four dependent HBM round trips (load, s_waitcnt vmcnt(0), store per trip) with every workgroup
+        // of the launch loading at the same time (round 4)
+        constexpr int NTH = fft_threads(LG), NLD = (n * n / 4 + NTH - 1) / NTH;
+        float4 v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) { const int i = (k * NTH + (int)threadIdx.x) * 4; v[k] = *reinterpret_cast<const float4*>(g + (i < n * n ? i : 0)); }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = (k * NTH + (int)threadIdx.x) * 4;
+            if (i < n * n) {
+                float2* d = buf + (i >> lg) * LD + (i & (n - 1));
+                d[0] = make_float2(v[k].x, 0.0f); d[1] = make_float2(v[k].y, 0.0f); d[2] = make_float2(v[k].z, 0.0f); d[3] = make_float2(v[k].w, 0.0f);
+            }
+        }
     }
     __syncthreads();
     // ---- rfft2: rows then columns
@@ -750,7 +764,7 @@ int launch_fftmix(const FftArgs& a, hipStream_t s) {
         if (e != hipSuccess) { lg_set_error("fftmix: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
-    int threads = n >= 128 ? 1024 : (n >= 64 ? 512 : 256);
+    int threads = fft_threads(lg);
     switch (lg) {
         case 3: k_fftmix<3><<<a.planes, threads, lds, s>>>(a); break;
         case 4: k_fftmix<4><<<a.planes, threads, lds, s>>>(a); break;
@@ -783,12 +797,27 @@ __global__ void k_fftmix_bwd(FftBwdArgs a) {
         float ang = 2.0f * (float)k / (float)n;
         tw[k] = make_float2(cospif(ang), 0.0f - sinpif(ang));
     }
-    for (int i = threadIdx.x * 4; i < n * n; i += blockDim.x * 4) {
-        const float4 u = *reinterpret_cast<const float4*>(a.do2 + base + i);
-        const float4 sg = *reinterpret_cast<const float4*>(a.sgn + base + i);
-        float2* d = buf + (i >> lg) * LD + (i & (n - 1));
-        d[0] = make_float2(u.x * sg.x, 0.0f); d[1] = make_float2(u.y * sg.y, 0.0f);
-        d[2] = make_float2(u.z * sg.z, 0.0f); d[3] = make_float2(u.w * sg.w, 0.0f);
+    // Every global operand of a thread is requested up front (round 4): the plane (do2, sgn) before the first store into LDS, and the saved
+    // spectrum (amp, pha) of the thread's bins in one batch in front of the edit.  As loops over blockDim the plane was 4 and the spectrum 9
+    // dependent HBM round trips (load, wait, use per trip) in a 35 us kernel.
+    constexpr int NTH = fft_threads(LG), NLD = (n * n / 4 + NTH - 1) / NTH, NBIN = n * (half + 1), NIT = (NBIN + NTH - 1) / NTH;
+    {
+        float4 u[NLD], sg[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = (k * NTH + (int)threadIdx.x) * 4, ic = i < n * n ? i : 0;
+            u[k] = *reinterpret_cast<const float4*>(a.do2 + base + ic);
+            sg[k] = *reinterpret_cast<const float4*>(a.sgn + base + ic);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = (k * NTH + (int)threadIdx.x) * 4;
+            if (i < n * n) {
+                float2* d = buf + (i >> lg) * LD + (i & (n - 1));
+                d[0] = make_float2(u[k].x * sg[k].x, 0.0f); d[1] = make_float2(u[k].y * sg[k].y, 0.0f);
+                d[2] = make_float2(u[k].z * sg[k].z, 0.0f); d[3] = make_float2(u[k].w * sg[k].w, 0.0f);
+            }
+        }
     }
     __syncthreads();
     fft_pass<false, false>(buf, tw, n, lg);
@@ -796,12 +825,26 @@ __global__ void k_fftmix_bwd(FftBwdArgs a) {
     const float aw = a.ampw[ch], ab = a.ampb[ch], pw = a.phaw[ch], pb = a.phab[ch];
     const float nn = (float)n * (float)n;
     float s_aw = 0.f, s_ab = 0.f, s_pw = 0.f, s_pb = 0.f;
-    for (int it = threadIdx.x; it < n * (half + 1); it += blockDim.x) {
+    // (requested here, in ONE batch, not in front of the transform: 16 waves per CU leave 128 registers per lane and the butterflies use them)
+    float ampv[NIT], phav[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int it = k * NTH + (int)threadIdx.x, itc = it < NBIN ? it : 0;
         int q, p, c;
-        half_bin(it, n, lg, q, p, c);
-        const float cf = (c == 0 || c == half) ? 1.0f : 2.0f;
+        half_bin(itc, n, lg, q, p, c);
         const size_t o = ((size_t)plane * n + q) * (half + 1) + c;
-        buf[q * LD + p] = bin_edit_bwd(buf[q * LD + p], cf, nn, a.amp[o], a.pha[o], aw, ab, pw, pb, s_aw, s_ab, s_pw, s_pb);
+        ampv[k] = a.amp[o];
+        phav[k] = a.pha[o];
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int it = k * NTH + (int)threadIdx.x;
+        if (it < NBIN) {
+            int q, p, c;
+            half_bin(it, n, lg, q, p, c);
+            const float cf = (c == 0 || c == half) ? 1.0f : 2.0f;
+            buf[q * LD + p] = bin_edit_bwd(buf[q * LD + p], cf, nn, ampv[k], phav[k], aw, ab, pw, pb, s_aw, s_ab, s_pw, s_pb);
+        }
     }
     __syncthreads();
     fft_pass<true, true>(buf, tw, n, lg);
@@ -866,7 +909,7 @@ static int launch_fftmix_bwd_kernels(const FftBwdArgs& a, hipStream_t s) {
         if (e != hipSuccess) { lg_set_error("fftmix_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
-    int threads = n >= 128 ? 1024 : (n >= 64 ? 512 : 256);
+    int threads = fft_threads(lg);
     switch (lg) {
         case 3: k_fftmix_bwd<3><<<a.planes, threads, lds, s>>>(a); break;
         case 4: k_fftmix_bwd<4><<<a.planes, threads, lds, s>>>(a); break;
