@@ -90,7 +90,8 @@ typedef struct lg_config {
 #define LG_VAR_FFN_BWD32_XS (1u << 4)   /* e = 32 FFN backward: the e = 16 kernel's template instance instead of the default pair */
 #define LG_VAR_FFN_DWBWD_TILE (1u << 5) /* e = 16 FFN backward, spatial half: round 2's tile kernel + weight-gradient launch */
 #define LG_VAR_ATTN_BWD_R3 (1u << 6)    /* e = 16 local-mixer backward: round 3's three-kernel form instead of k_attn_bwd_f */
-#define LG_VAR_ALL 0x7fu
+#define LG_VAR_DSTEP_TILES (1u << 7)    /* data step: the tile kernels (four launches forward, nine backward) also where the one-launch form exists */
+#define LG_VAR_ALL 0xffu
 
 typedef struct lg_plan lg_plan; /* host-side, immutable after creation */
 
@@ -152,7 +153,8 @@ int lg_dropout_mask(uint64_t seed, int32_t stage, int32_t blk, int64_t first, in
 /* ---- per-op entry points (unit-tested against the oracle; same kernels the orchestrators launch) ---- */
 /* bmu.sampling_ bicubic (basic_module_unformer_v2.py:21-23): mode 0: x0.5, 1: x2, 2: x4.  x [planes,hi,wi]. */
 int lg_op_resample(const float* x, float* y, int32_t planes, int32_t hi, int32_t wi, int32_t mode, void* stream);
-/* one data step (unlg_former.py:58-61) for stage `stage`: z_in -> z_out [B,C,H,W]; tmp: 3*B*C*H*W/4 floats. */
+/* one data step (unlg_former.py:58-61) for stage `stage`: z_in -> z_out [B,C,H,W]; tmp: 3*B*C*H*W/4 + B*H*W floats (the chain's three
+ * intermediates t1 | r | . | s1 in quarters of B*C*H*W/4, then the per-sample plane R Z - pan of the one-launch form). */
 int lg_op_data_step(const lg_plan* plan, const float* params, int32_t stage, const float* z_in, const float* ms,
                     const float* pan, float* z_out, float* tmp, int32_t B, void* stream);
 /* one LGT forward (LGT.py:314-344) with stage `stage`'s weights: z [B,C,H,W] -> out [B,C,H,W]. */

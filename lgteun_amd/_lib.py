@@ -30,6 +30,7 @@ class LgConfig(ctypes.Structure):
 LG_VAR_FFN_STRIP, LG_VAR_FFN_TILE, LG_VAR_FFN_XP = 1, 2, 3
 LG_VAR_FFN_SAVE3, LG_VAR_FFN_SAVE5 = 1 << 2, 2 << 2
 LG_VAR_FFN_BWD32_XS, LG_VAR_FFN_DWBWD_TILE, LG_VAR_ATTN_BWD_R3 = 1 << 4, 1 << 5, 1 << 6
+LG_VAR_DSTEP_TILES = 1 << 7
 
 
 def variant_from_env(env=None):
@@ -44,6 +45,8 @@ def variant_from_env(env=None):
         v |= LG_VAR_FFN_DWBWD_TILE
     if env.get('LG_ATTN_BWD') in ('old', 'r3'):
         v |= LG_VAR_ATTN_BWD_R3
+    if env.get('LG_DSTEP') == 'tiles':
+        v |= LG_VAR_DSTEP_TILES
     return v
 
 

@@ -140,6 +140,7 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
         p->bwd32_old = (v & LG_VAR_FFN_BWD32_XS) ? 0 : 1;   // default: the round-2 pair (k_ffn1_bwd_xs<32>: parity-green, measured 375 us against 203 + 121 us at C = 8)
         p->dwbwd_tile = (v & LG_VAR_FFN_DWBWD_TILE) ? 1 : 0;
         p->attn_bwd_old = (v & LG_VAR_ATTN_BWD_R3) ? 1 : 0;
+        p->dstep_tiles = (v & LG_VAR_DSTEP_TILES) ? 1 : 0;
     }
     p->off = (int64_t*)malloc(sizeof(int64_t) * n_offsets);
     memcpy(p->off, offsets, sizeof(int64_t) * n_offsets);
@@ -166,9 +167,19 @@ extern "C" size_t lg_workspace_bytes(const lg_plan* plan, int32_t B, int32_t tra
 // forward pieces
 // ------------------------------------------------------------------------------------------------
 static int data_step_fwd(const lg_plan* pl, const float* P, int stage, const float* z_in, const float* ms, const float* pan,
-                         float* z_out, float* t1, float* r, float* s1, int B, hipStream_t s) {
+                         float* z_out, float* t1, float* r, float* s1, float* pr, int B, hipStream_t s) {
     const lg_config& c = pl->cfg;
     const int planes = B * c.C, H = c.H, W = c.W;
+    if (pl->dstep_fused(H, W)) {
+        DstepFwdArgs f;
+        f.z = z_in; f.ms = ms; f.pan = pan; f.zout = z_out; f.t1 = t1; f.r = r; f.s1 = s1; f.pr = pr;
+        f.d1w = P + pl->shared(S_D1W); f.d1b = P + pl->shared(S_D1B); f.d3w = P + pl->shared(S_D3W); f.d3b = P + pl->shared(S_D3B);
+        f.dt1w = P + pl->shared(S_DT1W); f.dt1b = P + pl->shared(S_DT1B); f.dt3w = P + pl->shared(S_DT3W); f.dt3b = P + pl->shared(S_DT3B);
+        f.rw = P + pl->shared(S_RW); f.rb = P + pl->shared(S_RB); f.rtw = P + pl->shared(S_RTW); f.rtb = P + pl->shared(S_RTB);
+        f.eta = P + pl->eta(stage);
+        f.B = B; f.C = c.C; f.N = H;
+        return launch_dstep_fwd(f, s);
+    }
     DwArgs a;
     memset(&a, 0, sizeof(a));
     a.C = c.C; a.planes = planes;
@@ -334,14 +345,14 @@ extern "C" int lgteun_forward(const lg_plan* plan, const float* params, const fl
     if (chained) {
         // intended unfolding: X_{i+1} = LGT_i(data_step_i(X_i)); every stage saves into its own activation set when training
         for (int i = 0; i < c.K; ++i) {
-            if ((rc = data_step_fwd(plan, params, i, nb.X[i], ms, pan, nb.Z[i + 1], nb.t1[i], nb.r[i], nb.s1[i], B, s))) return rc;
+            if ((rc = data_step_fwd(plan, params, i, nb.X[i], ms, pan, nb.Z[i + 1], nb.t1[i], nb.r[i], nb.s1[i], nb.pr, B, s))) return rc;
             NetBufs sv = (train == 2) ? stage_view(nb, i) : nb;
             if ((rc = lgt_fwd(plan, params, i, nb.Z[i + 1], i == c.K - 1 ? out : nb.X[i + 1], sv, B, flags, seed, s, true))) return rc;
         }
         return 0;
     }
     for (int i = 0; i < c.K; ++i) {
-        if ((rc = data_step_fwd(plan, params, i, nb.Z[i], ms, pan, nb.Z[i + 1], nb.t1[i], nb.r[i], nb.s1[i], B, s))) return rc;
+        if ((rc = data_step_fwd(plan, params, i, nb.Z[i], ms, pan, nb.Z[i + 1], nb.t1[i], nb.r[i], nb.s1[i], nb.pr, B, s))) return rc;
         const bool last = (i == c.K - 1);
         if (last) {
             if ((rc = lgt_fwd(plan, params, i, nb.Z[i + 1], out, nb, B, flags, seed, s, true))) return rc;
@@ -401,7 +412,7 @@ extern "C" int lg_op_data_step(const lg_plan* plan, const float* params, int32_t
     if (!plan || !params || !z_in || !ms || !pan || !z_out || !tmp || stage < 0 || stage >= plan->cfg.K) { lg_set_error("op_data_step: invalid argument"); return -1; }
     const lg_config& c = plan->cfg;
     size_t q = (size_t)B * c.C * c.H * c.W / 4;
-    return data_step_fwd(plan, params, stage, z_in, ms, pan, z_out, tmp, tmp + q, tmp + 2 * q, B, (hipStream_t)stream);
+    return data_step_fwd(plan, params, stage, z_in, ms, pan, z_out, tmp, tmp + q, tmp + 2 * q, tmp + 3 * q, B, (hipStream_t)stream);
 }
 
 extern "C" int lg_op_lgt(const lg_plan* plan, const float* params, int32_t stage, const float* z, float* out, void* workspace,
@@ -496,7 +507,7 @@ extern "C" int lg_op_data_step_bwd(const lg_plan* plan, const float* params, flo
     carve(plan, B, 1, workspace, nb);
     int rc;
     // forward of the step: fills the intermediates its backward reads (t1, r, s1)
-    if ((rc = data_step_fwd(plan, params, stage, z_in, ms, pan, nb.Z[stage + 1], nb.t1[stage], nb.r[stage], nb.s1[stage], B, s))) return rc;
+    if ((rc = data_step_fwd(plan, params, stage, z_in, ms, pan, nb.Z[stage + 1], nb.t1[stage], nb.r[stage], nb.s1[stage], nb.pr, B, s))) return rc;
     return op_data_step_bwd(plan, params, grads, stage, nb, (char*)workspace + nb.bytes, z_in, pan, dz_out, dz_in, B, s);
 }
 

@@ -93,6 +93,28 @@ struct DstepTopArgs {
     int C, B, H, W;
 };
 int launch_dstep_top_bwd(const DstepTopArgs& a, hipStream_t s);
+// the data step's backward as one pixelwise launch + one plane-in-LDS launch (k_dstep.hip; planes dstep_fused_ok accepts)
+struct DstepPreBwdArgs {
+    const float *z, *g, *pan;
+    float* dz;
+    const float *rw, *rb, *rtw, *rtb, *eta;
+    float* part;      // [workgroups][C][4]
+    float* part_eta;  // [workgroups][C]
+    int hw4;
+};
+struct DstepBwdArgs {
+    const float* g;      // dZ' [B,C,N,N]
+    const float* z;      // Z_i [B,C,N,N]
+    const float* pan;    // [B,1,N,N]
+    const float *t1, *r, *s1;   // the forward's intermediates
+    float* dz;           // out: dZ_i [B,C,N,N]  (must not alias g)
+    const float *d1w, *d3w, *dt1w, *dt3w, *dt3b, *rw, *rb, *rtw, *rtb, *eta;
+    float *part_top, *part_dt1, *part_d3, *part_d1, *part_pre, *part_pre_eta;   // partial rows (dstep_bwd_part_floats in all, in this order)
+    int B, C, N;
+};
+struct DstepBwdGrads { float *d1w, *d1b, *d3w, *d3b, *dt1w, *dt1b, *dt3w, *dt3b, *rw, *rb, *rtw, *rtb, *eta; };   // (+=)
+size_t dstep_bwd_part_floats(int C, int B, int N);
+int launch_dstep_bwd(const DstepBwdArgs& a, const DstepBwdGrads& g, hipStream_t s);
 // adjoint of the bicubic resampler: gin[planes, hi, wi] (= or +=) R^T gout[planes, ho, wo]; mode 0: x0.5, 1: x2
 int launch_resample_adj(int mode, const float* gout, float* gin, int planes, int hi, int wi, int accumulate, hipStream_t s);
 

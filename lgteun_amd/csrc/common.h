@@ -45,6 +45,9 @@ struct lg_plan {
     bool hidden_bf16(int e) const { return cfg.precision == 1 && e != 64; }
     // precision = 'bf16' (plain bf16 MFMA, bf16 storage of the saved tensors) knows modes 2 and 5 only (3 falls back to 5)
     int attn_bwd_old; // A/B switch (lg_config.variant LG_VAR_ATTN_BWD_R3; Python side: LG_ATTN_BWD=r3): 1 = round 3's k_attn_bwd_core + k_attn_bwd_epi + k_wgrad_t at e = 16 instead of k_attn_bwd_f
+    int dstep_tiles; // A/B switch (lg_config.variant LG_VAR_DSTEP_TILES; Python side: LG_DSTEP=tiles): the tile kernels of the data step also where the one-launch
+                     // plane-in-LDS form (k_dstep.hip) exists
+    bool dstep_fused(int h, int w) const;   // k_dstep.hip: square planes of 128 or 64
     int bwd32_old; // A/B switch (lg_config.variant LG_VAR_FFN_BWD32_XS turns it off; Python side: LG_FFN_BWD32=xs): 1 = k_ffn1_bwd_x32 + k_wgrad_t at e = 32 (default);
                    // 0 = k_ffn1_bwd_xs<32>, the e = 16 kernel's template at 8 waves / one workgroup per CU -- correct, but slower there
     bool ffn1_bwd_x32(int e) const { return e == 32 && ffn_tile == 0 && !bwd32_old; }

@@ -295,6 +295,28 @@ static int data_step_bwd(const lg_plan* pl, const float* P, float* G, int st, co
                          const float* pan, const float* g, float* dz, int B, hipStream_t s) {
     const lg_config& c = pl->cfg;
     const int planes = B * c.C, H = c.H, W = c.W;
+    if (pl->dstep_fused(H, W)) {
+        // one pixelwise + one plane-in-LDS launch (k_dstep.hip) instead of the nine tile launches below
+        DstepBwdArgs a;
+        a.g = g; a.z = zin; a.pan = pan; a.t1 = nb.t1[st]; a.r = nb.r[st]; a.s1 = nb.s1[st]; a.dz = dz;
+        a.d1w = P + pl->shared(S_D1W); a.d3w = P + pl->shared(S_D3W); a.dt1w = P + pl->shared(S_DT1W); a.dt3w = P + pl->shared(S_DT3W);
+        a.dt3b = P + pl->shared(S_DT3B);
+        a.rw = P + pl->shared(S_RW); a.rb = P + pl->shared(S_RB); a.rtw = P + pl->shared(S_RTW); a.rtb = P + pl->shared(S_RTB);
+        a.eta = P + pl->eta(st);
+        a.B = B; a.C = c.C; a.N = H;
+        float* part = bb.rq.take(dstep_bwd_part_floats(c.C, B, H));
+        if (!part) return -3;
+        const size_t row = (size_t)B * c.C * 10;
+        a.part_top = part; a.part_dt1 = part + row; a.part_d3 = part + 2 * row; a.part_d1 = part + 3 * row; a.part_pre = part + 4 * row;
+        a.part_pre_eta = a.part_pre + (size_t)B * (H * H / 4 / 256) * c.C * 4;
+        DstepBwdGrads gg;
+        gg.d1w = G + pl->shared(S_D1W); gg.d1b = G + pl->shared(S_D1B); gg.d3w = G + pl->shared(S_D3W); gg.d3b = G + pl->shared(S_D3B);
+        gg.dt1w = G + pl->shared(S_DT1W); gg.dt1b = G + pl->shared(S_DT1B); gg.dt3w = G + pl->shared(S_DT3W); gg.dt3b = G + pl->shared(S_DT3B);
+        gg.rw = G + pl->shared(S_RW); gg.rb = G + pl->shared(S_RB); gg.rtw = G + pl->shared(S_RTW); gg.rtb = G + pl->shared(S_RTB);
+        gg.eta = G + pl->eta(st);
+        RC(launch_dstep_bwd(a, gg, s));
+        return bb.rq.flush();   // the K stages share these parameters: two stages' jobs must not meet in one reduce launch
+    }
     DstepTopArgs t;
     t.g = g; t.s1 = nb.s1[st]; t.z = zin; t.pan = pan; t.gu = bb.gu3; t.dz = dz;
     t.w9 = P + pl->shared(S_DT3W); t.b9 = P + pl->shared(S_DT3B);

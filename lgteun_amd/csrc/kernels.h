@@ -22,6 +22,19 @@ struct DwArgs {
 // MODE 0: x0.5, 1: x2 ; EPI 0: none, 1: minus sub, 2: data-step update
 int launch_resample_dw(int mode, int epi, const DwArgs& a, hipStream_t s);
 int launch_resample(int mode, const float* x, float* y, int planes, int hi, int wi, hipStream_t s);
+// the whole proximal-gradient step of a stage in ONE launch (k_dstep.hip): planes that fit the LDS of a CU (square, 128 or 64 wide)
+struct DstepFwdArgs {
+    const float* z;      // Z_i [B,C,N,N]
+    const float* ms;     // [B,C,N/4,N/4]
+    const float* pan;    // [B,1,N,N]
+    float* zout;         // [B,C,N,N]
+    float *t1, *r, *s1;  // the chain's intermediates (what the backward reads): [B,C,N/2,N/2], [B,C,N/4,N/4], [B,C,N/2,N/2]
+    float* pr;           // scratch [B,N,N]: R Z - pan of the sample (written by the pixelwise launch in front of the plane kernel)
+    const float *d1w, *d1b, *d3w, *d3b, *dt1w, *dt1b, *dt3w, *dt3b, *rw, *rb, *rtw, *rtb, *eta;
+    int B, C, N;
+};
+bool dstep_fused_ok(int C, int H, int W);
+int launch_dstep_fwd(const DstepFwdArgs& a, hipStream_t s);
 
 // ---------------- LGT pixelwise pieces (reference models/common/LGT.py) ----------------
 struct EmbedArgs {

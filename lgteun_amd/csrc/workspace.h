@@ -29,6 +29,7 @@ struct NetBufs {
     float* Z[LG_MAX_K + 1];                          // Z_0 .. Z_K  [B,C,H,W]: Z[i] -> data step i -> Z[i+1] (= input of LGT i)
     float* X[LG_MAX_K];                              // chained mode: input of data step i (X[0] = Z[0], X[i] = output of LGT i-1)
     float *t1[LG_MAX_K], *r[LG_MAX_K], *s1[LG_MAX_K];  // data-step intermediates per stage
+    float* pr;                                       // [B,H,W] scratch of the one-launch data step (k_dstep.hip): R Z - pan of the stage in flight
     float* posT;                                     // [K][5][2*64*64]
     BlockBufs blk[5];
     float* x0;        // embed output = blk[0].xin
@@ -67,6 +68,7 @@ static inline void carve(const lg_plan* plan, int B, int train, void* base, NetB
         nb.r[i] = cv.take(B * c.C * P1 / 4);
         nb.s1[i] = cv.take(B * c.C * P1);
     }
+    nb.pr = cv.take(B * P0);
     nb.posT = cv.take((size_t)c.K * 5 * 2 * 64 * 64);
     nb.wsplit = cv.take(ffn_wsplit_bytes((int)(2 * E)) / sizeof(float));   // sized for the widest block (level 1: e = 8 C)
     nb.deadout = cv.take(B * c.C * P0);

@@ -45,7 +45,7 @@ class Ops:
     def data_step(self, stage, z, ms, pan):
         B = z.shape[0]
         out = torch.empty_like(z)
-        tmp = torch.empty(3 * z.numel() // 4 + 1024, device=z.device)
+        tmp = torch.empty(3 * z.numel() // 4 + z.numel() // z.shape[1], device=z.device)   # include/lgteun_hip.h: lg_op_data_step
         _lib.check(self.lib.lg_op_data_step(self.plan, _ptr(self.eng.flat), stage, _ptr(z), _ptr(ms), _ptr(pan), _ptr(out),
                                             _ptr(tmp), B, _stream_ptr()), 'lg_op_data_step')
         return out

@@ -46,6 +46,39 @@ def test_resample_and_data_step(gpu, C):
     assert rel_l2(ops.data_step(0, z, x_ms, pan).cpu(), g['data_step']) < 2e-6
 
 
+@pytest.mark.parametrize('C,N,B', [(4, 128, 3), (8, 128, 2), (4, 64, 5), (8, 64, 1)])
+def test_one_launch_data_step_is_bitwise_the_tile_kernels(gpu, C, N, B, monkeypatch):
+    """k_dstep_fwd (round 4: the whole proximal-gradient step of a (sample, channel) plane in one workgroup's LDS, planes of 128 / 64)
+    against the four tile launches it replaces (lg_config.variant LG_VAR_DSTEP_TILES): same arithmetic in the same order -> the update
+    AND the three intermediates the backward reads are bit-for-bit equal; and both against the oracle"""
+    from gpu_helpers import Ops, make_module
+    rng = np.random.default_rng(C * 1000 + N)
+    z = T(rng.uniform(0, 1, (B, C, N, N)).astype(np.float32)).cuda()
+    ms = T(rng.uniform(0, 1, (B, C, N // 4, N // 4)).astype(np.float32)).cuda()
+    pan = T(rng.uniform(0, 1, (B, 1, N, N)).astype(np.float32)).cuda()
+
+    def run():
+        ops = Ops(make_module(C, 2), N, N)
+        out = torch.empty_like(z)
+        tmp = torch.full((3 * z.numel() // 4 + z.numel() // C,), float('nan'), device=z.device)
+        from lgteun_amd import _lib
+        from lgteun_amd.engine import _ptr, _stream_ptr
+        _lib.check(ops.lib.lg_op_data_step(ops.plan, _ptr(ops.eng.flat), 1, _ptr(z), _ptr(ms), _ptr(pan), _ptr(out), _ptr(tmp), B,
+                                           _stream_ptr()), 'lg_op_data_step')
+        q = z.numel() // 4
+        return out, tmp[:q], tmp[q:q + q // 4], tmp[2 * q:3 * q]          # z', t1, r, s1 (api.hip: lg_op_data_step)
+    monkeypatch.delenv('LG_DSTEP', raising=False)
+    new = run()
+    monkeypatch.setenv('LG_DSTEP', 'tiles')
+    old = run()
+    for a, b, name in zip(new, old, ("z'", 't1', 'r', 's1')):
+        assert not torch.isnan(a).any(), name
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    P = det_params(C, 2)
+    want = orc.data_step(P, z.cpu(), ms.cpu(), pan.cpu(), P['eta.1'])
+    assert rel_l2(new[0].cpu(), want) < 2e-6
+
+
 @pytest.mark.parametrize('C', [4, 8])
 def test_block_pieces(gpu, C):
     """global mixer / mixer half-block / ffn half-block of every block kind vs oracle, on the golden features."""

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 T = torch.from_numpy
 
 
-@pytest.mark.parametrize('C,H,W', [(4, 32, 32), (8, 48, 16), (4, 128, 128)])
+@pytest.mark.parametrize('C,H,W', [(4, 32, 32), (8, 48, 16), (4, 128, 128), (8, 128, 128), (4, 64, 64), (8, 64, 64)])
 def test_data_step_backward_vs_oracle(C, H, W):
     from gpu_helpers import Ops, make_module
     K, B, stage = 2, 2, 1
