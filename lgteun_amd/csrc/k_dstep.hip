@@ -19,13 +19,20 @@
 // stores s_memtime at the phase boundaries (branch-free: round 4's lesson on conditional stamp stores)
 #ifdef LG_STAMPS
 __device__ unsigned long long g_ds_stamps[512 * 16 * 32];   // [workgroup][wave][stamp]
+// stamps go to LDS and leave in one burst at the kernel's end: a global store in front of the parameter loads would turn those (uniform,
+// otherwise scalar) loads into vector loads with a full wait each -- the probe would measure its own disturbance
+#define DSTAMP_DECL __shared__ unsigned long long ds_stamp_lds[16 * 32]; int stamp_i = 0; (void)stamp_i; \
+    if (threadIdx.x < 16 * 32) ds_stamp_lds[threadIdx.x] = 0; __syncthreads();
 #define DSTAMP(i) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)); \
-                       g_ds_stamps[((blockIdx.x & 511) * 16 + (threadIdx.x >> 6)) * 32 + (i)] = t__; } while (0)
+                       ds_stamp_lds[(threadIdx.x >> 6) * 32 + (i)] = t__; } while (0)
+#define DSTAMP_FLUSH() do { __syncthreads(); if (threadIdx.x < 16 * 32) g_ds_stamps[(blockIdx.x & 511) * 16 * 32 + threadIdx.x] = ds_stamp_lds[threadIdx.x]; } while (0)
 extern "C" __attribute__((visibility("default"))) int lg_debug_ds_stamps(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ds_stamps), sizeof(g_ds_stamps));
 }
 #else
+#define DSTAMP_DECL int stamp_i = 0; (void)stamp_i;
 #define DSTAMP(i) do { } while (0)
+#define DSTAMP_FLUSH() do { } while (0)
 #endif
 
 namespace {
@@ -179,7 +186,8 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_fwd(DstepFwdArgs a) {
     float* Hq = R1 + L::O4;                           // row-contracted quarter-resolution images
     float* U2 = R1 + L::O5 + PQ + 4;
     float* Rq = R1 + L::O6 + 4;                       // r as resampler source
-    DSTAMP(0);
+    DSTAMP_DECL
+    DSTAMP(stamp_i++);
     const int plane = blockIdx.x, c = plane % C, b = plane / C;
     const int tid = threadIdx.x;
     // the thread's pixels of the full-resolution plane: NV quads
@@ -215,15 +223,15 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_fwd(DstepFwdArgs a) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) put_z(k);
     __syncthreads();
-    DSTAMP(1);
+    DSTAMP(stamp_i++);
     // ---- D, first half: x0.5 -> dw3 = t1
     ds_xhalf<N, N, P0, H + 4>(Zs, R1);
     __syncthreads();
-    DSTAMP(2);
+    DSTAMP(stamp_i++);
     ds_ycon<0, N, H, H + 4, PH>(R1, U1);
     ds_zero_rows<N, P0>(U4);       // Zs is dead
     __syncthreads();
-    DSTAMP(3);
+    DSTAMP(stamp_i++);
     ds_zero_rows<Q, PQ>(U2);       // the first row-contracted image is dead: the quarter-resolution images live in its buffer
     {
         float* __restrict__ t1 = a.t1 + (size_t)plane * H * H;
@@ -238,14 +246,14 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_fwd(DstepFwdArgs a) {
         }
     }
     __syncthreads();
-    DSTAMP(4);
+    DSTAMP(stamp_i++);
     // ---- D, second half: x0.5 -> dw3 - ms = r
     ds_xhalf<H, H, PH, Q + 4>(V1, Hq);
     __syncthreads();
-    DSTAMP(5);
+    DSTAMP(stamp_i++);
     ds_ycon<0, H, Q, Q + 4, PQ>(Hq, U2);
     __syncthreads();
-    DSTAMP(6);
+    DSTAMP(stamp_i++);
     static_assert((Q * Q / 4) % 64 == 0, "whole waves in the quarter-resolution conv");
     if (tid < Q * Q / 4) {
         const int oy = tid / (Q / 4), m = tid % (Q / 4);
@@ -258,14 +266,14 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_fwd(DstepFwdArgs a) {
         reinterpret_cast<float4*>(a.r + (size_t)plane * Q * Q)[tid] = make_float4(o[0], o[1], o[2], o[3]);
     }
     __syncthreads();
-    DSTAMP(7);
+    DSTAMP(stamp_i++);
     // ---- DT, first half: x2 -> dw3 = s1
     ds_xdouble<Q, Q, PQ, H + 4>(Rq, Hq);
     __syncthreads();
-    DSTAMP(8);
+    DSTAMP(stamp_i++);
     ds_ycon<1, Q, H, H + 4, PH>(Hq, U1);
     __syncthreads();
-    DSTAMP(9);
+    DSTAMP(stamp_i++);
     {
         float* __restrict__ s1 = a.s1 + (size_t)plane * H * H;
         for (int i = tid; i < H * H / 4; i += DS_NT) {
@@ -279,14 +287,14 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_fwd(DstepFwdArgs a) {
         }
     }
     __syncthreads();
-    DSTAMP(10);
+    DSTAMP(stamp_i++);
     // ---- DT, second half: x2 -> dw3, then the update   Z <- Z - eta (ms_term + RT(R Z - pan))      unlg_former.py:59-61
     ds_xdouble<H, H, PH, N + 4>(V1, R1);
     __syncthreads();
-    DSTAMP(11);
+    DSTAMP(stamp_i++);
     ds_ycon<1, H, N, N + 4, P0>(R1, U4);
     __syncthreads();
-    DSTAMP(12);
+    DSTAMP(stamp_i++);
     {
         float4* __restrict__ zo = reinterpret_cast<float4*>(a.zout + (size_t)plane * N * N);
 #pragma unroll
@@ -307,7 +315,8 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_fwd(DstepFwdArgs a) {
             if (tid + DS_NT * k < F4) zo[f] = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
-    DSTAMP(13);
+    DSTAMP(stamp_i++);
+    DSTAMP_FLUSH();
 }
 
 // ---- pixelwise launches in front of the plane kernels: the only place where the C planes of a sample meet (R / RT are 1x1 convs C -> 1 -> C).
@@ -428,25 +437,22 @@ __device__ __forceinline__ void ds_win(const float* __restrict__ U, int oy, int 
     }
 }
 // one depthwise-conv stage of the backward on a quad: inU = window of the conv's input, inG = window of the gradient wrt its output.
-//   part[k] += sum_u g_u U(u + tap k) (k < 9), part[9] += sum_u g_u ; gi_u = (dw^T g)_u ; optionally v_u = (dw U)_u (the forward value)
-template <bool WANT_V>
+//   part[k] += sum_u g_u U(u + tap k) (k < 9), part[9] += sum_u g_u ; gi_u = (dw^T g)_u
 __device__ __forceinline__ void ds_dw_bwd_quad(const float (&inU)[3][6], const float (&inG)[3][6], const float (&w)[9], float (&part)[10],
-                                               float (&gi)[4], float (&v)[4]) {
+                                               float (&gi)[4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const float g = inG[1][u + 1];
-        float acc = 0.f, vv = 0.f;
+        float acc = 0.f;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 acc += w[dy * 3 + dx] * inG[2 - dy][u + 2 - dx];
                 part[dy * 3 + dx] += g * inU[dy][u + dx];
-                if (WANT_V) vv += w[dy * 3 + dx] * inU[dy][u + dx];
             }
         part[9] += g;
         gi[u] = acc;
-        v[u] = vv;
     }
 }
 // Adjoints of the resamplers, written against the PADDED input index (F.interpolate clamps its taps: in_p[i] = in[clamp(i)], so the adjoint is
@@ -559,22 +565,24 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_bwd(DstepBwdArgs a) {
     float* RA = sm;
     float* RB = sm + L::RA;
     float* red = RB + L::RB;                          // [4 stages][16 waves][10]
-    DSTAMP(0);
+    DSTAMP_DECL
+    DSTAMP(stamp_i++);
     const int plane = blockIdx.x, c = plane % C;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // every load of the first stages is requested before anything else, in the order of use (the counter of outstanding loads is in-order)
+    const float4 s1q = reinterpret_cast<const float4*>(a.s1 + (size_t)plane * H * H)[min(tid, H * H / 4 - 1)];
+    const float4* __restrict__ gp = reinterpret_cast<const float4*>(a.g + (size_t)plane * N * N);
+    float4 gq[NV];                                    // parked in registers until region B is free (it holds the row-contracted image first)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) gq[k] = gp[tid + DS_NT * k];
+    const float4 rq = reinterpret_cast<const float4*>(a.r + (size_t)plane * Q * Q)[min(tid, Q * Q / 4 - 1)];
+    const float4 t1q = reinterpret_cast<const float4*>(a.t1 + (size_t)plane * H * H)[min(tid, H * H / 4 - 1)];
+    DSTAMP(stamp_i++);
     const float eta = a.eta[0];
     float wD1[9], wD3[9], wT1[9], wT3[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) { wD1[k] = a.d1w[c * 9 + k]; wD3[k] = a.d3w[c * 9 + k]; wT1[k] = a.dt1w[c * 9 + k]; wT3[k] = a.dt3w[c * 9 + k]; }
     const float bT3 = a.dt3b[c];
-    // loads of the first stages: every one requested before the first is used
-    const float4* __restrict__ gp = reinterpret_cast<const float4*>(a.g + (size_t)plane * N * N);
-    float4 gq[NV];                                    // parked in registers until region B is free (it holds the row-contracted image first)
-#pragma unroll
-    for (int k = 0; k < NV; ++k) gq[k] = gp[tid + DS_NT * k];
-    const float4 s1q = reinterpret_cast<const float4*>(a.s1 + (size_t)plane * H * H)[min(tid, H * H / 4 - 1)];
-    const float4 rq = reinterpret_cast<const float4*>(a.r + (size_t)plane * Q * Q)[min(tid, Q * Q / 4 - 1)];
-    const float4 t1q = reinterpret_cast<const float4*>(a.t1 + (size_t)plane * H * H)[min(tid, H * H / 4 - 1)];
     auto put4 = [](float4 v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; };
     // the partial sums of a stage: wave totals into red[stage][wave][k]; summed over the waves (fixed order) by sum_stage after a barrier
     auto wave_part = [&](int stage, const float (&part)[10]) {
@@ -594,16 +602,17 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_bwd(DstepBwdArgs a) {
     // ---- U4 = x2(s1) with its zero rows (region A), g (region B)
     float* Vs = RA + 4;
     if (tid < H * H / 4) { float o[4]; put4(s1q, o); ds_put_src<H, 2>(Vs + (tid / NQH) * PH, tid % NQH, o); }
+    DSTAMP(stamp_i++);
     __syncthreads();
-    DSTAMP(1);
+    DSTAMP(stamp_i++);
     ds_xdouble<H, H, PH, N + 4>(Vs, RB);
     __syncthreads();
-    DSTAMP(2);
+    DSTAMP(stamp_i++);
     float* U4 = RA + P0 + 4;
     ds_ycon<1, H, N, N + 4, P0>(RB, U4);
     ds_zero_rows<N, P0>(U4);
     __syncthreads();
-    DSTAMP(3);
+    DSTAMP(stamp_i++);
     float* Gs = RB + P0 + 4;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -612,41 +621,29 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_bwd(DstepBwdArgs a) {
     }
     ds_zero_rows<N, P0>(Gs);
     __syncthreads();
-    DSTAMP(4);
+    DSTAMP(stamp_i++);
     // ---- top: through the DT.3 conv (its weight gradient, the chain's part of d eta) and the x2 adjoint along x.  The row-contracted
     // gradient T [N][H + 4] of iteration k is written over the U4 rows iteration k has finished with (all threads walk the plane in row order)
     {
         float part[10];
 #pragma unroll
         for (int k = 0; k < 10; ++k) part[k] = 0.f;
-        float deta = 0.f;
         float* T = RA;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int f = tid + DS_NT * k, y = f / NQ0, m = f % NQ0;
-            float inU[3][6], inG[3][6], gi[4], v[4], o[2];
+            float inU[3][6], inG[3][6], gi[4], o[2];
             ds_win<P0, NQ0>(U4, y, m, inU);
             ds_win<P0, NQ0>(Gs, y, m, inG);
-            ds_dw_bwd_quad<true>(inU, inG, wT3, part, gi, v);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) deta += -inG[1][u + 1] * (v[u] + bT3);
+            ds_dw_bwd_quad(inU, inG, wT3, part, gi);
             ds_adj2_x<NQ0>(gi, m, o);
             __syncthreads();
             *reinterpret_cast<float2*>(T + y * (H + 4) + 2 * m) = make_float2(o[0], o[1]);
         }
-        part[9] = deta;                                   // slot 9 of the top stage = d eta (sum g is the pixelwise kernel's)
         wave_part(0, part);
     }
     __syncthreads();
-    DSTAMP(5);
-    if (tid == 9) {                                       // d eta: the pixelwise kernel's part of this (sample, channel), in workgroup order
-        constexpr int NWG = N * N / 4 / 256;
-        const float* __restrict__ pe = a.part_pre_eta + (size_t)(plane / C) * NWG * C + c;
-        float t = 0.f;
-        for (int j = 0; j < NWG; ++j) t += pe[j * C];
-        red[9] += t;                                      // wave 0's slot 9 of stage 0: summed with the others just below
-    }
-    sum_stage(0, 16, -eta, a.part_top);                   // the conv saw the raw g: its weight-gradient slots carry the -eta of gm = -eta g
+    DSTAMP(stamp_i++);
     // ---- gs1 = -eta adj_x2(...) (64 x 64, conv source G1 in region B), and U3 = x2(r)
     float* G1 = RB + L::B_G1 + PH + 4;
     float* Vr = RB + L::B_VR + 4;
@@ -660,14 +657,14 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_bwd(DstepBwdArgs a) {
     ds_zero_rows<H, PH>(G1);
     if (tid < Q * Q / 4) { float o[4]; put4(rq, o); ds_put_src<Q, 2>(Vr + (tid / NQQ) * PQ, tid % NQQ, o); }
     __syncthreads();
-    DSTAMP(6);
+    DSTAMP(stamp_i++);
     ds_xdouble<Q, Q, PQ, H + 4>(Vr, Hx3);
     __syncthreads();
-    DSTAMP(7);
+    DSTAMP(stamp_i++);
     ds_ycon<1, Q, H, H + 4, PH>(Hx3, U3);
     ds_zero_rows<H, PH>(U3);
     __syncthreads();
-    DSTAMP(8);
+    DSTAMP(stamp_i++);
     // ---- DT.1 conv stage (64 x 64), x2 adjoint along x -> T3 [H][Q + 4] (region A); t1 as x0.5 source into region A
     float* T3 = RA + L::A_T3;
     float* G2 = RA + L::A_G2 + PQ + 4;
@@ -684,10 +681,10 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_bwd(DstepBwdArgs a) {
         float part[10];
 #pragma unroll
         for (int k = 0; k < 10; ++k) part[k] = 0.f;
-        float inU[3][6], inG[3][6], gi[4], v[4], o[2];
+        float inU[3][6], inG[3][6], gi[4], o[2];
         ds_win<PH, NQH>(U3, i, m, inU);
         ds_win<PH, NQH>(G1, i, m, inG);
-        ds_dw_bwd_quad<false>(inU, inG, wT1, part, gi, v);
+        ds_dw_bwd_quad(inU, inG, wT1, part, gi);
         ds_adj2_x<NQH>(gi, m, o);
         *reinterpret_cast<float2*>(T3 + i * (Q + 4) + 2 * m) = make_float2(o[0], o[1]);
         wave_part(1, part);
@@ -696,7 +693,7 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_bwd(DstepBwdArgs a) {
         ds_put_src<H, 0>(Vt + i * PH, m, t);
     }
     __syncthreads();
-    DSTAMP(9);
+    DSTAMP(stamp_i++);
     sum_stage(1, H * H / 4 / 64, 1.0f, a.part_dt1);
     // ---- gr = adj_x2 along y (32 x 32, conv source G2); U2 = x0.5(t1)
     if (tid < Q * Q / 4) {
@@ -706,11 +703,11 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_bwd(DstepBwdArgs a) {
     ds_zero_rows<Q, PQ>(G2);
     ds_xhalf<H, H, PH, Q + 4>(Vt, Hx2);
     __syncthreads();
-    DSTAMP(10);
+    DSTAMP(stamp_i++);
     ds_ycon<0, H, Q, Q + 4, PQ>(Hx2, U2);
     ds_zero_rows<Q, PQ>(U2);
     __syncthreads();
-    DSTAMP(11);
+    DSTAMP(stamp_i++);
     // ---- D.3 conv stage (32 x 32), x0.5 adjoint along x -> T2 [Q][H + 4] (region B)
     float* T2 = RB + L::B_T2;
     float* G3 = RB + L::B_G3 + PH + 4;
@@ -720,10 +717,10 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_bwd(DstepBwdArgs a) {
         float part[10];
 #pragma unroll
         for (int k = 0; k < 10; ++k) part[k] = 0.f;
-        float inU[3][6], inG[3][6], gi[4], v[4], o[8];
+        float inU[3][6], inG[3][6], gi[4], o[8];
         ds_win<PQ, NQQ>(U2, i, m, inU);
         ds_win<PQ, NQQ>(G2, i, m, inG);
-        ds_dw_bwd_quad<false>(inU, inG, wD3, part, gi, v);
+        ds_dw_bwd_quad(inU, inG, wD3, part, gi);
         ds_adjh_x<NQQ>(gi, m, o);
         *reinterpret_cast<float4*>(T2 + i * (H + 4) + 8 * m) = make_float4(o[0], o[1], o[2], o[3]);
         *reinterpret_cast<float4*>(T2 + i * (H + 4) + 8 * m + 4) = make_float4(o[4], o[5], o[6], o[7]);
@@ -732,7 +729,7 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_bwd(DstepBwdArgs a) {
     // region A is free: Z as the x0.5 source of the last conv input
     float* Zs = RA + 4;
     __syncthreads();
-    DSTAMP(12);
+    DSTAMP(stamp_i++);
     sum_stage(2, Q * Q / 4 / 64, 1.0f, a.part_d3);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -748,10 +745,10 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_bwd(DstepBwdArgs a) {
     }
     ds_zero_rows<H, PH>(G3);
     __syncthreads();
-    DSTAMP(13);
+    DSTAMP(stamp_i++);
     ds_xhalf<N, N, P0, H + 4>(Zs, Hx1);
     __syncthreads();
-    DSTAMP(14);
+    DSTAMP(stamp_i++);
     float* U1 = RA + L::A_U1 + PH + 4;
     float* T1 = RA + L::A_T1;
     ds_ycon<0, N, H, H + 4, PH>(Hx1, U1);
@@ -762,24 +759,24 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_bwd(DstepBwdArgs a) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) dq[k] = dzp[tid + DS_NT * k];
     __syncthreads();
-    DSTAMP(15);
+    DSTAMP(stamp_i++);
     // ---- D.1 conv stage (64 x 64), x0.5 adjoint along x -> T1 [H][N + 4] (region A)
     if (tid < H * H / 4) {
         const int i = tid / NQH, m = tid % NQH;
         float part[10];
 #pragma unroll
         for (int k = 0; k < 10; ++k) part[k] = 0.f;
-        float inU[3][6], inG[3][6], gi[4], v[4], o[8];
+        float inU[3][6], inG[3][6], gi[4], o[8];
         ds_win<PH, NQH>(U1, i, m, inU);
         ds_win<PH, NQH>(G3, i, m, inG);
-        ds_dw_bwd_quad<false>(inU, inG, wD1, part, gi, v);
+        ds_dw_bwd_quad(inU, inG, wD1, part, gi);
         ds_adjh_x<NQH>(gi, m, o);
         *reinterpret_cast<float4*>(T1 + i * (N + 4) + 8 * m) = make_float4(o[0], o[1], o[2], o[3]);
         *reinterpret_cast<float4*>(T1 + i * (N + 4) + 8 * m + 4) = make_float4(o[4], o[5], o[6], o[7]);
         wave_part(3, part);
     }
     __syncthreads();
-    DSTAMP(16);
+    DSTAMP(stamp_i++);
     sum_stage(3, H * H / 4 / 64, 1.0f, a.part_d1);
     // ---- dZ = direct part + adj_x0.5 along y
 #pragma unroll
@@ -788,7 +785,33 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_bwd(DstepBwdArgs a) {
         const float4 t = ds_adjh_y<N, N + 4>(T1, f / NQ0, f % NQ0);
         dzp[f] = make_float4(dq[k].x + t.x, dq[k].y + t.y, dq[k].z + t.z, dq[k].w + t.w);
     }
-    DSTAMP(17);
+    // ---- the top stage's row, last: its sums have been waiting in `red` since the top loop, and the one thread that combines d eta (160
+    // LDS reads, the pixelwise kernel's rows) would hold every barrier behind it up (9 000 cycles where it stood).
+    // slot 9 of the top stage = d eta = sum -g (DT.3(up(s1)) + pt): the chain's part needs no pass of its own,
+    //   sum_pix g (w . U-window + b) = sum_k w[k] (sum_pix g U(+tap k)) + b sum_pix g = w . (the conv's raw weight-gradient sums) + b (slot 9),
+    // and the pixelwise kernel's part (pt) of this (sample, channel) is picked up from its workgroups' rows, in workgroup order
+    if (tid < 9) {
+        float t = 0.f;
+        for (int wv = 0; wv < 16; ++wv) t += red[wv * 10 + tid];
+        a.part_top[(size_t)plane * 10 + tid] = -eta * t;   // the conv saw the raw g: its weight-gradient slots carry the -eta of gm = -eta g
+    } else if (tid == 9) {
+        float ch = 0.f;
+        for (int k = 0; k < 10; ++k) {
+            float t = 0.f;
+            for (int wv = 0; wv < 16; ++wv) t += red[wv * 10 + k];
+            ch += (k < 9 ? a.dt3w[c * 9 + k] : bT3) * t;
+        }
+        constexpr int NWG = N * N / 4 / 256;
+        const float* __restrict__ pe = a.part_pre_eta + (size_t)(plane / C) * NWG * C + c;
+        float pv[NWG], t = 0.f;
+#pragma unroll
+        for (int j = 0; j < NWG; ++j) pv[j] = pe[j * C];
+#pragma unroll
+        for (int j = 0; j < NWG; ++j) t += pv[j];
+        a.part_top[(size_t)plane * 10 + 9] = t - ch;
+    }
+    DSTAMP(stamp_i++);
+    DSTAMP_FLUSH();
 }
 
 template <int N, int C>

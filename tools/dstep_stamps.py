@@ -30,7 +30,7 @@ f = ops.lib.lg_debug_ds_stamps
 f.restype = ctypes.c_int
 assert f(buf) == 0
 st = np.frombuffer(buf, dtype=np.uint64).reshape(512, NW, NS).astype(np.int64)[:B * C]
-last = int(np.max(np.nonzero(st[0, 0])[0]))
+last = int(np.max(np.nonzero(st[0, 0])[0]))  # LDS stamp slots are zeroed at kernel start
 print(f'{B * C} workgroups, {last} phases; s_memtime ticks (shader cycles, ~2.3 GHz) per phase: mean over workgroups of (slowest wave end - slowest wave start)')
 t0 = st[:, :, 0].min()
 for i in range(1, last + 1):
