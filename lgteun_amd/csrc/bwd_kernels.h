@@ -98,8 +98,7 @@ struct DstepPreBwdArgs {
     const float *z, *g, *pan;
     float* dz;
     const float *rw, *rb, *rtw, *rtb, *eta;
-    float* part;      // [workgroups][C][4]
-    float* part_eta;  // [workgroups][C]
+    float* part;   // [workgroups][C][5]
     int hw4;
 };
 struct DstepBwdArgs {
@@ -109,7 +108,7 @@ struct DstepBwdArgs {
     const float *t1, *r, *s1;   // the forward's intermediates
     float* dz;           // out: dZ_i [B,C,N,N]  (must not alias g)
     const float *d1w, *d3w, *dt1w, *dt3w, *dt3b, *rw, *rb, *rtw, *rtb, *eta;
-    float *part_top, *part_dt1, *part_d3, *part_d1, *part_pre, *part_pre_eta;   // partial rows (dstep_bwd_part_floats in all, in this order)
+    float *part_top, *part_dt1, *part_d3, *part_d1, *part_pre;   // partial rows: [B*C][14], 3 x [B*C][10], [workgroups of the pixelwise kernel][C][5]
     int B, C, N;
 };
 struct DstepBwdGrads { float *d1w, *d1b, *d3w, *d3b, *dt1w, *dt1b, *dt3w, *dt3b, *rw, *rb, *rtw, *rtb, *eta; };   // (+=)

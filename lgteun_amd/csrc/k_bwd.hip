@@ -306,9 +306,8 @@ static int data_step_bwd(const lg_plan* pl, const float* P, float* G, int st, co
         a.B = B; a.C = c.C; a.N = H;
         float* part = bb.rq.take(dstep_bwd_part_floats(c.C, B, H));
         if (!part) return -3;
-        const size_t row = (size_t)B * c.C * 10;
-        a.part_top = part; a.part_dt1 = part + row; a.part_d3 = part + 2 * row; a.part_d1 = part + 3 * row; a.part_pre = part + 4 * row;
-        a.part_pre_eta = a.part_pre + (size_t)B * (H * H / 4 / 256) * c.C * 4;
+        const size_t bc = (size_t)B * c.C;
+        a.part_top = part; a.part_dt1 = part + 14 * bc; a.part_d3 = part + 24 * bc; a.part_d1 = part + 34 * bc; a.part_pre = part + 44 * bc;
         DstepBwdGrads gg;
         gg.d1w = G + pl->shared(S_D1W); gg.d1b = G + pl->shared(S_D1B); gg.d3w = G + pl->shared(S_D3W); gg.d3b = G + pl->shared(S_D3B);
         gg.dt1w = G + pl->shared(S_DT1W); gg.dt1b = G + pl->shared(S_DT1B); gg.dt3w = G + pl->shared(S_DT3W); gg.dt3b = G + pl->shared(S_DT3B);

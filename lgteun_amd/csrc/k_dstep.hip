@@ -361,8 +361,9 @@ __device__ __forceinline__ float ds_wave_sum63(float v) {
 // Backward, pixelwise part: everything of the step's top that needs no neighbour (autograd of unlg_former.py:59-61 around the DT chain):
 //   dpr = -eta sum_c RTw[c] g_c ;  dZ_c (direct part) = g_c + Rw[c] dpr  -> dz (the plane kernel adds the chain's part on top)
 //   per channel: sum gm (d bias(DT.3), d RT.bias), sum -g (RTw[c] pr + RTb[c]) (d eta, the part without the chain), sum gm pr (d RT.weight),
-//   sum dpr z_c (d R.weight), sum dpr (d R.bias; channel 0's row), with gm = -eta g, pr = R Z - pan.  One partial row [C][4] per workgroup
-// (+ its d eta part per channel, which the plane kernel picks up).
+//   sum dpr z_c (d R.weight), sum dpr (d R.bias; channel 0's row), with gm = -eta g, pr = R Z - pan.  One partial row [C][5] per workgroup;
+// the plane kernel of (sample, channel) folds the sample's rows into its own (no reduce job of 512 x C slices; and two jobs adding into
+// d eta would race inside the deferred reduce launch).
 template <int C>
 __global__ __launch_bounds__(256) void k_dstep_pre_bwd(DstepPreBwdArgs a) {
     __shared__ float red[4][C * 5];   // per channel: [sum gm | d eta part | d RT.weight | d R.weight | d R.bias]
@@ -415,12 +416,8 @@ __global__ __launch_bounds__(256) void k_dstep_pre_bwd(DstepPreBwdArgs a) {
     }
     __syncthreads();
     if (threadIdx.x < C * 5) {
-        const int t = threadIdx.x, cc = t / 5, k = t - cc * 5;
-        const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-        // d eta has a second part in the plane kernel: that kernel adds this workgroup's value to its own row (two reduce jobs into one
-        // destination would race inside the deferred reduce launch)
-        if (k == 1) a.part_eta[(size_t)blockIdx.x * C + cc] = v;
-        else a.part[((size_t)blockIdx.x * C + cc) * 4 + (k > 1 ? k - 1 : 0)] = v;
+        const int t = threadIdx.x;
+        a.part[(size_t)blockIdx.x * C * 5 + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
     }
 }
 
@@ -785,30 +782,38 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_bwd(DstepBwdArgs a) {
         const float4 t = ds_adjh_y<N, N + 4>(T1, f / NQ0, f % NQ0);
         dzp[f] = make_float4(dq[k].x + t.x, dq[k].y + t.y, dq[k].z + t.z, dq[k].w + t.w);
     }
-    // ---- the top stage's row, last: its sums have been waiting in `red` since the top loop, and the one thread that combines d eta (160
-    // LDS reads, the pixelwise kernel's rows) would hold every barrier behind it up (9 000 cycles where it stood).
-    // slot 9 of the top stage = d eta = sum -g (DT.3(up(s1)) + pt): the chain's part needs no pass of its own,
-    //   sum_pix g (w . U-window + b) = sum_k w[k] (sum_pix g U(+tap k)) + b sum_pix g = w . (the conv's raw weight-gradient sums) + b (slot 9),
-    // and the pixelwise kernel's part (pt) of this (sample, channel) is picked up from its workgroups' rows, in workgroup order
-    if (tid < 9) {
-        float t = 0.f;
-        for (int wv = 0; wv < 16; ++wv) t += red[wv * 10 + tid];
-        a.part_top[(size_t)plane * 10 + tid] = -eta * t;   // the conv saw the raw g: its weight-gradient slots carry the -eta of gm = -eta g
-    } else if (tid == 9) {
-        float ch = 0.f;
-        for (int k = 0; k < 10; ++k) {
-            float t = 0.f;
-            for (int wv = 0; wv < 16; ++wv) t += red[wv * 10 + k];
-            ch += (k < 9 ? a.dt3w[c * 9 + k] : bT3) * t;
-        }
+    // ---- the top stage's row, last: its sums have been waiting in `red` since the top loop, and the few threads that combine them with the
+    // pixelwise kernel's rows would hold every barrier behind them up (9 000 cycles where this stood).  Row = [d DT.3 weight (9) | d eta |
+    // sum gm (d DT.3 bias, d RT.bias) | d RT.weight | d R.weight | d R.bias]:
+    //   d eta = sum -g (DT.3(up(s1)) + pt); the chain's part needs no pass of its own,
+    //   sum_pix g (w . U-window + b) = sum_k w[k] (sum_pix g U(+tap k)) + b sum_pix g = w . (the conv's raw weight-gradient sums) + b (slot 9)
+    if (tid < 14) {
         constexpr int NWG = N * N / 4 / 256;
-        const float* __restrict__ pe = a.part_pre_eta + (size_t)(plane / C) * NWG * C + c;
-        float pv[NWG], t = 0.f;
+        float v;
+        if (tid < 9) {
+            float t = 0.f;
+            for (int wv = 0; wv < 16; ++wv) t += red[wv * 10 + tid];
+            v = -eta * t;                                  // the conv saw the raw g: its weight-gradient slots carry the -eta of gm = -eta g
+        } else {
+            const int slot = tid == 9 ? 1 : (tid == 10 ? 0 : tid - 9);   // row of the pixelwise kernel: [sum gm | d eta | d RTw | d Rw | d Rb]
+            const float* __restrict__ pe = a.part_pre + ((size_t)(plane / C) * NWG * C + c) * 5 + slot;
+            float pv[NWG];
 #pragma unroll
-        for (int j = 0; j < NWG; ++j) pv[j] = pe[j * C];
+            for (int j = 0; j < NWG; ++j) pv[j] = pe[j * C * 5];
+            v = 0.f;
 #pragma unroll
-        for (int j = 0; j < NWG; ++j) t += pv[j];
-        a.part_top[(size_t)plane * 10 + 9] = t - ch;
+            for (int j = 0; j < NWG; ++j) v += pv[j];
+            if (tid == 9) {
+                float ch = 0.f;
+                for (int k = 0; k < 10; ++k) {
+                    float t = 0.f;
+                    for (int wv = 0; wv < 16; ++wv) t += red[wv * 10 + k];
+                    ch += (k < 9 ? a.dt3w[c * 9 + k] : bT3) * t;
+                }
+                v -= ch;
+            }
+        }
+        a.part_top[(size_t)plane * 14 + tid] = v;
     }
     DSTAMP(stamp_i++);
     DSTAMP_FLUSH();
@@ -843,7 +848,7 @@ int launch_bwd_t(const DstepBwdArgs& a, hipStream_t s) {
     }
     DstepPreBwdArgs p;
     p.z = a.z; p.g = a.g; p.pan = a.pan; p.dz = a.dz; p.rw = a.rw; p.rb = a.rb; p.rtw = a.rtw; p.rtb = a.rtb; p.eta = a.eta;
-    p.part = a.part_pre; p.part_eta = a.part_pre_eta; p.hw4 = N * N / 4;
+    p.part = a.part_pre; p.hw4 = N * N / 4;
     static_assert((N * N / 4) % 256 == 0, "whole workgroups per sample");
     k_dstep_pre_bwd<C><<<a.B * (N * N / 4 / 256), 256, 0, s>>>(p);
     LG_CHECK_LAUNCH();
@@ -863,31 +868,27 @@ int launch_dstep_fwd(const DstepFwdArgs& a, hipStream_t s) {
     return a.C == 4 ? launch_fwd_t<64, 4>(a, s) : launch_fwd_t<64, 8>(a, s);
 }
 
-size_t dstep_bwd_part_floats(int C, int B, int N) { return (size_t)B * C * 10 * 4 + (size_t)B * (N * N / 4 / 256) * C * 5; }   // four stages' rows | pixelwise [wg][C][4] | its d eta [wg][C]
+size_t dstep_bwd_part_floats(int C, int B, int N) { return (size_t)B * C * (14 + 3 * 10) + (size_t)B * (N * N / 4 / 256) * C * 5; }   // the four stages' rows | the pixelwise kernel's [wg][C][5]
 
 // the launch pair + the five reductions of its partial rows (deferred when a reduce queue is active)
 int launch_dstep_bwd(const DstepBwdArgs& a, const DstepBwdGrads& g, hipStream_t s) {
     if (!dstep_fused_ok(a.C, a.N, a.N)) { lg_set_error("dstep_bwd: C=%d N=%d has no one-launch instance", a.C, a.N); return -2; }
     if (a.g == a.dz) { lg_set_error("dstep_bwd: the incoming gradient and dz must be different buffers"); return -2; }
-    if (!a.part_pre || !a.part_pre_eta || !a.part_top || !a.part_dt1 || !a.part_d3 || !a.part_d1) { lg_set_error("dstep_bwd: partial-sum scratch missing"); return -2; }
+    if (!a.part_pre || !a.part_top || !a.part_dt1 || !a.part_d3 || !a.part_d1) { lg_set_error("dstep_bwd: partial-sum scratch missing"); return -2; }
     int rc;
     if (a.N == 128) rc = a.C == 4 ? launch_bwd_t<128, 4>(a, s) : launch_bwd_t<128, 8>(a, s);
     else rc = a.C == 4 ? launch_bwd_t<64, 4>(a, s) : launch_bwd_t<64, 8>(a, s);
     if (rc) return rc;
     ChanReduce m;
-    // pixelwise kernel: [sum gm | d RT.weight | d R.weight | d R.bias]
-    memset(&m, 0, sizeof(m));
-    m.dst[0] = g.dt3b; m.dst2[0] = g.rtb; m.stride[0] = 1;
-    m.dst[1] = g.rtw; m.stride[1] = 1;
-    m.dst[2] = g.rw; m.stride[2] = 1;
-    m.dst[3] = g.rb; m.stride[3] = 0;
-    m.NK = 4; m.C = a.C; m.nslices = a.B * (a.N * a.N / 4 / 256); m.allc_mask = 1u << 3;
-    if ((rc = launch_reduce_chan(a.part_pre, m, s))) return rc;
-    // plane kernel, top stage: [d DT.3 weight (9) | d eta (the chain's part)]
+    // top stage (the pixelwise kernel's sums folded in): the slots of k_dstep_top_bwd
     memset(&m, 0, sizeof(m));
     for (int k = 0; k < 9; ++k) { m.dst[k] = g.dt3w + k; m.stride[k] = 9; }
-    m.dst[9] = g.eta; m.stride[9] = 0;
-    m.NK = 10; m.C = a.C; m.nslices = a.B; m.allc_mask = 1u << 9;
+    m.dst[9] = g.eta; m.stride[9] = 0;                          // summed over channels
+    m.dst[10] = g.dt3b; m.dst2[10] = g.rtb; m.stride[10] = 1;   // d bias(DT.3) and d RT.bias
+    m.dst[11] = g.rtw; m.stride[11] = 1;
+    m.dst[12] = g.rw; m.stride[12] = 1;
+    m.dst[13] = g.rb; m.stride[13] = 0;                         // summed over channels
+    m.NK = 14; m.C = a.C; m.nslices = a.B; m.allc_mask = (1u << 9) | (1u << 13);
     if ((rc = launch_reduce_chan(a.part_top, m, s))) return rc;
     const float* parts[3] = {a.part_dt1, a.part_d3, a.part_d1};
     float* dw[3] = {g.dt1w, g.d3w, g.d1w};

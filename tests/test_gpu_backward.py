@@ -391,6 +391,35 @@ def test_fused_attention_backward_agrees_with_the_round3_path(drop, monkeypatch)
         assert float((a - b).norm()) <= tol * float(a.norm()) + 1e-10, (drop, eng.names[i], float((a - b).norm()), float(a.norm()))
 
 
+@pytest.mark.parametrize('C', [4, 8])
+def test_one_launch_data_step_agrees_with_the_tile_kernels_on_a_train_step(C, monkeypatch):
+    """k_dstep.hip (round 4: the data step of a 128 x 128 plane as one pixelwise + one plane-in-LDS launch per direction) against the four + nine
+    tile launches it replaces (LG_DSTEP=tiles), whole train step, K = 3 so that the shared D / DT / R / RT gradients are sums over stages:
+    the output bitwise (the forward is the same arithmetic in the same order), every live gradient tensor to rounding"""
+    from gpu_helpers import make_module
+    from lgteun_amd.engine import LG_FLAG_SAVE, LG_FLAG_FAITHFUL
+    ms, pan, gt = (T(a).cuda() for a in dw.make_inputs(2, C, 32, 32, seed=21, kind='smooth'))
+    flags = LG_FLAG_SAVE | LG_FLAG_FAITHFUL
+
+    def run():
+        eng = make_module(C, 3).engine()
+        y, saved = eng.forward_raw(ms, pan, flags, seed=1)
+        r = torch.randn(y.shape, generator=torch.Generator(device='cpu').manual_seed(8)).cuda()
+        g = torch.zeros_like(eng.flat)
+        eng.backward_raw(saved, r, g, flags, seed=1)
+        return y.clone(), g, eng
+    monkeypatch.delenv('LG_DSTEP', raising=False)
+    y1, g1, eng = run()
+    monkeypatch.setenv('LG_DSTEP', 'tiles')                        # read once per plan: a fresh module builds a fresh plan
+    y0, g0, _ = run()
+    assert torch.equal(y0, y1)
+    assert float(g0.abs().max()) > 0
+    for i in eng.live_idx:
+        o, n = eng.offsets[i], eng.params[i].numel()
+        a, b = g0[o:o + n].double(), g1[o:o + n].double()
+        assert float((a - b).norm()) <= 2e-5 * float(a.norm()) + 1e-10, (eng.names[i], float((a - b).norm()), float(a.norm()))
+
+
 @pytest.mark.parametrize('B,h,w', [(1, 16, 16), (1, 16, 32), (3, 16, 48), (5, 32, 32), (5, 128, 128)])
 def test_mixer_backward_kernel_at_awkward_shapes(B, h, w):
     """the fused local-mixer backward in isolation against the fp64 oracle at sizes that exercise its edges: one window group (a single workgroup), two,
