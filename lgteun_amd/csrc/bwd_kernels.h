@@ -334,7 +334,9 @@ struct ProjO2BwdKArgs {
     long total;
     uint64_t seed;
 };
-#define PROJ_O2_K_WGS 1024
+#ifndef PROJ_O2_K_WGS
+#define PROJ_O2_K_WGS 512   // 1 024 workgroups: the same kernel time, but the bias-gradient reduce job behind it walks twice the slices (step 6.31 -> 6.285 ms)
+#endif
 int launch_proj_o2_bwd_k(int e, const ProjO2BwdKArgs& a, hipStream_t s);
 struct AttnBwdFArgs {
     const float* x;        // [P,e] block input

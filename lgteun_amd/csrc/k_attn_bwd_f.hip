@@ -620,14 +620,29 @@ __global__ __launch_bounds__(256) void k_proj_o2_bwd_k(ProjO2BwdKArgs a) {
     float db[E];
 #pragma unroll
     for (int n = 0; n < E; ++n) db[n] = 0.f;
-    for (long p = blockIdx.x * 256L + threadIdx.x; p < a.total; p += (long)gridDim.x * 256L) {
+    // the next pixel's row is requested before this one is worked on (a grid-stride loop of load -> hash -> matvec -> store trips is one
+    // exposed round trip per trip)
+    const long stride = (long)gridDim.x * 256L;
+    long p = blockIdx.x * 256L + threadIdx.x;
+    float4 nx[E / 4];
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.dy + (p < a.total ? p : 0) * E);
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k) nx[k] = src[k];
+    }
+    for (; p < a.total; p += stride) {
         const long b = p / a.HW, s = p - b * a.HW;
         float dy[E];
-        const float4* src = reinterpret_cast<const float4*>(a.dy + p * E);
 #pragma unroll
-        for (int k = 0; k < E / 4; ++k) {
-            const float4 v = src[k];
-            dy[4 * k] = v.x; dy[4 * k + 1] = v.y; dy[4 * k + 2] = v.z; dy[4 * k + 3] = v.w;
+        for (int k = 0; k < E / 4; ++k) { dy[4 * k] = nx[k].x; dy[4 * k + 1] = nx[k].y; dy[4 * k + 2] = nx[k].z; dy[4 * k + 3] = nx[k].w; }
+#ifndef LG_O2_PREF
+#define LG_O2_PREF 1
+#endif
+        if (LG_O2_PREF) {
+            const long pn = p + stride < a.total ? p + stride : p;
+            const float4* src = reinterpret_cast<const float4*>(a.dy + pn * E);
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) nx[k] = src[k];
         }
         if (a.keep) {
             uint32_t kw = 0;
@@ -647,6 +662,11 @@ __global__ __launch_bounds__(256) void k_proj_o2_bwd_k(ProjO2BwdKArgs a) {
 #pragma unroll
             for (int n = 0; n < E; ++n) acc += sProj[n * HC + c] * dy[n];
             a.do2[(b * HC + c) * a.HW + s] = acc;
+        }
+        if (!LG_O2_PREF && p + stride < a.total) {
+            const float4* src = reinterpret_cast<const float4*>(a.dy + (p + stride) * E);
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) nx[k] = src[k];
         }
     }
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;

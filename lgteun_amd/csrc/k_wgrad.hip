@@ -259,6 +259,11 @@ int ReduceQueue::flush() {
         if (n > nmax) nmax = n;
     }
     dim3 grid((unsigned)((nmax + 15) / 16), (unsigned)tab.n);
+#ifdef LG_RQ_DEBUG
+    fprintf(stderr, "[rq] flush: %d jobs, grid.x %u:", tab.n, grid.x);
+    for (int k = 0; k < tab.n; ++k) fprintf(stderr, " (%ld sl x %d x %d)", tab.j[k].nslices, tab.j[k].rows, tab.j[k].cols);
+    fprintf(stderr, "\n");
+#endif
     k_reduce_jobs<<<grid, 256, 0, stream>>>(tab);
     tab.n = 0;
     LG_CHECK_LAUNCH();
