@@ -162,6 +162,36 @@ __device__ __forceinline__ void gelu2_both_f(lg_v2f x, lg_v2f& a, lg_v2f& g) {
     const lg_v2f cs = (lg_v2f){copysignf(sv.x, x.x), copysignf(sv.y, x.y)};
     g = x * (ex * 0.39894228040143267794f) + (cs + 0.5f);
 }
+// precision = 'bf16' (the NP = 1 instances of the FFN kernels): GELU in its tanh form, x * sigmoid(2 sqrt(2/pi) (x + 0.044715 x^3)) -- the
+// nn.GELU(approximate='tanh') function.  Max deviation from the erf form 4.7e-4 (gelu) / 8.7e-4 (gelu'), i.e. below the resolution of the
+// bf16 operands it is rounded to (3.9e-3 relative), at 5 packed instructions + 2 transcendentals per pair of values against 13 + 4: the
+// erf form was ~45 % of that mode's FFN kernels.  Forward and backward instances use the same pair of functions (FAST = (NP == 1)).
+__device__ __forceinline__ lg_v2f gelu2_fast_sig(lg_v2f x, lg_v2f& x2) {
+    x2 = x * x;
+    const lg_v2f v = x * (x2 * -0.1029432395800235f + -2.302208198144325f);      // -(2 sqrt(2/pi) (x + 0.044715 x^3)) log2(e)
+    const lg_v2f d = (lg_v2f){__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)} + 1.0f;
+    return (lg_v2f){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};    // sigmoid; exp2 -> inf gives 1 / inf = 0 for x << 0
+}
+template <bool FAST>
+__device__ __forceinline__ lg_v2f gelu2_t(lg_v2f x) {
+    if constexpr (FAST) {
+        lg_v2f x2;
+        return x * gelu2_fast_sig(x, x2);
+    } else {
+        return gelu2_f(x);
+    }
+}
+template <bool FAST>
+__device__ __forceinline__ void gelu2_both_t(lg_v2f x, lg_v2f& a, lg_v2f& g) {
+    if constexpr (FAST) {
+        lg_v2f x2;
+        const lg_v2f sg = gelu2_fast_sig(x, x2);
+        a = x * sg;
+        g = a * (1.0f - sg) * (x2 * 0.21406444881780073f + 1.5957691216057308f) + sg;   // d/dx [x s(v(x))] = s + x s (1 - s) v'(x)
+    } else {
+        gelu2_both_f(x, a, g);
+    }
+}
 // d gelu / dx = Phi(x) + x * phi(x)
 __device__ __forceinline__ float gelu_grad_f(float x) {
     const float z = x * 0.70710678118654752440f;

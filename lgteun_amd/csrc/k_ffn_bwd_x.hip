@@ -307,8 +307,8 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
             KB_FENCE();
             // ---- gelu(h1), gelu'(h1) with one exponential for both; dh1 = da1 * gelu'(h1); pieces
             lg_v2f a01, a23, g01, g23;
-            gelu2_both_f((lg_v2f){h1[0], h1[1]}, a01, g01);
-            gelu2_both_f((lg_v2f){h1[2], h1[3]}, a23, g23);
+            gelu2_both_t<NP == 1>((lg_v2f){h1[0], h1[1]}, a01, g01);
+            gelu2_both_t<NP == 1>((lg_v2f){h1[2], h1[3]}, a23, g23);
             const float a1v[4] = {a01.x, a01.y, a23.x, a23.y};
             const float d1v[4] = {da[0] * g01.x, da[1] * g01.y, da[2] * g23.x, da[3] * g23.y};
             bs1 += (d1v[0] + d1v[1]) + (d1v[2] + d1v[3]);

@@ -238,8 +238,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void k_
                 }
                 lg_v2f a01, a23, g01, g23;
                 const float4 h3v = HS<BF>::widen(h3c[pb]);
-                gelu2_both_f((lg_v2f){h3v.x, h3v.y}, a01, g01);
-                gelu2_both_f((lg_v2f){h3v.z, h3v.w}, a23, g23);
+                gelu2_both_t<NP == 1>((lg_v2f){h3v.x, h3v.y}, a01, g01);
+                gelu2_both_t<NP == 1>((lg_v2f){h3v.z, h3v.w}, a23, g23);
                 // dh3 (0 outside the image: dy is 0 there) -> ring
                 int rp = ring0 + m;
                 rp = rp >= RING * HX ? rp - RING * HX : rp;

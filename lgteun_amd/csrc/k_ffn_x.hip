@@ -199,8 +199,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 float av[4];
                 if (SAVE == 1) {
                     lg_v2f a01, a23, g01, g23;
-                    gelu2_both_f((lg_v2f){acc[pb][0], acc[pb][1]}, a01, g01);
-                    gelu2_both_f((lg_v2f){acc[pb][2], acc[pb][3]}, a23, g23);
+                    gelu2_both_t<NP == 1>((lg_v2f){acc[pb][0], acc[pb][1]}, a01, g01);
+                    gelu2_both_t<NP == 1>((lg_v2f){acc[pb][2], acc[pb][3]}, a23, g23);
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                     if (inner[pb]) {
                         HS<BF>::st4(a1.a1s, prow[pb], make_float4(av[0], av[1], av[2], av[3]));
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     }
                 } else {
                     if (SAVE == 2 && inner[pb]) HS<BF>::st4(a1.a1s, prow[pb], make_float4(acc[pb][0], acc[pb][1], acc[pb][2], acc[pb][3]));
-                    const lg_v2f a01 = gelu2_f((lg_v2f){acc[pb][0], acc[pb][1]}), a23 = gelu2_f((lg_v2f){acc[pb][2], acc[pb][3]});
+                    const lg_v2f a01 = gelu2_t<NP == 1>((lg_v2f){acc[pb][0], acc[pb][1]}), a23 = gelu2_t<NP == 1>((lg_v2f){acc[pb][2], acc[pb][3]});
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 }
                 u32x2_t q1, q2, q3;
@@ -325,8 +325,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 float av[4];
                 if (SAVE == 1) {
                     lg_v2f a01, a23, g01, g23;
-                    gelu2_both_f((lg_v2f){acc.x, acc.y}, a01, g01);
-                    gelu2_both_f((lg_v2f){acc.z, acc.w}, a23, g23);
+                    gelu2_both_t<NP == 1>((lg_v2f){acc.x, acc.y}, a01, g01);
+                    gelu2_both_t<NP == 1>((lg_v2f){acc.z, acc.w}, a23, g23);
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                     const int y = y0 + ty, x = x0 + tx;
                     if (y < Yend && x < w) {
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                         const int y = y0 + ty, x = x0 + tx;
                         if (y < Yend && x < w) HS<BF>::st4(a2.a3s, ((b * h + y) * (long)w + x) * N1 + 4 * q, acc);
                     }
-                    const lg_v2f a01 = gelu2_f((lg_v2f){acc.x, acc.y}), a23 = gelu2_f((lg_v2f){acc.z, acc.w});
+                    const lg_v2f a01 = gelu2_t<NP == 1>((lg_v2f){acc.x, acc.y}), a23 = gelu2_t<NP == 1>((lg_v2f){acc.z, acc.w});
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 }
                 u32x2_t q1, q2, q3;

@@ -168,15 +168,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const bool inner = m < npx && hx >= 1 && hx <= TX && x < w && y >= Y0 && y < Yend;
                 const long prow = ((b * h + y) * (long)w + x) * N1 + c0;
                 lg_v2f a01, a23, g01, g23;
-                gelu2_both_f((lg_v2f){acc[pb][0], acc[pb][1]}, a01, g01);
-                gelu2_both_f((lg_v2f){acc[pb][2], acc[pb][3]}, a23, g23);
+                gelu2_both_t<NP == 1>((lg_v2f){acc[pb][0], acc[pb][1]}, a01, g01);
+                gelu2_both_t<NP == 1>((lg_v2f){acc[pb][2], acc[pb][3]}, a23, g23);
                 av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 if (inner) {
                     HS<BF>::st4(a1.a1s, prow, make_float4(av[0], av[1], av[2], av[3]));
                     HS<BF>::st4(a1.g1s, prow, make_float4(g01.x, g01.y, g23.x, g23.y));
                 }
             } else {
-                const lg_v2f a01 = gelu2_f((lg_v2f){acc[pb][0], acc[pb][1]}), a23 = gelu2_f((lg_v2f){acc[pb][2], acc[pb][3]});
+                const lg_v2f a01 = gelu2_t<NP == 1>((lg_v2f){acc[pb][0], acc[pb][1]}), a23 = gelu2_t<NP == 1>((lg_v2f){acc[pb][2], acc[pb][3]});
                 av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
             }
             u32x2_t q1, q2, q3;
@@ -369,8 +369,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 float av[4];
                 if (SAVE) {
                     lg_v2f a01, a23, g01, g23;
-                    gelu2_both_f((lg_v2f){acc.x, acc.y}, a01, g01);
-                    gelu2_both_f((lg_v2f){acc.z, acc.w}, a23, g23);
+                    gelu2_both_t<NP == 1>((lg_v2f){acc.x, acc.y}, a01, g01);
+                    gelu2_both_t<NP == 1>((lg_v2f){acc.z, acc.w}, a23, g23);
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                     const int y = y0 + ty, x = x0 + tx;
                     if (y < Yend && x < w) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         }
                     }
                 } else {
-                    const lg_v2f a01 = gelu2_f((lg_v2f){acc.x, acc.y}), a23 = gelu2_f((lg_v2f){acc.z, acc.w});
+                    const lg_v2f a01 = gelu2_t<NP == 1>((lg_v2f){acc.x, acc.y}), a23 = gelu2_t<NP == 1>((lg_v2f){acc.z, acc.w});
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 }
                 u32x2_t q1, q2, q3;
