@@ -481,7 +481,20 @@ int launch_upfuse(int E, const UpFuseArgs& a, hipStream_t s) {
 template <int C, int E>
 __global__ __launch_bounds__(256) void k_tail(TailArgs a) {
     __shared__ float sW[C * E], sB[C];
+    // EVERY load of the workgroup's life is requested before its first wait: the pixel's row and its C values of z together with the
+    // parameter arrays.  As staging -> barrier -> row -> matvec -> z the kernel was three dependent round trips long (a workgroup lives for
+    // one pixel per thread), 12.0 us for 50 MB
+    const long pr = blockIdx.x * 256L + threadIdx.x;
+    const long p = pr < a.total ? pr : a.total - 1;
+    const long b = p / a.HW, s = p - b * a.HW;
+    float4 xv[E / 4];
+    float zv[C];
     {
+        const float4* src = reinterpret_cast<const float4*>(a.x + p * E);
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k) xv[k] = src[k];
+#pragma unroll
+        for (int c = 0; c < C; ++c) zv[c] = a.z[(b * C + c) * a.HW + s];
         float vw[(C * E + 255) / 256], vb[1];
         lds_stage_ld<256, C * E>(vw, a.w);
         lds_stage_ld<256, C>(vb, a.b);
@@ -489,23 +502,16 @@ __global__ __launch_bounds__(256) void k_tail(TailArgs a) {
         lds_stage_st<256, C>(sB, vb);
     }
     __syncthreads();
-    long p = blockIdx.x * 256L + threadIdx.x;
-    if (p >= a.total) return;
-    long b = p / a.HW, s = p - b * a.HW;
+    if (pr >= a.total) return;
     float x[E];
-    const float4* src = reinterpret_cast<const float4*>(a.x + p * E);
 #pragma unroll
-    for (int k = 0; k < E / 4; ++k) {
-        float4 v = src[k];
-        x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
-    }
+    for (int k = 0; k < E / 4; ++k) { x[4 * k] = xv[k].x; x[4 * k + 1] = xv[k].y; x[4 * k + 2] = xv[k].z; x[4 * k + 3] = xv[k].w; }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         float v = 0.f;
 #pragma unroll
         for (int k = 0; k < E; ++k) v += sW[c * E + k] * x[k];
-        long o = (b * C + c) * a.HW + s;
-        a.out[o] = v + sB[c] + a.z[o];
+        a.out[(b * C + c) * a.HW + s] = v + sB[c] + zv[c];
     }
 }
 
