@@ -163,9 +163,33 @@ __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
     ln_stats<E>(e, mu, rstd);
 #pragma unroll
     for (int n = 0; n < E; ++n) e[n] = (e[n] - mu) * rstd * a.lng[n] + a.lnb[n];
-    float4* xo = reinterpret_cast<float4*>(a.x + p * E);
+#ifndef LG_EMBED_TR
+#define LG_EMBED_TR 1
+#endif
+    if (LG_EMBED_TR && a.total % 64 == 0) {
+        // the NHWC rows leave COALESCED: the wave's 64 pixel vectors pass through a wave-private LDS image and every store instruction
+        // writes 1 KB of consecutive bytes (lane -> (pixel 16 j + lane / Q4, quad lane % Q4)); as one row per lane a store instruction is
+        // 64 separate 16-byte pieces at a 64- / 128-byte stride
+        constexpr int Q4 = E / 4, LDT = E + 4;
+        __shared__ __attribute__((aligned(16))) float tr[4][64 * LDT];
+        const int lane = threadIdx.x & 63;
+        float* mine = tr[threadIdx.x >> 6];
 #pragma unroll
-    for (int n = 0; n < E / 4; ++n) xo[n] = make_float4(e[4 * n], e[4 * n + 1], e[4 * n + 2], e[4 * n + 3]);
+        for (int n = 0; n < Q4; ++n) *reinterpret_cast<float4*>(mine + lane * LDT + 4 * n) = make_float4(e[4 * n], e[4 * n + 1], e[4 * n + 2], e[4 * n + 3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float4* xo = reinterpret_cast<float4*>(a.x + (p - lane) * E);
+#pragma unroll
+        for (int j = 0; j < Q4; ++j) {
+            const int i = j * 64 + lane;                 // float4 index inside the wave's 64 x E block
+            xo[i] = *reinterpret_cast<const float4*>(mine + (i / Q4) * LDT + 4 * (i % Q4));
+        }
+    } else {
+        float4* xo = reinterpret_cast<float4*>(a.x + p * E);
+#pragma unroll
+        for (int n = 0; n < E / 4; ++n) xo[n] = make_float4(e[4 * n], e[4 * n + 1], e[4 * n + 2], e[4 * n + 3]);
+    }
     if (a.g) emit_g<E>(e, a.n1g, a.n1b, a.g, b, s, a.HW);
 }
 
