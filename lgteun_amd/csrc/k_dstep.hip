@@ -566,6 +566,12 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_bwd(DstepBwdArgs a) {
     DSTAMP(stamp_i++);
     const int plane = blockIdx.x, c = plane % C;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // the channel's parameters first (scalar loads: their two dependent fetches -- pointer, then data -- run under the first vector load's round trip)
+    const float eta = a.eta[0];
+    float wD1[9], wD3[9], wT1[9], wT3[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { wD1[k] = a.d1w[c * 9 + k]; wD3[k] = a.d3w[c * 9 + k]; wT1[k] = a.dt1w[c * 9 + k]; wT3[k] = a.dt3w[c * 9 + k]; }
+    const float bT3 = a.dt3b[c];
     // every load of the first stages is requested before anything else, in the order of use (the counter of outstanding loads is in-order)
     const float4 s1q = reinterpret_cast<const float4*>(a.s1 + (size_t)plane * H * H)[min(tid, H * H / 4 - 1)];
     const float4* __restrict__ gp = reinterpret_cast<const float4*>(a.g + (size_t)plane * N * N);
@@ -574,12 +580,11 @@ __global__ __launch_bounds__(DS_NT) void k_dstep_bwd(DstepBwdArgs a) {
     for (int k = 0; k < NV; ++k) gq[k] = gp[tid + DS_NT * k];
     const float4 rq = reinterpret_cast<const float4*>(a.r + (size_t)plane * Q * Q)[min(tid, Q * Q / 4 - 1)];
     const float4 t1q = reinterpret_cast<const float4*>(a.t1 + (size_t)plane * H * H)[min(tid, H * H / 4 - 1)];
+    // (the parameters pinned HERE, behind the requests: left to itself the compiler sinks their scalar loads behind the first vector load's wait)
+#define DS_PIN9(w) asm volatile("" :: "s"(w[0]), "s"(w[1]), "s"(w[2]), "s"(w[3]), "s"(w[4]), "s"(w[5]), "s"(w[6]), "s"(w[7]), "s"(w[8]))
+    DS_PIN9(wT3); DS_PIN9(wT1); DS_PIN9(wD3); DS_PIN9(wD1);
+    asm volatile("" :: "s"(eta), "s"(bT3));
     DSTAMP(stamp_i++);
-    const float eta = a.eta[0];
-    float wD1[9], wD3[9], wT1[9], wT3[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { wD1[k] = a.d1w[c * 9 + k]; wD3[k] = a.d3w[c * 9 + k]; wT1[k] = a.dt1w[c * 9 + k]; wT3[k] = a.dt3w[c * 9 + k]; }
-    const float bT3 = a.dt3b[c];
     auto put4 = [](float4 v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; };
     // the partial sums of a stage: wave totals into red[stage][wave][k]; summed over the waves (fixed order) by sum_stage after a barrier
     auto wave_part = [&](int stage, const float (&part)[10]) {
