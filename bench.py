@@ -220,8 +220,8 @@ def main():
     global C, K, H, B_PER_GPU, E, P0
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)   # 0.3 s timed region at configs[1] (20 steps were 0.14 s)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS), help='c2 = BASELINE configs[1] (the metric; default); c3 / c5 = the 8-band configs')
     ap.add_argument('--prof-kernel', default='ffn', help='kernel timed live for the roofline object (default: the dominant one)')
     ap.add_argument('--mode', default='faithful', choices=['faithful', 'live', 'chained'],
