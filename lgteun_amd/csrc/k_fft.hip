@@ -296,7 +296,9 @@ __global__ void k_fftmix(FftArgs a) {
 // Split path for planes that do not fit LDS (n = 256, 512): rows -> global half spectrum S[plane][n][n/2+1] -> columns
 // (+ amplitude/phase edit, in place) -> rows.  Same arithmetic as the in-LDS kernels; three launches per direction.
 // ================================================================================================
-#define FFT_ROWS_PER_WG(n) (16384 / (n))   // 128 KiB complex tile
+#define FFT_ROWS_PER_WG(n) (8192 / (n))    // 64 KiB complex tile, 512 threads: TWO workgroups per CU, so one's loads / stores run under the other's
+                                           // transform (as one 128 KiB tile of 1 024 threads per CU the three phases of a tile were serial)
+#define FFT_ROWS_NT 512
 #define FFT_COLS_PER_WG(n) (8192 / (n))    // 64 KiB complex tile
 
 __device__ __forceinline__ void make_twiddles(float2* tw, int n) {
@@ -316,12 +318,27 @@ __global__ void k_fft_rows_fwd(const float* __restrict__ in, const float* __rest
     float2* tw = smem2 + R * n;
     const size_t plane = blockIdx.x;
     const int row0 = blockIdx.y * R;
-    make_twiddles(tw, n);
     const size_t base = (plane * n + row0) * n;
-    for (int i = threadIdx.x; i < R * n; i += blockDim.x) {
-        float v = in[base + i];
-        if (mul) v *= mul[base + i];
-        buf[i] = make_float2(v, 0.0f);
+    {   // the tile's 8 192 reals = four 16-byte loads per thread (512 threads), ALL requested before the twiddles are made and the first value
+        // is stored: as sixteen load -> store trips of one float the kernel was sixteen dependent round trips long (one workgroup per CU)
+        const float4* __restrict__ in4 = reinterpret_cast<const float4*>(in + base);
+        float4 v[4], m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = in4[threadIdx.x + FFT_ROWS_NT * k];
+        if (mul) {
+            const float4* __restrict__ mul4 = reinterpret_cast<const float4*>(mul + base);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] = mul4[threadIdx.x + FFT_ROWS_NT * k];
+        }
+        make_twiddles(tw, n);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 t = v[k];
+            if (mul) { t.x *= m[k].x; t.y *= m[k].y; t.z *= m[k].z; t.w *= m[k].w; }
+            float4* dst = reinterpret_cast<float4*>(buf + 4 * (threadIdx.x + FFT_ROWS_NT * k));
+            dst[0] = make_float4(t.x, 0.0f, t.y, 0.0f);
+            dst[1] = make_float4(t.z, 0.0f, t.w, 0.0f);
+        }
     }
     __syncthreads();
     fft_lines<false, false>(buf, tw, lg, lgR, n, 1);
@@ -348,10 +365,19 @@ __global__ void k_fft_cols(FftArgs fa, FftBwdArgs ba, float2* __restrict__ S, in
     const int ch = (int)(plane % chn);
     const int kx0 = blockIdx.y * CB;
     const int ncols = min(CB, half + 1 - kx0);
-    make_twiddles(tw, n);
-    for (int i = threadIdx.x; i < n * CB; i += blockDim.x) {
-        const int y = i >> lgCB, c = i & (CB - 1);
-        buf[i] = (c < ncols) ? S[(plane * n + y) * (half + 1) + kx0 + c] : make_float2(0.f, 0.f);
+    {   // the tile's 8 192 bins = sixteen 8-byte loads per thread (512 threads), all requested first (clamped columns, zeroed afterwards)
+        float2 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = threadIdx.x + 512 * k, y = i >> lgCB, c = i & (CB - 1);
+            v[k] = S[(plane * n + y) * (half + 1) + kx0 + min(c, ncols - 1)];
+        }
+        make_twiddles(tw, n);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = threadIdx.x + 512 * k, c = i & (CB - 1);
+            buf[i] = (c < ncols) ? v[k] : make_float2(0.f, 0.f);
+        }
     }
     __syncthreads();
     fft_lines<false, false>(buf, tw, lg, lgCB, 1, CB);
@@ -366,18 +392,32 @@ __global__ void k_fft_cols(FftArgs fa, FftBwdArgs ba, float2* __restrict__ S, in
     const float pw = (BWD ? ba.phaw : fa.phaw)[ch], pb = (BWD ? ba.phab : fa.phab)[ch];
     const float nn = (float)n * (float)n;
     float s_aw = 0.f, s_ab = 0.f, s_pw = 0.f, s_pb = 0.f;
-    for (int i = threadIdx.x; i < n * CB; i += blockDim.x) {
-        const int q = i >> lgCB, c = i & (CB - 1);
-        if (c >= ncols) continue;
-        const int ky = (int)(__brev((unsigned)q) >> (32 - lg)), kx = kx0 + c;
-        const size_t o = (plane * n + ky) * (half + 1) + kx;
-        if (!BWD) {
-            float amp, pha;
-            buf[i] = bin_edit_fwd(buf[i], aw, ab, pw, pb, amp, pha);
-            if (fa.amp) { fa.amp[o] = amp; fa.pha[o] = pha; }
-        } else {
-            const float cw = (kx == 0 || kx == half) ? 1.0f : 2.0f;
-            buf[i] = bin_edit_bwd(buf[i], cw, nn, ba.amp[o], ba.pha[o], aw, ab, pw, pb, s_aw, s_ab, s_pw, s_pb);
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {   // four groups of four bins per thread; the backward's saved amplitude / phase of a group in one batch
+        float sa[4], sp[4];
+        if (BWD) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = threadIdx.x + 512 * (4 * g + u), q = i >> lgCB, c = min(i & (CB - 1), ncols - 1);
+                const size_t o = (plane * n + (int)(__brev((unsigned)q) >> (32 - lg))) * (half + 1) + kx0 + c;
+                sa[u] = ba.amp[o]; sp[u] = ba.pha[o];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = threadIdx.x + 512 * (4 * g + u);
+            const int q = i >> lgCB, c = i & (CB - 1);
+            if (c >= ncols) continue;
+            const int ky = (int)(__brev((unsigned)q) >> (32 - lg)), kx = kx0 + c;
+            const size_t o = (plane * n + ky) * (half + 1) + kx;
+            if (!BWD) {
+                float amp, pha;
+                buf[i] = bin_edit_fwd(buf[i], aw, ab, pw, pb, amp, pha);
+                if (fa.amp) { fa.amp[o] = amp; fa.pha[o] = pha; }
+            } else {
+                const float cw = (kx == 0 || kx == half) ? 1.0f : 2.0f;
+                buf[i] = bin_edit_bwd(buf[i], cw, nn, sa[u], sp[u], aw, ab, pw, pb, s_aw, s_ab, s_pw, s_pb);
+            }
         }
     }
     __syncthreads();
@@ -415,29 +455,47 @@ __global__ void k_fft_rows_inv(const float2* __restrict__ S, float* __restrict__
     float2* tw = smem2 + R * n;
     const size_t plane = blockIdx.x;
     const int row0 = blockIdx.y * R;
-    make_twiddles(tw, n);
-    for (int i = threadIdx.x; i < R * (half + 1); i += blockDim.x) {
-        const int r = i / (half + 1), kx = i - r * (half + 1);
-        float2 v = S[(plane * n + row0 + r) * (half + 1) + kx];
-        const int p = (int)(__brev((unsigned)kx) >> (32 - lg));
-        if (kx == 0 || kx == half) {
-            buf[r * n + p] = make_float2(v.x, 0.0f);           // c2r drops these imaginary parts
-        } else {
-            buf[r * n + p] = v;
-            buf[r * n + (int)(__brev((unsigned)(n - kx)) >> (32 - lg))] = make_float2(v.x, -v.y);
+    {   // the tile's R (n/2 + 1) bins (contiguous in S): nine 8-byte loads per thread, all requested first
+        const float2* __restrict__ Sb = S + (plane * n + row0) * (size_t)(half + 1);
+        const int total = R * (half + 1);
+        float2 v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = Sb[min((int)threadIdx.x + FFT_ROWS_NT * k, total - 1)];
+        make_twiddles(tw, n);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int i = threadIdx.x + FFT_ROWS_NT * k;
+            if (i < total) {
+                const int r = i / (half + 1), kx = i - r * (half + 1);
+                const int p = (int)(__brev((unsigned)kx) >> (32 - lg));
+                if (kx == 0 || kx == half) {
+                    buf[r * n + p] = make_float2(v[k].x, 0.0f);           // c2r drops these imaginary parts
+                } else {
+                    buf[r * n + p] = v[k];
+                    buf[r * n + (int)(__brev((unsigned)(n - kx)) >> (32 - lg))] = make_float2(v[k].x, -v[k].y);
+                }
+            }
         }
     }
     __syncthreads();
     fft_lines<true, false>(buf, tw, lg, lgR, n, 1);
     const float sc = 1.0f / ((float)n * (float)n);
     const size_t base = (plane * n + row0) * n;
-    for (int i = threadIdx.x; i < R * n; i += blockDim.x) {
-        const float v = buf[i].x * sc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {   // 8 192 reals = four 16-byte stores per thread
+        const int i4 = threadIdx.x + FFT_ROWS_NT * k;
+        const float4 a0 = *reinterpret_cast<const float4*>(buf + 4 * i4), a1 = *reinterpret_cast<const float4*>(buf + 4 * i4 + 2);
+        const float v[4] = {a0.x * sc, a0.z * sc, a1.x * sc, a1.z * sc};
         if (absout) {
-            out[base + i] = fabsf(v);
-            if (sgn) sgn[base + i] = (v > 0.f) ? 1.0f : ((v < 0.f) ? -1.0f : 0.0f);
+            reinterpret_cast<float4*>(out + base)[i4] = make_float4(fabsf(v[0]), fabsf(v[1]), fabsf(v[2]), fabsf(v[3]));
+            if (sgn) {
+                float sg[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sg[u] = (v[u] > 0.f) ? 1.0f : ((v[u] < 0.f) ? -1.0f : 0.0f);
+                reinterpret_cast<float4*>(sgn + base)[i4] = make_float4(sg[0], sg[1], sg[2], sg[3]);
+            }
         } else {
-            out[base + i] = v;
+            reinterpret_cast<float4*>(out + base)[i4] = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
 }
@@ -474,22 +532,22 @@ static int launch_fft_split(const FftArgs* fa, const FftBwdArgs* ba, hipStream_t
     const size_t lds_cols = ((size_t)n * CB + half) * sizeof(float2) + 64 * sizeof(float);
     dim3 grows(planes, n / R), gcols(planes, (half + 1 + CB - 1) / CB);
     if (fa) {
-        k_fft_rows_fwd<<<grows, 1024, lds_rows, s>>>(fa->g, nullptr, S, n, lg, 1);
+        k_fft_rows_fwd<<<grows, FFT_ROWS_NT, lds_rows, s>>>(fa->g, nullptr, S, n, lg, 1);
         LG_CHECK_LAUNCH();
         FftBwdArgs dummy;
         memset(&dummy, 0, sizeof(dummy));
         k_fft_cols<false><<<gcols, 512, lds_cols, s>>>(*fa, dummy, S, n, lg);
         LG_CHECK_LAUNCH();
-        k_fft_rows_inv<<<grows, 1024, lds_rows, s>>>(S, fa->o, fa->sgn, n, lg, 1);
+        k_fft_rows_inv<<<grows, FFT_ROWS_NT, lds_rows, s>>>(S, fa->o, fa->sgn, n, lg, 1);
         LG_CHECK_LAUNCH();
     } else {
-        k_fft_rows_fwd<<<grows, 1024, lds_rows, s>>>(ba->do2, ba->sgn, S, n, lg, 0);
+        k_fft_rows_fwd<<<grows, FFT_ROWS_NT, lds_rows, s>>>(ba->do2, ba->sgn, S, n, lg, 0);
         LG_CHECK_LAUNCH();
         FftArgs dummy;
         memset(&dummy, 0, sizeof(dummy));
         k_fft_cols<true><<<gcols, 512, lds_cols, s>>>(dummy, *ba, S, n, lg);
         LG_CHECK_LAUNCH();
-        k_fft_rows_inv<<<grows, 1024, lds_rows, s>>>(S, ba->dg, nullptr, n, lg, 0);
+        k_fft_rows_inv<<<grows, FFT_ROWS_NT, lds_rows, s>>>(S, ba->dg, nullptr, n, lg, 0);
         LG_CHECK_LAUNCH();
     }
     return 0;
