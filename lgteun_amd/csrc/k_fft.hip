@@ -309,13 +309,17 @@ __device__ __forceinline__ void make_twiddles(float2* tw, int n) {
 }
 
 // real rows -> half spectrum (natural kx order).  mul: optional elementwise factor (backward: sign of the forward output)
-__global__ void k_fft_rows_fwd(const float* __restrict__ in, const float* __restrict__ mul, float2* __restrict__ S, int n, int lg, int force_real) {
+// (LG = log2 n is a template parameter here too: the passes' shifts and the divisions by n/2 + 1 of the staging loops become immediates)
+template <int LG>
+__global__ void k_fft_rows_fwd(const float* __restrict__ in, const float* __restrict__ mul, float2* __restrict__ S, int force_real) {
     extern __shared__ float2 smem2[];
-    const int R = FFT_ROWS_PER_WG(n), half = n >> 1;
-    int lgR = 0;
-    while ((1 << lgR) < R) ++lgR;
+    constexpr int n = 1 << LG, lg = LG, R = FFT_ROWS_PER_WG(n), half = n >> 1, lgR = 13 - LG;
+    static_assert((1 << lgR) == R, "rows per tile");
+    // row pitch n + 1 complex and consecutive lanes on consecutive ROWS: a lane stride of 2n + 2 dwords (= 2 mod 64) is conflict-free in every pass;
+    // with the rows back to back and lanes walking along a row the second pass (span-1 groups of 16 points) was a 16-way bank conflict
+    constexpr int LD = n + 1;
     float2* buf = smem2;
-    float2* tw = smem2 + R * n;
+    float2* tw = smem2 + R * LD;
     const size_t plane = blockIdx.x;
     const int row0 = blockIdx.y * R;
     const size_t base = (plane * n + row0) * n;
@@ -335,28 +339,27 @@ __global__ void k_fft_rows_fwd(const float* __restrict__ in, const float* __rest
         for (int k = 0; k < 4; ++k) {
             float4 t = v[k];
             if (mul) { t.x *= m[k].x; t.y *= m[k].y; t.z *= m[k].z; t.w *= m[k].w; }
-            float4* dst = reinterpret_cast<float4*>(buf + 4 * (threadIdx.x + FFT_ROWS_NT * k));
-            dst[0] = make_float4(t.x, 0.0f, t.y, 0.0f);
-            dst[1] = make_float4(t.z, 0.0f, t.w, 0.0f);
+            const int i4 = threadIdx.x + FFT_ROWS_NT * k;              // float4 index of the tile: row i4 / (n / 4), columns 4 (i4 % (n / 4)) ...
+            float2* dst = buf + (i4 / (n / 4)) * LD + 4 * (i4 % (n / 4));
+            dst[0] = make_float2(t.x, 0.0f); dst[1] = make_float2(t.y, 0.0f); dst[2] = make_float2(t.z, 0.0f); dst[3] = make_float2(t.w, 0.0f);
         }
     }
     __syncthreads();
-    fft_lines<false, false>(buf, tw, lg, lgR, n, 1);
+    fft_lines<false, false, true>(buf, tw, lg, lgR, LD, 1);
     for (int i = threadIdx.x; i < R * (half + 1); i += blockDim.x) {
         const int r = i / (half + 1), kx = i - r * (half + 1);
-        float2 v = buf[r * n + (int)(__brev((unsigned)kx) >> (32 - lg))];
+        float2 v = buf[r * LD + (int)(__brev((unsigned)kx) >> (32 - lg))];
         if (force_real && (kx == 0 || kx == half)) v.y = 0.0f;
         S[(plane * n + row0 + r) * (half + 1) + kx] = v;
     }
 }
 
 // columns of the half spectrum, in place: forward column FFT, bin edit (forward or backward), inverse column FFT
-template <bool BWD>
-__global__ void k_fft_cols(FftArgs fa, FftBwdArgs ba, float2* __restrict__ S, int n, int lg) {
+template <bool BWD, int LG>
+__global__ void k_fft_cols(FftArgs fa, FftBwdArgs ba, float2* __restrict__ S) {
     extern __shared__ float2 smem2[];
-    const int CB = FFT_COLS_PER_WG(n), half = n >> 1;
-    int lgCB = 0;
-    while ((1 << lgCB) < CB) ++lgCB;
+    constexpr int n = 1 << LG, lg = LG, CB = FFT_COLS_PER_WG(n), half = n >> 1, lgCB = 13 - LG;
+    static_assert((1 << lgCB) == CB, "columns per tile");
     float2* buf = smem2;            // [n rows][CB cols]
     float2* tw = smem2 + n * CB;
     float* red = reinterpret_cast<float*>(tw + half);
@@ -446,13 +449,14 @@ __global__ void k_fft_cols(FftArgs fa, FftBwdArgs ba, float2* __restrict__ S, in
 }
 
 // half spectrum rows -> real rows (c2r): out = |x| (+ sign save) when absout, else the signed value
-__global__ void k_fft_rows_inv(const float2* __restrict__ S, float* __restrict__ out, float* __restrict__ sgn, int n, int lg, int absout) {
+template <int LG>
+__global__ void k_fft_rows_inv(const float2* __restrict__ S, float* __restrict__ out, float* __restrict__ sgn, int absout) {
     extern __shared__ float2 smem2[];
-    const int R = FFT_ROWS_PER_WG(n), half = n >> 1;
-    int lgR = 0;
-    while ((1 << lgR) < R) ++lgR;
+    constexpr int n = 1 << LG, lg = LG, R = FFT_ROWS_PER_WG(n), half = n >> 1, lgR = 13 - LG;
+    static_assert((1 << lgR) == R, "rows per tile");
+    constexpr int LD = n + 1;   // as in k_fft_rows_fwd
     float2* buf = smem2;
-    float2* tw = smem2 + R * n;
+    float2* tw = smem2 + R * LD;
     const size_t plane = blockIdx.x;
     const int row0 = blockIdx.y * R;
     {   // the tile's R (n/2 + 1) bins (contiguous in S): nine 8-byte loads per thread, all requested first
@@ -469,23 +473,23 @@ __global__ void k_fft_rows_inv(const float2* __restrict__ S, float* __restrict__
                 const int r = i / (half + 1), kx = i - r * (half + 1);
                 const int p = (int)(__brev((unsigned)kx) >> (32 - lg));
                 if (kx == 0 || kx == half) {
-                    buf[r * n + p] = make_float2(v[k].x, 0.0f);           // c2r drops these imaginary parts
+                    buf[r * LD + p] = make_float2(v[k].x, 0.0f);           // c2r drops these imaginary parts
                 } else {
-                    buf[r * n + p] = v[k];
-                    buf[r * n + (int)(__brev((unsigned)(n - kx)) >> (32 - lg))] = make_float2(v[k].x, -v[k].y);
+                    buf[r * LD + p] = v[k];
+                    buf[r * LD + (int)(__brev((unsigned)(n - kx)) >> (32 - lg))] = make_float2(v[k].x, -v[k].y);
                 }
             }
         }
     }
     __syncthreads();
-    fft_lines<true, false>(buf, tw, lg, lgR, n, 1);
+    fft_lines<true, false, true>(buf, tw, lg, lgR, LD, 1);
     const float sc = 1.0f / ((float)n * (float)n);
     const size_t base = (plane * n + row0) * n;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {   // 8 192 reals = four 16-byte stores per thread
         const int i4 = threadIdx.x + FFT_ROWS_NT * k;
-        const float4 a0 = *reinterpret_cast<const float4*>(buf + 4 * i4), a1 = *reinterpret_cast<const float4*>(buf + 4 * i4 + 2);
-        const float v[4] = {a0.x * sc, a0.z * sc, a1.x * sc, a1.z * sc};
+        const float2* src = buf + (i4 / (n / 4)) * LD + 4 * (i4 % (n / 4));
+        const float v[4] = {src[0].x * sc, src[1].x * sc, src[2].x * sc, src[3].x * sc};
         if (absout) {
             reinterpret_cast<float4*>(out + base)[i4] = make_float4(fabsf(v[0]), fabsf(v[1]), fabsf(v[2]), fabsf(v[3]));
             if (sgn) {
@@ -507,50 +511,51 @@ size_t fft_scratch_floats_hw(int planes, int h, int w) {
     return (fft_is_generic(h, w) || h > 128) ? (size_t)planes * h * (w / 2 + 1) * 2 : 0;
 }
 
-static int split_attrs() {
-    static bool done = false;
-    if (done) return 0;
-    const void* fns[4] = {(const void*)k_fft_rows_fwd, (const void*)k_fft_cols<false>, (const void*)k_fft_cols<true>, (const void*)k_fft_rows_inv};
-    for (int i = 0; i < 4; ++i) {
-        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        if (e != hipSuccess) { lg_set_error("fft split: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+template <int LG>
+static int launch_fft_split_t(const FftArgs* fa, const FftBwdArgs* ba, float2* S, int planes, hipStream_t s) {
+    constexpr int n = 1 << LG;
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
+        const void* fns[4] = {(const void*)k_fft_rows_fwd<LG>, (const void*)k_fft_cols<false, LG>, (const void*)k_fft_cols<true, LG>, (const void*)k_fft_rows_inv<LG>};
+        for (int i = 0; i < 4; ++i) {
+            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+            if (e != hipSuccess) { lg_set_error("fft split: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        }
+        attr_once.done();
     }
-    done = true;
+    const int R = FFT_ROWS_PER_WG(n), CB = FFT_COLS_PER_WG(n), half = n / 2;
+    const size_t lds_rows = ((size_t)R * (n + 1) + half) * sizeof(float2);
+    const size_t lds_cols = ((size_t)n * CB + half) * sizeof(float2) + 64 * sizeof(float);
+    dim3 grows(planes, n / R), gcols(planes, (half + 1 + CB - 1) / CB);
+    if (fa) {
+        k_fft_rows_fwd<LG><<<grows, FFT_ROWS_NT, lds_rows, s>>>(fa->g, nullptr, S, 1);
+        LG_CHECK_LAUNCH();
+        FftBwdArgs dummy;
+        memset(&dummy, 0, sizeof(dummy));
+        k_fft_cols<false, LG><<<gcols, 512, lds_cols, s>>>(*fa, dummy, S);
+        LG_CHECK_LAUNCH();
+        k_fft_rows_inv<LG><<<grows, FFT_ROWS_NT, lds_rows, s>>>(S, fa->o, fa->sgn, 1);
+        LG_CHECK_LAUNCH();
+    } else {
+        k_fft_rows_fwd<LG><<<grows, FFT_ROWS_NT, lds_rows, s>>>(ba->do2, ba->sgn, S, 0);
+        LG_CHECK_LAUNCH();
+        FftArgs dummy;
+        memset(&dummy, 0, sizeof(dummy));
+        k_fft_cols<true, LG><<<gcols, 512, lds_cols, s>>>(dummy, *ba, S);
+        LG_CHECK_LAUNCH();
+        k_fft_rows_inv<LG><<<grows, FFT_ROWS_NT, lds_rows, s>>>(S, ba->dg, nullptr, 0);
+        LG_CHECK_LAUNCH();
+    }
     return 0;
 }
-
 static int launch_fft_split(const FftArgs* fa, const FftBwdArgs* ba, hipStream_t s) {
     const int n = fa ? fa->n : ba->n, planes = fa ? fa->planes : ba->planes;
     float2* S = reinterpret_cast<float2*>(fa ? fa->scratch : ba->scratch);
     if (!S) { lg_set_error("fftmix: plane size %d needs the split path but no scratch buffer was given", n); return -2; }
-    int lg = 0;
-    while ((1 << lg) < n) ++lg;
-    int rc = split_attrs();
-    if (rc) return rc;
-    const int R = FFT_ROWS_PER_WG(n), CB = FFT_COLS_PER_WG(n), half = n / 2;
-    const size_t lds_rows = ((size_t)R * n + half) * sizeof(float2);
-    const size_t lds_cols = ((size_t)n * CB + half) * sizeof(float2) + 64 * sizeof(float);
-    dim3 grows(planes, n / R), gcols(planes, (half + 1 + CB - 1) / CB);
-    if (fa) {
-        k_fft_rows_fwd<<<grows, FFT_ROWS_NT, lds_rows, s>>>(fa->g, nullptr, S, n, lg, 1);
-        LG_CHECK_LAUNCH();
-        FftBwdArgs dummy;
-        memset(&dummy, 0, sizeof(dummy));
-        k_fft_cols<false><<<gcols, 512, lds_cols, s>>>(*fa, dummy, S, n, lg);
-        LG_CHECK_LAUNCH();
-        k_fft_rows_inv<<<grows, FFT_ROWS_NT, lds_rows, s>>>(S, fa->o, fa->sgn, n, lg, 1);
-        LG_CHECK_LAUNCH();
-    } else {
-        k_fft_rows_fwd<<<grows, FFT_ROWS_NT, lds_rows, s>>>(ba->do2, ba->sgn, S, n, lg, 0);
-        LG_CHECK_LAUNCH();
-        FftArgs dummy;
-        memset(&dummy, 0, sizeof(dummy));
-        k_fft_cols<true><<<gcols, 512, lds_cols, s>>>(dummy, *ba, S, n, lg);
-        LG_CHECK_LAUNCH();
-        k_fft_rows_inv<<<grows, FFT_ROWS_NT, lds_rows, s>>>(S, ba->dg, nullptr, n, lg, 0);
-        LG_CHECK_LAUNCH();
-    }
-    return 0;
+    if (n == 256) return launch_fft_split_t<8>(fa, ba, S, planes, s);
+    if (n == 512) return launch_fft_split_t<9>(fa, ba, S, planes, s);
+    lg_set_error("fftmix: the split path exists for planes of 256 and 512 (got %d)", n);
+    return -2;
 }
 
 
