@@ -214,7 +214,8 @@ template <int E>
 __global__ __launch_bounds__(256) void k_down(DownArgs a) {
     constexpr int LPP = E / 4, PPW = 256 / LPP, NO = 2 * E / LPP, LDU = E + 4;
     static_assert(NO == 8, "eight outputs per lane");
-    __shared__ float sW[2 * E * E], sB[2 * E], sNg[2 * E], sNb[2 * E];
+    __shared__ __attribute__((aligned(16))) float sW[2 * E * E];   // [k][n]
+    __shared__ float sB[2 * E], sNg[2 * E], sNb[2 * E];
     __shared__ __attribute__((aligned(16))) float ux[PPW * LDU];
     {   // all four arrays requested before the first store (common.h: lds_stage_ld / _st); absent LayerNorm vectors: a valid dummy source
         float vw[(2 * E * E + 255) / 256], vb[1], vg[1], vn[1];
@@ -222,7 +223,14 @@ __global__ __launch_bounds__(256) void k_down(DownArgs a) {
         lds_stage_ld<256, 2 * E>(vb, a.b);
         lds_stage_ld<256, 2 * E>(vg, a.g ? a.n1g : a.b);
         lds_stage_ld<256, 2 * E>(vn, a.g ? a.n1b : a.b);
-        lds_stage_st<256, 2 * E * E>(sW, vw);
+        // the weight goes into LDS TRANSPOSED, sW[k][n]: lane q then reads its eight outputs' weights of one k as 32 consecutive bytes, the
+        // LPP lanes of a pixel 32 bytes apart -- conflict-free.  Row-major (sW[n][k], lane q on rows 8q .. 8q+7) the lanes of a pixel were
+        // 8 E dwords apart = on the SAME banks: SQ_LDS_BANK_CONFLICT was 3 x the kernel's LDS time at E = 32 (52 of its 68 us)
+#pragma unroll
+        for (int k = 0; k < (2 * E * E + 255) / 256; ++k) {
+            const int i = k * 256 + threadIdx.x;
+            if (i < 2 * E * E) sW[(i % E) * (2 * E) + i / E] = vw[k];
+        }
         lds_stage_st<256, 2 * E>(sB, vb);
         lds_stage_st<256, 2 * E>(sNg, vg);
         lds_stage_st<256, 2 * E>(sNb, vn);
@@ -268,13 +276,15 @@ __global__ __launch_bounds__(256) void k_down(DownArgs a) {
     }
     float o[NO];
 #pragma unroll
-    for (int j = 0; j < NO; ++j) {
-        const int n = NO * q + j;
-        float v = 0.f;
+    for (int j = 0; j < NO; ++j) o[j] = 0.f;
 #pragma unroll
-        for (int k = 0; k < E; ++k) v += sW[n * E + k] * u[k];
-        o[j] = v + sB[n];
+    for (int k = 0; k < E; ++k) {
+        const float4 w0 = *reinterpret_cast<const float4*>(sW + k * (2 * E) + NO * q), w1 = *reinterpret_cast<const float4*>(sW + k * (2 * E) + NO * q + 4);
+        o[0] += w0.x * u[k]; o[1] += w0.y * u[k]; o[2] += w0.z * u[k]; o[3] += w0.w * u[k];
+        o[4] += w1.x * u[k]; o[5] += w1.y * u[k]; o[6] += w1.z * u[k]; o[7] += w1.w * u[k];
     }
+#pragma unroll
+    for (int j = 0; j < NO; ++j) o[j] += sB[NO * q + j];
     if (pv) {
         float4* yo = reinterpret_cast<float4*>(a.y + p * (2 * E) + NO * q);
         yo[0] = make_float4(o[0], o[1], o[2], o[3]);
