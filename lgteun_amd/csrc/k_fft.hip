@@ -69,7 +69,13 @@ __device__ __forceinline__ void fft_butterflies(float2 (&v)[1 << S], const float
 // 3 times per 1-D transform (7 = 3 + 3 + 1 stages at n = 128) instead of 7.
 // Lines: `nlines` transforms of length n = 2^lg; element i of line l sits at buf[l * ls + i * es].
 // SKIP (square in-LDS planes only): lines are columns in bit-reversed kx order; columns with kx > n/2 are not needed.
-template <bool INVERSE, bool SKIP, int S, bool LINESFAST = false>
+// position of element p of a line inside a row tile of the split path (SWZ): the element's 32-block keeps its place, the position inside the block
+// is rotated by the block's number.  Any fixed permutation of a line leaves the passes conflict-free (all lanes of a wave touch the same element of
+// DIFFERENT lines, a conflict-free pitch apart); this one also spreads over all banks what the staging loops touch with consecutive lanes: 32
+// consecutive elements, and the bit-reversed images of 32 consecutive bins (8 m + c becomes 8 m + c + (m >> 2): 32 different residues mod 32)
+template <bool SWZ>
+__device__ __forceinline__ int fft_pos(int p) { return SWZ ? ((p & ~31) | ((p + (p >> 5)) & 31)) : p; }
+template <bool INVERSE, bool SKIP, int S, bool LINESFAST = false, bool SWZ = false>
 __device__ __forceinline__ void fft_fused(float2* buf, const float2* tw, int lg, int lgnl, int ls, int es, int st) {
     const int nlines = 1 << lgnl;
     constexpr int R = 1 << S;
@@ -93,10 +99,10 @@ __device__ __forceinline__ void fft_fused(float2* buf, const float2* tw, int lg,
         float2* base = buf + line * ls;
         float2 v[R];
 #pragma unroll
-        for (int c = 0; c < R; ++c) v[c] = base[(i_base + (c << lgmL)) * es];
+        for (int c = 0; c < R; ++c) v[c] = base[fft_pos<SWZ>(i_base + (c << lgmL)) * es];
         fft_butterflies<INVERSE, S>(v, tw, lo, lgmL, lg);
 #pragma unroll
-        for (int c = 0; c < R; ++c) base[(i_base + (c << lgmL)) * es] = v[c];
+        for (int c = 0; c < R; ++c) base[fft_pos<SWZ>(i_base + (c << lgmL)) * es] = v[c];
     }
     __syncthreads();
 }
@@ -146,7 +152,7 @@ __device__ __forceinline__ void fft_rows_inv_first(float2* buf, const float2* tw
 // full 1-D transform of every line in ceil(lg / 4) LDS passes of up to four fused radix-2 stages (16 points per thread in
 // registers): 7 = 4 + 3, 6 = 3 + 3, 8 = 4 + 4, 9 = 3 + 3 + 3.  Every pass costs one read and one write of the plane plus a
 // barrier, so at n = 128 a transform is 2 passes instead of the 3 of the (3, 3, 1) grouping.
-template <bool INVERSE, bool SKIP, bool LINESFAST = false, bool HERMFIRST = false>
+template <bool INVERSE, bool SKIP, bool LINESFAST = false, bool HERMFIRST = false, bool SWZ = false>
 __device__ __forceinline__ void fft_lines(float2* buf, const float2* tw, int lg, int lgnl, int ls, int es) {
     const int npass = (lg + 3) >> 2, base = lg / npass, extra = lg - base * npass;
     int st = 0;
@@ -157,10 +163,10 @@ __device__ __forceinline__ void fft_lines(float2* buf, const float2* tw, int lg,
             else if (S == 3) fft_rows_inv_first<3>(buf, tw, lg, ls);
             else if (S == 2) fft_rows_inv_first<2>(buf, tw, lg, ls);
             else fft_rows_inv_first<1>(buf, tw, lg, ls);
-        } else if (S == 4) fft_fused<INVERSE, SKIP, 4, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
-        else if (S == 3) fft_fused<INVERSE, SKIP, 3, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
-        else if (S == 2) fft_fused<INVERSE, SKIP, 2, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
-        else fft_fused<INVERSE, SKIP, 1, LINESFAST>(buf, tw, lg, lgnl, ls, es, st);
+        } else if (S == 4) fft_fused<INVERSE, SKIP, 4, LINESFAST, SWZ>(buf, tw, lg, lgnl, ls, es, st);
+        else if (S == 3) fft_fused<INVERSE, SKIP, 3, LINESFAST, SWZ>(buf, tw, lg, lgnl, ls, es, st);
+        else if (S == 2) fft_fused<INVERSE, SKIP, 2, LINESFAST, SWZ>(buf, tw, lg, lgnl, ls, es, st);
+        else fft_fused<INVERSE, SKIP, 1, LINESFAST, SWZ>(buf, tw, lg, lgnl, ls, es, st);
         st += S;
     }
 }
@@ -340,15 +346,17 @@ __global__ void k_fft_rows_fwd(const float* __restrict__ in, const float* __rest
             float4 t = v[k];
             if (mul) { t.x *= m[k].x; t.y *= m[k].y; t.z *= m[k].z; t.w *= m[k].w; }
             const int i4 = threadIdx.x + FFT_ROWS_NT * k;              // float4 index of the tile: row i4 / (n / 4), columns 4 (i4 % (n / 4)) ...
-            float2* dst = buf + (i4 / (n / 4)) * LD + 4 * (i4 % (n / 4));
-            dst[0] = make_float2(t.x, 0.0f); dst[1] = make_float2(t.y, 0.0f); dst[2] = make_float2(t.z, 0.0f); dst[3] = make_float2(t.w, 0.0f);
+            const int c0 = 4 * (i4 % (n / 4));
+            float2* row = buf + (i4 / (n / 4)) * LD;
+            row[fft_pos<true>(c0)] = make_float2(t.x, 0.0f); row[fft_pos<true>(c0 + 1)] = make_float2(t.y, 0.0f);
+            row[fft_pos<true>(c0 + 2)] = make_float2(t.z, 0.0f); row[fft_pos<true>(c0 + 3)] = make_float2(t.w, 0.0f);
         }
     }
     __syncthreads();
-    fft_lines<false, false, true>(buf, tw, lg, lgR, LD, 1);
+    fft_lines<false, false, true, false, true>(buf, tw, lg, lgR, LD, 1);
     for (int i = threadIdx.x; i < R * (half + 1); i += blockDim.x) {
         const int r = i / (half + 1), kx = i - r * (half + 1);
-        float2 v = buf[r * LD + (int)(__brev((unsigned)kx) >> (32 - lg))];
+        float2 v = buf[r * LD + fft_pos<true>((int)(__brev((unsigned)kx) >> (32 - lg)))];
         if (force_real && (kx == 0 || kx == half)) v.y = 0.0f;
         S[(plane * n + row0 + r) * (half + 1) + kx] = v;
     }
@@ -471,25 +479,26 @@ __global__ void k_fft_rows_inv(const float2* __restrict__ S, float* __restrict__
             const int i = threadIdx.x + FFT_ROWS_NT * k;
             if (i < total) {
                 const int r = i / (half + 1), kx = i - r * (half + 1);
-                const int p = (int)(__brev((unsigned)kx) >> (32 - lg));
+                const int p = fft_pos<true>((int)(__brev((unsigned)kx) >> (32 - lg)));
                 if (kx == 0 || kx == half) {
                     buf[r * LD + p] = make_float2(v[k].x, 0.0f);           // c2r drops these imaginary parts
                 } else {
                     buf[r * LD + p] = v[k];
-                    buf[r * LD + (int)(__brev((unsigned)(n - kx)) >> (32 - lg))] = make_float2(v[k].x, -v[k].y);
+                    buf[r * LD + fft_pos<true>((int)(__brev((unsigned)(n - kx)) >> (32 - lg)))] = make_float2(v[k].x, -v[k].y);
                 }
             }
         }
     }
     __syncthreads();
-    fft_lines<true, false, true>(buf, tw, lg, lgR, LD, 1);
+    fft_lines<true, false, true, false, true>(buf, tw, lg, lgR, LD, 1);
     const float sc = 1.0f / ((float)n * (float)n);
     const size_t base = (plane * n + row0) * n;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {   // 8 192 reals = four 16-byte stores per thread
         const int i4 = threadIdx.x + FFT_ROWS_NT * k;
-        const float2* src = buf + (i4 / (n / 4)) * LD + 4 * (i4 % (n / 4));
-        const float v[4] = {src[0].x * sc, src[1].x * sc, src[2].x * sc, src[3].x * sc};
+        const float2* row = buf + (i4 / (n / 4)) * LD;
+        const int c0 = 4 * (i4 % (n / 4));
+        const float v[4] = {row[fft_pos<true>(c0)].x * sc, row[fft_pos<true>(c0 + 1)].x * sc, row[fft_pos<true>(c0 + 2)].x * sc, row[fft_pos<true>(c0 + 3)].x * sc};
         if (absout) {
             reinterpret_cast<float4*>(out + base)[i4] = make_float4(fabsf(v[0]), fabsf(v[1]), fabsf(v[2]), fabsf(v[3]));
             if (sgn) {
