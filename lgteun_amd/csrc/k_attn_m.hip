@@ -1,0 +1,452 @@
+// Local (window) mixer + LGMixer projection + residual on the gfx950 MATRIX pipe (round 5).
+// Reference: models/common/LGT.py:112-146 (local_mixer), 183-219 (LGMixer), 45-61,231-248 (pre_norm / residual).
+//
+// One wavefront = one 8x8 window.  Every product of the half-block is an MFMA -- to_qkv, Q K^T, P V and proj -- and NO activation
+// crosses LDS: one lane map carries the window through all four products.
+//
+//   lane l = (g = l >> 4, c = l & 15);  token tile t = 0..3: token 16 t + c (window row 2 t + (c >> 3), column c & 7);
+//   of its token a lane holds the 16-byte channel chunks {4 m + g}: channels 16 m + 4 g .. + 3.
+//
+// That is (a) a coalesced 16-byte access per lane and chunk for x, the residual and y, (b) the B operand of v_mfma_f32_16x16x32
+// when the WEIGHTS sit on the A side -- lane (g, c) supplies k-slots 8 g .. 8 g + 7 of column c, and which (channel, piece) a slot
+// means is ours to choose as long as the weight fragment agrees -- and (c) the C layout of such a product: rows 4 g + v, column c.
+// So proj's output lands on the lanes that hold the residual x, and, with the rows of to_qkv's weight tiles PERMUTED so that row
+// 4 g + v is a q / k channel of group g's share of the head dimension, q and k of a token come out in the lane that will feed them
+// to Q K^T as k-slots (the sum over the four lane groups is the sum over the head dimension).  v is made by the same instruction
+// with the operand roles swapped (A = LN(x) fragment, B = Wv^T): C = [token 4 g + v][channel c], which is exactly the A operand of
+// O^T = V^T P^T (row = channel on the lane, k = keys in the lane's registers) -- and the scores S^T = K Q^T leave the matrix pipe as
+// [key 4 g + v][query c], exactly P^T's B operand.  O^T's C layout is again (channel chunk g, token c): the cat(o1, o2) fragment
+// of proj.  Softmax: 16 in-lane values per (head, query tile) and two v_permlane*_swap steps across the lane groups.
+//
+// Arithmetic (NP = 3, the default): to_qkv, Q K^T and proj in the split-bf16 form of split_bf16.h (every fp32 operand = three bf16
+// pieces, six piece products, fp32 accumulation -- at the head dimension of the 4-band net all six products of a score tile are ONE
+// 32-deep instruction); P V on the f16 pipe with TWO pieces per operand: p in (0, 2^11] and v scaled by a per-window power of two
+// into f16's range are each hi + lo with |lo| <= 2^-12 |hi| (round-to-nearest twice = 24 significant bits, v_fma_mix_f32 forms
+// the residual in one instruction), three piece products.  pos_emb enters as the initial accumulator of the score tile.
+// NP = 1 (precision = 'bf16'): one round-to-nearest piece everywhere.
+#include "kernels.h"
+#include "split_bf16.h"
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+namespace am {
+
+// piece tables of the six products (small terms are summed by the matrix core in its own order)
+__host__ __device__ constexpr int pw(int prod) { return prod == 0 ? 1 : prod == 1 ? 1 : prod == 2 ? 2 : prod == 3 ? 1 : prod == 4 ? 3 : 2; }   // A side
+__host__ __device__ constexpr int px(int prod) { return prod == 0 ? 1 : prod == 1 ? 2 : prod == 2 ? 1 : prod == 3 ? 3 : prod == 4 ? 1 : 2; }   // B side
+__host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float xg_sum(float v) {   // sum over the four lane groups (lanes c, c + 16, c + 32, c + 48); every lane gets it
+    u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r.x) + __uint_as_float(r.y);
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float xg_max(float v) {
+    u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+}
+__device__ __forceinline__ float wave_max(float v) {   // max over all 64 lanes
+    v = xg_max(v);
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// fp32 patterns whose high halves are the bf16 pieces of v (NP = 3: exact three-way split; NP = 1: round to nearest)
+template <int NP>
+struct Pat { uint32_t p[3]; };
+template <int NP>
+__device__ __forceinline__ Pat<NP> pat_of(float v) {
+    Pat<NP> r;
+    if (NP == 3) {
+        const Split3 s = split3(v);
+        r.p[0] = s.p1; r.p[1] = s.p2; r.p[2] = s.p3;
+    } else {
+        const __bf16 h = (__bf16)v;
+        r.p[0] = (uint32_t)__builtin_bit_cast(uint16_t, h) << 16; r.p[1] = 0; r.p[2] = 0;
+    }
+    return r;
+}
+
+// f16 pairs: round to nearest, and the exact residual a - f16(a) in one instruction each (v_fma_mix_f32)
+__device__ __forceinline__ uint32_t cvt_f16x2(float a, float b) {
+    const f16x2_t h = {(_Float16)a, (_Float16)b};   // v_cvt_pk_f16_f32
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ float res_lo(uint32_t h, float a) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float res_hi(uint32_t h, float b) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ f32x4_t mfma_bf(u32x4_t a, u32x4_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t mfma_h(u32x4_t a, u32x4_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+// Operand fragment k of a lane that holds CH channels as piece patterns pat[ch].p[piece]: slot s = 8 k + j means product s / CH
+// (piece table A or B side) of channel s % CH; slots past the last product are zero.  CH = 1: a dword pairs two products of the one
+// channel; CH >= 2: a dword is a channel pair of one product.
+template <int NP, int CH, bool ASIDE>
+__device__ __forceinline__ u32x4_t build_frag(const Pat<NP> (&pat)[CH], int k) {
+    constexpr int NPROD = NP == 3 ? 6 : 1;
+    uint32_t d[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s = 8 * k + 2 * i;
+        if constexpr (CH == 1) {
+            const int p0 = s, p1 = s + 1;
+            const uint32_t lo = p0 < NPROD ? pat[0].p[(ASIDE ? pw(p0) : px(p0)) - 1] : 0u;
+            const uint32_t hi = p1 < NPROD ? pat[0].p[(ASIDE ? pw(p1) : px(p1)) - 1] : 0u;
+            d[i] = (p0 < NPROD) ? pack_hi16(lo, hi) : 0u;
+        } else {
+            const int prod = s / CH, ch = s % CH;
+            if (prod < NPROD) {
+                const int pc = (ASIDE ? pw(prod) : px(prod)) - 1;
+                d[i] = pack_hi16(pat[ch].p[pc], pat[ch + 1].p[pc]);
+            } else d[i] = 0u;
+        }
+    }
+    return (u32x4_t){d[0], d[1], d[2], d[3]};
+}
+
+// Weight fragments, staged once per workgroup in LDS as [tile][k][lane] 16-byte units (a conflict-free ds_read_b128 per use).
+// Element (lane = (g, r), slot s = 8 k + j) of tile `tile`: product s / CH (A-side piece table: the weights are always the "W" factor),
+// input channel 16 (chl >> 2) + 4 g + (chl & 3) with chl = s % CH -- the lane map of the activation fragments -- of output channel
+// oc_of(tile, r) (negative: a zero row).  ALL threads of the block call it.
+template <int NP, int CH, int NK, class OC>
+__device__ __forceinline__ void stage_w(u32x4_t* dst, const float* __restrict__ W, int ldw, int kdim, int ntile, OC oc_of) {
+    constexpr int NPROD = NP == 3 ? 6 : 1;
+    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
+    const int total = ntile * NK * 256;
+    for (int u = threadIdx.x; u < total; u += 256) {
+        const int i = u & 3, ln = (u >> 2) & 63, f = u >> 8;
+        const int k = f % NK, tile = f / NK;
+        const int s = 8 * k + 2 * i, prod = s / CH, chl = s % CH;
+        const int oc = oc_of(tile, ln & 15);
+        const int ic = 16 * (chl >> 2) + 4 * (ln >> 4) + (chl & 3);
+        uint32_t val = 0;
+        if (prod < NPROD && oc >= 0 && ic < kdim) {
+            const int pc = pw(prod) - 1;
+            const Pat<NP> a0 = pat_of<NP>(W[(size_t)oc * ldw + ic]), a1 = pat_of<NP>(W[(size_t)oc * ldw + ic + 1]);
+            val = pc == 0 ? pack_hi16(a0.p[0], a1.p[0]) : (pc == 1 ? pack_hi16(a0.p[1], a1.p[1]) : pack_hi16(a0.p[2], a1.p[2]));   // (no runtime index: that is scratch)
+        }
+        d32[u] = val;
+    }
+}
+
+template <int HC>
+struct Geo {
+    static constexpr int E = 2 * HC, D = HC / 2, DG = D / 4;      // DG: channels of a head that one lane group owns
+    static constexpr int NCH = E / 16;                            // 16-byte chunks of x / cat / y per lane and token
+    static constexpr int NY = HC >= 16 ? HC / 16 : 1;             // chunks of the local half per lane (HC = 8: lane groups 0, 1 only)
+    static constexpr int MTQK = D / 4;                            // row tiles of the q / k part of to_qkv
+    static constexpr int NTV = HC >= 16 ? HC / 16 : 1;            // column tiles of its v part
+    // q / k row `idx` = 4 mt + v of lane group gq: (is_q, head, dd) with head-dimension index gq * DG + dd
+    __host__ __device__ static constexpr int qk_oc(int mt, int r) {
+        const int gq = r >> 2, idx = mt * 4 + (r & 3);
+        const int isq = idx / (2 * DG), h = (idx / DG) % 2, dd = idx % DG;
+        return (isq ? 0 : HC) + h * D + gq * DG + dd;
+    }
+    __host__ __device__ static constexpr int v_oc(int nt, int c) { return (HC == 8 && c >= 8) ? -1 : 2 * HC + 16 * nt + c; }
+};
+
+}  // namespace am
+
+template <int HC, int NP>
+__global__ __launch_bounds__(256) void k_attn_m(AttnArgs a, int nwin, int nquads) {
+    using namespace am;
+    using G = Geo<HC>;
+    constexpr int E = G::E, D = G::D, DG = G::DG, NCH = G::NCH, NY = G::NY, MTQK = G::MTQK, NTV = G::NTV;
+    constexpr int NPROD = NP == 3 ? 6 : 1;
+    constexpr int CHY = 4 * NY, NKQ = cdiv(NPROD * CHY, 8);       // to_qkv: channels per lane, instructions per output tile
+    constexpr int NKS = cdiv(NPROD * DG, 8);                      // Q K^T: instructions per 16 x 16 score tile
+    constexpr int CHC = 4 * NCH, NKP = cdiv(NPROD * CHC, 8);      // proj
+    constexpr int MTP = NCH;
+    constexpr int NPV = NP == 3 ? 2 : 1;                          // f16 pieces of p and v
+    constexpr bool RELOADX = HC >= 32;                            // the residual x is read again (L2) instead of held across the window
+    constexpr float LOG2E = 1.44269504088896340736f;
+    extern __shared__ __attribute__((aligned(16))) u32x4_t smem4[];
+    float4* sPos = reinterpret_cast<float4*>(smem4);              // [2][4 qt][4 kt][64 lanes]: the score tile's initial accumulator
+    u32x4_t* sWqk = smem4 + 2 * 4 * 4 * 64;                       // [MTQK][NKQ][64]
+    u32x4_t* sWv = sWqk + MTQK * NKQ * 64;                        // [NTV][NKQ][64]
+    u32x4_t* sWp = sWv + NTV * NKQ * 64;                          // [MTP][NKP][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+
+    // ---- once per (persistent) workgroup: pos_emb in fragment order, the weight fragments
+    for (int u = threadIdx.x; u < 2 * 4 * 4 * 64; u += 256) {
+        const int ln = u & 63, kt = (u >> 6) & 3, qt = (u >> 8) & 3, h = u >> 10;
+        const float4 v = *reinterpret_cast<const float4*>(a.pos + ((h * 64 + 16 * qt + (ln & 15)) * 64 + 16 * kt + 4 * (ln >> 4)));
+        sPos[u] = make_float4(v.x * LOG2E, v.y * LOG2E, v.z * LOG2E, v.w * LOG2E);   // scores live in the log2 domain
+    }
+    stage_w<NP, CHY, NKQ>(sWqk, a.qkvw, HC, HC, MTQK, [](int t, int r) { return G::qk_oc(t, r); });
+    stage_w<NP, CHY, NKQ>(sWv, a.qkvw, HC, HC, NTV, [](int t, int r) { return G::v_oc(t, r); });
+    stage_w<NP, CHC, NKP>(sWp, a.projw, E, E, MTP, [](int t, int r) { return 16 * t + r; });
+    // lane constants: biases as initial accumulators, LayerNorm affine of the lane's local-half channels
+    float bqk[MTQK][4], bv[NTV], bp[MTP][4], gam[CHY], bet[CHY];
+#pragma unroll
+    for (int mt = 0; mt < MTQK; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) bqk[mt][v] = a.qkvb[G::qk_oc(mt, 4 * g + v)];
+#pragma unroll
+    for (int nt = 0; nt < NTV; ++nt) { const int oc = G::v_oc(nt, c); bv[nt] = oc >= 0 ? a.qkvb[oc] : 0.f; }
+#pragma unroll
+    for (int mt = 0; mt < MTP; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) bp[mt][v] = a.projb[16 * mt + 4 * g + v];
+#pragma unroll
+    for (int i = 0; i < CHY; ++i) { const int ch = 16 * (i >> 2) + 4 * g + (i & 3); gam[i] = a.ln1g[ch]; bet[i] = a.ln1b[ch]; }
+    __syncthreads();
+
+    const int nwx = a.w >> 3, nwy = a.h >> 3;
+    const long hw = (long)a.h * a.w;
+    const float qscale = (float)(1.0 / sqrt((double)D)) * LOG2E;
+
+    for (int quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
+        const int win = quad * 4 + wave;
+        if (win >= nwin) continue;   // no barrier inside the loop
+        const int wx = win % nwx, rr = win / nwx, wy = rr % nwy;
+        const long b = rr / nwy;
+        const long pix0 = (b * a.h + wy * 8 + (c >> 3)) * a.w + wx * 8 + (c & 7);   // token tile t: pix0 + 2 t w
+
+        // ---- x, LayerNorm, y1 fragments, to_qkv
+        float4 xv[4][NCH];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m = 0; m < NCH; ++m) xv[t][m] = *reinterpret_cast<const float4*>(a.x + (pix0 + 2 * t * a.w) * E + 16 * m + 4 * g);
+
+        float qk[4][4 * MTQK];                   // the lane's q / k channels of token 16 t + c: idx = ((is_q 2 + head) DG + dd)
+        float vv[4][NTV][4];                     // V[token 16 t + 4 g + v][channel (nt, c)]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < NCH; ++m) s += (xv[t][m].x + xv[t][m].y) + (xv[t][m].z + xv[t][m].w);
+            const float mu = xg_sum(s) * (1.0f / E);
+            float q = 0.f;
+#pragma unroll
+            for (int m = 0; m < NCH; ++m) {
+                const float d0 = xv[t][m].x - mu, d1 = xv[t][m].y - mu, d2 = xv[t][m].z - mu, d3 = xv[t][m].w - mu;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            const float rstd = __builtin_amdgcn_rsqf(xg_sum(q) * (1.0f / E) + LG_EPS);
+            Pat<NP> yp[CHY];
+#pragma unroll
+            for (int m = 0; m < NY; ++m) {
+                const float xs[4] = {xv[t][m].x, xv[t][m].y, xv[t][m].z, xv[t][m].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) yp[4 * m + i] = pat_of<NP>((xs[i] - mu) * rstd * gam[4 * m + i] + bet[4 * m + i]);
+            }
+            u32x4_t yf[NKQ];
+#pragma unroll
+            for (int k = 0; k < NKQ; ++k) yf[k] = build_frag<NP, CHY, false>(yp, k);
+            // q / k: weights on the A side -> [channel row 4 g + v][token c]
+#pragma unroll
+            for (int mt = 0; mt < MTQK; ++mt) {
+                f32x4_t acc = {bqk[mt][0], bqk[mt][1], bqk[mt][2], bqk[mt][3]};
+#pragma unroll
+                for (int k = 0; k < NKQ; ++k) acc = mfma_bf(sWqk[(mt * NKQ + k) * 64 + lane], yf[k], acc);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) qk[t][4 * mt + v] = acc[v];
+            }
+            // v: the same y1 fragment on the A side -> [token row 4 g + v][channel c]
+#pragma unroll
+            for (int nt = 0; nt < NTV; ++nt) {
+                f32x4_t acc = {bv[nt], bv[nt], bv[nt], bv[nt]};
+#pragma unroll
+                for (int k = 0; k < NKQ; ++k) acc = mfma_bf(yf[k], sWv[(nt * NKQ + k) * 64 + lane], acc);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) vv[t][nt][v] = acc[v];
+            }
+        }
+
+        // ---- cat(o1, o2) of the lane: the FFT-mixer chunks (channels >= HC) are requested now, the o1 chunks are filled per head below
+        float cat[4][NCH][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m = 0; m < NCH; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ch = 16 * m + 4 * g + i - HC;   // channel of o2 (negative: an o1 chunk)
+                    cat[t][m][i] = 0.f;
+                    if (16 * m + 12 + 3 >= HC) {              // the chunk can be an o2 chunk for some lane group
+                        if (ch >= 0) cat[t][m][i] = a.o2[(b * HC + ch) * hw + (pix0 - b * hw) + 2 * t * a.w];
+                    }
+                }
+
+        // ---- V^T fragments: f16 pieces of v 2^sh, the power of two that puts the window's largest |v| into [2^14, 2^15)
+        float vmax = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NTV; ++nt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) vmax = fmaxf(vmax, fabsf(vv[t][nt][v]));
+        vmax = wave_max(vmax);
+        const int sh = 15 - __builtin_amdgcn_frexp_expf(vmax);   // vmax = f 2^e, f in [0.5, 1): |v| 2^sh < 2^15
+        u32x4_t Vf[NTV][2][NPV];                                 // [column tile][k step][piece]; k-slot j of step s2: token tile 2 s2 + (j >> 2), row 4 g + (j & 3)
+#pragma unroll
+        for (int nt = 0; nt < NTV; ++nt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float w8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w8[j] = __builtin_amdgcn_ldexpf(vv[2 * s2 + (j >> 2)][nt][j & 3], sh);
+                uint32_t hi[4], lo[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    hi[i] = cvt_f16x2(w8[2 * i], w8[2 * i + 1]);
+                    if (NPV == 2) lo[i] = cvt_f16x2(res_lo(hi[i], w8[2 * i]), res_hi(hi[i], w8[2 * i + 1]));
+                }
+                Vf[nt][s2][0] = (u32x4_t){hi[0], hi[1], hi[2], hi[3]};
+                if (NPV == 2) Vf[nt][s2][1] = (u32x4_t){lo[0], lo[1], lo[2], lo[3]};
+            }
+
+        // ---- per head: Q K^T operand fragments from the lane's own q / k channels, then per query tile scores, softmax, P V
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4_t Kf[4][NKS], Qf[4][NKS];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                Pat<NP> kp[DG], qp[DG];
+#pragma unroll
+                for (int dd = 0; dd < DG; ++dd) {
+                    kp[dd] = pat_of<NP>(qk[t][h * DG + dd]);
+                    qp[dd] = pat_of<NP>(qk[t][(2 + h) * DG + dd] * qscale);
+                }
+#pragma unroll
+                for (int k = 0; k < NKS; ++k) {
+                    Kf[t][k] = build_frag<NP, DG, true>(kp, k);
+                    Qf[t][k] = build_frag<NP, DG, false>(qp, k);
+                }
+            }
+            // rows 4 g + v of O^T belong to this head on these lanes (HC = 8: channel chunk g of head g; HC = 16: chunks 0, 1 | 2, 3; HC = 32: column tile h)
+            const bool mine = HC >= 32 ? true : (HC == 8 ? (g == h) : ((g >> 1) == h));
+            const int mo = HC >= 32 ? h : 0;    // cat chunk that receives them
+            const int nt = HC >= 32 ? h : 0;
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                f32x4_t S[4];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const float4 p4 = sPos[((h * 4 + qt) * 4 + kt) * 64 + lane];
+                    S[kt] = (f32x4_t){p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+                    for (int k = 0; k < NKS; ++k) S[kt] = mfma_bf(Kf[kt][k], Qf[qt][k], S[kt]);
+                }
+                float mx = fmaxf(fmaxf(S[0][0], S[0][1]), fmaxf(S[0][2], S[0][3]));
+#pragma unroll
+                for (int kt = 1; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(S[kt][0], S[kt][1]), fmaxf(S[kt][2], S[kt][3])));
+                mx = xg_max(mx) - 11.0f;     // p = 2^(s - max + 11) in (0, 2^11]: f16's normal range also holds the low piece of the large ones
+                float l = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { S[kt][v] = __builtin_amdgcn_exp2f(S[kt][v] - mx); l += S[kt][v]; }
+                const float f = __builtin_amdgcn_ldexpf(__builtin_amdgcn_rcpf(xg_sum(l)), -sh);
+                // O^T[channel][query] += V^T[channel][key] P^T[key][query]
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    uint32_t hi[4], lo[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float p0 = S[2 * s2 + (i >> 1)][2 * (i & 1)], p1 = S[2 * s2 + (i >> 1)][2 * (i & 1) + 1];
+                        hi[i] = cvt_f16x2(p0, p1);
+                        if (NPV == 2) lo[i] = cvt_f16x2(res_lo(hi[i], p0), res_hi(hi[i], p1));
+                    }
+                    const u32x4_t ph = {hi[0], hi[1], hi[2], hi[3]};
+                    if (NPV == 2) {
+                        const u32x4_t pl = {lo[0], lo[1], lo[2], lo[3]};
+                        acc = mfma_h(Vf[nt][s2][1], ph, acc);
+                        acc = mfma_h(Vf[nt][s2][0], pl, acc);
+                    }
+                    acc = mfma_h(Vf[nt][s2][0], ph, acc);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) cat[qt][mo][v] = mine ? acc[v] * f : cat[qt][mo][v];
+            }
+        }
+
+        // ---- proj -> dropout -> + x
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            const long pix = pix0 + 2 * qt * a.w;
+            Pat<NP> cp[CHC];
+#pragma unroll
+            for (int m = 0; m < NCH; ++m)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) cp[4 * m + v] = pat_of<NP>(cat[qt][m][v]);
+            u32x4_t cf[NKP];
+#pragma unroll
+            for (int k = 0; k < NKP; ++k) cf[k] = build_frag<NP, CHC, false>(cp, k);
+#pragma unroll
+            for (int mt = 0; mt < MTP; ++mt) {
+                f32x4_t acc = {bp[mt][0], bp[mt][1], bp[mt][2], bp[mt][3]};
+#pragma unroll
+                for (int k = 0; k < NKP; ++k) acc = mfma_bf(sWp[(mt * NKP + k) * 64 + lane], cf[k], acc);
+                float o[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    o[v] = acc[v];
+                    if (a.dropout) o[v] *= dropout_scale(a.seed, (uint64_t)(pix * E + 16 * mt + 4 * g + v));
+                }
+                const float4 xr = RELOADX ? *reinterpret_cast<const float4*>(a.x + pix * E + 16 * mt + 4 * g) : xv[qt][mt];
+                *reinterpret_cast<float4*>(a.y + pix * E + 16 * mt + 4 * g) = make_float4(xr.x + o[0], xr.y + o[1], xr.z + o[2], xr.w + o[3]);
+            }
+        }
+    }
+}
+
+template <int HC, int NP>
+static int launch_attn_m_t(const AttnArgs& a, hipStream_t s) {
+    using G = am::Geo<HC>;
+    constexpr int NPROD = NP == 3 ? 6 : 1;
+    constexpr int NKQ = am::cdiv(NPROD * 4 * G::NY, 8), NKP = am::cdiv(NPROD * 4 * G::NCH, 8);
+    const int nwin = a.B * (a.h / 8) * (a.w / 8);
+    const int nquads = (nwin + 3) / 4;
+    const size_t lds = (size_t)(2 * 4 * 4 * 64 + (G::MTQK + G::NTV) * NKQ * 64 + G::NCH * NKP * 64) * 16;
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn_m<HC, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { lg_set_error("attn_m: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_once.done();
+    }
+    // persistent grid: the workgroups that are resident at once, each walking its window quads with pos_emb and the weight fragments in LDS
+    const int per_cu = (int)((160 * 1024) / lds) < 2 ? 1 : ((int)((160 * 1024) / lds) > 3 ? 3 : (int)((160 * 1024) / lds));
+    const int cap = 256 * per_cu;
+    const int rounds = (nquads + cap - 1) / cap;
+    const int grid = nquads < cap ? nquads : (nquads + rounds - 1) / rounds;
+    k_attn_m<HC, NP><<<grid, 256, lds, s>>>(a, nwin, nquads);
+    LG_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_attn_m(int e, const AttnArgs& a, hipStream_t s) {
+    ProfScope prof__(LG_K_ATTN, s);
+    if ((a.h & 7) || (a.w & 7)) { lg_set_error("attn: h,w must be multiples of 8"); return -2; }
+    if (a.bf16) {
+        if (e == 16) return launch_attn_m_t<8, 1>(a, s);
+        if (e == 32) return launch_attn_m_t<16, 1>(a, s);
+        if (e == 64) return launch_attn_m_t<32, 1>(a, s);
+    } else {
+        if (e == 16) return launch_attn_m_t<8, 3>(a, s);
+        if (e == 32) return launch_attn_m_t<16, 3>(a, s);
+        if (e == 64) return launch_attn_m_t<32, 3>(a, s);
+    }
+    lg_set_error("attn: e=%d unsupported", e);
+    return -1;
+}

@@ -100,13 +100,16 @@ struct AttnArgs {
     const float* x;     // [B,h,w,e]
     const float* o2;    // [B,e/2,h,w] planar global-mixer output
     float* y;           // [B,h,w,e] = x + dropout(proj(cat(attn, o2)))
-    const float* posT;  // [2,64,64] transposed pos_emb: posT[h][j][i] = pos[h][i][j]
+    const float* posT;  // [2,64,64] transposed pos_emb: posT[h][j][i] = pos[h][i][j]   (k_attn, the vector-pipe kernel)
+    const float* pos;   // [2,64,64] pos_emb as stored: pos[h][i][j]                      (k_attn_m, the matrix-pipe kernel)
     const float *ln1g, *ln1b, *qkvw, *qkvb, *projw, *projb;
     int B, h, w;
     int dropout;
     uint64_t seed;
+    int bf16;           // k_attn_m: 1 = one round-to-nearest piece per operand (precision = 'bf16'), 0 = fp32-equivalent split arithmetic
 };
-int launch_attn(int e, const AttnArgs& a, hipStream_t s);
+int launch_attn(int e, const AttnArgs& a, hipStream_t s);     // round 2's kernel: lane = token, every product on the vector pipe (LG_VAR_ATTN_FWD_VALU)
+int launch_attn_m(int e, const AttnArgs& a, hipStream_t s);   // round 5: every product on the matrix pipe (k_attn_m.hip)
 // posT[blk] for nblk blocks: src pointers via offsets into params
 int launch_pos_transpose(const float* pos, float* posT, hipStream_t s);
 int launch_pos_transpose_n(int n, const float* const* pos, float* const* posT, hipStream_t s);   // n <= 5 * LG_MAX_K tables in one launch
