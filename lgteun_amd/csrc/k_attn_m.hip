@@ -37,6 +37,11 @@ __host__ __device__ constexpr int pw(int prod) { return prod == 0 ? 1 : prod == 
 __host__ __device__ constexpr int px(int prod) { return prod == 0 ? 1 : prod == 1 ? 2 : prod == 2 ? 1 : prod == 3 ? 3 : prod == 4 ? 1 : 2; }   // B side
 __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Built with -fno-honor-nans (Makefile): fmaxf() on values the compiler cannot prove canonical (matrix-core results, v_exp_f32 results)
+// otherwise gets a canonicalising v_max_f32 x, x in front of every operand (IEEE mode).  NOT inline asm: an asm statement that reads a
+// matrix-core result gets none of the wait states the hardware needs between the two (NaNs on some waves of some launches).
+__device__ __forceinline__ float vmax2(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float xg_sum(float v) {   // sum over the four lane groups (lanes c, c + 16, c + 32, c + 48); every lane gets it
     u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = __uint_as_float(r.x) + __uint_as_float(r.y);
@@ -45,14 +50,14 @@ __device__ __forceinline__ float xg_sum(float v) {   // sum over the four lane g
 }
 __device__ __forceinline__ float xg_max(float v) {
     u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+    v = vmax2(__uint_as_float(r.x), __uint_as_float(r.y));
     r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+    return vmax2(__uint_as_float(r.x), __uint_as_float(r.y));
 }
 __device__ __forceinline__ float wave_max(float v) {   // max over all 64 lanes
     v = xg_max(v);
 #pragma unroll
-    for (int o = 8; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    for (int o = 8; o >= 1; o >>= 1) v = vmax2(v, __shfl_xor(v, o));
     return v;
 }
 
@@ -165,7 +170,7 @@ struct Geo {
 }  // namespace am
 
 template <int HC, int NP>
-__global__ __launch_bounds__(256) void k_attn_m(AttnArgs a, int nwin, int nquads) {
+__global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, int nwin, int nquads) {
     using namespace am;
     using G = Geo<HC>;
     constexpr int E = G::E, D = G::D, DG = G::DG, NCH = G::NCH, NY = G::NY, MTQK = G::MTQK, NTV = G::NTV;
@@ -200,7 +205,10 @@ __global__ __launch_bounds__(256) void k_attn_m(AttnArgs a, int nwin, int nquads
 #pragma unroll
         for (int v = 0; v < 4; ++v) bqk[mt][v] = a.qkvb[G::qk_oc(mt, 4 * g + v)];
 #pragma unroll
-    for (int nt = 0; nt < NTV; ++nt) { const int oc = G::v_oc(nt, c); bv[nt] = oc >= 0 ? a.qkvb[oc] : 0.f; }
+    for (int nt = 0; nt < NTV; ++nt) { const int oc = G::v_oc(nt, c); bv[nt] = oc >= 0 ? a.qkvb[oc] : ((c & 3) == 0 ? 1.0f : 0.f); }
+    // HC = 8: the v tile has eight idle columns.  Columns 8 and 12 are ONES (zero weights, bias 1, left unscaled): rows 8 and 12 of O^T = the
+    // softmax denominators of the tile's queries, on lane groups 2 and 3 -- one v_permlane32_swap brings them to groups 0 (head 0) and 1 (head 1)
+    constexpr bool ONES = HC == 8;
 #pragma unroll
     for (int mt = 0; mt < MTP; ++mt)
 #pragma unroll
@@ -212,20 +220,27 @@ __global__ __launch_bounds__(256) void k_attn_m(AttnArgs a, int nwin, int nquads
     const int nwx = a.w >> 3, nwy = a.h >> 3;
     const long hw = (long)a.h * a.w;
     const float qscale = (float)(1.0 / sqrt((double)D)) * LOG2E;
+    const int lpix = (c >> 3) * a.w + (c & 7);       // the lane's token inside a window, tile 0
+    const int lx = lpix * E + 4 * g;                 // ... its first chunk in x / y (floats)
+    const int tstep = 2 * a.w;                       // pixels per token tile
 
     for (int quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
-        const int win = quad * 4 + wave;
+        const int win = quad * 4 + __builtin_amdgcn_readfirstlane(wave);   // provably wave-uniform: window origins stay in scalar registers
         if (win >= nwin) continue;   // no barrier inside the loop
         const int wx = win % nwx, rr = win / nwx, wy = rr % nwy;
         const long b = rr / nwy;
-        const long pix0 = (b * a.h + wy * 8 + (c >> 3)) * a.w + wx * 8 + (c & 7);   // token tile t: pix0 + 2 t w
+        const long porg = (b * a.h + wy * 8) * a.w + wx * 8;          // first pixel of the window (uniform)
+        const long pix0 = porg + lpix;                                // this lane's token of tile 0; tile t: + 2 t w
+        const float* __restrict__ xw = a.x + porg * E;                // uniform bases; lane offsets are 32-bit
+        float* __restrict__ yw = a.y + porg * E;
+        const float* __restrict__ o2w = a.o2 + b * HC * hw + (porg - b * hw);
 
         // ---- x, LayerNorm, y1 fragments, to_qkv
         float4 xv[4][NCH];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int m = 0; m < NCH; ++m) xv[t][m] = *reinterpret_cast<const float4*>(a.x + (pix0 + 2 * t * a.w) * E + 16 * m + 4 * g);
+            for (int m = 0; m < NCH; ++m) xv[t][m] = *reinterpret_cast<const float4*>(xw + (t * tstep * E + 16 * m + lx));
 
         float qk[4][4 * MTQK];                   // the lane's q / k channels of token 16 t + c: idx = ((is_q 2 + head) DG + dd)
         float vv[4][NTV][4];                     // V[token 16 t + 4 g + v][channel (nt, c)]
@@ -283,7 +298,7 @@ __global__ __launch_bounds__(256) void k_attn_m(AttnArgs a, int nwin, int nquads
                     const int ch = 16 * m + 4 * g + i - HC;   // channel of o2 (negative: an o1 chunk)
                     cat[t][m][i] = 0.f;
                     if (16 * m + 12 + 3 >= HC) {              // the chunk can be an o2 chunk for some lane group
-                        if (ch >= 0) cat[t][m][i] = a.o2[(b * HC + ch) * hw + (pix0 - b * hw) + 2 * t * a.w];
+                        if (ch >= 0) cat[t][m][i] = o2w[ch * (int)hw + t * tstep + lpix];
                     }
                 }
 
@@ -295,8 +310,10 @@ __global__ __launch_bounds__(256) void k_attn_m(AttnArgs a, int nwin, int nquads
             for (int nt = 0; nt < NTV; ++nt)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) vmax = fmaxf(vmax, fabsf(vv[t][nt][v]));
+        if (ONES && c >= 8) vmax = 0.f;
         vmax = wave_max(vmax);
         const int sh = 15 - __builtin_amdgcn_frexp_expf(vmax);   // vmax = f 2^e, f in [0.5, 1): |v| 2^sh < 2^15
+        const int shl = (ONES && c >= 8) ? 0 : sh;
         u32x4_t Vf[NTV][2][NPV];                                 // [column tile][k step][piece]; k-slot j of step s2: token tile 2 s2 + (j >> 2), row 4 g + (j & 3)
 #pragma unroll
         for (int nt = 0; nt < NTV; ++nt)
@@ -304,7 +321,7 @@ __global__ __launch_bounds__(256) void k_attn_m(AttnArgs a, int nwin, int nquads
             for (int s2 = 0; s2 < 2; ++s2) {
                 float w8[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) w8[j] = __builtin_amdgcn_ldexpf(vv[2 * s2 + (j >> 2)][nt][j & 3], sh);
+                for (int j = 0; j < 8; ++j) w8[j] = __builtin_amdgcn_ldexpf(vv[2 * s2 + (j >> 2)][nt][j & 3], shl);
                 uint32_t hi[4], lo[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -347,16 +364,17 @@ __global__ __launch_bounds__(256) void k_attn_m(AttnArgs a, int nwin, int nquads
 #pragma unroll
                     for (int k = 0; k < NKS; ++k) S[kt] = mfma_bf(Kf[kt][k], Qf[qt][k], S[kt]);
                 }
-                float mx = fmaxf(fmaxf(S[0][0], S[0][1]), fmaxf(S[0][2], S[0][3]));
-#pragma unroll
-                for (int kt = 1; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(S[kt][0], S[kt][1]), fmaxf(S[kt][2], S[kt][3])));
+                float mx = vmax3(vmax3(S[0][0], S[0][1], S[0][2]), S[0][3], S[1][0]);
+                mx = vmax3(vmax3(mx, S[1][1], S[1][2]), S[1][3], S[2][0]);
+                mx = vmax3(vmax3(mx, S[2][1], S[2][2]), S[2][3], S[3][0]);
+                mx = vmax2(vmax3(mx, S[3][1], S[3][2]), S[3][3]);
                 mx = xg_max(mx) - 11.0f;     // p = 2^(s - max + 11) in (0, 2^11]: f16's normal range also holds the low piece of the large ones
                 float l = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) { S[kt][v] = __builtin_amdgcn_exp2f(S[kt][v] - mx); l += S[kt][v]; }
-                const float f = __builtin_amdgcn_ldexpf(__builtin_amdgcn_rcpf(xg_sum(l)), -sh);
+                    for (int v = 0; v < 4; ++v) { S[kt][v] = __builtin_amdgcn_exp2f(S[kt][v] - mx); if (!ONES) l += S[kt][v]; }
+                if (!ONES) l = xg_sum(l);
                 // O^T[channel][query] += V^T[channel][key] P^T[key][query]
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -376,6 +394,11 @@ __global__ __launch_bounds__(256) void k_attn_m(AttnArgs a, int nwin, int nquads
                     }
                     acc = mfma_h(Vf[nt][s2][0], ph, acc);
                 }
+                if (ONES) {   // lanes 0 .. 31 receive acc[0] of lanes 32 .. 63: group 0 <- row 8, group 1 <- row 12
+                    const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0]), __float_as_uint(acc[0]), false, false);
+                    l = __uint_as_float(r.y);
+                }
+                const float f = __builtin_amdgcn_ldexpf(__builtin_amdgcn_rcpf(l), -sh);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) cat[qt][mo][v] = mine ? acc[v] * f : cat[qt][mo][v];
             }
@@ -399,13 +422,14 @@ __global__ __launch_bounds__(256) void k_attn_m(AttnArgs a, int nwin, int nquads
 #pragma unroll
                 for (int k = 0; k < NKP; ++k) acc = mfma_bf(sWp[(mt * NKP + k) * 64 + lane], cf[k], acc);
                 float o[4];
+                const uint64_t di = (uint64_t)(pix * E + 16 * mt + 4 * g);   // a multiple of 4: | v below never carries
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     o[v] = acc[v];
-                    if (a.dropout) o[v] *= dropout_scale(a.seed, (uint64_t)(pix * E + 16 * mt + 4 * g + v));
+                    if (a.dropout) o[v] *= dropout_scale(a.seed, di | (uint64_t)v);
                 }
-                const float4 xr = RELOADX ? *reinterpret_cast<const float4*>(a.x + pix * E + 16 * mt + 4 * g) : xv[qt][mt];
-                *reinterpret_cast<float4*>(a.y + pix * E + 16 * mt + 4 * g) = make_float4(xr.x + o[0], xr.y + o[1], xr.z + o[2], xr.w + o[3]);
+                const float4 xr = RELOADX ? *reinterpret_cast<const float4*>(xw + (qt * tstep * E + 16 * mt + lx)) : xv[qt][mt];
+                *reinterpret_cast<float4*>(yw + (qt * tstep * E + 16 * mt + lx)) = make_float4(xr.x + o[0], xr.y + o[1], xr.z + o[2], xr.w + o[3]);
             }
         }
     }
