@@ -91,11 +91,16 @@ typedef struct lg_config {
 #define LG_VAR_FFN_DWBWD_TILE (1u << 5) /* e = 16 FFN backward, spatial half: round 2's tile kernel + weight-gradient launch */
 #define LG_VAR_ATTN_BWD_R3 (1u << 6)    /* e = 16 local-mixer backward: round 3's three-kernel form instead of k_attn_bwd_f */
 #define LG_VAR_DSTEP_TILES (1u << 7)    /* data step: the tile kernels (four launches forward, nine backward) also where the one-launch form exists */
-#define LG_VAR_ALL 0xffu
+#define LG_VAR_ATTN_FWD_VALU (1u << 8)  /* local-mixer forward: round 2's vector-pipe kernel k_attn (lane = token, fp32 FMAs) instead of the matrix-pipe k_attn_m */
+#define LG_VAR_ALL 0x1ffu
 
 typedef struct lg_plan lg_plan; /* host-side, immutable after creation */
 
 const char* lg_version(void);
+/* Bumped whenever a struct layout, an argument meaning or a caller-provided buffer size changes (2: lg_config.variant, the data step's
+ * tmp of 3*B*C*H*W/4 + B*H*W floats).  A binding checks it at load time -- lgteun_amd/_lib.py does -- instead of passing a stale struct. */
+#define LG_ABI_VERSION 2
+int32_t lg_abi_version(void);
 const char* lg_last_error(void); /* thread-local, host string */
 
 /* offsets: host array of n_offsets = 12 + K + 119*K int64 (float offsets into the flat parameter buffer). */

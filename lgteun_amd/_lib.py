@@ -31,6 +31,8 @@ LG_VAR_FFN_STRIP, LG_VAR_FFN_TILE, LG_VAR_FFN_XP = 1, 2, 3
 LG_VAR_FFN_SAVE3, LG_VAR_FFN_SAVE5 = 1 << 2, 2 << 2
 LG_VAR_FFN_BWD32_XS, LG_VAR_FFN_DWBWD_TILE, LG_VAR_ATTN_BWD_R3 = 1 << 4, 1 << 5, 1 << 6
 LG_VAR_DSTEP_TILES = 1 << 7
+LG_VAR_ATTN_FWD_VALU = 1 << 8
+LG_ABI_VERSION = 2   # include/lgteun_hip.h: checked against lg_abi_version() when the library is loaded
 
 
 def variant_from_env(env=None):
@@ -47,6 +49,8 @@ def variant_from_env(env=None):
         v |= LG_VAR_ATTN_BWD_R3
     if env.get('LG_DSTEP') == 'tiles':
         v |= LG_VAR_DSTEP_TILES
+    if env.get('LG_ATTN_FWD', '') == 'valu':
+        v |= LG_VAR_ATTN_FWD_VALU
     return v
 
 
@@ -59,6 +63,7 @@ _lib = None
 # name -> (restype, argtypes); every symbol include/lgteun_hip.h declares
 SIGNATURES = {
     'lg_version': (c_char_p, []),
+    'lg_abi_version': (c_int32, []),
     'lg_last_error': (c_char_p, []),
     'lg_plan_create': (c_int32, [POINTER(LgConfig), POINTER(c_int64), c_int32, POINTER(c_void_p)]),
     'lg_plan_destroy': (None, [c_void_p]),
@@ -107,6 +112,9 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        got = int(L.lg_abi_version())
+        if got != LG_ABI_VERSION:   # a stale .so next to newer Python (or the reverse) would read structs / buffers of the other layout
+            raise LgteunHipError(f'{LIB_PATH}: ABI version {got}, this binding was written for {LG_ABI_VERSION} (include/lgteun_hip.h): rebuild with `make`')
         _lib = L
     return _lib
 

@@ -105,7 +105,8 @@ extern "C" const char* lg_kernel_name(int32_t k) {
     return (k >= 0 && k < LG_K_COUNT) ? names[k] : "?";
 }
 
-extern "C" const char* lg_version(void) { return "lgteun_hip 0.1 (gfx950)"; }
+extern "C" const char* lg_version(void) { return "lgteun_hip 0.2 (gfx950)"; }
+extern "C" int32_t lg_abi_version(void) { return LG_ABI_VERSION; }
 extern "C" const char* lg_last_error(void) { return g_err; }
 
 extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int32_t n_offsets, lg_plan** out) {
@@ -141,6 +142,7 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
         p->dwbwd_tile = (v & LG_VAR_FFN_DWBWD_TILE) ? 1 : 0;
         p->attn_bwd_old = (v & LG_VAR_ATTN_BWD_R3) ? 1 : 0;
         p->dstep_tiles = (v & LG_VAR_DSTEP_TILES) ? 1 : 0;
+        p->attn_fwd_valu = (v & LG_VAR_ATTN_FWD_VALU) ? 1 : 0;
     }
     p->off = (int64_t*)malloc(sizeof(int64_t) * n_offsets);
     memcpy(p->off, offsets, sizeof(int64_t) * n_offsets);
@@ -217,14 +219,15 @@ static int block_mixer_fwd(const lg_plan* pl, const float* P, int stage, int j, 
     f.ch = bb.e / 2; f.planes = B * f.ch; f.n = bb.h; f.h = bb.h; f.w = bb.w;
     if ((rc = launch_fftmix(f, s))) return rc;
     AttnArgs t;
-    t.x = bb.xin; t.o2 = bb.o2; t.y = bb.xmid; t.posT = posT;
+    t.x = bb.xin; t.o2 = bb.o2; t.y = bb.xmid; t.posT = posT; t.pos = P + pl->blk(stage, j, B_POS);
+    t.bf16 = pl->cfg.precision == 1 ? 1 : 0;
     t.ln1g = P + pl->blk(stage, j, B_LN1G); t.ln1b = P + pl->blk(stage, j, B_LN1B);
     t.qkvw = P + pl->blk(stage, j, B_QKVW); t.qkvb = P + pl->blk(stage, j, B_QKVB);
     t.projw = P + pl->blk(stage, j, B_PROJW); t.projb = P + pl->blk(stage, j, B_PROJB);
     t.B = B; t.h = bb.h; t.w = bb.w;
     t.dropout = (flags & LG_FLAG_DROPOUT) ? 1 : 0;
     t.seed = mix_seed(seed, stage, j);
-    return launch_attn(bb.e, t, s);
+    return pl->attn_fwd_valu ? launch_attn(bb.e, t, s) : launch_attn_m(bb.e, t, s);
 }
 
 static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, const BlockBufs& bb, float* g_next, int next_blk,

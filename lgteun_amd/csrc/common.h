@@ -45,6 +45,7 @@ struct lg_plan {
     bool hidden_bf16(int e) const { return cfg.precision == 1 && e != 64; }
     // precision = 'bf16' (plain bf16 MFMA, bf16 storage of the saved tensors) knows modes 2 and 5 only (3 falls back to 5)
     int attn_bwd_old; // A/B switch (lg_config.variant LG_VAR_ATTN_BWD_R3; Python side: LG_ATTN_BWD=r3): 1 = round 3's k_attn_bwd_core + k_attn_bwd_epi + k_wgrad_t at e = 16 instead of k_attn_bwd_f
+    int attn_fwd_valu; // A/B switch (lg_config.variant LG_VAR_ATTN_FWD_VALU; Python side: LG_ATTN_FWD=valu): round 2's vector-pipe k_attn instead of the matrix-pipe k_attn_m
     int dstep_tiles; // A/B switch (lg_config.variant LG_VAR_DSTEP_TILES; Python side: LG_DSTEP=tiles): the tile kernels of the data step also where the one-launch
                      // plane-in-LDS form (k_dstep.hip) exists
     bool dstep_fused(int h, int w) const;   // k_dstep.hip: square planes of 128 or 64

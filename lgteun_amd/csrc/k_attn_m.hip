@@ -130,24 +130,37 @@ __device__ __forceinline__ u32x4_t build_frag(const Pat<NP> (&pat)[CH], int k) {
 // Element (lane = (g, r), slot s = 8 k + j) of tile `tile`: product s / CH (A-side piece table: the weights are always the "W" factor),
 // input channel 16 (chl >> 2) + 4 g + (chl & 3) with chl = s % CH -- the lane map of the activation fragments -- of output channel
 // oc_of(tile, r) (negative: a zero row).  ALL threads of the block call it.
-template <int NP, int CH, int NK, class OC>
-__device__ __forceinline__ void stage_w(u32x4_t* dst, const float* __restrict__ W, int ldw, int kdim, int ntile, OC oc_of) {
+template <int NP, int CH, int NK, int NTILE, class OC>
+__device__ __forceinline__ void stage_w(u32x4_t* dst, const float* __restrict__ W, int ldw, int kdim, OC oc_of) {
     constexpr int NPROD = NP == 3 ? 6 : 1;
+    constexpr int NF = NTILE * NK;              // fragments; thread tid owns dword (tid & 3) of lane (tid >> 2) in every one of them
+    constexpr int CHUNK = NF < 16 ? NF : 16;    // loads in flight per thread and round (every load of a round is requested before its first store)
     uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
-    const int total = ntile * NK * 256;
-    for (int u = threadIdx.x; u < total; u += 256) {
-        const int i = u & 3, ln = (u >> 2) & 63, f = u >> 8;
-        const int k = f % NK, tile = f / NK;
-        const int s = 8 * k + 2 * i, prod = s / CH, chl = s % CH;
-        const int oc = oc_of(tile, ln & 15);
-        const int ic = 16 * (chl >> 2) + 4 * (ln >> 4) + (chl & 3);
-        uint32_t val = 0;
-        if (prod < NPROD && oc >= 0 && ic < kdim) {
-            const int pc = pw(prod) - 1;
-            const Pat<NP> a0 = pat_of<NP>(W[(size_t)oc * ldw + ic]), a1 = pat_of<NP>(W[(size_t)oc * ldw + ic + 1]);
-            val = pc == 0 ? pack_hi16(a0.p[0], a1.p[0]) : (pc == 1 ? pack_hi16(a0.p[1], a1.p[1]) : pack_hi16(a0.p[2], a1.p[2]));   // (no runtime index: that is scratch)
+    const int i = threadIdx.x & 3, ln = threadIdx.x >> 2, g = ln >> 4, r = ln & 15;
+#pragma unroll
+    for (int f0 = 0; f0 < NF; f0 += CHUNK) {
+        float w0[CHUNK], w1[CHUNK];
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j) {
+            const int f = f0 + j < NF ? f0 + j : NF - 1, k = f % NK, tile = f / NK;
+            const int s = 8 * k + 2 * i, prod = s / CH, chl = s % CH;
+            const int oc = oc_of(tile, r), ic = 16 * (chl >> 2) + 4 * g + (chl & 3);
+            const bool ok = prod < NPROD && oc >= 0 && ic < kdim;
+            const float* src = W + (ok ? (size_t)oc * ldw + ic : 0);
+            w0[j] = src[0]; w1[j] = src[1];     // unconditional (index 0, 1 for the zero slots): no exec-masked branch, no wait at a join
         }
-        d32[u] = val;
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j) {
+            if (f0 + j >= NF) break;
+            const int f = f0 + j, k = f % NK, tile = f / NK;
+            const int s = 8 * k + 2 * i, prod = s / CH, chl = s % CH;
+            const int oc = oc_of(tile, r), ic = 16 * (chl >> 2) + 4 * g + (chl & 3);
+            const bool ok = prod < NPROD && oc >= 0 && ic < kdim;
+            const int pc = pw(prod < NPROD ? prod : 0) - 1;
+            const Pat<NP> a0 = pat_of<NP>(w0[j]), a1 = pat_of<NP>(w1[j]);
+            const uint32_t val = pc == 0 ? pack_hi16(a0.p[0], a1.p[0]) : (pc == 1 ? pack_hi16(a0.p[1], a1.p[1]) : pack_hi16(a0.p[2], a1.p[2]));   // (no runtime index: that is scratch)
+            d32[f * 256 + threadIdx.x] = ok ? val : 0u;
+        }
     }
 }
 
@@ -169,6 +182,12 @@ struct Geo {
 
 }  // namespace am
 
+#ifdef LG_ATTN_STAMPS   // diagnostic build of tools/micro/attn_m_check.hip only: s_memtime ticks per phase, summed over the windows of every wave
+__device__ unsigned long long am_stamps[1024][4][8];
+#define AM_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t__ = __builtin_amdgcn_s_memtime(); st[i] += t__ - tprev; tprev = t__; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define AM_STAMP(i) do { } while (0)
+#endif
 template <int HC, int NP>
 __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, int nwin, int nquads) {
     using namespace am;
@@ -189,15 +208,24 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
     u32x4_t* sWp = sWv + NTV * NKQ * 64;                          // [MTP][NKP][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
 
+#ifdef LG_ATTN_STAMPS
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
     // ---- once per (persistent) workgroup: pos_emb in fragment order, the weight fragments
-    for (int u = threadIdx.x; u < 2 * 4 * 4 * 64; u += 256) {
-        const int ln = u & 63, kt = (u >> 6) & 3, qt = (u >> 8) & 3, h = u >> 10;
-        const float4 v = *reinterpret_cast<const float4*>(a.pos + ((h * 64 + 16 * qt + (ln & 15)) * 64 + 16 * kt + 4 * (ln >> 4)));
-        sPos[u] = make_float4(v.x * LOG2E, v.y * LOG2E, v.z * LOG2E, v.w * LOG2E);   // scores live in the log2 domain
+    {
+        float4 pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int u = j * 256 + threadIdx.x, ln = u & 63, kt = (u >> 6) & 3, qt = (u >> 8) & 3, h = u >> 10;
+            pv[j] = *reinterpret_cast<const float4*>(a.pos + ((h * 64 + 16 * qt + (ln & 15)) * 64 + 16 * kt + 4 * (ln >> 4)));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)   // scores live in the log2 domain
+            sPos[j * 256 + threadIdx.x] = make_float4(pv[j].x * LOG2E, pv[j].y * LOG2E, pv[j].z * LOG2E, pv[j].w * LOG2E);
     }
-    stage_w<NP, CHY, NKQ>(sWqk, a.qkvw, HC, HC, MTQK, [](int t, int r) { return G::qk_oc(t, r); });
-    stage_w<NP, CHY, NKQ>(sWv, a.qkvw, HC, HC, NTV, [](int t, int r) { return G::v_oc(t, r); });
-    stage_w<NP, CHC, NKP>(sWp, a.projw, E, E, MTP, [](int t, int r) { return 16 * t + r; });
+    stage_w<NP, CHY, NKQ, MTQK>(sWqk, a.qkvw, HC, HC, [](int t, int r) { return G::qk_oc(t, r); });
+    stage_w<NP, CHY, NKQ, NTV>(sWv, a.qkvw, HC, HC, [](int t, int r) { return G::v_oc(t, r); });
+    stage_w<NP, CHC, NKP, MTP>(sWp, a.projw, E, E, [](int t, int r) { return 16 * t + r; });
     // lane constants: biases as initial accumulators, LayerNorm affine of the lane's local-half channels
     float bqk[MTQK][4], bv[NTV], bp[MTP][4], gam[CHY], bet[CHY];
 #pragma unroll
@@ -216,6 +244,7 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
 #pragma unroll
     for (int i = 0; i < CHY; ++i) { const int ch = 16 * (i >> 2) + 4 * g + (i & 3); gam[i] = a.ln1g[ch]; bet[i] = a.ln1b[ch]; }
     __syncthreads();
+    AM_STAMP(0);
 
     const int nwx = a.w >> 3, nwy = a.h >> 3;
     const long hw = (long)a.h * a.w;
@@ -242,6 +271,7 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
 #pragma unroll
             for (int m = 0; m < NCH; ++m) xv[t][m] = *reinterpret_cast<const float4*>(xw + (t * tstep * E + 16 * m + lx));
 
+        AM_STAMP(1);   // window addresses + x loads issued
         float qk[4][4 * MTQK];                   // the lane's q / k channels of token 16 t + c: idx = ((is_q 2 + head) DG + dd)
         float vv[4][NTV][4];                     // V[token 16 t + 4 g + v][channel (nt, c)]
 #pragma unroll
@@ -287,6 +317,7 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
             }
         }
 
+        AM_STAMP(2);   // wait for x, LayerNorm, to_qkv
         // ---- cat(o1, o2) of the lane: the FFT-mixer chunks (channels >= HC) are requested now, the o1 chunks are filled per head below
         float cat[4][NCH][4];
 #pragma unroll
@@ -332,6 +363,7 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
                 if (NPV == 2) Vf[nt][s2][1] = (u32x4_t){lo[0], lo[1], lo[2], lo[3]};
             }
 
+        AM_STAMP(3);   // o2 requests, V^T fragments
         // ---- per head: Q K^T operand fragments from the lane's own q / k channels, then per query tile scores, softmax, P V
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -404,6 +436,7 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
             }
         }
 
+        AM_STAMP(4);   // scores, softmax, P V
         // ---- proj -> dropout -> + x
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
@@ -432,7 +465,14 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
                 *reinterpret_cast<float4*>(yw + (qt * tstep * E + 16 * mt + lx)) = make_float4(xr.x + o[0], xr.y + o[1], xr.z + o[2], xr.w + o[3]);
             }
         }
+        AM_STAMP(5);   // proj, dropout, residual, stores issued
     }
+#ifdef LG_ATTN_STAMPS
+    if (lane == 0 && blockIdx.x < 1024) {
+        for (int i = 0; i < 6; ++i) am_stamps[blockIdx.x][wave][i] = st[i];
+        am_stamps[blockIdx.x][wave][7] = 1ull;
+    }
+#endif
 }
 
 template <int HC, int NP>
@@ -449,9 +489,20 @@ static int launch_attn_m_t(const AttnArgs& a, hipStream_t s) {
         if (e != hipSuccess) { lg_set_error("attn_m: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
-    // persistent grid: the workgroups that are resident at once, each walking its window quads with pos_emb and the weight fragments in LDS
-    const int per_cu = (int)((160 * 1024) / lds) < 2 ? 1 : ((int)((160 * 1024) / lds) > 3 ? 3 : (int)((160 * 1024) / lds));
-    const int cap = 256 * per_cu;
+    // persistent grid: the workgroups that are RESIDENT at once (registers and LDS: asked of the runtime once per device), each walking its
+    // window quads with pos_emb and the weight fragments in LDS.  A larger grid runs in rounds -- 683 workgroups on 512 slots: two stagings
+    // and 2 x 3 windows per slot instead of one and 4.
+    static std::atomic<int> per_cu_cache[64];
+    int per_cu = per_cu_cache[DeviceOnce::dev()].load(std::memory_order_acquire);
+    if (per_cu <= 0) {
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_attn_m<HC, NP>, 256, lds);
+        if (e != hipSuccess || nb < 1) { lg_set_error("attn_m: occupancy query: %s (%d)", hipGetErrorString(e), nb); return e != hipSuccess ? (int)e : -3; }
+        per_cu = nb;
+        per_cu_cache[DeviceOnce::dev()].store(per_cu, std::memory_order_release);
+    }
+    int ncu = 256;
+    const int cap = ncu * per_cu;
     const int rounds = (nquads + cap - 1) / cap;
     const int grid = nquads < cap ? nquads : (nquads + rounds - 1) / rounds;
     k_attn_m<HC, NP><<<grid, 256, lds, s>>>(a, nwin, nquads);

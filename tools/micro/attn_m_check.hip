@@ -10,6 +10,7 @@
 #include <cmath>
 #include <vector>
 #include <cstdarg>
+#include <cstring>
 void lg_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 void lg_prof_begin(int, hipStream_t) {}
 void lg_prof_end(int, hipStream_t) {}
@@ -138,6 +139,25 @@ int main(int argc, char** argv) {
             float ms; CK(hipEventElapsedTime(&ms, e0_, e1_));
             printf("%s: %.2f us per launch\n", which ? "k_attn_m" : "k_attn  ", ms * 1e3 / reps);
         }
+#ifdef LG_ATTN_STAMPS
+        {   // ticks per phase, averaged over the waves of ONE launch
+            static unsigned long long all[1024][4][8];
+            memset(all, 0, sizeof all);
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(am_stamps), all, sizeof all));
+            a.y = dy; launch_attn_m(E, a, 0);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpyFromSymbol(all, HIP_SYMBOL(am_stamps), sizeof all));
+            unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int b_ = 0; b_ < 1024; ++b_) for (int w_ = 0; w_ < 4; ++w_) for (int i = 0; i < 8; ++i) st[i] += all[b_][w_][i];
+            st[7] /= 4;
+            const double nw = (double)st[7] * 4;
+            const char* nm[6] = {"staging + barrier", "window setup, x requested", "x wait, LayerNorm, to_qkv", "o2 requests, V^T fragments", "scores, softmax, P V", "proj, dropout, residual"};
+            double tot = 0;
+            for (int i = 0; i < 6; ++i) tot += st[i] / nw;
+            for (int i = 0; i < 6; ++i) printf("  stamps: %-28s %9.0f ticks per wave (%4.1f %%)\n", nm[i], st[i] / nw, 100.0 * st[i] / nw / tot);
+            printf("  stamps: %.0f workgroups, %.0f ticks per wave in all (s_memtime = 100 MHz)\n", (double)st[7], tot);
+        }
+#endif
     }
     return 0;
 }
