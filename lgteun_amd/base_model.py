@@ -225,7 +225,7 @@ class Base_model:
         def to_np(t):   # [b c h w] -> [b h w c]
             t = data_denormalize(t, self.cfg.bit_depth) if denorm else t
             return t.permute(0, 2, 3, 1).cpu().numpy()
-        res = []
+        res, ids = [], []
         for bi, input_batch in enumerate(loader or []):
             if self.world > 1 and not sharded and bi % self.world != self.rank:
                 continue
@@ -238,6 +238,7 @@ class Base_model:
             else:                                                # full-resolution set: no target (base_model.py:330-334)
                 pan_np, lr_np = to_np(input_batch['input_pan']), to_np(input_batch['input_lr'])
                 res.extend(mtc.no_ref_evaluate(out[i], pan_np[i], lr_np[i]) for i in range(out.shape[0]))
+            ids.extend(str(i) for i in input_batch.get('image_id', range(len(ids), len(ids) + out.shape[0])))
             if save:
                 for i, image_id in enumerate(input_batch['image_id']):
                     # [C, H, W] for the writer (the reference hands its HWC array to a CHW writer, base_model.py:336: a
@@ -247,8 +248,15 @@ class Base_model:
         if self.world > 1:
             import torch.distributed as dist
             rows = [None] * self.world
-            dist.all_gather_object(rows, [list(map(float, r)) for r in res])
-            res = [r for part in rows for r in part]
+            dist.all_gather_object(rows, [(i, list(map(float, r))) for i, r in zip(ids, res)])
+            # an image that reached two ranks (a PADDED sharded sampler wraps around when world does not divide the set: build the
+            # evaluation loaders with build_loader(..., evaluation=True)) is scored once, like the reference's one-process loop
+            seen, res = set(), []
+            for part in rows:
+                for i, r in part:
+                    if i not in seen:
+                        seen.add(i)
+                        res.append(r)
         if res:
             res = np.array(res)
             for k, name in enumerate(names):

@@ -311,14 +311,17 @@ def data_augmentation(img_dict, aug_dict=None, rng=None):
 class ShardedSampler(data.Sampler):
     """Rank `rank` of `world` gets an equal, disjoint slice of every epoch's order (torch DistributedSampler semantics: the order
     is padded by wrapping around so that all ranks run the same number of steps -- or truncated with drop_last).  The permutation
-    depends on (seed, epoch) only, so all ranks agree without communicating.  set_epoch(e) before each epoch."""
+    depends on (seed, epoch) only, so all ranks agree without communicating.  set_epoch(e) before each epoch.
+    pad=False is the EVALUATION form: rank r gets order[r::world] and nothing else -- every element exactly once over the ranks, which
+    then hold unequal counts when world does not divide n (a padded evaluation would score the wrapped images twice)."""
 
-    def __init__(self, n, rank=0, world=1, shuffle=True, seed=0, drop_last=False):
+    def __init__(self, n, rank=0, world=1, shuffle=True, seed=0, drop_last=False, pad=True):
         if not 0 <= rank < world:
             raise ValueError(f'rank {rank} outside world {world}')
         self.n, self.rank, self.world, self.shuffle, self.seed, self.drop_last = n, rank, world, shuffle, seed, drop_last
+        self.pad = bool(pad)
         self.epoch = 0
-        self.per_rank = n // world if drop_last else (n + world - 1) // world
+        self.per_rank = n // world if drop_last else ((n + world - 1) // world if self.pad else len(range(rank, n, world)))
 
     def set_epoch(self, epoch):
         self.epoch = epoch
@@ -330,6 +333,8 @@ class ShardedSampler(data.Sampler):
             order = torch.randperm(self.n, generator=g).tolist()
         else:
             order = list(range(self.n))
+        if not self.pad and not self.drop_last:
+            return iter(order[self.rank::self.world])
         total = self.per_rank * self.world
         while order and len(order) < total:      # pad by wrapping around (every rank runs the same number of steps)
             order += order[:total - len(order)]
@@ -386,16 +391,16 @@ class PrefetchLoader:
             yield moved
 
 
-def build_loader(set_cfg, rank=0, world=1, device=None, seed=0, prefetch_depth=2):
+def build_loader(set_cfg, rank=0, world=1, device=None, seed=0, prefetch_depth=2, evaluation=False):
     """main.py:71-86: `set_cfg` = dict(dataset=dict(type='PSDataset', ...), batch_size=, num_workers=, shuffle=) -> loader.
     With world > 1 the shuffle flag moves into a ShardedSampler (batch_size is per rank); with `device` the loader is wrapped
-    in a PrefetchLoader.  Returns (loader, sampler-or-None)."""
+    in a PrefetchLoader.  evaluation=True: the sampler does not pad (each image on exactly one rank).  Returns (loader, sampler-or-None)."""
     cfg = dict(set_cfg)
     cfg['dataset'] = build_dataset(cfg['dataset'])
     sampler = None
     if world > 1:
         sampler = ShardedSampler(len(cfg['dataset']), rank, world, shuffle=bool(cfg.pop('shuffle', False)), seed=seed,
-                                 drop_last=bool(cfg.get('drop_last', False)))
+                                 drop_last=bool(cfg.get('drop_last', False)), pad=not evaluation)
         cfg['sampler'] = sampler
         cfg['shuffle'] = False
     if device is not None and torch.device(device).type == 'cuda':

@@ -124,3 +124,68 @@ def test_shard_bounds_and_layout():
     assert ranges[0][0] == 0 and ranges[1][1] == total and ranges[0][1] <= ranges[1][0]
     assert ddp.GradBuckets(ranges).span == (0, total)          # the default bucket: one span over every live range
     assert ddp.GradBuckets(ranges).overlap is False            # two asynchronous buckets are opt-in (LG_DDP_OVERLAP=1)
+
+
+# ---- sharded evaluation when world does not divide the set: every image is scored exactly once --------------------------
+class _EvalSet(torch.utils.data.Dataset):
+    """7 tiny 'images' whose PSNR against the target differs per image (the fused image IS the input here: see _EvalRunner)"""
+    N = 7
+
+    def __len__(self):
+        return self.N
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(100 + i)
+        tgt = torch.rand(4, 16, 16, generator=g) * 2047
+        return dict(input_lr=tgt + (i + 1) * 3.0 * torch.randn(4, 16, 16, generator=g), input_pan=torch.zeros(1, 16, 16), target=tgt, image_id=f'img{i}')
+
+
+def _eval_runner(loader, rank, world, work):
+    from lgteun_amd.base_model import Base_model
+    from lgteun_amd.compat import Config
+
+    class _EvalRunner(Base_model):          # the runner's evaluation loop around a stand-in model (no GPU here): output = its input
+        def get_model_output(self, input_batch):
+            return input_batch['input_lr']
+    cfg = Config(dict(work_dir=work, datas='GF-2', bit_depth=11, norm_input=True, loss_cfg=dict(rec_loss=dict(type='l1', w=1.0))))
+    r = _EvalRunner(cfg, None, None, None, loader)
+    r.add_module('core_module', torch.nn.Linear(1, 1))
+    r.rank, r.world = rank, world
+    return r
+
+
+def _eval_worker(rank, world, port, q, work, padded):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from lgteun_amd import dataset as ds, ddp
+    ddp.init_from_env('gloo')
+    smp = ds.ShardedSampler(_EvalSet.N, rank, world, shuffle=False, pad=padded)
+    loader = torch.utils.data.DataLoader(_EvalSet(), batch_size=2, sampler=smp)
+    out = _eval_runner(loader, rank, world, work).test(iter_id=0, ref=True)
+    if rank == 0:
+        q.put((out, len(smp)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('padded', [False, True])
+def test_two_rank_evaluation_scores_every_image_once(tmp_path, padded):
+    """7 images on 2 ranks: the evaluation sampler (pad=False) gives 4 + 3; a PADDED sampler hands image 0 to both ranks and test()
+    drops the second copy by image_id.  Either way mean / std equal the one-process evaluation's (the reference: base_model.py:267-352)."""
+    single = _eval_runner(torch.utils.data.DataLoader(_EvalSet(), batch_size=2), 0, 1, str(tmp_path / 's')).test(iter_id=0, ref=True)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q, str(tmp_path / 'd'), padded)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, n0 = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert n0 == 4
+    assert set(got) == set(single) == {'PSNR', 'SSIM', 'Q', 'SAM', 'ERGAS'}
+    for k in single:      # the rows arrive in another order (rank-major), so the sums differ in the last bits only
+        assert got[k] == pytest.approx(single[k], rel=1e-12, abs=1e-12), k

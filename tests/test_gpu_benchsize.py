@@ -179,13 +179,19 @@ def test_two_autograd_graphs_keep_their_own_activations():
 
 
 def test_split_bf16_gemms_are_as_close_to_fp64_as_fp32_arithmetic(manifest, monkeypatch):
-    """The FFN GEMMs run on the bf16 matrix pipe in a three-piece split (csrc/split_bf16.h: six piece products, fp32 accumulation;
-    per dot product at least as accurate as an fp32 fma chain, tools/micro/split_bf16_gemm.hip).  Condition for that being the
-    HEADLINE arithmetic: on every whole-net reference golden the output is no further from the reference's fp64
-    result than 2x what fp32 arithmetic gives -- fp32 arithmetic being the reference's own fp32 run (manifest rel_fp32_vs_fp64) or
-    this build's exact-f32-MFMA kernels (LG_FFN_IMPL=strip, the round-1 path), whichever is further: the FFT mixer's angle() branch
-    cut turns a 1e-7 perturbation of a near-negative-real bin into a 1e-5 .. 1e-4 output change, so two fp32 evaluations of the same
-    net differ from fp64 by amounts that vary 100x from input to input (net_c4_k4_p64: reference 2e-7, both of ours 1e-4)."""
+    """The FFN GEMMs and (round 5) the four products of the local mixer run on the 16-bit matrix pipe in split arithmetic
+    (csrc/split_bf16.h: three bf16 pieces, six piece products; P V: two f16 pieces, three products; fp32 accumulation -- per dot product
+    at least as accurate as an fp32 fma chain, tools/micro/split_bf16_gemm.hip, tools/micro/attn_m_check.hip).  Condition for that being
+    the HEADLINE arithmetic: on every whole-net reference golden the output is no further from the reference's fp64
+    result than 2x what fp32 arithmetic gives -- fp32 arithmetic being the reference's own fp32 run (manifest rel_fp32_vs_fp64) or this
+    build's exact fp32 kernels (LG_FFN_IMPL=strip: v_mfma_f32_16x16x4_f32, LG_ATTN_FWD=valu: fp32 FMAs), whichever is further.
+
+    The comparison has to be made ACROSS two roundings of each arithmetic: the FFT mixer's angle() branch cut turns a 1e-7 perturbation
+    of a near-negative-real bin into a 1e-5 .. 3e-4 output change, so two equally accurate fp32 evaluations of one net land 100 - 1000x
+    apart from fp64 on inputs that have such a bin -- which of them flips is chance (profiles/r05_err_vs_fp64.txt: net_c4_k4_p128 is
+    1.1e-7 in three of the four kernel combinations and 1.6e-5, the reference's own fp32 value, in the fourth; net_c4_k2_p32 3.0e-4 in
+    one and 1.6e-7 in three).  So each arithmetic is evaluated with both local-mixer kernels (two different roundings of the same
+    function) and is credited with the better of the two; every single evaluation still has to meet the 1e-3 parity gate."""
     from gpu_helpers import make_module
     names = [n for n, m in manifest.items() if n.startswith('net_') or (n.startswith('grad_') and 'w' in m)]
     assert len(names) >= 11
@@ -195,13 +201,53 @@ def test_split_bf16_gemms_are_as_close_to_fp64_as_fp32_arithmetic(manifest, monk
         ms, pan, _ = (T(a).cuda() for a in dw.make_inputs(m['B'], m['C'], m['h'], m.get('w', m['h']), seed=m['seed'], kind=m['kind']))
         err = {}
         for impl in ('split', 'strip'):
-            if impl == 'strip':
-                monkeypatch.setenv('LG_FFN_IMPL', 'strip')     # read once per plan: a fresh module builds a fresh plan
-            else:
-                monkeypatch.delenv('LG_FFN_IMPL', raising=False)
-            net = make_module(m['C'], m['K'])
-            with torch.no_grad():
-                err[impl] = rel_l2(net(ms, pan).cpu().numpy(), g['out_fp64'])
-        rows.append((name, err['split'], err['strip'], m['rel_fp32_vs_fp64']))
-        assert err['split'] <= 2.0 * max(err['strip'], m['rel_fp32_vs_fp64']), rows[-1]
+            for attn in ('m', 'valu'):
+                for k, v in (('LG_FFN_IMPL', 'strip' if impl == 'strip' else None), ('LG_ATTN_FWD', 'valu' if attn == 'valu' else None)):
+                    if v is None:
+                        monkeypatch.delenv(k, raising=False)
+                    else:
+                        monkeypatch.setenv(k, v)       # read once per plan: a fresh module builds a fresh plan
+                net = make_module(m['C'], m['K'])
+                with torch.no_grad():
+                    err[impl, attn] = rel_l2(net(ms, pan).cpu().numpy(), g['out_fp64'])
+        split = min(err['split', 'm'], err['split', 'valu'])      # the product arithmetic (its default kernels: ('split', 'm'))
+        exact = min(err['strip', 'm'], err['strip', 'valu'])
+        rows.append((name, err, m['rel_fp32_vs_fp64']))
+        assert max(err.values()) < 1e-3, rows[-1]
+        assert split <= 2.0 * max(exact, m['rel_fp32_vs_fp64']), rows[-1]
     monkeypatch.delenv('LG_FFN_IMPL', raising=False)
+    monkeypatch.delenv('LG_ATTN_FWD', raising=False)
+
+
+@pytest.mark.parametrize('C', [4, 8])
+def test_matrix_pipe_mixer_is_as_close_to_fp64_as_the_fp32_kernel(C, monkeypatch):
+    """The same criterion at kernel level, where no branch cut interferes: the mixer half-block of both levels through k_attn_m (split
+    arithmetic on the matrix pipe) and through k_attn (fp32 FMAs), each against an fp64 evaluation of proj(cat(local_mixer, o2)) + x in
+    which o2 is THIS build's global-mixer output (one kernel, same input: identical in both runs): the matrix-pipe kernel is within
+    1.6x of the fp32 kernel's distance from fp64 (measured 1.3 - 1.5x: 2.0 - 2.7e-7 against 1.4 - 2.1e-7), and both are below 1e-6."""
+    from gpu_helpers import Ops, make_module
+    from helpers import det_params
+    from oracle import lgteun_oracle as orc
+    E = 4 * C
+    P64 = {k: v.double() for k, v in det_params(C, 1).items()}
+    rng = np.random.default_rng(11)
+    for blk, e, n in ((0, E, 32), (2, 2 * E, 16)):
+        x = T((rng.standard_normal((2, n, n, e)) * 1.5 + 0.3).astype(np.float32))
+        pre = 'prior_module.0.' + ('encoder_layers.0.0.blocks.0.' if blk == 0 else 'bottleneck.blocks.0.') + '0.fn.'
+        got = {}
+        for attn in ('m', 'valu'):
+            if attn == 'valu':
+                monkeypatch.setenv('LG_ATTN_FWD', 'valu')
+            else:
+                monkeypatch.delenv('LG_ATTN_FWD', raising=False)
+            ops = Ops(make_module(C, 1), 32, 32)
+            got[attn] = ops.block(0, blk, 1, x.cuda()).cpu().double()
+            o2 = ops.block(0, blk, 0, x.cuda()).cpu().double()               # [B, e/2, n, n]
+        y = orc.layer_norm(x.double(), P64[pre + 'norm.weight'], P64[pre + 'norm.bias'])
+        x1 = orc.local_mixer(P64, pre + 'fn.local_mixer.', y[..., :e // 2])
+        cat = torch.cat((x1, o2.permute(0, 2, 3, 1)), dim=-1).permute(0, 3, 1, 2)
+        want = x.double() + orc.point_conv(cat, P64[pre + 'fn.proj.weight'], P64[pre + 'fn.proj.bias']).permute(0, 2, 3, 1)
+        den = float((want - x.double()).norm())
+        em, ev = float((got['m'] - want).norm()) / den, float((got['valu'] - want).norm()) / den
+        print(f'C={C} block {blk}: matrix pipe {em:.3e}  fp32 FMAs {ev:.3e}')
+        assert ev < 1e-6 and em < 1e-6 and em <= 1.6 * ev, (blk, em, ev)
