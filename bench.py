@@ -253,7 +253,8 @@ def main():
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    forced_pg = os.environ.get('LGTEUN_FORCE_PG') if world == 1 else None   # nccl: a ONE-rank RCCL group on a single-GPU box (what the collective costs)
+    if world > 1 or forced_pg:
         ddp.init_from_env(os.environ.get('LGTEUN_DDP_BACKEND', 'nccl'))   # nccl = RCCL over xGMI; gloo only for rehearsal
     import torch.distributed as dist
 
@@ -266,7 +267,7 @@ def main():
     net.mode = args.mode
     net.precision = args.precision
     net.train()
-    eng = net.attach_ddp() if world > 1 else net.engine()
+    eng = net.attach_ddp(force=bool(forced_pg)) if (world > 1 or forced_pg) else net.engine()
     opt = lgteun_amd.FusedAdam(net.parameters(), lr=1.5e-3, betas=(0.9, 0.999))          # configs/unlg_former.py:82-84
     sched = torch.optim.lr_scheduler.StepLR(opt, step_size=25900, gamma=0.85)              # :86, stepped every iteration
     ms, pan, gt = synth_batch(B_PER_GPU, rank, device)
@@ -410,11 +411,14 @@ def main():
         out = dict(metric=metric, value=round(value, 2), unit='image-pairs/sec',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
                    scaling='weak', vs_baseline=None,
-                   dtype='f32 (GEMMs: bf16x3-split MFMA, fp32 accumulate; fp32-equivalent)' if args.precision == 'fp32'
-                         else 'bf16 MFMA + bf16 saved activations, f32 elsewhere', data='synthetic',
+                   dtype='f32 (GEMMs and the local mixer: split 16-bit MFMA -- bf16x3, f16x2 for P V -- fp32 accumulate; fp32-equivalent)' if args.precision == 'fp32'
+                         else 'bf16 / f16 MFMA (FFN, local mixer) + bf16 saved activations, f32 elsewhere', data='synthetic',
                    config=dict(workload=label + ', train step = fwd + L1 + bwd + Adam + StepLR tick', mode=args.mode,
                                global_batch=B_PER_GPU * world, parallelism=f'dp{world}', dropout=True),
                    roofline=roof)
+        if forced_pg:
+            out['forced_process_group'] = dict(backend=dist.get_backend(), world=1, note='LGTEUN_FORCE_PG: the per-step gradient all-reduce (and the weight '
+                                               'broadcast) run on a one-rank communicator: what the collective call costs on this box, not a scaling point')
         if loss is not None:
             out['final_loss'] = round(loss, 6)
         if live is not None:

@@ -28,7 +28,9 @@ def env_world():
 def init_from_env(backend=None):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun contract)."""
     rank, world, local_rank = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get('LGTEUN_FORCE_PG')) and not dist.is_initialized():
+        if world == 1:      # LGTEUN_FORCE_PG=nccl|gloo: a process group of ONE rank (RCCL on the single MI355X of a test box)
+            backend = os.environ['LGTEUN_FORCE_PG']
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -47,9 +49,9 @@ def shard_bounds(n_global, rank, world):
     return rank * per, (rank + 1) * per
 
 
-def broadcast_flat(flat, src=0, group=None):
-    """identical initial weights on every rank"""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+def broadcast_flat(flat, src=0, group=None, force=False):
+    """identical initial weights on every rank (force: also in a group of one rank -- the single-GPU RCCL check)"""
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         dist.broadcast(flat, src=src, group=group)
 
 

@@ -130,6 +130,7 @@ class Engine:
         self.rank = 0
         self.process_group = None
         self.buckets = None
+        self.force_collectives = False   # attach_ddp(force=True): collectives also in a group of one rank
         self.local_only = False        # True: the caller runs independent replicas inside an initialised process group on purpose
 
     def chained(self):
@@ -151,19 +152,22 @@ class Engine:
     def max_range(self):
         return max(b - a for a, b in self.live_ranges)
 
-    def attach_ddp(self, group=None, broadcast=True):
+    def attach_ddp(self, group=None, broadcast=True, force=False):
         """join a torch.distributed group: reduce the flat gradient buffer every step.  broadcast=True (an explicit
         `module.attach_ddp()`): rank-0 weights go to every rank -- a COLLECTIVE, so every rank of the group must make the call.
         broadcast=False (an engine rebuilt under an attached module, e.g. after `.to()`): no communication; the ranks' weights
-        were made equal by the first attachment and identical updates keep them equal."""
+        were made equal by the first attachment and identical updates keep them equal.
+        force=True: issue the collectives in a group of ONE rank too (the broadcast here, the all-reduce(s) of every train step) --
+        how a single-GPU box exercises the RCCL communicator and the bucket code an 8-GPU run takes (tests, `LGTEUN_FORCE_PG`)."""
         import torch.distributed as dist
         from .ddp import GradBuckets, broadcast_flat
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.process_group = group
-        if self.world > 1:
+        self.force_collectives = bool(force and dist.is_initialized())
+        if self.world > 1 or self.force_collectives:
             if broadcast:
-                broadcast_flat(self.flat, 0, group)
+                broadcast_flat(self.flat, 0, group, force=self.force_collectives)
             self.buckets = {ch: GradBuckets(rg, group) for ch, (_, rg) in self._live.items()}
         return self
 
@@ -318,7 +322,7 @@ class Engine:
         n_local = out.numel()
         check(self.lib.lg_l1_loss(_ptr(out), _ptr(gt), _ptr(dout), _ptr(self._loss), n_local, n_local * self.world,
                                   float(loss_weight), _stream_ptr()), 'lg_l1_loss')
-        bk = self.buckets[bool(flags & LG_FLAG_CHAINED)] if self.world > 1 else None
+        bk = self.buckets[bool(flags & LG_FLAG_CHAINED)] if (self.world > 1 or self.force_collectives) else None
         overlap = bool(bk is not None and bk.overlap and not (flags & LG_FLAG_CHAINED))
         if defer or overlap:
             # two backward calls: the dead-stage forwards (side stream) and / or the opt-in asynchronous bucket of the last stage's

@@ -123,18 +123,18 @@ class Pansharpening(nn.Module):
             if self._ddp is not None:  # the data-parallel attachment belongs to the module, not to one Engine object
                 # no broadcast here: a rebuild may happen on one rank only (a collective would hang) and must not overwrite what
                 # the ranks loaded; call attach_ddp() again on EVERY rank to re-synchronise the weights
-                self._engine.attach_ddp(self._ddp[0], broadcast=False)
+                self._engine.attach_ddp(self._ddp[0], broadcast=False, force=len(self._ddp) > 1 and self._ddp[1])
         return self._engine
 
-    def attach_ddp(self, group=None):
+    def attach_ddp(self, group=None, force=False):
         """join a torch.distributed process group (one process per GPU; backend nccl = RCCL over xGMI): rank-0 weights are
         broadcast and every train step / autograd backward all-reduces the flat gradient buffer.  A COLLECTIVE call: every rank
         of the group makes it (again after loading weights on one rank only).  Replaces the reference's nn.DataParallel wrap
         (models/base/base_model.py:91-100)."""
         self._ddp = None
         eng = self.engine()            # (re)built without an attachment
-        self._ddp = (group,)
-        return eng.attach_ddp(group, broadcast=True)
+        self._ddp = (group, bool(force))
+        return eng.attach_ddp(group, broadcast=True, force=force)
 
     def canonical_names(self):
         return canonical_names(self.in_channels, self.stage)

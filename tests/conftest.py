@@ -15,8 +15,8 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """-m gpu sessions on a GPU box: start the two ranks of the Engine data-parallel check (tests/ddp_engine_worker.py) NOW,
-    as fresh child processes, before this process initialises the GPU (a process that has must not spawn programs on this
+    """-m gpu sessions on a GPU box: start the two ranks of the Engine data-parallel check (tests/ddp_engine_worker.py) and the one-rank
+    RCCL check (tests/rccl_one_rank_worker.py) NOW, as fresh child processes, before this process initialises the GPU (a process that has must not spawn programs on this
     pool).  tests/test_gpu_ddp_engine.py joins them.  Nothing here imports torch or touches the device."""
     import shutil
     import socket
@@ -43,6 +43,16 @@ def pytest_sessionstart(session):
         procs.append(subprocess.Popen([sys.executable, '-W', 'ignore', os.path.join(ROOT, 'tests', 'ddp_engine_worker.py'), outdir],
                                       stdout=open(log, 'w'), stderr=subprocess.STDOUT, env=env, cwd=ROOT))
     config._lgteun_ddp_job = (outdir, procs, logs)
+    # a third child: a process group of ONE rank on backend nccl (RCCL) -- tests/rccl_one_rank_worker.py
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port1 = s.getsockname()[1]
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port1), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('LG_DDP_OVERLAP', None)
+    log1 = os.path.join(outdir, 'rccl1.log')
+    p1 = subprocess.Popen([sys.executable, '-W', 'ignore', os.path.join(ROOT, 'tests', 'rccl_one_rank_worker.py'), outdir],
+                          stdout=open(log1, 'w'), stderr=subprocess.STDOUT, env=env, cwd=ROOT)
+    config._lgteun_rccl_job = (outdir, p1, log1)
     config.add_cleanup(lambda: shutil.rmtree(outdir, ignore_errors=True))
 
 
@@ -52,6 +62,9 @@ def pytest_sessionfinish(session, exitstatus):
         for p in job[1]:
             if p.poll() is None:
                 p.kill()
+    job = getattr(session.config, '_lgteun_rccl_job', None)
+    if job and job[1].poll() is None:
+        job[1].kill()
 
 
 @pytest.fixture(scope='session')

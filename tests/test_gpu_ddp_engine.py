@@ -78,3 +78,28 @@ def test_two_rank_runner_writes_once_and_logs_the_global_loss(request):
     assert list(r1['runner_tifs']) == ['r0_0_mul_hat.tif', 'r0_1_mul_hat.tif', 'r1_0_mul_hat.tif', 'r1_1_mul_hat.tif'] or \
         list(r0['runner_tifs']) == ['r0_0_mul_hat.tif', 'r0_1_mul_hat.tif', 'r1_0_mul_hat.tif', 'r1_1_mul_hat.tif']
     assert float(r0['runner_eval_psnr']) == float(r1['runner_eval_psnr']) and float(r0['runner_eval_psnr']) > 0   # mean over ALL images, on both ranks
+
+
+def test_one_rank_rccl_group_is_bitwise_the_unattached_engine(request):
+    """backend "nccl" = RCCL, a process group of one rank on the box's MI355X (tests/rccl_one_rank_worker.py): the communicator is
+    created, the weight broadcast and the per-step all-reduce(s) of Engine.train_step run on it -- the default single stream-ordered
+    collective and the two ordered buckets of LG_DDP_OVERLAP=serial -- and, a one-rank SUM being the identity, three steps leave
+    gradients and weights BITWISE those of an unattached engine.  librccl is mapped into the worker."""
+    job = getattr(request.config, '_lgteun_rccl_job', None)
+    assert job is not None, 'conftest did not start the one-rank RCCL worker (no /dev/kfd?)'
+    outdir, proc, log = job
+    try:
+        rc = proc.wait(timeout=900)
+    except Exception:  # noqa: BLE001
+        proc.kill()
+        raise
+    assert rc == 0, open(log).read()[-4000:]
+    r = np.load(f'{outdir}/rccl1.npz')
+    print(open(log).read()[-400:])
+    assert int(r['librccl_mapped']) == 1 and int(r['bare_ok']) == 1
+    for name in ('default', 'serial'):
+        assert float(r[f'{name}_gmax']) > 0
+        assert int(r[f'{name}_grads_equal']) == 1 and int(r[f'{name}_weights_equal']) == 1, name
+    # the collective is a latency-bound message behind the backward: the step with it is within 5 % (+ 50 us) of the plain step here
+    # (a 64 x 64 PAN, 2-pair step of ~2 ms; at configs[1] the same absolute cost is < 1 %: bench.py under LGTEUN_FORCE_PG=nccl)
+    assert float(r['ms_rccl']) < 1.05 * float(r['ms_plain']) + 0.05, (float(r['ms_rccl']), float(r['ms_plain']))
