@@ -137,3 +137,52 @@ def test_build_loader_and_prefetch_passthrough(tmp_path):
     ids0 = [i for b in l0 for i in b['image_id']]
     ids1 = [i for b in l1 for i in b['image_id']]
     assert len(ids0) == len(ids1) == 3 and set(ids0) | set(ids1) == {str(i) for i in range(6)} and not set(ids0) & set(ids1)
+
+
+# ---- the reference's own dataset/utils.py functions (:155-263), captured by tools/gen_goldens.py --only-r5 -------------------------
+# (the augmentation cases and their random() draws live in ONE place: the generator)
+def _dataset_cases():
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))          # gen_goldens imports its sibling _ref_import at module level (no reference import happens)
+    try:
+        spec = importlib.util.spec_from_file_location('lg_gen_goldens', os.path.join(root, 'tools', 'gen_goldens.py'))
+        gg = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(gg)
+    finally:
+        sys.path.pop(0)
+    return gg.DATASET_CASES, gg.dataset_batch()
+
+
+def test_normalise_denormalise_and_augmentation_equal_the_reference():
+    """data_normalize / data_denormalize (bit depths 11 and 10) and data_augmentation under eight fixed draw sequences -- no
+    augmentation dict, nothing selected, ud flip, lr flip, BOTH flips (the later one wins, dataset/utils.py:216-219), the r4 and r2
+    crop + bicubic align_corners=True resize with drawn offsets, and all four at once -- against the arrays the reference's own
+    functions produced (tests/golden/dataset_utils.npz).  This pins the pure-torch part of SURVEY 8(f)-3; TIFF I/O stays unpinned
+    (tifffile / gdal are absent here and the reference ships no image)."""
+    from conftest import load_gold
+    from lgteun_amd.base_model import data_denormalize, data_normalize
+    g = load_gold('dataset_utils')
+    cases, base = _dataset_cases()
+    for name, probs, draws in cases:
+        seq = iter(draws)
+        batch = dict({k: torch.from_numpy(v.copy()) for k, v in base.items()}, image_id=['a', 'b'])
+        res = ds.data_augmentation(batch, None if probs is None else dict(probs), rng=lambda: next(seq))
+        assert next(seq, None) is None, name                   # the same number of draws as the reference
+        assert res['image_id'] == ['a', 'b']
+        for k in base:
+            want = g[f'aug_{name}_{k}']
+            assert tuple(res[k].shape) == want.shape, (name, k)
+            assert np.allclose(res[k].numpy(), want, rtol=0, atol=1e-3), (name, k, float(np.abs(res[k].numpy() - want).max()))   # digital numbers up to 2047
+    for bits in (11, 10):
+        batch = dict({k: torch.from_numpy(v.copy()) for k, v in base.items()}, image_id=['a', 'b'])
+        nrm = data_normalize(batch, bits)
+        assert nrm['image_id'] == ['a', 'b']
+        for k in base:
+            assert np.array_equal(nrm[k].numpy(), g[f'norm{bits}_{k}']), (bits, k)
+        assert np.array_equal(data_denormalize(nrm['target'], bits).numpy(), g[f'denorm{bits}_target'])
+    # the cases differ from one another (a generator that ignored its draws would make this fixture vacuous)
+    assert not np.array_equal(g['aug_ud_target'], g['aug_lr_target']) and np.array_equal(g['aug_ud_and_lr_target'], g['aug_lr_target'])
+    assert not np.array_equal(g['aug_r4_target'], g['aug_r2_target']) and not np.array_equal(g['aug_all_target'], g['aug_ud_and_lr_target'])

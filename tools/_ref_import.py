@@ -96,3 +96,17 @@ def import_reference():
     import models.common.basic_module_unformer_v2 as bmu  # noqa
     return types.SimpleNamespace(Pansharpening=Pansharpening, UnlgFormer=UnlgFormer, LGT=LGT, bmu=bmu,
                                  Config=Config)
+
+
+def import_reference_dataset_utils():
+    """dataset/utils.py of the reference (data_normalize / data_denormalize / data_augmentation, :155-263): pure torch / numpy
+    functions behind imports of gdal / osr / tifffile / numba (stubbed as above; none of the three functions touches them).  The
+    package's __init__ (which pulls in the TIFF dataset class and its registry) is bypassed the same way `models` is."""
+    _stub_modules()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    pkg = types.ModuleType('dataset')
+    pkg.__path__ = [REF + '/dataset']
+    sys.modules['dataset'] = pkg
+    import dataset.utils as du  # noqa
+    return du

@@ -156,8 +156,55 @@ def round4(R, manifest):
         json.dump(out, f, indent=1, sort_keys=True)
 
 
+# the augmentation cases of tests/golden/dataset_utils.npz: (probabilities in the reference's dict order, the U[0,1) draws the call
+# consumes: one per probability, then two per selected crop).  tests/test_dataset_cpu.py feeds lgteun_amd.dataset the same draws.
+DATASET_CASES = [
+    ('none', None, []),
+    ('nothing_selected', dict(ud_flip=0.5, lr_flip=0.5, r4_crop=0.3, r2_crop=0.3), [0.9, 0.8, 0.7, 0.6]),
+    ('ud', dict(ud_flip=0.5, lr_flip=0.5), [0.1, 0.9]),
+    ('lr', dict(ud_flip=0.5, lr_flip=0.5), [0.9, 0.1]),
+    ('ud_and_lr', dict(ud_flip=0.5, lr_flip=0.5), [0.1, 0.2]),                     # the later one wins (utils.py:216-219)
+    ('r4', dict(ud_flip=0.5, lr_flip=0.5, r4_crop=0.3, r2_crop=0.3), [0.9, 0.9, 0.1, 0.9, 0.55, 0.80]),
+    ('r2', dict(ud_flip=0.5, lr_flip=0.5, r4_crop=0.3, r2_crop=0.3), [0.9, 0.9, 0.9, 0.1, 0.30, 0.95]),
+    ('all', dict(ud_flip=0.5, lr_flip=0.5, r4_crop=0.3, r2_crop=0.3), [0.1, 0.1, 0.1, 0.1, 0.99, 0.01, 0.49, 0.51]),
+]
+
+
+def dataset_batch():
+    rng = np.random.default_rng(2023)
+    return dict(input_lr=rng.integers(0, 2048, (2, 4, 8, 8)).astype(np.float32), input_pan=rng.integers(0, 2048, (2, 1, 32, 32)).astype(np.float32),
+                target=rng.integers(0, 2048, (2, 4, 32, 32)).astype(np.float32))
+
+
+def round5():
+    """the pure-torch part of the reference's input pipeline (dataset/utils.py:155-263): data_normalize, data_denormalize and
+    data_augmentation for fixed random() sequences -> tests/golden/dataset_utils.npz"""
+    from _ref_import import import_reference_dataset_utils
+    du = import_reference_dataset_utils()
+    base = dataset_batch()
+    out = {}
+    for name, probs, draws in DATASET_CASES:
+        seq = iter(draws)
+        du.random = lambda: next(seq)          # the module-level numpy.random.random the function draws from
+        batch = dict({k: torch.from_numpy(v.copy()) for k, v in base.items()}, image_id=['a', 'b'])
+        res = du.data_augmentation(batch, None if probs is None else dict(probs))
+        assert next(seq, None) is None, name   # every listed draw was consumed
+        for k in base:
+            out[f'aug_{name}_{k}'] = res[k].numpy()
+    for bits in (11, 10):
+        batch = dict({k: torch.from_numpy(v.copy()) for k, v in base.items()}, image_id=['a', 'b'])
+        nrm = du.data_normalize(batch, bits)
+        assert nrm['image_id'] == ['a', 'b']
+        for k in base:
+            out[f'norm{bits}_{k}'] = nrm[k].numpy()
+        out[f'denorm{bits}_target'] = du.data_denormalize(nrm['target'], bits).numpy()
+    np.savez_compressed(os.path.join(GOLD, 'dataset_utils.npz'), **out)
+    print('dataset_utils.npz:', len(out), 'arrays')
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--only-r5', action='store_true', help='write only the round-5 fixture (the reference\'s dataset/utils.py functions)')
     ap.add_argument('--check', action='store_true')
     ap.add_argument('--only-r3', action='store_true', help='write only the round-3 fixtures (fp64 gradients of the cancelling-sum kinds)')
     ap.add_argument('--only-r2', action='store_true', help='write only the round-2 fixtures (bench-size / configs[4] / non-pow2 '
@@ -165,6 +212,9 @@ def main():
     ap.add_argument('--only-r4', action='store_true', help='write only the round-4 fixture (the reference fp32 gradients\' own noise band)')
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
+    if args.only_r5:
+        round5()
+        return
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = import_reference()
@@ -314,6 +364,7 @@ def main():
         json.dump(manifest, f, indent=1, sort_keys=True)
     round3(R, manifest)
     round4(R, manifest)
+    round5()
     print('wrote', GOLD)
 
 
