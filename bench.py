@@ -254,7 +254,14 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     forced_pg = os.environ.get('LGTEUN_FORCE_PG') if world == 1 else None   # nccl: a ONE-rank RCCL group on a single-GPU box (what the collective costs)
+    # librccl prints a version banner on STDOUT when its first communicator is created (measured: five lines in front of the JSON line of
+    # the one-rank run); stdout carries exactly ONE JSON line by contract, so file descriptor 1 points at stderr until the communicator
+    # exists (a first collective below forces its creation)
+    saved_stdout = None
     if world > 1 or forced_pg:
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         ddp.init_from_env(os.environ.get('LGTEUN_DDP_BACKEND', 'nccl'))   # nccl = RCCL over xGMI; gloo only for rehearsal
     import torch.distributed as dist
 
@@ -268,6 +275,11 @@ def main():
     net.precision = args.precision
     net.train()
     eng = net.attach_ddp(force=bool(forced_pg)) if (world > 1 or forced_pg) else net.engine()
+    if saved_stdout is not None:      # attach_ddp has broadcast the weights: the communicator exists and has said what it had to say
+        torch.cuda.synchronize()
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     opt = lgteun_amd.FusedAdam(net.parameters(), lr=1.5e-3, betas=(0.9, 0.999))          # configs/unlg_former.py:82-84
     sched = torch.optim.lr_scheduler.StepLR(opt, step_size=25900, gamma=0.85)              # :86, stepped every iteration
     ms, pan, gt = synth_batch(B_PER_GPU, rank, device)
