@@ -27,8 +27,6 @@
 #include "kernels.h"
 #include "split_bf16.h"
 
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
 namespace am {
 
@@ -77,21 +75,10 @@ __device__ __forceinline__ Pat<NP> pat_of(float v) {
     return r;
 }
 
-// f16 pairs: round to nearest, and the exact residual a - f16(a) in one instruction each (v_fma_mix_f32)
-__device__ __forceinline__ uint32_t cvt_f16x2(float a, float b) {
-    const f16x2_t h = {(_Float16)a, (_Float16)b};   // v_cvt_pk_f16_f32
-    return __builtin_bit_cast(uint32_t, h);
-}
-__device__ __forceinline__ float res_lo(uint32_t h, float a) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
-    return r;
-}
-__device__ __forceinline__ float res_hi(uint32_t h, float b) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(b));
-    return r;
-}
+// f16 pairs: round to nearest, and the exact residual a - f16(a) in one instruction each (split_bf16.h, NP = 2)
+__device__ __forceinline__ uint32_t cvt_f16x2(float a, float b) { return sb_cvt_f16x2(a, b); }
+__device__ __forceinline__ float res_lo(uint32_t h, float a) { return sb_res_lo(h, a); }
+__device__ __forceinline__ float res_hi(uint32_t h, float b) { return sb_res_hi(h, b); }
 
 __device__ __forceinline__ f32x4_t mfma_bf(u32x4_t a, u32x4_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);

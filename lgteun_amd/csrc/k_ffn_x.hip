@@ -88,11 +88,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const float4 b1v = *reinterpret_cast<const float4*>(a1.b1 + c0);
     const float4 b2v = *reinterpret_cast<const float4*>(a1.b2 + c0);
     constexpr bool BF = (NP == 1);                    // plain-bf16 mode: saved activations are stored as bf16 too (hstore.h)
-    const WFrag16 w1f = NP == 3 ? load_wfrag16(a1.w1 + (size_t)(wave * 16) * E, E, 0) : load_wfrag16_rne(a1.w1 + (size_t)(wave * 16) * E, E, 0);
-    const WFrag32 w2f0 = NP == 3 ? load_wfrag32(a1.w2 + (size_t)(wave * 16) * N1, N1, 0) : load_wfrag32_rne(a1.w2 + (size_t)(wave * 16) * N1, N1, 0);
-    const WFrag32 w2f1 = NP == 3 ? load_wfrag32(a1.w2 + (size_t)(wave * 16) * N1, N1, 1) : load_wfrag32_rne(a1.w2 + (size_t)(wave * 16) * N1, N1, 1);
-    const WFrag32 w3f0 = NP == 3 ? load_wfrag32(a2.w3, N1, 0) : load_wfrag32_rne(a2.w3, N1, 0);
-    const WFrag32 w3f1 = NP == 3 ? load_wfrag32(a2.w3, N1, 1) : load_wfrag32_rne(a2.w3, N1, 1);
+    const WFrag16 w1f = NP == 3 ? load_wfrag16(a1.w1 + (size_t)(wave * 16) * E, E, 0) : (NP == 2 ? load_wfrag16_h2(a1.w1 + (size_t)(wave * 16) * E, E, 0, 1.0f) : load_wfrag16_rne(a1.w1 + (size_t)(wave * 16) * E, E, 0));
+    const WFrag32 w2f0 = NP == 3 ? load_wfrag32(a1.w2 + (size_t)(wave * 16) * N1, N1, 0) : (NP == 2 ? load_wfrag32_h2(a1.w2 + (size_t)(wave * 16) * N1, N1, 0, 1.0f) : load_wfrag32_rne(a1.w2 + (size_t)(wave * 16) * N1, N1, 0));
+    const WFrag32 w2f1 = NP == 3 ? load_wfrag32(a1.w2 + (size_t)(wave * 16) * N1, N1, 1) : (NP == 2 ? load_wfrag32_h2(a1.w2 + (size_t)(wave * 16) * N1, N1, 1, 1.0f) : load_wfrag32_rne(a1.w2 + (size_t)(wave * 16) * N1, N1, 1));
+    const WFrag32 w3f0 = NP == 3 ? load_wfrag32(a2.w3, N1, 0) : (NP == 2 ? load_wfrag32_h2(a2.w3, N1, 0, 1.0f) : load_wfrag32_rne(a2.w3, N1, 0));
+    const WFrag32 w3f1 = NP == 3 ? load_wfrag32(a2.w3, N1, 1) : (NP == 2 ? load_wfrag32_h2(a2.w3, N1, 1, 1.0f) : load_wfrag32_rne(a2.w3, N1, 1));
     // depthwise taps of the lane's four channels (phase P2: lane = (pixel slot lane / 16, channel quad q)): 36 + 4 contiguous
     // floats, re-read (L1 / L2 hits) at the top of every step instead of pinning 40 VGPRs through the GEMM phases
     const int q = lane % CQ;
@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         split_x4<NP>(yv, q1, q2, q3);
         uint16_t* dst = XA + slot * XA_SLOT + lpx * E + 4 * lq;
         *reinterpret_cast<u32x2_t*>(dst) = q1;
-        *reinterpret_cast<u32x2_t*>(dst + CH * E) = q2;
-        *reinterpret_cast<u32x2_t*>(dst + 2 * CH * E) = q3;
+        if (NP >= 2) *reinterpret_cast<u32x2_t*>(dst + CH * E) = q2;
+        if (NP == 3) *reinterpret_cast<u32x2_t*>(dst + 2 * CH * E) = q3;
         if (lq == 0) sMask[slot][lpx] = m_;
     };
 
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 split_x4<NP>(av, q1, q2, q3);
                 uint16_t* dst = A2 + (pb * 16 + r) * LDP + c0;
                 *reinterpret_cast<u32x2_t*>(dst) = q1;
-                *reinterpret_cast<u32x2_t*>(dst + CH * LDP) = q2;
-                *reinterpret_cast<u32x2_t*>(dst + 2 * CH * LDP) = q3;
+                if (NP >= 2) *reinterpret_cast<u32x2_t*>(dst + CH * LDP) = q2;
+                if (NP == 3) *reinterpret_cast<u32x2_t*>(dst + 2 * CH * LDP) = q3;
             }
             STAMP(4 + 4 * c);
             __syncthreads();
@@ -346,8 +346,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 split_x4<NP>(av, q1, q2, q3);
                 uint16_t* dst = G3 + tx * LDP + 4 * q;
                 *reinterpret_cast<u32x2_t*>(dst) = q1;
-                *reinterpret_cast<u32x2_t*>(dst + 16 * LDP) = q2;
-                *reinterpret_cast<u32x2_t*>(dst + 2 * 16 * LDP) = q3;
+                if (NP >= 2) *reinterpret_cast<u32x2_t*>(dst + 16 * LDP) = q2;
+                if (NP == 3) *reinterpret_cast<u32x2_t*>(dst + 2 * 16 * LDP) = q3;
             }
             STAMP(16 + 3 * ch);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -396,14 +396,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 
 }   // namespace
 
+#ifndef LG_FFN_NP
+#define LG_FFN_NP 3   // pieces of the fp32-equivalent mode: 3 = bf16 x 3 (six products), 2 = f16 x 2 (three products)
+#endif
 int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
+    constexpr int NPF = LG_FFN_NP;
     ProfScope prof__(LG_K_FFN2, s);
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_xs<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_xs<0, NPF>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<1, NPF>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<2, NPF>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<3, NPF>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
@@ -427,10 +431,10 @@ int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
         if (noh1) k_ffn_xs<3, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
         else if (save) k_ffn_xs<1, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
         else k_ffn_xs<0, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
-    } else if (noh1) k_ffn_xs<3, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
-    else if (pre) k_ffn_xs<2, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
-    else if (save) k_ffn_xs<1, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
-    else k_ffn_xs<0, 3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    } else if (noh1) k_ffn_xs<3, NPF><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    else if (pre) k_ffn_xs<2, NPF><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    else if (save) k_ffn_xs<1, NPF><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    else k_ffn_xs<0, NPF><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
     LG_CHECK_LAUNCH();
     return 0;
 }

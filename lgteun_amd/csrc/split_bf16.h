@@ -138,12 +138,75 @@ __device__ __forceinline__ void mfma_split16(f32x4_t& acc, const WFrag16& w, s16
     acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.p[0], x1, acc, 0, 0, 0);
 }
 
+// ---- NP = 2: TWO f16 pieces per operand (round 5).  v = hi + lo with hi = f16(v) and lo = f16(v - hi), both round-to-nearest: |lo| <= 2^-12 |hi|,
+// so the pair carries 24 significant bits as long as hi is a normal f16 and lo >= 2^-24 -- i.e. for 2^-2 <= |v| < 2^16 exactly, below that
+// with an ABSOLUTE error of <= 2^-25.  Three piece products (hi hi, hi lo, lo hi; the dropped lo lo is <= 2^-24 relative) instead of six, and
+// 4.2 instead of 7.9 VALU cycles per value for the split (v_cvt_pk_f16_f32 twice per pair + one v_fma_mix_f32 per value, which forms the
+// exact residual v - f16(v) in one instruction; tools/micro/valu_rates2.hip).  f16 has 5 exponent bits: the caller scales every operand
+// by a power of two derived from a bound it can prove (k_attn_m: p <= 2^11 by construction, v by the window's own maximum).
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t sb_cvt_f16x2(float a, float b) {
+    const f16x2_t h = {(_Float16)a, (_Float16)b};   // v_cvt_pk_f16_f32 (round to nearest even)
+    return __builtin_bit_cast(uint32_t, h);
+}
+// a - f16 (low / high half of h), exact.  The asm statements read VALU results only (never a matrix-core accumulator: an asm statement gets
+// none of the wait states the hardware needs behind an MFMA)
+__device__ __forceinline__ float sb_res_lo(uint32_t h, float a) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float sb_res_hi(uint32_t h, float b) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void split2_x4(const float (&v)[4], u32x2_t& q1, u32x2_t& q2) {
+    const uint32_t h01 = sb_cvt_f16x2(v[0], v[1]), h23 = sb_cvt_f16x2(v[2], v[3]);
+    q1 = (u32x2_t){h01, h23};
+    q2 = (u32x2_t){sb_cvt_f16x2(sb_res_lo(h01, v[0]), sb_res_hi(h01, v[1])), sb_cvt_f16x2(sb_res_lo(h23, v[2]), sb_res_hi(h23, v[3]))};
+}
+__device__ __forceinline__ f32x4_t sb_mfma_h(bf16x8_t a, bf16x8_t b, f32x4_t c) {   // operands carried in the bf16x8_t registers of the NP = 3 code; the bits are f16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+// weight fragments as f16 pairs of W * wscale (wscale a power of two): p[0] = hi, p[1] = lo
+__device__ __forceinline__ WFrag32 load_wfrag32_h2(const float* __restrict__ W, int K, int kb, float wscale) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const float4 lo = *reinterpret_cast<const float4*>(W + (size_t)r * K + kb * 32 + 8 * g);
+    const float4 hi = *reinterpret_cast<const float4*>(W + (size_t)r * K + kb * 32 + 8 * g + 4);
+    const float a[4] = {lo.x * wscale, lo.y * wscale, lo.z * wscale, lo.w * wscale}, b[4] = {hi.x * wscale, hi.y * wscale, hi.z * wscale, hi.w * wscale};
+    u32x2_t a1, a2, b1, b2;
+    split2_x4(a, a1, a2);
+    split2_x4(b, b1, b2);
+    WFrag32 f;
+    f.p[0] = __builtin_bit_cast(bf16x8_t, (u32x4_t){a1.x, a1.y, b1.x, b1.y});
+    f.p[1] = __builtin_bit_cast(bf16x8_t, (u32x4_t){a2.x, a2.y, b2.x, b2.y});
+    f.p[2] = f.p[0];
+    return f;
+}
+__device__ __forceinline__ WFrag16 load_wfrag16_h2(const float* __restrict__ W, int K, int k0, float wscale) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const float4 v = *reinterpret_cast<const float4*>(W + (size_t)r * K + k0 + 4 * g);
+    const float a[4] = {v.x * wscale, v.y * wscale, v.z * wscale, v.w * wscale};
+    u32x2_t a1, a2;
+    split2_x4(a, a1, a2);
+    WFrag16 f;
+    f.p[0] = __builtin_bit_cast(s16x4_t, a1);
+    f.p[1] = __builtin_bit_cast(s16x4_t, a2);
+    f.p[2] = f.p[0];
+    return f;
+}
+
 // ---- NP = number of pieces: 3 = the fp32-equivalent arithmetic above; 1 = plain bf16 operands (round-to-nearest), the opt-in
 // `precision='bf16'` throughput mode: one MFMA per block instead of six, one conversion per value pair instead of 5.5 instructions.
 template <int NP>
 __device__ __forceinline__ void split_x4(const float (&v)[4], u32x2_t& q1, u32x2_t& q2, u32x2_t& q3) {
     if (NP == 3) {
         split3_x4(v, q1, q2, q3);
+    } else if (NP == 2) {
+        split2_x4(v, q1, q2);
+        q3 = q1;   // unused
     } else {
         typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
         const bf16x2_t lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};      // v_cvt_pk_bf16_f32 (RNE)
@@ -154,12 +217,20 @@ __device__ __forceinline__ void split_x4(const float (&v)[4], u32x2_t& q1, u32x2
 template <int NP>
 __device__ __forceinline__ void mfma_np32(f32x4_t& acc, const WFrag32& w, bf16x8_t x1, bf16x8_t x2, bf16x8_t x3) {
     if (NP == 3) mfma_split32(acc, w, x1, x2, x3);
-    else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[0], x1, acc, 0, 0, 0);
+    else if (NP == 2) {   // small terms first: lo hi, hi lo, hi hi
+        acc = sb_mfma_h(w.p[1], x1, acc);
+        acc = sb_mfma_h(w.p[0], x2, acc);
+        acc = sb_mfma_h(w.p[0], x1, acc);
+    } else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[0], x1, acc, 0, 0, 0);
 }
 template <int NP>
 __device__ __forceinline__ void mfma_np16(f32x4_t& acc, const WFrag16& w, s16x4_t x1, s16x4_t x2, s16x4_t x3) {
     if (NP == 3) mfma_split16(acc, w, x1, x2, x3);
-    else acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.p[0], x1, acc, 0, 0, 0);
+    else if (NP == 2) {   // K = 16: two piece products share one 32-deep instruction (operands concatenated along K): w_lo x_hi + w_hi x_lo | w_hi x_hi
+        const s16x4_t z = {0, 0, 0, 0};
+        acc = sb_mfma_h(sb_cat8(w.p[1], w.p[0]), sb_cat8(x1, x2), acc);
+        acc = sb_mfma_h(sb_cat8(w.p[0], z), sb_cat8(x1, z), acc);
+    } else acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w.p[0], x1, acc, 0, 0, 0);
 }
 // weight fragments for NP = 1: piece 0 rounded to nearest (pieces 1, 2 unused)
 __device__ __forceinline__ WFrag32 load_wfrag32_rne(const float* __restrict__ W, int K, int kb) {

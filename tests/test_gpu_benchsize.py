@@ -76,19 +76,51 @@ def test_train_step_vs_reference_gradients(manifest, name, mode):
         den = sum(float((t64[k] ** 2).sum()) for k in ks) ** 0.5
         ours = sum(float(((grads[k].astype(np.float64) - t64[k]) ** 2).sum()) for k in ks) ** 0.5 / den
         nk = noise[kd]
-        bound = 3.0 * max(nk['ref_vs_fp64'], max(nk['ref_spread']))
+        bound = min(3.0 * max(nk['ref_vs_fp64'], max(nk['ref_spread'])), 0.1)   # capped: the band-against-band test below is the discriminating gate
         report[kd] = (ours, nk['ref_vs_fp64'], max(nk['ref_spread']))
         assert ours <= bound, (name, kd, ours, nk)
         for k in ks:
             nt = noise['tensors'][k]
             e_t = float(((grads[k].astype(np.float64) - t64[k]) ** 2).sum()) ** 0.5 / float((t64[k] ** 2).sum()) ** 0.5
-            assert e_t <= 5.0 * max(nt['ref_vs_fp64'], max(nt['ref_spread'])), (name, k, e_t, nt)
+            assert e_t <= min(5.0 * max(nt['ref_vs_fp64'], max(nt['ref_spread'])), 0.25), (name, k, e_t, nt)   # (kernel-level truth: test_mixer_backward_kernel_at_awkward_shapes, 1e-4 vs fp64)
     print(name, mode, {k: tuple(f'{v:.2e}' for v in r) for k, r in report.items()})
     worst = max((float(np.abs(v - g[k.replace('.', '/')]).max() / max(float(np.abs(g[k.replace('.', '/')]).max()), 2e-5)) / 3e-2, k)
                 for k, v in grads.items() if not k.endswith(kinds))
     assert worst[0] < 1.0, worst
     a, b = eng.live_ranges[0][1], eng.live_ranges[1][0]
     assert float(eng.gflat[a:b].abs().max()) == 0.0            # dead-stage slots of the flat gradient buffer: never written
+
+
+@pytest.mark.parametrize('name', ['grad_c4_k4_p128', 'grad_c8_k4_p128', 'grad_c4_k2_p80x48', 'grad_c4_k2_p208x176', 'grad_c8_k8_p256'])
+def test_cancelling_sum_gradient_kinds_band_against_band(manifest, name):
+    """The five gradient kinds that cancel to ~1e-5 of their terms, gated BAND AGAINST BAND: this build's gradients go
+    through the same four seeded +-1-ulp input nudges the reference's own fp32 gradients went through (tools/gen_goldens.py round4 ->
+    tests/golden/gradnoise.json; tools/grad_spread.py is the function and the table, profiles/r05_grad_spread.txt), and per kind
+      (i)  the rms of this build's spread is at most 2 x the reference's (measured 0.0 ... 1.4 x): the build's band is no wider;
+      (ii) the MEAN of the five draws is within 2 x max(the reference's one-run distance, the reference's spread rms) of the fp64 gradient
+           (measured 0.1 ... 0.65 x on the power-of-two sizes): the band is centred where the reference's is.  3 x on the two non-power-of-two
+           cases, whose FFT mixer runs Bluestein lines: their offset (up to 2.8 x at 208 x 176) is deterministic fp32 arithmetic of another
+           algorithm (pocketfft's mixed radix on the reference's side), which nudged inputs do not average out.
+    A one-draw comparison cannot tell "inside the band" from "a 3 x wider band"; this can.  How it was checked to have teeth: with
+    k_attn_bwd_f's pos_emb accumulation degraded on purpose (every dS rounded to bf16 before it is added, `-DLG_DEGRADE_DPOS` variant
+    build) (ii) goes red for pos_emb in every 4-band case (profiles/r05_grad_spread.txt, last block)."""
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), '..', 'tools'))
+    from grad_spread import KINDS, grad_spread
+    with open(f'{GOLD}/gradnoise.json') as f:
+        noise = json.load(f)[name]
+    ours = grad_spread(name, manifest, GOLD)
+    pow2 = all((v & (v - 1)) == 0 for v in (4 * manifest[name]['h'], 4 * manifest[name].get('w', manifest[name]['h'])))
+    rows = {}
+    for kd in KINDS:
+        o, r = ours[kd], noise[kd]
+        rows[kd] = (o['spread_rms'] / r['ref_spread_rms'], o['mean_vs_fp64'] / max(r['ref_vs_fp64'], r['ref_spread_rms']))
+    print(name, {k.split('.', 1)[1]: (round(a, 2), round(b, 2)) for k, (a, b) in rows.items()})
+    for kd, (rs, rm) in rows.items():
+        assert rs <= 2.0, (name, kd, 'spread', rs)
+        assert rm <= (2.0 if pow2 else 3.0), (name, kd, 'mean', rm)
 
 
 @pytest.mark.parametrize('C,h,K,B', [(4, 32, 4, 3), (8, 16, 2, 2)])
