@@ -32,6 +32,7 @@ LG_VAR_FFN_SAVE3, LG_VAR_FFN_SAVE5 = 1 << 2, 2 << 2
 LG_VAR_FFN_BWD32_XS, LG_VAR_FFN_DWBWD_TILE, LG_VAR_ATTN_BWD_R3 = 1 << 4, 1 << 5, 1 << 6
 LG_VAR_DSTEP_TILES = 1 << 7
 LG_VAR_ATTN_FWD_VALU = 1 << 8
+LG_VAR_FFN_BF16X3 = 1 << 9
 LG_ABI_VERSION = 2   # include/lgteun_hip.h: checked against lg_abi_version() when the library is loaded
 
 
@@ -51,6 +52,8 @@ def variant_from_env(env=None):
         v |= LG_VAR_DSTEP_TILES
     if env.get('LG_ATTN_FWD', '') == 'valu':
         v |= LG_VAR_ATTN_FWD_VALU
+    if env.get('LG_FFN_SPLIT', '') == 'bf16x3':
+        v |= LG_VAR_FFN_BF16X3
     return v
 
 

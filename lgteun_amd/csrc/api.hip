@@ -143,6 +143,7 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
         p->attn_bwd_old = (v & LG_VAR_ATTN_BWD_R3) ? 1 : 0;
         p->dstep_tiles = (v & LG_VAR_DSTEP_TILES) ? 1 : 0;
         p->attn_fwd_valu = (v & LG_VAR_ATTN_FWD_VALU) ? 1 : 0;
+        p->ffn_bf16x3 = (v & LG_VAR_FFN_BF16X3) ? 1 : 0;
     }
     p->off = (int64_t*)malloc(sizeof(int64_t) * n_offsets);
     memcpy(p->off, offsets, sizeof(int64_t) * n_offsets);
@@ -231,7 +232,7 @@ static int block_mixer_fwd(const lg_plan* pl, const float* P, int stage, int j, 
 }
 
 static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, const BlockBufs& bb, float* g_next, int next_blk,
-                         int B, int flags, hipStream_t s, float* wsplit) {
+                         int B, int flags, hipStream_t s, float* wsplit, const float* ffn_scales) {
     int rc;
     Ffn1Args a1;
     const bool pre = pl->ffn_saves_preact(bb.e);   // h1 / h3 go to the a1 / a3 slots, nothing to g1 / g3
@@ -243,6 +244,7 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     a1.hbf = pl->hidden_bf16(bb.e) ? 1 : 0;
     a1.tile16 = pl->ffn_tile;
     a1.wsplit = wsplit;
+    a1.scales = pl->ffn_f16x2(bb.e) ? ffn_scales + ((size_t)stage * 5 + j) * 8 : nullptr;   // written by prep_stages for the stages of this call
     Ffn2Args a2;
     a2.h2 = bb.h2; a2.x = bb.xmid; a2.a3s = (flags & LG_FLAG_SAVE) ? bb.a3 : nullptr; a2.g3s = ((flags & LG_FLAG_SAVE) && !pre && !pl->ffn_dw_x32(bb.e, bb.h, bb.w)) ? bb.g3 : nullptr; a2.y = bb.xout;   // g3s null with a3s set: a3 receives the PRE-activation h3
     a2.g = g_next;
@@ -270,6 +272,25 @@ static int pos_transpose_stages(const lg_plan* pl, const float* P, int st0, int 
         for (int j = 0; j < 5; ++j, ++n) { src[n] = P + pl->blk(st, j, B_POS); dst[n] = posT_all + ((size_t)st * 5 + j) * 2 * 64 * 64; }
     return launch_pos_transpose_n(n, src, dst, s);
 }
+// what the LGTs of stages [st0, st1) need in front of their first kernel: the transposed pos_emb tables (round 2's vector-pipe mixer and the
+// backward kernels read them) and the operand scales of the f16-pair FFN arithmetic -- one launch each for all stages of the call
+static int prep_stages(const lg_plan* pl, const float* P, int st0, int st1, NetBufs& nb, hipStream_t s) {
+    int rc = pos_transpose_stages(pl, P, st0, st1, nb.posT, s);
+    if (rc || st1 <= st0) return rc;
+    const int E = 4 * pl->cfg.C;
+    if (!pl->ffn_f16x2(E) && !pl->ffn_f16x2(2 * E)) return 0;
+    FfnPrepJob jobs[5 * LG_MAX_K];
+    int n = 0;
+    for (int st = st0; st < st1; ++st)
+        for (int j = 0; j < 5; ++j, ++n) {
+            FfnPrepJob& q = jobs[n];
+            q.ln2g = P + pl->blk(st, j, B_LN2G); q.ln2b = P + pl->blk(st, j, B_LN2B);
+            q.w1 = P + pl->blk(st, j, B_W1); q.b1 = P + pl->blk(st, j, B_B1); q.w2 = P + pl->blk(st, j, B_W2); q.b2 = P + pl->blk(st, j, B_B2);
+            q.dww = P + pl->blk(st, j, B_DWW); q.dwb = P + pl->blk(st, j, B_DWB); q.w3 = P + pl->blk(st, j, B_W3);
+            q.e = j == 2 ? 2 * E : E;
+        }
+    return launch_ffn_scales(n, jobs, nb.ffn_scales + (size_t)st0 * 5 * 8, s);
+}
 
 // LGT.forward (LGT.py:314-344) on z -> out with the buffers of `nb`
 // pos_ready: nb.posT already holds this stage's transposed pos_emb tables (the net-level entries transpose all stages in one launch)
@@ -279,7 +300,7 @@ static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z,
     const int E = 4 * c.C;
     int rc;
     float* posT = nb.posT + (size_t)stage * 5 * 2 * 64 * 64;
-    if (!pos_ready && (rc = pos_transpose_stages(pl, P, stage, stage + 1, nb.posT, s))) return rc;
+    if (!pos_ready && (rc = prep_stages(pl, P, stage, stage + 1, nb, s))) return rc;
     EmbedArgs ea;
     ea.z = z; ea.x = nb.x0; ea.g = nb.blk[0].g;
     ea.dww = P + pl->lgt(stage, L_PE_DWW); ea.dwb = P + pl->lgt(stage, L_PE_DWB);
@@ -290,9 +311,9 @@ static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z,
     if ((rc = launch_embed(c.C, ea, s))) return rc;
     // encoder LGB (2 blocks)
     if ((rc = block_mixer_fwd(pl, P, stage, 0, nb.blk[0], posT + 0 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
-    if ((rc = block_ffn_fwd(pl, P, stage, 0, nb.blk[0], nb.blk[1].g, 1, B, flags, s, nb.wsplit))) return rc;
+    if ((rc = block_ffn_fwd(pl, P, stage, 0, nb.blk[0], nb.blk[1].g, 1, B, flags, s, nb.wsplit, nb.ffn_scales))) return rc;
     if ((rc = block_mixer_fwd(pl, P, stage, 1, nb.blk[1], posT + 1 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
-    if ((rc = block_ffn_fwd(pl, P, stage, 1, nb.blk[1], nullptr, 0, B, flags, s, nb.wsplit))) return rc;
+    if ((rc = block_ffn_fwd(pl, P, stage, 1, nb.blk[1], nullptr, 0, B, flags, s, nb.wsplit, nb.ffn_scales))) return rc;
     // down
     DownArgs da;
     da.x = nb.blk[1].xout; da.y = nb.blk[2].xin; da.g = nb.blk[2].g;
@@ -303,7 +324,7 @@ static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z,
     if ((rc = launch_down(E, da, s))) return rc;
     // bottleneck
     if ((rc = block_mixer_fwd(pl, P, stage, 2, nb.blk[2], posT + 2 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
-    if ((rc = block_ffn_fwd(pl, P, stage, 2, nb.blk[2], nullptr, 0, B, flags, s, nb.wsplit))) return rc;
+    if ((rc = block_ffn_fwd(pl, P, stage, 2, nb.blk[2], nullptr, 0, B, flags, s, nb.wsplit, nb.ffn_scales))) return rc;
     // up + fusion
     UpFuseArgs ua;
     ua.xb = nb.blk[2].xout; ua.skip = nb.blk[1].xout; ua.y = nb.blk[3].xin; ua.g = nb.blk[3].g;
@@ -315,9 +336,9 @@ static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z,
     if ((rc = launch_upfuse(E, ua, s))) return rc;
     // decoder LGB (2 blocks)
     if ((rc = block_mixer_fwd(pl, P, stage, 3, nb.blk[3], posT + 3 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
-    if ((rc = block_ffn_fwd(pl, P, stage, 3, nb.blk[3], nb.blk[4].g, 4, B, flags, s, nb.wsplit))) return rc;
+    if ((rc = block_ffn_fwd(pl, P, stage, 3, nb.blk[3], nb.blk[4].g, 4, B, flags, s, nb.wsplit, nb.ffn_scales))) return rc;
     if ((rc = block_mixer_fwd(pl, P, stage, 4, nb.blk[4], posT + 4 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
-    if ((rc = block_ffn_fwd(pl, P, stage, 4, nb.blk[4], nullptr, 0, B, flags, s, nb.wsplit))) return rc;
+    if ((rc = block_ffn_fwd(pl, P, stage, 4, nb.blk[4], nullptr, 0, B, flags, s, nb.wsplit, nb.ffn_scales))) return rc;
     // tail
     TailArgs ta;
     ta.x = nb.blk[4].xout; ta.z = z; ta.out = out;
@@ -342,7 +363,7 @@ extern "C" int lgteun_forward(const lg_plan* plan, const float* params, const fl
     int rc;
     // pos_emb^T of every stage whose LGT runs in this call
     const bool all_stages = chained || ((flags & LG_FLAG_FAITHFUL) && !(flags & LG_FLAG_DEFER_DEAD));
-    if ((rc = pos_transpose_stages(plan, params, all_stages ? 0 : c.K - 1, c.K, nb.posT, s))) return rc;
+    if ((rc = prep_stages(plan, params, all_stages ? 0 : c.K - 1, c.K, nb, s))) return rc;
     // Z0 = bicubic x4 (unlg_former.py:53)
     if ((rc = launch_resample(2, ms, nb.Z[0], B * c.C, c.H / 4, c.W / 4, s))) return rc;
     if (chained) {
@@ -376,7 +397,7 @@ extern "C" int lgteun_dead_forward(const lg_plan* plan, const float* params, voi
     NetBufs nb;
     carve(plan, B, train, workspace, nb);
     {
-        const int rc = pos_transpose_stages(plan, params, 0, plan->cfg.K - 1, nb.posT, (hipStream_t)stream);
+        const int rc = prep_stages(plan, params, 0, plan->cfg.K - 1, nb, (hipStream_t)stream);
         if (rc) return rc;
     }
     for (int i = 0; i + 1 < plan->cfg.K; ++i) {
@@ -465,7 +486,8 @@ extern "C" int lg_op_block(const lg_plan* plan, const float* params, int32_t sta
     bb.xmid = const_cast<float*>(x);
     bb.xout = y;
     (void)npix;
-    return block_ffn_fwd(plan, params, stage, blk, bb, nullptr, 0, B, 0, s, nb.wsplit);
+    if ((rc = prep_stages(plan, params, stage, stage + 1, nb, s))) return rc;   // the FFN's operand scales
+    return block_ffn_fwd(plan, params, stage, blk, bb, nullptr, 0, B, 0, s, nb.wsplit, nb.ffn_scales);
 }
 
 extern "C" int lg_op_block_bwd(const lg_plan* plan, const float* params, float* grads, int32_t stage, int32_t blk, int32_t which,
@@ -492,7 +514,8 @@ extern "C" int lg_op_block_bwd(const lg_plan* plan, const float* params, float* 
         if ((rc = block_mixer_fwd(plan, params, stage, blk, bb, nb.posT, B, LG_FLAG_SAVE, 0, s, nb.fft_scratch))) return rc;
     } else {
         bb.xmid = const_cast<float*>(x);
-        if ((rc = block_ffn_fwd(plan, params, stage, blk, bb, nullptr, 0, B, LG_FLAG_SAVE, s, nb.wsplit))) return rc;
+        if ((rc = prep_stages(plan, params, stage, stage + 1, nb, s))) return rc;
+        if ((rc = block_ffn_fwd(plan, params, stage, blk, bb, nullptr, 0, B, LG_FLAG_SAVE, s, nb.wsplit, nb.ffn_scales))) return rc;
     }
     return op_block_bwd(plan, params, grads, stage, blk, which, dy, dx, nb, (char*)workspace + nb.bytes, B, s);
 }

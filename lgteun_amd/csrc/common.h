@@ -45,6 +45,9 @@ struct lg_plan {
     bool hidden_bf16(int e) const { return cfg.precision == 1 && e != 64; }
     // precision = 'bf16' (plain bf16 MFMA, bf16 storage of the saved tensors) knows modes 2 and 5 only (3 falls back to 5)
     int attn_bwd_old; // A/B switch (lg_config.variant LG_VAR_ATTN_BWD_R3; Python side: LG_ATTN_BWD=r3): 1 = round 3's k_attn_bwd_core + k_attn_bwd_epi + k_wgrad_t at e = 16 instead of k_attn_bwd_f
+    int ffn_bf16x3;    // A/B switch (lg_config.variant LG_VAR_FFN_BF16X3; Python side: LG_FFN_SPLIT=bf16x3): the fused FFN forward's GEMMs as three bf16 pieces / six
+                       // products (round 2) instead of two f16 pieces / three products with proven power-of-two operand scales (round 5, k_ffn_prep.hip)
+    bool ffn_f16x2(int e) const { return cfg.precision == 0 && ffn_tile == 0 && !ffn_bf16x3 && save_mode == 2 && e == 16; }
     int attn_fwd_valu; // A/B switch (lg_config.variant LG_VAR_ATTN_FWD_VALU; Python side: LG_ATTN_FWD=valu): round 2's vector-pipe k_attn instead of the matrix-pipe k_attn_m
     int dstep_tiles; // A/B switch (lg_config.variant LG_VAR_DSTEP_TILES; Python side: LG_DSTEP=tiles): the tile kernels of the data step also where the one-launch
                      // plane-in-LDS form (k_dstep.hip) exists
@@ -162,6 +165,20 @@ __device__ __forceinline__ void gelu2_both_f(lg_v2f x, lg_v2f& a, lg_v2f& g) {
     a = absx * sv + x * 0.5f;
     const lg_v2f cs = (lg_v2f){copysignf(sv.x, x.x), copysignf(sv.y, x.y)};
     g = x * (ex * 0.39894228040143267794f) + (cs + 0.5f);
+}
+// gelu of a value that arrives SCALED by a power of two s_in and has to leave scaled by s_out (the f16-pair arithmetic of the FFN kernels,
+// split_bf16.h NP = 2): returns s_out * gelu(x / s_in) for c1 = sqrt(1/2) / s_in, hr = 0.5 s_out / s_in.  The same instruction sequence as
+// gelu2_f with two of its immediates replaced by these (power-of-two multiples of them): bit for bit s_out times gelu2_f's result.
+__device__ __forceinline__ lg_v2f gelu2_scaled(lg_v2f x, float c1, float hr) {
+    const lg_v2f absx = (lg_v2f){fabsf(x.x), fabsf(x.y)};
+    const lg_v2f az = absx * c1;
+    const lg_v2f d = az * 0.3275911f + 1.0f;
+    const lg_v2f t = (lg_v2f){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const lg_v2f poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const lg_v2f m = az * az * -1.44269504088896340736f;
+    const lg_v2f ex = (lg_v2f){__builtin_amdgcn_exp2f(m.x), __builtin_amdgcn_exp2f(m.y)};
+    const lg_v2f sv = poly * ex * (0.0f - hr) + hr;
+    return absx * sv + x * hr;
 }
 // precision = 'bf16' (the NP = 1 instances of the FFN kernels): GELU in its tanh form, x * sigmoid(2 sqrt(2/pi) (x + 0.044715 x^3)) -- the
 // nn.GELU(approximate='tanh') function.  Max deviation from the erf form 4.7e-4 (gelu) / 8.7e-4 (gelu'), i.e. below the resolution of the

@@ -411,10 +411,10 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
                 const lg_v2f P0 = (lg_v2f){__builtin_amdgcn_exp2f(e0.x), __builtin_amdgcn_exp2f(e0.y)} * (lg_v2f){sinv.x, sinv.y};
                 const lg_v2f P1 = (lg_v2f){__builtin_amdgcn_exp2f(e1.x), __builtin_amdgcn_exp2f(e1.y)} * (lg_v2f){sinv.z, sinv.w};
                 const lg_v2f dS0 = P0 * (dP0 - (lg_v2f){sdv.x, sdv.y}), dS1 = P1 * (dP1 - (lg_v2f){sdv.z, sdv.w});
-#ifdef LG_DEGRADE_DPOS   // diagnostic variant only (never in the product build): every dS rounded to bf16 before it enters the pos_emb gradient --
-                        // what tests/test_gpu_benchsize.py::test_cancelling_sum_gradient_kinds_band_against_band must turn red on
-                dpacc[2 * g] += (lg_v2f){(float)(__bf16)dS0.x, (float)(__bf16)dS0.y};
-                dpacc[2 * g + 1] += (lg_v2f){(float)(__bf16)dS1.x, (float)(__bf16)dS1.y};
+#ifdef LG_DEGRADE_DPOS   // diagnostic variant only (never in the product build): a 5 % error in what enters the pos_emb gradient -- what
+                        // tests/test_gpu_benchsize.py::test_cancelling_sum_gradient_kinds_band_against_band must turn red on
+                dpacc[2 * g] += dS0 * 1.05f;
+                dpacc[2 * g + 1] += dS1 * 1.05f;
 #else
                 dpacc[2 * g] += dS0;
                 dpacc[2 * g + 1] += dS1;

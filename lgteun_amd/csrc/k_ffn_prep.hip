@@ -1,0 +1,81 @@
+// Power-of-two operand scales of the fused feed_forward kernels' f16-pair arithmetic (split_bf16.h, NP = 2) -- reference
+// models/common/LGT.py:91-109 has no counterpart: this is bookkeeping of the number format.
+//
+// An f16 pair (hi, lo) carries 24 significant bits only while the value sits in f16's exponent range (|v| < 2^16, and down to 2^-17 of
+// that before the low piece starts to lose bits), so every MFMA operand of the forward FFN is multiplied by a power of two -- exact, and
+// undone exactly behind the accumulator -- chosen from a bound that holds for EVERY input, computed here from the block's weights:
+//     |LN(x)_k|   <= sqrt(e) |gamma_k| + |beta_k|                         =: y_k          (LayerNorm output: |x^_k| <= sqrt(e - 1))
+//     |h1_c|      <= |b1_c| + sum_k |W1_ck| y_k,   |gelu(h)| <= max(|h|, 0.17)          =: a1_c
+//     |h2_c|      <= |b2_c| + sum_k |W2_ck| a1_k
+//     |h3_c|      <= |dwb_c| + (sum_t |dww_ct|) |h2_c|                                 =: a3_c (same max)
+// The bounds are loose by 2^3 .. 2^10 against typical activations (sums of absolute values); f16's 30 binades absorb that: an operand
+// scaled so that its BOUND is below 2^15 keeps elements down to 2^-17 of the bound exact to 2^-24 and smaller ones to an absolute 2^-25
+// (2^-40 of the bound).  One workgroup per block, all blocks of a forward call in ONE launch.
+// out[job][8] = { s_x, s_a1, s_a3, s_w1, s_w2, s_w3, 0, 0 }: scales of LN(x), gelu(h1), gelu(h3) and the three weights.
+#include "kernels.h"
+
+namespace {
+__device__ __forceinline__ float block_max(float v, float* red) {
+    __syncthreads();
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    return red[0];
+}
+__device__ __forceinline__ float pow2_below(float bound) {   // the power of two s with bound * s in [2^14, 2^15)   (bound = 0: 2^15)
+    return __builtin_amdgcn_ldexpf(1.0f, 15 - __builtin_amdgcn_frexp_expf(bound));
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_ffn_scales(FfnPrepTable tab, float* __restrict__ out) {
+    const FfnPrepJob& j = tab.j[blockIdx.x];
+    const int e = j.e, n1 = 4 * e, t = threadIdx.x;
+    __shared__ float ylim[64], a1lim[256], red[256];
+    float by = 0.f;
+    if (t < e) { by = sqrtf((float)e) * fabsf(j.ln2g[t]) + fabsf(j.ln2b[t]); ylim[t] = by; }
+    const float By = block_max(by, red);
+    float bh1 = 0.f, mw1 = 0.f;
+    if (t < n1) {
+        bh1 = fabsf(j.b1[t]);
+        for (int k = 0; k < e; ++k) { const float w = fabsf(j.w1[(size_t)t * e + k]); bh1 += w * ylim[k]; mw1 = fmaxf(mw1, w); }
+        bh1 = fmaxf(bh1, 0.17f);
+        a1lim[t] = bh1;
+    }
+    const float A1 = block_max(bh1, red);
+    const float MW1 = block_max(mw1, red);
+    float bh3 = 0.f, mw2 = 0.f;
+    if (t < n1) {
+        float bh2 = fabsf(j.b2[t]);
+        for (int k = 0; k < n1; ++k) { const float w = fabsf(j.w2[(size_t)t * n1 + k]); bh2 += w * a1lim[k]; mw2 = fmaxf(mw2, w); }
+        float taps = 0.f;
+        for (int k = 0; k < 9; ++k) taps += fabsf(j.dww[t * 9 + k]);
+        bh3 = fmaxf(fabsf(j.dwb[t]) + taps * bh2, 0.17f);
+    }
+    const float A3 = block_max(bh3, red);
+    const float MW2 = block_max(mw2, red);
+    float mw3 = 0.f;
+    for (int i = t; i < e * n1; i += 256) mw3 = fmaxf(mw3, fabsf(j.w3[i]));
+    const float MW3 = block_max(mw3, red);
+    if (t == 0) {
+        float* o = out + (size_t)blockIdx.x * 8;
+        o[0] = pow2_below(By); o[1] = pow2_below(A1); o[2] = pow2_below(A3);
+        o[3] = pow2_below(MW1); o[4] = pow2_below(MW2); o[5] = pow2_below(MW3);
+        o[6] = 0.f; o[7] = 0.f;
+    }
+}
+
+int launch_ffn_scales(int n, const FfnPrepJob* jobs, float* out, hipStream_t s) {
+    for (int j0 = 0; j0 < n; j0 += LG_MAX_FFN_PREP_JOBS) {   // (the table travels as a kernel argument: at most LG_MAX_FFN_PREP_JOBS blocks per launch)
+        const int m = n - j0 < LG_MAX_FFN_PREP_JOBS ? n - j0 : LG_MAX_FFN_PREP_JOBS;
+        FfnPrepTable tab;
+        for (int i = 0; i < LG_MAX_FFN_PREP_JOBS; ++i) tab.j[i] = jobs[j0 + (i < m ? i : 0)];
+        for (int i = 0; i < m; ++i)
+            if (tab.j[i].e != 16 && tab.j[i].e != 32 && tab.j[i].e != 64) { lg_set_error("ffn_scales: e=%d unsupported", tab.j[i].e); return -2; }
+        k_ffn_scales<<<m, 256, 0, s>>>(tab, out + (size_t)j0 * 8);
+        LG_CHECK_LAUNCH();
+    }
+    return 0;
+}

@@ -83,16 +83,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         sLn2g[i] = a1.ln2g[i]; sLn2b[i] = a1.ln2b[i]; sB3[i] = a2.b3[i];
         sN1g[i] = a2.g ? a2.n1g[i] : 0.f; sN1b[i] = a2.g ? a2.n1b[i] : 0.f;
     }
+    // ---- NP = 2 (two f16 pieces per operand): every matrix-core operand is scaled by a power of two that puts its PROVEN bound below 2^15
+    // (k_ffn_prep.hip), exactly, and the product of the two scales is taken out again behind the accumulator -- by constants that were
+    // multiplications already (the GELUs' two immediates, the halo mask, the residual add that becomes an fma): no instruction is added.
+    //   GEMM1: (s_x LN(x)) x (s_w1 W1), bias b1 S1 as initial accumulator -> S1 h1, S1 = s_x s_w1;  gelu -> s_a1 gelu(h1)
+    //   GEMM2: x (s_w2 W2) -> S2 h2, S2 = s_a1 s_w2; the halo mask carries 1 / S2: the ring (and the saved h2) hold h2 itself
+    //   depthwise conv, gelu -> s_a3 gelu(h3);  GEMM3: x (s_w3 W3) -> S3 (...), S3 = s_a3 s_w3;  y = acc / S3 + x
+    float sx = 1.f, sa1 = 1.f, sa3 = 1.f, sw1 = 1.f, sw2 = 1.f, sw3 = 1.f;
+    if (NP == 2) { sx = a1.scales[0]; sa1 = a1.scales[1]; sa3 = a1.scales[2]; sw1 = a1.scales[3]; sw2 = a1.scales[4]; sw3 = a1.scales[5]; }
+    const float S1 = sx * sw1, S2 = sa1 * sw2, S3 = sa3 * sw3;
+    const float g1c = 0.70710678118654752440f / S1, g1h = 0.5f * sa1 / S1, g3h = 0.5f * sa3, inv2 = 1.0f / S2, inv3 = 1.0f / S3;   // (powers of two: exact)
     // ---- weights: split once, register-resident for every strip of this workgroup
     const int c0 = wave * 16 + 4 * g;                 // first of the four h1 / h2 channels this lane holds after GEMM1 / GEMM2
-    const float4 b1v = *reinterpret_cast<const float4*>(a1.b1 + c0);
-    const float4 b2v = *reinterpret_cast<const float4*>(a1.b2 + c0);
+    float4 b1v = *reinterpret_cast<const float4*>(a1.b1 + c0);
+    float4 b2v = *reinterpret_cast<const float4*>(a1.b2 + c0);
+    if (NP == 2) { b1v = make_float4(b1v.x * S1, b1v.y * S1, b1v.z * S1, b1v.w * S1); b2v = make_float4(b2v.x * S2, b2v.y * S2, b2v.z * S2, b2v.w * S2); }
     constexpr bool BF = (NP == 1);                    // plain-bf16 mode: saved activations are stored as bf16 too (hstore.h)
-    const WFrag16 w1f = NP == 3 ? load_wfrag16(a1.w1 + (size_t)(wave * 16) * E, E, 0) : (NP == 2 ? load_wfrag16_h2(a1.w1 + (size_t)(wave * 16) * E, E, 0, 1.0f) : load_wfrag16_rne(a1.w1 + (size_t)(wave * 16) * E, E, 0));
-    const WFrag32 w2f0 = NP == 3 ? load_wfrag32(a1.w2 + (size_t)(wave * 16) * N1, N1, 0) : (NP == 2 ? load_wfrag32_h2(a1.w2 + (size_t)(wave * 16) * N1, N1, 0, 1.0f) : load_wfrag32_rne(a1.w2 + (size_t)(wave * 16) * N1, N1, 0));
-    const WFrag32 w2f1 = NP == 3 ? load_wfrag32(a1.w2 + (size_t)(wave * 16) * N1, N1, 1) : (NP == 2 ? load_wfrag32_h2(a1.w2 + (size_t)(wave * 16) * N1, N1, 1, 1.0f) : load_wfrag32_rne(a1.w2 + (size_t)(wave * 16) * N1, N1, 1));
-    const WFrag32 w3f0 = NP == 3 ? load_wfrag32(a2.w3, N1, 0) : (NP == 2 ? load_wfrag32_h2(a2.w3, N1, 0, 1.0f) : load_wfrag32_rne(a2.w3, N1, 0));
-    const WFrag32 w3f1 = NP == 3 ? load_wfrag32(a2.w3, N1, 1) : (NP == 2 ? load_wfrag32_h2(a2.w3, N1, 1, 1.0f) : load_wfrag32_rne(a2.w3, N1, 1));
+    const WFrag16 w1f = NP == 3 ? load_wfrag16(a1.w1 + (size_t)(wave * 16) * E, E, 0) : (NP == 2 ? load_wfrag16_h2(a1.w1 + (size_t)(wave * 16) * E, E, 0, sw1) : load_wfrag16_rne(a1.w1 + (size_t)(wave * 16) * E, E, 0));
+    const WFrag32 w2f0 = NP == 3 ? load_wfrag32(a1.w2 + (size_t)(wave * 16) * N1, N1, 0) : (NP == 2 ? load_wfrag32_h2(a1.w2 + (size_t)(wave * 16) * N1, N1, 0, sw2) : load_wfrag32_rne(a1.w2 + (size_t)(wave * 16) * N1, N1, 0));
+    const WFrag32 w2f1 = NP == 3 ? load_wfrag32(a1.w2 + (size_t)(wave * 16) * N1, N1, 1) : (NP == 2 ? load_wfrag32_h2(a1.w2 + (size_t)(wave * 16) * N1, N1, 1, sw2) : load_wfrag32_rne(a1.w2 + (size_t)(wave * 16) * N1, N1, 1));
+    const WFrag32 w3f0 = NP == 3 ? load_wfrag32(a2.w3, N1, 0) : (NP == 2 ? load_wfrag32_h2(a2.w3, N1, 0, sw3) : load_wfrag32_rne(a2.w3, N1, 0));
+    const WFrag32 w3f1 = NP == 3 ? load_wfrag32(a2.w3, N1, 1) : (NP == 2 ? load_wfrag32_h2(a2.w3, N1, 1, sw3) : load_wfrag32_rne(a2.w3, N1, 1));
     // depthwise taps of the lane's four channels (phase P2: lane = (pixel slot lane / 16, channel quad q)): 36 + 4 contiguous
     // floats, re-read (L1 / L2 hits) at the top of every step instead of pinning 40 VGPRs through the GEMM phases
     const int q = lane % CQ;
@@ -100,7 +111,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int lpx = threadIdx.x >> 2, lq = threadIdx.x & 3;
     const bool ln_thread = threadIdx.x < 4 * CH;
     __syncthreads();
-    const float4 lng = *reinterpret_cast<const float4*>(sLn2g + 4 * lq), lnb = *reinterpret_cast<const float4*>(sLn2b + 4 * lq);
+    float4 lng = *reinterpret_cast<const float4*>(sLn2g + 4 * lq), lnb = *reinterpret_cast<const float4*>(sLn2b + 4 * lq);
+    if (NP == 2) { lng = make_float4(lng.x * sx, lng.y * sx, lng.z * sx, lng.w * sx); lnb = make_float4(lnb.x * sx, lnb.y * sx, lnb.z * sx, lnb.w * sx); }
 
 #pragma unroll 1
     for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
@@ -146,7 +158,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         *reinterpret_cast<u32x2_t*>(dst) = q1;
         if (NP >= 2) *reinterpret_cast<u32x2_t*>(dst + CH * E) = q2;
         if (NP == 3) *reinterpret_cast<u32x2_t*>(dst + 2 * CH * E) = q3;
-        if (lq == 0) sMask[slot][lpx] = m_;
+        if (lq == 0) sMask[slot][lpx] = NP == 2 ? m_ * inv2 : m_;   // NP = 2: the mask also takes S2 out of the accumulator
     };
 
     // h2 of halo rows [ya, ya + nr) x columns [x0 - 1, x0 + 17) -> ring   (nr = 2: strip prologue, 8: one step).
@@ -208,7 +220,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     }
                 } else {
                     if (SAVE == 2 && inner[pb]) HS<BF>::st4(a1.a1s, prow[pb], make_float4(acc[pb][0], acc[pb][1], acc[pb][2], acc[pb][3]));
-                    const lg_v2f a01 = gelu2_t<NP == 1>((lg_v2f){acc[pb][0], acc[pb][1]}), a23 = gelu2_t<NP == 1>((lg_v2f){acc[pb][2], acc[pb][3]});
+                    const lg_v2f a01 = NP == 2 ? gelu2_scaled((lg_v2f){acc[pb][0], acc[pb][1]}, g1c, g1h) : gelu2_t<NP == 1>((lg_v2f){acc[pb][0], acc[pb][1]});
+                    const lg_v2f a23 = NP == 2 ? gelu2_scaled((lg_v2f){acc[pb][2], acc[pb][3]}, g1c, g1h) : gelu2_t<NP == 1>((lg_v2f){acc[pb][2], acc[pb][3]});
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 }
                 u32x2_t q1, q2, q3;
@@ -339,7 +352,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                         const int y = y0 + ty, x = x0 + tx;
                         if (y < Yend && x < w) HS<BF>::st4(a2.a3s, ((b * h + y) * (long)w + x) * N1 + 4 * q, acc);
                     }
-                    const lg_v2f a01 = gelu2_t<NP == 1>((lg_v2f){acc.x, acc.y}), a23 = gelu2_t<NP == 1>((lg_v2f){acc.z, acc.w});
+                    const lg_v2f a01 = NP == 2 ? gelu2_scaled((lg_v2f){acc.x, acc.y}, 0.70710678118654752440f, g3h) : gelu2_t<NP == 1>((lg_v2f){acc.x, acc.y});
+                    const lg_v2f a23 = NP == 2 ? gelu2_scaled((lg_v2f){acc.z, acc.w}, 0.70710678118654752440f, g3h) : gelu2_t<NP == 1>((lg_v2f){acc.z, acc.w});
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 }
                 u32x2_t q1, q2, q3;
@@ -354,7 +368,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             __builtin_amdgcn_wave_barrier();
             // ---- GEMM3 (K = 64): out[16 channels][16 pixels of tile row ty]
             const float4 b3v = *reinterpret_cast<const float4*>(sB3 + 4 * g);
-            f32x4_t o = (f32x4_t){b3v.x, b3v.y, b3v.z, b3v.w};
+            f32x4_t o = NP == 2 ? (f32x4_t){b3v.x * S3, b3v.y * S3, b3v.z * S3, b3v.w * S3} : (f32x4_t){b3v.x, b3v.y, b3v.z, b3v.w};
             {
                 const uint16_t* p = G3 + r * LDP + 8 * g;
                 mfma_np32<NP>(o, w3f0, lds_x8(p), lds_x8(p + 16 * LDP), lds_x8(p + 2 * 16 * LDP));
@@ -364,7 +378,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             STAMP(17 + 3 * ch);
             // ---- epilogue in registers: residual, store, LayerNorm statistics of the next block across the four lane groups
             const int y = y0 + ty, x = x0 + r;
-            const float o0 = o[0] + xres[ch].x, o1 = o[1] + xres[ch].y, o2 = o[2] + xres[ch].z, o3 = o[3] + xres[ch].w;
+            const float os = NP == 2 ? inv3 : 1.0f;
+            const float o0 = o[0] * os + xres[ch].x, o1 = o[1] * os + xres[ch].y, o2 = o[2] * os + xres[ch].z, o3 = o[3] * os + xres[ch].w;
             const bool ok = y < Yend && x < w;
             if (ok) *reinterpret_cast<float4*>(a2.y + ((b * h + y) * (long)w + x) * E + 4 * g) = make_float4(o0, o1, o2, o3);
             if (a2.g) {
@@ -396,11 +411,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 
 }   // namespace
 
-#ifndef LG_FFN_NP
-#define LG_FFN_NP 3   // pieces of the fp32-equivalent mode: 3 = bf16 x 3 (six products), 2 = f16 x 2 (three products)
-#endif
 int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
-    constexpr int NPF = LG_FFN_NP;
+    constexpr int NPF = 3;
     ProfScope prof__(LG_K_FFN2, s);
     static DeviceOnce attr_once;
     if (attr_once.need()) {
@@ -408,6 +420,8 @@ int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<1, NPF>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<2, NPF>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<3, NPF>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
@@ -431,7 +445,9 @@ int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
         if (noh1) k_ffn_xs<3, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
         else if (save) k_ffn_xs<1, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
         else k_ffn_xs<0, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
-    } else if (noh1) k_ffn_xs<3, NPF><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    } else if (a1.scales && noh1) k_ffn_xs<3, 2><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);   // f16 pairs: the two default save modes
+    else if (a1.scales && !save) k_ffn_xs<0, 2><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    else if (noh1) k_ffn_xs<3, NPF><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
     else if (pre) k_ffn_xs<2, NPF><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
     else if (save) k_ffn_xs<1, NPF><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
     else k_ffn_xs<0, NPF><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);

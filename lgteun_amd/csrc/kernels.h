@@ -125,7 +125,14 @@ struct Ffn1Args {
     const float *ln2g, *ln2b, *w1, *b1, *w2, *b2;
     long P;
     void* wsplit;    // workspace scratch for pre-split weight fragments (ffn_wsplit_bytes; k_ffn_x32.hip), or nullptr
+    const float* scales;   // this block's operand scales { s_x, s_a1, s_a3, s_w1, s_w2, s_w3 } (k_ffn_prep.hip): the f16-pair arithmetic (NP = 2) of the
+                           // fused forward kernels; nullptr = the three-piece bf16 arithmetic (NP = 3)
 };
+// operand scales of the f16-pair FFN arithmetic: one job per block, all in one launch (k_ffn_prep.hip); out[job][8]
+struct FfnPrepJob { const float *ln2g, *ln2b, *w1, *b1, *w2, *b2, *dww, *dwb, *w3; int e; };
+#define LG_MAX_FFN_PREP_JOBS 40
+struct FfnPrepTable { FfnPrepJob j[LG_MAX_FFN_PREP_JOBS]; };
+int launch_ffn_scales(int n, const FfnPrepJob* jobs, float* out, hipStream_t s);
 int launch_ffn1(int e, const Ffn1Args& a, hipStream_t s);
 struct Ffn2Args {
     const void* h2;   // [B,h,w,4e]
