@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
     constexpr int CHC = 4 * NCH, NKP = cdiv(NPROD * CHC, 8);      // proj
     constexpr int MTP = NCH;
     constexpr int NPV = NP == 3 ? 2 : 1;                          // f16 pieces of p and v
-    constexpr bool RELOADX = HC >= 16;                            // the residual x is read again (L2) instead of held across the window
+    constexpr bool RELOADX = HC >= 32;                            // the residual x is read again (L2) instead of held across the window
     constexpr float LOG2E = 1.44269504088896340736f;
     extern __shared__ __attribute__((aligned(16))) u32x4_t smem4[];
     float4* sPos = reinterpret_cast<float4*>(smem4);              // [2][4 qt][4 kt][64 lanes]: the score tile's initial accumulator
@@ -230,26 +230,6 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
         for (int v = 0; v < 4; ++v) bp[mt][v] = a.projb[16 * mt + 4 * g + v];
 #pragma unroll
     for (int i = 0; i < CHY; ++i) { const int ch = 16 * (i >> 2) + 4 * g + (i & 3); gam[i] = a.ln1g[ch]; bet[i] = a.ln1b[ch]; }
-    // power-of-two scale of v for its f16 pieces, from a bound that holds for EVERY input: |LayerNorm(x)_k| <= sqrt(E), so
-    // |v_c| <= |b_c| + sum_k |Wv[c][k]| (sqrt(E) |gamma_k| + |beta_k|).  (A per-window maximum would be tighter -- f16's 30 binades make
-    // that irrelevant: the pair (hi, lo) is exact to 2^-24 from the bound down to 2^-17 of it -- and costs a wave reduction per window.)
-    int sh;
-    {
-        float bound = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < NTV; ++nt) {
-            const int oc = G::v_oc(nt, c);
-            float bnd = 0.f;
-            if (oc >= 0) {
-                bnd = fabsf(a.qkvb[oc]);
-                for (int k = 0; k < HC; ++k) bnd += fabsf(a.qkvw[(size_t)oc * HC + k]) * (sqrtf((float)E) * fabsf(a.ln1g[k]) + fabsf(a.ln1b[k]));
-            }
-            bound = fmaxf(bound, bnd);
-        }
-        bound = wave_max(bound);
-        sh = 15 - __builtin_amdgcn_frexp_expf(bound);   // bound = f 2^e, f in [0.5, 1): |v| 2^sh < 2^15
-    }
-    const int shl = (ONES && c >= 8) ? 0 : sh;      // the ones columns stay unscaled
     __syncthreads();
     AM_STAMP(0);
 
@@ -260,34 +240,12 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
     const int lx = lpix * E + 4 * g;                 // ... its first chunk in x / y (floats)
     const int tstep = 2 * a.w;                       // pixels per token tile
 
-    // window `quad * 4 + wave` -> (sample, first pixel); false past the last window.  All of it wave-uniform (scalar registers)
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto locate = [&](int quad, long& b, long& porg) -> bool {
-        const int win = quad * 4 + wave_u;
-        if (quad >= nquads || win >= nwin) return false;
+    for (int quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
+        const int win = quad * 4 + __builtin_amdgcn_readfirstlane(wave);   // provably wave-uniform: window origins stay in scalar registers
+        if (win >= nwin) continue;   // no barrier inside the loop
         const int wx = win % nwx, rr = win / nwx, wy = rr % nwy;
-        b = rr / nwy;
-        porg = (b * a.h + wy * 8) * a.w + wx * 8;
-        return true;
-    };
-    // software prefetch where the registers allow it (HC = 8: 16 of them): the x rows of the wave's NEXT window are requested behind the
-    // to_qkv phase of the current one, so a window does not start with a full HBM round trip in front of its LayerNorm
-    constexpr bool PRE = HC <= 8;
-    long b = 0, porg = 0;
-    bool have = locate(blockIdx.x, b, porg);
-    float4 xpre[PRE ? 4 : 1][PRE ? NCH : 1];
-    if (PRE && have) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int m = 0; m < NCH; ++m) xpre[t][m] = *reinterpret_cast<const float4*>(a.x + porg * E + (t * tstep * E + 16 * m + lx));
-    }
-    for (int quad = blockIdx.x; have; quad += gridDim.x) {   // (no barrier inside the loop: a wave past its last window just leaves)
-        // The loop body stores nothing to LDS, so the compiler may hoist every weight-fragment read out of the window loop -- register-
-        // resident weights, which is what HC = 8 wants (9 fragments = 36 registers) and what spills at HC >= 16 (21 / 84 fragments).
-        // An opaque copy of the base pointers per iteration keeps the reads where they are written.
-        const u32x4_t* wqk = sWqk; const u32x4_t* wv = sWv; const u32x4_t* wp = sWp;
-        if (HC >= 16 || NP == 1) asm volatile("" : "+v"(wqk), "+v"(wv), "+v"(wp));
+        const long b = rr / nwy;
+        const long porg = (b * a.h + wy * 8) * a.w + wx * 8;          // first pixel of the window (uniform)
         const long pix0 = porg + lpix;                                // this lane's token of tile 0; tile t: + 2 t w
         const float* __restrict__ xw = a.x + porg * E;                // uniform bases; lane offsets are 32-bit
         float* __restrict__ yw = a.y + porg * E;
@@ -298,7 +256,7 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int m = 0; m < NCH; ++m) xv[t][m] = PRE ? xpre[PRE ? t : 0][PRE ? m : 0] : *reinterpret_cast<const float4*>(xw + (t * tstep * E + 16 * m + lx));
+            for (int m = 0; m < NCH; ++m) xv[t][m] = *reinterpret_cast<const float4*>(xw + (t * tstep * E + 16 * m + lx));
 
         AM_STAMP(1);   // window addresses + x loads issued
         float qk[4][4 * MTQK];                   // the lane's q / k channels of token 16 t + c: idx = ((is_q 2 + head) DG + dd)
@@ -331,7 +289,7 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
             for (int mt = 0; mt < MTQK; ++mt) {
                 f32x4_t acc = {bqk[mt][0], bqk[mt][1], bqk[mt][2], bqk[mt][3]};
 #pragma unroll
-                for (int k = 0; k < NKQ; ++k) acc = mfma_bf(wqk[(mt * NKQ + k) * 64 + lane], yf[k], acc);
+                for (int k = 0; k < NKQ; ++k) acc = mfma_bf(sWqk[(mt * NKQ + k) * 64 + lane], yf[k], acc);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) qk[t][4 * mt + v] = acc[v];
             }
@@ -340,21 +298,13 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
             for (int nt = 0; nt < NTV; ++nt) {
                 f32x4_t acc = {bv[nt], bv[nt], bv[nt], bv[nt]};
 #pragma unroll
-                for (int k = 0; k < NKQ; ++k) acc = mfma_bf(yf[k], wv[(nt * NKQ + k) * 64 + lane], acc);
+                for (int k = 0; k < NKQ; ++k) acc = mfma_bf(yf[k], sWv[(nt * NKQ + k) * 64 + lane], acc);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) vv[t][nt][v] = acc[v];
             }
         }
 
         AM_STAMP(2);   // wait for x, LayerNorm, to_qkv
-        long bn = 0, porgn = 0;
-        const bool haven = locate(quad + (int)gridDim.x, bn, porgn);
-        if (PRE && haven) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int m = 0; m < NCH; ++m) xpre[t][m] = *reinterpret_cast<const float4*>(a.x + porgn * E + (t * tstep * E + 16 * m + lx));
-        }
         // ---- cat(o1, o2) of the lane: the FFT-mixer chunks (channels >= HC) are requested now, the o1 chunks are filled per head below
         float cat[4][NCH][4];
 #pragma unroll
@@ -370,7 +320,18 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
                     }
                 }
 
-        // ---- V^T fragments: f16 pieces of v 2^sh
+        // ---- V^T fragments: f16 pieces of v 2^sh, the power of two that puts the window's largest |v| into [2^14, 2^15)
+        float vmax = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NTV; ++nt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) vmax = fmaxf(vmax, fabsf(vv[t][nt][v]));
+        if (ONES && c >= 8) vmax = 0.f;
+        vmax = wave_max(vmax);
+        const int sh = 15 - __builtin_amdgcn_frexp_expf(vmax);   // vmax = f 2^e, f in [0.5, 1): |v| 2^sh < 2^15
+        const int shl = (ONES && c >= 8) ? 0 : sh;
         u32x4_t Vf[NTV][2][NPV];                                 // [column tile][k step][piece]; k-slot j of step s2: token tile 2 s2 + (j >> 2), row 4 g + (j & 3)
 #pragma unroll
         for (int nt = 0; nt < NTV; ++nt)
@@ -479,7 +440,7 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
             for (int mt = 0; mt < MTP; ++mt) {
                 f32x4_t acc = {bp[mt][0], bp[mt][1], bp[mt][2], bp[mt][3]};
 #pragma unroll
-                for (int k = 0; k < NKP; ++k) acc = mfma_bf(wp[(mt * NKP + k) * 64 + lane], cf[k], acc);
+                for (int k = 0; k < NKP; ++k) acc = mfma_bf(sWp[(mt * NKP + k) * 64 + lane], cf[k], acc);
                 float o[4];
                 const uint64_t di = (uint64_t)(pix * E + 16 * mt + 4 * g);   // a multiple of 4: | v below never carries
 #pragma unroll
@@ -492,7 +453,6 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
             }
         }
         AM_STAMP(5);   // proj, dropout, residual, stores issued
-        have = haven; b = bn; porg = porgn;
     }
 #ifdef LG_ATTN_STAMPS
     if (lane == 0 && blockIdx.x < 1024) {

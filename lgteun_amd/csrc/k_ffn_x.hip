@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     float sx = 1.f, sa1 = 1.f, sa3 = 1.f, sw1 = 1.f, sw2 = 1.f, sw3 = 1.f;
     if (NP == 2) { sx = a1.scales[0]; sa1 = a1.scales[1]; sa3 = a1.scales[2]; sw1 = a1.scales[3]; sw2 = a1.scales[4]; sw3 = a1.scales[5]; }
     const float S1 = sx * sw1, S2 = sa1 * sw2, S3 = sa3 * sw3;
-    const float g1c = 0.70710678118654752440f / S1, g1h = 0.5f * sa1 / S1, g3h = 0.5f * sa3, inv2 = 1.0f / S2, inv3 = 1.0f / S3;   // (powers of two: exact)
+    const float inv1 = 1.0f / S1, g1c = 0.70710678118654752440f / S1, g1h = 0.5f * sa1 / S1, g3h = 0.5f * sa3, inv2 = 1.0f / S2, inv3 = 1.0f / S3;   // (powers of two: exact)
     // ---- weights: split once, register-resident for every strip of this workgroup
     const int c0 = wave * 16 + 4 * g;                 // first of the four h1 / h2 channels this lane holds after GEMM1 / GEMM2
     float4 b1v = *reinterpret_cast<const float4*>(a1.b1 + c0);
@@ -209,17 +209,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int pb = 0; pb < 3; ++pb) {
                 float av[4];
+                const float us = NP == 2 ? inv1 : 1.0f;   // NP = 2: what is SAVED is the true h1 (the accumulator holds S1 h1)
                 if (SAVE == 1) {
                     lg_v2f a01, a23, g01, g23;
-                    gelu2_both_t<NP == 1>((lg_v2f){acc[pb][0], acc[pb][1]}, a01, g01);
-                    gelu2_both_t<NP == 1>((lg_v2f){acc[pb][2], acc[pb][3]}, a23, g23);
+                    gelu2_both_t<NP == 1>((lg_v2f){acc[pb][0] * us, acc[pb][1] * us}, a01, g01);
+                    gelu2_both_t<NP == 1>((lg_v2f){acc[pb][2] * us, acc[pb][3] * us}, a23, g23);
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                     if (inner[pb]) {
                         HS<BF>::st4(a1.a1s, prow[pb], make_float4(av[0], av[1], av[2], av[3]));
                         HS<BF>::st4(a1.g1s, prow[pb], make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
+                    if (NP == 2) { av[0] *= sa1; av[1] *= sa1; av[2] *= sa1; av[3] *= sa1; }
                 } else {
-                    if (SAVE == 2 && inner[pb]) HS<BF>::st4(a1.a1s, prow[pb], make_float4(acc[pb][0], acc[pb][1], acc[pb][2], acc[pb][3]));
+                    if (SAVE == 2 && inner[pb]) HS<BF>::st4(a1.a1s, prow[pb], make_float4(acc[pb][0] * us, acc[pb][1] * us, acc[pb][2] * us, acc[pb][3] * us));
                     const lg_v2f a01 = NP == 2 ? gelu2_scaled((lg_v2f){acc[pb][0], acc[pb][1]}, g1c, g1h) : gelu2_t<NP == 1>((lg_v2f){acc[pb][0], acc[pb][1]});
                     const lg_v2f a23 = NP == 2 ? gelu2_scaled((lg_v2f){acc[pb][2], acc[pb][3]}, g1c, g1h) : gelu2_t<NP == 1>((lg_v2f){acc[pb][2], acc[pb][3]});
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                         HS<BF>::st4(a2.a3s, o, make_float4(av[0], av[1], av[2], av[3]));
                         HS<BF>::st4(a2.g3s, o, make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
+                    if (NP == 2) { av[0] *= sa3; av[1] *= sa3; av[2] *= sa3; av[3] *= sa3; }
                 } else {
                     if (SAVE >= 2) {
                         const int y = y0 + ty, x = x0 + tx;
@@ -421,6 +424,8 @@ int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<2, NPF>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<3, NPF>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xs<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
@@ -445,9 +450,12 @@ int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
         if (noh1) k_ffn_xs<3, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
         else if (save) k_ffn_xs<1, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
         else k_ffn_xs<0, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
-    } else if (a1.scales && noh1) k_ffn_xs<3, 2><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);   // f16 pairs: the two default save modes
-    else if (a1.scales && !save) k_ffn_xs<0, 2><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
-    else if (noh1) k_ffn_xs<3, NPF><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    } else if (a1.scales) {   // f16 pairs (three piece products per block instead of six)
+        if (noh1) k_ffn_xs<3, 2><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+        else if (pre) k_ffn_xs<2, 2><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+        else if (save) k_ffn_xs<1, 2><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+        else k_ffn_xs<0, 2><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    } else if (noh1) k_ffn_xs<3, NPF><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
     else if (pre) k_ffn_xs<2, NPF><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
     else if (save) k_ffn_xs<1, NPF><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
     else k_ffn_xs<0, NPF><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);

@@ -44,7 +44,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 }
 // W [rows][K] fp32 -> fragments (mb, kb) of 16 x 32, three bf16 pieces each, in the order a wave loads them
 __global__ __launch_bounds__(256) void k_split_w(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
-                                                 u32x4_t* __restrict__ out, int e, int np) {
+                                                 u32x4_t* __restrict__ out, int e, int np, const float* __restrict__ scales) {
     const int n1 = 4 * e, kb1 = e / 32, kb2 = n1 / 32;
     const int nf1 = (n1 / 16) * kb1, nf2 = (n1 / 16) * kb2, nf3 = (e / 16) * kb2;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -58,11 +58,18 @@ __global__ __launch_bounds__(256) void k_split_w(const float* __restrict__ w1, c
     const int kbn = K / 32, mb = fl / kbn, kb = fl - mb * kbn;
     const float* src = W + (size_t)(mb * 16 + r) * K + kb * 32 + 8 * g;
     const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
-    const float a[4] = {lo.x, lo.y, lo.z, lo.w}, b[4] = {hi.x, hi.y, hi.z, hi.w};
+    float a[4] = {lo.x, lo.y, lo.z, lo.w}, b[4] = {hi.x, hi.y, hi.z, hi.w};
     u32x2_t a1, a2, a3, b1, b2, b3;
     if (np == 3) {
         split3_x4(a, a1, a2, a3);
         split3_x4(b, b1, b2, b3);
+    } else if (np == 2) {   // f16 pairs of W * (the matrix's power-of-two scale, k_ffn_prep.hip)
+        const float sw = scales[f < nf1 ? 3 : (f < nf1 + nf2 ? 4 : 5)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] *= sw; b[i] *= sw; }
+        split2_x4(a, a1, a2);
+        split2_x4(b, b1, b2);
+        a3 = a1; b3 = b1;
     } else {   // plain-bf16 mode: piece 0 rounded to nearest, the others unused
         split_x4<1>(a, a1, a2, a3);
         split_x4<1>(b, b1, b2, b3);
@@ -91,13 +98,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         sN1g[i] = a2.g ? a2.n1g[i] : 0.f; sN1b[i] = a2.g ? a2.n1b[i] : 0.f;
     }
     constexpr bool BF = (NP == 1);                    // plain-bf16 mode: saved activations stored as bf16 (hstore.h)
+    // NP = 2 (f16 pairs): the operand scales of k_ffn_prep.hip and how they leave again -- k_ffn_x.hip has the scheme
+    float sx = 1.f, sa1 = 1.f, sa3 = 1.f, sw1 = 1.f, sw2 = 1.f, sw3 = 1.f;
+    if (NP == 2) { sx = a1.scales[0]; sa1 = a1.scales[1]; sa3 = a1.scales[2]; sw1 = a1.scales[3]; sw2 = a1.scales[4]; sw3 = a1.scales[5]; }
+    const float S1 = sx * sw1, S2 = sa1 * sw2, S3 = sa3 * sw3;
+    const float inv1 = 1.0f / S1, g1c = 0.70710678118654752440f / S1, g1h = 0.5f * sa1 / S1, g3h = 0.5f * sa3, inv2 = 1.0f / S2, inv3 = 1.0f / S3;   // (powers of two: exact)
     const int c0 = wave * 16 + 4 * g;                 // first of the four h1 / h2 channels this lane holds after GEMM1 / GEMM2
-    const float4 b1v = *reinterpret_cast<const float4*>(a1.b1 + c0);
-    const float4 b2v = *reinterpret_cast<const float4*>(a1.b2 + c0);
-    const WFrag32 w1f = ld_wfrag(wsp, wave);                                   // W1 rows 16 w .., K = 32
+    float4 b1v = *reinterpret_cast<const float4*>(a1.b1 + c0);
+    float4 b2v = *reinterpret_cast<const float4*>(a1.b2 + c0);
+    if (NP == 2) { b1v = make_float4(b1v.x * S1, b1v.y * S1, b1v.z * S1, b1v.w * S1); b2v = make_float4(b2v.x * S2, b2v.y * S2, b2v.z * S2, b2v.w * S2); }
+    const WFrag32 w1f = ld_wfrag<NP>(wsp, wave);                                   // W1 rows 16 w .., K = 32
     WFrag32 w2f[4];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) w2f[kb] = ld_wfrag(wsp, NF_W1 + wave * 4 + kb);
+    for (int kb = 0; kb < 4; ++kb) w2f[kb] = ld_wfrag<NP>(wsp, NF_W1 + wave * 4 + kb);
     const u32x4_t* w3p = wsp + (size_t)(NF_W1 + NF_W2) * 3 * 64;             // W3 fragments (mb, kb): f = mb * 4 + kb
     // LayerNorm phase: thread t < 8 CH = (chunk pixel t / 8, channel quad t % 8)
     const int lpx = threadIdx.x >> 3, lq = threadIdx.x & 7;
@@ -105,7 +118,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // depthwise phase: lane = (pixel slot lane / 16, channel quad q16 of the current K-half)
     const int q16 = lane & 15;
     __syncthreads();
-    const float4 lng = *reinterpret_cast<const float4*>(sLn2g + 4 * lq), lnb = *reinterpret_cast<const float4*>(sLn2b + 4 * lq);
+    float4 lng = *reinterpret_cast<const float4*>(sLn2g + 4 * lq), lnb = *reinterpret_cast<const float4*>(sLn2b + 4 * lq);
+    if (NP == 2) { lng = make_float4(lng.x * sx, lng.y * sx, lng.z * sx, lng.w * sx); lnb = make_float4(lnb.x * sx, lnb.y * sx, lnb.z * sx, lnb.w * sx); }
 
 #pragma unroll 1
     for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
@@ -141,9 +155,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         split_x4<NP>(yv, q1, q2, q3);
         uint16_t* dst = XA + slot * XA_SLOT + lpx * E + 4 * lq;
         *reinterpret_cast<u32x2_t*>(dst) = q1;
-        *reinterpret_cast<u32x2_t*>(dst + CH * E) = q2;
-        *reinterpret_cast<u32x2_t*>(dst + 2 * CH * E) = q3;
-        if (lq == 0) sMask[mslot][lpx] = m_;
+        if (NP >= 2) *reinterpret_cast<u32x2_t*>(dst + CH * E) = q2;
+        if (NP == 3) *reinterpret_cast<u32x2_t*>(dst + 2 * CH * E) = q3;
+        if (lq == 0) sMask[mslot][lpx] = NP == 2 ? m_ * inv2 : m_;   // NP = 2: the mask also takes S2 out of GEMM2's accumulator
     };
     // ---- the two stages of a chunk.  stage1: GEMM1 (K = 32: h1[16 w .. +15][CH pixels] = W1 LN(x)) + GELU + split -> gelu(h1) image `img`;
     //      stage2: GEMM2 (K = 128: h2 = W2 gelu(h1)) from image `img` -> masked -> ring (+ saves)
@@ -168,15 +182,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const bool inner = m < npx && hx >= 1 && hx <= TX && x < w && y >= Y0 && y < Yend;
                 const long prow = ((b * h + y) * (long)w + x) * N1 + c0;
                 lg_v2f a01, a23, g01, g23;
-                gelu2_both_t<NP == 1>((lg_v2f){acc[pb][0], acc[pb][1]}, a01, g01);
-                gelu2_both_t<NP == 1>((lg_v2f){acc[pb][2], acc[pb][3]}, a23, g23);
+                const float us = NP == 2 ? inv1 : 1.0f;   // NP = 2, saving launch: gelu / gelu' of the TRUE h1 (what the backward reads), scaled afterwards
+                gelu2_both_t<NP == 1>((lg_v2f){acc[pb][0] * us, acc[pb][1] * us}, a01, g01);
+                gelu2_both_t<NP == 1>((lg_v2f){acc[pb][2] * us, acc[pb][3] * us}, a23, g23);
                 av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 if (inner) {
                     HS<BF>::st4(a1.a1s, prow, make_float4(av[0], av[1], av[2], av[3]));
                     HS<BF>::st4(a1.g1s, prow, make_float4(g01.x, g01.y, g23.x, g23.y));
                 }
+                if (NP == 2) { av[0] *= sa1; av[1] *= sa1; av[2] *= sa1; av[3] *= sa1; }
             } else {
-                const lg_v2f a01 = gelu2_t<NP == 1>((lg_v2f){acc[pb][0], acc[pb][1]}), a23 = gelu2_t<NP == 1>((lg_v2f){acc[pb][2], acc[pb][3]});
+                const lg_v2f a01 = NP == 2 ? gelu2_scaled((lg_v2f){acc[pb][0], acc[pb][1]}, g1c, g1h) : gelu2_t<NP == 1>((lg_v2f){acc[pb][0], acc[pb][1]});
+                const lg_v2f a23 = NP == 2 ? gelu2_scaled((lg_v2f){acc[pb][2], acc[pb][3]}, g1c, g1h) : gelu2_t<NP == 1>((lg_v2f){acc[pb][2], acc[pb][3]});
                 av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
             }
             u32x2_t q1, q2, q3;
@@ -184,8 +201,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int px = pb * 16 + r;
             uint16_t* dst = A2i + px * N1 + (((2 * wave + (g >> 1)) ^ (px & 15)) << 3) + 4 * (g & 1);
             *reinterpret_cast<u32x2_t*>(dst) = q1;
-            *reinterpret_cast<u32x2_t*>(dst + CH * N1) = q2;
-            *reinterpret_cast<u32x2_t*>(dst + 2 * CH * N1) = q3;
+            if (NP >= 2) *reinterpret_cast<u32x2_t*>(dst + CH * N1) = q2;
+            if (NP == 3) *reinterpret_cast<u32x2_t*>(dst + 2 * CH * N1) = q3;
         }
     };
     auto stage2 = [&](int ya, int npx, int c, int mslot, int img, int ring0) {
@@ -329,7 +346,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const float4 b3v = *reinterpret_cast<const float4*>(sB3 + 16 * mb + 4 * g);
-            o[mb] = (f32x4_t){b3v.x, b3v.y, b3v.z, b3v.w};
+            o[mb] = NP == 2 ? (f32x4_t){b3v.x * S3, b3v.y * S3, b3v.z * S3, b3v.w * S3} : (f32x4_t){b3v.x, b3v.y, b3v.z, b3v.w};
         }
 #pragma unroll 1
         for (int kh = 0; kh < 2; ++kh) {
@@ -382,8 +399,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             HS<BF>::st4(a2.a3s, off, acc);
                         }
                     }
+                    if (NP == 2) { av[0] *= sa3; av[1] *= sa3; av[2] *= sa3; av[3] *= sa3; }
                 } else {
-                    const lg_v2f a01 = gelu2_t<NP == 1>((lg_v2f){acc.x, acc.y}), a23 = gelu2_t<NP == 1>((lg_v2f){acc.z, acc.w});
+                    const lg_v2f a01 = NP == 2 ? gelu2_scaled((lg_v2f){acc.x, acc.y}, 0.70710678118654752440f, g3h) : gelu2_t<NP == 1>((lg_v2f){acc.x, acc.y});
+                    const lg_v2f a23 = NP == 2 ? gelu2_scaled((lg_v2f){acc.z, acc.w}, 0.70710678118654752440f, g3h) : gelu2_t<NP == 1>((lg_v2f){acc.z, acc.w});
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 }
                 u32x2_t q1, q2, q3;
@@ -391,8 +410,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 // row of 64 halves = 8 chunks of 16 bytes: logical chunk q16 / 2, stored at chunk ^ (pixel & 7)
                 uint16_t* dst = G3 + tx * 64 + ((((q16 >> 1)) ^ (tx & 7)) << 3) + 4 * (q16 & 1);
                 *reinterpret_cast<u32x2_t*>(dst) = q1;
-                *reinterpret_cast<u32x2_t*>(dst + 16 * 64) = q2;
-                *reinterpret_cast<u32x2_t*>(dst + 2 * 16 * 64) = q3;
+                if (NP >= 2) *reinterpret_cast<u32x2_t*>(dst + 16 * 64) = q2;
+                if (NP == 3) *reinterpret_cast<u32x2_t*>(dst + 2 * 16 * 64) = q3;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -403,7 +422,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const bf16x8_t x1 = lds_x8(p), x2 = lds_x8(p + 16 * 64), x3 = lds_x8(p + 2 * 16 * 64);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
-                    const WFrag32 wf = ld_wfrag(w3p, mb * 4 + 2 * kh + kb);
+                    const WFrag32 wf = ld_wfrag<NP>(w3p, mb * 4 + 2 * kh + kb);
                     mfma_np32<NP>(o[mb], wf, x1, x2, x3);
                 }
             }
@@ -415,8 +434,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float ov[8];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
-            ov[4 * mb + 0] = o[mb][0] + xres[mb].x; ov[4 * mb + 1] = o[mb][1] + xres[mb].y;
-            ov[4 * mb + 2] = o[mb][2] + xres[mb].z; ov[4 * mb + 3] = o[mb][3] + xres[mb].w;
+            const float os = NP == 2 ? inv3 : 1.0f;
+            ov[4 * mb + 0] = o[mb][0] * os + xres[mb].x; ov[4 * mb + 1] = o[mb][1] * os + xres[mb].y;
+            ov[4 * mb + 2] = o[mb][2] * os + xres[mb].z; ov[4 * mb + 3] = o[mb][3] * os + xres[mb].w;
             if (ok) *reinterpret_cast<float4*>(a2.y + ((b * h + y) * (long)w + x) * E + 16 * mb + 4 * g) =
                         make_float4(ov[4 * mb], ov[4 * mb + 1], ov[4 * mb + 2], ov[4 * mb + 3]);
         }
@@ -455,10 +475,11 @@ size_t ffn_wsplit_bytes(int e) {
 }
 
 // fragments in the order W1 (mb, kb), W2 (mb, kb), W3 (mb, kb); e a multiple of 32
-int launch_split_w(const float* w1, const float* w2, const float* w3, void* out, int e, int np, hipStream_t s) {
+int launch_split_w(const float* w1, const float* w2, const float* w3, void* out, int e, int np, hipStream_t s, const float* scales) {
+    if (np == 2 && !scales) { lg_set_error("split_w: f16 pairs need the operand scales"); return -2; }
     const int n1 = 4 * e, kb1 = e / 32, kb2 = n1 / 32;
     const int nfrag = (n1 / 16) * kb1 + (n1 / 16) * kb2 + (e / 16) * kb2;
-    k_split_w<<<(nfrag * 64 + 255) / 256, 256, 0, s>>>(w1, w2, w3, reinterpret_cast<u32x4_t*>(out), e, np);
+    k_split_w<<<(nfrag * 64 + 255) / 256, 256, 0, s>>>(w1, w2, w3, reinterpret_cast<u32x4_t*>(out), e, np, scales);
     LG_CHECK_LAUNCH();
     return 0;
 }
@@ -470,13 +491,15 @@ int launch_ffn_x32(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ffn_x32<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) { lg_set_error("ffn_x32: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
     {
-        const int rc = launch_split_w(a1.w1, a1.w2, a2.w3, a1.wsplit, E, a1.hbf ? 1 : 3, s);
+        const int rc = launch_split_w(a1.w1, a1.w2, a2.w3, a1.wsplit, E, a1.hbf ? 1 : (a1.scales ? 2 : 3), s, a1.scales);
         if (rc) return rc;
     }
     const int tiles_x = (a2.w + 15) / 16;
@@ -491,6 +514,9 @@ int launch_ffn_x32(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     if (a1.hbf) {   // precision = 'bf16'
         if (save) k_ffn_x32<true, 1><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
         else k_ffn_x32<false, 1><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
+    } else if (a1.scales) {   // f16 pairs (three products per block instead of six)
+        if (save) k_ffn_x32<true, 2><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
+        else k_ffn_x32<false, 2><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
     } else if (save) k_ffn_x32<true, 3><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
     else k_ffn_x32<false, 3><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
     LG_CHECK_LAUNCH();

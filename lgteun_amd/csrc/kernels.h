@@ -154,7 +154,8 @@ int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s);   // e
 int launch_ffn_xp(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s);   // e = 16, software-pipelined halo pass (k_ffn_xp.hip)
 int launch_ffn_x32(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s);  // e = 32, fp32 storage (k_ffn_x32.hip)
 size_t ffn_wsplit_bytes(int e);   // bytes of a1.wsplit for hidden width 4e
-int launch_split_w(const float* w1, const float* w2, const float* w3, void* out, int e, int np, hipStream_t s);   // pre-split weight fragments (np = 3), or RNE bf16 (np = 1)
+// pre-split weight fragments: np = 3 three bf16 pieces, np = 1 one RNE bf16 piece, np = 2 f16 pairs of W * scales[3 + which matrix] (k_ffn_prep.hip)
+int launch_split_w(const float* w1, const float* w2, const float* w3, void* out, int e, int np, hipStream_t s, const float* scales = nullptr);
 int launch_ffn_x64(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s);  // e = 64: two kernels (h2 through HBM), split-bf16 GEMMs (k_ffn_x64.hip)
 
 // test helper: g[B,e/2,HW] = LayerNorm(x)[..., e/2:] (the epilogue the producing kernels fuse)

@@ -255,11 +255,12 @@ __device__ __forceinline__ WFrag16 load_wfrag16_rne(const float* __restrict__ W,
 
 // fragment `f` of a PRE-SPLIT weight (k_split_w layout, k_ffn_x32.hip: [fragment][piece][lane] 16-byte units): one coalesced 1 KB
 // read per piece
+template <int NP = 3>
 __device__ __forceinline__ WFrag32 ld_wfrag(const u32x4_t* __restrict__ base, int f) {
     const int lane = threadIdx.x & 63;
     WFrag32 w;
     w.p[0] = __builtin_bit_cast(bf16x8_t, base[(f * 3 + 0) * 64 + lane]);
-    w.p[1] = __builtin_bit_cast(bf16x8_t, base[(f * 3 + 1) * 64 + lane]);
-    w.p[2] = __builtin_bit_cast(bf16x8_t, base[(f * 3 + 2) * 64 + lane]);
+    w.p[1] = NP >= 2 ? __builtin_bit_cast(bf16x8_t, base[(f * 3 + 1) * 64 + lane]) : w.p[0];
+    w.p[2] = NP == 3 ? __builtin_bit_cast(bf16x8_t, base[(f * 3 + 2) * 64 + lane]) : w.p[0];   // (unused pieces are not read)
     return w;
 }

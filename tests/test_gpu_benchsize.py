@@ -101,9 +101,13 @@ def test_cancelling_sum_gradient_kinds_band_against_band(manifest, name):
            (measured 0.1 ... 0.65 x on the power-of-two sizes): the band is centred where the reference's is.  3 x on the two non-power-of-two
            cases, whose FFT mixer runs Bluestein lines: their offset (up to 2.8 x at 208 x 176) is deterministic fp32 arithmetic of another
            algorithm (pocketfft's mixed radix on the reference's side), which nudged inputs do not average out.
-    A one-draw comparison cannot tell "inside the band" from "a 3 x wider band"; this can.  How it was checked to have teeth: with
-    k_attn_bwd_f's pos_emb accumulation degraded on purpose (every dS rounded to bf16 before it is added, `-DLG_DEGRADE_DPOS` variant
-    build) (ii) goes red for pos_emb in every 4-band case (profiles/r05_grad_spread.txt, last block)."""
+    A one-draw comparison cannot tell "inside the band" from "a 3 x wider band"; this can.  What it can and cannot see, checked with
+    k_attn_bwd_f's pos_emb accumulation degraded on purpose (`-DLG_DEGRADE_DPOS` variant builds, LGTEUN_HIP_LIB): a 5 % error in what
+    enters the pos_emb gradient turns (ii) red at 208 x 176 (4.65 against its limit 3; 2.76 without) and moves grad_c4_k4_p128 from 0.50
+    to 1.9 of its limit 2; rounding every dS to bf16 before it is added changes nothing measurable (0.93 -> 0.94): random 2^-9 errors
+    of 16 k terms average out far below the band the reference's own fp32 arithmetic has.  Errors below ~5 % of these kinds are inside
+    the reference's band by construction -- the kernel-level fp64 tests (test_mixer_backward_kernel_at_awkward_shapes, 1e-4) are the
+    gate for those."""
     import json
     import os
     import sys
