@@ -35,26 +35,36 @@ __device__ __forceinline__ float oct_sum(float v) {
 // ------------------------------------------------------------------------------------------------
 // k_ffn1_x64
 // ------------------------------------------------------------------------------------------------
-template <bool SAVE>
+// NP = 3: three bf16 pieces per operand (six products); NP = 2: f16 pairs (three products) with the operand scales of k_ffn_prep.hip -- the
+// scheme is k_ffn_x.hip's: operands scaled by proven powers of two, the product of the scales taken out behind the accumulator by constants
+// that were multiplications already; what goes to HBM (h2, the saved activations) is always the true value.
+template <bool SAVE, int NP>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ffn1_x64(Ffn1Args a, const u32x4_t* __restrict__ wsp, long ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint16_t* XA = reinterpret_cast<uint16_t*>(smem_raw);      // [3][TP][E], chunk ^ (px & 7)
     uint16_t* A2 = XA + XA_HALVES;                             // [3][TP][N1], chunk ^ (px & 15) within its group of 16
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     __shared__ __attribute__((aligned(16))) float sLn[2 * E];
-    for (int i = threadIdx.x; i < E; i += 512) { sLn[i] = a.ln2g[i]; sLn[E + i] = a.ln2b[i]; }
+    float sx = 1.f, sa1 = 1.f, sw1 = 1.f, sw2 = 1.f;
+    if (NP == 2) { sx = a.scales[0]; sa1 = a.scales[1]; sw1 = a.scales[3]; sw2 = a.scales[4]; }
+    const float S1 = sx * sw1, S2 = sa1 * sw2, inv1 = 1.0f / S1, inv2 = 1.0f / S2, g1c = 0.70710678118654752440f / S1, g1h = 0.5f * sa1 / S1;   // (powers of two: exact)
+    for (int i = threadIdx.x; i < E; i += 512) { sLn[i] = a.ln2g[i] * sx; sLn[E + i] = a.ln2b[i] * sx; }
     // W1 fragments of this wave's two row blocks (mb = 2 w, 2 w + 1), both K blocks
     WFrag32 w1f[2][2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) w1f[m][kb] = ld_wfrag(wsp, (2 * wave + m) * 2 + kb);
+        for (int kb = 0; kb < 2; ++kb) w1f[m][kb] = ld_wfrag<NP>(wsp, (2 * wave + m) * 2 + kb);
     const u32x4_t* w2p = wsp + (size_t)NF_W1 * 3 * 64;        // W2 fragment (mb, kb): f = mb * 8 + kb
     float4 b1v[2], b2v[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         b1v[m] = *reinterpret_cast<const float4*>(a.b1 + 16 * (2 * wave + m) + 4 * g);
         b2v[m] = *reinterpret_cast<const float4*>(a.b2 + 16 * (2 * wave + m) + 4 * g);
+        if (NP == 2) {
+            b1v[m] = make_float4(b1v[m].x * S1, b1v[m].y * S1, b1v[m].z * S1, b1v[m].w * S1);
+            b2v[m] = make_float4(b2v[m].x * S2, b2v[m].y * S2, b2v[m].z * S2, b2v[m].w * S2);
+        }
     }
     // LayerNorm phase: thread t = (tile pixel t / 8, channel octet t % 8)
     const int lpx = threadIdx.x >> 3, l8 = threadIdx.x & 7;
@@ -89,12 +99,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int k = 0; k < 4; ++k) { y0[k] = d[k] * rstd * lng[k] + lnb[k]; y1[k] = d[4 + k] * rstd * lng[4 + k] + lnb[4 + k]; }
             u32x2_t a1, a2, a3, c1, c2, c3;
-            split3_x4(y0, a1, a2, a3);
-            split3_x4(y1, c1, c2, c3);
+            split_x4<NP>(y0, a1, a2, a3);
+            split_x4<NP>(y1, c1, c2, c3);
             uint16_t* dst = XA + lpx * E + ((l8 ^ (lpx & 7)) << 3);
             *reinterpret_cast<u32x4_t*>(dst) = (u32x4_t){a1.x, a1.y, c1.x, c1.y};
             *reinterpret_cast<u32x4_t*>(dst + TP * E) = (u32x4_t){a2.x, a2.y, c2.x, c2.y};
-            *reinterpret_cast<u32x4_t*>(dst + 2 * TP * E) = (u32x4_t){a3.x, a3.y, c3.x, c3.y};
+            if (NP == 3) *reinterpret_cast<u32x4_t*>(dst + 2 * TP * E) = (u32x4_t){a3.x, a3.y, c3.x, c3.y};
         }
         if (tile + gridDim.x < ntiles) fetch_x(tile + gridDim.x);      // next tile's rows: in flight under the GEMMs
         __syncthreads();
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const uint16_t* p = XA + px * E + (((4 * kb + g) ^ (px & 7)) << 3);
                 const bf16x8_t x1 = lds_x8(p), x2 = lds_x8(p + TP * E), x3 = lds_x8(p + 2 * TP * E);
 #pragma unroll
-                for (int m = 0; m < 2; ++m) mfma_split32(acc[m][pb], w1f[m][kb], x1, x2, x3);
+                for (int m = 0; m < 2; ++m) mfma_np32<NP>(acc[m][pb], w1f[m][kb], x1, x2, x3);
             }
         // ---- GELU, split -> A2
 #pragma unroll
@@ -123,25 +133,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 float av[4];
                 if (SAVE) {
                     lg_v2f a01, a23, g01, g23;
-                    gelu2_both_f((lg_v2f){acc[m][pb][0], acc[m][pb][1]}, a01, g01);
-                    gelu2_both_f((lg_v2f){acc[m][pb][2], acc[m][pb][3]}, a23, g23);
+                    const float us = NP == 2 ? inv1 : 1.0f;
+                    gelu2_both_f((lg_v2f){acc[m][pb][0] * us, acc[m][pb][1] * us}, a01, g01);
+                    gelu2_both_f((lg_v2f){acc[m][pb][2] * us, acc[m][pb][3] * us}, a23, g23);
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                     if (p0 + px < a.P) {
                         const long o = (p0 + px) * N1 + 16 * (2 * wave + m) + 4 * g;
                         HS<false>::st4(a.a1s, o, make_float4(av[0], av[1], av[2], av[3]));
                         HS<false>::st4(a.g1s, o, make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
+                    if (NP == 2) { av[0] *= sa1; av[1] *= sa1; av[2] *= sa1; av[3] *= sa1; }
                 } else {
-                    const lg_v2f a01 = gelu2_f((lg_v2f){acc[m][pb][0], acc[m][pb][1]}), a23 = gelu2_f((lg_v2f){acc[m][pb][2], acc[m][pb][3]});
+                    const lg_v2f a01 = NP == 2 ? gelu2_scaled((lg_v2f){acc[m][pb][0], acc[m][pb][1]}, g1c, g1h) : gelu2_f((lg_v2f){acc[m][pb][0], acc[m][pb][1]});
+                    const lg_v2f a23 = NP == 2 ? gelu2_scaled((lg_v2f){acc[m][pb][2], acc[m][pb][3]}, g1c, g1h) : gelu2_f((lg_v2f){acc[m][pb][2], acc[m][pb][3]});
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 }
                 u32x2_t q1, q2, q3;
-                split3_x4(av, q1, q2, q3);
+                split_x4<NP>(av, q1, q2, q3);
                 const int chunk = 2 * (2 * wave + m) + (g >> 1);           // logical 16-byte chunk of channels 16 mb + 4 g ..
                 uint16_t* dst = A2 + px * N1 + ((chunk ^ (px & 15)) << 3) + 4 * (g & 1);
                 *reinterpret_cast<u32x2_t*>(dst) = q1;
                 *reinterpret_cast<u32x2_t*>(dst + TP * N1) = q2;
-                *reinterpret_cast<u32x2_t*>(dst + 2 * TP * N1) = q3;
+                if (NP == 3) *reinterpret_cast<u32x2_t*>(dst + 2 * TP * N1) = q3;
             }
         __syncthreads();
         // ---- GEMM2 (K = 256): h2[32 w .. +31][64 pixels]; W2 fragments streamed per K block, next block in flight under the MFMAs
@@ -151,13 +164,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int pb = 0; pb < 4; ++pb) acc[m][pb] = (f32x4_t){b2v[m].x, b2v[m].y, b2v[m].z, b2v[m].w};
         WFrag32 wc[2], wn[2];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) wc[m] = ld_wfrag(w2p, (2 * wave + m) * 8);
+        for (int m = 0; m < 2; ++m) wc[m] = ld_wfrag<NP>(w2p, (2 * wave + m) * 8);
 #pragma unroll 1
         for (int kb = 0; kb < 8; ++kb) {
             {
                 const int kn = kb < 7 ? kb + 1 : 7;      // (the last iteration re-reads its own block: cached, unused)
 #pragma unroll
-                for (int m = 0; m < 2; ++m) wn[m] = ld_wfrag(w2p, (2 * wave + m) * 8 + kn);
+                for (int m = 0; m < 2; ++m) wn[m] = ld_wfrag<NP>(w2p, (2 * wave + m) * 8 + kn);
             }
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb) {
@@ -165,7 +178,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const uint16_t* p = A2 + px * N1 + (((4 * kb + g) ^ (px & 15)) << 3);
                 const bf16x8_t x1 = lds_x8(p), x2 = lds_x8(p + TP * N1), x3 = lds_x8(p + 2 * TP * N1);
 #pragma unroll
-                for (int m = 0; m < 2; ++m) mfma_split32(acc[m][pb], wc[m], x1, x2, x3);
+                for (int m = 0; m < 2; ++m) mfma_np32<NP>(acc[m][pb], wc[m], x1, x2, x3);
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m) wc[m] = wn[m];
@@ -175,7 +188,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb) {
                 const long p = p0 + pb * 16 + r;
-                if (p < a.P) HS<false>::st4(a.h2, p * N1 + 16 * (2 * wave + m) + 4 * g, make_float4(acc[m][pb][0], acc[m][pb][1], acc[m][pb][2], acc[m][pb][3]));
+                const float us = NP == 2 ? inv2 : 1.0f;      // h2 itself goes to HBM
+                if (p < a.P) HS<false>::st4(a.h2, p * N1 + 16 * (2 * wave + m) + 4 * g, make_float4(acc[m][pb][0] * us, acc[m][pb][1] * us, acc[m][pb][2] * us, acc[m][pb][3] * us));
             }
         __syncthreads();      // A2 / XA are rewritten by the next tile
     }
@@ -189,8 +203,8 @@ constexpr int G3_WAVE = 3 * 16 * CC;                                    // 3072 
 constexpr size_t LDS2_BYTES = (size_t)HY * HX * LDH * 4 + (size_t)8 * G3_WAVE * 2;
 constexpr int NLD = (HY * HX * (CC / 4) + 511) / 512;                  // float4 items per thread of one halo chunk (6)
 
-template <bool SAVE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ffn2_x64(Ffn2Args a, const u32x4_t* __restrict__ w3p, int tiles_x, int tiles_y, int ntiles) {
+template <bool SAVE, int NP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ffn2_x64(Ffn2Args a, const u32x4_t* __restrict__ w3p, const float* __restrict__ scales, int tiles_x, int tiles_y, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* H = reinterpret_cast<float*>(smem_raw);                                         // [HY*HX][LDH] h2 halo tile, one chunk
     uint16_t* G3all = reinterpret_cast<uint16_t*>(smem_raw + (size_t)HY * HX * LDH * 4);
@@ -200,6 +214,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ __attribute__((aligned(16))) float sPar[3 * E];
     for (int i = threadIdx.x; i < E; i += 512) { sPar[i] = a.b3[i]; sPar[E + i] = a.g ? a.n1g[i] : 0.f; sPar[2 * E + i] = a.g ? a.n1b[i] : 0.f; }
     const int q16 = lane & 15;
+    float sa3 = 1.f, sw3 = 1.f;
+    if (NP == 2) { sa3 = scales[2]; sw3 = scales[5]; }
+    const float S3 = sa3 * sw3, inv3 = 1.0f / S3, g3h = 0.5f * sa3;
     __syncthreads();
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -224,7 +241,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             const float4 b3v = *reinterpret_cast<const float4*>(sPar + 16 * mb + 4 * g);
-            o[mb] = (f32x4_t){b3v.x, b3v.y, b3v.z, b3v.w};
+            o[mb] = (f32x4_t){b3v.x * S3, b3v.y * S3, b3v.z * S3, b3v.w * S3};
         }
         // halo chunk loader: item i = (halo pixel i / 16, channel quad i % 16) of chunk kc
         float4 hr[NLD];
@@ -294,16 +311,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         HS<false>::st4(a.a3s, off, make_float4(av[0], av[1], av[2], av[3]));
                         HS<false>::st4(a.g3s, off, make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
+                    if (NP == 2) { av[0] *= sa3; av[1] *= sa3; av[2] *= sa3; av[3] *= sa3; }
                 } else {
-                    const lg_v2f a01 = gelu2_f((lg_v2f){acc.x, acc.y}), a23 = gelu2_f((lg_v2f){acc.z, acc.w});
+                    const lg_v2f a01 = NP == 2 ? gelu2_scaled((lg_v2f){acc.x, acc.y}, 0.70710678118654752440f, g3h) : gelu2_f((lg_v2f){acc.x, acc.y});
+                    const lg_v2f a23 = NP == 2 ? gelu2_scaled((lg_v2f){acc.z, acc.w}, 0.70710678118654752440f, g3h) : gelu2_f((lg_v2f){acc.z, acc.w});
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 }
                 u32x2_t q1, q2, q3;
-                split3_x4(av, q1, q2, q3);
+                split_x4<NP>(av, q1, q2, q3);
                 uint16_t* dst = G3 + tx * CC + (((q16 >> 1) ^ (tx & 7)) << 3) + 4 * (q16 & 1);
                 *reinterpret_cast<u32x2_t*>(dst) = q1;
                 *reinterpret_cast<u32x2_t*>(dst + 16 * CC) = q2;
-                *reinterpret_cast<u32x2_t*>(dst + 2 * 16 * CC) = q3;
+                if (NP == 3) *reinterpret_cast<u32x2_t*>(dst + 2 * 16 * CC) = q3;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -314,8 +333,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const bf16x8_t x1 = lds_x8(p), x2 = lds_x8(p + 16 * CC), x3 = lds_x8(p + 2 * 16 * CC);
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {
-                    const WFrag32 wf = ld_wfrag(w3p, mb * 8 + 2 * kc + kb);
-                    mfma_split32(o[mb], wf, x1, x2, x3);
+                    const WFrag32 wf = ld_wfrag<NP>(w3p, mb * 8 + 2 * kc + kb);
+                    mfma_np32<NP>(o[mb], wf, x1, x2, x3);
                 }
             }
             __builtin_amdgcn_wave_barrier();             // G3 is rewritten by the next chunk
@@ -326,8 +345,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float ov[16];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-            ov[4 * mb + 0] = o[mb][0] + xres[mb].x; ov[4 * mb + 1] = o[mb][1] + xres[mb].y;
-            ov[4 * mb + 2] = o[mb][2] + xres[mb].z; ov[4 * mb + 3] = o[mb][3] + xres[mb].w;
+            ov[4 * mb + 0] = o[mb][0] * inv3 + xres[mb].x; ov[4 * mb + 1] = o[mb][1] * inv3 + xres[mb].y;
+            ov[4 * mb + 2] = o[mb][2] * inv3 + xres[mb].z; ov[4 * mb + 3] = o[mb][3] * inv3 + xres[mb].w;
             if (ok) *reinterpret_cast<float4*>(a.y + ((b * h + y) * (long)w + x) * E + 16 * mb + 4 * g) =
                         make_float4(ov[4 * mb], ov[4 * mb + 1], ov[4 * mb + 2], ov[4 * mb + 3]);
         }
@@ -362,19 +381,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 }   // namespace
 
-int launch_ffn_x64(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
-    if (!a1.wsplit || !a1.h2) { lg_set_error("ffn_x64: missing workspace (weight fragments / h2)"); return -3; }
+template <int NP>
+static int launch_ffn_x64_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn1_x64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS1_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1_x64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS1_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn2_x64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS2_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn2_x64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS2_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn1_x64<false, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS1_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1_x64<true, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS1_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn2_x64<false, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS2_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn2_x64<true, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS2_BYTES);
         if (e != hipSuccess) { lg_set_error("ffn_x64: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
     {
-        const int rc = launch_split_w(a1.w1, a1.w2, a2.w3, a1.wsplit, E, 3, s);
+        const int rc = launch_split_w(a1.w1, a1.w2, a2.w3, a1.wsplit, E, NP, s, a1.scales);
         if (rc) return rc;
     }
     const u32x4_t* wsp = reinterpret_cast<const u32x4_t*>(a1.wsplit);
@@ -384,8 +403,8 @@ int launch_ffn_x64(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     {
         const long ntiles = (a1.P + TP - 1) / TP;
         const int grid = (int)(ntiles < 256 ? ntiles : 256);
-        if (save) k_ffn1_x64<true><<<grid, 512, LDS1_BYTES, s>>>(a1, wsp, ntiles);
-        else k_ffn1_x64<false><<<grid, 512, LDS1_BYTES, s>>>(a1, wsp, ntiles);
+        if (save) k_ffn1_x64<true, NP><<<grid, 512, LDS1_BYTES, s>>>(a1, wsp, ntiles);
+        else k_ffn1_x64<false, NP><<<grid, 512, LDS1_BYTES, s>>>(a1, wsp, ntiles);
         LG_CHECK_LAUNCH();
     }
     {
@@ -393,9 +412,14 @@ int launch_ffn_x64(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
         const int ntiles = a2.B * tiles_x * tiles_y;
         const int grid = ntiles < 256 ? ntiles : 256;
         const u32x4_t* w3p = wsp + (size_t)(NF_W1 + NF_W2) * 3 * 64;
-        if (save) k_ffn2_x64<true><<<grid, 512, LDS2_BYTES, s>>>(a2, w3p, tiles_x, tiles_y, ntiles);
-        else k_ffn2_x64<false><<<grid, 512, LDS2_BYTES, s>>>(a2, w3p, tiles_x, tiles_y, ntiles);
+        if (save) k_ffn2_x64<true, NP><<<grid, 512, LDS2_BYTES, s>>>(a2, w3p, a1.scales, tiles_x, tiles_y, ntiles);
+        else k_ffn2_x64<false, NP><<<grid, 512, LDS2_BYTES, s>>>(a2, w3p, a1.scales, tiles_x, tiles_y, ntiles);
         LG_CHECK_LAUNCH();
     }
     return 0;
+}
+
+int launch_ffn_x64(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
+    if (!a1.wsplit || !a1.h2) { lg_set_error("ffn_x64: missing workspace (weight fragments / h2)"); return -3; }
+    return a1.scales ? launch_ffn_x64_t<2>(a1, a2, s) : launch_ffn_x64_t<3>(a1, a2, s);
 }
