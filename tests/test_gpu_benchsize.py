@@ -287,3 +287,45 @@ def test_matrix_pipe_mixer_is_as_close_to_fp64_as_the_fp32_kernel(C, monkeypatch
         em, ev = float((got['m'] - want).norm()) / den, float((got['valu'] - want).norm()) / den
         print(f'C={C} block {blk}: matrix pipe {em:.3e}  fp32 FMAs {ev:.3e}')
         assert ev < 1e-6 and em < 1e-6 and em <= 1.6 * ev, (blk, em, ev)
+
+
+@pytest.mark.parametrize('C', [4, 8])
+@pytest.mark.parametrize('case', ['as_initialised', 'w1_tiny_w2_huge', 'w1_huge_w3_tiny', 'ln_affine_huge', 'w2_dw_huge_w3_tiny'])
+def test_f16_pair_ffn_holds_fp32_accuracy_at_extreme_operand_scales(C, case, monkeypatch):
+    """The fused FFN forward multiplies f16 PAIRS (split_bf16.h NP = 2), whose exponent range is 2^-24 .. 2^16: every operand is scaled by a
+    power of two derived from a bound on the block's weights (k_ffn_prep.hip).  The FFN half-block of both levels (e = 16 / 32 at C = 4,
+    32 / 64 at C = 8: all three kernels) against an fp64 evaluation with the block's weights pushed far out of f16's range in opposite
+    directions (so that the OUTPUT stays O(1) and the residual add does not drown the comparison) -- hidden activations of 1e-4 and of
+    1e3 .. 1e6, weights of 1e-5 and of 1e3, LayerNorm outputs of 1e3: the error stays at the level of the three-piece bf16 arithmetic
+    (LG_FFN_SPLIT=bf16x3, which has fp32's exponent range), within 2 x of it (+ 1e-7), and below 2e-6 in absolute terms."""
+    from gpu_helpers import Ops, make_module
+    from oracle import lgteun_oracle as orc
+    E = 4 * C
+    mult = {'as_initialised': {},
+            'w1_tiny_w2_huge': {'net.0.weight': 1e-4, 'net.0.bias': 1e-4, 'net.2.point_conv.weight': 1e4},
+            'w1_huge_w3_tiny': {'net.0.weight': 1e3, 'net.0.bias': 1e3, 'net.4.weight': 1e-3},
+            'ln_affine_huge': {'norm.weight': 1e3, 'norm.bias': 1e3, 'net.0.weight': 1e-3},
+            'w2_dw_huge_w3_tiny': {'net.2.point_conv.weight': 3e3, 'net.2.point_conv.bias': 3e3, 'net.2.depth_conv.weight': 30.0, 'net.2.depth_conv.bias': 1e5,
+                                   'net.4.weight': 1e-5}}[case]
+    rng = np.random.default_rng(17)
+    for blk, e, n in ((0, E, 32), (2, 2 * E, 16)):
+        pre = 'prior_module.0.' + ('encoder_layers.0.0.blocks.0.' if blk == 0 else 'bottleneck.blocks.0.') + '1.fn.'
+        x = T((rng.standard_normal((2, n, n, e)) * 1.5 + 0.3).astype(np.float32))
+        got = {}
+        for split in ('f16x2', 'bf16x3'):
+            monkeypatch.setenv('LG_FFN_SPLIT', split)
+            net = make_module(C, 1)
+            sd = net.state_dict()
+            for k, f in mult.items():
+                key = pre + (k if k.startswith('norm') else 'fn.' + k)
+                sd[key] = sd[key] * f
+            net.load_state_dict(sd)
+            got[split] = Ops(net, 32, 32).block(0, blk, 2, x.cuda()).cpu().double()
+        P64 = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+        y = orc.layer_norm(x.double(), P64[pre + 'norm.weight'], P64[pre + 'norm.bias'])
+        want = x.double() + orc.feed_forward(P64, pre + 'fn.', y)
+        den = float((want - x.double()).norm())
+        e2, e3 = (float((got[s] - want).norm()) / den for s in ('f16x2', 'bf16x3'))
+        print(f'C={C} {case} block {blk} (e={e}): |ffn| / |x| = {den / float(x.double().norm()):.2e}   f16 pairs {e2:.3e}   bf16 x 3 {e3:.3e}')
+        assert e2 < 2e-6 and e2 <= 2.0 * e3 + 1e-7, (case, blk, e2, e3)
+    monkeypatch.delenv('LG_FFN_SPLIT', raising=False)
