@@ -31,9 +31,10 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0
 PEAK_F32_MFMA_TFLOPS = 157.3
 
-# fp32-equivalent split arithmetic (csrc/split_bf16.h): six bf16 MFMAs per 16x16x32 block -> what the bf16 pipe could deliver
+# fp32-equivalent split arithmetic (csrc/split_bf16.h): three f16-pair MFMAs per 16x16x32 block in the forward FFN (round 5; six bf16-piece
+# ones in the backward and under LG_FFN_SPLIT=bf16x3) -> what the 16-bit matrix pipe could deliver
 PEAK_BF16_MFMA_TFLOPS = 2500.0
-PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / (6.0 if os.environ.get('LG_FFN_SPLIT') == 'bf16x3' else 3.0)
 
 CONFIGS = {   # BASELINE.json configs[...] that fit one GPU: (C, K, PAN size, pairs per GPU, label)
     'c2': (4, 4, 128, 32, 'BASELINE configs[1]: C=4, MS 32x32, PAN 128x128, K=4, 32 pairs/GPU'),
@@ -416,14 +417,14 @@ def main():
                     avg_launch_us=round(avg_us, 2), algorithmic_bytes_per_launch=int(byts), algorithmic_flops_per_launch=int(flops),
                     hbm_frac=round(f_hbm, 4), mfma_frac_fp32=round(f_mfma, 4), peak_hbm_GBs=PEAK_HBM_GBS,
                     peak_fp32_mfma_TFLOPs=PEAK_F32_MFMA_TFLOPS,
-                    note='peak = the f32 matrix rate (the reference arithmetic\'s dtype). The GEMMs execute as 6 bf16 MFMAs per product '
-                         f'(fp32-equivalent 3-piece split): their own pipe would allow {PEAK_SPLIT_TFLOPS:.0f} TFLOP/s; the kernel is bound by its '
+                    note='peak = the f32 matrix rate (the reference arithmetic\'s dtype). The GEMMs execute as 3 f16 MFMAs per product '
+                         f'(fp32-equivalent two-piece split, power-of-two operand scales): their own pipe would allow {PEAK_SPLIT_TFLOPS:.0f} TFLOP/s; the kernel is bound by its '
                          'VALU work (two erf-GELUs per hidden element, depthwise 3x3, LayerNorm, operand splitting), not by either matrix rate')
         metric = 'train image-pairs/sec, GF-2 4-band 128x128, K=4, bs=32/GPU' if args.config == 'c2' else f'train image-pairs/sec, {label}'
         out = dict(metric=metric, value=round(value, 2), unit='image-pairs/sec',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
                    scaling='weak', vs_baseline=None,
-                   dtype='f32 (GEMMs and the local mixer: split 16-bit MFMA -- bf16x3, f16x2 for P V -- fp32 accumulate; fp32-equivalent)' if args.precision == 'fp32'
+                   dtype='f32 (GEMMs and the local mixer: split 16-bit MFMA -- f16 pairs in the forward FFN and P V, bf16 triples elsewhere -- fp32 accumulate; fp32-equivalent)' if args.precision == 'fp32'
                          else 'bf16 / f16 MFMA (FFN, local mixer) + bf16 saved activations, f32 elsewhere', data='synthetic',
                    config=dict(workload=label + ', train step = fwd + L1 + bwd + Adam + StepLR tick', mode=args.mode,
                                global_batch=B_PER_GPU * world, parallelism=f'dp{world}', dropout=True),
