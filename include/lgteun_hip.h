@@ -87,7 +87,7 @@ typedef struct lg_config {
                                         * five-tensor GELU-free form */
 #define LG_VAR_FFN_SAVE3 (1u << 2)
 #define LG_VAR_FFN_SAVE5 (2u << 2)
-#define LG_VAR_FFN_BWD32_XS (1u << 4)   /* e = 32 FFN backward: the e = 16 kernel's template instance instead of the default pair */
+#define LG_VAR_FFN_BWD32_PAIR (1u << 4) /* e = 32 FFN backward, pixelwise half: round 2's k_ffn1_bwd_x32 + two weight-gradient launches instead of k_ffn1_bwd_xs<32> */
 #define LG_VAR_FFN_DWBWD_TILE (1u << 5) /* e = 16 FFN backward, spatial half: round 2's tile kernel + weight-gradient launch */
 #define LG_VAR_ATTN_BWD_R3 (1u << 6)    /* e = 16 local-mixer backward: round 3's three-kernel form instead of k_attn_bwd_f */
 #define LG_VAR_DSTEP_TILES (1u << 7)    /* data step: the tile kernels (four launches forward, nine backward) also where the one-launch form exists */

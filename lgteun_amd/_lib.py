@@ -29,7 +29,7 @@ class LgConfig(ctypes.Structure):
 # lg_config.variant bits (include/lgteun_hip.h): A/B kernels that compute the same function as the product path
 LG_VAR_FFN_STRIP, LG_VAR_FFN_TILE, LG_VAR_FFN_XP = 1, 2, 3
 LG_VAR_FFN_SAVE3, LG_VAR_FFN_SAVE5 = 1 << 2, 2 << 2
-LG_VAR_FFN_BWD32_XS, LG_VAR_FFN_DWBWD_TILE, LG_VAR_ATTN_BWD_R3 = 1 << 4, 1 << 5, 1 << 6
+LG_VAR_FFN_BWD32_PAIR, LG_VAR_FFN_DWBWD_TILE, LG_VAR_ATTN_BWD_R3 = 1 << 4, 1 << 5, 1 << 6
 LG_VAR_DSTEP_TILES = 1 << 7
 LG_VAR_ATTN_FWD_VALU = 1 << 8
 LG_VAR_FFN_BF16X3 = 1 << 9
@@ -42,8 +42,8 @@ def variant_from_env(env=None):
     env = os.environ if env is None else env
     v = {'strip': LG_VAR_FFN_STRIP, 'tile': LG_VAR_FFN_TILE, 'xp': LG_VAR_FFN_XP}.get(env.get('LG_FFN_IMPL', ''), 0)
     v |= {'3': LG_VAR_FFN_SAVE3, '5': LG_VAR_FFN_SAVE5}.get(env.get('LG_FFN_SAVE', ''), 0)
-    if env.get('LG_FFN_BWD32') == 'xs':
-        v |= LG_VAR_FFN_BWD32_XS
+    if env.get('LG_FFN_BWD32') == 'pair':
+        v |= LG_VAR_FFN_BWD32_PAIR
     if env.get('LG_FFN_DWBWD') == 'tile':
         v |= LG_VAR_FFN_DWBWD_TILE
     if env.get('LG_ATTN_BWD') in ('old', 'r3'):

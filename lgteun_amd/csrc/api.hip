@@ -127,7 +127,6 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
     if ((cfg->variant & LG_VAR_FFN_SAVE_MASK) == LG_VAR_FFN_SAVE_MASK) { lg_set_error("plan_create: invalid FFN save variant"); return -2; }
 #ifndef LG_BUILD_AB
     if ((cfg->variant & LG_VAR_FFN_IMPL_MASK) >= LG_VAR_FFN_TILE) { lg_set_error("plan_create: FFN variants 2 / 3 exist in `make AB=1` builds only"); return -2; }
-    if (cfg->variant & LG_VAR_FFN_BWD32_XS) { lg_set_error("plan_create: LG_VAR_FFN_BWD32_XS (k_ffn1_bwd_xs<32>) exists in `make AB=1` builds only"); return -2; }
     if (cfg->precision == 1 && (cfg->variant & LG_VAR_FFN_IMPL_MASK)) { lg_set_error("plan_create: precision = 1 with an FFN variant exists in `make AB=1` builds only"); return -2; }
 #endif
     lg_plan* p = new lg_plan;
@@ -138,7 +137,7 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
         p->ffn_tile = (int)(v & LG_VAR_FFN_IMPL_MASK);
         const uint32_t sv = v & LG_VAR_FFN_SAVE_MASK;
         p->save_mode = sv == LG_VAR_FFN_SAVE5 ? 5 : (sv == LG_VAR_FFN_SAVE3 ? 3 : 2);   // common.h: lg_plan::save_mode
-        p->bwd32_old = (v & LG_VAR_FFN_BWD32_XS) ? 0 : 1;   // default: the round-2 pair (k_ffn1_bwd_xs<32>: parity-green, measured 375 us against 203 + 121 us at C = 8)
+        p->bwd32_old = (v & LG_VAR_FFN_BWD32_PAIR) ? 1 : 0;   // default (round 5): k_ffn1_bwd_xs<32> behind the strip-walking spatial half -- 14.36 -> 14.20 ms per c3 step, and the forward no longer saves gelu(h1) / gelu'(h1)
         p->dwbwd_tile = (v & LG_VAR_FFN_DWBWD_TILE) ? 1 : 0;
         p->attn_bwd_old = (v & LG_VAR_ATTN_BWD_R3) ? 1 : 0;
         p->dstep_tiles = (v & LG_VAR_DSTEP_TILES) ? 1 : 0;
@@ -236,7 +235,8 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     int rc;
     Ffn1Args a1;
     const bool pre = pl->ffn_saves_preact(bb.e);   // h1 / h3 go to the a1 / a3 slots, nothing to g1 / g3
-    a1.x = bb.xmid; a1.a1s = ((flags & LG_FLAG_SAVE) && !pl->ffn_bwd_x(bb.e)) ? bb.a1 : nullptr; a1.g1s = ((flags & LG_FLAG_SAVE) && !pre) ? bb.g1 : nullptr; a1.h2 = bb.h2;
+    const bool noh1 = pl->ffn_bwd_x(bb.e) || pl->ffn1_bwd_x32(bb.e);   // the backward re-computes h1 from x: nothing of it is saved
+    a1.x = bb.xmid; a1.a1s = ((flags & LG_FLAG_SAVE) && !noh1) ? bb.a1 : nullptr; a1.g1s = ((flags & LG_FLAG_SAVE) && !pre && !noh1) ? bb.g1 : nullptr; a1.h2 = bb.h2;
     a1.ln2g = P + pl->blk(stage, j, B_LN2G); a1.ln2b = P + pl->blk(stage, j, B_LN2B);
     a1.w1 = P + pl->blk(stage, j, B_W1); a1.b1 = P + pl->blk(stage, j, B_B1);
     a1.w2 = P + pl->blk(stage, j, B_W2); a1.b2 = P + pl->blk(stage, j, B_B2);

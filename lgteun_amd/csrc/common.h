@@ -52,13 +52,13 @@ struct lg_plan {
     int dstep_tiles; // A/B switch (lg_config.variant LG_VAR_DSTEP_TILES; Python side: LG_DSTEP=tiles): the tile kernels of the data step also where the one-launch
                      // plane-in-LDS form (k_dstep.hip) exists
     bool dstep_fused(int h, int w) const;   // k_dstep.hip: square planes of 128 or 64
-    int bwd32_old; // A/B switch (lg_config.variant LG_VAR_FFN_BWD32_XS turns it off; Python side: LG_FFN_BWD32=xs): 1 = k_ffn1_bwd_x32 + k_wgrad_t at e = 32 (default);
+    int bwd32_old; // A/B switch (lg_config.variant LG_VAR_FFN_BWD32_PAIR turns it on; Python side: LG_FFN_BWD32=pair): 1 = k_ffn1_bwd_x32 + two k_wgrad_t launches at e = 32 (round 2 .. 4's default);
                    // 0 = k_ffn1_bwd_xs<32>, the e = 16 kernel's template at 8 waves / one workgroup per CU -- correct, but slower there
     bool ffn1_bwd_x32(int e) const { return e == 32 && ffn_tile == 0 && !bwd32_old; }
     // e = 32 (round 4): the spatial half through the strip-walking k_ffn_dw_bwd_xs<32> (dW3 / db3 included): the forward saves the PRE-activation h3
     // in the a3 slot and nothing in g3; the pixelwise half stays k_ffn1_bwd_x32 + the 128 x 128 weight-gradient launch on the saved gelu(h1) / gelu'(h1)
     // (a strip is 16 columns wide and every output pixel of a step must be inside the plane: level-1 planes whose width is 8 mod 16 keep round 2's kernels)
-    bool ffn_dw_x32(int e, int h, int w) const { return e == 32 && ffn_tile == 0 && !dwbwd_tile && !ffn1_bwd_x32(32) && (h & 7) == 0 && (w & 15) == 0; }
+    bool ffn_dw_x32(int e, int h, int w) const { return e == 32 && ffn_tile == 0 && !dwbwd_tile && (h & 7) == 0 && (w & 15) == 0; }
     bool ffn_bwd_x(int e) const { return e == 16 && ffn_tile == 0 && save_mode == 2; }   // h1 not saved; backward through k_ffn_dw_bwd_xs + k_ffn1_bwd_xs
     bool ffn_saves_preact(int e) const { return e == 16 && ffn_tile == 0 && (save_mode == 2 || (save_mode == 3 && cfg.precision == 0)); }
     int64_t* off;  // host copy of offsets

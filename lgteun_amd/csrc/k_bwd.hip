@@ -160,6 +160,7 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         fx.d_ln2g = G + pl->blk(st, j, B_LN2G); fx.d_ln2b = G + pl->blk(st, j, B_LN2B);
         fx.P = Pn; fx.hbf = hbf;
         RC(launch_ffn1_bwd_xs(e, fx, s));
+        if (dwx32) return 0;   // dW3 / db3 came out of k_ffn_dw_bwd_xs<32>
         return wgrad(dy, e, fb.a3, n1, G + pl->blk(st, j, B_W3), n1, G + pl->blk(st, j, B_B3), Pn, e, n1, e, n1, 0, hbf, bb, s, pre);
     }
     Ffn1BwdArgs f1;

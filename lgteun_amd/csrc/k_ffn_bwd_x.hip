@@ -459,22 +459,15 @@ int launch_t(const Ffn1BwdXArgs& a, hipStream_t s) {
 }   // namespace
 
 size_t ffn1_bwd_x_slab_floats(int e) { return (size_t)ffn1_bwd_x_wgs(e) * (e == 16 ? KB<16>::ROW : KB<32>::ROW); }
-bool ffn1_bwd_x32_built() {
-#ifdef LG_BUILD_AB
-    return true;
-#else
-    return false;
-#endif
-}
+bool ffn1_bwd_x32_built() { return true; }
 
 int launch_ffn1_bwd_xs(int e, const Ffn1BwdXArgs& a, hipStream_t s) {
     ProfScope prof__(LG_K_FFN1_BWD, s);
     if (e != 16 && e != 32) { lg_set_error("ffn1_bwd_xs: e=%d unsupported", e); return -1; }
     if (a.P <= 0 || a.P % NPX) { lg_set_error("ffn1_bwd_xs: pixel count %ld is not a multiple of %d", a.P, NPX); return -2; }
     if (!a.dh2 || !a.x || !a.dy || !a.dx || !a.slab || !a.w1 || !a.w1t || !a.w2t || !a.b1 || !a.ln2g || !a.ln2b) { lg_set_error("ffn1_bwd_xs: null argument"); return -2; }
-#ifdef LG_BUILD_AB   // the e = 32 instance (one 8-wave workgroup per CU: correct, slower than k_ffn1_bwd_x32 + k_wgrad_t): A/B builds only
+    // e = 32 (one 8-wave workgroup per CU): behind the strip-walking spatial half it replaces k_ffn1_bwd_x32 AND its two weight-gradient
+    // launches (round 5: 14.36 -> 14.20 ms per c3 step) -- the pixelwise half alone was measured slower than the pair in round 4
     if (e == 32) return launch_t<32>(a, s);
-#endif
-    if (e != 16) { lg_set_error("ffn1_bwd_xs: the e = 32 instance exists in `make AB=1` builds only"); return -2; }
     return launch_t<16>(a, s);
 }

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int pb = 0; pb < NPB; ++pb) {
             float av[4];
-            if (SAVE) {
+            if (SAVE && a1.a1s) {   // (a1s null in a saving launch: the backward re-computes h1 from x -- k_ffn1_bwd_xs<32> -- and nothing of it is saved)
                 const int m = c * CH + pb * 16 + r;
                 const int hy = m / HX, hx = m - hy * HX;
                 const int y = ya + hy, x = x0 + hx - 1;
@@ -510,7 +510,7 @@ int launch_ffn_x32(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     const int nstrips = a2.B * tiles_x * strips_y;
     const int grid = nstrips < 256 ? nstrips : 256;
     const u32x4_t* wsp = reinterpret_cast<const u32x4_t*>(a1.wsplit);
-    const bool save = a1.a1s != nullptr;
+    const bool save = a1.h2 != nullptr;           // h2 leaves the chip only for the backward
     if (a1.hbf) {   // precision = 'bf16'
         if (save) k_ffn_x32<true, 1><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
         else k_ffn_x32<false, 1><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
