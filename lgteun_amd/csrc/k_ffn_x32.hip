@@ -79,7 +79,10 @@ __global__ __launch_bounds__(256) void k_split_w(const float* __restrict__ w1, c
     out[(f * 3 + 2) * 64 + lane] = (u32x4_t){a3.x, a3.y, b3.x, b3.y};
 }
 
-template <bool SAVE, int NP>
+// SAVE: 0 nothing; 1 gelu(h1), gelu'(h1), h2 and gelu(h3) / gelu'(h3) or the pre-activation h3 (a2.g3s null); 2 h2 and h3 only (the backward
+// re-computes h1 from x: k_ffn1_bwd_xs<32>) -- a compile-time mode: as a run-time test of a1.a1s inside the unrolled stage the saving launch
+// spilled and ran 570 us instead of 341
+template <int SAVE, int NP>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ffn_x32(Ffn1Args a1, Ffn2Args a2, const u32x4_t* __restrict__ wsp, int tiles_x, int strips_y, int nstrips, int SH) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* ring = reinterpret_cast<float*>(smem_raw);                                   // [RING*HX][LDR]
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int pb = 0; pb < NPB; ++pb) {
             float av[4];
-            if (SAVE && a1.a1s) {   // (a1s null in a saving launch: the backward re-computes h1 from x -- k_ffn1_bwd_xs<32> -- and nothing of it is saved)
+            if (SAVE == 1) {
                 const int m = c * CH + pb * 16 + r;
                 const int hy = m / HX, hx = m - hy * HX;
                 const int y = ya + hy, x = x0 + hx - 1;
@@ -489,12 +492,15 @@ int launch_ffn_x32(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     if (!a1.wsplit) { lg_set_error("ffn_x32: no weight-fragment scratch in the workspace"); return -3; }
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_x32<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_x32<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_x32<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) { lg_set_error("ffn_x32: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
@@ -512,13 +518,16 @@ int launch_ffn_x32(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     const u32x4_t* wsp = reinterpret_cast<const u32x4_t*>(a1.wsplit);
     const bool save = a1.h2 != nullptr;           // h2 leaves the chip only for the backward
     if (a1.hbf) {   // precision = 'bf16'
-        if (save) k_ffn_x32<true, 1><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
-        else k_ffn_x32<false, 1><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
+        if (save && !a1.a1s) k_ffn_x32<2, 1><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
+        else if (save) k_ffn_x32<1, 1><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
+        else k_ffn_x32<0, 1><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
     } else if (a1.scales) {   // f16 pairs (three products per block instead of six)
-        if (save) k_ffn_x32<true, 2><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
-        else k_ffn_x32<false, 2><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
-    } else if (save) k_ffn_x32<true, 3><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
-    else k_ffn_x32<false, 3><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
+        if (save && !a1.a1s) k_ffn_x32<2, 2><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
+        else if (save) k_ffn_x32<1, 2><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
+        else k_ffn_x32<0, 2><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
+    } else if (save && !a1.a1s) k_ffn_x32<2, 3><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
+    else if (save) k_ffn_x32<1, 3><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
+    else k_ffn_x32<0, 3><<<grid, 512, LDS_BYTES, s>>>(a1, a2, wsp, tiles_x, strips_y, nstrips, SH);
     LG_CHECK_LAUNCH();
     return 0;
 }
