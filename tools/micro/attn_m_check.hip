@@ -155,7 +155,7 @@ int main(int argc, char** argv) {
             double tot = 0;
             for (int i = 0; i < 6; ++i) tot += st[i] / nw;
             for (int i = 0; i < 6; ++i) printf("  stamps: %-28s %9.0f ticks per wave (%4.1f %%)\n", nm[i], st[i] / nw, 100.0 * st[i] / nw / tot);
-            printf("  stamps: %.0f workgroups, %.0f ticks per wave in all (s_memtime = 100 MHz)\n", (double)st[7], tot);
+            printf("  stamps: %.0f workgroups, %.0f ticks per wave in all (s_memtime ticks = shader cycles)\n", (double)st[7], tot);
         }
 #endif
     }
