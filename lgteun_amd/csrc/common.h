@@ -288,17 +288,28 @@ __device__ __forceinline__ float lane_group_sum(float v) {
     if (N >= 16) v += __shfl_xor(v, 8);
     return v;
 }
-// counter-hash RNG for dropout (keep probability 0.9, nn.Dropout(0.1) of LGT.py:197): element idx is dropped when a 32-bit hash of its
-// counter falls below 0.1 * 2^32.  The hash is a two-round multiply-xorshift keyed by both halves of the 64-bit per-(stage, block) seed:
-// 2 quarter-rate 32-bit multiplies per element against the 10 of the 64-bit splitmix it replaced (8.5 % of k_attn).
-// Forward and backward call the same function, so the masks agree by construction.
-__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx) {
-    uint32_t x = (uint32_t)idx + (uint32_t)seed;
+// counter-hash RNG for dropout (keep probability 0.9, nn.Dropout(0.1) of LGT.py:197): a two-round 32-bit multiply-xorshift of a counter,
+// keyed by both halves of the 64-bit per-(stage, block) seed.  Forward and backward call the same function, so the masks agree by construction.
+// Round 5: ONE hash decides a PAIR of elements -- the hash of counter idx >> 1; element 2 j is dropped when its low 16 bits are below 6554,
+// element 2 j + 1 when its high 16 bits are (6554 / 65536 = 0.100006).  Half the hashes per pixel: the hash was 10 % of k_attn_m<8> and 13 % of
+// k_attn_m<16>.  dropout_scale() is the per-element view of the same function; dropout_scale2() returns both decisions of a pair.
+#define LG_DROP_T16 6554u
+__device__ __forceinline__ uint32_t dropout_hash(uint64_t seed, uint64_t pair) {
+    uint32_t x = (uint32_t)pair + (uint32_t)seed;
     x ^= x >> 16; x *= 0x7feb352du;
-    x ^= (uint32_t)(seed >> 32) ^ (uint32_t)(idx >> 32);
+    x ^= (uint32_t)(seed >> 32) ^ (uint32_t)(pair >> 32);
     x ^= x >> 15; x *= 0x846ca68bu;
     x ^= x >> 16;
-    return x < 429496730u ? 0.0f : (1.0f / 0.9f);
+    return x;
+}
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx) {
+    const uint32_t x = dropout_hash(seed, idx >> 1);
+    return ((idx & 1) ? (x >> 16) : (x & 0xffffu)) < LG_DROP_T16 ? 0.0f : (1.0f / 0.9f);
+}
+__device__ __forceinline__ void dropout_scale2(uint64_t seed, uint64_t idx_even, float& s0, float& s1) {   // elements idx_even, idx_even + 1
+    const uint32_t x = dropout_hash(seed, idx_even >> 1);
+    s0 = (x & 0xffffu) < LG_DROP_T16 ? 0.0f : (1.0f / 0.9f);
+    s1 = (x >> 16) < LG_DROP_T16 ? 0.0f : (1.0f / 0.9f);
 }
 // Small parameter tensors (weights / biases of the per-pixel matvecs) are staged in LDS once per workgroup and read back as
 // broadcasts: indexed straight from global memory inside a per-pixel loop they compile to long chains of dependent vector

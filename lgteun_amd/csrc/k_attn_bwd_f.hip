@@ -653,10 +653,11 @@ __global__ __launch_bounds__(256) void k_proj_o2_bwd_k(ProjO2BwdKArgs a) {
         if (a.keep) {
             uint32_t kw = 0;
 #pragma unroll
-            for (int n = 0; n < E; ++n) {
-                const bool kept = dropout_scale(a.seed, (uint64_t)(p * E + n)) != 0.0f;
-                kw |= kept ? (1u << n) : 0u;
-                dy[n] = kept ? dy[n] * (1.0f / 0.9f) : 0.0f;
+            for (int n = 0; n < E; n += 2) {   // one hash per channel pair (common.h)
+                float s0, s1;
+                dropout_scale2(a.seed, (uint64_t)(p * E + n), s0, s1);
+                kw |= (s0 != 0.0f ? (1u << n) : 0u) | (s1 != 0.0f ? (2u << n) : 0u);
+                dy[n] *= s0; dy[n + 1] *= s1;
             }
             a.keep[p] = kw;
         }

@@ -444,9 +444,12 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
                 float o[4];
                 const uint64_t di = (uint64_t)(pix * E + 16 * mt + 4 * g);   // a multiple of 4: | v below never carries
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    o[v] = acc[v];
-                    if (a.dropout) o[v] *= dropout_scale(a.seed, di | (uint64_t)v);
+                for (int v = 0; v < 4; ++v) o[v] = acc[v];
+                if (a.dropout) {   // two hashes for the lane's four consecutive channels
+                    float s0, s1, s2, s3;
+                    dropout_scale2(a.seed, di, s0, s1);
+                    dropout_scale2(a.seed, di + 2, s2, s3);
+                    o[0] *= s0; o[1] *= s1; o[2] *= s2; o[3] *= s3;
                 }
                 const float4 xr = RELOADX ? *reinterpret_cast<const float4*>(xw + (qt * tstep * E + 16 * mt + lx)) : xv[qt][mt];
                 *reinterpret_cast<float4*>(yw + (qt * tstep * E + 16 * mt + lx)) = make_float4(xr.x + o[0], xr.y + o[1], xr.z + o[2], xr.w + o[3]);

@@ -197,12 +197,14 @@ def _dropout_mask_numpy(seed, stage, blk, first, n):
     z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
     z ^= z >> 31
     idx = np.arange(first, first + n, dtype=np.uint64)
-    x = (idx + np.uint64(z & 0xffffffff)).astype(np.uint32)
+    pair = idx >> np.uint64(1)                 # round 5: one hash per PAIR of elements, 16 bits of it per element
+    x = (pair + np.uint64(z & 0xffffffff)).astype(np.uint32)
     x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d)
-    x ^= np.uint32(z >> 32) ^ (idx >> np.uint64(32)).astype(np.uint32)
+    x ^= np.uint32(z >> 32) ^ (pair >> np.uint64(32)).astype(np.uint32)
     x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b)
     x ^= x >> np.uint32(16)
-    return np.where(x < np.uint32(429496730), np.float32(0), np.float32(1.0 / 0.9))
+    h = np.where((idx & np.uint64(1)) == 1, x >> np.uint32(16), x & np.uint32(0xffff))
+    return np.where(h < np.uint32(6554), np.float32(0), np.float32(1.0 / 0.9))
 
 
 def test_dropout_mask_rate_independence_and_restatement():
