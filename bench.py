@@ -63,7 +63,7 @@ def traffic_from_profile(kernel, config='c2'):
     """HBM bytes per launch of the roofline kernel from the committed PMC summary (FETCH_SIZE x2 corrected + WRITE_SIZE, separate
     --pmc passes of `python bench.py`; tools/summarize_profiles.py), launch-weighted over the kernel's variants.  None if absent."""
     import csv
-    names = {'ffn': FFN_KERNELS, 'attn': ('k_attn<',), 'fft': ('k_fftmix<',), 'attn_bwd': ('k_attn_bwd_core', 'k_attn_bwd_f'), 'fft_bwd': ('k_fftmix_bwd',)}.get(kernel)
+    names = {'ffn': FFN_KERNELS, 'attn': ('k_attn<', 'k_attn_m<'), 'fft': ('k_fftmix<',), 'attn_bwd': ('k_attn_bwd_core', 'k_attn_bwd_f'), 'fft_bwd': ('k_fftmix_bwd',)}.get(kernel)
     path = PMC_SUMMARIES.get(config)
     if not names or not path or not os.path.exists(path):
         return None
@@ -91,7 +91,7 @@ def synth_batch(B, rank, device, c=None, h=None):
 
 # what the SQ counters of a committed profile show the roofline kernel to be held by -- per (config, kernel), with the file that says so.
 # No entry = no counters were taken for that kernel in that config: the label is then None rather than a guess.
-LIMITERS = {('c2', 'ffn'): ('valu-issue', 'profiles/r04_sq_counters_step.txt'), ('c2', 'attn_bwd'): ('valu-issue', 'profiles/r04_sq_counters_step.txt'),
+LIMITERS = {('c2', 'ffn'): ('valu-issue', 'profiles/r05_sq_counters_step.txt'), ('c2', 'attn_bwd'): ('valu-issue', 'profiles/r05_sq_counters_step.txt'),
             ('c3', 'ffn'): ('valu-issue (54 % vector-active, 31 % matrix-busy, in alternating phases)', 'profiles/r04_sq_counters_c3.txt'),
             ('c5', 'ffn'): ('valu-issue (vector-active and matrix-busy in alternating phases)', 'profiles/r04_sq_counters_c5.txt')}
 
