@@ -92,8 +92,8 @@ def synth_batch(B, rank, device, c=None, h=None):
 # what the SQ counters of a committed profile show the roofline kernel to be held by -- per (config, kernel), with the file that says so.
 # No entry = no counters were taken for that kernel in that config: the label is then None rather than a guess.
 LIMITERS = {('c2', 'ffn'): ('valu-issue', 'profiles/r05_sq_counters_step.txt'), ('c2', 'attn_bwd'): ('valu-issue', 'profiles/r05_sq_counters_step.txt'),
-            ('c3', 'ffn'): ('valu-issue (54 % vector-active, 31 % matrix-busy, in alternating phases)', 'profiles/r04_sq_counters_c3.txt'),
-            ('c5', 'ffn'): ('valu-issue (vector-active and matrix-busy in alternating phases)', 'profiles/r04_sq_counters_c5.txt')}
+            ('c3', 'ffn'): ('valu-issue (49 % vector-active, 17 % matrix-busy, in alternating phases)', 'profiles/r05_sq_counters_c3.txt'),
+            ('c5', 'ffn'): ('valu-issue (49 % vector-active, 17 % matrix-busy, in alternating phases)', 'profiles/r05_sq_counters_c5.txt')}
 
 
 def side_config(name, device, n_steps):
