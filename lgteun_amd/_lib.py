@@ -33,6 +33,7 @@ LG_VAR_FFN_BWD32_PAIR, LG_VAR_FFN_DWBWD_TILE, LG_VAR_ATTN_BWD_R3 = 1 << 4, 1 << 
 LG_VAR_DSTEP_TILES = 1 << 7
 LG_VAR_ATTN_FWD_VALU = 1 << 8
 LG_VAR_FFN_BF16X3 = 1 << 9
+LG_VAR_FFT_FULL = 1 << 10
 LG_ABI_VERSION = 2   # include/lgteun_hip.h: checked against lg_abi_version() when the library is loaded
 
 
@@ -54,6 +55,8 @@ def variant_from_env(env=None):
         v |= LG_VAR_ATTN_FWD_VALU
     if env.get('LG_FFN_SPLIT', '') == 'bf16x3':
         v |= LG_VAR_FFN_BF16X3
+    if env.get('LG_FFT', '') == 'full':
+        v |= LG_VAR_FFT_FULL
     return v
 
 

@@ -143,6 +143,7 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
         p->dstep_tiles = (v & LG_VAR_DSTEP_TILES) ? 1 : 0;
         p->attn_fwd_valu = (v & LG_VAR_ATTN_FWD_VALU) ? 1 : 0;
         p->ffn_bf16x3 = (v & LG_VAR_FFN_BF16X3) ? 1 : 0;
+        p->fft_full = (v & LG_VAR_FFT_FULL) ? 1 : 0;
     }
     p->off = (int64_t*)malloc(sizeof(int64_t) * n_offsets);
     memcpy(p->off, offsets, sizeof(int64_t) * n_offsets);
@@ -216,7 +217,7 @@ static int block_mixer_fwd(const lg_plan* pl, const float* P, int stage, int j, 
     f.scratch = fft_scratch;
     f.ampw = P + pl->blk(stage, j, B_AMPW); f.ampb = P + pl->blk(stage, j, B_AMPB);
     f.phaw = P + pl->blk(stage, j, B_PHAW); f.phab = P + pl->blk(stage, j, B_PHAB);
-    f.ch = bb.e / 2; f.planes = B * f.ch; f.n = bb.h; f.h = bb.h; f.w = bb.w;
+    f.ch = bb.e / 2; f.planes = B * f.ch; f.n = bb.h; f.h = bb.h; f.w = bb.w; f.full = pl->fft_full;
     if ((rc = launch_fftmix(f, s))) return rc;
     AttnArgs t;
     t.x = bb.xin; t.o2 = bb.o2; t.y = bb.xmid; t.posT = posT; t.pos = P + pl->blk(stage, j, B_POS);
@@ -473,7 +474,7 @@ extern "C" int lg_op_block(const lg_plan* plan, const float* params, int32_t sta
         f.g = bb.g; f.o = y; f.amp = nullptr; f.pha = nullptr; f.sgn = nullptr; f.scratch = nb.fft_scratch;
         f.ampw = params + plan->blk(stage, blk, B_AMPW); f.ampb = params + plan->blk(stage, blk, B_AMPB);
         f.phaw = params + plan->blk(stage, blk, B_PHAW); f.phab = params + plan->blk(stage, blk, B_PHAB);
-        f.ch = bb.e / 2; f.planes = B * f.ch; f.n = bb.h; f.h = bb.h; f.w = bb.w;
+        f.ch = bb.e / 2; f.planes = B * f.ch; f.n = bb.h; f.h = bb.h; f.w = bb.w; f.full = plan->fft_full;
         return launch_fftmix(f, s);
     }
     if (which == 1) {

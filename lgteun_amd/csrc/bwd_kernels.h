@@ -288,6 +288,7 @@ struct FftBwdArgs {
     float* part;       // scratch: per-workgroup partial sums of the four parameter gradients, fft_bwd_part_floats()
     int planes, ch, n;
     int h, w;          // plane size (when non-zero; n = side of a square plane otherwise)
+    int full = 0;      // 1: the complex-row in-LDS kernels (A/B variant LG_VAR_FFT_FULL); 0: the real-input kernels (k_fftmix_r / k_fftmix_bwd_r)
 };
 size_t fft_bwd_part_floats(int planes, int h, int w);
 int launch_fftmix_bwd(const FftBwdArgs& a, hipStream_t s);

@@ -203,7 +203,7 @@ static int fft_bwd_call(const lg_plan* pl, const float* P, float* G, int st, int
     fa.phaw = P + pl->blk(st, j, B_PHAW); fa.phab = P + pl->blk(st, j, B_PHAB);
     fa.d_ampw = G + pl->blk(st, j, B_AMPW); fa.d_ampb = G + pl->blk(st, j, B_AMPB);
     fa.d_phaw = G + pl->blk(st, j, B_PHAW); fa.d_phab = G + pl->blk(st, j, B_PHAB);
-    fa.ch = hc; fa.planes = B * hc; fa.n = fb.h; fa.h = fb.h; fa.w = fb.w; fa.part = part;
+    fa.ch = hc; fa.planes = B * hc; fa.n = fb.h; fa.h = fb.h; fa.w = fb.w; fa.part = part; fa.full = pl->fft_full;
     return launch_fftmix_bwd(fa, s);
 }
 

@@ -8,12 +8,47 @@
 // rows are Hermitian-extended before the last (row) inverse, with Im of the kx = 0 and kx = n/2 columns
 // dropped exactly as a c2r transform does.  The four purely-real bins get +0.0 imaginary parts so that
 // angle() takes the same branch as pocketfft's r2c (+pi for negative DC).  fp32 throughout.
+#include <math.h>
 #include <string.h>
 
 #include "kernels.h"
 #include "bwd_kernels.h"
 
 #define FFT_LD(n) ((n) + 1)   // row pitch (complex values) of a plane held in LDS, see fft_pass
+// exp(-2 pi i k / 512), k < 256, in constant memory (filled once per device by fft_const_twiddles()).  In every pass of a plane with at least 64
+// lines the 64 lanes of a wave hold the SAME butterfly group of 64 different lines, so the twiddle index is wave-uniform: read from here it is an
+// s_load (scalar cache, SGPR operand of the packed multiply) instead of one ds_read_b64 per lane and twiddle -- which were a third of the LDS
+// instructions of a fused pass (15 twiddle + 16 + 16 data accesses per 16-point item) in kernels whose passes are LDS-issue bound (round 5)
+__constant__ float2 c_tw512[256];
+static int lg_num_cus() {     // compute units of the current device (256 on an MI355X)
+    static std::atomic<int> cus[64];
+    int d = 0; (void)hipGetDevice(&d); d &= 63;
+    int c = cus[d].load(std::memory_order_relaxed);
+    if (!c) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || c <= 0) c = 256;
+        cus[d].store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+static int fft_const_twiddles() {
+    static DeviceOnce once;
+    if (once.need()) {
+        float2 h[256];
+        for (int k = 0; k < 256; ++k) {
+            const double ang = 2.0 * 3.14159265358979323846 * (double)k / 512.0;
+            h[k] = make_float2((float)cos(ang), (float)(0.0 - sin(ang)));
+        }
+        h[0] = make_float2(1.0f, 0.0f); h[128] = make_float2(0.0f, -1.0f);     // (cos(pi/2) in double is 6e-17, not 0)
+        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_tw512), h, sizeof(h));
+        if (e != hipSuccess) { lg_set_error("fft: hipMemcpyToSymbol(twiddles): %s", hipGetErrorString(e)); return (int)e; }
+        once.done();
+    }
+    return 0;
+}
+// the kernel's LDS twiddle table exp(-2 pi i k / n), k < n/2, taken from the constant table (so the uniform and the per-lane path of a pass use the same values)
+__device__ __forceinline__ void fft_tw_from_const(float2* tw, int lg) {
+    for (int k = threadIdx.x; k < (1 << (lg - 1)); k += blockDim.x) tw[k] = c_tw512[k << (9 - lg)];
+}
 __device__ __forceinline__ float2 cmul(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
 __device__ __forceinline__ float2 cmulc(float2 a, float2 w) { return make_float2(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y); }
 
@@ -29,8 +64,9 @@ __device__ __forceinline__ lg_v2f pk_cmulc(lg_v2f a, lg_v2f w) {   // a * conj(w
     return (lg_v2f){a.y, a.y} * (lg_v2f){w.y, w.x} + t;
 }
 // the S butterfly levels of one fused pass on the 2^S points a thread holds
-template <bool INVERSE, int S>
+template <bool INVERSE, int S, bool UNI = false>
 __device__ __forceinline__ void fft_butterflies(float2 (&v)[1 << S], const float2* tw, int lo, int lgmL, int lg) {
+    if (UNI) lg = 9;     // twiddles from c_tw512 (lo is wave-uniform: scalar loads)
     constexpr int R = 1 << S;
     lg_v2f u[R];
 #pragma unroll
@@ -45,7 +81,7 @@ __device__ __forceinline__ void fft_butterflies(float2 (&v)[1 << S], const float
         for (int c = 0; c < R; ++c) {
             if (c & d) continue;
             const int j = lo + ((c & (d - 1)) << lgmL);
-            const float2 wf = tw[j << twshift];
+            const float2 wf = UNI ? c_tw512[j << twshift] : tw[j << twshift];
             const lg_v2f w = (lg_v2f){wf.x, wf.y};
             const lg_v2f a = u[c], b = u[c + d];
             if (!INVERSE) {
@@ -75,8 +111,10 @@ __device__ __forceinline__ void fft_butterflies(float2 (&v)[1 << S], const float
 // consecutive elements, and the bit-reversed images of 32 consecutive bins (8 m + c becomes 8 m + c + (m >> 2): 32 different residues mod 32)
 template <bool SWZ>
 __device__ __forceinline__ int fft_pos(int p) { return SWZ ? ((p & ~31) | ((p + (p >> 5)) & 31)) : p; }
-template <bool INVERSE, bool SKIP, int S, bool LINESFAST = false, bool SWZ = false>
-__device__ __forceinline__ void fft_fused(float2* buf, const float2* tw, int lg, int lgnl, int ls, int es, int st) {
+// SKIP = 2 (compact half-width plane of the real-input kernels): the lines are the n/2 + 1 columns 0 .. n/2 of a plane of n rows.
+// twlg: log2 of the length the twiddle table was made for (exp(-2 pi i k / 2^twlg)); a half-length transform on the full table passes lg + 1
+template <bool INVERSE, int SKIP, int S, bool LINESFAST = false, bool SWZ = false, bool UNI = false>
+__device__ __forceinline__ void fft_fused(float2* buf, const float2* tw, int lg, int lgnl, int ls, int es, int st, int twlg) {
     const int nlines = 1 << lgnl;
     constexpr int R = 1 << S;
     const int n = 1 << lg, half = n >> 1;
@@ -87,22 +125,34 @@ __device__ __forceinline__ void fft_fused(float2* buf, const float2* tw, int lg,
     // SKIP: only the half + 1 needed columns are enumerated (bit-reversed positions: kx < n/2 <-> even p, kx = n/2 <-> p = 1),
     // so every lane of a wave works (skipping by predicate left half of each wave idle)
     const int items = SKIP ? ((half + 1) << lgpl) : (nlines << lgpl);
+#pragma unroll 1
     for (int it = threadIdx.x; it < items; it += blockDim.x) {
         int line, t;
         if (SKIP) {
-            if (it < (half << lgpl)) { t = it >> (lgnl - 1); line = 2 * (it & (half - 1)); }
-            else { t = it - (half << lgpl); line = 1; }
+            if (it < (half << lgpl)) { t = it >> (lgnl - 1); line = (SKIP == 2 ? 1 : 2) * (it & (half - 1)); }
+            else { t = it - (half << lgpl); line = SKIP == 2 ? half : 1; }
         } else if (es != 1 || LINESFAST) { t = it >> lgnl; line = it & (nlines - 1); }   // consecutive threads -> consecutive lines
         else { line = it >> lgpl; t = it & ((1 << lgpl) - 1); }             // row transforms: consecutive threads -> consecutive items
-        const int lo = t & (mL - 1), hi = t >> lgmL;
-        const int i_base = (hi << (lgmL + S)) + lo;
         float2* base = buf + line * ls;
         float2 v[R];
+        const int t0 = UNI ? __builtin_amdgcn_readfirstlane(t) : t;
+        if (UNI && __builtin_amdgcn_ballot_w64(t != t0) == 0) {      // the wave's lanes hold the same butterfly group of different lines
+            const int lo = t0 & (mL - 1), hi = t0 >> lgmL;
+            const int i_base = (hi << (lgmL + S)) + lo;
 #pragma unroll
-        for (int c = 0; c < R; ++c) v[c] = base[fft_pos<SWZ>(i_base + (c << lgmL)) * es];
-        fft_butterflies<INVERSE, S>(v, tw, lo, lgmL, lg);
+            for (int c = 0; c < R; ++c) v[c] = base[fft_pos<SWZ>(i_base + (c << lgmL)) * es];
+            fft_butterflies<INVERSE, S, true>(v, tw, lo, lgmL, twlg);
 #pragma unroll
-        for (int c = 0; c < R; ++c) base[fft_pos<SWZ>(i_base + (c << lgmL)) * es] = v[c];
+            for (int c = 0; c < R; ++c) base[fft_pos<SWZ>(i_base + (c << lgmL)) * es] = v[c];
+        } else {
+            const int lo = t & (mL - 1), hi = t >> lgmL;
+            const int i_base = (hi << (lgmL + S)) + lo;
+#pragma unroll
+            for (int c = 0; c < R; ++c) v[c] = base[fft_pos<SWZ>(i_base + (c << lgmL)) * es];
+            fft_butterflies<INVERSE, S>(v, tw, lo, lgmL, twlg);
+#pragma unroll
+            for (int c = 0; c < R; ++c) base[fft_pos<SWZ>(i_base + (c << lgmL)) * es] = v[c];
+        }
     }
     __syncthreads();
 }
@@ -152,8 +202,9 @@ __device__ __forceinline__ void fft_rows_inv_first(float2* buf, const float2* tw
 // full 1-D transform of every line in ceil(lg / 4) LDS passes of up to four fused radix-2 stages (16 points per thread in
 // registers): 7 = 4 + 3, 6 = 3 + 3, 8 = 4 + 4, 9 = 3 + 3 + 3.  Every pass costs one read and one write of the plane plus a
 // barrier, so at n = 128 a transform is 2 passes instead of the 3 of the (3, 3, 1) grouping.
-template <bool INVERSE, bool SKIP, bool LINESFAST = false, bool HERMFIRST = false, bool SWZ = false>
-__device__ __forceinline__ void fft_lines(float2* buf, const float2* tw, int lg, int lgnl, int ls, int es) {
+template <bool INVERSE, int SKIP, bool LINESFAST = false, bool HERMFIRST = false, bool SWZ = false, bool UNI = false>
+__device__ __forceinline__ void fft_lines(float2* buf, const float2* tw, int lg, int lgnl, int ls, int es, int twlg = -1) {
+    if (twlg < 0) twlg = lg;
     const int npass = (lg + 3) >> 2, base = lg / npass, extra = lg - base * npass;
     int st = 0;
     for (int ps = 0; ps < npass; ++ps) {
@@ -163,10 +214,10 @@ __device__ __forceinline__ void fft_lines(float2* buf, const float2* tw, int lg,
             else if (S == 3) fft_rows_inv_first<3>(buf, tw, lg, ls);
             else if (S == 2) fft_rows_inv_first<2>(buf, tw, lg, ls);
             else fft_rows_inv_first<1>(buf, tw, lg, ls);
-        } else if (S == 4) fft_fused<INVERSE, SKIP, 4, LINESFAST, SWZ>(buf, tw, lg, lgnl, ls, es, st);
-        else if (S == 3) fft_fused<INVERSE, SKIP, 3, LINESFAST, SWZ>(buf, tw, lg, lgnl, ls, es, st);
-        else if (S == 2) fft_fused<INVERSE, SKIP, 2, LINESFAST, SWZ>(buf, tw, lg, lgnl, ls, es, st);
-        else fft_fused<INVERSE, SKIP, 1, LINESFAST, SWZ>(buf, tw, lg, lgnl, ls, es, st);
+        } else if (S == 4) fft_fused<INVERSE, SKIP, 4, LINESFAST, SWZ, UNI>(buf, tw, lg, lgnl, ls, es, st, twlg);
+        else if (S == 3) fft_fused<INVERSE, SKIP, 3, LINESFAST, SWZ, UNI>(buf, tw, lg, lgnl, ls, es, st, twlg);
+        else if (S == 2) fft_fused<INVERSE, SKIP, 2, LINESFAST, SWZ, UNI>(buf, tw, lg, lgnl, ls, es, st, twlg);
+        else fft_fused<INVERSE, SKIP, 1, LINESFAST, SWZ, UNI>(buf, tw, lg, lgnl, ls, es, st, twlg);
         st += S;
     }
 }
@@ -176,17 +227,60 @@ __device__ __forceinline__ void fft_lines(float2* buf, const float2* tw, int lg,
 // radix-2 spans put 4..16 lanes on the same banks in every row pass.)
 template <bool INVERSE, bool COLS>
 __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int n, int lg) {
-    if (COLS) fft_lines<INVERSE, true>(buf, tw, lg, lg, 1, FFT_LD(n));
-    else fft_lines<INVERSE, false, true, INVERSE>(buf, tw, lg, lg, FFT_LD(n), 1);   // inverse rows: Hermitian extension fused in
+    if (COLS) fft_lines<INVERSE, 1>(buf, tw, lg, lg, 1, FFT_LD(n));
+    else fft_lines<INVERSE, 0, true, INVERSE>(buf, tw, lg, lg, FFT_LD(n), 1);   // inverse rows: Hermitian extension fused in
+}
+
+// ---- the edit's elementary functions.  The bin edit is pure vector arithmetic (no LDS, no matrix pipe): at 128 x 128 it was 26 % of k_fftmix_r and
+// 150 instructions per bin with the library's hypotf / atan2f / sincosf (argument paths for every float, IEEE square root and division).  The bins of
+// an image spectrum are ordinary numbers and the edited phase is a few radians, so each function is a short straight-line form here, with the
+// library function kept behind a wave-uniform branch for the arguments the short form does not cover (measured in tools/micro/fft_check.hip
+// against double precision: errors in the last place or two, as the library's).
+// sin and cos of x, |x| <= 100: Cody-Waite reduction by pi/2 in three pieces (k * piece exact for |k| < 2^12), Cephes' minimax pair on [-pi/4, pi/4]
+__device__ __forceinline__ void edit_sincos(float x, float& sn, float& cs) {
+    if (__builtin_amdgcn_ballot_w64(!(fabsf(x) <= 100.0f)) != 0) { sincosf(x, &sn, &cs); return; }
+    const float k = rintf(x * 0.63661977236758134f);
+    float r = fmaf(k, -1.57073974609375f, x);
+    r = fmaf(k, -5.657970905303955078e-05f, r);
+    r = fmaf(k, -9.920936294705029468e-10f, r);
+    const float s = r * r;
+    const float ps = fmaf(fmaf(-1.9515295891e-4f, s, 8.3321608736e-3f), s, -1.6666654611e-1f);
+    const float si = fmaf(ps * s, r, r);
+    const float pc = fmaf(fmaf(2.443315711809948e-5f, s, -1.388731625493765e-3f), s, 4.166664568298827e-2f);
+    const float co = fmaf(pc * s, s, fmaf(-0.5f, s, 1.0f));
+    const unsigned kq = (unsigned)(int)k;
+    const float a = (kq & 1u) ? co : si, b = (kq & 1u) ? si : co;
+    sn = __uint_as_float(__float_as_uint(a) ^ ((kq & 2u) << 30));
+    cs = __uint_as_float(__float_as_uint(b) ^ (((kq + 1u) & 2u) << 30));
+}
+// |f| and angle(f) (torch.abs / torch.angle of a complex value: hypot and atan2 with IEEE signed-zero conventions -- angle(-a + 0 i) = +pi,
+// angle(0) = 0) for 1e-18 <= max(|re|, |im|) <= 1e18 or f = 0; anything else in the wave sends the wave to the library functions
+__device__ __forceinline__ void edit_abs_angle(float2 f, float& amp, float& pha) {
+    const float ax = fabsf(f.x), ay = fabsf(f.y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    if (__builtin_amdgcn_ballot_w64(!(mx <= 1e18f) || (mx < 1e-18f && mx > 0.0f)) != 0) { amp = hypotf(f.x, f.y); pha = atan2f(f.y, f.x); return; }
+    amp = __builtin_amdgcn_sqrtf(fmaf(f.x, f.x, f.y * f.y));
+    const float r = __builtin_amdgcn_rcpf(mx);
+    float q = mn * r;
+    q = fmaf(fmaf(-mx, q, mn), r, q);            // mn / mx to the last place
+    q = mx == 0.0f ? 0.0f : q;
+    const float t = q * q;
+    float p = -0.0017540286062285304f;           // atan(q) = q + q t P(t) on [0, 1]: degree-9 minimax in t (relative error 2.4e-9)
+    p = fmaf(p, t, 0.010727421380579472f); p = fmaf(p, t, -0.030805569142103195f); p = fmaf(p, t, 0.05755317956209183f);
+    p = fmaf(p, t, -0.08377385884523392f); p = fmaf(p, t, 0.10942058265209198f); p = fmaf(p, t, -0.14261938631534576f);
+    p = fmaf(p, t, 0.1999826729297638f); p = fmaf(p, t, -0.3333328366279602f);
+    p = fmaf(p * t, q, q);
+    p = ay > ax ? (1.57079637050628662f - p) + -4.37113883e-8f : p;
+    p = (__float_as_uint(f.x) >> 31) ? (3.14159274101257324f - p) + -8.74227766e-8f : p;
+    pha = copysignf(p, f.y);
 }
 
 // amplitude / phase edit of one bin (LGT.py:168-177) and its backward, shared by the in-LDS and the split (256^2) paths
 __device__ __forceinline__ float2 bin_edit_fwd(float2 f, float aw, float ab, float pw, float pb, float& amp, float& pha) {
-    amp = hypotf(f.x, f.y);
-    pha = atan2f(f.y, f.x);
+    edit_abs_angle(f, amp, pha);
     const float am = aw * amp + ab, ph = pw * pha + pb;
     float sn, cs;
-    sincosf(ph, &sn, &cs);
+    edit_sincos(ph, sn, cs);
     return make_float2((am * cs + 1e-8f) + 1e-8f, am * sn + 1e-8f);
 }
 // f = c/n^2 * rfft2(dt) bin; returns dF * n^2 / c and accumulates the four parameter-gradient partials
@@ -195,13 +289,13 @@ __device__ __forceinline__ float2 bin_edit_bwd(float2 f, float c, float nn, floa
     const float dR = f.x * (c / nn), dI = f.y * (c / nn);
     const float Am = aw * A + ab, Ph = pw * PH + pb;
     float sn, cs;
-    sincosf(Ph, &sn, &cs);
+    edit_sincos(Ph, sn, cs);
     const float dAm = dR * cs + dI * sn;
     const float dPh = Am * (dI * cs - dR * sn);
     s_aw += dAm * A; s_ab += dAm; s_pw += dPh * PH; s_pb += dPh;
     const float dA = aw * dAm, dPH = pw * dPh;
     float sn0, cs0;
-    sincosf(PH, &sn0, &cs0);
+    edit_sincos(PH, sn0, cs0);
     float dFr = 0.f, dFi = 0.f;
     if (A > 0.f) {
         const float ia = 1.0f / A;
@@ -295,6 +389,168 @@ __global__ void k_fftmix(FftArgs a) {
             *reinterpret_cast<float4*>(a.sgn + (size_t)plane * n * n + i) = make_float4(sg[0], sg[1], sg[2], sg[3]);
         }
     }
+}
+
+
+// ================================================================================================
+// Real-input form of the in-LDS mixer (round 5; the default): the rows are REAL, so a row of n reals is transformed as n/2 complex
+// values z[j] = x[2j] + i x[2j+1] -- an n/2-point transform and one unpack step (X[k] = E[k] + w^k O[k], E / O from Z[k], conj Z[n/2-k]) give
+// the half spectrum X[0 .. n/2].  The plane is kept COMPACT, n rows x (n/2 + 1) complex: 65 KiB at n = 128 instead of 129 KiB, so TWO
+// workgroups (512 threads each) share a CU and one's global loads / stores / barriers run under the other's butterflies; the row passes
+// move half the LDS bytes and do half the butterflies of the complex-row form (k_fftmix above: the A/B variant LG_VAR_FFT_FULL).
+// Slots: Z[k] sits at slot brev_{lg-1}(k) of its row after the DIF row transform; X[k] (k < n/2) goes to the SAME slot -- which is the
+// compact column c = brev_{lg-1}(kx) the half_bin map of the complex-row kernels uses (saved amplitude / phase files are identical) --
+// and X[n/2] to slot n/2.  The pair (k, n/2 - k) is read and written by one thread: in place, no barrier inside the step.
+// ================================================================================================
+#define FFT_HP(n) ((n) / 2 + 1)
+__host__ __device__ constexpr int fftr_threads(int lg) { return lg >= 7 ? 1024 : (lg >= 6 ? 512 : 256); }   // as the complex-row kernels: the launches are one or two planes per CU, a plane's latency is what is timed
+
+template <int LG>
+__device__ __forceinline__ void fftr_unpack(float2* buf, const float2* tw) {
+    constexpr int n = 1 << LG, half = n >> 1, quarter = n >> 2, HP = FFT_HP(n);
+    for (int it = threadIdx.x; it < n * (quarter + 1); it += blockDim.x) {
+        const int y = it & (n - 1), k = it >> LG;
+        float2* row = buf + y * HP;
+        if (k == 0) {
+            const float2 A = row[0];
+            row[0] = make_float2(A.x + A.y, 0.0f);        // kx = 0 and kx = n/2 are real: Im = +0 (the branch-cut convention of the edit)
+            row[half] = make_float2(A.x - A.y, 0.0f);
+        } else {
+            const int qa = (int)(__brev((unsigned)k) >> (33 - LG)), qb = (int)(__brev((unsigned)(half - k)) >> (33 - LG));
+            const float2 A = row[qa], B = row[qb], w = tw[k];
+            const float ex = 0.5f * (A.x + B.x), ey = 0.5f * (A.y - B.y);      // E = (A + conj B) / 2
+            const float ox = 0.5f * (A.y + B.y), oy = 0.5f * (B.x - A.x);      // O = -i (A - conj B) / 2
+            const float px = w.x * ox - w.y * oy, py = w.x * oy + w.y * ox;    // w^k O
+            row[qa] = make_float2(ex + px, ey + py);                           // X[k] = E + w^k O
+            row[qb] = make_float2(ex - px, py - ey);                           // X[n/2 - k] = conj(E - w^k O)
+        }
+    }
+    __syncthreads();
+}
+// inverse of the step above for a c2r row transform: half spectrum Y[0 .. n/2] -> Z'[k] = E' + i O' (unnormalised: the n/2-point inverse
+// then yields n y[2j] + i n y[2j+1], the same scale as the n-point inverse of the complex-row form).  Im Y[0], Im Y[n/2] are dropped (c2r).
+template <int LG>
+__device__ __forceinline__ void fftr_pack(float2* buf, const float2* tw) {
+    constexpr int n = 1 << LG, half = n >> 1, quarter = n >> 2, HP = FFT_HP(n);
+    for (int it = threadIdx.x; it < n * (quarter + 1); it += blockDim.x) {
+        const int y = it & (n - 1), k = it >> LG;
+        float2* row = buf + y * HP;
+        if (k == 0) {
+            const float a = row[0].x, b = row[half].x;
+            row[0] = make_float2(a + b, a - b);
+        } else {
+            const int qa = (int)(__brev((unsigned)k) >> (33 - LG)), qb = (int)(__brev((unsigned)(half - k)) >> (33 - LG));
+            const float2 A = row[qa], B = row[qb], w = tw[k];
+            const float ex = A.x + B.x, ey = A.y - B.y;                        // E' = Y[k] + conj Y[n/2 - k]
+            const float dx = A.x - B.x, dy = A.y + B.y;                        // D  = Y[k] - conj Y[n/2 - k]
+            const float ox = w.x * dx + w.y * dy, oy = w.x * dy - w.y * dx;    // O' = conj(w^k) D
+            row[qa] = make_float2(ex - oy, ey + ox);                           // Z'[k] = E' + i O'
+            row[qb] = make_float2(ex + oy, ox - ey);                           // Z'[n/2 - k] = conj E' + i conj O'
+        }
+    }
+    __syncthreads();
+}
+template <int LG> __device__ __forceinline__ void fftr_rows_fwd(float2* buf, const float2* tw) {
+    fft_lines<false, 0, true, false, false, true>(buf, tw, LG - 1, LG, FFT_HP(1 << LG), 1, LG);
+    fftr_unpack<LG>(buf, tw);
+}
+template <int LG> __device__ __forceinline__ void fftr_rows_inv(float2* buf, const float2* tw) {
+    fftr_pack<LG>(buf, tw);
+    fft_lines<true, 0, true, false, false, true>(buf, tw, LG - 1, LG, FFT_HP(1 << LG), 1, LG);
+}
+template <bool INVERSE, int LG> __device__ __forceinline__ void fftr_cols(float2* buf, const float2* tw) {
+    fft_lines<INVERSE, 2, false, false, false, true>(buf, tw, LG, LG, 1, FFT_HP(1 << LG));
+}
+// half-spectrum bins of the compact plane: item it in [0, n (n/2 + 1)) -> row q (bit-reversed ky), column c (c < n/2: kx = brev(c); c = n/2: kx = n/2)
+__device__ __forceinline__ void fftr_bin(int it, int n, int lg, int& q, int& c) {
+    const int half = n >> 1;
+    if (it < n * half) { q = it >> (lg - 1); c = it & (half - 1); }
+    else { q = it - n * half; c = half; }
+}
+
+#ifdef LG_FFT_STAMPS     // tools/micro/fft_check.hip: s_memtime at the phase boundaries of workgroup 0 .. 255, wave 0
+__device__ unsigned long long fft_stamps[256][12];
+#define FFT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 256) fft_stamps[blockIdx.x][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FFT_STAMP(i) do { } while (0)
+#endif
+// NTH = 1024 at n = 128 when the launch has at most one plane per CU (a plane's latency is the launch's duration); NTH = 512 otherwise: two workgroups
+// per CU (2 x 65.5 KiB of LDS, 128 registers per lane), one's loads / stores / barriers under the other's butterflies
+template <int LG, int NTH>
+__global__ void __launch_bounds__(NTH, (LG >= 7 && NTH == 512) ? 4 : 1) k_fftmix_r(FftArgs a) {
+    extern __shared__ float2 smem2[];
+    constexpr int lg = LG, n = 1 << LG, half = n >> 1, HP = FFT_HP(n);
+    float2* buf = smem2;            // [n][HP]
+    float2* tw = smem2 + n * HP;    // [n/2]  exp(-2 pi i k / n)
+    FFT_STAMP(0);
+    const int plane = blockIdx.x;
+    const int ch = plane % a.ch;
+    const float* g = a.g + (size_t)plane * n * n;
+    constexpr int NLD = (n * n / 4 + NTH - 1) / NTH;     // (n = 8: 16 of the 64 threads hold a load)
+    {   // every 16-byte load of the thread requested before the first store; four reals = two packed complex values of a row
+        float4 v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) { const int i = (k * NTH + (int)threadIdx.x) * 4; v[k] = *reinterpret_cast<const float4*>(g + (i < n * n ? i : 0)); }
+        fft_tw_from_const(tw, lg);
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = (k * NTH + (int)threadIdx.x) * 4;
+            if (i < n * n) {
+                float2* d = buf + (i >> lg) * HP + ((i & (n - 1)) >> 1);
+                d[0] = make_float2(v[k].x, v[k].y); d[1] = make_float2(v[k].z, v[k].w);
+            }
+        }
+    }
+    __syncthreads();
+    FFT_STAMP(1);
+    // ---- rfft2: rows (real-input form), then the n/2 + 1 columns
+    fftr_rows_fwd<LG>(buf, tw);
+    FFT_STAMP(2);
+    fftr_cols<false, LG>(buf, tw);
+    if (threadIdx.x < 4) buf[(threadIdx.x >> 1) * HP + (threadIdx.x & 1) * half].y = 0.0f;  // the four purely-real bins (ky in {0, n/2}: rows 0, 1)
+    __syncthreads();
+    FFT_STAMP(3);
+    // ---- amplitude / phase edit (LGT.py:168-177)
+    const float aw = a.ampw[ch], ab = a.ampb[ch], pw = a.phaw[ch], pb = a.phab[ch];
+    for (int it = threadIdx.x; it < n * (half + 1); it += NTH) {
+        int q, c;
+        fftr_bin(it, n, lg, q, c);
+        float amp, pha;
+        const float2 ed = bin_edit_fwd(buf[q * HP + c], aw, ab, pw, pb, amp, pha);
+        if (a.amp) {
+            size_t o = ((size_t)plane * n + q) * (half + 1) + c;
+            a.amp[o] = amp;
+            a.pha[o] = pha;
+        }
+        buf[q * HP + c] = ed;
+    }
+    __syncthreads();
+    FFT_STAMP(4);
+    // ---- irfft2: columns (complex), rows (c2r: pack + n/2-point inverse)
+    fftr_cols<true, LG>(buf, tw);
+    FFT_STAMP(5);
+    fftr_rows_inv<LG>(buf, tw);
+    FFT_STAMP(6);
+    const float sc = 1.0f / ((float)n * (float)n);
+    float* o = a.o + (size_t)plane * n * n;
+    int tid_s = threadIdx.x;
+    asm volatile("" : "+v"(tid_s));      // the store offsets are recomputed here, not kept in registers (or scratch) since the loads
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = (k * NTH + tid_s) * 4;
+        if (i >= n * n) break;
+        const float2* r = buf + (i >> lg) * HP + ((i & (n - 1)) >> 1);
+        const float2 r0 = r[0], r1 = r[1];
+        const float v[4] = {r0.x * sc, r0.y * sc, r1.x * sc, r1.y * sc};
+        *reinterpret_cast<float4*>(o + i) = make_float4(fabsf(v[0]), fabsf(v[1]), fabsf(v[2]), fabsf(v[3]));
+        if (a.sgn) {
+            float sg[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sg[u] = (v[u] > 0.f) ? 1.0f : ((v[u] < 0.f) ? -1.0f : 0.0f);
+            *reinterpret_cast<float4*>(a.sgn + (size_t)plane * n * n + i) = make_float4(sg[0], sg[1], sg[2], sg[3]);
+        }
+    }
+    FFT_STAMP(7);
 }
 
 
@@ -829,6 +1085,29 @@ int launch_fftmix(const FftArgs& a, hipStream_t s) {
     int n = ph, lg = 0;
     while ((1 << lg) < n) ++lg;
     if (n > 128) return launch_fft_split(&a, nullptr, s);
+    if (!a.full) {
+        if (int rc = fft_const_twiddles()) return rc;
+        static DeviceOnce attr_r;
+        if (attr_r.need()) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_fftmix_r<7, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 512);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_fftmix_r<7, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 512);
+            if (e != hipSuccess) { lg_set_error("fftmix: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+            attr_r.done();
+        }
+        const size_t ldsr = ((size_t)n * FFT_HP(n) + n / 2) * sizeof(float2);
+        switch (lg) {
+            case 3: k_fftmix_r<3, fftr_threads(3)><<<a.planes, fftr_threads(3), ldsr, s>>>(a); break;
+            case 4: k_fftmix_r<4, fftr_threads(4)><<<a.planes, fftr_threads(4), ldsr, s>>>(a); break;
+            case 5: k_fftmix_r<5, fftr_threads(5)><<<a.planes, fftr_threads(5), ldsr, s>>>(a); break;
+            case 6: k_fftmix_r<6, fftr_threads(6)><<<a.planes, fftr_threads(6), ldsr, s>>>(a); break;
+            default:
+                if (a.planes <= lg_num_cus()) k_fftmix_r<7, 1024><<<a.planes, 1024, ldsr, s>>>(a);
+                else k_fftmix_r<7, 512><<<a.planes, 512, ldsr, s>>>(a);
+                break;
+        }
+        LG_CHECK_LAUNCH();
+        return 0;
+    }
     size_t lds = ((size_t)n * FFT_LD(n) + n / 2) * sizeof(float2);
     static DeviceOnce attr_once;
     if (attr_once.need()) {
@@ -943,6 +1222,98 @@ __global__ void k_fftmix_bwd(FftBwdArgs a) {
     }
 }
 
+// real-input form of the backward (see k_fftmix_r): the same two real <-> half-spectrum row steps around the same bin edit
+template <int LG, int NTH>
+__global__ void __launch_bounds__(NTH, (LG >= 7 && NTH == 512) ? 4 : 1) k_fftmix_bwd_r(FftBwdArgs a) {
+    extern __shared__ float2 smem2[];
+    constexpr int lg = LG, n = 1 << LG, half = n >> 1, HP = FFT_HP(n);
+    float2* buf = smem2;           // [n][HP]
+    float2* tw = smem2 + n * HP;
+    float* red = reinterpret_cast<float*>(tw + half);  // [waves][4]
+    const int plane = blockIdx.x;
+    const int ch = plane % a.ch;
+    const size_t base = (size_t)plane * n * n;
+    constexpr int NLD = (n * n / 4 + NTH - 1) / NTH, NBIN = n * (half + 1), NIT = (NBIN + NTH - 1) / NTH;
+    constexpr int LB = NLD > 4 ? 4 : NLD;     // loads in batches of four (do2 and sgn: 32 registers in flight)
+#pragma unroll
+    for (int b = 0; b < NLD; b += LB) {
+        float4 u[LB], sg[LB];
+#pragma unroll
+        for (int k = 0; k < LB; ++k) {
+            const int i = ((b + k) * NTH + (int)threadIdx.x) * 4, ic = i < n * n ? i : 0;
+            u[k] = *reinterpret_cast<const float4*>(a.do2 + base + ic);
+            sg[k] = *reinterpret_cast<const float4*>(a.sgn + base + ic);
+        }
+        if (b == 0) fft_tw_from_const(tw, lg);
+#pragma unroll
+        for (int k = 0; k < LB; ++k) {
+            const int i = ((b + k) * NTH + (int)threadIdx.x) * 4;
+            if (i >= n * n) continue;
+            float2* d = buf + (i >> lg) * HP + ((i & (n - 1)) >> 1);
+            d[0] = make_float2(u[k].x * sg[k].x, u[k].y * sg[k].y); d[1] = make_float2(u[k].z * sg[k].z, u[k].w * sg[k].w);
+        }
+    }
+    __syncthreads();
+    fftr_rows_fwd<LG>(buf, tw);
+    fftr_cols<false, LG>(buf, tw);
+    const float aw = a.ampw[ch], ab = a.ampb[ch], pw = a.phaw[ch], pb = a.phab[ch];
+    const float nn = (float)n * (float)n;
+    float s_aw = 0.f, s_ab = 0.f, s_pw = 0.f, s_pb = 0.f;
+    constexpr int EB = NIT > 9 ? 9 : NIT;     // saved amplitude / phase of the thread's bins in batches of nine
+#pragma unroll 1
+    for (int b = 0; b < NIT; b += EB) {
+        float ampv[EB], phav[EB];
+#pragma unroll
+        for (int k = 0; k < EB; ++k) {
+            const int it = (b + k) * NTH + (int)threadIdx.x, itc = it < NBIN ? it : 0;
+            int q, c;
+            fftr_bin(itc, n, lg, q, c);
+            const size_t o = ((size_t)plane * n + q) * (half + 1) + c;
+            ampv[k] = a.amp[o];
+            phav[k] = a.pha[o];
+        }
+#pragma unroll
+        for (int k = 0; k < EB; ++k) {
+            const int it = (b + k) * NTH + (int)threadIdx.x;
+            if (it < NBIN) {
+                int q, c;
+                fftr_bin(it, n, lg, q, c);
+                const float cf = (c == 0 || c == half) ? 1.0f : 2.0f;
+                buf[q * HP + c] = bin_edit_bwd(buf[q * HP + c], cf, nn, ampv[k], phav[k], aw, ab, pw, pb, s_aw, s_ab, s_pw, s_pb);
+            }
+        }
+    }
+    __syncthreads();
+    fftr_cols<true, LG>(buf, tw);
+    fftr_rows_inv<LG>(buf, tw);
+    const float sc = 1.0f / nn;
+    int tid_s = threadIdx.x;
+    asm volatile("" : "+v"(tid_s));      // (see k_fftmix_r)
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = (k * NTH + tid_s) * 4;
+        if (i >= n * n) break;
+        const float2* r = buf + (i >> lg) * HP + ((i & (n - 1)) >> 1);
+        const float2 r0 = r[0], r1 = r[1];
+        *reinterpret_cast<float4*>(a.dg + base + i) = make_float4(r0.x * sc, r0.y * sc, r1.x * sc, r1.y * sc);
+    }
+    // parameter gradient partials
+    float v[4] = {s_aw, s_ab, s_pw, s_pb};
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = NTH >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
+        if (lane == 0) red[wave * 4 + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float s = 0.f;
+        for (int w = 0; w < nw; ++w) s += red[w * 4 + threadIdx.x];
+        a.part[(size_t)plane * 4 + threadIdx.x] = s;
+    }
+}
+
 static int fft_bwd_col_groups(int h, int w) {
     if (fft_is_generic(h, w)) return fft_generic_col_groups(h, w);
     return h > 128 ? (h / 2 + 1 + FFT_COLS_PER_WG(h) - 1) / FFT_COLS_PER_WG(h) : 1;
@@ -974,6 +1345,29 @@ static int launch_fftmix_bwd_kernels(const FftBwdArgs& a, hipStream_t s) {
     int n = ph, lg = 0;
     while ((1 << lg) < n) ++lg;
     if (n > 128) return launch_fft_split(nullptr, &a, s);
+    if (!a.full) {
+        if (int rc = fft_const_twiddles()) return rc;
+        static DeviceOnce attr_r;
+        if (attr_r.need()) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_fftmix_bwd_r<7, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 512);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_fftmix_bwd_r<7, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 512);
+            if (e != hipSuccess) { lg_set_error("fftmix_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+            attr_r.done();
+        }
+        const size_t ldsr = ((size_t)n * FFT_HP(n) + n / 2) * sizeof(float2) + 64 * sizeof(float);
+        switch (lg) {
+            case 3: k_fftmix_bwd_r<3, fftr_threads(3)><<<a.planes, fftr_threads(3), ldsr, s>>>(a); break;
+            case 4: k_fftmix_bwd_r<4, fftr_threads(4)><<<a.planes, fftr_threads(4), ldsr, s>>>(a); break;
+            case 5: k_fftmix_bwd_r<5, fftr_threads(5)><<<a.planes, fftr_threads(5), ldsr, s>>>(a); break;
+            case 6: k_fftmix_bwd_r<6, fftr_threads(6)><<<a.planes, fftr_threads(6), ldsr, s>>>(a); break;
+            default:
+                if (a.planes <= lg_num_cus()) k_fftmix_bwd_r<7, 1024><<<a.planes, 1024, ldsr, s>>>(a);
+                else k_fftmix_bwd_r<7, 512><<<a.planes, 512, ldsr, s>>>(a);
+                break;
+        }
+        LG_CHECK_LAUNCH();
+        return 0;
+    }
     size_t lds = ((size_t)n * FFT_LD(n) + n / 2) * sizeof(float2) + 64 * sizeof(float);
     static DeviceOnce attr_once;
     if (attr_once.need()) {

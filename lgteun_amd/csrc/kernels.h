@@ -89,6 +89,7 @@ struct FftArgs {
     const float *ampw, *ampb, *phaw, *phab;  // [ch]
     int planes, ch, n;   // n: side of a square plane (legacy callers); h, w (when non-zero) override it
     int h, w;
+    int full = 0;      // 1: the complex-row in-LDS kernels (A/B variant LG_VAR_FFT_FULL); 0: the real-input kernels (k_fftmix_r / k_fftmix_bwd_r)
 };
 int launch_fftmix(const FftArgs& a, hipStream_t s);
 size_t fft_scratch_floats(int planes, int n);

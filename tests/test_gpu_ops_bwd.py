@@ -65,3 +65,35 @@ def test_lgt_backward_vs_oracle(C, H):
     for n in ('patch_embed.proj.0.weight', 'patch_embed.proj.1.weight', 'patch_embed.norm.weight', 'encoder_layers.0.1.1.weight',
               'decoder_layers.0.0.1.weight', 'decoder_layers.0.1.weight', 'decoder_layers.0.1.bias', 'tail.1.weight', 'tail.1.bias'):
         assert rel_l2(ops.grad_of(grads, pre + n).cpu(), P[pre + n].grad) < 2e-3, n
+
+
+@pytest.mark.parametrize('H,B', [(128, 2), (128, 33), (64, 3), (32, 2), (16, 2)])    # (8 x 8 planes: level 2 of the 32 x 32 whole-net goldens)
+def test_real_input_fft_mixer_agrees_with_the_complex_row_kernels(H, B, monkeypatch):
+    """k_fftmix_r / k_fftmix_bwd_r (round 5: rows as n/2-point transforms of packed reals, compact n x (n/2 + 1) plane, wave-uniform twiddles
+    from constant memory; B = 33 at 128 x 128 = 264 planes takes the two-workgroups-per-CU instance) against the complex-row kernels
+    (LG_FFT=full) on the same random features: the global mixer's forward output, and its backward (dx and the four parameter gradients)
+    from the same upstream gradient.  Two fp32 evaluations of the same transforms: agreement to a few 1e-7 of the output's norm; the
+    parameter gradients are sums of ~1e5 terms of both signs (tolerance relative to the sum of magnitudes would be 1e-7: 1e-4 of the value)."""
+    from gpu_helpers import Ops, make_module
+    rng = np.random.default_rng(100 + H + B)
+    feat = T(rng.standard_normal((B, H, H, 16)).astype(np.float32)).cuda()
+    dy = T(rng.standard_normal((B, 8, H, H)).astype(np.float32)).cuda()
+    res = {}
+    for kind in ('real', 'full'):
+        if kind == 'full':
+            monkeypatch.setenv('LG_FFT', 'full')          # read once per plan: a fresh module builds a fresh plan
+        else:
+            monkeypatch.delenv('LG_FFT', raising=False)
+        ops = Ops(make_module(4, 1), H, H)
+        y = ops.block(0, 0, 0, feat)
+        dx, grads = ops.block_bwd(0, 0, 0, feat, dy)
+        pre = 'prior_module.0.encoder_layers.0.0.blocks.0.0.fn.fn.global_mixer.'
+        pg = {k: ops.grad_of(grads, pre + k).double().cpu() for k in ('conv_amp.0.weight', 'conv_amp.0.bias', 'conv_pha.0.weight', 'conv_pha.0.bias')}
+        res[kind] = (y.double().cpu(), dx.double().cpu(), pg)
+    monkeypatch.delenv('LG_FFT', raising=False)
+    (y0, dx0, pg0), (y1, dx1, pg1) = res['real'], res['full']
+    assert float(y1.norm()) > 0 and float(dx1.norm()) > 0
+    assert float((y0 - y1).norm()) <= 2e-6 * float(y1.norm()), float((y0 - y1).norm() / y1.norm())
+    assert float((dx0 - dx1).norm()) <= 1e-5 * float(dx1.norm()), float((dx0 - dx1).norm() / dx1.norm())
+    for k in pg0:
+        assert float((pg0[k] - pg1[k]).norm()) <= 1e-4 * float(pg1[k].norm()) + 1e-9, (k, float((pg0[k] - pg1[k]).norm()), float(pg1[k].norm()))
