@@ -233,6 +233,8 @@ struct Ffn1BwdXArgs {
     float* slab;       // ffn1_bwd_x_slab_floats(e) floats (per-workgroup partial sums)
     float *d_w1, *d_b1, *d_w2, *d_b2, *d_ln2g, *d_ln2b;   // accumulated (+=) by the deferred reduce launch
     long P;            // multiple of 64
+    const float* scales = nullptr;   // the block's row of NetBufs::ffn_scales (k_ffn_prep.hip) + in [6] max |dh2| of this backward (k_ffn_dw_bwd_xs): f16-pair
+                                     // products (NP = 2) when set; null: bf16 triples
 };
 inline int ffn1_bwd_x_wgs(int e) { return e == 16 ? 512 : 256; }   // persistent grid: two workgroups per CU at e = 16 (55 KB of LDS), one at e = 32 (139 KB)
 size_t ffn1_bwd_x_slab_floats(int e);                               // floats of Ffn1BwdXArgs::slab
@@ -251,6 +253,7 @@ struct FfnDwBwdXArgs {
     float* slab;       // FFN_DW_BWD_X_WGS rows of FFN_DW_BWD_X_ROW floats (per-workgroup partial sums)
     float *d_dww, *d_dwb, *d_w3, *d_b3;   // accumulated (+=) by the deferred reduce launch
     int B, h, w;
+    float* dh2_max = nullptr;   // optional: max |dh2| of the launch is atomically max-ed into this word (float bits; zeroed by k_ffn_scales every forward)
 };
 #define FFN_DW_BWD_X_WGS 512      // e = 16: two resident workgroups per CU
 #define FFN_DW_BWD_X_DB 576

@@ -12,6 +12,7 @@ struct BwdBufs {
     float *dh2, *dh1, *y2, *do2, *dg, *dym, *cat, *y1, *dqkv, *dpos_slab;
     float *w3t[5], *w2t[5], *w1t[5], *wsp, *dt, *dskip, *v, *du, *fft_scratch;   // transposed FFN weights, one set per block of the LGT
     float* slab_arena;    // scratch of the deferred parameter-gradient reductions (ReduceQueue, bwd_kernels.h)
+    float* ffn_scales;    // NetBufs::ffn_scales of the forward this backward belongs to ([stage][5][8]); null: no f16-pair products in the backward
     size_t slab_cap;      // floats
     ReduceQueue rq;
     size_t bytes;
@@ -52,6 +53,7 @@ static void carve_bwd(const lg_plan* plan, int B, void* base, BwdBufs& bb) {
     if (ffn_dw_bwd_x_slab_floats(32) > sl) sl = ffn_dw_bwd_x_slab_floats(32);
     bb.slab_cap = 4 * sl;
     bb.slab_arena = cv.take(bb.slab_cap);
+    bb.ffn_scales = nullptr;
     bb.dt = cv.take(P0 * E); bb.dskip = cv.take(P0 * E); bb.v = cv.take(P1 * E); bb.du = cv.take(P1 * E);
     bb.bytes = cv.off;
 }
@@ -113,8 +115,12 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         if (!fk.slab) return -3;
         fk.d_dww = G + pl->blk(st, j, B_DWW); fk.d_dwb = G + pl->blk(st, j, B_DWB); fk.d_w3 = G + pl->blk(st, j, B_W3); fk.d_b3 = G + pl->blk(st, j, B_B3);
         fk.B = B; fk.h = fb.h; fk.w = fb.w; fk.hbf = hbf;
+        // f16-pair products in the pixelwise half (round 5): the forward's operand scales of this block + max |dh2|, which the spatial half leaves in word 6
+        float* fsc = (bb.ffn_scales && pl->ffn_f16x2(e) && !pl->ffn_bwd_bf16x3 && !hbf) ? bb.ffn_scales + ((size_t)st * 5 + j) * 8 : nullptr;
+        fk.dh2_max = fsc ? fsc + 6 : nullptr;
         RC(launch_ffn_dw_bwd_xs(e, fk, s));
         Ffn1BwdXArgs fx;
+        fx.scales = fsc;
         fx.dh2 = bb.dh2; fx.x = fb.xmid; fx.dy = dy; fx.dx = tmp;
         fx.w1 = P + pl->blk(st, j, B_W1); fx.b1 = P + pl->blk(st, j, B_B1); fx.w2t = bb.w2t[j]; fx.w1t = bb.w1t[j];
         fx.ln2g = P + pl->blk(st, j, B_LN2G); fx.ln2b = P + pl->blk(st, j, B_LN2B);
@@ -126,6 +132,7 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         return launch_ffn1_bwd_xs(e, fx, s);
     }
     const bool dwx32 = pl->ffn_dw_x32(e, fb.h, fb.w);
+    float* fsc2 = nullptr;
     if (dwx32) {
         // e = 32: the strip-walking spatial half (dh3 in an LDS ring -> dh2; depthwise gradients, dW3 / db3 in the same pass) on the saved
         // pre-activation h3; the pixelwise half below is round 2's k_ffn1_bwd_x32 + the 128 x 128 weight-gradient launch
@@ -135,6 +142,8 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         if (!fk.slab) return -3;
         fk.d_dww = G + pl->blk(st, j, B_DWW); fk.d_dwb = G + pl->blk(st, j, B_DWB); fk.d_w3 = G + pl->blk(st, j, B_W3); fk.d_b3 = G + pl->blk(st, j, B_B3);
         fk.B = B; fk.h = fb.h; fk.w = fb.w; fk.hbf = hbf;
+        fsc2 = (bb.ffn_scales && pl->ffn_f16x2(e) && !pl->ffn_bwd_bf16x3 && !hbf && pl->ffn1_bwd_x32(e)) ? bb.ffn_scales + ((size_t)st * 5 + j) * 8 : nullptr;
+        fk.dh2_max = fsc2 ? fsc2 + 6 : nullptr;
         RC(launch_ffn_dw_bwd_xs(e, fk, s));
     }
     if (!dwx32) {
@@ -151,6 +160,7 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         // one pass over dh2 re-computes h1 and yields dx, the LayerNorm gradients, dW1 / db1 and dW2 / db2 (e = 16: h1 was not saved; e = 32:
         // the saved gelu(h1) / gelu'(h1) are simply not read)
         Ffn1BwdXArgs fx;
+        fx.scales = fsc2;      // (set only when dh2 came from k_ffn_dw_bwd_xs, which leaves max |dh2| behind)
         fx.dh2 = bb.dh2; fx.x = fb.xmid; fx.dy = dy; fx.dx = tmp;
         fx.w1 = P + pl->blk(st, j, B_W1); fx.b1 = P + pl->blk(st, j, B_B1); fx.w2t = bb.w2t[j]; fx.w1t = bb.w1t[j];
         fx.ln2g = P + pl->blk(st, j, B_LN2G); fx.ln2b = P + pl->blk(st, j, B_LN2B);
@@ -281,6 +291,7 @@ int op_block_bwd(const lg_plan* pl, const float* P, float* G, int st, int j, int
     BwdBufs bb;
     carve_bwd(pl, B, bwd_ws, bb);
     bb.fft_scratch = nb.fft_scratch;
+    bb.ffn_scales = nb.ffn_scales;
     const BlockBufs& fb = nb.blk[j];
     if (which == 0) return fft_bwd_call(pl, P, G, st, j, fb, dy, dx, B, s, nb.fft_scratch, bb.slab_arena);   // no queue: summed at once
     ReduceQueueScope rqs(bb, s);
@@ -429,6 +440,7 @@ int op_lgt_bwd(const lg_plan* pl, const float* P, float* G, int st, NetBufs& nb,
     BwdBufs bb;
     carve_bwd(pl, B, bwd_ws, bb);
     bb.fft_scratch = nb.fft_scratch;
+    bb.ffn_scales = nb.ffn_scales;
     bb.dzA = dz;                       // lgt_bwd leaves the gradient wrt the LGT's input here
     ReduceQueueScope rqs(bb, s);
     const int rc = lgt_bwd(pl, P, G, st, nb, bb, dout, z, B, flags, seed, s);
@@ -443,6 +455,7 @@ int net_backward(const lg_plan* pl, const float* P, float* G, const float* ms, c
     BwdBufs bb;
     carve_bwd(pl, B, bwd_ws, bb);
     bb.fft_scratch = nb.fft_scratch;
+    bb.ffn_scales = nb.ffn_scales;
     ReduceQueueScope rqs(bb, s);
     if (flags & LG_FLAG_CHAINED) {
         // intended unfolding (every stage live): LGT_i then data step i, last stage first; each LGT reads its own activation set

@@ -123,15 +123,24 @@ __device__ __forceinline__ void mfma3_16(f32x4_t& acc, const s16x4_t (&a)[3], co
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(a[0], a[0]), b21, acc, 0, 0, 0);
 }
 // NP = 3: the six piece products (fp32-equivalent); NP = 1 (precision = 'bf16'): one product of round-to-nearest bf16 operands
+// NP = 2 (round 5): f16 pairs (split_bf16.h), three piece products; every operand arrives multiplied by a power of two (see the kernel)
 template <int NP>
 __device__ __forceinline__ void mfmaN_16(f32x4_t& acc, const s16x4_t (&a)[3], const s16x4_t (&b)[3]) {
     if (NP == 3) { if (LG_KB_PAIR) mfma3_16(acc, a, b); else mfma6_16(acc, a, b); }
-    else acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[0], acc, 0, 0, 0);
+    else if (NP == 2) {   // K = 16: two piece products share one 32-deep instruction: a_lo b_hi + a_hi b_lo | a_hi b_hi
+        const s16x4_t z = {0, 0, 0, 0};
+        acc = sb_mfma_h(cat8(a[1], a[0]), cat8(b[0], b[1]), acc);
+        acc = sb_mfma_h(cat8(a[0], z), cat8(b[0], z), acc);
+    } else acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[0], acc, 0, 0, 0);
 }
 template <int NP>
 __device__ __forceinline__ void mfmaN_32(f32x4_t& acc, const bf16x8_t (&a)[3], const bf16x8_t (&b)[3]) {
     if (NP == 3) mfma6_32(acc, a, b);
-    else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+    else if (NP == 2) {
+        acc = sb_mfma_h(a[1], b[0], acc);
+        acc = sb_mfma_h(a[0], b[1], acc);
+        acc = sb_mfma_h(a[0], b[0], acc);
+    } else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
 }
 template <int NP>
 __device__ __forceinline__ void split4(const float (&v)[4], s16x4_t (&p)[3]) {
@@ -144,22 +153,24 @@ __device__ __forceinline__ void split4(const float (&v)[4], s16x4_t (&p)[3]) {
 template <int NP>
 __device__ __forceinline__ void ld3_x4(const uint16_t* p, int piece, s16x4_t (&o)[3]) {
     o[0] = lds_x4(p);
-    if (NP == 3) { o[1] = lds_x4(p + piece); o[2] = lds_x4(p + 2 * piece); } else { o[1] = o[0]; o[2] = o[0]; }
+    if (NP == 3) { o[1] = lds_x4(p + piece); o[2] = lds_x4(p + 2 * piece); } else if (NP == 2) { o[1] = lds_x4(p + piece); o[2] = o[0]; } else { o[1] = o[0]; o[2] = o[0]; }
 }
 template <int NP>
 __device__ __forceinline__ void ld3_x8(const uint16_t* p, int piece, bf16x8_t (&o)[3]) {
     o[0] = lds_x8(p);
-    if (NP == 3) { o[1] = lds_x8(p + piece); o[2] = lds_x8(p + 2 * piece); } else { o[1] = o[0]; o[2] = o[0]; }
+    if (NP == 3) { o[1] = lds_x8(p + piece); o[2] = lds_x8(p + 2 * piece); } else if (NP == 2) { o[1] = lds_x8(p + piece); o[2] = o[0]; } else { o[1] = o[0]; o[2] = o[0]; }
 }
 template <int NP>
 __device__ __forceinline__ void ld3_tr(const uint16_t* p, int piece, s16x4_t (&o)[3]) {
     o[0] = lds_tr4(p);
-    if (NP == 3) { o[1] = lds_tr4(p + piece); o[2] = lds_tr4(p + 2 * piece); } else { o[1] = o[0]; o[2] = o[0]; }
+    if (NP == 3) { o[1] = lds_tr4(p + piece); o[2] = lds_tr4(p + 2 * piece); } else if (NP == 2) { o[1] = lds_tr4(p + piece); o[2] = o[0]; } else { o[1] = o[0]; o[2] = o[0]; }
 }
 template <int NP>
-__device__ __forceinline__ WFrag32 wfrag32(const float* W, int K, int kb) { return NP == 3 ? load_wfrag32(W, K, kb) : load_wfrag32_rne(W, K, kb); }
+__device__ __forceinline__ WFrag32 wfrag32(const float* W, int K, int kb, float ws) { return NP == 3 ? load_wfrag32(W, K, kb) : (NP == 2 ? load_wfrag32_h2(W, K, kb, ws) : load_wfrag32_rne(W, K, kb)); }
 template <int NP>
-__device__ __forceinline__ WFrag16 wfrag16(const float* W, int K, int k0) { return NP == 3 ? load_wfrag16(W, K, k0) : load_wfrag16_rne(W, K, k0); }
+__device__ __forceinline__ WFrag16 wfrag16(const float* W, int K, int k0, float ws) { return NP == 3 ? load_wfrag16(W, K, k0) : (NP == 2 ? load_wfrag16_h2(W, K, k0, ws) : load_wfrag16_rne(W, K, k0)); }
+// the power of two s with bound * s in [2^14, 2^15)
+__device__ __forceinline__ float kb_pow2_below(float bound) { return __builtin_amdgcn_ldexpf(1.0f, 15 - __builtin_amdgcn_frexp_expf(bound)); }
 
 template <int E, int NP>
 __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn1_bwd_xs(Ffn1BwdXArgs a, long ntiles) {
@@ -177,17 +188,32 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
 
     // ---- weights of this wave's hidden-channel block, split once, register-resident
     // W1 rows [16 w, 16 w + 16) (B of h1 = LN(x) W1^T): one 16-deep block at e = 16, one 32-deep block at e = 32
+    // ---- NP = 2: power-of-two operand scales.  LN(x), gelu(h1) and the weights carry the forward's static scales (k_ffn_prep.hip: bounds that
+    // hold for every input).  The gradient operands have no static bound: dh2 is scaled from the launch-wide max |dh2| its producer
+    // (k_ffn_dw_bwd_xs) left in scales[6], and dh1 = (dh2 W2) gelu'(h1) from the bound that follows from it, |dh1| <= 1.13 N1 max|dh2| max|W2|
+    // (max |W2| < 2^15 / s_w2).  One scale per operand and LAUNCH, so every accumulator -- the weight gradients, which run across all the
+    // tiles of the workgroup, included -- is a fixed power of two times its true value, undone where it is written.
+    float S_x = 1.f, S_a1 = 1.f, S_w1 = 1.f, S_w2 = 1.f, S_d2 = 1.f, S_d1 = 1.f;
+    if constexpr (NP == 2) {
+        S_x = a.scales[0]; S_a1 = a.scales[1]; S_w1 = a.scales[3]; S_w2 = a.scales[4];
+        const float gmax = fmaxf(a.scales[6], 8.6736174e-19f);       // (2^-60: an all-zero gradient stays finite)
+        S_d2 = kb_pow2_below(gmax);
+        S_d1 = kb_pow2_below(1.13f * (float)N1 * gmax * (32768.0f / S_w2));
+    }
+    const float inv_h1 = 1.0f / (S_x * S_w1);                  // behind h1's accumulator
+    const float c_d1 = S_d1 / (S_d2 * S_w2);                   // dh1 operand = (dh2 W2 accumulator) gelu'(h1) c_d1
+    const float inv_o = 1.0f / (S_w1 * S_d1);                  // behind W1^T dh1
     WFrag16 w1f16;
     WFrag32 w1f32;
-    if constexpr (E == 16) w1f16 = wfrag16<NP>(a.w1 + (size_t)(wave * 16) * E, E, 0);
-    else w1f32 = wfrag32<NP>(a.w1 + (size_t)(wave * 16) * E, E, 0);
+    if constexpr (E == 16) w1f16 = wfrag16<NP>(a.w1 + (size_t)(wave * 16) * E, E, 0, S_w1);
+    else w1f32 = wfrag32<NP>(a.w1 + (size_t)(wave * 16) * E, E, 0, S_w1);
     WFrag32 w2f[KB2];                  // W2^T rows [16 w, 16 w + 16) (B of da1 = dh2 W2)
 #pragma unroll
-    for (int kb = 0; kb < KB2; ++kb) w2f[kb] = wfrag32<NP>(a.w2t + (size_t)(wave * 16) * N1, N1, kb);
+    for (int kb = 0; kb < KB2; ++kb) w2f[kb] = wfrag32<NP>(a.w2t + (size_t)(wave * 16) * N1, N1, kb, S_w2);
     WFrag16 w1tf[NE];                  // W1^T [16 rb + r][16 w + 4 g ..] (A of this wave's K = 16 slice of W1^T dh1)
 #pragma unroll
-    for (int rb = 0; rb < NE; ++rb) w1tf[rb] = wfrag16<NP>(a.w1t + (size_t)(rb * 16) * N1, N1, wave * 16);
-    const float b1s = a.b1[wave * 16 + r];
+    for (int rb = 0; rb < NE; ++rb) w1tf[rb] = wfrag16<NP>(a.w1t + (size_t)(rb * 16) * N1, N1, wave * 16, S_w1);
+    const float b1s = a.b1[wave * 16 + r] * (NP == 2 ? S_x * S_w1 : 1.0f);
     // LayerNorm role: thread = (pixel t / (e/4), channel quad t % (e/4))
     const int lpx = threadIdx.x / LPP, lq = threadIdx.x % LPP;
     const float4 lng = *reinterpret_cast<const float4*>(a.ln2g + 4 * lq), lnb = *reinterpret_cast<const float4*>(a.ln2b + 4 * lq);
@@ -230,12 +256,12 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
             if constexpr (BF) {
                 *reinterpret_cast<u32x2_t*>(dst) = __builtin_bit_cast(u32x2_t, d2n[it]);   // the stored bf16 values ARE the operand
             } else {
-                const float v[4] = {d.x, d.y, d.z, d.w};
+                const float v[4] = {d.x * S_d2, d.y * S_d2, d.z * S_d2, d.w * S_d2};     // (S_d2 = 1 at NP = 3)
                 u32x2_t q1, q2, q3;
-                split3_x4(v, q1, q2, q3);
+                split_x4<NP>(v, q1, q2, q3);
                 *reinterpret_cast<u32x2_t*>(dst) = q1;
                 *reinterpret_cast<u32x2_t*>(dst + D2_PIECE) = q2;
-                *reinterpret_cast<u32x2_t*>(dst + 2 * D2_PIECE) = q3;
+                if (NP == 3) *reinterpret_cast<u32x2_t*>(dst + 2 * D2_PIECE) = q3;
             }
         }
         const float4 xv = xnx, dyv = dyn;
@@ -244,15 +270,13 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
         const float rstd = __builtin_amdgcn_rsqf(lane_group_sum<LPP>((c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3)) * (1.0f / E) + LG_EPS);
         const float xh[4] = {c0 * rstd, c1 * rstd, c2 * rstd, c3 * rstd};
         {
-            const float yv[4] = {xh[0] * lng.x + lnb.x, xh[1] * lng.y + lnb.y, xh[2] * lng.z + lnb.z, xh[3] * lng.w + lnb.w};
+            const float yv[4] = {(xh[0] * lng.x + lnb.x) * S_x, (xh[1] * lng.y + lnb.y) * S_x, (xh[2] * lng.z + lnb.z) * S_x, (xh[3] * lng.w + lnb.w) * S_x};
             u32x2_t q1, q2, q3;
             split_x4<NP>(yv, q1, q2, q3);
             uint16_t* dst = XN + lpx * E + 4 * lq;
             *reinterpret_cast<u32x2_t*>(dst) = q1;
-            if (NP == 3) {
-                *reinterpret_cast<u32x2_t*>(dst + XN_PIECE) = q2;
-                *reinterpret_cast<u32x2_t*>(dst + 2 * XN_PIECE) = q3;
-            }
+            if (NP >= 2) *reinterpret_cast<u32x2_t*>(dst + XN_PIECE) = q2;
+            if (NP == 3) *reinterpret_cast<u32x2_t*>(dst + 2 * XN_PIECE) = q3;
         }
         if (tile + (long)gridDim.x < ntiles) issue(tile + gridDim.x);   // next tile's operands: in flight during the GEMM phase
         STAMP(1);
@@ -312,8 +336,10 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
             KB_FENCE();
             // ---- gelu(h1), gelu'(h1) with one exponential for both; dh1 = da1 * gelu'(h1); pieces
             lg_v2f a01, a23, g01, g23;
+            if (NP == 2) h1 *= inv_h1;
             gelu2_both_t<NP == 1>((lg_v2f){h1[0], h1[1]}, a01, g01);
             gelu2_both_t<NP == 1>((lg_v2f){h1[2], h1[3]}, a23, g23);
+            if (NP == 2) { a01 *= S_a1; a23 *= S_a1; g01 *= c_d1; g23 *= c_d1; }
             const float a1v[4] = {a01.x, a01.y, a23.x, a23.y};
             const float d1v[4] = {da[0] * g01.x, da[1] * g01.y, da[2] * g23.x, da[3] * g23.y};
             bs1 += (d1v[0] + d1v[1]) + (d1v[2] + d1v[3]);
@@ -344,10 +370,8 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
             {
                 uint16_t* dst = D1T + r * 16 + 4 * g;
                 *reinterpret_cast<u32x2_t*>(dst) = __builtin_bit_cast(u32x2_t, d1p[0]);
-                if (NP == 3) {
-                    *reinterpret_cast<u32x2_t*>(dst + D1T_PIECE) = __builtin_bit_cast(u32x2_t, d1p[1]);
-                    *reinterpret_cast<u32x2_t*>(dst + 2 * D1T_PIECE) = __builtin_bit_cast(u32x2_t, d1p[2]);
-                }
+                if (NP >= 2) *reinterpret_cast<u32x2_t*>(dst + D1T_PIECE) = __builtin_bit_cast(u32x2_t, d1p[1]);
+                if (NP == 3) *reinterpret_cast<u32x2_t*>(dst + 2 * D1T_PIECE) = __builtin_bit_cast(u32x2_t, d1p[2]);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 s16x4_t dtp[3];
@@ -374,6 +398,7 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
                 const float4 s0 = *reinterpret_cast<const float4*>(rp + (size_t)w2 * NPX * E), s1 = *reinterpret_cast<const float4*>(rp + (size_t)(w2 + 1) * NPX * E);
                 dl[0] += s0.x + s1.x; dl[1] += s0.y + s1.y; dl[2] += s0.z + s1.z; dl[3] += s0.w + s1.w;
             }
+            if (NP == 2) { dl[0] *= inv_o; dl[1] *= inv_o; dl[2] *= inv_o; dl[3] *= inv_o; }
             pg.x += dl[0] * xh[0]; pg.y += dl[1] * xh[1]; pg.z += dl[2] * xh[2]; pg.w += dl[3] * xh[3];
             pb.x += dl[0]; pb.y += dl[1]; pb.z += dl[2]; pb.w += dl[3];
             const float dxh[4] = {dl[0] * lng.x, dl[1] * lng.y, dl[2] * lng.z, dl[3] * lng.w};
@@ -390,16 +415,17 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
 
     // ---- this workgroup's partial sums -> its slab row [dW2 N1 x N1 | db2 N1 | dW1 N1 x e | db1 N1 | d gamma e | d beta e]
     float* row = a.slab + (size_t)blockIdx.x * C::ROW;
+    const float inv_w2 = 1.0f / (S_d2 * S_a1), inv_w1 = 1.0f / (S_d1 * S_x);     // (1 at NP = 1, 3)
 #pragma unroll
     for (int nb = 0; nb < NW; ++nb)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) row[(16 * nb + 4 * g + v) * N1 + 16 * wave + r] = acc2[nb][v];
+        for (int v = 0; v < 4; ++v) row[(16 * nb + 4 * g + v) * N1 + 16 * wave + r] = acc2[nb][v] * inv_w2;
 #pragma unroll
     for (int cb = 0; cb < NE; ++cb)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) row[C::R_W1 + (16 * wave + 4 * g + v) * E + 16 * cb + r] = acc1[cb][v];
+        for (int v = 0; v < 4; ++v) row[C::R_W1 + (16 * wave + 4 * g + v) * E + 16 * cb + r] = acc1[cb][v] * inv_w1;
     {
-        float s = bs1;
+        float s = bs1 * (1.0f / S_d1);
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
         if (g == 0) row[C::R_B1 + 16 * wave + r] = s;
@@ -431,6 +457,7 @@ int launch_t(const Ffn1BwdXArgs& a, hipStream_t s) {
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_ffn1_bwd_xs<E, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1_bwd_xs<E, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn1_bwd_xs<E, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
         if (e != hipSuccess) { lg_set_error("ffn1_bwd_xs: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
@@ -438,6 +465,7 @@ int launch_t(const Ffn1BwdXArgs& a, hipStream_t s) {
     const int cap = ffn1_bwd_x_wgs(E);
     const int grid = (int)(ntiles < cap ? ntiles : cap);
     if (a.hbf) k_ffn1_bwd_xs<E, 1><<<grid, C::NT, C::LDS_BYTES, s>>>(a, ntiles);      // precision = 'bf16': plain bf16 operands, dh2 stored as bf16
+    else if (a.scales) k_ffn1_bwd_xs<E, 2><<<grid, C::NT, C::LDS_BYTES, s>>>(a, ntiles);   // f16 pairs, scaled operands
     else k_ffn1_bwd_xs<E, 3><<<grid, C::NT, C::LDS_BYTES, s>>>(a, ntiles);
     LG_CHECK_LAUNCH();
     // the slab rows, summed in a fixed order by the deferred reduce launch

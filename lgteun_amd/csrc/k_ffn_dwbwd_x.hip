@@ -138,6 +138,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void k_
     for (int mt = 0; mt < NM; ++mt) acc3[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     float4 sb3 = make_float4(0.f, 0.f, 0.f, 0.f);     // db3[4 lq ..], this thread's own pixels
 
+    float dmx = 0.f;     // max |dh2| of this thread's stores (a.dh2_max: the operand scale of k_ffn1_bwd_xs's f16-pair products)
 #pragma unroll 1
     for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
     int t = strip;
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void k_
                         if (k == 4) { pw01[9] += g01; pw23[9] += g23; }
                     }
                 HS<BF>::st4(a.dh2, ((b * h + y) * (long)w + x) * N1 + hoff + 4 * q, make_float4(acc01.x, acc01.y, acc23.x, acc23.y));
+                if (NP != 1) dmx = fmaxf(fmaxf(dmx, fmaxf(fabsf(acc01.x), fabsf(acc01.y))), fmaxf(fabsf(acc23.x), fabsf(acc23.y)));
                 if (LG_KA_ITEMFENCE && ((it + 1) % LG_KA_ITEMFENCE) == 0) __builtin_amdgcn_sched_barrier(0);   // one item at a time: interleaved items need more registers than there are
             };
             item(0, h2a); item(1, h2b); item(2, h2c); item(3, h2d);
@@ -390,6 +392,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void k_
     __syncthreads();   // the last step's P2 readers of the ring are done before the next strip's prologue writes it
     }   // strips of this workgroup
 
+    if (NP != 1 && a.dh2_max) {     // one atomic per wave (non-negative floats order as their bit patterns)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmx = fmaxf(dmx, __shfl_xor(dmx, off));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(a.dh2_max), __float_as_uint(dmx));
+    }
     // ---- this workgroup's partial sums -> its slab row [d dww 64 x 9 | d dwb 64 | dW3 E x 64 | db3 E] of its channel half
     float* row = a.slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * C::ROW;
 #pragma unroll
