@@ -335,3 +335,50 @@ def test_f16_pair_ffn_holds_fp32_accuracy_at_extreme_operand_scales(C, case, mon
         print(f'C={C} {case} block {blk} (e={e}): |ffn| / |x| = {den / float(x.double().norm()):.2e}   f16 pairs {e2:.3e}   bf16 x 3 {e3:.3e}')
         assert e2 < 2e-6 and e2 <= 2.0 * e3 + 1e-7, (case, blk, e2, e3)
     monkeypatch.delenv('LG_FFN_SPLIT', raising=False)
+
+
+@pytest.mark.parametrize('case', ['as_initialised', 'w2_huge_w1_tiny', 'w1_huge_w2_tiny'])
+@pytest.mark.parametrize('gscale', [1e-12, 1.0, 1e8])
+def test_f16_pair_ffn_backward_holds_fp32_accuracy_at_extreme_scales(case, gscale, monkeypatch):
+    """The pixelwise half of the FFN backward (k_ffn1_bwd_xs, round 5) multiplies f16 PAIRS: LN(x), gelu(h1) and the weights under the
+    forward's static power-of-two scales, the gradient operands dh2 / dh1 under scales taken from the launch-wide max |dh2| that the
+    spatial half leaves behind (and the bound on dh1 that follows from it).  The FFN half-block of both xs widths (e = 16, 32) against
+    fp64 autograd over the oracle, with upstream gradients of 1e-12, 1 and 1e8 times a unit normal and weights pushed out of f16's range
+    in opposite directions.  An f16 pair represents a value to 2^-24 RELATIVE (a bf16 triple holds all 24 bits exactly), and a sum over
+    pixels whose terms cancel amplifies that: profiles/r05_ffn_bwd_err.txt -- dx 1.2e-7 (bf16 x 3: 2.7e-8), dW1 and the LayerNorm pair
+    4 - 6e-6 (3e-7 - 3e-6; the same at 2 048 and at 65 536 pixels: the operand errors are independent), everything else equal.  That is the
+    level of the reference's own fp32 gradients against fp64 (7e-6 .. 2.7e-4 over the gradient goldens, manifest rel_fp32_vs_fp64).  Gate:
+    within 3 x of the bf16-triple build's error + 1e-5 of the tensor's norm, at every scale."""
+    from gpu_helpers import Ops, make_module
+    from test_gpu_backward import _oracle_block
+    mult = {'as_initialised': {},
+            'w2_huge_w1_tiny': {'net.0.weight': 1e-4, 'net.0.bias': 1e-4, 'net.2.point_conv.weight': 1e4},
+            'w1_huge_w2_tiny': {'net.0.weight': 1e3, 'net.0.bias': 1e3, 'net.2.point_conv.weight': 1e-3, 'net.4.weight': 1e-3}}[case]
+    rng = np.random.default_rng(23)
+    for blk, e, n in ((0, 16, 32), (2, 32, 16)):
+        pre = 'prior_module.0.' + ('encoder_layers.0.0.blocks.0.' if blk == 0 else 'bottleneck.blocks.0.') + '1.fn.'
+        x = T((rng.standard_normal((2, n, n, e)) * 1.5 + 0.3).astype(np.float32))
+        dy = T((rng.standard_normal((2, n, n, e)) * gscale).astype(np.float32))
+        got = {}
+        for split in ('f16x2', 'bf16x3'):
+            monkeypatch.setenv('LG_FFN_BWD_SPLIT', split)
+            net = make_module(4, 1)
+            sd = net.state_dict()
+            for k, f in mult.items():
+                key = pre + (k if k.startswith('norm') else 'fn.' + k)
+                sd[key] = sd[key] * f
+            net.load_state_dict(sd)
+            ops = Ops(net, 32, 32)
+            dx, grads = ops.block_bwd(0, blk, 2, x.cuda(), dy.cuda())
+            names = [nm for nm in ops.eng.names if nm.startswith(pre)]
+            got[split] = {'dx': dx.double().cpu(), **{nm: ops.grad_of(grads, nm).double().cpu() for nm in names}}
+        P64 = {k: v.detach().cpu().double().requires_grad_(True) for k, v in net.state_dict().items()}
+        want_dx, want_g = _oracle_block(P64, 4, blk, 2, x.double(), dy.double())
+        want = {'dx': want_dx.detach(), **{k: v for k, v in want_g.items() if k.startswith(pre)}}
+        assert len(want) == 11 and set(want) == set(got['f16x2'])
+        for k, ref in want.items():
+            assert torch.isfinite(got['f16x2'][k]).all(), (case, gscale, blk, k)
+            rn = float(ref.norm())
+            e2, e3 = (float((got[sp][k].reshape(ref.shape) - ref).norm()) for sp in ('f16x2', 'bf16x3'))
+            assert e2 <= 3.0 * e3 + 1e-5 * rn + 1e-30, (case, gscale, blk, k, e2 / max(rn, 1e-300), e3 / max(rn, 1e-300))
+    monkeypatch.delenv('LG_FFN_BWD_SPLIT', raising=False)
