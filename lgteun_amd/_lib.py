@@ -35,6 +35,7 @@ LG_VAR_ATTN_FWD_VALU = 1 << 8
 LG_VAR_FFN_BF16X3 = 1 << 9
 LG_VAR_FFT_FULL = 1 << 10
 LG_VAR_FFN_BWD_BF16X3 = 1 << 11
+LG_VAR_ATTN_BWD_CORE_M = 1 << 12
 LG_ABI_VERSION = 2   # include/lgteun_hip.h: checked against lg_abi_version() when the library is loaded
 
 
@@ -60,6 +61,8 @@ def variant_from_env(env=None):
         v |= LG_VAR_FFT_FULL
     if env.get('LG_FFN_BWD_SPLIT', '') == 'bf16x3':
         v |= LG_VAR_FFN_BWD_BF16X3
+    if env.get('LG_ATTN_BWD_CORE', '') == 'm':
+        v |= LG_VAR_ATTN_BWD_CORE_M
     return v
 
 

@@ -144,6 +144,7 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
         p->attn_fwd_valu = (v & LG_VAR_ATTN_FWD_VALU) ? 1 : 0;
         p->ffn_bf16x3 = (v & LG_VAR_FFN_BF16X3) ? 1 : 0;
         p->fft_full = (v & LG_VAR_FFT_FULL) ? 1 : 0;
+        p->attn_bwd_core_m = (v & LG_VAR_ATTN_BWD_CORE_M) ? 1 : 0;
         p->ffn_bwd_bf16x3 = (v & LG_VAR_FFN_BWD_BF16X3) ? 1 : 0;
     }
     p->off = (int64_t*)malloc(sizeof(int64_t) * n_offsets);

@@ -46,6 +46,7 @@ struct lg_plan {
     // precision = 'bf16' (plain bf16 MFMA, bf16 storage of the saved tensors) knows modes 2 and 5 only (3 falls back to 5)
     int attn_bwd_old; // A/B switch (lg_config.variant LG_VAR_ATTN_BWD_R3; Python side: LG_ATTN_BWD=r3): 1 = round 3's k_attn_bwd_core + k_attn_bwd_epi + k_wgrad_t at e = 16 instead of k_attn_bwd_f
     int ffn_bwd_bf16x3; // A/B switch (lg_config.variant LG_VAR_FFN_BWD_BF16X3; Python side: LG_FFN_BWD_SPLIT=bf16x3): the pixelwise half of the FFN backward on three bf16 pieces / six products (rounds 3 - 4) instead of f16 pairs
+    int attn_bwd_core_m; // A/B switch (lg_config.variant LG_VAR_ATTN_BWD_CORE_M; Python side: LG_ATTN_BWD_CORE=m): the matrix-pipe k_attn_bwd_core_m at e = 32 instead of the vector-pipe k_attn_bwd_core
     int fft_full;      // A/B switch (lg_config.variant LG_VAR_FFT_FULL; Python side: LG_FFT=full): complex-row in-LDS FFT mixer kernels instead of the real-input ones
     int ffn_bf16x3;    // A/B switch (lg_config.variant LG_VAR_FFN_BF16X3; Python side: LG_FFN_SPLIT=bf16x3): the fused FFN forward's GEMMs as three bf16 pieces / six
                        // products (round 2) instead of two f16 pieces / three products with proven power-of-two operand scales (round 5, k_ffn_prep.hip)

@@ -585,8 +585,13 @@ static int launch_attn_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
         attr_once.done();
     }
     int grid = grid_t<HC, NW>(a.B, a.h, a.w);
-    k_attn_bwd_core<HC, NW><<<dim3(grid, 2), NW * 64, lds, s>>>(a, nwin, ngroups);
-    LG_CHECK_LAUNCH();
+    if (HC == 16 && a.core_m) {      // e = 32, A/B: the matrix-pipe core (k_attn_bwd_m.hip; same arguments, outputs and launch shape)
+        int rc = launch_attn_bwd_core_m(2 * HC, a, grid, nwin, ngroups, s);
+        if (rc) return rc;
+    } else {
+        k_attn_bwd_core<HC, NW><<<dim3(grid, 2), NW * 64, lds, s>>>(a, nwin, ngroups);
+        LG_CHECK_LAUNCH();
+    }
     const long total = (long)a.B * a.h * a.w;
     if (!a.part) { lg_set_error("attn_bwd: partial-sum scratch missing"); return -2; }
     constexpr int E = 2 * HC;

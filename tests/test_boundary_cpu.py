@@ -113,10 +113,11 @@ def test_variant_word_from_the_diagnostic_environment_variables():
     assert _lib.variant_from_env({'LG_FFN_SPLIT': 'bf16x3'}) == _lib.LG_VAR_FFN_BF16X3
     assert _lib.variant_from_env({'LG_FFT': 'full'}) == _lib.LG_VAR_FFT_FULL
     assert _lib.variant_from_env({'LG_FFN_BWD_SPLIT': 'bf16x3'}) == _lib.LG_VAR_FFN_BWD_BF16X3
+    assert _lib.variant_from_env({'LG_ATTN_BWD_CORE': 'm'}) == _lib.LG_VAR_ATTN_BWD_CORE_M
     hdr = open(os.path.join(ROOT, 'include', 'lgteun_hip.h')).read()
     for name in ('LG_VAR_FFN_STRIP', 'LG_VAR_FFN_TILE', 'LG_VAR_FFN_XP'):
         assert int(re.search(rf'#define {name} (\d+)u', hdr).group(1)) == getattr(_lib, name)
-    for name in ('LG_VAR_FFN_SAVE3', 'LG_VAR_FFN_SAVE5', 'LG_VAR_FFN_BWD32_PAIR', 'LG_VAR_FFN_DWBWD_TILE', 'LG_VAR_ATTN_BWD_R3', 'LG_VAR_DSTEP_TILES', 'LG_VAR_ATTN_FWD_VALU', 'LG_VAR_FFN_BF16X3', 'LG_VAR_FFT_FULL', 'LG_VAR_FFN_BWD_BF16X3'):
+    for name in ('LG_VAR_FFN_SAVE3', 'LG_VAR_FFN_SAVE5', 'LG_VAR_FFN_BWD32_PAIR', 'LG_VAR_FFN_DWBWD_TILE', 'LG_VAR_ATTN_BWD_R3', 'LG_VAR_DSTEP_TILES', 'LG_VAR_ATTN_FWD_VALU', 'LG_VAR_FFN_BF16X3', 'LG_VAR_FFT_FULL', 'LG_VAR_FFN_BWD_BF16X3', 'LG_VAR_ATTN_BWD_CORE_M'):
         a, b = re.search(rf'#define {name} \((\d+)u << (\d+)\)', hdr).groups()
         assert int(a) << int(b) == getattr(_lib, name), name
 

@@ -444,3 +444,36 @@ def test_mixer_backward_kernel_at_awkward_shapes(B, h, w):
         ref = g.numpy()
         err = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
         assert err < (2e-3 if 'global_mixer' in k else 1e-4), (k, err)
+
+
+@pytest.mark.parametrize('C', [4, 8])
+def test_matrix_pipe_attention_backward_core_agrees_with_the_vector_pipe_core(C, monkeypatch):
+    """k_attn_bwd_core_m (round 5, LG_ATTN_BWD_CORE=m: the e = 32 local-mixer backward core on the matrix pipe -- LayerNorm / to_qkv / proj^T,
+    S^T / dP^T and S / dP as f16-pair MFMAs in two orientations, P and dS from the accumulator registers into the O, dQ, dV, dK products,
+    the pos_emb gradient in 64 accumulator registers; an A/B variant: correct, not faster than the vector-pipe core yet)
+    against the default k_attn_bwd_core on a whole train step: C = 4 has its e = 32 block at level 1
+    (8 x 8 planes of a 16 x 16 PAN: one window per sample), C = 8 at level 0 -- every live gradient tensor to rounding (2e-5 of its norm:
+    two fp32-equivalent evaluations; pos_emb sums over all windows)"""
+    from gpu_helpers import make_module
+    from lgteun_amd import FusedAdam
+    ms, pan, gt = (T(a).cuda() for a in dw.make_inputs(3, C, 32, 48, seed=21, kind='smooth'))
+
+    def grads():
+        net = make_module(C, 2)
+        opt = FusedAdam(net.parameters(), lr=0.0)
+        opt.dropout = False
+        eng = net.engine()
+        eng.train_step(ms, pan, gt, opt)
+        return eng.gflat.clone(), eng
+    monkeypatch.delenv('LG_ATTN_BWD_CORE', raising=False)
+    g0, eng = grads()
+    monkeypatch.setenv('LG_ATTN_BWD_CORE', 'm')                      # read once per plan: a fresh module builds a fresh plan
+    g1, _ = grads()
+    monkeypatch.delenv('LG_ATTN_BWD_CORE', raising=False)
+    assert float(g0.abs().max()) > 0
+    for i in eng.live_idx:
+        o, n = eng.offsets[i], eng.params[i].numel()
+        a, b = g0[o:o + n].double(), g1[o:o + n].double()
+        assert torch.isfinite(b).all(), eng.names[i]
+        assert float((a - b).norm()) <= 2e-5 * float(a.norm()) + 1e-12, (eng.names[i], float((a - b).norm()), float(a.norm()))
+
