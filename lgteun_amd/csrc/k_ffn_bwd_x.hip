@@ -179,6 +179,11 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
     constexpr int KB2 = N1 / 32;       // 32-deep K blocks of dh2 W2
     constexpr int NE = E / 16;         // 16-wide blocks of the e-channel axis (columns of dW1, rows of W1^T dh1)
     constexpr bool BF = (NP == 1);     // plain-bf16 mode: dh2 is stored as bf16 (hstore.h) and is its own (single) piece
+    // NP = 2: f16 pairs for the W2 products only (da = dh2 W2, K = 4 e: the bulk; dW2 = dh2^T gelu(h1), whose terms do not cancel).  LN(x), dh1, W1
+    // and W1^T stay bf16 TRIPLES (NPE = 3): an f16 pair holds a value to 2^-24 relative, a triple all 24 bits, and the sums over pixels that dh1 and
+    // LN(x) enter -- dW1, and through W1^T dh1 the LayerNorm gradients -- cancel to ~1 % of their terms: with pairs everywhere they came out at
+    // 4e-6 .. 1.5e-5 of their norm against fp64 (triples: 5e-7; profiles/r05_ffn_bwd_err.txt)
+    constexpr int NPE = NP == 2 ? 3 : NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint16_t* D2 = reinterpret_cast<uint16_t*>(smem_raw);                    // [3][NPX][LDP]   bf16 pieces of dh2
     uint16_t* XN = reinterpret_cast<uint16_t*>(smem_raw + C::OFF_XN);        // [3][NPX][E]     bf16 pieces of LN(x)
@@ -188,32 +193,27 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
 
     // ---- weights of this wave's hidden-channel block, split once, register-resident
     // W1 rows [16 w, 16 w + 16) (B of h1 = LN(x) W1^T): one 16-deep block at e = 16, one 32-deep block at e = 32
-    // ---- NP = 2: power-of-two operand scales.  LN(x), gelu(h1) and the weights carry the forward's static scales (k_ffn_prep.hip: bounds that
-    // hold for every input).  The gradient operands have no static bound: dh2 is scaled from the launch-wide max |dh2| its producer
-    // (k_ffn_dw_bwd_xs) left in scales[6], and dh1 = (dh2 W2) gelu'(h1) from the bound that follows from it, |dh1| <= 1.13 N1 max|dh2| max|W2|
-    // (max |W2| < 2^15 / s_w2).  One scale per operand and LAUNCH, so every accumulator -- the weight gradients, which run across all the
-    // tiles of the workgroup, included -- is a fixed power of two times its true value, undone where it is written.
-    float S_x = 1.f, S_a1 = 1.f, S_w1 = 1.f, S_w2 = 1.f, S_d2 = 1.f, S_d1 = 1.f;
+    // ---- NP = 2: power-of-two scales of the f16-pair operands.  gelu(h1) and W2 carry the forward's static scales (k_ffn_prep.hip: bounds that hold
+    // for every input); dh2 has no static bound: it is scaled from the launch-wide max |dh2| its producer (k_ffn_dw_bwd_xs) left in scales[6].
+    // One scale per operand and LAUNCH, so the dW2 accumulators -- which run across all the tiles of the workgroup -- are a fixed power of two
+    // times their true value, undone where they are written.
+    float S_a1 = 1.f, S_w2 = 1.f, S_d2 = 1.f;
     if constexpr (NP == 2) {
-        S_x = a.scales[0]; S_a1 = a.scales[1]; S_w1 = a.scales[3]; S_w2 = a.scales[4];
-        const float gmax = fmaxf(a.scales[6], 8.6736174e-19f);       // (2^-60: an all-zero gradient stays finite)
-        S_d2 = kb_pow2_below(gmax);
-        S_d1 = kb_pow2_below(1.13f * (float)N1 * gmax * (32768.0f / S_w2));
+        S_a1 = a.scales[1]; S_w2 = a.scales[4];
+        S_d2 = kb_pow2_below(fmaxf(a.scales[6], 8.6736174e-19f));       // (2^-60: an all-zero gradient stays finite)
     }
-    const float inv_h1 = 1.0f / (S_x * S_w1);                  // behind h1's accumulator
-    const float c_d1 = S_d1 / (S_d2 * S_w2);                   // dh1 operand = (dh2 W2 accumulator) gelu'(h1) c_d1
-    const float inv_o = 1.0f / (S_w1 * S_d1);                  // behind W1^T dh1
+    const float c_d1 = 1.0f / (S_d2 * S_w2);                   // behind the dh2 W2 accumulator
     WFrag16 w1f16;
     WFrag32 w1f32;
-    if constexpr (E == 16) w1f16 = wfrag16<NP>(a.w1 + (size_t)(wave * 16) * E, E, 0, S_w1);
-    else w1f32 = wfrag32<NP>(a.w1 + (size_t)(wave * 16) * E, E, 0, S_w1);
+    if constexpr (E == 16) w1f16 = wfrag16<NPE>(a.w1 + (size_t)(wave * 16) * E, E, 0, 1.0f);
+    else w1f32 = wfrag32<NPE>(a.w1 + (size_t)(wave * 16) * E, E, 0, 1.0f);
     WFrag32 w2f[KB2];                  // W2^T rows [16 w, 16 w + 16) (B of da1 = dh2 W2)
 #pragma unroll
     for (int kb = 0; kb < KB2; ++kb) w2f[kb] = wfrag32<NP>(a.w2t + (size_t)(wave * 16) * N1, N1, kb, S_w2);
     WFrag16 w1tf[NE];                  // W1^T [16 rb + r][16 w + 4 g ..] (A of this wave's K = 16 slice of W1^T dh1)
 #pragma unroll
-    for (int rb = 0; rb < NE; ++rb) w1tf[rb] = wfrag16<NP>(a.w1t + (size_t)(rb * 16) * N1, N1, wave * 16, S_w1);
-    const float b1s = a.b1[wave * 16 + r] * (NP == 2 ? S_x * S_w1 : 1.0f);
+    for (int rb = 0; rb < NE; ++rb) w1tf[rb] = wfrag16<NPE>(a.w1t + (size_t)(rb * 16) * N1, N1, wave * 16, 1.0f);
+    const float b1s = a.b1[wave * 16 + r];
     // LayerNorm role: thread = (pixel t / (e/4), channel quad t % (e/4))
     const int lpx = threadIdx.x / LPP, lq = threadIdx.x % LPP;
     const float4 lng = *reinterpret_cast<const float4*>(a.ln2g + 4 * lq), lnb = *reinterpret_cast<const float4*>(a.ln2b + 4 * lq);
@@ -270,13 +270,15 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
         const float rstd = __builtin_amdgcn_rsqf(lane_group_sum<LPP>((c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3)) * (1.0f / E) + LG_EPS);
         const float xh[4] = {c0 * rstd, c1 * rstd, c2 * rstd, c3 * rstd};
         {
-            const float yv[4] = {(xh[0] * lng.x + lnb.x) * S_x, (xh[1] * lng.y + lnb.y) * S_x, (xh[2] * lng.z + lnb.z) * S_x, (xh[3] * lng.w + lnb.w) * S_x};
+            const float yv[4] = {xh[0] * lng.x + lnb.x, xh[1] * lng.y + lnb.y, xh[2] * lng.z + lnb.z, xh[3] * lng.w + lnb.w};
             u32x2_t q1, q2, q3;
-            split_x4<NP>(yv, q1, q2, q3);
+            split_x4<NPE>(yv, q1, q2, q3);
             uint16_t* dst = XN + lpx * E + 4 * lq;
             *reinterpret_cast<u32x2_t*>(dst) = q1;
-            if (NP >= 2) *reinterpret_cast<u32x2_t*>(dst + XN_PIECE) = q2;
-            if (NP == 3) *reinterpret_cast<u32x2_t*>(dst + 2 * XN_PIECE) = q3;
+            if (NPE == 3) {
+                *reinterpret_cast<u32x2_t*>(dst + XN_PIECE) = q2;
+                *reinterpret_cast<u32x2_t*>(dst + 2 * XN_PIECE) = q3;
+            }
         }
         if (tile + (long)gridDim.x < ntiles) issue(tile + gridDim.x);   // next tile's operands: in flight during the GEMM phase
         STAMP(1);
@@ -299,14 +301,14 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
             f32x4_t h1 = (f32x4_t){b1s, b1s, b1s, b1s};
             if constexpr (E == 16) {
                 s16x4_t xa[3];
-                ld3_x4<NP>(XN + (pbk * 16 + r) * E + 4 * g, XN_PIECE, xa);
+                ld3_x4<NPE>(XN + (pbk * 16 + r) * E + 4 * g, XN_PIECE, xa);
                 KB_FENCE();
-                mfmaN_16<NP>(h1, xa, w1f16.p);
+                mfmaN_16<NPE>(h1, xa, w1f16.p);
             } else {
                 bf16x8_t xa[3];
-                ld3_x8<NP>(XN + (pbk * 16 + r) * E + 8 * g, XN_PIECE, xa);
+                ld3_x8<NPE>(XN + (pbk * 16 + r) * E + 8 * g, XN_PIECE, xa);
                 KB_FENCE();
-                mfmaN_32<NP>(h1, xa, w1f32.p);
+                mfmaN_32<NPE>(h1, xa, w1f32.p);
             }
             f32x4_t da = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             {
@@ -336,16 +338,15 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
             KB_FENCE();
             // ---- gelu(h1), gelu'(h1) with one exponential for both; dh1 = da1 * gelu'(h1); pieces
             lg_v2f a01, a23, g01, g23;
-            if (NP == 2) h1 *= inv_h1;
             gelu2_both_t<NP == 1>((lg_v2f){h1[0], h1[1]}, a01, g01);
             gelu2_both_t<NP == 1>((lg_v2f){h1[2], h1[3]}, a23, g23);
-            if (NP == 2) { a01 *= S_a1; a23 *= S_a1; g01 *= c_d1; g23 *= c_d1; }
+            if (NP == 2) { a01 *= S_a1; a23 *= S_a1; g01 *= c_d1; g23 *= c_d1; }      // gelu(h1) as an f16-pair operand; dh1 = (accumulator / (S_d2 S_w2)) gelu'(h1), true scale
             const float a1v[4] = {a01.x, a01.y, a23.x, a23.y};
             const float d1v[4] = {da[0] * g01.x, da[1] * g01.y, da[2] * g23.x, da[3] * g23.y};
             bs1 += (d1v[0] + d1v[1]) + (d1v[2] + d1v[3]);
             s16x4_t a1p[3], d1p[3];
             split4<NP>(a1v, a1p);
-            split4<NP>(d1v, d1p);
+            split4<NPE>(d1v, d1p);
             KB_FENCE();
             // ---- dW1[16 w + .][.] += dh1^T LN(x) (A = dh1 from the registers, B = LN(x) read by columns);
             //      dW2[.][16 w + .] += dh2^T gelu(h1) (A = dh2 read by columns, B = gelu(h1) from the registers)
@@ -354,8 +355,8 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
 #pragma unroll
                 for (int cb = 0; cb < NE; ++cb) {
                     s16x4_t xt[3];
-                    ld3_tr<NP>(px + 16 * cb, XN_PIECE, xt);
-                    mfmaN_16<NP>(acc1[cb], d1p, xt);
+                    ld3_tr<NPE>(px + 16 * cb, XN_PIECE, xt);
+                    mfmaN_16<NPE>(acc1[cb], d1p, xt);
                 }
                 const uint16_t* pt = D2 + (pbk * 16 + 4 * g + (r >> 2)) * LDP + 4 * (r & 3);
 #pragma unroll
@@ -370,16 +371,18 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
             {
                 uint16_t* dst = D1T + r * 16 + 4 * g;
                 *reinterpret_cast<u32x2_t*>(dst) = __builtin_bit_cast(u32x2_t, d1p[0]);
-                if (NP >= 2) *reinterpret_cast<u32x2_t*>(dst + D1T_PIECE) = __builtin_bit_cast(u32x2_t, d1p[1]);
-                if (NP == 3) *reinterpret_cast<u32x2_t*>(dst + 2 * D1T_PIECE) = __builtin_bit_cast(u32x2_t, d1p[2]);
+                if (NPE == 3) {
+                    *reinterpret_cast<u32x2_t*>(dst + D1T_PIECE) = __builtin_bit_cast(u32x2_t, d1p[1]);
+                    *reinterpret_cast<u32x2_t*>(dst + 2 * D1T_PIECE) = __builtin_bit_cast(u32x2_t, d1p[2]);
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 s16x4_t dtp[3];
-                ld3_tr<NP>(D1T + (4 * g + (r >> 2)) * 16 + 4 * (r & 3), D1T_PIECE, dtp);
+                ld3_tr<NPE>(D1T + (4 * g + (r >> 2)) * 16 + 4 * (r & 3), D1T_PIECE, dtp);
 #pragma unroll
                 for (int rb = 0; rb < NE; ++rb) {
                     f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                    mfmaN_16<NP>(o, w1tf[rb].p, dtp);     // o[v] = (W1^T dh1)[out channel 16 rb + 4 g + v][pixel r], hidden channels 16 w .. 16 w + 15 only
+                    mfmaN_16<NPE>(o, w1tf[rb].p, dtp);     // o[v] = (W1^T dh1)[out channel 16 rb + 4 g + v][pixel r], hidden channels 16 w .. 16 w + 15 only
                     *reinterpret_cast<float4*>(red + ((size_t)wave * NPX + pbk * 16 + r) * E + 16 * rb + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
                 }
                 __builtin_amdgcn_wave_barrier();      // D1T is rewritten by the next pixel block
@@ -398,7 +401,6 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
                 const float4 s0 = *reinterpret_cast<const float4*>(rp + (size_t)w2 * NPX * E), s1 = *reinterpret_cast<const float4*>(rp + (size_t)(w2 + 1) * NPX * E);
                 dl[0] += s0.x + s1.x; dl[1] += s0.y + s1.y; dl[2] += s0.z + s1.z; dl[3] += s0.w + s1.w;
             }
-            if (NP == 2) { dl[0] *= inv_o; dl[1] *= inv_o; dl[2] *= inv_o; dl[3] *= inv_o; }
             pg.x += dl[0] * xh[0]; pg.y += dl[1] * xh[1]; pg.z += dl[2] * xh[2]; pg.w += dl[3] * xh[3];
             pb.x += dl[0]; pb.y += dl[1]; pb.z += dl[2]; pb.w += dl[3];
             const float dxh[4] = {dl[0] * lng.x, dl[1] * lng.y, dl[2] * lng.z, dl[3] * lng.w};
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
 
     // ---- this workgroup's partial sums -> its slab row [dW2 N1 x N1 | db2 N1 | dW1 N1 x e | db1 N1 | d gamma e | d beta e]
     float* row = a.slab + (size_t)blockIdx.x * C::ROW;
-    const float inv_w2 = 1.0f / (S_d2 * S_a1), inv_w1 = 1.0f / (S_d1 * S_x);     // (1 at NP = 1, 3)
+    const float inv_w2 = 1.0f / (S_d2 * S_a1);     // (1 at NP = 1, 3)
 #pragma unroll
     for (int nb = 0; nb < NW; ++nb)
 #pragma unroll
@@ -423,9 +425,9 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
 #pragma unroll
     for (int cb = 0; cb < NE; ++cb)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) row[C::R_W1 + (16 * wave + 4 * g + v) * E + 16 * cb + r] = acc1[cb][v] * inv_w1;
+        for (int v = 0; v < 4; ++v) row[C::R_W1 + (16 * wave + 4 * g + v) * E + 16 * cb + r] = acc1[cb][v];
     {
-        float s = bs1 * (1.0f / S_d1);
+        float s = bs1;
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
         if (g == 0) row[C::R_B1 + 16 * wave + r] = s;

@@ -344,11 +344,11 @@ def test_f16_pair_ffn_backward_holds_fp32_accuracy_at_extreme_scales(case, gscal
     forward's static power-of-two scales, the gradient operands dh2 / dh1 under scales taken from the launch-wide max |dh2| that the
     spatial half leaves behind (and the bound on dh1 that follows from it).  The FFN half-block of both xs widths (e = 16, 32) against
     fp64 autograd over the oracle, with upstream gradients of 1e-12, 1 and 1e8 times a unit normal and weights pushed out of f16's range
-    in opposite directions.  An f16 pair represents a value to 2^-24 RELATIVE (a bf16 triple holds all 24 bits exactly), and a sum over
-    pixels whose terms cancel amplifies that: profiles/r05_ffn_bwd_err.txt -- dx 1.2e-7 (bf16 x 3: 2.7e-8), dW1 and the LayerNorm pair
-    4 - 6e-6 (3e-7 - 3e-6; the same at 2 048 and at 65 536 pixels: the operand errors are independent), everything else equal.  That is the
-    level of the reference's own fp32 gradients against fp64 (7e-6 .. 2.7e-4 over the gradient goldens, manifest rel_fp32_vs_fp64).  Gate:
-    within 3 x of the bf16-triple build's error + 1e-5 of the tensor's norm, at every scale."""
+    in opposite directions: for dx and every parameter gradient of the half-block the error stays at the level of the three-piece bf16
+    arithmetic (LG_FFN_BWD_SPLIT=bf16x3, which has fp32's exponent range) -- within 2 x of it + 5e-7 of the tensor's norm
+    (profiles/r05_ffn_bwd_err.txt: equal to two digits on every tensor).  The pairs are used for the two W2 products only: with pairs in EVERY
+    product (the first form of the kernel) dW1 and the LayerNorm gradients came out at 4e-6 .. 1.5e-5 against the triples' 5e-7 -- a pair holds a
+    value to 2^-24 relative, a triple exactly, and those sums over pixels cancel to ~1 % of their terms -- which is what this gate is sized to catch."""
     from gpu_helpers import Ops, make_module
     from test_gpu_backward import _oracle_block
     mult = {'as_initialised': {},
@@ -380,5 +380,5 @@ def test_f16_pair_ffn_backward_holds_fp32_accuracy_at_extreme_scales(case, gscal
             assert torch.isfinite(got['f16x2'][k]).all(), (case, gscale, blk, k)
             rn = float(ref.norm())
             e2, e3 = (float((got[sp][k].reshape(ref.shape) - ref).norm()) for sp in ('f16x2', 'bf16x3'))
-            assert e2 <= 3.0 * e3 + 1e-5 * rn + 1e-30, (case, gscale, blk, k, e2 / max(rn, 1e-300), e3 / max(rn, 1e-300))
+            assert e2 <= 2.0 * e3 + 5e-7 * rn + 1e-30, (case, gscale, blk, k, e2 / max(rn, 1e-300), e3 / max(rn, 1e-300))
     monkeypatch.delenv('LG_FFN_BWD_SPLIT', raising=False)
