@@ -424,7 +424,7 @@ def main():
         out = dict(metric=metric, value=round(value, 2), unit='image-pairs/sec',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
                    scaling='weak', vs_baseline=None,
-                   dtype='f32 (GEMMs and the local mixer: split 16-bit MFMA -- f16 pairs in the forward FFN and P V, bf16 triples elsewhere -- fp32 accumulate; fp32-equivalent)' if args.precision == 'fp32'
+                   dtype='f32 (GEMMs and the local mixer: split 16-bit MFMA -- f16 pairs in the forward FFN, the W2 products of its backward and P V, bf16 triples elsewhere -- fp32 accumulate; fp32-equivalent)' if args.precision == 'fp32'
                          else 'bf16 / f16 MFMA (FFN, local mixer) + bf16 saved activations, f32 elsewhere', data='synthetic',
                    config=dict(workload=label + ', train step = fwd + L1 + bwd + Adam + StepLR tick', mode=args.mode,
                                global_batch=B_PER_GPU * world, parallelism=f'dp{world}', dropout=True),
