@@ -314,6 +314,7 @@ struct AttnBwdArgs {
     float *d_qkvw, *d_qkvb;   // e = 16 (attn_bwd_fuses_qkv): to_qkv's weight / bias gradients are accumulated in the epilogue kernel (+=); y1 may be null
     float* part;        // scratch: per-workgroup partial sums, attn_bwd_part_floats(e) floats
     int B, h, w;
+    float* stats = nullptr;   // k_attn_bwd_core_m only: [P][2 heads][4] row statistics between its two launches
     int core_m = 0;     // 1 (lg_config.variant LG_VAR_ATTN_BWD_CORE_M): the matrix-pipe core k_attn_bwd_core_m at e = 32 instead of the vector-pipe k_attn_bwd_core
 };
 int launch_attn_bwd_core_m(int e, const AttnBwdArgs& a, int grid, int nwin, int ngroups, hipStream_t s);   // k_attn_bwd_m.hip

@@ -92,8 +92,12 @@ __device__ __forceinline__ f32x4_t mfma3(u32x4_t ah, u32x4_t al, u32x4_t bh, u32
 }
 }  // namespace abm
 
-template <int HC, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1))) void k_attn_bwd_core_m(AttnBwdArgs a, int nwin, int ngroups) {
+// PH = 0: prologue + orientation A (O, dQ, the pos_emb gradient; the row statistics go to a.stats);  PH = 1: prologue + orientation B (dV, dK) from the
+// statistics.  Two launches because of the register file: the 64 pos_emb accumulators of a lane live across all windows of its wave, and beside them one
+// orientation fits 256 registers, both do not (330) -- the second launch has no accumulators and pays the prologue again (cheap on
+// the matrix pipe) plus 32 bytes of statistics per pixel.
+template <int HC, int NW, int PH>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) void k_attn_bwd_core_m(AttnBwdArgs a, int nwin, int ngroups) {
     using namespace abm;
     constexpr int E = 2 * HC, D = HC / 2;
     static_assert(D == 8, "fragment builders are written for a head dimension of 8 (e = 32)");
@@ -184,9 +188,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1))) vo
     const float scale = (float)(1.0 / sqrt((double)D));
     // pos_emb gradient [qt][kt]: rows = keys 16 kt + 4 g + v, column = query 16 qt + c; all windows of this wave.  (ds_add_f32 into one LDS image per
     // workgroup instead: 434 us per launch against 217; the accumulators as they are needed every trick below to fit 256 registers.)
-    f32x4_t dpa[4][4];
+    f32x4_t dpa[PH == 0 ? 4 : 1][4];
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt)
+    for (int qt = 0; qt < (PH == 0 ? 4 : 1); ++qt)
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) dpa[qt][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1))) vo
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) xv[t][m] = *reinterpret_cast<const float4*>(xw + ((t * tstep + lpix) * E + 16 * m + 4 * g));
-            if (hd == 0) {   // the FFT-mixer half of the proj input: planar o2 -> cat[..][HC + .] (lane = token here)
+            if (PH == 0 && hd == 0) {   // the FFT-mixer half of the proj input: planar o2 -> cat[..][HC + .] (lane = token here)
                 const long p = porg + (lane >> 3) * a.w + (lane & 7);
                 const long sp = p - b * hw;
                 float o2v[HC];
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1))) vo
                 const float xs[4] = {xv[t][0].x, xv[t][0].y, xv[t][0].z, xv[t][0].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { y1[t][i] = (xs[i] - mu) * rstd * gam[i] + bet[i]; ym = fmaxf(ym, fabsf(y1[t][i])); }
-                if (hd == 0 && a.y1) *reinterpret_cast<float4*>(a.y1 + (porg + t * tstep + lpix) * Y1LD + 4 * g) = make_float4(y1[t][0], y1[t][1], y1[t][2], y1[t][3]);
+                if (PH == 0 && hd == 0 && a.y1) *reinterpret_cast<float4*>(a.y1 + (porg + t * tstep + lpix) * Y1LD + 4 * g) = make_float4(y1[t][0], y1[t][1], y1[t][2], y1[t][3]);
             }
             // dym is requested only now (x is dead): both at once do not fit beside the 64 pos_emb accumulators
             __builtin_amdgcn_sched_barrier(0);
@@ -310,13 +314,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1))) vo
         const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
 
         // ---------------- orientation A: rows = keys, columns = queries
-        {
+        if constexpr (PH == 0) {
             u32x4_t fK[4], fV[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) { fK[t] = row_frag(sK, t, g, c, sh_k); fV[t] = row_frag(sV, t, g, c, sh_v); }
-            u32x4_t Vh[2], Vl[2];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) col_frag(sV, s2, g, c, sh_v, Vh[s2], Vl[s2]);
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
                 f32x4_t S[4], P[4];
@@ -348,14 +349,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1))) vo
                     for (int v = 0; v < 4; ++v) { S[kt][v] *= il14; P[kt][v] *= c_dp; dsum = fmaf(S[kt][v], P[kt][v], dsum); }
                 // D_i 2^(sh_s - 14) = 2^-14 sum_j P14 (dP c_dp)
                 const float dq_s = __builtin_amdgcn_ldexpf(xg_sum(dsum), -14);
-                if (g == 0) { sSt[16 * qt + c] = mx; sSt[64 + 16 * qt + c] = il14; sSt[128 + 16 * qt + c] = dq_s; }
+                if (g == 0)     // row statistics of query 16 qt + c for the second launch: max (log2 domain), 2^14 / sum, D_i 2^(sh_s - 14)
+                    *reinterpret_cast<float4*>(a.stats + ((porg + 2 * qt * a.w + tok_off) * 2 + hd) * 4) = make_float4(mx, il14, dq_s, 0.f);
                 // O^T = V^T P^T before P's registers become dS
                 f32x4_t oacc = z4, qacc = z4;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    u32x4_t ph, pl;
+                    u32x4_t ph, pl, Vh, Vl;
                     tile_frag(S[2 * s2], S[2 * s2 + 1], ph, pl);
-                    oacc = mfma3(Vh[s2], Vl[s2], ph, pl, oacc);
+                    col_frag(sV, s2, g, c, sh_v, Vh, Vl);      // (rebuilt per query tile, as K's below: 16 registers each)
+                    oacc = mfma3(Vh, Vl, ph, pl, oacc);
                 }
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
@@ -380,13 +383,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1))) vo
                 __builtin_amdgcn_sched_barrier(0);   // one query tile at a time: interleaved tiles need more registers than there are
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();    // the row statistics are this wave's own
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
         // ---------------- orientation B: rows = queries, columns = keys
 #ifndef ABM_SKIP_B
-        {
+        if constexpr (PH == 1) {
+            {   // the statistics of this wave's 64 queries: lane = token, through the wave's LDS region
+                const float4 st = *reinterpret_cast<const float4*>(a.stats + ((porg + (lane >> 3) * a.w + (lane & 7)) * 2 + hd) * 4);
+                sSt[lane] = st.x; sSt[64 + lane] = st.y; sSt[128 + lane] = st.z;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             u32x4_t fQ[4], fD[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) { fQ[t] = row_frag(sQ, t, g, c, sh_q); fD[t] = row_frag(sDO, t, g, c, sh_d); }
@@ -437,6 +443,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1))) vo
 #endif
 #endif
     }
+    if constexpr (PH == 1) return;
     // ---------------- pos_emb gradient of this workgroup: the waves add their accumulators in turn (fixed order), then one slab row
     __syncthreads();     // every wave is done with the pos table
     for (int i = threadIdx.x; i < 64 * PLD; i += NW * 64) sDpos[i] = 0.f;
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1))) vo
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) sDpos[(16 * qt + c) * PLD + 16 * kt + 4 * g + v] += dpa[qt][kt][v];
+                    for (int v = 0; v < 4; ++v) sDpos[(16 * qt + c) * PLD + 16 * kt + 4 * g + v] += dpa[PH == 0 ? qt : 0][kt][v];
         }
         __syncthreads();
     }
@@ -463,11 +470,15 @@ int launch_attn_bwd_core_m(int e, const AttnBwdArgs& a, int grid, int nwin, int 
     const size_t lds = (size_t)(4192 + NW * (4 * 64 * (HC / 2) + 64 * 4)) * sizeof(float);
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        hipError_t er = hipFuncSetAttribute((const void*)k_attn_bwd_core_m<HC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        hipError_t er = hipFuncSetAttribute((const void*)k_attn_bwd_core_m<HC, NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attn_bwd_core_m<HC, NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
         if (er != hipSuccess) { lg_set_error("attn_bwd_core_m: hipFuncSetAttribute: %s", hipGetErrorString(er)); return (int)er; }
         attr_once.done();
     }
-    k_attn_bwd_core_m<HC, NW><<<dim3(grid, 2), NW * 64, lds, s>>>(a, nwin, ngroups);
+    if (!a.stats) { lg_set_error("attn_bwd_core_m: statistics scratch missing"); return -2; }
+    k_attn_bwd_core_m<HC, NW, 0><<<dim3(grid, 2), NW * 64, lds, s>>>(a, nwin, ngroups);
+    LG_CHECK_LAUNCH();
+    k_attn_bwd_core_m<HC, NW, 1><<<dim3(grid, 2), NW * 64, lds, s>>>(a, nwin, ngroups);
     LG_CHECK_LAUNCH();
     return 0;
 }

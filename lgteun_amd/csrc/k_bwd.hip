@@ -12,6 +12,7 @@ struct BwdBufs {
     float *dh2, *dh1, *y2, *do2, *dg, *dym, *cat, *y1, *dqkv, *dpos_slab;
     float *w3t[5], *w2t[5], *w1t[5], *wsp, *dt, *dskip, *v, *du, *fft_scratch;   // transposed FFN weights, one set per block of the LGT
     float* slab_arena;    // scratch of the deferred parameter-gradient reductions (ReduceQueue, bwd_kernels.h)
+    float* attn_stats;    // [P0][2][4]: row statistics between the two launches of k_attn_bwd_core_m (LG_ATTN_BWD_CORE=m)
     float* ffn_scales;    // NetBufs::ffn_scales of the forward this backward belongs to ([stage][5][8]); null: no f16-pair products in the backward
     size_t slab_cap;      // floats
     ReduceQueue rq;
@@ -30,6 +31,7 @@ static void carve_bwd(const lg_plan* plan, int B, void* base, BwdBufs& bb) {
     bb.y2 = cv.take(P0 * E); bb.do2 = cv.take(P0 * E / 2); bb.dg = cv.take(P0 * E / 2);
     bb.dym = cv.take(P0 * E); bb.cat = cv.take(P0 * E); bb.y1 = cv.take(P0 * 16 > P0 * E / 2 ? P0 * 16 : P0 * E / 2);
     bb.dqkv = cv.take(P0 * 2 * E);
+    bb.attn_stats = cv.take(P0 * 8);
     bb.dpos_slab = cv.take((size_t)ATTN_BWD_F_WGS * ATTN_BWD_F_ROW > (size_t)512 * 2 * 64 * 64 ? (size_t)ATTN_BWD_F_WGS * ATTN_BWD_F_ROW : (size_t)512 * 2 * 64 * 64);
     for (int j = 0; j < 5; ++j) { bb.w3t[j] = cv.take(8 * E * 2 * E); bb.w2t[j] = cv.take(8 * E * 8 * E); bb.w1t[j] = cv.take(8 * E * 2 * E); }
     bb.wsp = cv.take(ffn_wsplit_bytes(32) / sizeof(float));   // pre-split W2^T / W1^T fragments of k_ffn1_bwd_x32 (e = 32 blocks)
@@ -265,7 +267,7 @@ static int mixer_half_bwd(const lg_plan* pl, const float* P, float* G, int st, i
     at.d_qkvw = G + pl->blk(st, j, B_QKVW); at.d_qkvb = G + pl->blk(st, j, B_QKVB);
     if (attn_bwd_fuses_qkv(e)) at.y1 = nullptr;   // the epilogue kernel forms y1 itself and accumulates the to_qkv weight gradient
     if (!at.part) return -3;
-    at.B = B; at.h = fb.h; at.w = fb.w; at.core_m = pl->attn_bwd_core_m;
+    at.B = B; at.h = fb.h; at.w = fb.w; at.core_m = pl->attn_bwd_core_m; at.stats = bb.attn_stats;
     RC(launch_attn_bwd(e, at, s));
     const int grid = attn_bwd_grid(e, B, fb.h, fb.w);
     RC(launch_reduce_slab(bb.dpos_slab, grid, 1, 2 * 64 * 64, G + pl->blk(st, j, B_POS), 2 * 64 * 64, 1, 2 * 64 * 64, s));
