@@ -196,3 +196,29 @@ def test_edge_shapes_vs_oracle(gpu, C, K, B, h):
         y = net(T(ms).cuda(), T(pan).cuda()).cpu()
         want = orc.forward(det_params(C, K), T(ms), T(pan), K)
     assert rel_l2(y, want) < 1e-4
+
+
+@pytest.mark.parametrize('impl', ['strip', 'tile', 'xp'])
+def test_ffn_forward_ab_kernels_agree_with_the_default(gpu, impl, monkeypatch):
+    """the A/B kernels of the fused FFN forward (LG_FFN_IMPL: strip = the exact f32-MFMA strip kernel, in every build; tile = round 1's tile
+    kernel and xp = the software-pipelined halo pass, in `make AB=1` builds only -- ADVICE r4: profiles/r05_ab_build_tests.txt is this suite on
+    that build) against the default f16-pair kernel on the FFN half-block of both levels (op level: a whole forward would put the FFT mixer's
+    branch cut between the two): 2e-6 of the half-block's own contribution"""
+    from gpu_helpers import Ops, make_module
+    from lgteun_amd._lib import LgteunHipError
+    rng = np.random.default_rng(77)
+    for blk, e, n in ((0, 16, 32), (2, 32, 16)):
+        x = T((rng.standard_normal((2, n, n, e)) * 1.5 + 0.3).astype(np.float32)).cuda()
+        monkeypatch.delenv('LG_FFN_IMPL', raising=False)
+        want = Ops(make_module(4, 1), 32, 32).block(0, blk, 2, x).double().cpu()
+        monkeypatch.setenv('LG_FFN_IMPL', impl)                      # read once per plan: a fresh module builds a fresh plan
+        try:
+            got = Ops(make_module(4, 1), 32, 32).block(0, blk, 2, x).double().cpu()
+        except LgteunHipError as err:
+            if 'AB=1' in str(err):
+                pytest.skip('this variant is compiled into `make AB=1` builds only')
+            raise
+        finally:
+            monkeypatch.delenv('LG_FFN_IMPL', raising=False)
+        den = float((want - x.double().cpu()).norm())
+        assert float((got - want).norm()) <= 2e-6 * den, (blk, float((got - want).norm()) / den)
