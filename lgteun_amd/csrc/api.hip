@@ -246,7 +246,8 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     a1.P = (long)B * bb.h * bb.w;
     a1.hbf = pl->hidden_bf16(bb.e) ? 1 : 0;
     a1.tile16 = pl->ffn_tile;
-    a1.wsplit = wsplit;
+    a1.wsplit = wsplit ? wsplit + ((size_t)stage * 5 + j) * (ffn_wsplit_bytes(8 * pl->cfg.C) / sizeof(float)) : nullptr;   // this block's slot, filled by prep_stages
+    a1.wsplit_ready = (wsplit && bb.e >= 32) ? 1 : 0;
     a1.scales = pl->ffn_f16x2(bb.e) ? ffn_scales + ((size_t)stage * 5 + j) * 8 : nullptr;   // written by prep_stages for the stages of this call
     Ffn2Args a2;
     a2.h2 = bb.h2; a2.x = bb.xmid; a2.a3s = (flags & LG_FLAG_SAVE) ? bb.a3 : nullptr; a2.g3s = ((flags & LG_FLAG_SAVE) && !pre && !pl->ffn_dw_x32(bb.e, bb.h, bb.w)) ? bb.g3 : nullptr; a2.y = bb.xout;   // g3s null with a3s set: a3 receives the PRE-activation h3
@@ -281,18 +282,35 @@ static int prep_stages(const lg_plan* pl, const float* P, int st0, int st1, NetB
     int rc = pos_transpose_stages(pl, P, st0, st1, nb.posT, s);
     if (rc || st1 <= st0) return rc;
     const int E = 4 * pl->cfg.C;
-    if (!pl->ffn_f16x2(E) && !pl->ffn_f16x2(2 * E)) return 0;
-    FfnPrepJob jobs[5 * LG_MAX_K];
-    int n = 0;
+    if (pl->ffn_f16x2(E) || pl->ffn_f16x2(2 * E)) {
+        FfnPrepJob jobs[5 * LG_MAX_K];
+        int n = 0;
+        for (int st = st0; st < st1; ++st)
+            for (int j = 0; j < 5; ++j, ++n) {
+                FfnPrepJob& q = jobs[n];
+                q.ln2g = P + pl->blk(st, j, B_LN2G); q.ln2b = P + pl->blk(st, j, B_LN2B);
+                q.w1 = P + pl->blk(st, j, B_W1); q.b1 = P + pl->blk(st, j, B_B1); q.w2 = P + pl->blk(st, j, B_W2); q.b2 = P + pl->blk(st, j, B_B2);
+                q.dww = P + pl->blk(st, j, B_DWW); q.dwb = P + pl->blk(st, j, B_DWB); q.w3 = P + pl->blk(st, j, B_W3);
+                q.e = j == 2 ? 2 * E : E;
+            }
+        if ((rc = launch_ffn_scales(n, jobs, nb.ffn_scales + (size_t)st0 * 5 * 8, s))) return rc;
+    }
+    // the pre-split weight fragments of every e >= 32 block of these stages, behind the scales they are multiplied by (round 5: one launch per
+    // forward call instead of one in front of every FFN launch)
+    SplitWJob sj[5 * LG_MAX_K];
+    int ns = 0;
+    const size_t slot = ffn_wsplit_bytes(2 * E) / sizeof(float);
     for (int st = st0; st < st1; ++st)
-        for (int j = 0; j < 5; ++j, ++n) {
-            FfnPrepJob& q = jobs[n];
-            q.ln2g = P + pl->blk(st, j, B_LN2G); q.ln2b = P + pl->blk(st, j, B_LN2B);
-            q.w1 = P + pl->blk(st, j, B_W1); q.b1 = P + pl->blk(st, j, B_B1); q.w2 = P + pl->blk(st, j, B_W2); q.b2 = P + pl->blk(st, j, B_B2);
-            q.dww = P + pl->blk(st, j, B_DWW); q.dwb = P + pl->blk(st, j, B_DWB); q.w3 = P + pl->blk(st, j, B_W3);
-            q.e = j == 2 ? 2 * E : E;
+        for (int j = 0; j < 5; ++j) {
+            const int e = j == 2 ? 2 * E : E;
+            if (e < 32 || e % 32) continue;
+            SplitWJob& q = sj[ns++];
+            q.w1 = P + pl->blk(st, j, B_W1); q.w2 = P + pl->blk(st, j, B_W2); q.w3 = P + pl->blk(st, j, B_W3);
+            q.e = e; q.np = pl->hidden_bf16(e) ? 1 : (pl->ffn_f16x2(e) ? 2 : 3);
+            q.scales = q.np == 2 ? nb.ffn_scales + ((size_t)st * 5 + j) * 8 : nullptr;
+            q.out = nb.wsplit + ((size_t)st * 5 + j) * slot;
         }
-    return launch_ffn_scales(n, jobs, nb.ffn_scales + (size_t)st0 * 5 * 8, s);
+    return ns ? launch_split_w_jobs(ns, sj, s) : 0;
 }
 
 // LGT.forward (LGT.py:314-344) on z -> out with the buffers of `nb`

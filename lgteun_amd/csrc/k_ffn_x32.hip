@@ -43,8 +43,8 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 // W [rows][K] fp32 -> fragments (mb, kb) of 16 x 32, three bf16 pieces each, in the order a wave loads them
-__global__ __launch_bounds__(256) void k_split_w(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
-                                                 u32x4_t* __restrict__ out, int e, int np, const float* __restrict__ scales) {
+__device__ __forceinline__ void split_w_body(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
+                                             u32x4_t* __restrict__ out, int e, int np, const float* __restrict__ scales) {
     const int n1 = 4 * e, kb1 = e / 32, kb2 = n1 / 32;
     const int nf1 = (n1 / 16) * kb1, nf2 = (n1 / 16) * kb2, nf3 = (e / 16) * kb2;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -77,6 +77,15 @@ __global__ __launch_bounds__(256) void k_split_w(const float* __restrict__ w1, c
     out[(f * 3 + 0) * 64 + lane] = (u32x4_t){a1.x, a1.y, b1.x, b1.y};
     out[(f * 3 + 1) * 64 + lane] = (u32x4_t){a2.x, a2.y, b2.x, b2.y};
     out[(f * 3 + 2) * 64 + lane] = (u32x4_t){a3.x, a3.y, b3.x, b3.y};
+}
+__global__ __launch_bounds__(256) void k_split_w(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
+                                                 u32x4_t* __restrict__ out, int e, int np, const float* __restrict__ scales) {
+    split_w_body(w1, w2, w3, out, e, np, scales);
+}
+// every e >= 32 block of a forward call in one launch: blockIdx.y = job (round 5: one k_split_w per FFN launch was 5 / 20 / 40 launches of 4.8 us per step)
+__global__ __launch_bounds__(256) void k_split_w_jobs(SplitWTable tab) {
+    const SplitWJob& j = tab.j[blockIdx.y];
+    split_w_body(j.w1, j.w2, j.w3, reinterpret_cast<u32x4_t*>(j.out), j.e, j.np, j.scales);
 }
 
 // SAVE: 0 nothing; 1 gelu(h1), gelu'(h1), h2 and gelu(h3) / gelu'(h3) or the pre-activation h3 (a2.g3s null); 2 h2 and h3 only (the backward
@@ -487,6 +496,24 @@ int launch_split_w(const float* w1, const float* w2, const float* w3, void* out,
     return 0;
 }
 
+int launch_split_w_jobs(int n, const SplitWJob* jobs, hipStream_t s) {
+    for (int j0 = 0; j0 < n; j0 += LG_MAX_FFN_PREP_JOBS) {
+        const int m = n - j0 < LG_MAX_FFN_PREP_JOBS ? n - j0 : LG_MAX_FFN_PREP_JOBS;
+        SplitWTable tab;
+        int nfmax = 0;
+        for (int i = 0; i < LG_MAX_FFN_PREP_JOBS; ++i) tab.j[i] = jobs[j0 + (i < m ? i : 0)];
+        for (int i = 0; i < m; ++i) {
+            const SplitWJob& q = tab.j[i];
+            if (q.e % 32 || (q.np == 2 && !q.scales) || !q.out) { lg_set_error("split_w_jobs: job %d: e=%d np=%d", j0 + i, q.e, q.np); return -2; }
+            const int n1 = 4 * q.e, kb1 = q.e / 32, kb2 = n1 / 32, nf = (n1 / 16) * kb1 + (n1 / 16) * kb2 + (q.e / 16) * kb2;
+            if (nf > nfmax) nfmax = nf;
+        }
+        k_split_w_jobs<<<dim3((nfmax * 64 + 255) / 256, m), 256, 0, s>>>(tab);
+        LG_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
 int launch_ffn_x32(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     ProfScope prof__(LG_K_FFN2, s);
     if (!a1.wsplit) { lg_set_error("ffn_x32: no weight-fragment scratch in the workspace"); return -3; }
@@ -504,7 +531,7 @@ int launch_ffn_x32(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
         if (e != hipSuccess) { lg_set_error("ffn_x32: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
-    {
+    if (!a1.wsplit_ready) {
         const int rc = launch_split_w(a1.w1, a1.w2, a2.w3, a1.wsplit, E, a1.hbf ? 1 : (a1.scales ? 2 : 3), s, a1.scales);
         if (rc) return rc;
     }

@@ -392,7 +392,7 @@ static int launch_ffn_x64_t(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t 
         if (e != hipSuccess) { lg_set_error("ffn_x64: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
-    {
+    if (!a1.wsplit_ready) {
         const int rc = launch_split_w(a1.w1, a1.w2, a2.w3, a1.wsplit, E, NP, s, a1.scales);
         if (rc) return rc;
     }

@@ -126,6 +126,7 @@ struct Ffn1Args {
     const float *ln2g, *ln2b, *w1, *b1, *w2, *b2;
     long P;
     void* wsplit;    // workspace scratch for pre-split weight fragments (ffn_wsplit_bytes; k_ffn_x32.hip), or nullptr
+    int wsplit_ready = 0;   // 1: the fragments are in `wsplit` already (prep launch of the forward call: launch_split_w_jobs); 0: the launcher splits in front of its kernel
     const float* scales;   // this block's operand scales { s_x, s_a1, s_a3, s_w1, s_w2, s_w3 } (k_ffn_prep.hip): the f16-pair arithmetic (NP = 2) of the
                            // fused forward kernels; nullptr = the three-piece bf16 arithmetic (NP = 3)
 };
@@ -134,6 +135,10 @@ struct FfnPrepJob { const float *ln2g, *ln2b, *w1, *b1, *w2, *b2, *dww, *dwb, *w
 #define LG_MAX_FFN_PREP_JOBS 40
 struct FfnPrepTable { FfnPrepJob j[LG_MAX_FFN_PREP_JOBS]; };
 int launch_ffn_scales(int n, const FfnPrepJob* jobs, float* out, hipStream_t s);
+// pre-split weight fragments of the e >= 32 FFN blocks: one job per block, all blocks of a forward call in ONE launch (k_ffn_x32.hip)
+struct SplitWJob { const float *w1, *w2, *w3, *scales; void* out; int e, np; };
+struct SplitWTable { SplitWJob j[LG_MAX_FFN_PREP_JOBS]; };
+int launch_split_w_jobs(int n, const SplitWJob* jobs, hipStream_t s);
 int launch_ffn1(int e, const Ffn1Args& a, hipStream_t s);
 struct Ffn2Args {
     const void* h2;   // [B,h,w,4e]
