@@ -19,6 +19,11 @@ struct HS<false> {
     static __device__ __forceinline__ float4 widen(raw4 u) { return u; }
     static __device__ __forceinline__ float4 ld4(const void* base, long idx) { return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + idx); }
     static __device__ __forceinline__ void st4(void* base, long idx, float4 v) { *reinterpret_cast<float4*>(static_cast<float*>(base) + idx) = v; }
+    // streaming store: a saved activation is not read again before the backward (hundreds of megabytes later)
+    static __device__ __forceinline__ void st4_nt(void* base, long idx, float4 v) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store((f4){v.x, v.y, v.z, v.w}, reinterpret_cast<f4*>(static_cast<float*>(base) + idx));
+    }
     static __device__ __forceinline__ float ld1(const void* base, long idx) { return static_cast<const float*>(base)[idx]; }
     static __device__ __forceinline__ void st1(void* base, long idx, float v) { static_cast<float*>(base)[idx] = v; }
 };
@@ -41,6 +46,7 @@ struct HS<true> {
         bf16_t h[4] = {static_cast<bf16_t>(v.x), static_cast<bf16_t>(v.y), static_cast<bf16_t>(v.z), static_cast<bf16_t>(v.w)};
         *reinterpret_cast<uint2*>(static_cast<bf16_t*>(base) + idx) = *reinterpret_cast<const uint2*>(h);
     }
+    static __device__ __forceinline__ void st4_nt(void* base, long idx, float4 v) { st4(base, idx, v); }
     static __device__ __forceinline__ float ld1(const void* base, long idx) { return static_cast<float>(static_cast<const bf16_t*>(base)[idx]); }
     static __device__ __forceinline__ void st1(void* base, long idx, float v) { static_cast<bf16_t*>(base)[idx] = static_cast<bf16_t>(v); }
 };

@@ -216,12 +216,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     gelu2_both_t<NP == 1>((lg_v2f){acc[pb][2] * us, acc[pb][3] * us}, a23, g23);
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                     if (inner[pb]) {
-                        HS<BF>::st4(a1.a1s, prow[pb], make_float4(av[0], av[1], av[2], av[3]));
-                        HS<BF>::st4(a1.g1s, prow[pb], make_float4(g01.x, g01.y, g23.x, g23.y));
+                        HS<BF>::st4_nt(a1.a1s, prow[pb], make_float4(av[0], av[1], av[2], av[3]));
+                        HS<BF>::st4_nt(a1.g1s, prow[pb], make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
                     if (NP == 2) { av[0] *= sa1; av[1] *= sa1; av[2] *= sa1; av[3] *= sa1; }
                 } else {
-                    if (SAVE == 2 && inner[pb]) HS<BF>::st4(a1.a1s, prow[pb], make_float4(acc[pb][0] * us, acc[pb][1] * us, acc[pb][2] * us, acc[pb][3] * us));
+                    if (SAVE == 2 && inner[pb]) HS<BF>::st4_nt(a1.a1s, prow[pb], make_float4(acc[pb][0] * us, acc[pb][1] * us, acc[pb][2] * us, acc[pb][3] * us));
                     const lg_v2f a01 = NP == 2 ? gelu2_scaled((lg_v2f){acc[pb][0], acc[pb][1]}, g1c, g1h) : gelu2_t<NP == 1>((lg_v2f){acc[pb][0], acc[pb][1]});
                     const lg_v2f a23 = NP == 2 ? gelu2_scaled((lg_v2f){acc[pb][2], acc[pb][3]}, g1c, g1h) : gelu2_t<NP == 1>((lg_v2f){acc[pb][2], acc[pb][3]});
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 const int m = c * CH + pb * 16 + r;
                 const float mk = sMask[slot][pb * 16 + r];
                 const float4 hh = make_float4(acc[pb][0] * mk, acc[pb][1] * mk, acc[pb][2] * mk, acc[pb][3] * mk);
-                if (SAVE && inner[pb]) HS<BF>::st4(a1.h2, prow[pb], hh);
+                if (SAVE && inner[pb]) HS<BF>::st4_nt(a1.h2, prow[pb], hh);
                 int rp = ring0 + m;
                 rp = rp >= RING * HX ? rp - RING * HX : rp;
                 if (m < npx) *reinterpret_cast<float4*>(ring + rp * LDR + c0) = hh;
@@ -346,14 +346,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     const int y = y0 + ty, x = x0 + tx;
                     if (y < Yend && x < w) {
                         const long o = ((b * h + y) * (long)w + x) * N1 + 4 * q;
-                        HS<BF>::st4(a2.a3s, o, make_float4(av[0], av[1], av[2], av[3]));
-                        HS<BF>::st4(a2.g3s, o, make_float4(g01.x, g01.y, g23.x, g23.y));
+                        HS<BF>::st4_nt(a2.a3s, o, make_float4(av[0], av[1], av[2], av[3]));
+                        HS<BF>::st4_nt(a2.g3s, o, make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
                     if (NP == 2) { av[0] *= sa3; av[1] *= sa3; av[2] *= sa3; av[3] *= sa3; }
                 } else {
                     if (SAVE >= 2) {
                         const int y = y0 + ty, x = x0 + tx;
-                        if (y < Yend && x < w) HS<BF>::st4(a2.a3s, ((b * h + y) * (long)w + x) * N1 + 4 * q, acc);
+                        if (y < Yend && x < w) HS<BF>::st4_nt(a2.a3s, ((b * h + y) * (long)w + x) * N1 + 4 * q, acc);
                     }
                     const lg_v2f a01 = NP == 2 ? gelu2_scaled((lg_v2f){acc.x, acc.y}, 0.70710678118654752440f, g3h) : gelu2_t<NP == 1>((lg_v2f){acc.x, acc.y});
                     const lg_v2f a23 = NP == 2 ? gelu2_scaled((lg_v2f){acc.z, acc.w}, 0.70710678118654752440f, g3h) : gelu2_t<NP == 1>((lg_v2f){acc.z, acc.w});

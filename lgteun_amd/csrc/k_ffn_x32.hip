@@ -199,8 +199,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 gelu2_both_t<NP == 1>((lg_v2f){acc[pb][2] * us, acc[pb][3] * us}, a23, g23);
                 av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                 if (inner) {
-                    HS<BF>::st4(a1.a1s, prow, make_float4(av[0], av[1], av[2], av[3]));
-                    HS<BF>::st4(a1.g1s, prow, make_float4(g01.x, g01.y, g23.x, g23.y));
+                    HS<BF>::st4_nt(a1.a1s, prow, make_float4(av[0], av[1], av[2], av[3]));
+                    HS<BF>::st4_nt(a1.g1s, prow, make_float4(g01.x, g01.y, g23.x, g23.y));
                 }
                 if (NP == 2) { av[0] *= sa1; av[1] *= sa1; av[2] *= sa1; av[3] *= sa1; }
             } else {
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int hy = m / HX, hx = m - hy * HX;
                 const int y = ya + hy, x = x0 + hx - 1;
                 const bool inner = m < npx && hx >= 1 && hx <= TX && x < w && y >= Y0 && y < Yend;
-                if (inner) HS<BF>::st4(a1.h2, ((b * h + y) * (long)w + x) * N1 + c0, hh);
+                if (inner) HS<BF>::st4_nt(a1.h2, ((b * h + y) * (long)w + x) * N1 + c0, hh);
             }
             int rp = ring0 + m;
             rp = rp >= RING * HX ? rp - RING * HX : rp;
@@ -405,10 +405,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (y < Yend && x < w) {
                         const long off = ((b * h + y) * (long)w + x) * N1 + 4 * qc;
                         if (a2.g3s) {   // five-tensor form: gelu(h3), gelu'(h3)
-                            HS<BF>::st4(a2.a3s, off, make_float4(av[0], av[1], av[2], av[3]));
-                            HS<BF>::st4(a2.g3s, off, make_float4(g01.x, g01.y, g23.x, g23.y));
+                            HS<BF>::st4_nt(a2.a3s, off, make_float4(av[0], av[1], av[2], av[3]));
+                            HS<BF>::st4_nt(a2.g3s, off, make_float4(g01.x, g01.y, g23.x, g23.y));
                         } else {        // k_ffn_dw_bwd_xs<32> re-evaluates both from the pre-activation
-                            HS<BF>::st4(a2.a3s, off, acc);
+                            HS<BF>::st4_nt(a2.a3s, off, acc);
                         }
                     }
                     if (NP == 2) { av[0] *= sa3; av[1] *= sa3; av[2] *= sa3; av[3] *= sa3; }

@@ -139,8 +139,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     av[0] = a01.x; av[1] = a01.y; av[2] = a23.x; av[3] = a23.y;
                     if (p0 + px < a.P) {
                         const long o = (p0 + px) * N1 + 16 * (2 * wave + m) + 4 * g;
-                        HS<false>::st4(a.a1s, o, make_float4(av[0], av[1], av[2], av[3]));
-                        HS<false>::st4(a.g1s, o, make_float4(g01.x, g01.y, g23.x, g23.y));
+                        HS<false>::st4_nt(a.a1s, o, make_float4(av[0], av[1], av[2], av[3]));
+                        HS<false>::st4_nt(a.g1s, o, make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
                     if (NP == 2) { av[0] *= sa1; av[1] *= sa1; av[2] *= sa1; av[3] *= sa1; }
                 } else {
@@ -308,8 +308,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int y = y0 + ty, x = x0 + tx;
                     if (y < h && x < w) {
                         const long off = ((b * h + y) * (long)w + x) * N1 + 4 * qc;
-                        HS<false>::st4(a.a3s, off, make_float4(av[0], av[1], av[2], av[3]));
-                        HS<false>::st4(a.g3s, off, make_float4(g01.x, g01.y, g23.x, g23.y));
+                        HS<false>::st4_nt(a.a3s, off, make_float4(av[0], av[1], av[2], av[3]));
+                        HS<false>::st4_nt(a.g3s, off, make_float4(g01.x, g01.y, g23.x, g23.y));
                     }
                     if (NP == 2) { av[0] *= sa3; av[1] *= sa3; av[2] *= sa3; av[3] *= sa3; }
                 } else {

@@ -367,8 +367,8 @@ __global__ void k_fftmix(FftArgs a) {
         const float2 ed = bin_edit_fwd(buf[q * LD + p], aw, ab, pw, pb, amp, pha);
         if (a.amp) {
             size_t o = ((size_t)plane * n + q) * (half + 1) + c;
-            a.amp[o] = amp;
-            a.pha[o] = pha;
+            __builtin_nontemporal_store(amp, a.amp + o);      // saved for the backward only: streaming stores
+            __builtin_nontemporal_store(pha, a.pha + o);
         }
         buf[q * LD + p] = ed;
     }
@@ -386,7 +386,7 @@ __global__ void k_fftmix(FftArgs a) {
             float sg[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) sg[k] = (v[k] > 0.f) ? 1.0f : ((v[k] < 0.f) ? -1.0f : 0.0f);
-            *reinterpret_cast<float4*>(a.sgn + (size_t)plane * n * n + i) = make_float4(sg[0], sg[1], sg[2], sg[3]);
+            { typedef float f4 __attribute__((ext_vector_type(4))); __builtin_nontemporal_store((f4){sg[0], sg[1], sg[2], sg[3]}, reinterpret_cast<f4*>(a.sgn + (size_t)plane * n * n + i)); }
         }
     }
 }
@@ -519,8 +519,8 @@ __global__ void __launch_bounds__(NTH, (LG >= 7 && NTH == 512) ? 4 : 1) k_fftmix
         const float2 ed = bin_edit_fwd(buf[q * HP + c], aw, ab, pw, pb, amp, pha);
         if (a.amp) {
             size_t o = ((size_t)plane * n + q) * (half + 1) + c;
-            a.amp[o] = amp;
-            a.pha[o] = pha;
+            __builtin_nontemporal_store(amp, a.amp + o);      // saved for the backward only: streaming stores
+            __builtin_nontemporal_store(pha, a.pha + o);
         }
         buf[q * HP + c] = ed;
     }
@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(NTH, (LG >= 7 && NTH == 512) ? 4 : 1) k_fftmix
             float sg[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) sg[u] = (v[u] > 0.f) ? 1.0f : ((v[u] < 0.f) ? -1.0f : 0.0f);
-            *reinterpret_cast<float4*>(a.sgn + (size_t)plane * n * n + i) = make_float4(sg[0], sg[1], sg[2], sg[3]);
+            { typedef float f4 __attribute__((ext_vector_type(4))); __builtin_nontemporal_store((f4){sg[0], sg[1], sg[2], sg[3]}, reinterpret_cast<f4*>(a.sgn + (size_t)plane * n * n + i)); }
         }
     }
     FFT_STAMP(7);
@@ -680,7 +680,7 @@ __global__ void k_fft_cols(FftArgs fa, FftBwdArgs ba, float2* __restrict__ S) {
             if (!BWD) {
                 float amp, pha;
                 buf[i] = bin_edit_fwd(buf[i], aw, ab, pw, pb, amp, pha);
-                if (fa.amp) { fa.amp[o] = amp; fa.pha[o] = pha; }
+                if (fa.amp) { __builtin_nontemporal_store(amp, fa.amp + o); __builtin_nontemporal_store(pha, fa.pha + o); }
             } else {
                 const float cw = (kx == 0 || kx == half) ? 1.0f : 2.0f;
                 buf[i] = bin_edit_bwd(buf[i], cw, nn, sa[u], sp[u], aw, ab, pw, pb, s_aw, s_ab, s_pw, s_pb);
@@ -761,7 +761,7 @@ __global__ void k_fft_rows_inv(const float2* __restrict__ S, float* __restrict__
                 float sg[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) sg[u] = (v[u] > 0.f) ? 1.0f : ((v[u] < 0.f) ? -1.0f : 0.0f);
-                reinterpret_cast<float4*>(sgn + base)[i4] = make_float4(sg[0], sg[1], sg[2], sg[3]);
+                { typedef float f4 __attribute__((ext_vector_type(4))); __builtin_nontemporal_store((f4){sg[0], sg[1], sg[2], sg[3]}, reinterpret_cast<f4*>(sgn + base) + i4); }
             }
         } else {
             reinterpret_cast<float4*>(out + base)[i4] = make_float4(v[0], v[1], v[2], v[3]);
@@ -965,7 +965,7 @@ __global__ void k_gfft_cols(FftArgs fa, FftBwdArgs ba, float2* __restrict__ S, i
         if (!BWD) {
             float amp, pha;
             v = bin_edit_fwd(g.lines[idx], aw, ab, pw, pb, amp, pha);
-            if (fa.amp) { fa.amp[o] = amp; fa.pha[o] = pha; }
+            if (fa.amp) { __builtin_nontemporal_store(amp, fa.amp + o); __builtin_nontemporal_store(pha, fa.pha + o); }
         } else {
             const float cw = (kx == 0 || kx == halfw) ? 1.0f : 2.0f;
             v = bin_edit_bwd(g.lines[idx], cw, nn, ba.amp[o], ba.pha[o], aw, ab, pw, pb, s_aw, s_ab, s_pw, s_pb);
