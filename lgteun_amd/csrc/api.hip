@@ -146,6 +146,7 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
         p->fft_full = (v & LG_VAR_FFT_FULL) ? 1 : 0;
         p->attn_bwd_core_m = (v & LG_VAR_ATTN_BWD_CORE_M) ? 1 : 0;
         p->ffn_bwd_bf16x3 = (v & LG_VAR_FFN_BWD_BF16X3) ? 1 : 0;
+        p->ffn_xs = (v & LG_VAR_FFN_XS) ? 1 : 0;
     }
     p->off = (int64_t*)malloc(sizeof(int64_t) * n_offsets);
     memcpy(p->off, offsets, sizeof(int64_t) * n_offsets);
@@ -245,7 +246,7 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     a1.w2 = P + pl->blk(stage, j, B_W2); a1.b2 = P + pl->blk(stage, j, B_B2);
     a1.P = (long)B * bb.h * bb.w;
     a1.hbf = pl->hidden_bf16(bb.e) ? 1 : 0;
-    a1.tile16 = pl->ffn_tile;
+    a1.tile16 = pl->ffn_tile ? pl->ffn_tile : ((pl->ffn_xs && bb.e == 16) ? 4 : 0);
     a1.wsplit = wsplit ? wsplit + ((size_t)stage * 5 + j) * (ffn_wsplit_bytes(8 * pl->cfg.C) / sizeof(float)) : nullptr;   // this block's slot, filled by prep_stages
     a1.wsplit_ready = (wsplit && bb.e >= 32) ? 1 : 0;
     a1.scales = pl->ffn_f16x2(bb.e) ? ffn_scales + ((size_t)stage * 5 + j) * 8 : nullptr;   // written by prep_stages for the stages of this call

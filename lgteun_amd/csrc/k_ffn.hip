@@ -1213,7 +1213,14 @@ int launch_ffn_fused(int e, const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t 
 #ifdef LG_BUILD_AB
     if (e == 16 && a1.tile16 == 2) return launch_ffn_fused_t<16>(a1, a2, s);   // round 1's per-tile kernel at e = 16: A/B builds only
 #endif
-    if (e == 16) return a1.tile16 == 1 ? launch_ffn_strip(a1, a2, s) : launch_ffn_xs(a1, a2, s);
+    if (e == 16 && a1.tile16 == 1) return launch_ffn_strip(a1, a2, s);
+    if (e == 16) {
+        // round 6: the register chain k_ffn_xr where it exists (f16 pairs, nothing or h2 / h3 saved); k_ffn_xs for the bf16 x 3 arithmetic, the
+        // other save modes and as the A/B variant LG_VAR_FFN_XS
+        const bool save = a1.h2 != nullptr, h2h3 = save && !a1.a1s && !a1.g1s && a2.a3s && !a2.g3s;
+        if (a1.tile16 == 0 && a1.scales && (!save || h2h3)) return launch_ffn_xr(a1, a2, s);
+        return launch_ffn_xs(a1, a2, s);
+    }
     if (e == 32) return (a1.tile16 == 0 && a1.wsplit) ? launch_ffn_x32(a1, a2, s) : launch_ffn_fused_t<32>(a1, a2, s);
     if (e == 64 && a1.tile16 == 0 && a1.wsplit && a1.h2) return launch_ffn_x64(a1, a2, s);   // two kernels, split-bf16 GEMMs
     return LG_FFN_NOT_FUSED;

@@ -1,0 +1,611 @@
+// k_ffn_xr: the fused feed_forward half-block (reference models/common/LGT.py:91-109 + pre_norm / residual :45-61) at e = 16 as a
+// REGISTER CHAIN (round 6) -- the local mixer's lane map (k_attn_m.hip) applied to the FFN:
+//
+//   y = x + W3 gelu( dw3x3( W2 gelu( W1 LN(x) + b1 ) + b2 ) ) + b3
+//
+// k_ffn_xs (k_ffn_x.hip, rounds 2 - 5) splits the hidden CHANNELS over the four waves of a workgroup: every wave needs all 64 channels
+// of gelu(h1) for its 16 rows of GEMM2, so LN(x) and gelu(h1) cross LDS as operand pieces and a 48-pixel chunk costs three workgroup
+// barriers -- eleven per 8-row step; the counters showed 52 % vector-active, 10 % matrix-busy and ~40 % of the SIMD's cycles in neither
+// pipe at two waves per SIMD.  Here a wave owns PIXELS, not channels:
+//
+//   lane l = (g = l >> 4, c = l & 15): pixel c of a 16-pixel block; of that pixel the lane holds channels 4 g .. 4 g + 3 of x and, after a
+//   product with the weights on the A side, rows 4 g + v of every 16-row output tile: channels 16 mt + 4 g + v of h1 / h2.
+//
+// That is at once (a) the coalesced 16-byte access for x, the residual and y, (b) the B operand of GEMM1 (k-slots 4 g + j = the lane's
+// four channels), (c) the C layout of GEMM1 -- and the lane's sixteen h1 values, in the order (tile, v), ARE k-slots of GEMM2 as long as
+// the weight fragments agree on which channel a slot means (they are built for it) -- (d) the C layout of GEMM2: float4 stores of h2
+// into the halo ring, and (e) in the spatial phase the same map again: dw3x3 from the ring, gelu, GEMM3, residual, the next block's
+// LayerNorm.  LN(x), gelu(h1) and gelu(h3) never touch LDS; a step has TWO workgroup barriers (ring rows complete / ring rows free);
+// the weight fragments are staged once per workgroup as [fragment][lane] 16-byte units (a conflict-free ds_read_b128 per use).
+//
+// Work split of an 8-row step of a 16-column strip: the 8 x 18 halo pixels are nine 16-pixel blocks -- wave w takes blocks 2 w and
+// 2 w + 1 together (two independent chains in one instruction stream: one block's GEMMs run under the other's GELU), the ninth goes to
+// the waves in turn; then wave w takes tile rows 2 w, 2 w + 1 of the spatial phase (their 3 x 3 windows share two ring rows).
+// Arithmetic: f16 pairs with the proven operand scales of k_ffn_prep.hip, exactly as k_ffn_xs<., 2> (split_bf16.h NP = 2).
+// LDS 79.0 KB (two workgroups per CU): ring [10][18][68] fp32 | 28 weight fragments | depthwise taps [64][9] | biases.
+#include "kernels.h"
+
+#include "hstore.h"
+#include "split_bf16.h"
+
+// In-kernel phase stamps (diagnostic build only, -DLG_STAMPS: tools/mkvariant.sh + tools/xr_stamps.py): branch-free, every wave of every workgroup stores
+// s_memtime at the phase boundaries of every step; no stamp executes in the product build.
+#ifndef LG_XR_GRID
+#define LG_XR_GRID 512   // resident workgroups (two per CU); 256 in the diagnostic one-workgroup-per-CU build
+#endif
+#ifdef LG_STAMPS
+__device__ unsigned long long g_xr_stamps[512 * 4 * 10 * 8];   // [workgroup][wave][step of the strip][stamp]
+#define XSTAMP_AT(si_, i) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)); \
+                       g_xr_stamps[(((blockIdx.x & 511) * 4 + wave) * 10 + (si_)) * 8 + (i)] = t__; } while (0)
+#define XSTAMP(i) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)); \
+                       g_xr_stamps[(((blockIdx.x & 511) * 4 + wave) * 10 + (stamp_si < 9 ? stamp_si : 9)) * 8 + (i)] = t__; } while (0)
+extern "C" __attribute__((visibility("default"))) int lg_debug_xr_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_xr_stamps), sizeof(g_xr_stamps));
+}
+#else
+#define XSTAMP_AT(si_, i) do { } while (0)
+#define XSTAMP(i) do { } while (0)
+#endif
+
+namespace xr {
+
+constexpr int E = 16, N1 = 64, TX = 16, HX = 18, TY = 8, RING = 10, LDR = 68;
+constexpr int NF1 = 8, NF2 = 16, NF3 = 4, NFRAG = NF1 + NF2 + NF3;
+// the tables FIRST: a ds_read's immediate offset has 16 bits, and behind the 48 KB ring every fragment / tap row / bias vector needed a base
+// register of its own (the first build: 28 + 16 + .. hoisted addresses, 206 spilled registers)
+constexpr size_t OFF_W = 0;
+constexpr size_t OFF_TAPS = OFF_W + (size_t)NFRAG * 64 * 16;
+constexpr size_t OFF_PAR = OFF_TAPS + (size_t)N1 * 9 * 4;
+constexpr int P_B1 = 0, P_B2 = 64, P_DWB = 128, P_B3 = 192, P_N1G = 208, P_N1B = 224, P_FLOATS = 240;
+constexpr size_t OFF_RING = OFF_PAR + (size_t)P_FLOATS * 4;
+constexpr size_t LDS_BYTES = OFF_RING + (size_t)RING * HX * LDR * 4;
+static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+static_assert(OFF_RING % 16 == 0 && OFF_TAPS % 16 == 0 && OFF_PAR % 16 == 0, "16-byte aligned LDS regions");
+
+#ifndef LG_XR_FENCES
+#define LG_XR_FENCES 1   // scheduling fences between the sections of a block: without them the scheduler interleaves every section of a step and spills (206 registers)
+#endif
+#define XR_FENCE() do { if (LG_XR_FENCES) __builtin_amdgcn_sched_barrier(0); } while (0)
+template <int N>
+struct IC { static constexpr int value = N; };
+
+__device__ __forceinline__ float xg_sum(float v) {   // sum over the four lane groups (lanes c, c + 16, c + 32, c + 48); every lane gets it
+    u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r.x) + __uint_as_float(r.y);
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ f32x4_t mfma_h(u32x4_t a, u32x4_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+// f16 pair of two (scaled) values: hi dword, lo dword
+__device__ __forceinline__ void pair2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = sb_cvt_f16x2(a, b);
+    lo = sb_cvt_f16x2(sb_res_lo(hi, a), sb_res_hi(hi, b));
+}
+
+}  // namespace xr
+
+// SAVE: 0 nothing; 3 the pre-activations h2 and h3 (the backward re-computes h1 from x: k_ffn1_bwd_xs) -- the two modes of the default path
+template <int SAVE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn_xr(Ffn1Args a1, Ffn2Args a2, int tiles_x, int strips_y, int nstrips,
+                                                                                       int SH) {
+    using namespace xr;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* ring = reinterpret_cast<float*>(smem_raw + OFF_RING);             // [RING * HX][LDR] h2
+    u32x4_t* sW = reinterpret_cast<u32x4_t*>(smem_raw + OFF_W);              // [NFRAG][64]
+    float* sTaps = reinterpret_cast<float*>(smem_raw + OFF_TAPS);            // [16 quads][9 taps][4 channels of the quad]
+    float* sPar = reinterpret_cast<float*>(smem_raw + OFF_PAR);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c_ = lane & 15, c = c_;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);   // provably wave-uniform: branches on it are scalar branches
+    const int h = a2.h, w = a2.w;
+    // operand scales (k_ffn_prep.hip; k_ffn_x.hip has the derivation): S1 h1, S2 h2, S3 (...) in the accumulators
+    const float sx = a1.scales[0], sa1 = a1.scales[1], sa3 = a1.scales[2], sw1 = a1.scales[3], sw2 = a1.scales[4], sw3 = a1.scales[5];
+    const float S1 = sx * sw1, S2 = sa1 * sw2, S3 = sa3 * sw3;
+    const float g1c = 0.70710678118654752440f / S1, g1h = 0.5f * sa1 / S1, g3h = 0.5f * sa3, inv2 = 1.0f / S2, inv3 = 1.0f / S3;   // (powers of two: exact)
+
+    XSTAMP_AT(9, 0);
+    // ---- once per (persistent) workgroup: weight fragments, taps, biases
+    {
+        const int t = threadIdx.x, ln = t >> 2, i = t & 3, lg = ln >> 4, lr = ln & 15;
+        // every value is requested before the first store
+        float2 v1[4], v2[8], v3[2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) v1[mt] = *reinterpret_cast<const float2*>(a1.w1 + (size_t)(16 * mt + lr) * E + 4 * lg + 2 * (i & 1));
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {   // f = mt2 * 2 + s: k-slots of dword i = channels 16 (2 s + (i >> 1)) + 4 lg + 2 (i & 1) + {0, 1}
+            const int mt2 = f >> 1, s = f & 1;
+            v2[f] = *reinterpret_cast<const float2*>(a1.w2 + (size_t)(16 * mt2 + lr) * N1 + 16 * (2 * s + (i >> 1)) + 4 * lg + 2 * (i & 1));
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) v3[s] = *reinterpret_cast<const float2*>(a2.w3 + (size_t)lr * N1 + 16 * (2 * s + (i >> 1)) + 4 * lg + 2 * (i & 1));
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(sW);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {   // GEMM1 (K = 16): two piece products share one 32-deep instruction: A = {w_lo | w_hi}, {w_hi | 0} against B = {x_hi | x_lo}, {x_hi | 0}
+            uint32_t hi, lo;
+            pair2(v1[mt].x * sw1, v1[mt].y * sw1, hi, lo);
+            d32[(2 * mt) * 256 + t] = i < 2 ? lo : hi;
+            d32[(2 * mt + 1) * 256 + t] = i < 2 ? hi : 0u;
+        }
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            uint32_t hi, lo;
+            pair2(v2[f].x * sw2, v2[f].y * sw2, hi, lo);
+            d32[(NF1 + 2 * f) * 256 + t] = hi;
+            d32[(NF1 + 2 * f + 1) * 256 + t] = lo;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint32_t hi, lo;
+            pair2(v3[s].x * sw3, v3[s].y * sw3, hi, lo);
+            d32[(NF1 + NF2 + 2 * s) * 256 + t] = hi;
+            d32[(NF1 + NF2 + 2 * s + 1) * 256 + t] = lo;
+        }
+        for (int k = t; k < N1 * 9; k += 256) sTaps[k] = a2.dww[(4 * (k / 36) + (k & 3)) * 9 + (k % 36) / 4];   // [quad][tap][u] <- dww[4 quad + u][tap]
+        if (t < N1) { sPar[P_B1 + t] = a1.b1[t] * S1; sPar[P_B2 + t] = a1.b2[t] * S2; sPar[P_DWB + t] = a2.dwb[t]; }
+        if (t < E) {
+            sPar[P_B3 + t] = a2.b3[t] * S3;
+            sPar[P_N1G + t] = a2.g ? a2.n1g[t] : 0.f;
+            sPar[P_N1B + t] = a2.g ? a2.n1b[t] : 0.f;
+        }
+    }
+    // LayerNorm affine of the lane's four channels, with the operand scale folded in
+    float4 lng = *reinterpret_cast<const float4*>(a1.ln2g + 4 * g), lnb = *reinterpret_cast<const float4*>(a1.ln2b + 4 * g);
+    lng = make_float4(lng.x * sx, lng.y * sx, lng.z * sx, lng.w * sx);
+    lnb = make_float4(lnb.x * sx, lnb.y * sx, lnb.z * sx, lnb.w * sx);
+    __syncthreads();
+    XSTAMP_AT(9, 1);
+
+#pragma unroll 1
+    for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+        int t_ = strip;
+        const int tx_i = t_ % tiles_x;
+        t_ /= tiles_x;
+        const int sy = t_ % strips_y;
+        const long b = t_ / strips_y;
+        const int x0 = tx_i * TX, Y0 = sy * SH, Yend = min(Y0 + SH, h);
+
+        // x vector of the lane's pixel of halo block blk of the row block starting at ya: unconditional, from a clamped (always valid) address
+        auto xload = [&](int ya, int blk) -> float4 {
+            const int m = 16 * blk + c;
+            const int hy = m / HX, hx = m - hy * HX;
+            const int y = clampi(ya + hy, 0, h - 1), x = clampi(x0 + hx - 1, 0, w - 1);
+            return *reinterpret_cast<const float4*>(a1.x + ((b * h + y) * (long)w + x) * E + 4 * g);
+        };
+
+        // h2 of NB halo blocks (blk0, blk0 + 1, ..) of halo rows [ya, ..) -> ring.  LN -> GEMM1 -> GELU -> GEMM2, all in registers.
+        // PART 0: the whole block.  The NINTH block of a step is split between two waves along the hidden channels (a whole block on one wave
+        // held the other three at the barrier for 22 % of a step): PART 1 = h1 tiles 0, 1 = k-step 0 of GEMM2, with the bias, stored to the ring;
+        // PART 2 = tiles 2, 3 = k-step 1, kept in registers (`part`) and ADDED to the ring behind the barrier by ninth_add() -- on the wave that owns
+        // the step's last two tile rows, the only reader of those ring pixels before the next barrier.
+        // Every LDS operand is requested a section ahead of its use (a section = the code between two scheduling fences): the weight fragments of
+        // GEMM1 in front of the LayerNorm arithmetic, those of GEMM2's first tile in front of the GELUs, each further tile's behind the previous
+        // tile's MFMAs, whose results leave one tile later.
+        struct Geo { float mk; int rp; bool inner; long prow; };
+        auto halo = [&](auto nbc, auto partc, int ya, int npx, int blk0, const float4* xin, f32x4_t* part, Geo* geo_out) {
+            constexpr int NB = decltype(nbc)::value, PART = decltype(partc)::value;
+            constexpr int MT0 = PART == 2 ? 2 : 0, NMT = PART == 0 ? 4 : 2;      // h1 tiles [MT0, MT0 + NMT)
+            constexpr int S0 = PART == 2 ? 1 : 0, NS = PART == 0 ? 2 : 1;        // k-steps of GEMM2
+            int c = c_;
+            asm volatile("" : "+v"(c));    // the block geometry (row / column of the lane's halo pixel) is re-derived per call: as loop invariants of the
+                                            // step loop its ~30 values per lane were hoisted and spilled
+            const int ring0 = ((ya - Y0 + 1) % RING) * HX;
+            // GEMM1's fragments and biases: in flight under the LayerNorm
+            u32x4_t wa[NMT], wb[NMT];
+            float4 b1v[NMT];
+#pragma unroll
+            for (int i = 0; i < NMT; ++i) {
+                wa[i] = sW[(2 * (MT0 + i)) * 64 + lane];
+                wb[i] = sW[(2 * (MT0 + i) + 1) * 64 + lane];
+                b1v[i] = *reinterpret_cast<const float4*>(sPar + P_B1 + 16 * (MT0 + i) + 4 * g);
+            }
+            u32x4_t xb1[NB], xb2[NB];
+            Geo geo[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int m = 16 * (blk0 + nb) + c;
+                const int hy = m / HX, hx = m - hy * HX;
+                const int y = ya + hy, x = x0 + hx - 1;
+                const bool in = m < npx && y >= 0 && y < h && x >= 0 && x < w;
+                geo[nb].mk = in ? inv2 : 0.0f;            // dep_conv zero-pads h2; the mask also takes S2 out of the accumulator
+                int r_ = ring0 + m;
+                r_ = r_ >= RING * HX ? r_ - RING * HX : r_;
+                geo[nb].rp = m < npx ? r_ : -1;
+                geo[nb].inner = SAVE && m < npx && hx >= 1 && hx <= TX && x < w && y >= Y0 && y < Yend;
+                geo[nb].prow = ((b * h + y) * (long)w + x) * N1 + 4 * g;
+                const float4 xv = xin[nb];
+                const float s = xg_sum((xv.x + xv.y) + (xv.z + xv.w));
+                const float mu = s * (1.0f / E);
+                const float d0 = xv.x - mu, d1 = xv.y - mu, d2 = xv.z - mu, d3 = xv.w - mu;
+                const float vs = xg_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+                const float rstd = __builtin_amdgcn_rsqf(vs * (1.0f / E) + LG_EPS);
+                uint32_t h01, l01, h23, l23;
+                pair2(d0 * rstd * lng.x + lnb.x, d1 * rstd * lng.y + lnb.y, h01, l01);
+                pair2(d2 * rstd * lng.z + lnb.z, d3 * rstd * lng.w + lnb.w, h23, l23);
+                xb1[nb] = (u32x4_t){h01, h23, l01, l23};
+                xb2[nb] = (u32x4_t){h01, h23, 0u, 0u};
+            }
+            XR_FENCE();
+            // ---- GEMM1: every tile's MFMAs are issued before the first GELU reads a result
+            f32x4_t a1c[NB][NMT];
+#pragma unroll
+            for (int i = 0; i < NMT; ++i)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    f32x4_t acc = {b1v[i].x, b1v[i].y, b1v[i].z, b1v[i].w};
+                    acc = mfma_h(wa[i], xb1[nb], acc);
+                    a1c[nb][i] = mfma_h(wb[i], xb2[nb], acc);
+                }
+            // GEMM2's first tile: fragments and bias requested now, in flight under the GELUs
+            u32x4_t wh[NS], wl[NS];
+            float4 b2v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { wh[s] = sW[(NF1 + 2 * (S0 + s)) * 64 + lane]; wl[s] = sW[(NF1 + 2 * (S0 + s) + 1) * 64 + lane]; }
+            if (PART != 2) b2v = *reinterpret_cast<const float4*>(sPar + P_B2 + 4 * g);
+            XR_FENCE();
+            // ---- GELU -> f16 pairs of s_a1 gelu(h1): hi / lo [tile][channel pair]
+            uint32_t ghi[NB][NMT][2], glo[NB][NMT][2];
+#pragma unroll
+            for (int i = 0; i < NMT; ++i) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const lg_v2f a01 = gelu2_scaled((lg_v2f){a1c[nb][i][0], a1c[nb][i][1]}, g1c, g1h);
+                    const lg_v2f a23 = gelu2_scaled((lg_v2f){a1c[nb][i][2], a1c[nb][i][3]}, g1c, g1h);
+                    pair2(a01.x, a01.y, ghi[nb][i][0], glo[nb][i][0]);
+                    pair2(a23.x, a23.y, ghi[nb][i][1], glo[nb][i][1]);
+                    asm volatile("" : "+v"(ghi[nb][i][0]), "+v"(glo[nb][i][0]), "+v"(ghi[nb][i][1]), "+v"(glo[nb][i][1]));
+                }
+                XR_FENCE();
+            }
+            // ---- GEMM2 (K = 64: two 32-deep steps, k-slot j of step s = channel 16 (2 s + (j >> 2)) + 4 g + (j & 3)) -> ring (+ save)
+            auto leave = [&](int mt2, const f32x4_t (&acc)[NB]) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    if (PART == 2) { part[mt2] = acc[nb]; continue; }
+                    const float mk = geo[nb].mk;
+                    const float4 hh = make_float4(acc[nb][0] * mk, acc[nb][1] * mk, acc[nb][2] * mk, acc[nb][3] * mk);
+                    if (SAVE && PART == 0 && geo[nb].inner) HS<false>::st4_nt(a1.h2, geo[nb].prow + 16 * mt2, hh);
+                    if (geo[nb].rp >= 0) *reinterpret_cast<float4*>(ring + geo[nb].rp * LDR + 16 * mt2 + 4 * g) = hh;
+                }
+            };
+            f32x4_t accp[NB];
+#pragma unroll
+            for (int mt2 = 0; mt2 < 4; ++mt2) {
+                f32x4_t acc[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = (f32x4_t){b2v.x, b2v.y, b2v.z, b2v.w};
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const u32x4_t bh = {ghi[nb][2 * s][0], ghi[nb][2 * s][1], ghi[nb][2 * s + 1][0], ghi[nb][2 * s + 1][1]};
+                        const u32x4_t bl = {glo[nb][2 * s][0], glo[nb][2 * s][1], glo[nb][2 * s + 1][0], glo[nb][2 * s + 1][1]};
+                        acc[nb] = mfma_h(wl[s], bh, acc[nb]);     // small terms first: lo hi, hi lo, hi hi
+                        acc[nb] = mfma_h(wh[s], bl, acc[nb]);
+                        acc[nb] = mfma_h(wh[s], bh, acc[nb]);
+                    }
+                if (mt2 < 3) {   // the next tile's operands: requested behind this tile's MFMAs
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        wh[s] = sW[(NF1 + 2 * (2 * (mt2 + 1) + S0 + s)) * 64 + lane];
+                        wl[s] = sW[(NF1 + 2 * (2 * (mt2 + 1) + S0 + s) + 1) * 64 + lane];
+                    }
+                    if (PART != 2) b2v = *reinterpret_cast<const float4*>(sPar + P_B2 + 16 * (mt2 + 1) + 4 * g);
+                }
+                if (mt2 > 0) leave(mt2 - 1, accp);   // the previous tile's results leave while this tile's MFMAs run
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) accp[nb] = acc[nb];
+                XR_FENCE();
+            }
+            leave(3, accp);
+            if (PART == 2) *geo_out = geo[0];
+        };
+        // Two whole blocks as ONE software pipeline (the step's main work): block A's GEMM2 tile j (6 MFMAs) is issued in the section that holds block
+        // B's GELU of tile j -- matrix and vector work side by side in one instruction stream, whatever the SIMD's other wave is doing (two
+        // co-resident workgroups start in lockstep: with both waves of a SIMD in their GELUs, then both in their GEMM2s, steps took 17.4 k ticks
+        // against 13.0 k once the workgroups had drifted apart).
+        auto halo_pair = [&](int ya, int blk0, const float4* xin) {
+            constexpr int npx = TY * HX;
+            int c = c_;
+            asm volatile("" : "+v"(c));
+            const int ring0 = ((ya - Y0 + 1) % RING) * HX;
+            u32x4_t wa[4], wb[4];
+            float4 b1v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wa[i] = sW[(2 * i) * 64 + lane];
+                wb[i] = sW[(2 * i + 1) * 64 + lane];
+                b1v[i] = *reinterpret_cast<const float4*>(sPar + P_B1 + 16 * i + 4 * g);
+            }
+            u32x4_t xb1[2], xb2[2];
+            Geo geo[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int m = 16 * (blk0 + nb) + c;
+                const int hy = m / HX, hx = m - hy * HX;
+                const int y = ya + hy, x = x0 + hx - 1;
+                const bool in = y >= 0 && y < h && x >= 0 && x < w;
+                geo[nb].mk = in ? inv2 : 0.0f;
+                int r_ = ring0 + m;
+                r_ = r_ >= RING * HX ? r_ - RING * HX : r_;
+                geo[nb].rp = r_;
+                geo[nb].inner = SAVE && hx >= 1 && hx <= TX && x < w && y >= Y0 && y < Yend;
+                geo[nb].prow = ((b * h + y) * (long)w + x) * N1 + 4 * g;
+                const float4 xv = xin[nb];
+                const float s = xg_sum((xv.x + xv.y) + (xv.z + xv.w));
+                const float mu = s * (1.0f / E);
+                const float d0 = xv.x - mu, d1 = xv.y - mu, d2 = xv.z - mu, d3 = xv.w - mu;
+                const float vs = xg_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+                const float rstd = __builtin_amdgcn_rsqf(vs * (1.0f / E) + LG_EPS);
+                uint32_t h01, l01, h23, l23;
+                pair2(d0 * rstd * lng.x + lnb.x, d1 * rstd * lng.y + lnb.y, h01, l01);
+                pair2(d2 * rstd * lng.z + lnb.z, d3 * rstd * lng.w + lnb.w, h23, l23);
+                xb1[nb] = (u32x4_t){h01, h23, l01, l23};
+                xb2[nb] = (u32x4_t){h01, h23, 0u, 0u};
+            }
+            XR_FENCE();
+            f32x4_t a1c[2][4];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4_t acc = {b1v[i].x, b1v[i].y, b1v[i].z, b1v[i].w};
+                    acc = mfma_h(wa[i], xb1[nb], acc);
+                    a1c[nb][i] = mfma_h(wb[i], xb2[nb], acc);
+                }
+            u32x4_t wh[2], wl[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { wh[s] = sW[(NF1 + 2 * s) * 64 + lane]; wl[s] = sW[(NF1 + 2 * s + 1) * 64 + lane]; }
+            float4 b2v = *reinterpret_cast<const float4*>(sPar + P_B2 + 4 * g);
+            XR_FENCE();
+            uint32_t ghi[2][4][2], glo[2][4][2];
+            auto gelu_tile = [&](int nb, int i) {
+                const lg_v2f a01 = gelu2_scaled((lg_v2f){a1c[nb][i][0], a1c[nb][i][1]}, g1c, g1h);
+                const lg_v2f a23 = gelu2_scaled((lg_v2f){a1c[nb][i][2], a1c[nb][i][3]}, g1c, g1h);
+                pair2(a01.x, a01.y, ghi[nb][i][0], glo[nb][i][0]);
+                pair2(a23.x, a23.y, ghi[nb][i][1], glo[nb][i][1]);
+                asm volatile("" : "+v"(ghi[nb][i][0]), "+v"(glo[nb][i][0]), "+v"(ghi[nb][i][1]), "+v"(glo[nb][i][1]));
+            };
+            auto gemm2_tile = [&](int nb) -> f32x4_t {
+                f32x4_t acc = {b2v.x, b2v.y, b2v.z, b2v.w};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const u32x4_t bh = {ghi[nb][2 * s][0], ghi[nb][2 * s][1], ghi[nb][2 * s + 1][0], ghi[nb][2 * s + 1][1]};
+                    const u32x4_t bl = {glo[nb][2 * s][0], glo[nb][2 * s][1], glo[nb][2 * s + 1][0], glo[nb][2 * s + 1][1]};
+                    acc = mfma_h(wl[s], bh, acc);     // small terms first: lo hi, hi lo, hi hi
+                    acc = mfma_h(wh[s], bl, acc);
+                    acc = mfma_h(wh[s], bh, acc);
+                }
+                return acc;
+            };
+            auto next_w2 = [&](int mt2) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    wh[s] = sW[(NF1 + 2 * (2 * mt2 + s)) * 64 + lane];
+                    wl[s] = sW[(NF1 + 2 * (2 * mt2 + s) + 1) * 64 + lane];
+                }
+                b2v = *reinterpret_cast<const float4*>(sPar + P_B2 + 16 * mt2 + 4 * g);
+            };
+            auto leave = [&](int nb, int mt2, const f32x4_t& acc) {
+                const float mk = geo[nb].mk;
+                const float4 hh = make_float4(acc[0] * mk, acc[1] * mk, acc[2] * mk, acc[3] * mk);
+                if (SAVE && geo[nb].inner) HS<false>::st4_nt(a1.h2, geo[nb].prow + 16 * mt2, hh);
+                *reinterpret_cast<float4*>(ring + geo[nb].rp * LDR + 16 * mt2 + 4 * g) = hh;
+            };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { gelu_tile(0, i); XR_FENCE(); }
+            f32x4_t accp;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {        // block A's GEMM2 tile j beside block B's GELU of tile j
+                const f32x4_t acc = gemm2_tile(0);
+                next_w2(j < 3 ? j + 1 : 0);
+                gelu_tile(1, j);
+                if (j > 0) leave(0, j - 1, accp);
+                accp = acc;
+                XR_FENCE();
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {        // block B's GEMM2; the previous tile's results leave beside it
+                const f32x4_t acc = gemm2_tile(1);
+                if (j < 3) next_w2(j + 1);
+                leave(j > 0 ? 1 : 0, j > 0 ? j - 1 : 3, accp);
+                accp = acc;
+                XR_FENCE();
+            }
+            leave(1, 3, accp);
+        };
+        // the second half of a split ninth block joins the first in the ring (and, in the saving instance, leaves for HBM as the sum)
+        auto ninth_add = [&](const f32x4_t (&part)[4], const Geo& ge) {
+            if (ge.rp < 0) return;
+#pragma unroll
+            for (int mt2 = 0; mt2 < 4; ++mt2) {
+                float4* rp4 = reinterpret_cast<float4*>(ring + ge.rp * LDR + 16 * mt2 + 4 * g);
+                float4 r = *rp4;
+                r.x += part[mt2][0] * ge.mk; r.y += part[mt2][1] * ge.mk; r.z += part[mt2][2] * ge.mk; r.w += part[mt2][3] * ge.mk;
+                *rp4 = r;
+                if (SAVE && ge.inner) HS<false>::st4_nt(a1.h2, ge.prow + 16 * mt2, r);
+            }
+        };
+
+        // ---- strip prologue: halo rows Y0 - 1, Y0 (36 pixels: blocks 0 .. 2, one per wave)
+        {
+            const float4 xp = xload(Y0 - 1, wave < 3 ? wave : 0);
+            __syncthreads();     // the previous strip's spatial phase is done with the ring
+            if (uwave < 3) halo(IC<1>{}, IC<0>{}, Y0 - 1, 2 * HX, wave, &xp, nullptr, nullptr);
+            XSTAMP_AT(9, 2);
+        }
+        float4 xh[3];
+        xh[0] = xload(Y0 + 1, 2 * wave); xh[1] = xload(Y0 + 1, 2 * wave + 1); xh[2] = xload(Y0 + 1, 8);
+#pragma unroll 1
+        for (int y0 = Y0; y0 < Yend; y0 += TY) {
+            const int si = (y0 - Y0) >> 3;
+            // roles rotate with the step: `role` 3 owns tile rows 6, 7 and the second half of the ninth block, role 1 its first half
+            const int role = (uwave + si) & 3, ty0 = 2 * role;
+#ifdef LG_STAMPS
+            const int stamp_si = si;
+#endif
+            XSTAMP(0);
+            // the residual rows of the spatial phase, requested a phase ahead
+            float4 xres[2];
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2) {
+                const int y = min(y0 + ty0 + r2, h - 1), x = min(x0 + c, w - 1);
+                xres[r2] = *reinterpret_cast<const float4*>(a2.x + ((b * h + y) * (long)w + x) * E + 4 * g);
+            }
+            halo_pair(y0 + 1, 2 * wave, xh);
+            XSTAMP(1);
+            f32x4_t part9[4];
+            Geo geo9;
+            if (role == 1) halo(IC<1>{}, IC<1>{}, y0 + 1, TY * HX, 8, xh + 2, nullptr, nullptr);
+            if (role == 3) halo(IC<1>{}, IC<2>{}, y0 + 1, TY * HX, 8, xh + 2, part9, &geo9);
+            XSTAMP(2);
+            // next step's halo operands: in flight across the spatial phase (clamped addresses: harmless behind the last step)
+            xh[0] = xload(y0 + TY + 1, 2 * wave); xh[1] = xload(y0 + TY + 1, 2 * wave + 1); xh[2] = xload(y0 + TY + 1, 8);
+            __syncthreads();     // ring rows y0 - 1 .. y0 + 8 complete (but for the ninth block's second half)
+            XSTAMP(3);
+            if (role == 3) ninth_add(part9, geo9);
+            // ---- spatial phase: tile rows ty0, ty0 + 1: dw3x3 over the ring -> gelu -> GEMM3 -> + bias + residual -> y (+ planar LN half)
+            {
+                const int sbase = (y0 - Y0) % RING;
+                const float* rrow[4];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    int sl = sbase + ty0 + r4;
+                    sl = sl >= RING ? sl - RING : sl;
+                    sl = sl >= RING ? sl - RING : sl;
+                    rrow[r4] = ring + (sl * HX + c) * LDR + 4 * g;
+                }
+                float h3[2][4][4];
+                // sixteen sections (channel quad m, ring row r4); each requests the next one's three ring vectors, section (m, 1) the next quad's taps
+                // (stored pair-interleaved, [quad][tap][channel of the quad]: one 16-byte read IS the two packed operands of a tap)
+                float4 tq[9], tqn[9], rv[3], rvn[3], bq, bqn;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { tq[k] = *reinterpret_cast<const float4*>(sTaps + 36 * g + 4 * k); tqn[k] = tq[k]; }
+                bq = *reinterpret_cast<const float4*>(sPar + P_DWB + 4 * g); bqn = bq;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) rv[dx] = *reinterpret_cast<const float4*>(rrow[0] + dx * LDR);
+                lg_v2f acc01[2], acc23[2];
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int m = it >> 2, r4 = it & 3;
+                    if (r4 == 0) {
+                        acc01[0] = acc01[1] = (lg_v2f){bq.x, bq.y};
+                        acc23[0] = acc23[1] = (lg_v2f){bq.z, bq.w};
+                    }
+                    if (it < 15) {
+                        const int mn = (it + 1) >> 2, rn = (it + 1) & 3;
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) rvn[dx] = *reinterpret_cast<const float4*>(rrow[rn] + dx * LDR + 16 * mn);
+                    }
+                    if (r4 == 1 && m < 3) {
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) tqn[k] = *reinterpret_cast<const float4*>(sTaps + 36 * (4 * (m + 1) + g) + 4 * k);
+                        bqn = *reinterpret_cast<const float4*>(sPar + P_DWB + 16 * (m + 1) + 4 * g);
+                    }
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const lg_v2f v01 = (lg_v2f){rv[dx].x, rv[dx].y}, v23 = (lg_v2f){rv[dx].z, rv[dx].w};
+                        if (r4 <= 2) {
+                            const float4 t4 = tq[r4 * 3 + dx];
+                            acc01[0] = (lg_v2f){t4.x, t4.y} * v01 + acc01[0]; acc23[0] = (lg_v2f){t4.z, t4.w} * v23 + acc23[0];
+                        }
+                        if (r4 >= 1) {
+                            const float4 t4 = tq[(r4 - 1) * 3 + dx];
+                            acc01[1] = (lg_v2f){t4.x, t4.y} * v01 + acc01[1]; acc23[1] = (lg_v2f){t4.z, t4.w} * v23 + acc23[1];
+                        }
+                    }
+                    // (a scheduling fence alone does not do it: the instruction order the scheduler starts from had the second row's chain of every quad
+                    //  behind the first rows of all four, its twelve ring vectors spilled; an empty asm that "modifies" the sums pins them here)
+                    asm volatile("" : "+v"(acc01[0]), "+v"(acc23[0]), "+v"(acc01[1]), "+v"(acc23[1]));
+                    if (r4 == 3) {
+#pragma unroll
+                        for (int r2 = 0; r2 < 2; ++r2) { h3[r2][m][0] = acc01[r2].x; h3[r2][m][1] = acc01[r2].y; h3[r2][m][2] = acc23[r2].x; h3[r2][m][3] = acc23[r2].y; }
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) tq[k] = tqn[k];
+                        bq = bqn;
+                    }
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) rv[dx] = rvn[dx];
+                    XR_FENCE();
+                }
+                // GEMM3's fragments, bias, the next block's LayerNorm affine: requested in front of the GELUs
+                u32x4_t w3h[2], w3l[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) { w3h[s] = sW[(NF1 + NF2 + 2 * s) * 64 + lane]; w3l[s] = sW[(NF1 + NF2 + 2 * s + 1) * 64 + lane]; }
+                const float4 b3v = *reinterpret_cast<const float4*>(sPar + P_B3 + 4 * g);
+                const float4 ng = *reinterpret_cast<const float4*>(sPar + P_N1G + 4 * g), nbv = *reinterpret_cast<const float4*>(sPar + P_N1B + 4 * g);
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    const int y = y0 + ty0 + r2, x = x0 + c;
+                    const bool ok = y < Yend && x < w;
+                    uint32_t phi[4][2], plo[4][2];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        if (SAVE && ok) HS<false>::st4_nt(a2.a3s, ((b * h + y) * (long)w + x) * N1 + 16 * m + 4 * g, make_float4(h3[r2][m][0], h3[r2][m][1], h3[r2][m][2], h3[r2][m][3]));
+                        const lg_v2f a01 = gelu2_scaled((lg_v2f){h3[r2][m][0], h3[r2][m][1]}, 0.70710678118654752440f, g3h);
+                        const lg_v2f a23 = gelu2_scaled((lg_v2f){h3[r2][m][2], h3[r2][m][3]}, 0.70710678118654752440f, g3h);
+                        pair2(a01.x, a01.y, phi[m][0], plo[m][0]);
+                        pair2(a23.x, a23.y, phi[m][1], plo[m][1]);
+                    }
+                    f32x4_t o = {b3v.x, b3v.y, b3v.z, b3v.w};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const u32x4_t bh = {phi[2 * s][0], phi[2 * s][1], phi[2 * s + 1][0], phi[2 * s + 1][1]};
+                        const u32x4_t bl = {plo[2 * s][0], plo[2 * s][1], plo[2 * s + 1][0], plo[2 * s + 1][1]};
+                        o = mfma_h(w3l[s], bh, o);
+                        o = mfma_h(w3h[s], bl, o);
+                        o = mfma_h(w3h[s], bh, o);
+                    }
+                    // ---- epilogue in registers: residual, store, LayerNorm statistics of the next block across the four lane groups
+                    const float o0 = o[0] * inv3 + xres[r2].x, o1 = o[1] * inv3 + xres[r2].y, o2 = o[2] * inv3 + xres[r2].z, o3 = o[3] * inv3 + xres[r2].w;
+                    if (ok) *reinterpret_cast<float4*>(a2.y + ((b * h + y) * (long)w + x) * E + 4 * g) = make_float4(o0, o1, o2, o3);
+                    if (a2.g) {
+                        const float s = xg_sum((o0 + o1) + (o2 + o3));
+                        const float mu = s * (1.0f / E);
+                        const float d0 = o0 - mu, d1 = o1 - mu, d2 = o2 - mu, d3 = o3 - mu;
+                        const float vs = xg_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+                        const float rstd = __builtin_amdgcn_rsqf(vs * (1.0f / E) + LG_EPS);
+                        if (ok && g >= 2) {      // channels 8..15 = the global-mixer half, planar [B, e/2, h, w]
+                            const long hw = (long)h * w, sp = (long)y * w + x;
+                            float* dst = a2.g + (b * (E / 2) + (4 * g - E / 2)) * hw + sp;
+                            dst[0] = d0 * rstd * ng.x + nbv.x;
+                            dst[hw] = d1 * rstd * ng.y + nbv.y;
+                            dst[2 * hw] = d2 * rstd * ng.z + nbv.z;
+                            dst[3 * hw] = d3 * rstd * ng.w + nbv.w;
+                        }
+                    }
+                    XR_FENCE();
+                }
+            }
+            XSTAMP(4);
+            __syncthreads();     // the ring rows this step read are free for the next step's halo pass
+            XSTAMP(5);
+        }   // steps of the strip
+    }   // strips of this workgroup
+}
+
+int launch_ffn_xr(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
+    using namespace xr;
+    ProfScope prof__(LG_K_FFN2, s);
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_xr<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xr<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) { lg_set_error("ffn_xr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_once.done();
+    }
+    if (!a1.scales || a1.hbf) { lg_set_error("ffn_xr: the f16-pair kernel needs the operand scales and fp32 storage"); return -2; }
+    const bool save = a1.h2 != nullptr;
+    if (save && (a1.a1s || a1.g1s || !a2.a3s || a2.g3s)) { lg_set_error("ffn_xr: saves h2 / h3 only"); return -2; }
+    const int tiles_x = (a2.w + 15) / 16;
+    // strip height: the tallest multiple of 8 rows that still yields >= 512 strips (two resident workgroups per CU), at least 16
+    int SH = (a2.h + 7) / 8 * 8;
+    while (SH > 16 && (long)a2.B * tiles_x * ((a2.h + SH - 1) / SH) < LG_XR_GRID) SH = (SH / 2 + 7) / 8 * 8;
+    const int strips_y = (a2.h + SH - 1) / SH;
+    const int nstrips = a2.B * tiles_x * strips_y;
+    const int grid = nstrips < LG_XR_GRID ? nstrips : LG_XR_GRID;
+    if (save) k_ffn_xr<3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    else k_ffn_xr<0><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    LG_CHECK_LAUNCH();
+    return 0;
+}

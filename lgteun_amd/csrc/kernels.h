@@ -122,7 +122,7 @@ struct Ffn1Args {
     void* g1s;       // optional save [P,4e]: gelu'(h1)       (backward never re-evaluates GELU)
     void* h2;        // [P,4e] = W2 gelu(W1 LN(x) + b1) + b2
     int hbf;         // hidden storage: 0 fp32, 1 bf16 (hstore.h)
-    int tile16;      // A/B switch (lg_plan::ffn_tile): 0 = split-bf16 kernels (default), 1 = f32-MFMA strip kernel, 2 = f32-MFMA per-tile kernel, 3 = software-pipelined split kernel k_ffn_xp (e = 16)
+    int tile16;      // A/B switch (lg_plan::ffn_tile / ffn_xs): 0 = split-arithmetic kernels (default), 1 = f32-MFMA strip kernel, 2 = f32-MFMA per-tile kernel, 3 = software-pipelined split kernel k_ffn_xp (e = 16), 4 = the channel-split k_ffn_xs where the register-chain k_ffn_xr is the default (e = 16)
     const float *ln2g, *ln2b, *w1, *b1, *w2, *b2;
     long P;
     void* wsplit;    // workspace scratch for pre-split weight fragments (ffn_wsplit_bytes; k_ffn_x32.hip), or nullptr
@@ -157,6 +157,7 @@ int launch_ffn2(int e, const Ffn2Args& a, hipStream_t s);
 #define LG_FFN_NOT_FUSED (-1000)
 int launch_ffn_fused(int e, const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s);
 int launch_ffn_xs(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s);   // e = 16, fp32 storage (k_ffn_x.hip)
+int launch_ffn_xr(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s);   // e = 16, f16 pairs, fp32 storage: the register chain (k_ffn_xr.hip, round 6)
 int launch_ffn_xp(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s);   // e = 16, software-pipelined halo pass (k_ffn_xp.hip)
 int launch_ffn_x32(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s);  // e = 32, fp32 storage (k_ffn_x32.hip)
 size_t ffn_wsplit_bytes(int e);   // bytes of a1.wsplit for hidden width 4e

@@ -222,3 +222,22 @@ def test_ffn_forward_ab_kernels_agree_with_the_default(gpu, impl, monkeypatch):
             monkeypatch.delenv('LG_FFN_IMPL', raising=False)
         den = float((want - x.double().cpu()).norm())
         assert float((got - want).norm()) <= 2e-6 * den, (blk, float((got - want).norm()) / den)
+
+
+def test_register_chain_ffn_agrees_with_the_channel_split_kernel(gpu, monkeypatch):
+    """round 6: k_ffn_xr (a wave owns pixels; LN(x), gelu(h1), gelu(h3) stay in registers) against rounds 2 - 5's k_ffn_xs (LG_FFN_FWD=xs: a wave
+    owns hidden channels, operand pieces through LDS) -- the same f16-pair arithmetic under the same scales, products summed in another
+    order: 1e-6 of the half-block's own contribution at sizes that exercise partial strips (24 rows), one-tile planes and the bench plane"""
+    from gpu_helpers import Ops, make_module
+    rng = np.random.default_rng(78)
+    for B, n in ((2, 32), (1, 16), (3, 48), (2, 128)):
+        x = T((rng.standard_normal((B, n, n, 16)) * 1.5 + 0.3).astype(np.float32)).cuda()
+        monkeypatch.delenv('LG_FFN_FWD', raising=False)
+        got = Ops(make_module(4, 1), n, n).block(0, 0, 2, x).double().cpu()
+        monkeypatch.setenv('LG_FFN_FWD', 'xs')
+        try:
+            want = Ops(make_module(4, 1), n, n).block(0, 0, 2, x).double().cpu()
+        finally:
+            monkeypatch.delenv('LG_FFN_FWD', raising=False)
+        den = float((want - x.double().cpu()).norm())
+        assert float((got - want).norm()) <= 1e-6 * den, (B, n, float((got - want).norm()) / den)

@@ -30,6 +30,18 @@ for i in range(reps):
     ev[i + 1].record()
 torch.cuda.synchronize()
 ts = sorted(ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(reps))
+# the FFN kernel alone: the library's live timing facility (HIP events around the launch, on its stream) -- the op entry also runs the scale prep
+import ctypes
+from lgteun_amd import _lib
+L = _lib.lib()
+_lib.check(L.lg_prof_enable(_lib.KERNEL_IDS['ffn'], 4 * reps), 'lg_prof_enable')
+for i in range(reps):
+    y = ops.block(0, blk, 2, x)
+torch.cuda.synchronize()
+tot_ms, n_l = ctypes.c_double(), ctypes.c_int64()
+_lib.check(L.lg_prof_read(ctypes.byref(tot_ms), ctypes.byref(n_l)), 'lg_prof_read')
+L.lg_prof_disable()
+print(f'kernel alone (lg_prof, {n_l.value} launches): {tot_ms.value / max(n_l.value, 1) * 1e3:.2f} us   lib={os.environ.get("LGTEUN_HIP_LIB", "default")} LG_FFN_FWD={os.environ.get("LG_FFN_FWD", "")}')
 px = B * h * h
 flops = (2 * (e * 4 * e + 4 * e * 4 * e + 4 * e * e) + 18 * 4 * e) * px
 print(f'ffn half-block C={C} blk={blk} e={e} B={B} {h}x{h}: median {ts[len(ts) // 2]:.1f} us  min {ts[0]:.1f} us  '
