@@ -102,7 +102,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     // operand scales (k_ffn_prep.hip; k_ffn_x.hip has the derivation): S1 h1, S2 h2, S3 (...) in the accumulators
     const float sx = a1.scales[0], sa1 = a1.scales[1], sa3 = a1.scales[2], sw1 = a1.scales[3], sw2 = a1.scales[4], sw3 = a1.scales[5];
     const float S1 = sx * sw1, S2 = sa1 * sw2, S3 = sa3 * sw3;
-    const float g1c = 0.70710678118654752440f / S1, g1h = 0.5f * sa1 / S1, g3h = 0.5f * sa3, inv2 = 1.0f / S2, inv3 = 1.0f / S3;   // (powers of two: exact)
+    const float inv2 = 1.0f / S2, inv3 = 1.0f / S3;   // (powers of two: exact)
+#ifdef LG_XR_OLDGELU   // A/B build: rounds 2 - 5's GELU sequence (common.h gelu2_scaled)
+    struct GK { float c1, hr; };
+    const GK gk1 = {0.70710678118654752440f / S1, 0.5f * sa1 / S1}, gk3 = {0.70710678118654752440f, 0.5f * sa3};
+#define gelu2_k(x, k) gelu2_scaled(x, (k).c1, (k).hr)
+#else
+    const GeluK gk1 = gelu_k(0.70710678118654752440f / S1, 0.5f * sa1 / S1), gk3 = gelu_k(0.70710678118654752440f, 0.5f * sa3);   // S1 h1 -> s_a1 gelu(h1); h3 -> s_a3 gelu(h3)
+#endif
 
     XSTAMP_AT(9, 0);
     // ---- once per (persistent) workgroup: weight fragments, taps, biases
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         // Every LDS operand is requested a section ahead of its use (a section = the code between two scheduling fences): the weight fragments of
         // GEMM1 in front of the LayerNorm arithmetic, those of GEMM2's first tile in front of the GELUs, each further tile's behind the previous
         // tile's MFMAs, whose results leave one tile later.
-        struct Geo { float mk; int rp; bool inner; long prow; };
+        struct Geo { float mk; int rp; bool inner; uint32_t prow; };   // prow: element index into the saved h2 (32 bits: the launcher checks the tensor's size)
         auto halo = [&](auto nbc, auto partc, int ya, int npx, int blk0, const float4* xin, f32x4_t* part, Geo* geo_out) {
             constexpr int NB = decltype(nbc)::value, PART = decltype(partc)::value;
             constexpr int MT0 = PART == 2 ? 2 : 0, NMT = PART == 0 ? 4 : 2;      // h1 tiles [MT0, MT0 + NMT)
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 r_ = r_ >= RING * HX ? r_ - RING * HX : r_;
                 geo[nb].rp = m < npx ? r_ : -1;
                 geo[nb].inner = SAVE && m < npx && hx >= 1 && hx <= TX && x < w && y >= Y0 && y < Yend;
-                geo[nb].prow = ((b * h + y) * (long)w + x) * N1 + 4 * g;
+                geo[nb].prow = (uint32_t)(((b * h + y) * (long)w + x) * N1 + 4 * g);
                 const float4 xv = xin[nb];
                 const float s = xg_sum((xv.x + xv.y) + (xv.z + xv.w));
                 const float mu = s * (1.0f / E);
@@ -249,8 +256,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             for (int i = 0; i < NMT; ++i) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const lg_v2f a01 = gelu2_scaled((lg_v2f){a1c[nb][i][0], a1c[nb][i][1]}, g1c, g1h);
-                    const lg_v2f a23 = gelu2_scaled((lg_v2f){a1c[nb][i][2], a1c[nb][i][3]}, g1c, g1h);
+                    const lg_v2f a01 = gelu2_k((lg_v2f){a1c[nb][i][0], a1c[nb][i][1]}, gk1);
+                    const lg_v2f a23 = gelu2_k((lg_v2f){a1c[nb][i][2], a1c[nb][i][3]}, gk1);
                     pair2(a01.x, a01.y, ghi[nb][i][0], glo[nb][i][0]);
                     pair2(a23.x, a23.y, ghi[nb][i][1], glo[nb][i][1]);
                     asm volatile("" : "+v"(ghi[nb][i][0]), "+v"(glo[nb][i][0]), "+v"(ghi[nb][i][1]), "+v"(glo[nb][i][1]));
@@ -258,31 +265,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 XR_FENCE();
             }
             // ---- GEMM2 (K = 64: two 32-deep steps, k-slot j of step s = channel 16 (2 s + (j >> 2)) + 4 g + (j & 3)) -> ring (+ save)
-            auto leave = [&](int mt2, const f32x4_t (&acc)[NB]) {
+            // h2 = (b2 + k-step 0) mk + (k-step 1) mk, the two k-steps in accumulators of their own and joined by ONE fma: the form in which a
+            // split ninth block (k-step 0 stored, k-step 1 added behind the barrier) gives bit for bit what a whole block gives -- which pixels fall
+            // into a ninth block depends on the strip partition, i.e. on the batch size, and a pixel's value must not
+            auto leave = [&](int mt2, const f32x4_t (&k0)[NB], const f32x4_t (&k1)[NB]) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    if (PART == 2) { part[mt2] = acc[nb]; continue; }
+                    if (PART == 2) { part[mt2] = k1[nb]; continue; }
                     const float mk = geo[nb].mk;
-                    const float4 hh = make_float4(acc[nb][0] * mk, acc[nb][1] * mk, acc[nb][2] * mk, acc[nb][3] * mk);
+                    float4 hh = make_float4(k0[nb][0] * mk, k0[nb][1] * mk, k0[nb][2] * mk, k0[nb][3] * mk);
+                    if (PART == 0) hh = make_float4(__builtin_fmaf(k1[nb][0], mk, hh.x), __builtin_fmaf(k1[nb][1], mk, hh.y), __builtin_fmaf(k1[nb][2], mk, hh.z), __builtin_fmaf(k1[nb][3], mk, hh.w));
                     if (SAVE && PART == 0 && geo[nb].inner) HS<false>::st4_nt(a1.h2, geo[nb].prow + 16 * mt2, hh);
                     if (geo[nb].rp >= 0) *reinterpret_cast<float4*>(ring + geo[nb].rp * LDR + 16 * mt2 + 4 * g) = hh;
                 }
             };
-            f32x4_t accp[NB];
+            f32x4_t accp0[NB], accp1[NB];
 #pragma unroll
             for (int mt2 = 0; mt2 < 4; ++mt2) {
-                f32x4_t acc[NB];
+                f32x4_t acc0[NB], acc1[NB];
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nb] = (f32x4_t){b2v.x, b2v.y, b2v.z, b2v.w};
+                for (int nb = 0; nb < NB; ++nb) { acc0[nb] = (f32x4_t){b2v.x, b2v.y, b2v.z, b2v.w}; acc1[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         const u32x4_t bh = {ghi[nb][2 * s][0], ghi[nb][2 * s][1], ghi[nb][2 * s + 1][0], ghi[nb][2 * s + 1][1]};
                         const u32x4_t bl = {glo[nb][2 * s][0], glo[nb][2 * s][1], glo[nb][2 * s + 1][0], glo[nb][2 * s + 1][1]};
-                        acc[nb] = mfma_h(wl[s], bh, acc[nb]);     // small terms first: lo hi, hi lo, hi hi
-                        acc[nb] = mfma_h(wh[s], bl, acc[nb]);
-                        acc[nb] = mfma_h(wh[s], bh, acc[nb]);
+                        f32x4_t& acc = (S0 + s) == 0 ? acc0[nb] : acc1[nb];
+                        acc = mfma_h(wl[s], bh, acc);     // small terms first: lo hi, hi lo, hi hi
+                        acc = mfma_h(wh[s], bl, acc);
+                        acc = mfma_h(wh[s], bh, acc);
                     }
                 if (mt2 < 3) {   // the next tile's operands: requested behind this tile's MFMAs
 #pragma unroll
@@ -292,12 +304,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     }
                     if (PART != 2) b2v = *reinterpret_cast<const float4*>(sPar + P_B2 + 16 * (mt2 + 1) + 4 * g);
                 }
-                if (mt2 > 0) leave(mt2 - 1, accp);   // the previous tile's results leave while this tile's MFMAs run
+                if (mt2 > 0) leave(mt2 - 1, accp0, accp1);   // the previous tile's results leave while this tile's MFMAs run
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) accp[nb] = acc[nb];
+                for (int nb = 0; nb < NB; ++nb) { accp0[nb] = acc0[nb]; accp1[nb] = acc1[nb]; }
                 XR_FENCE();
             }
-            leave(3, accp);
+            leave(3, accp0, accp1);
             if (PART == 2) *geo_out = geo[0];
         };
         // Two whole blocks as ONE software pipeline (the step's main work): block A's GEMM2 tile j (6 MFMAs) is issued in the section that holds block
@@ -330,7 +342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 r_ = r_ >= RING * HX ? r_ - RING * HX : r_;
                 geo[nb].rp = r_;
                 geo[nb].inner = SAVE && hx >= 1 && hx <= TX && x < w && y >= Y0 && y < Yend;
-                geo[nb].prow = ((b * h + y) * (long)w + x) * N1 + 4 * g;
+                geo[nb].prow = (uint32_t)(((b * h + y) * (long)w + x) * N1 + 4 * g);
                 const float4 xv = xin[nb];
                 const float s = xg_sum((xv.x + xv.y) + (xv.z + xv.w));
                 const float mu = s * (1.0f / E);
@@ -360,23 +372,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             XR_FENCE();
             uint32_t ghi[2][4][2], glo[2][4][2];
             auto gelu_tile = [&](int nb, int i) {
-                const lg_v2f a01 = gelu2_scaled((lg_v2f){a1c[nb][i][0], a1c[nb][i][1]}, g1c, g1h);
-                const lg_v2f a23 = gelu2_scaled((lg_v2f){a1c[nb][i][2], a1c[nb][i][3]}, g1c, g1h);
+                const lg_v2f a01 = gelu2_k((lg_v2f){a1c[nb][i][0], a1c[nb][i][1]}, gk1);
+                const lg_v2f a23 = gelu2_k((lg_v2f){a1c[nb][i][2], a1c[nb][i][3]}, gk1);
                 pair2(a01.x, a01.y, ghi[nb][i][0], glo[nb][i][0]);
                 pair2(a23.x, a23.y, ghi[nb][i][1], glo[nb][i][1]);
                 asm volatile("" : "+v"(ghi[nb][i][0]), "+v"(glo[nb][i][0]), "+v"(ghi[nb][i][1]), "+v"(glo[nb][i][1]));
             };
-            auto gemm2_tile = [&](int nb) -> f32x4_t {
-                f32x4_t acc = {b2v.x, b2v.y, b2v.z, b2v.w};
+            struct Acc2 { f32x4_t k0, k1; };     // the two k-steps in accumulators of their own (see `halo`: bitwise the split ninth block's arithmetic)
+            auto gemm2_tile = [&](int nb) -> Acc2 {
+                Acc2 r;
+                r.k0 = (f32x4_t){b2v.x, b2v.y, b2v.z, b2v.w};
+                r.k1 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const u32x4_t bh = {ghi[nb][2 * s][0], ghi[nb][2 * s][1], ghi[nb][2 * s + 1][0], ghi[nb][2 * s + 1][1]};
                     const u32x4_t bl = {glo[nb][2 * s][0], glo[nb][2 * s][1], glo[nb][2 * s + 1][0], glo[nb][2 * s + 1][1]};
+                    f32x4_t& acc = s == 0 ? r.k0 : r.k1;
                     acc = mfma_h(wl[s], bh, acc);     // small terms first: lo hi, hi lo, hi hi
                     acc = mfma_h(wh[s], bl, acc);
                     acc = mfma_h(wh[s], bh, acc);
                 }
-                return acc;
+                return r;
             };
             auto next_w2 = [&](int mt2) {
 #pragma unroll
@@ -386,18 +402,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 }
                 b2v = *reinterpret_cast<const float4*>(sPar + P_B2 + 16 * mt2 + 4 * g);
             };
-            auto leave = [&](int nb, int mt2, const f32x4_t& acc) {
+            auto leave = [&](int nb, int mt2, const Acc2& acc) {
                 const float mk = geo[nb].mk;
-                const float4 hh = make_float4(acc[0] * mk, acc[1] * mk, acc[2] * mk, acc[3] * mk);
+                const float4 hh = make_float4(__builtin_fmaf(acc.k1[0], mk, acc.k0[0] * mk), __builtin_fmaf(acc.k1[1], mk, acc.k0[1] * mk),
+                                              __builtin_fmaf(acc.k1[2], mk, acc.k0[2] * mk), __builtin_fmaf(acc.k1[3], mk, acc.k0[3] * mk));
                 if (SAVE && geo[nb].inner) HS<false>::st4_nt(a1.h2, geo[nb].prow + 16 * mt2, hh);
                 *reinterpret_cast<float4*>(ring + geo[nb].rp * LDR + 16 * mt2 + 4 * g) = hh;
             };
 #pragma unroll
             for (int i = 0; i < 4; ++i) { gelu_tile(0, i); XR_FENCE(); }
-            f32x4_t accp;
+            Acc2 accp;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {        // block A's GEMM2 tile j beside block B's GELU of tile j
-                const f32x4_t acc = gemm2_tile(0);
+                const Acc2 acc = gemm2_tile(0);
                 next_w2(j < 3 ? j + 1 : 0);
                 gelu_tile(1, j);
                 if (j > 0) leave(0, j - 1, accp);
@@ -406,7 +423,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {        // block B's GEMM2; the previous tile's results leave beside it
-                const f32x4_t acc = gemm2_tile(1);
+                const Acc2 acc = gemm2_tile(1);
                 if (j < 3) next_w2(j + 1);
                 leave(j > 0 ? 1 : 0, j > 0 ? j - 1 : 3, accp);
                 accp = acc;
@@ -421,7 +438,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             for (int mt2 = 0; mt2 < 4; ++mt2) {
                 float4* rp4 = reinterpret_cast<float4*>(ring + ge.rp * LDR + 16 * mt2 + 4 * g);
                 float4 r = *rp4;
-                r.x += part[mt2][0] * ge.mk; r.y += part[mt2][1] * ge.mk; r.z += part[mt2][2] * ge.mk; r.w += part[mt2][3] * ge.mk;
+                r = make_float4(__builtin_fmaf(part[mt2][0], ge.mk, r.x), __builtin_fmaf(part[mt2][1], ge.mk, r.y), __builtin_fmaf(part[mt2][2], ge.mk, r.z), __builtin_fmaf(part[mt2][3], ge.mk, r.w));
                 *rp4 = r;
                 if (SAVE && ge.inner) HS<false>::st4_nt(a1.h2, ge.prow + 16 * mt2, r);
             }
@@ -542,8 +559,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
                         if (SAVE && ok) HS<false>::st4_nt(a2.a3s, ((b * h + y) * (long)w + x) * N1 + 16 * m + 4 * g, make_float4(h3[r2][m][0], h3[r2][m][1], h3[r2][m][2], h3[r2][m][3]));
-                        const lg_v2f a01 = gelu2_scaled((lg_v2f){h3[r2][m][0], h3[r2][m][1]}, 0.70710678118654752440f, g3h);
-                        const lg_v2f a23 = gelu2_scaled((lg_v2f){h3[r2][m][2], h3[r2][m][3]}, 0.70710678118654752440f, g3h);
+                        const lg_v2f a01 = gelu2_k((lg_v2f){h3[r2][m][0], h3[r2][m][1]}, gk3);
+                        const lg_v2f a23 = gelu2_k((lg_v2f){h3[r2][m][2], h3[r2][m][3]}, gk3);
                         pair2(a01.x, a01.y, phi[m][0], plo[m][0]);
                         pair2(a23.x, a23.y, phi[m][1], plo[m][1]);
                     }

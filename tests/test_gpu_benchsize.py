@@ -159,11 +159,14 @@ def test_all_ffn_save_modes_give_the_same_step(monkeypatch):
     """The live stage's e = 16 FFN half-blocks keep, for the backward (LG_FFN_SAVE, read at plan creation): '5' gelu / gelu' of both hidden
     tensors + h2 (five 4e-wide tensors per block, the backward evaluates no GELU); '3' the pre-activations h1 / h2 / h3 (the backward
     re-evaluates GELU with the forward's own function); '2' (default) h2 / h3 only -- h1 is re-computed from x by k_ffn1_bwd_xs, which
-    also forms dx, dW1 and dW2 on the bf16 matrix pipe in split arithmetic.  Same forward bit for bit; gradients equal to rounding."""
+    also forms dx, dW1 and dW2 on the bf16 matrix pipe in split arithmetic.  Same forward bit for bit; gradients equal to rounding.
+    (All three behind the channel-split forward k_ffn_xs, LG_FFN_FWD=xs: the register chain k_ffn_xr of round 6 knows mode '2' only and sums its
+    products in another order -- test_register_chain_ffn_train_step_agrees_with_the_channel_split_kernel compares the two forwards.)"""
     from gpu_helpers import make_module
     from lgteun_amd._lib import LG_FLAG_FAITHFUL, LG_FLAG_SAVE
     ms, pan, gt = (T(a).cuda() for a in dw.make_inputs(3, 4, 32, 32, seed=5, kind='dn'))
     res = {}
+    monkeypatch.setenv('LG_FFN_FWD', 'xs')
     for mode in ('5', '3', '2'):
         monkeypatch.setenv('LG_FFN_SAVE', mode)
         net = make_module(4, 2)
@@ -184,6 +187,37 @@ def test_all_ffn_save_modes_give_the_same_step(monkeypatch):
             o, n = eng.offsets[i], eng.params[i].numel()
             a, b = g5[o:o + n].double(), gm[o:o + n].double()
             assert float((a - b).norm()) <= 2e-6 * float(a.norm()) + 1e-12, (mode, eng.names[i], float((a - b).norm()), float(a.norm()))
+    monkeypatch.delenv('LG_FFN_FWD', raising=False)
+    monkeypatch.delenv('LG_FFN_SAVE', raising=False)
+
+
+def test_register_chain_ffn_train_step_agrees_with_the_channel_split_kernel(monkeypatch):
+    """round 6: the default forward of the e = 16 FFN half-blocks is k_ffn_xr (k_ffn_xr.hip); rounds 2 - 5's k_ffn_xs stays as LG_FFN_FWD=xs.  Same
+    arithmetic, another summation order: the whole train step (faithful, saving h2 / h3 for the same backward kernels) gives the same
+    output to 2e-6 and the same gradient to 2e-5 of its norm (per tensor 3e-2 of the tensor's scale: the cancelling-sum kinds amplify the
+    forward's rounding, tests/test_gpu_benchsize.py::test_cancelling_sum_gradient_kinds_band_against_band)"""
+    from gpu_helpers import make_module
+    from lgteun_amd._lib import LG_FLAG_FAITHFUL, LG_FLAG_SAVE
+    ms, pan, gt = (T(a).cuda() for a in dw.make_inputs(3, 4, 32, 32, seed=5, kind='dn'))
+    res = {}
+    for fwd in ('xr', 'xs'):
+        monkeypatch.setenv('LG_FFN_FWD', fwd)
+        net = make_module(4, 2)
+        eng = net.engine()
+        out, saved = eng.forward_raw(ms, pan, LG_FLAG_FAITHFUL | LG_FLAG_SAVE, 0)
+        dout = torch.sign(out - gt) / out.numel()
+        g = torch.zeros_like(eng.gflat)
+        eng.backward_raw(saved, dout, g, LG_FLAG_FAITHFUL | LG_FLAG_SAVE, 0)
+        res[fwd] = (out.clone(), g.clone(), eng)
+    monkeypatch.delenv('LG_FFN_FWD', raising=False)
+    assert not torch.equal(res['xr'][0], res['xs'][0])      # the switch was honoured
+    assert rel_l2(res['xr'][0].cpu(), res['xs'][0].cpu()) < 2e-6
+    ga, gb, eng = res['xr'][1].double(), res['xs'][1].double(), res['xr'][2]
+    assert float((ga - gb).norm()) <= 2e-5 * float(gb.norm())
+    for i in eng.live_idx:
+        o, n = eng.offsets[i], eng.params[i].numel()
+        a, b = ga[o:o + n], gb[o:o + n]
+        assert float((a - b).abs().max()) <= 3e-2 * max(float(b.abs().max()), 1e-12), (eng.names[i], float((a - b).abs().max()), float(b.abs().max()))
 
 
 def test_two_autograd_graphs_keep_their_own_activations():
