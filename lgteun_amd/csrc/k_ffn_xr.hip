@@ -84,6 +84,9 @@ __device__ __forceinline__ void pair2(float a, float b, uint32_t& hi, uint32_t& 
     lo = sb_cvt_f16x2(sb_res_lo(hi, a), sb_res_hi(hi, b));
 }
 
+struct GKold { float c1, hr; };
+__device__ __forceinline__ lg_v2f gelu2_k(lg_v2f x, const GKold& k) { return gelu2_scaled(x, k.c1, k.hr); }
+
 }  // namespace xr
 
 // SAVE: 0 nothing; 3 the pre-activations h2 and h3 (the backward re-computes h1 from x: k_ffn1_bwd_xs) -- the two modes of the default path
@@ -104,14 +107,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const float S1 = sx * sw1, S2 = sa1 * sw2, S3 = sa3 * sw3;
     const float inv2 = 1.0f / S2, inv3 = 1.0f / S3;   // (powers of two: exact)
 #ifdef LG_XR_OLDGELU   // A/B build: rounds 2 - 5's GELU sequence (common.h gelu2_scaled)
-    struct GK { float c1, hr; };
-    const GK gk1 = {0.70710678118654752440f / S1, 0.5f * sa1 / S1}, gk3 = {0.70710678118654752440f, 0.5f * sa3};
-#define gelu2_k(x, k) gelu2_scaled(x, (k).c1, (k).hr)
+    const xr::GKold gk1 = {0.70710678118654752440f / S1, 0.5f * sa1 / S1}, gk3 = {0.70710678118654752440f, 0.5f * sa3};
 #else
     const GeluK gk1 = gelu_k(0.70710678118654752440f / S1, 0.5f * sa1 / S1), gk3 = gelu_k(0.70710678118654752440f, 0.5f * sa3);   // S1 h1 -> s_a1 gelu(h1); h3 -> s_a3 gelu(h3)
 #endif
 
     XSTAMP_AT(9, 0);
+    // the prologue's x vector of this workgroup's FIRST strip: requested now, its HBM round trip runs under the table staging
+    float4 xp_first;
+    {
+        int t_ = blockIdx.x;
+        const int tx_i = t_ % tiles_x;
+        t_ /= tiles_x;
+        const int sy = t_ % strips_y;
+        const long b = t_ / strips_y;
+        const int m = 16 * (wave < 3 ? wave : 0) + c, hy = m / HX, hx = m - hy * HX;
+        const int y = clampi(sy * SH - 1 + hy, 0, h - 1), x = clampi(tx_i * TX + hx - 1, 0, w - 1);
+        xp_first = *reinterpret_cast<const float4*>(a1.x + ((b * h + y) * (long)w + x) * E + 4 * g);
+    }
     // ---- once per (persistent) workgroup: weight fragments, taps, biases
     {
         const int t = threadIdx.x, ln = t >> 2, i = t & 3, lg = ln >> 4, lr = ln & 15;
@@ -169,7 +182,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         const int tx_i = t_ % tiles_x;
         t_ /= tiles_x;
         const int sy = t_ % strips_y;
+#ifdef LG_XR_SAMEX   // diagnostic: every workgroup reads (and writes) sample 0 (results wrong)
+        const long b = 0;
+#else
         const long b = t_ / strips_y;
+#endif
         const int x0 = tx_i * TX, Y0 = sy * SH, Yend = min(Y0 + SH, h);
 
         // x vector of the lane's pixel of halo block blk of the row block starting at ya: unconditional, from a clamped (always valid) address
@@ -444,15 +461,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             }
         };
 
-        // ---- strip prologue: halo rows Y0 - 1, Y0 (36 pixels: blocks 0 .. 2, one per wave)
+        // ---- strip prologue: halo rows Y0 - 1, Y0 (36 pixels: blocks 0 .. 2, one per wave).  Its x vector (the workgroup's first strip: requested in
+        // front of the table staging) and the first step's are in flight before anything is computed
+        float4 xh[3];
         {
-            const float4 xp = xload(Y0 - 1, wave < 3 ? wave : 0);
+            const float4 xp = strip == (int)blockIdx.x ? xp_first : xload(Y0 - 1, wave < 3 ? wave : 0);
+            xh[0] = xload(Y0 + 1, 2 * wave); xh[1] = xload(Y0 + 1, 2 * wave + 1); xh[2] = xload(Y0 + 1, 8);
             __syncthreads();     // the previous strip's spatial phase is done with the ring
             if (uwave < 3) halo(IC<1>{}, IC<0>{}, Y0 - 1, 2 * HX, wave, &xp, nullptr, nullptr);
             XSTAMP_AT(9, 2);
         }
-        float4 xh[3];
-        xh[0] = xload(Y0 + 1, 2 * wave); xh[1] = xload(Y0 + 1, 2 * wave + 1); xh[2] = xload(Y0 + 1, 8);
 #pragma unroll 1
         for (int y0 = Y0; y0 < Yend; y0 += TY) {
             const int si = (y0 - Y0) >> 3;
@@ -575,14 +593,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     }
                     // ---- epilogue in registers: residual, store, LayerNorm statistics of the next block across the four lane groups
                     const float o0 = o[0] * inv3 + xres[r2].x, o1 = o[1] * inv3 + xres[r2].y, o2 = o[2] * inv3 + xres[r2].z, o3 = o[3] * inv3 + xres[r2].w;
+#ifdef LG_XR_NOSTORE   // diagnostic: no output traffic (results wrong)
+                    if (ok && o0 == 12345.678f) *reinterpret_cast<float4*>(a2.y + ((b * h + y) * (long)w + x) * E + 4 * g) = make_float4(o0, o1, o2, o3);
+#else
                     if (ok) *reinterpret_cast<float4*>(a2.y + ((b * h + y) * (long)w + x) * E + 4 * g) = make_float4(o0, o1, o2, o3);
+#endif
                     if (a2.g) {
                         const float s = xg_sum((o0 + o1) + (o2 + o3));
                         const float mu = s * (1.0f / E);
                         const float d0 = o0 - mu, d1 = o1 - mu, d2 = o2 - mu, d3 = o3 - mu;
                         const float vs = xg_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
                         const float rstd = __builtin_amdgcn_rsqf(vs * (1.0f / E) + LG_EPS);
+#ifdef LG_XR_NOSTORE
+                        if (ok && g >= 2 && d0 == 12345.678f) {
+#else
                         if (ok && g >= 2) {      // channels 8..15 = the global-mixer half, planar [B, e/2, h, w]
+#endif
                             const long hw = (long)h * w, sp = (long)y * w + x;
                             float* dst = a2.g + (b * (E / 2) + (4 * g - E / 2)) * hw + sp;
                             dst[0] = d0 * rstd * ng.x + nbv.x;

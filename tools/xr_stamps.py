@@ -12,7 +12,8 @@ from gpu_helpers import Ops, make_module
 
 net = make_module(4, 1)
 ops = Ops(net, 128, 128)
-x = torch.from_numpy(np.random.default_rng(0).standard_normal((32, 128, 128, 16)).astype(np.float32)).cuda()
+NB_ = int(os.environ.get("XR_B", "32"))
+x = torch.from_numpy(np.random.default_rng(0).standard_normal((NB_, 128, 128, 16)).astype(np.float32)).cuda()
 for _ in range(5):
     ops.block(0, 0, 2, x)
 torch.cuda.synchronize()
