@@ -46,7 +46,7 @@ E, P0 = 4 * C, H * H
 
 PROF_EVERY = 4   # live HIP-event timing of the roofline kernel: every 4th step of the timed region
 # kernels that make up the "ffn" launch slot (lg_kernel_id LG_K_FFN2): the fused feed_forward half-block, all variants
-FFN_KERNELS = ('k_ffn_xs', 'k_ffn_x32', 'k_ffn_strip', 'k_ffn_fused', 'k_ffn1_x64', 'k_ffn2_x64')
+FFN_KERNELS = ('k_ffn_xr', 'k_ffn_xs', 'k_ffn_x32', 'k_ffn_strip', 'k_ffn_fused', 'k_ffn1_x64', 'k_ffn2_x64')
 
 
 def _newest_summary(name):
@@ -76,6 +76,32 @@ def traffic_from_profile(kernel, config='c2'):
                 pair += int(r['launches'])
             den += int(r['launches'])
     den -= pair
+    return int(num / den) if den > 0 else None
+
+
+# per-kernel roofline entries: lg_prof id -> (label, kernel-name patterns of the committed PMC / stats summaries)
+KERNEL_GROUPS = [
+    ('ffn', 'ffn', FFN_KERNELS),
+    ('attn', 'attn', ('k_attn<', 'k_attn_m<')),
+    ('fft', 'fft', ('k_fftmix<', 'k_fftmix_r<', 'k_fft_rows_fwd', 'k_fft_cols', 'k_fft_rows_inv')),
+    ('attn_bwd', 'attn_bwd', ('k_attn_bwd_f', 'k_attn_bwd_core', 'k_attn_bwd_epi')),
+    ('ffn_bwd_spatial', 'ffn2_bwd', ('k_ffn_dw_bwd',)),
+    ('ffn_bwd_pixel', 'ffn1_bwd', ('k_ffn1_bwd',)),
+    ('fft_bwd', 'fft_bwd', ('k_fftmix_bwd',)),
+]
+
+
+def traffic_by_patterns(patterns, config='c2'):
+    """HBM bytes per launch (launch-weighted over the matching kernels) from the newest committed PMC summary; None if absent"""
+    import csv
+    path = PMC_SUMMARIES.get(config)
+    if not path or not os.path.exists(path):
+        return None
+    num = den = 0.0
+    for r in csv.DictReader(open(path)):
+        if any(n in r['Kernel_Name'] for n in patterns):
+            num += float(r['HBM_bytes_per_launch']) * int(r['launches'])
+            den += int(r['launches'])
     return int(num / den) if den > 0 else None
 
 
@@ -145,6 +171,22 @@ def algorithmic_per_launch(kernel, B):
         # mixer half-block unit: read x (e), write y (e); the two kernels split it by channel half
         byts = sum(2 * e * p * 4 for e, p in px) / 5 * B / 2
         flops = sum((2 * (3 * (e // 2) ** 2 + e * e) + 2 * 2 * 64 * (e // 2)) * p for e, p in px) / 5 * B if kernel == 'attn' else 0.0
+        return byts, flops
+    if kernel in ('ffn_bwd_spatial', 'ffn_bwd_pixel'):
+        # the feed_forward half-block's backward as ONE unit (two launches): read x, dy, the saved h2 / h3 (4e each), write dx; 2 x the forward's
+        # flops (every product once towards the input, once towards its weight).  Split: the spatial half owns W3 and the depthwise conv,
+        # the pixelwise half W1 and W2 -- bytes: dy + h2 + h3 in, dh2 out | x + dh2 in, dx out
+        if kernel == 'ffn_bwd_spatial':
+            byts = sum((e + 3 * 4 * e) * p * 4 for e, p in px) / 5 * B
+            flops = sum(2 * (2 * 4 * e * e + 18 * 4 * e) * p for e, p in px) / 5 * B
+        else:
+            byts = sum((2 * e + 4 * e) * p * 4 for e, p in px) / 5 * B
+            flops = sum(2 * 2 * (e * 4 * e + 4 * e * 4 * e) * p for e, p in px) / 5 * B
+        return byts, flops
+    if kernel == 'attn_bwd_unit':
+        # the mixer half-block's backward: read x, dy, write dx (the local-mixer kernel's half); 2 x the forward's flops
+        byts = sum(3 * e * p * 4 for e, p in px) / 5 * B / 2
+        flops = 2 * sum((2 * (3 * (e // 2) ** 2 + e * e) + 2 * 2 * 64 * (e // 2)) * p for e, p in px) / 5 * B
         return byts, flops
     return 0.0, 0.0   # kernels without a per-unit figure in SURVEY 8d: time only
 
@@ -258,29 +300,32 @@ def main():
     # librccl prints a version banner on STDOUT when its first communicator is created (measured: five lines in front of the JSON line of
     # the one-rank run); stdout carries exactly ONE JSON line by contract, so file descriptor 1 points at stderr until the communicator
     # exists (a first collective below forces its creation)
-    saved_stdout = None
-    if world > 1 or forced_pg:
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        ddp.init_from_env(os.environ.get('LGTEUN_DDP_BACKEND', 'nccl'))   # nccl = RCCL over xGMI; gloo only for rehearsal
     import torch.distributed as dist
 
     import lgteun_amd
     from lgteun_amd import _lib
     from lgteun_amd.compat import Config
 
-    torch.manual_seed(19971118)
-    net = lgteun_amd.Pansharpening(Config(ms_chans=C), None, stage=K).to(device)
-    net.mode = args.mode
-    net.precision = args.precision
-    net.train()
-    eng = net.attach_ddp(force=bool(forced_pg)) if (world > 1 or forced_pg) else net.engine()
-    if saved_stdout is not None:      # attach_ddp has broadcast the weights: the communicator exists and has said what it had to say
-        torch.cuda.synchronize()
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        os.close(saved_stdout)
+    saved_stdout = None
+    try:
+        if world > 1 or forced_pg:
+            sys.stdout.flush()
+            saved_stdout = os.dup(1)
+            os.dup2(2, 1)
+            ddp.init_from_env(os.environ.get('LGTEUN_DDP_BACKEND', 'nccl'))   # nccl = RCCL over xGMI; gloo only for rehearsal
+        torch.manual_seed(19971118)
+        net = lgteun_amd.Pansharpening(Config(ms_chans=C), None, stage=K).to(device)
+        net.mode = args.mode
+        net.precision = args.precision
+        net.train()
+        eng = net.attach_ddp(force=bool(forced_pg)) if (world > 1 or forced_pg) else net.engine()
+        if saved_stdout is not None:  # attach_ddp has broadcast the weights: the communicator exists and has said what it had to say
+            torch.cuda.synchronize()
+    finally:                          # whatever the group set-up raised: file descriptor 1 is stdout again
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     opt = lgteun_amd.FusedAdam(net.parameters(), lr=1.5e-3, betas=(0.9, 0.999))          # configs/unlg_former.py:82-84
     sched = torch.optim.lr_scheduler.StepLR(opt, step_size=25900, gamma=0.85)              # :86, stepped every iteration
     ms, pan, gt = synth_batch(B_PER_GPU, rank, device)
@@ -393,6 +438,65 @@ def main():
     if side and args.config == 'c2' and args.mode == 'faithful' and args.precision == 'fp32':
         others = {name: side_config(name, device, 10) for name in ('c3', 'c5')}
 
+    # per-kernel roofline entries: three extra steps per kernel id OUTSIDE the timed region, HIP events on every launch
+    # of that id (lg_prof times one id at a time)
+    def prof_kernel(name, n_steps=3, fn=None):
+        _lib.check(L.lg_prof_enable(_lib.KERNEL_IDS[name], 64 * (n_steps + 1)), 'lg_prof_enable')
+        for _ in range(n_steps):
+            (fn or step)()
+        torch.cuda.synchronize()
+        tm, nl = ctypes.c_double(), ctypes.c_int64()
+        _lib.check(L.lg_prof_read(ctypes.byref(tm), ctypes.byref(nl)), 'lg_prof_read')
+        L.lg_prof_disable()
+        return tm.value / max(nl.value, 1) * 1e3, nl.value / n_steps
+
+    by_kernel = None
+    if side and args.mode == 'faithful':
+        by_kernel = []
+        times = {label: prof_kernel(kid_name) for label, kid_name, _ in KERNEL_GROUPS}
+        for label, kid_name, pats in KERNEL_GROUPS:
+            avg_us_k, per_step = times[label]
+            byts_k, flops_k = algorithmic_per_launch('attn_bwd_unit' if label == 'attn_bwd' else label, B_PER_GPU)
+            by_kernel.append(dict(kernel=label, avg_us=round(avg_us_k, 2), launches_per_step=round(per_step, 1), alg_bytes=int(byts_k), alg_flops=int(flops_k),
+                                  hbm_frac=round(byts_k / (avg_us_k * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if avg_us_k > 0 else None,
+                                  mfma_frac=round(flops_k / (avg_us_k * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if avg_us_k > 0 else None,
+                                  traffic=traffic_by_patterns(pats, args.config)))
+    # the bf16 mode's own roofline: its fused FFN forward against the DENSE bf16 matrix peak it executes on
+    if bf16 is not None:
+        net.precision = 'bf16'
+        for _ in range(2):
+            step()
+        avg_us_b, _ = prof_kernel('ffn')
+        net.precision = 'fp32'
+        _, flops_b = algorithmic_per_launch('ffn', B_PER_GPU)
+        ach = flops_b / (avg_us_b * 1e-6) / 1e12 if avg_us_b > 0 else 0.0
+        bf16['roofline'] = dict(bound='mfma', achieved=round(ach, 2), peak=PEAK_BF16_MFMA_TFLOPS, unit='TFLOP/s', frac=round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                                kernel='fused FFN forward, plain bf16 MFMA (one piece per operand)', avg_launch_us=round(avg_us_b, 2),
+                                note='limiter: vector issue (GELU, depthwise conv, LayerNorm), not the bf16 matrix pipe')
+    # GPU single-image inference latency next to the paper's Table 1 (25.4 ms / image at K = 4, 13.7 ms at K = 2 on an RTX 3090): configs[0]'s
+    # shape, batch 1, every call synchronised
+    b1 = None
+    if side:
+        b1 = {}
+        msb, panb, _ = synth_batch(1, 0, device, 4, 128)
+        for kk in (4, 2):
+            nb1 = lgteun_amd.Pansharpening(Config(ms_chans=4), None, stage=kk).to(device).eval()
+            nb1.faithful_eval = True
+            for mode in ('faithful', 'live'):
+                nb1.mode = mode
+                with torch.no_grad():
+                    for _ in range(5):
+                        nb1(msb, panb)
+                    torch.cuda.synchronize()
+                    t_ = time.perf_counter()
+                    for _ in range(30):
+                        nb1(msb, panb)
+                        torch.cuda.synchronize()
+                    b1[f'K{kk}_{mode}'] = round((time.perf_counter() - t_) / 30 * 1e3, 3)
+            del nb1
+        b1 = dict(unit='ms per image (batch 1, synchronised per call)', workload='configs[0]: C=4, MS 32x32, PAN 128x128', **b1,
+                  paper_rtx3090_ms=dict(K4=25.4, K2=13.7), note='paper Table 1 numbers are the reference on other hardware: context, not a baseline for `vs_baseline`')
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = B_PER_GPU * world * args.steps / elapsed
@@ -429,6 +533,11 @@ def main():
                    config=dict(workload=label + ', train step = fwd + L1 + bwd + Adam + StepLR tick', mode=args.mode,
                                global_batch=B_PER_GPU * world, parallelism=f'dp{world}', dropout=True),
                    roofline=roof)
+        out['watchdog_s'] = wd
+        if world > 1 or forced_pg:
+            bk = eng.buckets[False] if eng.buckets else None
+            out['ddp'] = dict(backend=dist.get_backend(), bucket_form=('two buckets, LG_DDP_OVERLAP=' + os.environ.get('LG_DDP_OVERLAP', '')) if (bk is not None and bk.overlap)
+                              else 'one stream-ordered all-reduce behind the backward')
         if forced_pg:
             out['forced_process_group'] = dict(backend=dist.get_backend(), world=1, note='LGTEUN_FORCE_PG: the per-step gradient all-reduce (and the weight '
                                                'broadcast) run on a one-rank communicator: what the collective call costs on this box, not a scaling point')
@@ -442,6 +551,10 @@ def main():
             out['bf16_mode'] = bf16
         if evalf is not None:
             out['eval_forward'] = dict(unit='eval image-pairs/sec', batch=B_PER_GPU, **evalf)
+            if b1 is not None:
+                out['eval_forward']['b1'] = b1
+        if by_kernel is not None:
+            out['roofline_by_kernel'] = by_kernel
         if others is not None:
             out['c3_mode'] = others['c3']
             out['c5_mode'] = others['c5']

@@ -32,23 +32,19 @@ def smart_time(second):
 
 
 class Base_model:
+    """The attribute names are the reference's (subclasses and configs rely on them: base_model.py:26-54); how they are filled is this
+    build's."""
+    OUT_DIRS = ('train_out', 'test_out0', 'test_out1')            # under <work_dir>/<datas>/ (base_model.py:44-46)
+    FREQ_DEFAULTS = dict(save_freq=10000, test_freq=10000, eval_freq=10000, max_iter=100000)
+
     def __init__(self, cfg, logger, train_data_loader, test_data_loader0, test_data_loader1):
-        self.cfg = cfg
-        self.work_dir = cfg.work_dir
-        self.logger = logger
-        self.train_data_loader = train_data_loader
-        self.test_data_loader0 = test_data_loader0
-        self.test_data_loader1 = test_data_loader1
-        self.datas = cfg.datas
+        self.cfg, self.logger = cfg, logger
+        self.work_dir, self.datas = cfg.work_dir, cfg.datas
+        self.train_data_loader, self.test_data_loader0, self.test_data_loader1 = train_data_loader, test_data_loader0, test_data_loader1
         mkdir_or_exist(self.work_dir)
-        self.train_out = f'{self.work_dir}/{self.datas}/train_out'        # base_model.py:44-46
-        self.test_out0 = f'{self.work_dir}/{self.datas}/test_out0'
-        self.test_out1 = f'{self.work_dir}/{self.datas}/test_out1'
-        self.eval_results = {}
-        self.module_dict = {}
-        self.optim_dict = {}
-        self.sched_dict = {}
-        self.switch_dict = {}
+        for d in self.OUT_DIRS:
+            setattr(self, d, f'{self.work_dir}/{self.datas}/{d}')
+        self.module_dict, self.optim_dict, self.sched_dict, self.switch_dict, self.eval_results = {}, {}, {}, {}, {}
         self.loss_module = get_loss_module(full_cfg=cfg, logger=logger)
         self.last_iter = 0
         self.rank, self.world = 0, 1      # one process per GPU: set_cuda() reads them from torch.distributed
@@ -154,43 +150,52 @@ class Base_model:
         for name, optim in self.optim_dict.items():
             self.sched_dict[name] = lr_scheduler.StepLR(optimizer=optim, **sched_cfg)
 
-    def train(self):
-        for freq_str in ['save_freq', 'test_freq', 'eval_freq']:
-            self.cfg.setdefault(freq_str, 10000)
-        self.cfg.setdefault('max_iter', 100000)
-        self.timer = Timer()
-        iter_id = self.last_iter
-        dev = next(iter(self.module_dict.values())).parameters().__next__().device
-        while iter_id < self.cfg.max_iter:
-            for input_batch in self.train_data_loader:
-                input_batch = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in input_batch.items()}
-                input_batch = data_normalize(input_batch, self.cfg.bit_depth)     # unconditional, base_model.py:181
-                iter_id += 1
-                for module in self.module_dict.values():
-                    module.train()
-                self.train_iter(iter_id=iter_id, input_batch=input_batch)
+    def _device(self):
+        return next(next(iter(self.module_dict.values())).parameters()).device
 
-                def should(freq):
-                    return (freq != -1) and (iter_id % freq == 0) and (iter_id != self.cfg.max_iter)
-                if should(self.cfg.save_freq):
-                    self.save(iter_id=iter_id)
-                if should(self.cfg.eval_freq):                                     # base_model.py:193-195
-                    self.test(iter_id=iter_id, save=should(self.cfg.test_freq), ref=False)
-                    self.test(iter_id=iter_id, save=should(self.cfg.test_freq), ref=True)
-                for name, sched in self.sched_dict.items():
-                    if self.switch_dict[name]:
-                        sched.step()                      # StepLR per ITERATION (base_model.py:197-199)
-                if iter_id == self.cfg.max_iter:
-                    break
+    def _due(self, freq, iter_id):
+        """a periodic action of the training loop is due at this iteration (never at the last one, -1 switches it off: base_model.py:187-195)"""
+        return freq != -1 and iter_id % freq == 0 and iter_id != self.cfg.max_iter
+
+    def _train_batches(self, dev):
+        """(iteration number, normalised device batch) from last_iter + 1 up to cfg.max_iter, cycling through the training loader"""
+        it = self.last_iter
+        while it < self.cfg.max_iter:
+            for batch in self.train_data_loader:
+                it += 1
+                batch = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+                yield it, data_normalize(batch, self.cfg.bit_depth)           # normalised unconditionally (base_model.py:181)
+                if it >= self.cfg.max_iter:
+                    return
+
+    def train(self):
+        """the training cadence of the reference (base_model.py:164-204): train_iter on every batch, then save / evaluate when due (the
+        evaluation on the full-resolution set first, then the reduced-resolution one; fused images are written when test_freq is due too),
+        then one StepLR tick per ITERATION for every switched-on module"""
+        for key, default in self.FREQ_DEFAULTS.items():
+            self.cfg.setdefault(key, default)
+        self.timer = Timer()
+        for iter_id, input_batch in self._train_batches(self._device()):
+            for module in self.module_dict.values():
+                module.train()
+            self.train_iter(iter_id=iter_id, input_batch=input_batch)
+            if self._due(self.cfg.save_freq, iter_id):
+                self.save(iter_id=iter_id)
+            if self._due(self.cfg.eval_freq, iter_id):
+                write = self._due(self.cfg.test_freq, iter_id)
+                for ref in (False, True):
+                    self.test(iter_id=iter_id, save=write, ref=ref)
+            for name, sched in self.sched_dict.items():
+                if self.switch_dict[name]:
+                    sched.step()
 
     def print_train_log(self, iter_id, loss_res, log_freq=10):
         if iter_id % log_freq == 0 and self.logger is not None and self.rank == 0:
             avg_iter_time = self.timer.since_last_check() / log_freq
             remain_time = avg_iter_time * (self.cfg.max_iter - iter_id)
-            self.logger.info(f'===> training iteration[{iter_id}/{self.cfg.max_iter}] '
-                             f'lr: {self.optim_dict["core_module"].param_groups[0]["lr"]:.6f}, '
-                             f'ETA: {smart_time(remain_time)}')
-            self.logger.info(f'full loss: {loss_res["full_loss"]:.6f}')
+            lr = self.optim_dict['core_module'].param_groups[0]['lr']
+            self.logger.info('iteration %d of %d | lr %.6f | full loss %.6f | time left %s',
+                             iter_id, self.cfg.max_iter, lr, loss_res['full_loss'], smart_time(remain_time))
 
     def get_model_output(self, input_batch):
         raise NotImplementedError
@@ -208,7 +213,7 @@ class Base_model:
         loader = self.test_data_loader1 if ref else self.test_data_loader0
         for module in self.module_dict.values():
             module.eval()
-        dev = next(iter(self.module_dict.values())).parameters().__next__().device
+        dev = self._device()
         names = ['PSNR', 'SSIM', 'Q', 'SAM', 'ERGAS'] if ref else ['D_lambda', 'D_s', 'QNR']
         denorm = bool(self.cfg.get('norm_input', False))
         out_dir = osp.join(self.test_out1 if ref else self.test_out0, f'iter_{iter_id}')
@@ -225,7 +230,13 @@ class Base_model:
         def to_np(t):   # [b c h w] -> [b h w c]
             t = data_denormalize(t, self.cfg.bit_depth) if denorm else t
             return t.permute(0, 2, 3, 1).cpu().numpy()
-        res, ids = [], []
+        # what identifies an image ACROSS ranks (`image_id` is a file-name prefix -- two directories may hold equal ones -- and may be
+        # absent): the dataset index this rank's ShardedSampler hands out, in the order the loader consumes it; for a loader every rank iterates
+        # in full (batches dealt out round-robin) the position in that common sequence; for a foreign pre-sharded loader nothing is known,
+        # its rows are kept as they come (rank-tagged keys never collide)
+        smp = getattr(inner, 'sampler', None)
+        own_idx = [int(i) for i in smp] if (sharded and isinstance(smp, ShardedSampler)) else None
+        res, ids, seen_here = [], [], 0
         for bi, input_batch in enumerate(loader or []):
             if self.world > 1 and not sharded and bi % self.world != self.rank:
                 continue
@@ -238,7 +249,14 @@ class Base_model:
             else:                                                # full-resolution set: no target (base_model.py:330-334)
                 pan_np, lr_np = to_np(input_batch['input_pan']), to_np(input_batch['input_lr'])
                 res.extend(mtc.no_ref_evaluate(out[i], pan_np[i], lr_np[i]) for i in range(out.shape[0]))
-            ids.extend(str(i) for i in input_batch.get('image_id', range(len(ids), len(ids) + out.shape[0])))
+            nb = out.shape[0]
+            if own_idx is not None:
+                ids.extend(('idx', own_idx[seen_here + i]) for i in range(nb))
+            elif not sharded:
+                ids.extend(('pos', bi, i) for i in range(nb))
+            else:
+                ids.extend(('rank', self.rank, seen_here + i) for i in range(nb))
+            seen_here += nb
             if save:
                 for i, image_id in enumerate(input_batch['image_id']):
                     # [C, H, W] for the writer (the reference hands its HWC array to a CHW writer, base_model.py:336: a
@@ -248,9 +266,10 @@ class Base_model:
         if self.world > 1:
             import torch.distributed as dist
             rows = [None] * self.world
-            dist.all_gather_object(rows, [(i, list(map(float, r))) for i, r in zip(ids, res)])
+            dist.all_gather_object(rows, [(tuple(i), list(map(float, r))) for i, r in zip(ids, res)])
             # an image that reached two ranks (a PADDED sharded sampler wraps around when world does not divide the set: build the
-            # evaluation loaders with build_loader(..., evaluation=True)) is scored once, like the reference's one-process loop
+            # evaluation loaders with build_loader(..., evaluation=True)) is scored once, like the reference's one-process loop:
+            # told by its dataset index, never by its name
             seen, res = set(), []
             for part in rows:
                 for i, r in part:

@@ -26,7 +26,12 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return red[0];
 }
 __device__ __forceinline__ float pow2_below(float bound) {   // the power of two s with bound * s in [2^14, 2^15)   (bound = 0: 2^15)
-    return __builtin_amdgcn_ldexpf(1.0f, 15 - __builtin_amdgcn_frexp_expf(bound));
+    // exponent clamped to [-100, 60]: a vanishing bound (weights of 1e-35) would otherwise make the PRODUCT of two scales overflow
+    // (S1 = s_x s_w1 = inf, 1 / S1 = 0, NaN out), and a non-finite weight gives an arbitrary frexp exponent.  With the cap every scale product
+    // stays below 2^120; operands below 2^-74 flush to zero in f16 -- 2^-50 of anything that can matter beside O(1) activations
+    int ex = 15 - __builtin_amdgcn_frexp_expf(bound);
+    ex = ex < -100 ? -100 : (ex > 60 ? 60 : ex);
+    return __builtin_amdgcn_ldexpf(1.0f, ex);
 }
 }  // namespace
 

@@ -53,6 +53,11 @@ def pytest_sessionstart(session):
     p1 = subprocess.Popen([sys.executable, '-W', 'ignore', os.path.join(ROOT, 'tests', 'rccl_one_rank_worker.py'), outdir],
                           stdout=open(log1, 'w'), stderr=subprocess.STDOUT, env=env, cwd=ROOT)
     config._lgteun_rccl_job = (outdir, p1, log1)
+    # a fourth child, which never touches the device: it waits for the three above to exit, then runs `bench.py --gpus 2` under
+    # torch.distributed.run (tests/bench_rehearsal_launcher.py; joined by tests/test_gpu_zz_bench_rehearsal.py)
+    p2 = subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'bench_rehearsal_launcher.py'), outdir] + [str(p.pid) for p in procs] + [str(p1.pid)],
+                          stdout=open(os.path.join(outdir, 'launcher.log'), 'w'), stderr=subprocess.STDOUT, cwd=ROOT)
+    config._lgteun_bench2_job = (outdir, p2)
     config.add_cleanup(lambda: shutil.rmtree(outdir, ignore_errors=True))
 
 
@@ -63,6 +68,9 @@ def pytest_sessionfinish(session, exitstatus):
             if p.poll() is None:
                 p.kill()
     job = getattr(session.config, '_lgteun_rccl_job', None)
+    if job and job[1].poll() is None:
+        job[1].kill()
+    job = getattr(session.config, '_lgteun_bench2_job', None)
     if job and job[1].poll() is None:
         job[1].kill()
 

@@ -128,8 +128,13 @@ def test_shard_bounds_and_layout():
 
 # ---- sharded evaluation when world does not divide the set: every image is scored exactly once --------------------------
 class _EvalSet(torch.utils.data.Dataset):
-    """7 tiny 'images' whose PSNR against the target differs per image (the fused image IS the input here: see _EvalRunner)"""
+    """7 tiny 'images' whose PSNR against the target differs per image (the fused image IS the input here: see _EvalRunner).
+    ids: 'unique' img0 .. img6; 'collide' img0, img1, img2, img0, .. (PSDataset's image_id is a file-name prefix: two directories can hold
+    the same one -- ADVICE r5); 'none' no image_id key at all"""
     N = 7
+
+    def __init__(self, ids='unique'):
+        self.ids = ids
 
     def __len__(self):
         return self.N
@@ -137,7 +142,10 @@ class _EvalSet(torch.utils.data.Dataset):
     def __getitem__(self, i):
         g = torch.Generator().manual_seed(100 + i)
         tgt = torch.rand(4, 16, 16, generator=g) * 2047
-        return dict(input_lr=tgt + (i + 1) * 3.0 * torch.randn(4, 16, 16, generator=g), input_pan=torch.zeros(1, 16, 16), target=tgt, image_id=f'img{i}')
+        item = dict(input_lr=tgt + (i + 1) * 3.0 * torch.randn(4, 16, 16, generator=g), input_pan=torch.zeros(1, 16, 16), target=tgt)
+        if self.ids != 'none':
+            item['image_id'] = f'img{i % 3}' if self.ids == 'collide' else f'img{i}'
+        return item
 
 
 def _eval_runner(loader, rank, world, work):
@@ -154,13 +162,13 @@ def _eval_runner(loader, rank, world, work):
     return r
 
 
-def _eval_worker(rank, world, port, q, work, padded):
+def _eval_worker(rank, world, port, q, work, padded, ids='unique'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(1)
     from lgteun_amd import dataset as ds, ddp
     ddp.init_from_env('gloo')
     smp = ds.ShardedSampler(_EvalSet.N, rank, world, shuffle=False, pad=padded)
-    loader = torch.utils.data.DataLoader(_EvalSet(), batch_size=2, sampler=smp)
+    loader = torch.utils.data.DataLoader(_EvalSet(ids), batch_size=2, sampler=smp)
     out = _eval_runner(loader, rank, world, work).test(iter_id=0, ref=True)
     if rank == 0:
         q.put((out, len(smp)))
@@ -168,17 +176,19 @@ def _eval_worker(rank, world, port, q, work, padded):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('padded', [False, True])
-def test_two_rank_evaluation_scores_every_image_once(tmp_path, padded):
+@pytest.mark.parametrize('padded,ids', [(False, 'unique'), (True, 'unique'), (True, 'collide'), (False, 'collide'), (True, 'none'), (False, 'none')])
+def test_two_rank_evaluation_scores_every_image_once(tmp_path, padded, ids):
     """7 images on 2 ranks: the evaluation sampler (pad=False) gives 4 + 3; a PADDED sampler hands image 0 to both ranks and test()
-    drops the second copy by image_id.  Either way mean / std equal the one-process evaluation's (the reference: base_model.py:267-352)."""
-    single = _eval_runner(torch.utils.data.DataLoader(_EvalSet(), batch_size=2), 0, 1, str(tmp_path / 's')).test(iter_id=0, ref=True)
+    drops the second copy -- told by its DATASET INDEX (the sampler's), not by image_id: with equal ids on different images ('collide': two
+    directories) or no ids at all ('none') every image still counts exactly once.  Either way mean / std equal the
+    one-process evaluation's (the reference: base_model.py:267-352)."""
+    single = _eval_runner(torch.utils.data.DataLoader(_EvalSet(ids), batch_size=2), 0, 1, str(tmp_path / 's')).test(iter_id=0, ref=True)
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q, str(tmp_path / 'd'), padded)) for r in range(2)]
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q, str(tmp_path / 'd'), padded, ids)) for r in range(2)]
     for p in procs:
         p.start()
     got, n0 = q.get(timeout=120)

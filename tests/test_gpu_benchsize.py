@@ -91,6 +91,41 @@ def test_train_step_vs_reference_gradients(manifest, name, mode):
     assert float(eng.gflat[a:b].abs().max()) == 0.0            # dead-stage slots of the flat gradient buffer: never written
 
 
+@pytest.mark.parametrize('name', ['grad_c4_k4_p128', 'grad_c8_k4_p128', 'grad_c8_k8_p256'])
+def test_bf16_mode_at_the_measured_sizes(manifest, name):
+    """precision='bf16' -- the mode BASELINE configs[1] names and bench.py's `bf16_mode` measures -- gated WHERE it is measured (VERDICT r5
+    item 2): configs[1]'s shape (C = 4, 128 x 128, K = 4), configs[2]'s (C = 8) and configs[4]'s single-GPU shape (C = 8, 256 x 256, K = 8), i.e.
+    the NP = 1 instances of every width (e = 16 / 32 / 64), the tanh-GELU pair and bf16 storage of the saved tensors, against the
+    REFERENCE's own outputs and gradients: forward within 5e-3 relative and >= 50 dB PSNR of the default mode AND within 1e-2 of the
+    reference's fp64 output; loss 2e-3; global gradient relative L2 2e-2 against the reference's fp32 gradients."""
+    from gpu_helpers import make_module
+    from lgteun_amd import FusedAdam
+    m, g = manifest[name], load_gold(name)
+    ms, pan, gt = (T(a).cuda() for a in dw.make_inputs(m['B'], m['C'], m['h'], m['w'], seed=m['seed'], kind=m['kind']))
+    net = make_module(m['C'], m['K'])
+    net.faithful_eval = True
+    with torch.no_grad():
+        y32 = net(ms, pan)
+    net.precision = 'bf16'
+    with torch.no_grad():
+        y16 = net(ms, pan)
+    fwd_rel = rel_l2(y16.cpu(), y32.cpu())
+    psnr = 10 * np.log10(1.0 / max(float(((y16 - y32) ** 2).mean()), 1e-30))
+    ref_rel = rel_l2(y16.cpu().numpy(), g['out_fp64'])
+    assert fwd_rel < 5e-3 and psnr >= 50.0 and ref_rel < 1e-2, (fwd_rel, psnr, ref_rel)
+    opt = FusedAdam(net.parameters(), lr=0.0)
+    opt.dropout = False
+    eng = net.engine()
+    loss = float(eng.train_step(ms, pan, gt, opt).item())
+    assert abs(loss - float(g['loss'])) < 2e-3 * abs(float(g['loss'])), (loss, float(g['loss']))
+    grads = _live_grads(eng)
+    num = sum(float(((v.astype(np.float64) - g[k.replace('.', '/')]) ** 2).sum()) for k, v in grads.items())
+    den = sum(float((g[k.replace('.', '/')].astype(np.float64) ** 2).sum()) for k in grads)
+    err = (num / den) ** 0.5
+    print(f'bf16 mode {name}: forward {fwd_rel:.2e} of the default mode ({psnr:.1f} dB), {ref_rel:.2e} of the reference fp64; loss {loss:.6f} / {float(g["loss"]):.6f}; gradient {err:.2e}')
+    assert err < 2e-2, err
+
+
 @pytest.mark.parametrize('name', ['grad_c4_k4_p128', 'grad_c8_k4_p128', 'grad_c4_k2_p80x48', 'grad_c4_k2_p208x176', 'grad_c8_k8_p256'])
 def test_cancelling_sum_gradient_kinds_band_against_band(manifest, name):
     """The five gradient kinds that cancel to ~1e-5 of their terms, gated BAND AGAINST BAND: this build's gradients go
@@ -248,6 +283,11 @@ def test_two_autograd_graphs_keep_their_own_activations():
         assert float((gab[k] - want).abs().max()) <= 1e-6 * max(float(want.abs().max()), 1e-3), k
 
 
+# goldens on which the DEFAULT kernel combination draws an angle() branch-cut flip that other, equally accurate roundings do not (recorded, not
+# hidden: the kernel-level fp64 tests are the primary gate of each kernel's arithmetic)
+BRANCH_CUT_FLIPS_OF_THE_DEFAULT = {}
+
+
 def test_split_bf16_gemms_are_as_close_to_fp64_as_fp32_arithmetic(manifest, monkeypatch):
     """The FFN GEMMs and (round 5) the four products of the local mixer run on the 16-bit matrix pipe in split arithmetic
     (csrc/split_bf16.h: three bf16 pieces, six piece products; P V: two f16 pieces, three products; fp32 accumulation -- per dot product
@@ -285,11 +325,20 @@ def test_split_bf16_gemms_are_as_close_to_fp64_as_fp32_arithmetic(manifest, monk
                     net = make_module(m['C'], m['K'])
                     with torch.no_grad():
                         err[impl, attn, fft] = rel_l2(net(ms, pan).cpu().numpy(), g['out_fp64'])
-        split = min(v for k, v in err.items() if k[0] == 'split')      # the product arithmetic (its default kernels: ('split', 'm', 'real'))
+        splits = sorted(v for k, v in err.items() if k[0] == 'split')  # the product arithmetic (its default kernels: ('split', 'm', 'real'))
+        split = splits[0]
         exact = max(v for k, v in err.items() if k[0] == 'strip')
+        bar = 2.0 * max(exact, m['rel_fp32_vs_fp64'])
         rows.append((name, err, m['rel_fp32_vs_fp64']))
         assert max(err.values()) < 1e-3, rows[-1]
-        assert split <= 2.0 * max(exact, m['rel_fp32_vs_fp64']), rows[-1]
+        assert split <= bar, rows[-1]
+        #  the best of four must not be the only one that is held to the bar: the MEDIAN of the four roundings is too (two of four may
+        # draw a branch-cut flip, three may not), and the shipped default combination itself unless the golden is listed below with its reason
+        assert 0.5 * (splits[1] + splits[2]) <= bar, rows[-1]
+        if name not in BRANCH_CUT_FLIPS_OF_THE_DEFAULT:
+            assert err['split', 'm', 'real'] <= bar, ('default combination', rows[-1])
+        else:
+            print(f"{name}: default combination {err['split', 'm', 'real']:.2e} against a bar of {bar:.2e}: {BRANCH_CUT_FLIPS_OF_THE_DEFAULT[name]}")
     monkeypatch.delenv('LG_FFT', raising=False)
     monkeypatch.delenv('LG_FFN_IMPL', raising=False)
     monkeypatch.delenv('LG_ATTN_FWD', raising=False)
@@ -330,7 +379,7 @@ def test_matrix_pipe_mixer_is_as_close_to_fp64_as_the_fp32_kernel(C, monkeypatch
 
 
 @pytest.mark.parametrize('C', [4, 8])
-@pytest.mark.parametrize('case', ['as_initialised', 'w1_tiny_w2_huge', 'w1_huge_w3_tiny', 'ln_affine_huge', 'w2_dw_huge_w3_tiny'])
+@pytest.mark.parametrize('case', ['as_initialised', 'w1_tiny_w2_huge', 'w1_huge_w3_tiny', 'ln_affine_huge', 'w2_dw_huge_w3_tiny', 'w1_vanishing', 'ln_affine_vanishing'])
 def test_f16_pair_ffn_holds_fp32_accuracy_at_extreme_operand_scales(C, case, monkeypatch):
     """The fused FFN forward multiplies f16 PAIRS (split_bf16.h NP = 2), whose exponent range is 2^-24 .. 2^16: every operand is scaled by a
     power of two derived from a bound on the block's weights (k_ffn_prep.hip).  The FFN half-block of both levels (e = 16 / 32 at C = 4,
@@ -345,6 +394,8 @@ def test_f16_pair_ffn_holds_fp32_accuracy_at_extreme_operand_scales(C, case, mon
             'w1_tiny_w2_huge': {'net.0.weight': 1e-4, 'net.0.bias': 1e-4, 'net.2.point_conv.weight': 1e4},
             'w1_huge_w3_tiny': {'net.0.weight': 1e3, 'net.0.bias': 1e3, 'net.4.weight': 1e-3},
             'ln_affine_huge': {'norm.weight': 1e3, 'norm.bias': 1e3, 'net.0.weight': 1e-3},
+            #  bounds of 1e-35: the operand scales are capped (k_ffn_prep.hip pow2_below), nothing overflows, the output is finite
+            'w1_vanishing': {'net.0.weight': 1e-35}, 'ln_affine_vanishing': {'norm.weight': 1e-35, 'norm.bias': 1e-35},
             'w2_dw_huge_w3_tiny': {'net.2.point_conv.weight': 3e3, 'net.2.point_conv.bias': 3e3, 'net.2.depth_conv.weight': 30.0, 'net.2.depth_conv.bias': 1e5,
                                    'net.4.weight': 1e-5}}[case]
     rng = np.random.default_rng(17)
@@ -367,6 +418,7 @@ def test_f16_pair_ffn_holds_fp32_accuracy_at_extreme_operand_scales(C, case, mon
         den = float((want - x.double()).norm())
         e2, e3 = (float((got[s] - want).norm()) / den for s in ('f16x2', 'bf16x3'))
         print(f'C={C} {case} block {blk} (e={e}): |ffn| / |x| = {den / float(x.double().norm()):.2e}   f16 pairs {e2:.3e}   bf16 x 3 {e3:.3e}')
+        assert torch.isfinite(got['f16x2']).all(), (case, blk)
         assert e2 < 2e-6 and e2 <= 2.0 * e3 + 1e-7, (case, blk, e2, e3)
     monkeypatch.delenv('LG_FFN_SPLIT', raising=False)
 
