@@ -194,8 +194,8 @@ class Base_model:
             avg_iter_time = self.timer.since_last_check() / log_freq
             remain_time = avg_iter_time * (self.cfg.max_iter - iter_id)
             lr = self.optim_dict['core_module'].param_groups[0]['lr']
-            self.logger.info('iteration %d of %d | lr %.6f | full loss %.6f | time left %s',
-                             iter_id, self.cfg.max_iter, lr, loss_res['full_loss'], smart_time(remain_time))
+            self.logger.info(f'iteration {iter_id} of {self.cfg.max_iter} | lr {lr:.6f} | full loss {loss_res["full_loss"]:.6f} | '
+                             f'time left {smart_time(remain_time)}')
 
     def get_model_output(self, input_batch):
         raise NotImplementedError

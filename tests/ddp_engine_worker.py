@@ -126,8 +126,8 @@ def runner_check(outdir, rank, world, ms, pan, gt):
     eng = runner.module_dict['core_module'].engine()
     out['runner_local_loss'] = np.array(float(eng._loss.item()))
     out['runner_global_loss'] = np.array(eng.global_loss())
-    logged = [ln for ln in log.lines if ln.startswith('full loss')]
-    out['runner_logged_loss'] = np.array(float(logged[-1].split(':')[1]) if logged else -1.0)
+    logged = [ln for ln in log.lines if 'full loss' in ln]       # 'iteration N of M | lr .. | full loss X | time left ..'
+    out['runner_logged_loss'] = np.array(float(logged[-1].split('full loss')[1].split('|')[0]) if logged else -1.0)
     path = runner.save(iter_id=1)                       # rank 0 writes, everyone returns behind the barrier
     out['runner_ckpt_exists'] = np.array(int(os.path.exists(path)))
     out['runner_tmp_left'] = np.array(int(os.path.exists(path + '.tmp')))
