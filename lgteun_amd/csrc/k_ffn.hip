@@ -1196,7 +1196,11 @@ int launch_ffn_fused(int e, const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t 
         if (e == 16 && a1.tile16 != 0) return launch_ffn_fused_bf_t<16>(a1, a2, s);
         if (e == 32 && (a1.tile16 != 0 || !a1.wsplit)) return launch_ffn_fused_bf_t<32>(a1, a2, s);
 #endif
-        if (e == 16 && a1.tile16 == 0) return launch_ffn_xs(a1, a2, s);                 // k_ffn_xs<., NP = 1>
+        if (e == 16 && (a1.tile16 == 0 || a1.tile16 == 4)) {                            // k_ffn_xr<., NP = 1> (round 6) / k_ffn_xs<., NP = 1> (the other save modes, LG_VAR_FFN_XS)
+            const bool save = a1.h2 != nullptr, h2h3 = save && !a1.a1s && !a1.g1s && a2.a3s && !a2.g3s;
+            if (a1.tile16 == 0 && (!save || h2h3)) return launch_ffn_xr(a1, a2, s);
+            return launch_ffn_xs(a1, a2, s);
+        }
         if (e == 32 && a1.tile16 == 0 && a1.wsplit) return launch_ffn_x32(a1, a2, s);   // k_ffn_x32<., NP = 1>
         if (e == 64) return LG_FFN_NOT_FUSED;
         lg_set_error("ffn: precision = 1 with an FFN variant needs a `make AB=1` build");

@@ -84,13 +84,53 @@ __device__ __forceinline__ void pair2(float a, float b, uint32_t& hi, uint32_t& 
     lo = sb_cvt_f16x2(sb_res_lo(hi, a), sb_res_hi(hi, b));
 }
 
+// NP = 2: f16 pairs (the default arithmetic); NP = 1 (precision = 'bf16'): ONE round-to-nearest bf16 piece per operand, plain bf16 MFMAs, the tanh-form
+// GELU and bf16 storage of the saved tensors, as the NP = 1 instances of k_ffn_xs
+template <int NP>
+__device__ __forceinline__ void pairN(float a, float b, uint32_t& hi, uint32_t& lo) {
+    if (NP == 2) pair2(a, b, hi, lo);
+    else {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const bf16x2_t v = {(__bf16)a, (__bf16)b};      // v_cvt_pk_bf16_f32 (RNE)
+        hi = __builtin_bit_cast(uint32_t, v);
+        lo = 0u;
+    }
+}
+__device__ __forceinline__ f32x4_t mfma_b(u32x4_t a, u32x4_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// acc += W X for one 32-deep k-step: the three piece products of the pairs (small terms first: lo hi, hi lo, hi hi) or the one bf16 product
+template <int NP>
+__device__ __forceinline__ f32x4_t mfma3(u32x4_t wh, u32x4_t wl, u32x4_t bh, u32x4_t bl, f32x4_t acc) {
+    if (NP == 2) {
+        acc = mfma_h(wl, bh, acc);
+        acc = mfma_h(wh, bl, acc);
+        return mfma_h(wh, bh, acc);
+    }
+    return mfma_b(wh, bh, acc);
+}
+// GEMM1 (K = 16): pairs: A = {w_lo | w_hi}, {w_hi | 0} against B = {x_hi | x_lo}, {x_hi | 0}; bf16: the second product alone
+template <int NP>
+__device__ __forceinline__ f32x4_t mfma_g1(u32x4_t wa, u32x4_t wb, u32x4_t xb1, u32x4_t xb2, f32x4_t acc) {
+    if (NP == 2) {
+        acc = mfma_h(wa, xb1, acc);
+        return mfma_h(wb, xb2, acc);
+    }
+    return mfma_b(wb, xb2, acc);
+}
 struct GKold { float c1, hr; };
 __device__ __forceinline__ lg_v2f gelu2_k(lg_v2f x, const GKold& k) { return gelu2_scaled(x, k.c1, k.hr); }
+
+template <int NP, class GK>
+__device__ __forceinline__ lg_v2f geluN(lg_v2f x, const GK& k) {
+    if constexpr (NP == 2) return gelu2_k(x, k);
+    else return gelu2_t<true>(x);
+}
 
 }  // namespace xr
 
 // SAVE: 0 nothing; 3 the pre-activations h2 and h3 (the backward re-computes h1 from x: k_ffn1_bwd_xs) -- the two modes of the default path
-template <int SAVE>
+template <int SAVE, int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn_xr(Ffn1Args a1, Ffn2Args a2, int tiles_x, int strips_y, int nstrips,
                                                                                        int SH) {
     using namespace xr;
@@ -103,7 +143,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int uwave = __builtin_amdgcn_readfirstlane(wave);   // provably wave-uniform: branches on it are scalar branches
     const int h = a2.h, w = a2.w;
     // operand scales (k_ffn_prep.hip; k_ffn_x.hip has the derivation): S1 h1, S2 h2, S3 (...) in the accumulators
-    const float sx = a1.scales[0], sa1 = a1.scales[1], sa3 = a1.scales[2], sw1 = a1.scales[3], sw2 = a1.scales[4], sw3 = a1.scales[5];
+    constexpr bool BF = NP == 1;
+    float sx = 1.f, sa1 = 1.f, sa3 = 1.f, sw1 = 1.f, sw2 = 1.f, sw3 = 1.f;
+    if (NP == 2) { sx = a1.scales[0]; sa1 = a1.scales[1]; sa3 = a1.scales[2]; sw1 = a1.scales[3]; sw2 = a1.scales[4]; sw3 = a1.scales[5]; }
     const float S1 = sx * sw1, S2 = sa1 * sw2, S3 = sa3 * sw3;
     const float inv2 = 1.0f / S2, inv3 = 1.0f / S3;   // (powers of two: exact)
 #ifdef LG_XR_OLDGELU   // A/B build: rounds 2 - 5's GELU sequence (common.h gelu2_scaled)
@@ -143,21 +185,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {   // GEMM1 (K = 16): two piece products share one 32-deep instruction: A = {w_lo | w_hi}, {w_hi | 0} against B = {x_hi | x_lo}, {x_hi | 0}
             uint32_t hi, lo;
-            pair2(v1[mt].x * sw1, v1[mt].y * sw1, hi, lo);
+            pairN<NP>(v1[mt].x * sw1, v1[mt].y * sw1, hi, lo);
             d32[(2 * mt) * 256 + t] = i < 2 ? lo : hi;
             d32[(2 * mt + 1) * 256 + t] = i < 2 ? hi : 0u;
         }
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
             uint32_t hi, lo;
-            pair2(v2[f].x * sw2, v2[f].y * sw2, hi, lo);
+            pairN<NP>(v2[f].x * sw2, v2[f].y * sw2, hi, lo);
             d32[(NF1 + 2 * f) * 256 + t] = hi;
             d32[(NF1 + 2 * f + 1) * 256 + t] = lo;
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             uint32_t hi, lo;
-            pair2(v3[s].x * sw3, v3[s].y * sw3, hi, lo);
+            pairN<NP>(v3[s].x * sw3, v3[s].y * sw3, hi, lo);
             d32[(NF1 + NF2 + 2 * s) * 256 + t] = hi;
             d32[(NF1 + NF2 + 2 * s + 1) * 256 + t] = lo;
         }
@@ -244,8 +286,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 const float vs = xg_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
                 const float rstd = __builtin_amdgcn_rsqf(vs * (1.0f / E) + LG_EPS);
                 uint32_t h01, l01, h23, l23;
-                pair2(d0 * rstd * lng.x + lnb.x, d1 * rstd * lng.y + lnb.y, h01, l01);
-                pair2(d2 * rstd * lng.z + lnb.z, d3 * rstd * lng.w + lnb.w, h23, l23);
+                pairN<NP>(d0 * rstd * lng.x + lnb.x, d1 * rstd * lng.y + lnb.y, h01, l01);
+                pairN<NP>(d2 * rstd * lng.z + lnb.z, d3 * rstd * lng.w + lnb.w, h23, l23);
                 xb1[nb] = (u32x4_t){h01, h23, l01, l23};
                 xb2[nb] = (u32x4_t){h01, h23, 0u, 0u};
             }
@@ -257,8 +299,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     f32x4_t acc = {b1v[i].x, b1v[i].y, b1v[i].z, b1v[i].w};
-                    acc = mfma_h(wa[i], xb1[nb], acc);
-                    a1c[nb][i] = mfma_h(wb[i], xb2[nb], acc);
+                    a1c[nb][i] = mfma_g1<NP>(wa[i], wb[i], xb1[nb], xb2[nb], acc);
                 }
             // GEMM2's first tile: fragments and bias requested now, in flight under the GELUs
             u32x4_t wh[NS], wl[NS];
@@ -273,10 +314,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             for (int i = 0; i < NMT; ++i) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const lg_v2f a01 = gelu2_k((lg_v2f){a1c[nb][i][0], a1c[nb][i][1]}, gk1);
-                    const lg_v2f a23 = gelu2_k((lg_v2f){a1c[nb][i][2], a1c[nb][i][3]}, gk1);
-                    pair2(a01.x, a01.y, ghi[nb][i][0], glo[nb][i][0]);
-                    pair2(a23.x, a23.y, ghi[nb][i][1], glo[nb][i][1]);
+                    const lg_v2f a01 = geluN<NP>((lg_v2f){a1c[nb][i][0], a1c[nb][i][1]}, gk1);
+                    const lg_v2f a23 = geluN<NP>((lg_v2f){a1c[nb][i][2], a1c[nb][i][3]}, gk1);
+                    pairN<NP>(a01.x, a01.y, ghi[nb][i][0], glo[nb][i][0]);
+                    pairN<NP>(a23.x, a23.y, ghi[nb][i][1], glo[nb][i][1]);
                     asm volatile("" : "+v"(ghi[nb][i][0]), "+v"(glo[nb][i][0]), "+v"(ghi[nb][i][1]), "+v"(glo[nb][i][1]));
                 }
                 XR_FENCE();
@@ -292,7 +333,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     const float mk = geo[nb].mk;
                     float4 hh = make_float4(k0[nb][0] * mk, k0[nb][1] * mk, k0[nb][2] * mk, k0[nb][3] * mk);
                     if (PART == 0) hh = make_float4(__builtin_fmaf(k1[nb][0], mk, hh.x), __builtin_fmaf(k1[nb][1], mk, hh.y), __builtin_fmaf(k1[nb][2], mk, hh.z), __builtin_fmaf(k1[nb][3], mk, hh.w));
-                    if (SAVE && PART == 0 && geo[nb].inner) HS<false>::st4_nt(a1.h2, geo[nb].prow + 16 * mt2, hh);
+                    if (SAVE && PART == 0 && geo[nb].inner) HS<BF>::st4_nt(a1.h2, geo[nb].prow + 16 * mt2, hh);
                     if (geo[nb].rp >= 0) *reinterpret_cast<float4*>(ring + geo[nb].rp * LDR + 16 * mt2 + 4 * g) = hh;
                 }
             };
@@ -309,9 +350,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                         const u32x4_t bh = {ghi[nb][2 * s][0], ghi[nb][2 * s][1], ghi[nb][2 * s + 1][0], ghi[nb][2 * s + 1][1]};
                         const u32x4_t bl = {glo[nb][2 * s][0], glo[nb][2 * s][1], glo[nb][2 * s + 1][0], glo[nb][2 * s + 1][1]};
                         f32x4_t& acc = (S0 + s) == 0 ? acc0[nb] : acc1[nb];
-                        acc = mfma_h(wl[s], bh, acc);     // small terms first: lo hi, hi lo, hi hi
-                        acc = mfma_h(wh[s], bl, acc);
-                        acc = mfma_h(wh[s], bh, acc);
+                        acc = mfma3<NP>(wh[s], wl[s], bh, bl, acc);
                     }
                 if (mt2 < 3) {   // the next tile's operands: requested behind this tile's MFMAs
 #pragma unroll
@@ -367,8 +406,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 const float vs = xg_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
                 const float rstd = __builtin_amdgcn_rsqf(vs * (1.0f / E) + LG_EPS);
                 uint32_t h01, l01, h23, l23;
-                pair2(d0 * rstd * lng.x + lnb.x, d1 * rstd * lng.y + lnb.y, h01, l01);
-                pair2(d2 * rstd * lng.z + lnb.z, d3 * rstd * lng.w + lnb.w, h23, l23);
+                pairN<NP>(d0 * rstd * lng.x + lnb.x, d1 * rstd * lng.y + lnb.y, h01, l01);
+                pairN<NP>(d2 * rstd * lng.z + lnb.z, d3 * rstd * lng.w + lnb.w, h23, l23);
                 xb1[nb] = (u32x4_t){h01, h23, l01, l23};
                 xb2[nb] = (u32x4_t){h01, h23, 0u, 0u};
             }
@@ -379,8 +418,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     f32x4_t acc = {b1v[i].x, b1v[i].y, b1v[i].z, b1v[i].w};
-                    acc = mfma_h(wa[i], xb1[nb], acc);
-                    a1c[nb][i] = mfma_h(wb[i], xb2[nb], acc);
+                    a1c[nb][i] = mfma_g1<NP>(wa[i], wb[i], xb1[nb], xb2[nb], acc);
                 }
             u32x4_t wh[2], wl[2];
 #pragma unroll
@@ -389,10 +427,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             XR_FENCE();
             uint32_t ghi[2][4][2], glo[2][4][2];
             auto gelu_tile = [&](int nb, int i) {
-                const lg_v2f a01 = gelu2_k((lg_v2f){a1c[nb][i][0], a1c[nb][i][1]}, gk1);
-                const lg_v2f a23 = gelu2_k((lg_v2f){a1c[nb][i][2], a1c[nb][i][3]}, gk1);
-                pair2(a01.x, a01.y, ghi[nb][i][0], glo[nb][i][0]);
-                pair2(a23.x, a23.y, ghi[nb][i][1], glo[nb][i][1]);
+                const lg_v2f a01 = geluN<NP>((lg_v2f){a1c[nb][i][0], a1c[nb][i][1]}, gk1);
+                const lg_v2f a23 = geluN<NP>((lg_v2f){a1c[nb][i][2], a1c[nb][i][3]}, gk1);
+                pairN<NP>(a01.x, a01.y, ghi[nb][i][0], glo[nb][i][0]);
+                pairN<NP>(a23.x, a23.y, ghi[nb][i][1], glo[nb][i][1]);
                 asm volatile("" : "+v"(ghi[nb][i][0]), "+v"(glo[nb][i][0]), "+v"(ghi[nb][i][1]), "+v"(glo[nb][i][1]));
             };
             struct Acc2 { f32x4_t k0, k1; };     // the two k-steps in accumulators of their own (see `halo`: bitwise the split ninth block's arithmetic)
@@ -405,9 +443,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     const u32x4_t bh = {ghi[nb][2 * s][0], ghi[nb][2 * s][1], ghi[nb][2 * s + 1][0], ghi[nb][2 * s + 1][1]};
                     const u32x4_t bl = {glo[nb][2 * s][0], glo[nb][2 * s][1], glo[nb][2 * s + 1][0], glo[nb][2 * s + 1][1]};
                     f32x4_t& acc = s == 0 ? r.k0 : r.k1;
-                    acc = mfma_h(wl[s], bh, acc);     // small terms first: lo hi, hi lo, hi hi
-                    acc = mfma_h(wh[s], bl, acc);
-                    acc = mfma_h(wh[s], bh, acc);
+                    acc = mfma3<NP>(wh[s], wl[s], bh, bl, acc);
                 }
                 return r;
             };
@@ -423,7 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 const float mk = geo[nb].mk;
                 const float4 hh = make_float4(__builtin_fmaf(acc.k1[0], mk, acc.k0[0] * mk), __builtin_fmaf(acc.k1[1], mk, acc.k0[1] * mk),
                                               __builtin_fmaf(acc.k1[2], mk, acc.k0[2] * mk), __builtin_fmaf(acc.k1[3], mk, acc.k0[3] * mk));
-                if (SAVE && geo[nb].inner) HS<false>::st4_nt(a1.h2, geo[nb].prow + 16 * mt2, hh);
+                if (SAVE && geo[nb].inner) HS<BF>::st4_nt(a1.h2, geo[nb].prow + 16 * mt2, hh);
                 *reinterpret_cast<float4*>(ring + geo[nb].rp * LDR + 16 * mt2 + 4 * g) = hh;
             };
 #pragma unroll
@@ -457,7 +493,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 float4 r = *rp4;
                 r = make_float4(__builtin_fmaf(part[mt2][0], ge.mk, r.x), __builtin_fmaf(part[mt2][1], ge.mk, r.y), __builtin_fmaf(part[mt2][2], ge.mk, r.z), __builtin_fmaf(part[mt2][3], ge.mk, r.w));
                 *rp4 = r;
-                if (SAVE && ge.inner) HS<false>::st4_nt(a1.h2, ge.prow + 16 * mt2, r);
+                if (SAVE && ge.inner) HS<BF>::st4_nt(a1.h2, ge.prow + 16 * mt2, r);
             }
         };
 
@@ -576,20 +612,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     uint32_t phi[4][2], plo[4][2];
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
-                        if (SAVE && ok) HS<false>::st4_nt(a2.a3s, ((b * h + y) * (long)w + x) * N1 + 16 * m + 4 * g, make_float4(h3[r2][m][0], h3[r2][m][1], h3[r2][m][2], h3[r2][m][3]));
-                        const lg_v2f a01 = gelu2_k((lg_v2f){h3[r2][m][0], h3[r2][m][1]}, gk3);
-                        const lg_v2f a23 = gelu2_k((lg_v2f){h3[r2][m][2], h3[r2][m][3]}, gk3);
-                        pair2(a01.x, a01.y, phi[m][0], plo[m][0]);
-                        pair2(a23.x, a23.y, phi[m][1], plo[m][1]);
+                        if (SAVE && ok) HS<BF>::st4_nt(a2.a3s, ((b * h + y) * (long)w + x) * N1 + 16 * m + 4 * g, make_float4(h3[r2][m][0], h3[r2][m][1], h3[r2][m][2], h3[r2][m][3]));
+                        const lg_v2f a01 = geluN<NP>((lg_v2f){h3[r2][m][0], h3[r2][m][1]}, gk3);
+                        const lg_v2f a23 = geluN<NP>((lg_v2f){h3[r2][m][2], h3[r2][m][3]}, gk3);
+                        pairN<NP>(a01.x, a01.y, phi[m][0], plo[m][0]);
+                        pairN<NP>(a23.x, a23.y, phi[m][1], plo[m][1]);
                     }
                     f32x4_t o = {b3v.x, b3v.y, b3v.z, b3v.w};
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         const u32x4_t bh = {phi[2 * s][0], phi[2 * s][1], phi[2 * s + 1][0], phi[2 * s + 1][1]};
                         const u32x4_t bl = {plo[2 * s][0], plo[2 * s][1], plo[2 * s + 1][0], plo[2 * s + 1][1]};
-                        o = mfma_h(w3l[s], bh, o);
-                        o = mfma_h(w3h[s], bl, o);
-                        o = mfma_h(w3h[s], bh, o);
+                        o = mfma3<NP>(w3h[s], w3l[s], bh, bl, o);
                     }
                     // ---- epilogue in registers: residual, store, LayerNorm statistics of the next block across the four lane groups
                     const float o0 = o[0] * inv3 + xres[r2].x, o1 = o[1] * inv3 + xres[r2].y, o2 = o[2] * inv3 + xres[r2].z, o3 = o[3] * inv3 + xres[r2].w;
@@ -632,14 +666,17 @@ int launch_ffn_xr(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     ProfScope prof__(LG_K_FFN2, s);
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_xr<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xr<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_xr<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xr<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xr<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_ffn_xr<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) { lg_set_error("ffn_xr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
-    if (!a1.scales || a1.hbf) { lg_set_error("ffn_xr: the f16-pair kernel needs the operand scales and fp32 storage"); return -2; }
+    if (!a1.hbf && !a1.scales) { lg_set_error("ffn_xr: the f16-pair instance needs the operand scales"); return -2; }
     const bool save = a1.h2 != nullptr;
     if (save && (a1.a1s || a1.g1s || !a2.a3s || a2.g3s)) { lg_set_error("ffn_xr: saves h2 / h3 only"); return -2; }
+    if ((long)a2.B * a2.h * a2.w * N1 >= (1ll << 32)) { lg_set_error("ffn_xr: hidden tensor of %ld elements exceeds the 32-bit save index", (long)a2.B * a2.h * a2.w * N1); return -2; }
     const int tiles_x = (a2.w + 15) / 16;
     // strip height: the tallest multiple of 8 rows that still yields >= 512 strips (two resident workgroups per CU), at least 16
     int SH = (a2.h + 7) / 8 * 8;
@@ -647,8 +684,11 @@ int launch_ffn_xr(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     const int strips_y = (a2.h + SH - 1) / SH;
     const int nstrips = a2.B * tiles_x * strips_y;
     const int grid = nstrips < LG_XR_GRID ? nstrips : LG_XR_GRID;
-    if (save) k_ffn_xr<3><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
-    else k_ffn_xr<0><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    if (a1.hbf) {    // precision = 'bf16'
+        if (save) k_ffn_xr<3, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+        else k_ffn_xr<0, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    } else if (save) k_ffn_xr<3, 2><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+    else k_ffn_xr<0, 2><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
     LG_CHECK_LAUNCH();
     return 0;
 }
