@@ -97,7 +97,8 @@ typedef struct lg_config {
 #define LG_VAR_FFN_BWD_BF16X3 (1u << 11) /* FFN backward (k_ffn1_bwd_xs): three bf16 pieces / six products (rounds 3 - 4) instead of f16 pairs / three products with scaled operands */
 #define LG_VAR_ATTN_BWD_CORE_M (1u << 12) /* e = 32 local-mixer backward core: the matrix-pipe k_attn_bwd_core_m (round 5; same results, not faster yet: DESIGN.md 3.3) instead of the vector-pipe k_attn_bwd_core */
 #define LG_VAR_FFN_XS (1u << 13)        /* fused FFN forward at e = 16: the channel-split k_ffn_xs of rounds 2 - 5 (LN(x) / gelu(h1) pieces through LDS, eleven barriers per step) instead of the register-chain k_ffn_xr (round 6) */
-#define LG_VAR_ALL 0x3fffu
+#define LG_VAR_ATTN_BF16X3 (1u << 14)  /* local-mixer forward (k_attn_m): to_qkv and Q K^T on three bf16 pieces / six products (round 5) instead of f16 pairs with static operand scales (round 6) */
+#define LG_VAR_ALL 0x7fffu
 
 typedef struct lg_plan lg_plan; /* host-side, immutable after creation */
 

@@ -37,6 +37,7 @@ LG_VAR_FFT_FULL = 1 << 10
 LG_VAR_FFN_BWD_BF16X3 = 1 << 11
 LG_VAR_ATTN_BWD_CORE_M = 1 << 12
 LG_VAR_FFN_XS = 1 << 13
+LG_VAR_ATTN_BF16X3 = 1 << 14
 LG_ABI_VERSION = 2   # include/lgteun_hip.h: checked against lg_abi_version() when the library is loaded
 
 
@@ -66,6 +67,8 @@ def variant_from_env(env=None):
         v |= LG_VAR_ATTN_BWD_CORE_M
     if env.get('LG_FFN_FWD', '') == 'xs':
         v |= LG_VAR_FFN_XS
+    if env.get('LG_ATTN_SPLIT', '') == 'bf16x3':
+        v |= LG_VAR_ATTN_BF16X3
     return v
 
 

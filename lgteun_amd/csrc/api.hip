@@ -147,6 +147,7 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
         p->attn_bwd_core_m = (v & LG_VAR_ATTN_BWD_CORE_M) ? 1 : 0;
         p->ffn_bwd_bf16x3 = (v & LG_VAR_FFN_BWD_BF16X3) ? 1 : 0;
         p->ffn_xs = (v & LG_VAR_FFN_XS) ? 1 : 0;
+        p->attn_bf16x3 = (v & LG_VAR_ATTN_BF16X3) ? 1 : 0;
     }
     p->off = (int64_t*)malloc(sizeof(int64_t) * n_offsets);
     memcpy(p->off, offsets, sizeof(int64_t) * n_offsets);
@@ -210,7 +211,7 @@ static int data_step_fwd(const lg_plan* pl, const float* P, int stage, const flo
 }
 
 static int block_mixer_fwd(const lg_plan* pl, const float* P, int stage, int j, const BlockBufs& bb, const float* posT, int B,
-                           int flags, uint64_t seed, hipStream_t s, float* fft_scratch = nullptr) {
+                           int flags, uint64_t seed, hipStream_t s, float* fft_scratch = nullptr, const float* attn_scales = nullptr) {
     int rc;
     FftArgs f;
     f.g = bb.g; f.o = bb.o2;
@@ -231,6 +232,7 @@ static int block_mixer_fwd(const lg_plan* pl, const float* P, int stage, int j, 
     t.B = B; t.h = bb.h; t.w = bb.w;
     t.dropout = (flags & LG_FLAG_DROPOUT) ? 1 : 0;
     t.seed = mix_seed(seed, stage, j);
+    t.scales = (attn_scales && pl->attn_f16x2()) ? attn_scales + ((size_t)stage * 5 + j) * 4 : nullptr;   // written by prep_stages for the stages of this call
     return pl->attn_fwd_valu ? launch_attn(bb.e, t, s) : launch_attn_m(bb.e, t, s);
 }
 
@@ -293,8 +295,9 @@ static int prep_stages(const lg_plan* pl, const float* P, int st0, int st1, NetB
                 q.w1 = P + pl->blk(st, j, B_W1); q.b1 = P + pl->blk(st, j, B_B1); q.w2 = P + pl->blk(st, j, B_W2); q.b2 = P + pl->blk(st, j, B_B2);
                 q.dww = P + pl->blk(st, j, B_DWW); q.dwb = P + pl->blk(st, j, B_DWB); q.w3 = P + pl->blk(st, j, B_W3);
                 q.e = j == 2 ? 2 * E : E;
+                q.ln1g = P + pl->blk(st, j, B_LN1G); q.ln1b = P + pl->blk(st, j, B_LN1B); q.qkvw = P + pl->blk(st, j, B_QKVW); q.qkvb = P + pl->blk(st, j, B_QKVB);
             }
-        if ((rc = launch_ffn_scales(n, jobs, nb.ffn_scales + (size_t)st0 * 5 * 8, s))) return rc;
+        if ((rc = launch_ffn_scales(n, jobs, nb.ffn_scales + (size_t)st0 * 5 * 8, s, pl->attn_f16x2() ? nb.attn_scales + (size_t)st0 * 5 * 4 : nullptr))) return rc;
     }
     // the pre-split weight fragments of every e >= 32 block of these stages, behind the scales they are multiplied by (round 5: one launch per
     // forward call instead of one in front of every FFN launch)
@@ -332,9 +335,9 @@ static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z,
     ea.HW = c.H * c.W; ea.total = (long)B * c.H * c.W;
     if ((rc = launch_embed(c.C, ea, s))) return rc;
     // encoder LGB (2 blocks)
-    if ((rc = block_mixer_fwd(pl, P, stage, 0, nb.blk[0], posT + 0 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
+    if ((rc = block_mixer_fwd(pl, P, stage, 0, nb.blk[0], posT + 0 * 8192, B, flags, seed, s, nb.fft_scratch, nb.attn_scales))) return rc;
     if ((rc = block_ffn_fwd(pl, P, stage, 0, nb.blk[0], nb.blk[1].g, 1, B, flags, s, nb.wsplit, nb.ffn_scales))) return rc;
-    if ((rc = block_mixer_fwd(pl, P, stage, 1, nb.blk[1], posT + 1 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
+    if ((rc = block_mixer_fwd(pl, P, stage, 1, nb.blk[1], posT + 1 * 8192, B, flags, seed, s, nb.fft_scratch, nb.attn_scales))) return rc;
     if ((rc = block_ffn_fwd(pl, P, stage, 1, nb.blk[1], nullptr, 0, B, flags, s, nb.wsplit, nb.ffn_scales))) return rc;
     // down
     DownArgs da;
@@ -345,7 +348,7 @@ static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z,
     da.B = B; da.H = c.H; da.W = c.W;
     if ((rc = launch_down(E, da, s))) return rc;
     // bottleneck
-    if ((rc = block_mixer_fwd(pl, P, stage, 2, nb.blk[2], posT + 2 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
+    if ((rc = block_mixer_fwd(pl, P, stage, 2, nb.blk[2], posT + 2 * 8192, B, flags, seed, s, nb.fft_scratch, nb.attn_scales))) return rc;
     if ((rc = block_ffn_fwd(pl, P, stage, 2, nb.blk[2], nullptr, 0, B, flags, s, nb.wsplit, nb.ffn_scales))) return rc;
     // up + fusion
     UpFuseArgs ua;
@@ -357,9 +360,9 @@ static int lgt_fwd(const lg_plan* pl, const float* P, int stage, const float* z,
     ua.B = B; ua.H = c.H; ua.W = c.W;
     if ((rc = launch_upfuse(E, ua, s))) return rc;
     // decoder LGB (2 blocks)
-    if ((rc = block_mixer_fwd(pl, P, stage, 3, nb.blk[3], posT + 3 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
+    if ((rc = block_mixer_fwd(pl, P, stage, 3, nb.blk[3], posT + 3 * 8192, B, flags, seed, s, nb.fft_scratch, nb.attn_scales))) return rc;
     if ((rc = block_ffn_fwd(pl, P, stage, 3, nb.blk[3], nb.blk[4].g, 4, B, flags, s, nb.wsplit, nb.ffn_scales))) return rc;
-    if ((rc = block_mixer_fwd(pl, P, stage, 4, nb.blk[4], posT + 4 * 8192, B, flags, seed, s, nb.fft_scratch))) return rc;
+    if ((rc = block_mixer_fwd(pl, P, stage, 4, nb.blk[4], posT + 4 * 8192, B, flags, seed, s, nb.fft_scratch, nb.attn_scales))) return rc;
     if ((rc = block_ffn_fwd(pl, P, stage, 4, nb.blk[4], nullptr, 0, B, flags, s, nb.wsplit, nb.ffn_scales))) return rc;
     // tail
     TailArgs ta;
@@ -500,10 +503,11 @@ extern "C" int lg_op_block(const lg_plan* plan, const float* params, int32_t sta
     }
     if (which == 1) {
         float* posT = nb.posT;
+        if ((rc = prep_stages(plan, params, stage, stage + 1, nb, s))) return rc;   // the mixer's static operand scales (and the stage's tables; this block's table goes to slot 0 below)
         if ((rc = launch_pos_transpose(params + plan->blk(stage, blk, B_POS), posT, s))) return rc;
         bb.xin = const_cast<float*>(x);
         bb.xmid = y;
-        return block_mixer_fwd(plan, params, stage, blk, bb, posT, B, 0, 0, s, nb.fft_scratch);
+        return block_mixer_fwd(plan, params, stage, blk, bb, posT, B, 0, 0, s, nb.fft_scratch, nb.attn_scales);
     }
     bb.xmid = const_cast<float*>(x);
     bb.xout = y;
@@ -531,9 +535,10 @@ extern "C" int lg_op_block_bwd(const lg_plan* plan, const float* params, float* 
         if ((rc = launch_ln_split(bb.e, x, params + plan->blk(stage, blk, B_LN1G), params + plan->blk(stage, blk, B_LN1B), bb.g, B,
                                   bb.h * bb.w, s)))
             return rc;
+        if ((rc = prep_stages(plan, params, stage, stage + 1, nb, s))) return rc;   // the mixer's static operand scales
         if ((rc = launch_pos_transpose(params + plan->blk(stage, blk, B_POS), nb.posT, s))) return rc;
         bb.xin = const_cast<float*>(x);
-        if ((rc = block_mixer_fwd(plan, params, stage, blk, bb, nb.posT, B, LG_FLAG_SAVE, 0, s, nb.fft_scratch))) return rc;
+        if ((rc = block_mixer_fwd(plan, params, stage, blk, bb, nb.posT, B, LG_FLAG_SAVE, 0, s, nb.fft_scratch, nb.attn_scales))) return rc;
     } else {
         bb.xmid = const_cast<float*>(x);
         if ((rc = prep_stages(plan, params, stage, stage + 1, nb, s))) return rc;

@@ -33,6 +33,12 @@ namespace am {
 // piece tables of the six products (small terms are summed by the matrix core in its own order)
 __host__ __device__ constexpr int pw(int prod) { return prod == 0 ? 1 : prod == 1 ? 1 : prod == 2 ? 2 : prod == 3 ? 1 : prod == 4 ? 3 : 2; }   // A side
 __host__ __device__ constexpr int px(int prod) { return prod == 0 ? 1 : prod == 1 ? 2 : prod == 2 ? 1 : prod == 3 ? 3 : prod == 4 ? 1 : 2; }   // B side
+// NP = 2 (round 6): f16 PAIRS, three products: A side (lo, hi, hi) against B side (hi, lo, hi) -- piece 1 = hi, 2 = lo
+__host__ __device__ constexpr int pw2(int prod) { return prod == 0 ? 2 : 1; }
+__host__ __device__ constexpr int px2(int prod) { return prod == 1 ? 2 : 1; }
+__host__ __device__ constexpr int nprod(int np) { return np == 3 ? 6 : (np == 2 ? 3 : 1); }
+template <int NP> __host__ __device__ constexpr int pwN(int prod) { return NP == 2 ? pw2(prod) : pw(prod); }
+template <int NP> __host__ __device__ constexpr int pxN(int prod) { return NP == 2 ? px2(prod) : px(prod); }
 __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Built with -fno-honor-nans (Makefile): fmaxf() on values the compiler cannot prove canonical (matrix-core results, v_exp_f32 results)
@@ -59,7 +65,7 @@ __device__ __forceinline__ float wave_max(float v) {   // max over all 64 lanes
     return v;
 }
 
-// fp32 patterns whose high halves are the bf16 pieces of v (NP = 3: exact three-way split; NP = 1: round to nearest)
+// fp32 patterns whose high halves are the 16-bit pieces of v (NP = 3: exact three-way bf16 split; NP = 2: f16 hi + lo; NP = 1: bf16 round to nearest)
 template <int NP>
 struct Pat { uint32_t p[3]; };
 template <int NP>
@@ -68,6 +74,10 @@ __device__ __forceinline__ Pat<NP> pat_of(float v) {
     if (NP == 3) {
         const Split3 s = split3(v);
         r.p[0] = s.p1; r.p[1] = s.p2; r.p[2] = s.p3;
+    } else if (NP == 2) {   // f16 pair of the (scaled) value, each piece in the HIGH half of its pattern: v_cvt_pk_f16_f32 (0, v), the exact residual, again
+        r.p[0] = sb_cvt_f16x2(0.0f, v);
+        r.p[1] = sb_cvt_f16x2(0.0f, sb_res_hi(r.p[0], v));
+        r.p[2] = 0;
     } else {
         const __bf16 h = (__bf16)v;
         r.p[0] = (uint32_t)__builtin_bit_cast(uint16_t, h) << 16; r.p[1] = 0; r.p[2] = 0;
@@ -87,25 +97,28 @@ __device__ __forceinline__ f32x4_t mfma_h(u32x4_t a, u32x4_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 
+template <int NP>
+__device__ __forceinline__ f32x4_t mfma_n(u32x4_t a, u32x4_t b, f32x4_t c) { return NP == 2 ? mfma_h(a, b, c) : mfma_bf(a, b, c); }
+
 // Operand fragment k of a lane that holds CH channels as piece patterns pat[ch].p[piece]: slot s = 8 k + j means product s / CH
 // (piece table A or B side) of channel s % CH; slots past the last product are zero.  CH = 1: a dword pairs two products of the one
 // channel; CH >= 2: a dword is a channel pair of one product.
 template <int NP, int CH, bool ASIDE>
 __device__ __forceinline__ u32x4_t build_frag(const Pat<NP> (&pat)[CH], int k) {
-    constexpr int NPROD = NP == 3 ? 6 : 1;
+    constexpr int NPROD = nprod(NP);
     uint32_t d[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int s = 8 * k + 2 * i;
         if constexpr (CH == 1) {
             const int p0 = s, p1 = s + 1;
-            const uint32_t lo = p0 < NPROD ? pat[0].p[(ASIDE ? pw(p0) : px(p0)) - 1] : 0u;
-            const uint32_t hi = p1 < NPROD ? pat[0].p[(ASIDE ? pw(p1) : px(p1)) - 1] : 0u;
+            const uint32_t lo = p0 < NPROD ? pat[0].p[(ASIDE ? pwN<NP>(p0) : pxN<NP>(p0)) - 1] : 0u;
+            const uint32_t hi = p1 < NPROD ? pat[0].p[(ASIDE ? pwN<NP>(p1) : pxN<NP>(p1)) - 1] : 0u;
             d[i] = (p0 < NPROD) ? pack_hi16(lo, hi) : 0u;
         } else {
             const int prod = s / CH, ch = s % CH;
             if (prod < NPROD) {
-                const int pc = (ASIDE ? pw(prod) : px(prod)) - 1;
+                const int pc = (ASIDE ? pwN<NP>(prod) : pxN<NP>(prod)) - 1;
                 d[i] = pack_hi16(pat[ch].p[pc], pat[ch + 1].p[pc]);
             } else d[i] = 0u;
         }
@@ -118,8 +131,8 @@ __device__ __forceinline__ u32x4_t build_frag(const Pat<NP> (&pat)[CH], int k) {
 // input channel 16 (chl >> 2) + 4 g + (chl & 3) with chl = s % CH -- the lane map of the activation fragments -- of output channel
 // oc_of(tile, r) (negative: a zero row).  ALL threads of the block call it.
 template <int NP, int CH, int NK, int NTILE, class OC>
-__device__ __forceinline__ void stage_w(u32x4_t* dst, const float* __restrict__ W, int ldw, int kdim, OC oc_of) {
-    constexpr int NPROD = NP == 3 ? 6 : 1;
+__device__ __forceinline__ void stage_w(u32x4_t* dst, const float* __restrict__ W, int ldw, int kdim, OC oc_of, float wscale = 1.0f) {
+    constexpr int NPROD = nprod(NP);
     constexpr int NF = NTILE * NK;              // fragments; thread tid owns dword (tid & 3) of lane (tid >> 2) in every one of them
     constexpr int CHUNK = NF < 16 ? NF : 16;    // loads in flight per thread and round (every load of a round is requested before its first store)
     uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
@@ -143,8 +156,8 @@ __device__ __forceinline__ void stage_w(u32x4_t* dst, const float* __restrict__ 
             const int s = 8 * k + 2 * i, prod = s / CH, chl = s % CH;
             const int oc = oc_of(tile, r), ic = 16 * (chl >> 2) + 4 * g + (chl & 3);
             const bool ok = prod < NPROD && oc >= 0 && ic < kdim;
-            const int pc = pw(prod < NPROD ? prod : 0) - 1;
-            const Pat<NP> a0 = pat_of<NP>(w0[j]), a1 = pat_of<NP>(w1[j]);
+            const int pc = pwN<NP>(prod < NPROD ? prod : 0) - 1;
+            const Pat<NP> a0 = pat_of<NP>(NP == 2 ? w0[j] * wscale : w0[j]), a1 = pat_of<NP>(NP == 2 ? w1[j] * wscale : w1[j]);
             const uint32_t val = pc == 0 ? pack_hi16(a0.p[0], a1.p[0]) : (pc == 1 ? pack_hi16(a0.p[1], a1.p[1]) : pack_hi16(a0.p[2], a1.p[2]));   // (no runtime index: that is scratch)
             d32[f * 256 + threadIdx.x] = ok ? val : 0u;
         }
@@ -180,12 +193,14 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
     using namespace am;
     using G = Geo<HC>;
     constexpr int E = G::E, D = G::D, DG = G::DG, NCH = G::NCH, NY = G::NY, MTQK = G::MTQK, NTV = G::NTV;
-    constexpr int NPROD = NP == 3 ? 6 : 1;
-    constexpr int CHY = 4 * NY, NKQ = cdiv(NPROD * CHY, 8);       // to_qkv: channels per lane, instructions per output tile
-    constexpr int NKS = cdiv(NPROD * DG, 8);                      // Q K^T: instructions per 16 x 16 score tile
-    constexpr int CHC = 4 * NCH, NKP = cdiv(NPROD * CHC, 8);      // proj
+    // NP = 2 (round 6, the default): to_qkv and Q K^T on f16 PAIRS under static operand scales (a.scales: bounds from the block's weights,
+    // k_ffn_prep.hip); proj stays on bf16 triples (its cat(o1, o2) operand has no static bound: o2 is the FFT mixer's output)
+    constexpr int NPQ = NP == 2 ? 2 : NP, NPP = NP == 2 ? 3 : NP;
+    constexpr int CHY = 4 * NY, NKQ = cdiv(nprod(NPQ) * CHY, 8);  // to_qkv: channels per lane, instructions per output tile
+    constexpr int NKS = cdiv(nprod(NPQ) * DG, 8);                 // Q K^T: instructions per 16 x 16 score tile
+    constexpr int CHC = 4 * NCH, NKP = cdiv(nprod(NPP) * CHC, 8); // proj
     constexpr int MTP = NCH;
-    constexpr int NPV = NP == 3 ? 2 : 1;                          // f16 pieces of p and v
+    constexpr int NPV = NP >= 2 ? 2 : 1;                          // f16 pieces of p and v
     constexpr bool RELOADX = HC >= 32;                            // the residual x is read again (L2) instead of held across the window
     constexpr float LOG2E = 1.44269504088896340736f;
     extern __shared__ __attribute__((aligned(16))) u32x4_t smem4[];
@@ -198,6 +213,10 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
 #ifdef LG_ATTN_STAMPS
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
+    // static operand scales of the pairs (powers of two: exact; taken out again by constants that were multiplications already)
+    float sy = 1.f, sw = 1.f, sq = 1.f, sk = 1.f;
+    if (NP == 2) { sy = a.scales[0]; sw = a.scales[1]; sq = a.scales[2]; sk = a.scales[3]; }
+    const float syw = sy * sw, inv_yw = 1.0f / syw, sqk = sq * sk, inv_qk = 1.0f / sqk;
     // ---- once per (persistent) workgroup: pos_emb in fragment order, the weight fragments
     {
         float4 pv[8];
@@ -208,19 +227,19 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)   // scores live in the log2 domain
-            sPos[j * 256 + threadIdx.x] = make_float4(pv[j].x * LOG2E, pv[j].y * LOG2E, pv[j].z * LOG2E, pv[j].w * LOG2E);
+            sPos[j * 256 + threadIdx.x] = make_float4(pv[j].x * (LOG2E * sqk), pv[j].y * (LOG2E * sqk), pv[j].z * (LOG2E * sqk), pv[j].w * (LOG2E * sqk));   // (NP = 2: the score accumulator holds s_q s_k S)
     }
-    stage_w<NP, CHY, NKQ, MTQK>(sWqk, a.qkvw, HC, HC, [](int t, int r) { return G::qk_oc(t, r); });
-    stage_w<NP, CHY, NKQ, NTV>(sWv, a.qkvw, HC, HC, [](int t, int r) { return G::v_oc(t, r); });
-    stage_w<NP, CHC, NKP, MTP>(sWp, a.projw, E, E, [](int t, int r) { return 16 * t + r; });
+    stage_w<NPQ, CHY, NKQ, MTQK>(sWqk, a.qkvw, HC, HC, [](int t, int r) { return G::qk_oc(t, r); }, sw);
+    stage_w<NPQ, CHY, NKQ, NTV>(sWv, a.qkvw, HC, HC, [](int t, int r) { return G::v_oc(t, r); }, sw);
+    stage_w<NPP, CHC, NKP, MTP>(sWp, a.projw, E, E, [](int t, int r) { return 16 * t + r; });
     // lane constants: biases as initial accumulators, LayerNorm affine of the lane's local-half channels
     float bqk[MTQK][4], bv[NTV], bp[MTP][4], gam[CHY], bet[CHY];
 #pragma unroll
     for (int mt = 0; mt < MTQK; ++mt)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) bqk[mt][v] = a.qkvb[G::qk_oc(mt, 4 * g + v)];
+        for (int v = 0; v < 4; ++v) bqk[mt][v] = a.qkvb[G::qk_oc(mt, 4 * g + v)] * syw;
 #pragma unroll
-    for (int nt = 0; nt < NTV; ++nt) { const int oc = G::v_oc(nt, c); bv[nt] = oc >= 0 ? a.qkvb[oc] : ((c & 3) == 0 ? 1.0f : 0.f); }
+    for (int nt = 0; nt < NTV; ++nt) { const int oc = G::v_oc(nt, c); bv[nt] = oc >= 0 ? a.qkvb[oc] * syw : ((c & 3) == 0 ? 1.0f : 0.f); }
     // HC = 8: the v tile has eight idle columns.  Columns 8 and 12 are ONES (zero weights, bias 1, left unscaled): rows 8 and 12 of O^T = the
     // softmax denominators of the tile's queries, on lane groups 2 and 3 -- one v_permlane32_swap brings them to groups 0 (head 0) and 1 (head 1)
     constexpr bool ONES = HC == 8;
@@ -229,13 +248,13 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
 #pragma unroll
         for (int v = 0; v < 4; ++v) bp[mt][v] = a.projb[16 * mt + 4 * g + v];
 #pragma unroll
-    for (int i = 0; i < CHY; ++i) { const int ch = 16 * (i >> 2) + 4 * g + (i & 3); gam[i] = a.ln1g[ch]; bet[i] = a.ln1b[ch]; }
+    for (int i = 0; i < CHY; ++i) { const int ch = 16 * (i >> 2) + 4 * g + (i & 3); gam[i] = a.ln1g[ch] * sy; bet[i] = a.ln1b[ch] * sy; }
     __syncthreads();
     AM_STAMP(0);
 
     const int nwx = a.w >> 3, nwy = a.h >> 3;
     const long hw = (long)a.h * a.w;
-    const float qscale = (float)(1.0 / sqrt((double)D)) * LOG2E;
+    const float qscale = (float)(1.0 / sqrt((double)D)) * LOG2E * (sq * inv_yw), kscale = sk * inv_yw;   // accumulator (s_y s_w q) -> operand s_q q D^-1/2 log2(e); (s_y s_w k) -> s_k k
     const int lpix = (c >> 3) * a.w + (c & 7);       // the lane's token inside a window, tile 0
     const int lx = lpix * E + 4 * g;                 // ... its first chunk in x / y (floats)
     const int tstep = 2 * a.w;                       // pixels per token tile
@@ -274,22 +293,22 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
                 q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
             }
             const float rstd = __builtin_amdgcn_rsqf(xg_sum(q) * (1.0f / E) + LG_EPS);
-            Pat<NP> yp[CHY];
+            Pat<NPQ> yp[CHY];
 #pragma unroll
             for (int m = 0; m < NY; ++m) {
                 const float xs[4] = {xv[t][m].x, xv[t][m].y, xv[t][m].z, xv[t][m].w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) yp[4 * m + i] = pat_of<NP>((xs[i] - mu) * rstd * gam[4 * m + i] + bet[4 * m + i]);
+                for (int i = 0; i < 4; ++i) yp[4 * m + i] = pat_of<NPQ>((xs[i] - mu) * rstd * gam[4 * m + i] + bet[4 * m + i]);
             }
             u32x4_t yf[NKQ];
 #pragma unroll
-            for (int k = 0; k < NKQ; ++k) yf[k] = build_frag<NP, CHY, false>(yp, k);
+            for (int k = 0; k < NKQ; ++k) yf[k] = build_frag<NPQ, CHY, false>(yp, k);
             // q / k: weights on the A side -> [channel row 4 g + v][token c]
 #pragma unroll
             for (int mt = 0; mt < MTQK; ++mt) {
                 f32x4_t acc = {bqk[mt][0], bqk[mt][1], bqk[mt][2], bqk[mt][3]};
 #pragma unroll
-                for (int k = 0; k < NKQ; ++k) acc = mfma_bf(sWqk[(mt * NKQ + k) * 64 + lane], yf[k], acc);
+                for (int k = 0; k < NKQ; ++k) acc = mfma_n<NPQ>(sWqk[(mt * NKQ + k) * 64 + lane], yf[k], acc);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) qk[t][4 * mt + v] = acc[v];
             }
@@ -298,7 +317,7 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
             for (int nt = 0; nt < NTV; ++nt) {
                 f32x4_t acc = {bv[nt], bv[nt], bv[nt], bv[nt]};
 #pragma unroll
-                for (int k = 0; k < NKQ; ++k) acc = mfma_bf(yf[k], sWv[(nt * NKQ + k) * 64 + lane], acc);
+                for (int k = 0; k < NKQ; ++k) acc = mfma_n<NPQ>(yf[k], sWv[(nt * NKQ + k) * 64 + lane], acc);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) vv[t][nt][v] = acc[v];
             }
@@ -357,16 +376,16 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
             u32x4_t Kf[4][NKS], Qf[4][NKS];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                Pat<NP> kp[DG], qp[DG];
+                Pat<NPQ> kp[DG], qp[DG];
 #pragma unroll
                 for (int dd = 0; dd < DG; ++dd) {
-                    kp[dd] = pat_of<NP>(qk[t][h * DG + dd]);
-                    qp[dd] = pat_of<NP>(qk[t][(2 + h) * DG + dd] * qscale);
+                    kp[dd] = pat_of<NPQ>(NP == 2 ? qk[t][h * DG + dd] * kscale : qk[t][h * DG + dd]);
+                    qp[dd] = pat_of<NPQ>(qk[t][(2 + h) * DG + dd] * qscale);
                 }
 #pragma unroll
                 for (int k = 0; k < NKS; ++k) {
-                    Kf[t][k] = build_frag<NP, DG, true>(kp, k);
-                    Qf[t][k] = build_frag<NP, DG, false>(qp, k);
+                    Kf[t][k] = build_frag<NPQ, DG, true>(kp, k);
+                    Qf[t][k] = build_frag<NPQ, DG, false>(qp, k);
                 }
             }
             // rows 4 g + v of O^T belong to this head on these lanes (HC = 8: channel chunk g of head g; HC = 16: chunks 0, 1 | 2, 3; HC = 32: column tile h)
@@ -381,18 +400,19 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
                     const float4 p4 = sPos[((h * 4 + qt) * 4 + kt) * 64 + lane];
                     S[kt] = (f32x4_t){p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
-                    for (int k = 0; k < NKS; ++k) S[kt] = mfma_bf(Kf[kt][k], Qf[qt][k], S[kt]);
+                    for (int k = 0; k < NKS; ++k) S[kt] = mfma_n<NPQ>(Kf[kt][k], Qf[qt][k], S[kt]);
                 }
                 float mx = vmax3(vmax3(S[0][0], S[0][1], S[0][2]), S[0][3], S[1][0]);
                 mx = vmax3(vmax3(mx, S[1][1], S[1][2]), S[1][3], S[2][0]);
                 mx = vmax3(vmax3(mx, S[2][1], S[2][2]), S[2][3], S[3][0]);
                 mx = vmax2(vmax3(mx, S[3][1], S[3][2]), S[3][3]);
-                mx = xg_max(mx) - 11.0f;     // p = 2^(s - max + 11) in (0, 2^11]: f16's normal range also holds the low piece of the large ones
+                const float c0 = __builtin_fmaf(-xg_max(mx), inv_qk, 11.0f);   // p = 2^(s - max + 11) in (0, 2^11]: f16's normal range also holds the low piece of the large ones
+                                                                                // (the accumulators hold s_q s_k s: one fma takes the scale out and the maximum off)
                 float l = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) { S[kt][v] = __builtin_amdgcn_exp2f(S[kt][v] - mx); if (!ONES) l += S[kt][v]; }
+                    for (int v = 0; v < 4; ++v) { S[kt][v] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][v], inv_qk, c0)); if (!ONES) l += S[kt][v]; }
                 if (!ONES) l = xg_sum(l);
                 // O^T[channel][query] += V^T[channel][key] P^T[key][query]
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -417,7 +437,7 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
                     const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0]), __float_as_uint(acc[0]), false, false);
                     l = __uint_as_float(r.y);
                 }
-                const float f = __builtin_amdgcn_ldexpf(__builtin_amdgcn_rcpf(l), -sh);
+                const float f = __builtin_amdgcn_ldexpf(__builtin_amdgcn_rcpf(l), -sh) * inv_yw;     // (v carries s_y s_w)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) cat[qt][mo][v] = mine ? acc[v] * f : cat[qt][mo][v];
             }
@@ -428,14 +448,14 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
             const long pix = pix0 + 2 * qt * a.w;
-            Pat<NP> cp[CHC];
+            Pat<NPP> cp[CHC];
 #pragma unroll
             for (int m = 0; m < NCH; ++m)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) cp[4 * m + v] = pat_of<NP>(cat[qt][m][v]);
+                for (int v = 0; v < 4; ++v) cp[4 * m + v] = pat_of<NPP>(cat[qt][m][v]);
             u32x4_t cf[NKP];
 #pragma unroll
-            for (int k = 0; k < NKP; ++k) cf[k] = build_frag<NP, CHC, false>(cp, k);
+            for (int k = 0; k < NKP; ++k) cf[k] = build_frag<NPP, CHC, false>(cp, k);
 #pragma unroll
             for (int mt = 0; mt < MTP; ++mt) {
                 f32x4_t acc = {bp[mt][0], bp[mt][1], bp[mt][2], bp[mt][3]};
@@ -468,8 +488,8 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
 template <int HC, int NP>
 static int launch_attn_m_t(const AttnArgs& a, hipStream_t s) {
     using G = am::Geo<HC>;
-    constexpr int NPROD = NP == 3 ? 6 : 1;
-    constexpr int NKQ = am::cdiv(NPROD * 4 * G::NY, 8), NKP = am::cdiv(NPROD * 4 * G::NCH, 8);
+    constexpr int NPQ = NP == 2 ? 2 : NP, NPP = NP == 2 ? 3 : NP;
+    constexpr int NKQ = am::cdiv(am::nprod(NPQ) * 4 * G::NY, 8), NKP = am::cdiv(am::nprod(NPP) * 4 * G::NCH, 8);
     const int nwin = a.B * (a.h / 8) * (a.w / 8);
     const int nquads = (nwin + 3) / 4;
     const size_t lds = (size_t)(2 * 4 * 4 * 64 + (G::MTQK + G::NTV) * NKQ * 64 + G::NCH * NKP * 64) * 16;
@@ -507,6 +527,10 @@ int launch_attn_m(int e, const AttnArgs& a, hipStream_t s) {
         if (e == 16) return launch_attn_m_t<8, 1>(a, s);
         if (e == 32) return launch_attn_m_t<16, 1>(a, s);
         if (e == 64) return launch_attn_m_t<32, 1>(a, s);
+    } else if (a.scales) {   // round 6: to_qkv and Q K^T on f16 pairs under the block's static scales
+        if (e == 16) return launch_attn_m_t<8, 2>(a, s);
+        if (e == 32) return launch_attn_m_t<16, 2>(a, s);
+        if (e == 64) return launch_attn_m_t<32, 2>(a, s);
     } else {
         if (e == 16) return launch_attn_m_t<8, 3>(a, s);
         if (e == 32) return launch_attn_m_t<16, 3>(a, s);

@@ -35,10 +35,34 @@ __device__ __forceinline__ float pow2_below(float bound) {   // the power of two
 }
 }  // namespace
 
-__global__ __launch_bounds__(256) void k_ffn_scales(FfnPrepTable tab, float* __restrict__ out) {
+// blockIdx.y = 1: the LOCAL MIXER's static scales of the same block (round 6: to_qkv and Q K^T of k_attn_m on f16 pairs), from bounds of the same kind:
+//     |LN1(x)_k| <= sqrt(e) |gamma_k| + |beta_k| =: y_k  (local half: k < e / 2);   |q_c|, |k_c| <= |b_c| + sum_k |W_ck| y_k
+// attn_out[job][4] = { s_y, s_w, s_q, s_k }: scales of LN1(x), the to_qkv weights, q * D^-1/2 log2(e) and k
+__global__ __launch_bounds__(256) void k_ffn_scales(FfnPrepTable tab, float* __restrict__ out, float* __restrict__ attn_out) {
     const FfnPrepJob& j = tab.j[blockIdx.x];
     const int e = j.e, n1 = 4 * e, t = threadIdx.x;
     __shared__ float ylim[64], a1lim[256], red[256];
+    if (blockIdx.y == 1) {
+        const int hc = e / 2, d = hc / 2;
+        float by = 0.f;
+        if (t < hc) { by = sqrtf((float)e) * fabsf(j.ln1g[t]) + fabsf(j.ln1b[t]); ylim[t] = by; }
+        const float By = block_max(by, red);
+        float bq = 0.f, bk = 0.f, mw = 0.f;
+        if (t < 2 * hc) {      // rows [0, hc): q channels, [hc, 2 hc): k channels of to_qkv
+            float b = fabsf(j.qkvb[t]);
+            for (int k = 0; k < hc; ++k) b += fabsf(j.qkvw[(size_t)t * hc + k]) * ylim[k];
+            if (t < hc) bq = b; else bk = b;
+        }
+        for (int i = t; i < 3 * hc * hc; i += 256) mw = fmaxf(mw, fabsf(j.qkvw[i]));
+        const float Bq = block_max(bq, red) * (1.44269504088896340736f / sqrtf((float)d));
+        const float Bk = block_max(bk, red);
+        const float MW = block_max(mw, red);
+        if (t == 0) {
+            float* o = attn_out + (size_t)blockIdx.x * 4;
+            o[0] = pow2_below(By); o[1] = pow2_below(MW); o[2] = pow2_below(Bq); o[3] = pow2_below(Bk);
+        }
+        return;
+    }
     float by = 0.f;
     if (t < e) { by = sqrtf((float)e) * fabsf(j.ln2g[t]) + fabsf(j.ln2b[t]); ylim[t] = by; }
     const float By = block_max(by, red);
@@ -72,14 +96,14 @@ __global__ __launch_bounds__(256) void k_ffn_scales(FfnPrepTable tab, float* __r
     }
 }
 
-int launch_ffn_scales(int n, const FfnPrepJob* jobs, float* out, hipStream_t s) {
+int launch_ffn_scales(int n, const FfnPrepJob* jobs, float* out, hipStream_t s, float* attn_out) {
     for (int j0 = 0; j0 < n; j0 += LG_MAX_FFN_PREP_JOBS) {   // (the table travels as a kernel argument: at most LG_MAX_FFN_PREP_JOBS blocks per launch)
         const int m = n - j0 < LG_MAX_FFN_PREP_JOBS ? n - j0 : LG_MAX_FFN_PREP_JOBS;
         FfnPrepTable tab;
         for (int i = 0; i < LG_MAX_FFN_PREP_JOBS; ++i) tab.j[i] = jobs[j0 + (i < m ? i : 0)];
         for (int i = 0; i < m; ++i)
             if (tab.j[i].e != 16 && tab.j[i].e != 32 && tab.j[i].e != 64) { lg_set_error("ffn_scales: e=%d unsupported", tab.j[i].e); return -2; }
-        k_ffn_scales<<<m, 256, 0, s>>>(tab, out + (size_t)j0 * 8);
+        k_ffn_scales<<<dim3(m, attn_out ? 2 : 1), 256, 0, s>>>(tab, out + (size_t)j0 * 8, attn_out ? attn_out + (size_t)j0 * 4 : nullptr);
         LG_CHECK_LAUNCH();
     }
     return 0;

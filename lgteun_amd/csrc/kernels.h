@@ -108,6 +108,7 @@ struct AttnArgs {
     int dropout;
     uint64_t seed;
     int bf16;           // k_attn_m: 1 = one round-to-nearest piece per operand (precision = 'bf16'), 0 = fp32-equivalent split arithmetic
+    const float* scales = nullptr;   // k_attn_m: this block's static operand scales { s_y, s_w, s_q, s_k } (k_ffn_prep.hip, round 6): to_qkv and Q K^T on f16 pairs; nullptr: bf16 triples
 };
 int launch_attn(int e, const AttnArgs& a, hipStream_t s);     // round 2's kernel: lane = token, every product on the vector pipe (LG_VAR_ATTN_FWD_VALU)
 int launch_attn_m(int e, const AttnArgs& a, hipStream_t s);   // round 5: every product on the matrix pipe (k_attn_m.hip)
@@ -131,10 +132,10 @@ struct Ffn1Args {
                            // fused forward kernels; nullptr = the three-piece bf16 arithmetic (NP = 3)
 };
 // operand scales of the f16-pair FFN arithmetic: one job per block, all in one launch (k_ffn_prep.hip); out[job][8]
-struct FfnPrepJob { const float *ln2g, *ln2b, *w1, *b1, *w2, *b2, *dww, *dwb, *w3; int e; };
+struct FfnPrepJob { const float *ln2g, *ln2b, *w1, *b1, *w2, *b2, *dww, *dwb, *w3; int e; const float *ln1g, *ln1b, *qkvw, *qkvb; };   // ln1 / qkv: the local mixer's static scales (attn_out)
 #define LG_MAX_FFN_PREP_JOBS 40
 struct FfnPrepTable { FfnPrepJob j[LG_MAX_FFN_PREP_JOBS]; };
-int launch_ffn_scales(int n, const FfnPrepJob* jobs, float* out, hipStream_t s);
+int launch_ffn_scales(int n, const FfnPrepJob* jobs, float* out, hipStream_t s, float* attn_out = nullptr);   // attn_out[job][4] = { s_y, s_w, s_q, s_k } (nullptr: not computed)
 // pre-split weight fragments of the e >= 32 FFN blocks: one job per block, all blocks of a forward call in ONE launch (k_ffn_x32.hip)
 struct SplitWJob { const float *w1, *w2, *w3, *scales; void* out; int e, np; };
 struct SplitWTable { SplitWJob j[LG_MAX_FFN_PREP_JOBS]; };

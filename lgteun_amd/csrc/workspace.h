@@ -38,6 +38,7 @@ struct NetBufs {
     float* t_up;      // saved up-path tensor [B,H,W,E] (train)
     float* fft_scratch;  // PAN > 128 only: half-spectrum scratch of the split FFT path
     float* ffn_scales;   // [K][5][8] operand scales of the f16-pair FFN arithmetic (k_ffn_prep.hip), written once per forward call
+    float* attn_scales;  // [K][5][4] static operand scales of the local mixer's f16-pair products { s_y, s_w, s_q, s_k } (k_ffn_prep.hip), written once per forward call
     float* wsplit;       // [K][5] slots of pre-split (and pre-scaled) weight fragments of the e >= 32 FFN blocks (k_ffn_x32.hip), written once per forward call
     size_t set_off, set_bytes;  // the per-LGT activation set [set_off, set_off + set_bytes): train == 2 carves K of them back to back
     size_t bytes;
@@ -72,6 +73,7 @@ static inline void carve(const lg_plan* plan, int B, int train, void* base, NetB
     nb.pr = cv.take(B * P0);
     nb.posT = cv.take((size_t)c.K * 5 * 2 * 64 * 64);
     nb.ffn_scales = cv.take((size_t)c.K * 5 * 8);
+    nb.attn_scales = cv.take((size_t)c.K * 5 * 4);
     nb.wsplit = cv.take((size_t)c.K * 5 * (ffn_wsplit_bytes((int)(2 * E)) / sizeof(float)));   // [K][5] slots sized for the widest block (level 1: e = 8 C): written once per forward call (prep_stages)
     nb.deadout = cv.take(B * c.C * P0);
     nb.X[0] = nb.Z[0];

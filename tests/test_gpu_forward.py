@@ -241,3 +241,30 @@ def test_register_chain_ffn_agrees_with_the_channel_split_kernel(gpu, monkeypatc
             monkeypatch.delenv('LG_FFN_FWD', raising=False)
         den = float((want - x.double().cpu()).norm())
         assert float((got - want).norm()) <= 1e-6 * den, (B, n, float((got - want).norm()) / den)
+
+
+def test_mixer_f16_pair_products_agree_with_the_bf16_triples(gpu, monkeypatch):
+    """round 6: to_qkv and Q K^T of k_attn_m multiply f16 pairs under static operand scales (bounds from the block's LayerNorm affine and to_qkv
+    weights, k_ffn_prep.hip) instead of bf16 triples (LG_ATTN_SPLIT=bf16x3): the mixer half-block of both levels, C = 4 and 8 (head dimensions
+    4, 8, 16), agrees to 2e-6 of its own contribution -- also with the LayerNorm affine and the to_qkv weights pushed out of f16's range in
+    opposite directions"""
+    from gpu_helpers import Ops, make_module
+    rng = np.random.default_rng(79)
+    for C in (4, 8):
+        for blk, e, n in ((0, 4 * C, 32), (2, 8 * C, 16)):
+            for mult in ({}, {'norm.weight': 1e3, 'norm.bias': 1e3, 'fn.local_mixer.to_qkv.weight': 1e-3}, {'norm.weight': 1e-4, 'norm.bias': 1e-4, 'fn.local_mixer.to_qkv.weight': 3e3}):
+                x = T((rng.standard_normal((2, n, n, e)) * 1.5 + 0.3).astype(np.float32)).cuda()
+                got = {}
+                for split in ('f16x2', 'bf16x3'):
+                    monkeypatch.setenv('LG_ATTN_SPLIT', split)
+                    net = make_module(C, 1)
+                    sd = net.state_dict()
+                    pre = 'prior_module.0.' + ('encoder_layers.0.0.blocks.0.' if blk == 0 else 'bottleneck.blocks.0.') + '0.fn.'
+                    for k, f in mult.items():
+                        sd[pre + k] = sd[pre + k] * f
+                    net.load_state_dict(sd)
+                    got[split] = Ops(net, 32, 32).block(0, blk, 1, x).double().cpu()
+                monkeypatch.delenv('LG_ATTN_SPLIT', raising=False)
+                den = float((got['bf16x3'] - x.double().cpu()).norm())
+                err = float((got['f16x2'] - got['bf16x3']).norm()) / den
+                assert torch.isfinite(got['f16x2']).all() and err <= 2e-6, (C, blk, sorted(mult), err)
