@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := lgteun_amd/csrc
-SRCS  := $(CSRC)/api.hip $(CSRC)/k_pixel.hip $(CSRC)/k_dstep.hip $(CSRC)/k_fft.hip $(CSRC)/k_attn.hip $(CSRC)/k_attn_m.hip $(CSRC)/k_ffn.hip $(CSRC)/k_ffn_prep.hip $(CSRC)/k_ffn_x.hip $(CSRC)/k_ffn_xr.hip $(CSRC)/k_ffn_x32.hip $(CSRC)/k_ffn_x64.hip $(CSRC)/k_bwd.hip $(CSRC)/k_bwd_pixel.hip $(CSRC)/k_wgrad.hip $(CSRC)/k_ffn_bwd.hip $(CSRC)/k_ffn_bwd_x.hip $(CSRC)/k_ffn_dwbwd_x.hip $(CSRC)/k_ffn1_bwd_x32.hip $(CSRC)/k_attn_bwd.hip $(CSRC)/k_attn_bwd_f.hip $(CSRC)/k_attn_bwd_m.hip
+SRCS  := $(CSRC)/api.hip $(CSRC)/k_pixel.hip $(CSRC)/k_dstep.hip $(CSRC)/k_fft.hip $(CSRC)/k_attn.hip $(CSRC)/k_attn_m.hip $(CSRC)/k_ffn.hip $(CSRC)/k_ffn_prep.hip $(CSRC)/k_ffn_x.hip $(CSRC)/k_ffn_xr.hip $(CSRC)/k_ffn_x32.hip $(CSRC)/k_ffn_x64.hip $(CSRC)/k_bwd.hip $(CSRC)/k_bwd_pixel.hip $(CSRC)/k_wgrad.hip $(CSRC)/k_ffn_bwd.hip $(CSRC)/k_ffn_bwd_x.hip $(CSRC)/k_ffn_dwbwd_x.hip $(CSRC)/k_ffn_dwbwd_h.hip $(CSRC)/k_ffn1_bwd_x32.hip $(CSRC)/k_attn_bwd.hip $(CSRC)/k_attn_bwd_f.hip $(CSRC)/k_attn_bwd_m.hip
 # A/B-only kernels stay out of the product library: `make AB=1` adds k_ffn_xp (LG_FFN_IMPL=xp: the software-pipelined variant of the
 # fused FFN forward, bitwise the same results, measured 2.5 % slower)
 # (AB objects get their own suffix, so a product build never links objects compiled with the other flag set and vice versa)

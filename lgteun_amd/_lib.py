@@ -38,6 +38,7 @@ LG_VAR_FFN_BWD_BF16X3 = 1 << 11
 LG_VAR_ATTN_BWD_CORE_M = 1 << 12
 LG_VAR_FFN_XS = 1 << 13
 LG_VAR_ATTN_BF16X3 = 1 << 14
+LG_VAR_FFN_H3_RECOMPUTE = 1 << 15
 LG_ABI_VERSION = 2   # include/lgteun_hip.h: checked against lg_abi_version() when the library is loaded
 
 
@@ -69,6 +70,8 @@ def variant_from_env(env=None):
         v |= LG_VAR_FFN_XS
     if env.get('LG_ATTN_SPLIT', '') == 'bf16x3':
         v |= LG_VAR_ATTN_BF16X3
+    if env.get('LG_FFN_H3', '') == 'recompute':
+        v |= LG_VAR_FFN_H3_RECOMPUTE
     return v
 
 

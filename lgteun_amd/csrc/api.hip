@@ -148,6 +148,7 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
         p->ffn_bwd_bf16x3 = (v & LG_VAR_FFN_BWD_BF16X3) ? 1 : 0;
         p->ffn_xs = (v & LG_VAR_FFN_XS) ? 1 : 0;
         p->attn_bf16x3 = (v & LG_VAR_ATTN_BF16X3) ? 1 : 0;
+        p->ffn_h3_re = (v & LG_VAR_FFN_H3_RECOMPUTE) ? 1 : 0;
     }
     p->off = (int64_t*)malloc(sizeof(int64_t) * n_offsets);
     memcpy(p->off, offsets, sizeof(int64_t) * n_offsets);
@@ -253,7 +254,7 @@ static int block_ffn_fwd(const lg_plan* pl, const float* P, int stage, int j, co
     a1.wsplit_ready = (wsplit && bb.e >= 32) ? 1 : 0;
     a1.scales = pl->ffn_f16x2(bb.e) ? ffn_scales + ((size_t)stage * 5 + j) * 8 : nullptr;   // written by prep_stages for the stages of this call
     Ffn2Args a2;
-    a2.h2 = bb.h2; a2.x = bb.xmid; a2.a3s = (flags & LG_FLAG_SAVE) ? bb.a3 : nullptr; a2.g3s = ((flags & LG_FLAG_SAVE) && !pre && !pl->ffn_dw_x32(bb.e, bb.h, bb.w)) ? bb.g3 : nullptr; a2.y = bb.xout;   // g3s null with a3s set: a3 receives the PRE-activation h3
+    a2.h2 = bb.h2; a2.x = bb.xmid; a2.a3s = ((flags & LG_FLAG_SAVE) && !pl->ffn_h3_recompute(bb.e)) ? bb.a3 : nullptr; a2.g3s = ((flags & LG_FLAG_SAVE) && !pre && !pl->ffn_dw_x32(bb.e, bb.h, bb.w)) ? bb.g3 : nullptr; a2.y = bb.xout;   // g3s null with a3s set: a3 receives the PRE-activation h3
     a2.g = g_next;
     a2.dww = P + pl->blk(stage, j, B_DWW); a2.dwb = P + pl->blk(stage, j, B_DWB);
     a2.w3 = P + pl->blk(stage, j, B_W3); a2.b3 = P + pl->blk(stage, j, B_B3);

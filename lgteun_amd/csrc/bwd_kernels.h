@@ -250,6 +250,7 @@ struct FfnDwBwdXArgs {
     int hbf;           // 1: precision = 'bf16' (plain bf16 products, bf16 storage of h2 / h3 / dh2)
     const float* w3t;  // [4e][e] transposed W3
     const float* dww;  // [4e,1,3,3]
+    const float* dwb = nullptr;   // [4e] depthwise bias: k_ffn_dw_bwd_h only (it re-computes h3 = dw3x3(h2) + b; h3 is then nullptr)
     float* slab;       // FFN_DW_BWD_X_WGS rows of FFN_DW_BWD_X_ROW floats (per-workgroup partial sums)
     float *d_dww, *d_dwb, *d_w3, *d_b3;   // accumulated (+=) by the deferred reduce launch
     int B, h, w;
@@ -263,6 +264,11 @@ struct FfnDwBwdXArgs {
 #define FFN_DW_BWD_X32_ROW 2720   // e = 32: [d dww 64 x 9 | d dwb 64 | dW3 32 x 64 | db3 32] per channel half; 256 workgroups per half
 inline size_t ffn_dw_bwd_x_slab_floats(int e) { return (size_t)FFN_DW_BWD_X_WGS * (e == 16 ? FFN_DW_BWD_X_ROW : FFN_DW_BWD_X32_ROW); }
 int launch_ffn_dw_bwd_xs(int e, const FfnDwBwdXArgs& a, hipStream_t s);   // e = 16 | 32
+// round 6, e = 16: the same half WITHOUT a saved h3 (re-computed from an LDS ring of h2; two channel halves of 32): k_ffn_dwbwd_h.hip
+#define FFN_DW_BWD_H_WGS 512
+#define FFN_DW_BWD_H_ROW 848      // [d dww 32 x 9 | d dwb 32 | dW3 16 x 32 | db3 16] per workgroup and channel half
+inline size_t ffn_dw_bwd_h_slab_floats() { return (size_t)2 * FFN_DW_BWD_H_WGS * FFN_DW_BWD_H_ROW; }
+int launch_ffn_dw_bwd_h(const FfnDwBwdXArgs& a, hipStream_t s);
 int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[cols][rows]
 int launch_transpose3(const float* const* src, float* const* dst, const int* rows, const int* cols, int njobs, hipStream_t s);
 

@@ -53,6 +53,7 @@ static void carve_bwd(const lg_plan* plan, int B, void* base, BwdBufs& bb) {
         }
     if (ffn_dw_bwd_x_slab_floats(16) > sl) sl = ffn_dw_bwd_x_slab_floats(16);
     if (ffn_dw_bwd_x_slab_floats(32) > sl) sl = ffn_dw_bwd_x_slab_floats(32);
+    if (ffn_dw_bwd_h_slab_floats() > sl) sl = ffn_dw_bwd_h_slab_floats();
     bb.slab_cap = 4 * sl;
     bb.slab_arena = cv.take(bb.slab_cap);
     bb.ffn_scales = nullptr;
@@ -112,15 +113,16 @@ static int ffn_half_bwd(const lg_plan* pl, const float* P, float* G, int st, int
         // two launches per half-block: the strip-walking spatial half (dh3 in LDS -> dh2, depthwise gradients, dW3 / db3) and the pixelwise
         // half (h1 re-computed, dx, LayerNorm gradients, dW1 / db1, dW2 / db2); dh2 is the only tensor between them
         FfnDwBwdXArgs fk;
-        fk.dy = dy; fk.h3 = fb.a3; fk.h2 = fb.h2; fk.dh2 = bb.dh2; fk.w3t = bb.w3t[j]; fk.dww = P + pl->blk(st, j, B_DWW);
-        fk.slab = bb.rq.take(ffn_dw_bwd_x_slab_floats(e));
+        const bool h3re = pl->ffn_h3_recompute(e) && (fb.h & 7) == 0 && (fb.w & 15) == 0;   // round 6: the forward saved h2 only; h3 is re-computed in the kernel
+        fk.dy = dy; fk.h3 = h3re ? nullptr : fb.a3; fk.h2 = fb.h2; fk.dh2 = bb.dh2; fk.w3t = bb.w3t[j]; fk.dww = P + pl->blk(st, j, B_DWW); fk.dwb = P + pl->blk(st, j, B_DWB);
+        fk.slab = bb.rq.take(h3re ? ffn_dw_bwd_h_slab_floats() : ffn_dw_bwd_x_slab_floats(e));
         if (!fk.slab) return -3;
         fk.d_dww = G + pl->blk(st, j, B_DWW); fk.d_dwb = G + pl->blk(st, j, B_DWB); fk.d_w3 = G + pl->blk(st, j, B_W3); fk.d_b3 = G + pl->blk(st, j, B_B3);
         fk.B = B; fk.h = fb.h; fk.w = fb.w; fk.hbf = hbf;
         // f16-pair products in the pixelwise half (round 5): the forward's operand scales of this block + max |dh2|, which the spatial half leaves in word 6
         float* fsc = (bb.ffn_scales && pl->ffn_f16x2(e) && !pl->ffn_bwd_bf16x3 && !hbf) ? bb.ffn_scales + ((size_t)st * 5 + j) * 8 : nullptr;
         fk.dh2_max = fsc ? fsc + 6 : nullptr;
-        RC(launch_ffn_dw_bwd_xs(e, fk, s));
+        RC(h3re ? launch_ffn_dw_bwd_h(fk, s) : launch_ffn_dw_bwd_xs(e, fk, s));
         Ffn1BwdXArgs fx;
         fx.scales = fsc;
         fx.dh2 = bb.dh2; fx.x = fb.xmid; fx.dy = dy; fx.dx = tmp;

@@ -1221,7 +1221,7 @@ int launch_ffn_fused(int e, const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t 
     if (e == 16) {
         // round 6: the register chain k_ffn_xr where it exists (f16 pairs, nothing or h2 / h3 saved); k_ffn_xs for the bf16 x 3 arithmetic, the
         // other save modes and as the A/B variant LG_VAR_FFN_XS
-        const bool save = a1.h2 != nullptr, h2h3 = save && !a1.a1s && !a1.g1s && a2.a3s && !a2.g3s;
+        const bool save = a1.h2 != nullptr, h2h3 = save && !a1.a1s && !a1.g1s && !a2.g3s;   // (a3s null: h2 alone, the backward re-computes h3)
         if (a1.tile16 == 0 && a1.scales && (!save || h2h3)) return launch_ffn_xr(a1, a2, s);
         return launch_ffn_xs(a1, a2, s);
     }

@@ -612,7 +612,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     uint32_t phi[4][2], plo[4][2];
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
-                        if (SAVE && ok) HS<BF>::st4_nt(a2.a3s, ((b * h + y) * (long)w + x) * N1 + 16 * m + 4 * g, make_float4(h3[r2][m][0], h3[r2][m][1], h3[r2][m][2], h3[r2][m][3]));
+#ifndef LG_XR_NOH3   // diagnostic A/B: what not saving h3 would buy the forward (VERDICT r5 lever b)
+                        if (SAVE && ok && a2.a3s) HS<BF>::st4_nt(a2.a3s, ((b * h + y) * (long)w + x) * N1 + 16 * m + 4 * g, make_float4(h3[r2][m][0], h3[r2][m][1], h3[r2][m][2], h3[r2][m][3]));
+#endif
                         const lg_v2f a01 = geluN<NP>((lg_v2f){h3[r2][m][0], h3[r2][m][1]}, gk3);
                         const lg_v2f a23 = geluN<NP>((lg_v2f){h3[r2][m][2], h3[r2][m][3]}, gk3);
                         pairN<NP>(a01.x, a01.y, phi[m][0], plo[m][0]);
@@ -675,7 +677,7 @@ int launch_ffn_xr(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     }
     if (!a1.hbf && !a1.scales) { lg_set_error("ffn_xr: the f16-pair instance needs the operand scales"); return -2; }
     const bool save = a1.h2 != nullptr;
-    if (save && (a1.a1s || a1.g1s || !a2.a3s || a2.g3s)) { lg_set_error("ffn_xr: saves h2 / h3 only"); return -2; }
+    if (save && (a1.a1s || a1.g1s || a2.g3s)) { lg_set_error("ffn_xr: saves h2 / h3 (or h2 alone: a3s null, the backward re-computes h3) only"); return -2; }
     if ((long)a2.B * a2.h * a2.w * N1 >= (1ll << 32)) { lg_set_error("ffn_xr: hidden tensor of %ld elements exceeds the 32-bit save index", (long)a2.B * a2.h * a2.w * N1); return -2; }
     const int tiles_x = (a2.w + 15) / 16;
     // strip height: the tallest multiple of 8 rows that still yields >= 512 strips (two resident workgroups per CU), at least 16

@@ -361,9 +361,9 @@ def test_ffn_backward_kernels_at_awkward_shapes(C, B, h, w):
         assert float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)) < 2e-4, (k, float(np.abs(got - ref).max() / np.abs(ref).max()))
 
 
-@pytest.mark.parametrize('env', [{'LG_FFN_DWBWD': 'tile'}, {'LG_FFN_SAVE': '3'}, {'LG_FFN_BWD32': 'pair'}, {'LG_FFN_BWD_SPLIT': 'bf16x3'}])
+@pytest.mark.parametrize('env', [{'LG_FFN_DWBWD': 'tile'}, {'LG_FFN_SAVE': '3'}, {'LG_FFN_BWD32': 'pair'}, {'LG_FFN_BWD_SPLIT': 'bf16x3'}, {'LG_FFN_H3': 'recompute'}])
 def test_ffn_backward_ab_paths_agree_with_the_default(env, monkeypatch):
-    """the A/B switches of the FFN backward (round 2's tile kernel + weight-gradient launch; the three-tensor save mode; round 2's
+    """the A/B switches of the FFN backward (LG_FFN_H3=recompute: round 6's k_ffn_dw_bwd_h, which re-computes h3 from an LDS ring of h2 -- the forward then saves h2 only -- against the default k_ffn_dw_bwd_xs on a saved h3; round 2's tile kernel + weight-gradient launch; the three-tensor save mode; round 2's
     k_ffn1_bwd_x32 + weight-gradient launches at e = 32 instead of k_ffn1_bwd_xs<32>; bf16 triples instead of f16 pairs in k_ffn1_bwd_xs) give the default path's gradients to rounding on a whole train step (C = 4: e = 16 at level 0, e = 32 at
     level 1)"""
     from gpu_helpers import make_module
