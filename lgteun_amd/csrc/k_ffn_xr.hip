@@ -62,9 +62,14 @@ constexpr size_t LDS_BYTES = OFF_RING + (size_t)RING * HX * LDR * 4;
 static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 static_assert(OFF_RING % 16 == 0 && OFF_TAPS % 16 == 0 && OFF_PAR % 16 == 0, "16-byte aligned LDS regions");
 
+#ifndef LG_XR_NT
+#define LG_XR_NT 0    // streaming (non-temporal) stores of the saved tensors: bit 0 = h2, bit 1 = h3.  OFF here (k_ffn_xs had them on: its h3 rows left as whole 256-byte lines): the register chain writes a pixel's row as four 64-byte pieces, which only the L2 merges into lines -- WRITE_SIZE 421 MB per saving launch with streaming stores against 310 MB of data; 5.496 -> 5.466 ms per step
+#endif
 #ifndef LG_XR_FENCES
 #define LG_XR_FENCES 1   // scheduling fences between the sections of a block: without them the scheduler interleaves every section of a step and spills (206 registers)
 #endif
+#define XR_ST2(base, idx, v) do { if (LG_XR_NT & 1) HS<BF>::st4_nt(base, idx, v); else HS<BF>::st4(base, idx, v); } while (0)
+#define XR_ST3(base, idx, v) do { if (LG_XR_NT & 2) HS<BF>::st4_nt(base, idx, v); else HS<BF>::st4(base, idx, v); } while (0)
 #define XR_FENCE() do { if (LG_XR_FENCES) __builtin_amdgcn_sched_barrier(0); } while (0)
 template <int N>
 struct IC { static constexpr int value = N; };
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     const float mk = geo[nb].mk;
                     float4 hh = make_float4(k0[nb][0] * mk, k0[nb][1] * mk, k0[nb][2] * mk, k0[nb][3] * mk);
                     if (PART == 0) hh = make_float4(__builtin_fmaf(k1[nb][0], mk, hh.x), __builtin_fmaf(k1[nb][1], mk, hh.y), __builtin_fmaf(k1[nb][2], mk, hh.z), __builtin_fmaf(k1[nb][3], mk, hh.w));
-                    if (SAVE && PART == 0 && geo[nb].inner) HS<BF>::st4_nt(a1.h2, geo[nb].prow + 16 * mt2, hh);
+                    if (SAVE && PART == 0 && geo[nb].inner) XR_ST2(a1.h2, geo[nb].prow + 16 * mt2, hh);
                     if (geo[nb].rp >= 0) *reinterpret_cast<float4*>(ring + geo[nb].rp * LDR + 16 * mt2 + 4 * g) = hh;
                 }
             };
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 const float mk = geo[nb].mk;
                 const float4 hh = make_float4(__builtin_fmaf(acc.k1[0], mk, acc.k0[0] * mk), __builtin_fmaf(acc.k1[1], mk, acc.k0[1] * mk),
                                               __builtin_fmaf(acc.k1[2], mk, acc.k0[2] * mk), __builtin_fmaf(acc.k1[3], mk, acc.k0[3] * mk));
-                if (SAVE && geo[nb].inner) HS<BF>::st4_nt(a1.h2, geo[nb].prow + 16 * mt2, hh);
+                if (SAVE && geo[nb].inner) XR_ST2(a1.h2, geo[nb].prow + 16 * mt2, hh);
                 *reinterpret_cast<float4*>(ring + geo[nb].rp * LDR + 16 * mt2 + 4 * g) = hh;
             };
 #pragma unroll
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 float4 r = *rp4;
                 r = make_float4(__builtin_fmaf(part[mt2][0], ge.mk, r.x), __builtin_fmaf(part[mt2][1], ge.mk, r.y), __builtin_fmaf(part[mt2][2], ge.mk, r.z), __builtin_fmaf(part[mt2][3], ge.mk, r.w));
                 *rp4 = r;
-                if (SAVE && ge.inner) HS<BF>::st4_nt(a1.h2, ge.prow + 16 * mt2, r);
+                if (SAVE && ge.inner) XR_ST2(a1.h2, ge.prow + 16 * mt2, r);
             }
         };
 
@@ -613,7 +618,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
 #ifndef LG_XR_NOH3   // diagnostic A/B: what not saving h3 would buy the forward (VERDICT r5 lever b)
-                        if (SAVE && ok && a2.a3s) HS<BF>::st4_nt(a2.a3s, ((b * h + y) * (long)w + x) * N1 + 16 * m + 4 * g, make_float4(h3[r2][m][0], h3[r2][m][1], h3[r2][m][2], h3[r2][m][3]));
+                        if (SAVE && ok && a2.a3s) XR_ST3(a2.a3s, ((b * h + y) * (long)w + x) * N1 + 16 * m + 4 * g, make_float4(h3[r2][m][0], h3[r2][m][1], h3[r2][m][2], h3[r2][m][3]));
 #endif
                         const lg_v2f a01 = geluN<NP>((lg_v2f){h3[r2][m][0], h3[r2][m][1]}, gk3);
                         const lg_v2f a23 = geluN<NP>((lg_v2f){h3[r2][m][2], h3[r2][m][3]}, gk3);

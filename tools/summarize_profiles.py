@@ -40,7 +40,7 @@ with open(f'profiles/{prefix}_{name}_pmc_hbm.csv', 'w', newline='') as fh:
                 'WRITE_bytes_per_launch', 'HBM_bytes_per_launch'])
     for r in rows:
         w.writerow([r[0], r[1], f'{r[2]:.1f}', int(r[3]), f'{r[4]:.1f}', int(r[5]), int(r[6])])
-fused = [r for r in rows if any(n in r[0] for n in ('k_ffn_xs', 'k_ffn_x32', 'k_ffn_fused', 'k_ffn_strip'))]   # the fused FFN forward, all variants
+fused = [r for r in rows if any(n in r[0] for n in ('k_ffn_xr', 'k_ffn_xs', 'k_ffn_x32', 'k_ffn_fused', 'k_ffn_strip'))]   # the fused FFN forward, all variants
 if fused:
     tot = sum(r[6] * r[1] for r in fused) / sum(r[1] for r in fused)
     print(f'fused FFN forward (k_ffn_xs + k_ffn_x32), all variants averaged: {int(tot)} HBM bytes per launch  (what bench.py reads as roofline.traffic)')
