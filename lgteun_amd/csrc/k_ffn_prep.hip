@@ -15,15 +15,13 @@
 #include "kernels.h"
 
 namespace {
-__device__ __forceinline__ float block_max(float v, float* red) {
+__device__ __forceinline__ float block_max(float v, float* red) {   // 256 threads: wave shuffles, then four values through LDS (round 6: the eight-level
+#pragma unroll                                                        // barrier tree made this one-workgroup-per-block kernel a 16 us latency chain)
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    __syncthreads();                      // the previous call's readers are done
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
-        __syncthreads();
-    }
-    return red[0];
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 __device__ __forceinline__ float pow2_below(float bound) {   // the power of two s with bound * s in [2^14, 2^15)   (bound = 0: 2^15)
     // exponent clamped to [-100, 60]: a vanishing bound (weights of 1e-35) would otherwise make the PRODUCT of two scales overflow

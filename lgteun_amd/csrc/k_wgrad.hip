@@ -212,11 +212,56 @@ __global__ __launch_bounds__(256) void k_reduce_slab(const float* __restrict__ s
 
 // all queued jobs in one launch: blockIdx.y = job, same 16 outputs x 16 slice phases shape as k_reduce_slab
 __global__ __launch_bounds__(256) void k_reduce_jobs(ReduceJobTable t) {
-    __shared__ float part[16][17];
+    __shared__ float4 part[16][17];
     const ReduceJob& jb = t.j[blockIdx.y];
     const long n = (long)jb.rows * jb.cols;
-    if (blockIdx.x * 16L >= n) return;
     const int o = threadIdx.x & 15, ph = threadIdx.x >> 4;
+    // round 6: jobs whose rows are whole, 16-byte aligned quads (every large one: pos_emb, the FFN weight slabs) move FOUR outputs per thread -- a
+    // 16-lane group reads 256 contiguous bytes of a slice instead of 64, a quarter of the workgroups.  Same order of additions per output.
+    const bool v4 = ((jb.cols | jb.row_stride | jb.ld) & 3) == 0 && (jb.slice_stride & 3) == 0 && jb.rows_valid == jb.rows && jb.cols_valid == jb.cols &&
+                    ((reinterpret_cast<uintptr_t>(jb.slab) | reinterpret_cast<uintptr_t>(jb.dst) | reinterpret_cast<uintptr_t>(jb.dst2)) & 15) == 0;
+    if (v4) {
+        const long n4 = n >> 2;
+        if (blockIdx.x * 16L >= n4) return;
+        const long i4 = blockIdx.x * 16L + o;
+        const long i = i4 << 2;
+        const int row = (int)(i / jb.cols), col = (int)(i - (long)row * jb.cols);
+        float4 sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i4 < n4) {
+            const float* __restrict__ src = jb.slab + (long)row * jb.row_stride + col;
+            const long ss = jb.slice_stride, ns = jb.nslices;
+            long k = ph;
+            for (; k + 16 * 7 < ns; k += 16 * 8) {
+                float4 ld[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ld[u] = *reinterpret_cast<const float4*>(src + (k + 16 * u) * ss);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { sv[u].x += ld[u].x; sv[u].y += ld[u].y; sv[u].z += ld[u].z; sv[u].w += ld[u].w; }
+            }
+            for (; k < ns; k += 16) {
+                const float4 l = *reinterpret_cast<const float4*>(src + k * ss);
+                sv[0].x += l.x; sv[0].y += l.y; sv[0].z += l.z; sv[0].w += l.w;
+            }
+        }
+        auto add4 = [](const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+        part[ph][o] = add4(add4(add4(sv[0], sv[1]), add4(sv[2], sv[3])), add4(add4(sv[4], sv[5]), add4(sv[6], sv[7])));
+        __syncthreads();
+        if (ph == 0 && i4 < n4) {
+            float4 ts = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) ts = add4(ts, part[q][o]);
+            float4* d = reinterpret_cast<float4*>(jb.dst + (long)row * jb.ld + col);
+            *d = add4(*d, ts);
+            if (jb.dst2) {
+                float4* d2 = reinterpret_cast<float4*>(jb.dst2 + (long)row * jb.ld + col);
+                *d2 = add4(*d2, ts);
+            }
+        }
+        return;
+    }
+    if (blockIdx.x * 16L >= n) return;
     const long i = blockIdx.x * 16L + o;
     const int row = (int)(i / jb.cols), col = (int)(i - (long)row * jb.cols);
     float sv[8];
@@ -232,12 +277,13 @@ __global__ __launch_bounds__(256) void k_reduce_jobs(ReduceJobTable t) {
         }
         for (; k < ns; k += 16) sv[0] += src[k * ss];
     }
-    part[ph][o] = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
+    float* parts = reinterpret_cast<float*>(part);
+    parts[ph * 17 + o] = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
     __syncthreads();
     if (ph == 0 && i < n && row < jb.rows_valid && col < jb.cols_valid) {
         float tsum = 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) tsum += part[q][o];
+        for (int q = 0; q < 16; ++q) tsum += parts[q * 17 + o];
         jb.dst[(long)row * jb.ld + col] += tsum;
         if (jb.dst2) jb.dst2[(long)row * jb.ld + col] += tsum;
     }

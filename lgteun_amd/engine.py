@@ -110,13 +110,15 @@ class Engine:
             view = self.flat[o:o + p.numel()].view(p.shape)
             view.copy_(p.data)
             p.data = view
-        self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        # gradients + (one 16-byte slot behind them) the loss scalar of the fused step: ONE buffer, so that train_step clears both with one fill launch
+        self._gbuf = torch.zeros(total + 4, dtype=torch.float32, device=dev)
+        self.gflat = self._gbuf[:total]
         self._ranges_dev = {ch: torch.tensor([v for r in rg for v in r], dtype=torch.int64, device=dev)
                             for ch, (_, rg) in self._live.items()}
         self._plans = {}
         self._ws = {}
         self._ws_pool = {}             # autograd path: released training workspaces by (plan, B, train), see _WsLease
-        self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._loss = self._gbuf[total:total + 1]
         self._seed_ctr = 0
         # opt-in (LG_OVERLAP_DEAD=1 / engine.overlap_dead = True): 'faithful' training enqueues the K-1 dead-stage LGT forwards on a
         # second stream behind the LGT backward, beside the K data-step backwards + Adam (a chain of small latency-bound launches).
@@ -311,8 +313,7 @@ class Engine:
         if not getattr(optim, 'dropout', True):
             flags &= ~LG_FLAG_DROPOUT
         seed = self.next_seed()
-        self.gflat.zero_()
-        self._loss.zero_()
+        self._gbuf.zero_()                 # gradients and the loss scalar
         defer = bool(self.overlap_dead and (flags & LG_FLAG_FAITHFUL) and not (flags & LG_FLAG_CHAINED) and self.K > 1)
         if defer:
             flags |= LG_FLAG_DEFER_DEAD
