@@ -117,7 +117,8 @@ def synth_batch(B, rank, device, c=None, h=None):
 
 # what the SQ counters of a committed profile show the roofline kernel to be held by -- per (config, kernel), with the file that says so.
 # No entry = no counters were taken for that kernel in that config: the label is then None rather than a guess.
-LIMITERS = {('c2', 'ffn'): ('valu-issue', 'profiles/r05_sq_counters_step.txt'), ('c2', 'attn_bwd'): ('valu-issue', 'profiles/r05_sq_counters_step.txt'),
+LIMITERS = {('c2', 'ffn'): ('valu-issue (75 % vector-busy at two waves per SIMD)', 'profiles/r06_sq_counters_ffn.txt'),
+            ('c2', 'attn_bwd'): ('valu-issue', 'profiles/r05_sq_counters_step.txt'),
             ('c3', 'ffn'): ('valu-issue (49 % vector-active, 17 % matrix-busy, in alternating phases)', 'profiles/r05_sq_counters_c3.txt'),
             ('c5', 'ffn'): ('valu-issue (49 % vector-active, 17 % matrix-busy, in alternating phases)', 'profiles/r05_sq_counters_c5.txt')}
 
@@ -453,11 +454,11 @@ def main():
     by_kernel = None
     if side and args.mode == 'faithful':
         by_kernel = []
-        times = {label: prof_kernel(kid_name) for label, kid_name, _ in KERNEL_GROUPS}
-        for label, kid_name, pats in KERNEL_GROUPS:
-            avg_us_k, per_step = times[label]
-            byts_k, flops_k = algorithmic_per_launch('attn_bwd_unit' if label == 'attn_bwd' else label, B_PER_GPU)
-            by_kernel.append(dict(kernel=label, avg_us=round(avg_us_k, 2), launches_per_step=round(per_step, 1), alg_bytes=int(byts_k), alg_flops=int(flops_k),
+        times = {klabel: prof_kernel(kid_name) for klabel, kid_name, _ in KERNEL_GROUPS}
+        for klabel, kid_name, pats in KERNEL_GROUPS:
+            avg_us_k, per_step = times[klabel]
+            byts_k, flops_k = algorithmic_per_launch('attn_bwd_unit' if klabel == 'attn_bwd' else klabel, B_PER_GPU)
+            by_kernel.append(dict(kernel=klabel, avg_us=round(avg_us_k, 2), launches_per_step=round(per_step, 1), alg_bytes=int(byts_k), alg_flops=int(flops_k),
                                   hbm_frac=round(byts_k / (avg_us_k * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if avg_us_k > 0 else None,
                                   mfma_frac=round(flops_k / (avg_us_k * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if avg_us_k > 0 else None,
                                   traffic=traffic_by_patterns(pats, args.config)))

@@ -290,24 +290,39 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
                     sp1 = qq * (lg_v2f){kv.z, kv.w} + sp1;
                 }
                 sc[2 * g] = sp0; sc[2 * g + 1] = sp1;
+#ifndef LG_ATTNF_DIAG_FWDSTATS
                 mx = fmaxf(mx, fmaxf(fmaxf(sp0.x, sp0.y), fmaxf(sp1.x, sp1.y)));
+#endif
                 PASS_FENCE(g);
             }
             asm volatile("" ::: "memory");
+#ifdef LG_ATTNF_DIAG_FWDSTATS
+            // TIMING-ONLY diagnostic (never in the product build; results are wrong): what pass 1 would cost if the forward had saved the rows'
+            // log-sum-exp and the attention output (VERDICT r5 lever a, "light" form): no row maximum, no row sum, no normalisation, no P V
+            mx = q[0];
+#endif
             lg_v2f l2 = (lg_v2f){0.f, 0.f};
             const lg_v2f mx2 = (lg_v2f){mx, mx};
 #pragma unroll
             for (int g = 0; g < 32; ++g) {
                 const lg_v2f t = sc[g] - mx2;
                 sc[g] = (lg_v2f){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+#ifndef LG_ATTNF_DIAG_FWDSTATS
                 l2 += sc[g];
+#endif
             }
+#ifdef LG_ATTNF_DIAG_FWDSTATS
+            l2 = (lg_v2f){dOi[0], dOi[1]};
+#endif
             const float inv = __builtin_amdgcn_rcpf(l2.x + l2.y);
             const lg_v2f inv2 = (lg_v2f){inv, inv};
             lg_v2f O2[D];
 #pragma unroll
             for (int c = 0; c < D; ++c) O2[c] = (lg_v2f){0.f, 0.f};
 #pragma unroll
+#ifdef LG_ATTNF_DIAG_FWDSTATS
+            for (int c = 0; c < D; ++c) O2[c] = (lg_v2f){q[c] * inv, dOi[c]};
+#else
             for (int g = 0; g < 16; ++g) {
                 sc[2 * g] *= inv2; sc[2 * g + 1] *= inv2;
 #pragma unroll
@@ -318,6 +333,7 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
                 }
                 PASS_FENCE(g);
             }
+#endif
             float O[D];
             float Dv = 0.f;   // D_i = sum_j P_ij dP_ij = dO_i . O_i
 #pragma unroll

@@ -32,6 +32,7 @@ def test_two_rank_bench_prints_one_json_line(request):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['warmup'] == 1
     assert d['config']['global_batch'] == 64 and d['config']['parallelism'] == 'dp2' and d['scaling'] == 'weak'
+    assert d['config']['workload'].startswith('BASELINE configs[1]') and d['metric'].startswith('train image-pairs/sec, GF-2 4-band')
     assert d['watchdog_s'] == 600                        # armed by default for multi-rank runs (LG_BENCH_WATCHDOG overrides)
     assert d['value'] > 0 and abs(d['value'] - 64 / (d['ms_per_step'] * 1e-3)) < 1e-2 * d['value']
     assert d['ddp']['backend'] == 'gloo' and d['ddp']['bucket_form'] == 'one stream-ordered all-reduce behind the backward'
