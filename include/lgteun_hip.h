@@ -99,7 +99,8 @@ typedef struct lg_config {
 #define LG_VAR_FFN_XS (1u << 13)        /* fused FFN forward at e = 16: the channel-split k_ffn_xs of rounds 2 - 5 (LN(x) / gelu(h1) pieces through LDS, eleven barriers per step) instead of the register-chain k_ffn_xr (round 6) */
 #define LG_VAR_ATTN_BF16X3 (1u << 14)  /* local-mixer forward (k_attn_m): to_qkv and Q K^T on three bf16 pieces / six products (round 5) instead of f16 pairs with static operand scales (round 6) */
 #define LG_VAR_FFN_H3_RECOMPUTE (1u << 15)  /* e = 16 FFN of the live stage: save h2 ONLY and re-compute h3 in the backward (k_ffn_dw_bwd_h, round 6: the saving forward launch -17 us, the backward kernel +70 us: opt-in) instead of saving h2 and h3 (k_ffn_dw_bwd_xs) */
-#define LG_VAR_ALL 0xffffu
+#define LG_VAR_ATTN_BWD_RESTATS (1u << 16)  /* e = 16 local mixer of the live stage: k_attn_bwd_f re-derives the softmax row statistics and the attention output with a reduction pass of its own (rounds 4 - 5) instead of reading what k_attn_m's saving launch left (round 6: log-sum-exp + attention output, 40 bytes per pixel) */
+#define LG_VAR_ALL 0x1ffffu
 
 typedef struct lg_plan lg_plan; /* host-side, immutable after creation */
 

@@ -39,6 +39,7 @@ LG_VAR_ATTN_BWD_CORE_M = 1 << 12
 LG_VAR_FFN_XS = 1 << 13
 LG_VAR_ATTN_BF16X3 = 1 << 14
 LG_VAR_FFN_H3_RECOMPUTE = 1 << 15
+LG_VAR_ATTN_BWD_RESTATS = 1 << 16
 LG_ABI_VERSION = 2   # include/lgteun_hip.h: checked against lg_abi_version() when the library is loaded
 
 
@@ -72,6 +73,8 @@ def variant_from_env(env=None):
         v |= LG_VAR_ATTN_BF16X3
     if env.get('LG_FFN_H3', '') == 'recompute':
         v |= LG_VAR_FFN_H3_RECOMPUTE
+    if env.get('LG_ATTN_BWD_STATS', '') == 'recompute':
+        v |= LG_VAR_ATTN_BWD_RESTATS
     return v
 
 

@@ -149,6 +149,7 @@ extern "C" int lg_plan_create(const lg_config* cfg, const int64_t* offsets, int3
         p->ffn_xs = (v & LG_VAR_FFN_XS) ? 1 : 0;
         p->attn_bf16x3 = (v & LG_VAR_ATTN_BF16X3) ? 1 : 0;
         p->ffn_h3_re = (v & LG_VAR_FFN_H3_RECOMPUTE) ? 1 : 0;
+        p->attn_restats = (v & LG_VAR_ATTN_BWD_RESTATS) ? 1 : 0;
     }
     p->off = (int64_t*)malloc(sizeof(int64_t) * n_offsets);
     memcpy(p->off, offsets, sizeof(int64_t) * n_offsets);
@@ -234,6 +235,7 @@ static int block_mixer_fwd(const lg_plan* pl, const float* P, int stage, int j, 
     t.dropout = (flags & LG_FLAG_DROPOUT) ? 1 : 0;
     t.seed = mix_seed(seed, stage, j);
     t.scales = (attn_scales && pl->attn_f16x2()) ? attn_scales + ((size_t)stage * 5 + j) * 4 : nullptr;   // written by prep_stages for the stages of this call
+    if ((flags & LG_FLAG_SAVE) && pl->attn_saves_stats(bb.e)) { t.save_o = bb.att_o; t.save_l = bb.att_l; }
     return pl->attn_fwd_valu ? launch_attn(bb.e, t, s) : launch_attn_m(bb.e, t, s);
 }
 

@@ -360,6 +360,8 @@ struct AttnBwdFArgs {
     float* dx;             // [P,e]
     const float* pos;      // [2,64,64]
     const float *ln1g, *ln1b, *qkvw, *qkvb, *projw;
+    const float* so = nullptr;   // [P,e/2] the forward's attention output (pre-proj, head-major) and
+    const float* sl = nullptr;   // [P,2] log-sum-exp of its score rows (log2 domain), saved by k_attn_m's saving launch (round 6); both null: recomputed here
     float* slab;           // ATTN_BWD_F_WGS rows of ATTN_BWD_F_ROW floats: per-workgroup partial sums
     float *d_pos, *d_qkvw, *d_qkvb, *d_projw, *d_ln1g, *d_ln1b;   // += by the deferred reduce launch
     int B, h, w;

@@ -24,6 +24,7 @@
 #include "kernels.h"
 #include "bwd_kernels.h"
 #include "mfma.h"
+#include <utility>
 
 // In-kernel phase stamps (diagnostic build only, -DLG_STAMPS: tools/build_stamps.sh + tools/attn_bwd_stamps.py): the eight waves of workgroup 0
 // write s_memtime at the phase boundaries of their third window group; no stamp executes in the product build.
@@ -43,6 +44,11 @@ extern "C" __attribute__((visibility("default"))) int lg_debug_kf_stamps(unsigne
 #ifndef LG_ATTNF_SB
 #define LG_ATTNF_SB 2   // a scheduling fence behind every LG_ATTNF_SB-th key / query group of the flash passes (0: none).  Same-box A/B of the kernel's
                         // average launch: none 140.5 us, every group 123.3, every 2nd 122.9 (kept), every 4th 128.9, every 8th 130.3
+#endif
+#ifndef LG_ATTNF_DPP
+#define LG_ATTNF_DPP 0    // A/B build (-DLG_ATTNF_DPP=1): broadcast operands of the recomputing flash passes through DPP row broadcasts instead of wave-uniform LDS reads.
+                          // Measured SLOWER (142.7 against 124.7 us): a DPP multiply-add issues at the 4-cycle rate of the SDWA / conversion class and does ONE
+                          // multiply-add per lane where v_pk_fma_f32 does two in 4.7 cycles -- the LDS pipe was relieved, the vector pipe got twice the work
 #endif
 #define PASS_FENCE(g) do { if (LG_ATTNF_SB && ((g) % LG_ATTNF_SB) == LG_ATTNF_SB - 1) __builtin_amdgcn_sched_barrier(0); } while (0)
 namespace {
@@ -95,11 +101,39 @@ __device__ __forceinline__ float row8_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));   // row_ror:8
     return v;
 }
+// Lane-broadcast operands (round 6).  In the flash passes every lane needs the SAME k / v (pass 1) or q / dO / row statistics (pass 2) of one token per
+// multiply-add.  Read from LDS those are wave-uniform 16-byte reads: 64 lanes x 16 bytes through a 128-byte port = 8 cycles of the CU's ONE LDS pipe for 16
+// useful bytes, ~450 of them per wave and window -- 8 waves x 3.6 k cycles = 29 k of a window group's 33.7 k cycles (SQ counters: 62 % LDS-busy, 56 %
+// vector-busy; profiles/r06_sq_counters_step.txt).  Here a lane keeps the values of the four tokens 16 r + (lane & 15) in registers (one conflict-free
+// ds_read_b32 each) and the multiply-adds take them through the DPP row broadcast of gfx90a+ (row_newbcast:n = lane n of the reader's own 16-lane row):
+// the same fused multiply-adds in the same order, as plain instead of packed fp32 (same issue rate on this chip), and no LDS traffic.
+// DPP hazard (2 wait states between a VALU write of a register and its use as the DPP source): the broadcast sources are only ever registers loaded from
+// LDS a phase earlier; tools/check_dpp_hazards.py verifies it on the assembly.
+template <int N> __device__ __forceinline__ float fmac_bc(float acc, float src, float b) {   // acc + src[lane N of the row] * b
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(b), "n"(N));
+    return acc;
+}
+template <int N> __device__ __forceinline__ float sub_bc(float a, float src) {               // a - src[lane N of the row]
+    float d;
+    asm("v_subrev_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(src), "v"(a), "n"(N));
+    return d;
+}
+template <int N> __device__ __forceinline__ float mul_bc(float a, float src) {               // a * src[lane N of the row]
+    float d;
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(src), "v"(a), "n"(N));
+    return d;
+}
+template <class F, int... Is> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 __device__ __forceinline__ float dpp_even(float v) {   // the even lane's value on both lanes of the pair
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xA0, 0xF, 0xF, true));   // quad_perm [0,0,2,2]
 }
 }  // namespace
 
+// STATS (round 6, VERDICT r5 lever a in its light form): the forward's saving launch left, per token and head, the log-sum-exp of the score row (log2 domain)
+// and the attention output O (k_attn_m: a.sl, a.so).  Pass 1 then needs no row maximum, no row sum, no normalisation and no P V product -- ONE loop over the
+// keys (scores -> P = 2^(s - L) -> dP -> dS -> dq) that reads k and v once; D_i = dO_i . O_i and the cat image come out of the prologue.
+template <bool STATS>
 __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void k_attn_bwd_f(AttnBwdFArgs a, int nwin, int ngroups) {
     constexpr int HC = F_HC, E = F_E, D = F_D, PLD = F_PLD;
     constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
@@ -190,7 +224,8 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
     //     the low-pressure epilogue phases);
     //   * the epilogue's operands of THIS group (x / dy again -- an L2 hit --, dg, o2, keep) behind pass 1, across pass 2 (e*: 29 registers).
     const uint32_t* const keepp = a.keep ? a.keep : reinterpret_cast<const uint32_t*>(a.x);   // no dropout: any valid address, value unused
-    float4 nx0, nx1, nd0, nd1;
+    float4 nx0, nx1, nd0, nd1, nO;
+    float nL;
     uint32_t nkw;
     auto issue_prologue = [&](int win) {
         long bT, sT;
@@ -199,6 +234,10 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
         const float4* ds = reinterpret_cast<const float4*>(a.dy + pT * E + HC * ch);
         nx0 = xs[0]; nx1 = xs[1]; nd0 = ds[0]; nd1 = ds[1];
         nkw = keepp[pT];
+        if constexpr (STATS) {   // head `ch` of the token: the forward's O (4 channels) and row log-sum-exp
+            nO = *reinterpret_cast<const float4*>(a.so + pT * HC + D * ch);
+            nL = a.sl[pT * 2 + ch];
+        }
     };
     if (blockIdx.x < ngroups) issue_prologue(blockIdx.x * F_NS + ws);
 #pragma unroll 1
@@ -212,6 +251,9 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
             // ---------------- prologue: lane = (token tk, channel half ch)
             const float4 x0 = nx0, x1 = nx1, d0 = nd0, d1 = nd1;
             const uint32_t kw = a.keep ? nkw : 0xffffffffu;
+            float4 O4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float Lrow = 0.f;
+            if constexpr (STATS) { O4 = nO; Lrow = nL; }
             float xh[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
             float sm = ((xh[0] + xh[1]) + (xh[2] + xh[3])) + ((xh[4] + xh[5]) + (xh[6] + xh[7]));
             sm += dpp_xor1(sm);
@@ -250,11 +292,19 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
                 pr[0] += wa.x * dm; pr[1] += wa.y * dm; pr[2] += wa.z * dm; pr[3] += wa.w * dm;
                 pr[4] += wb.x * dm; pr[5] += wb.y * dm; pr[6] += wb.z * dm; pr[7] += wb.w * dm;
             }
+            float dOh[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float send = ch ? pr[k] : pr[4 + k];     // what the other lane keeps
                 const float keepv = ch ? pr[4 + k] : pr[k];
-                tile[F_T_DO + k * 64 + tk] = keepv + dpp_xor1(send);
+                dOh[k] = keepv + dpp_xor1(send);
+                tile[F_T_DO + k * 64 + tk] = dOh[k];
+            }
+            if constexpr (STATS) {   // row statistics of (token tk, head ch) for both passes; the head's attention output into the window's cat image
+                const float Dv = ((dOh[0] * O4.x + dOh[1] * O4.y) + dOh[2] * O4.z) + dOh[3] * O4.w;   // D_i = sum_j P_ij dP_ij = dO_i . O_i
+                tile[F_T_ST + tk] = Lrow;
+                tile[F_T_ST + 128 + tk] = Dv;
+                *reinterpret_cast<float4*>(sCat + tk * E + D * ch) = O4;
             }
             // y1 image of the window (B operand of the to_qkv weight-gradient product; column 8 = 1 carries the bias gradient)
             float4* y4 = reinterpret_cast<float4*>(sY1 + tk * F_Y1LD);
@@ -275,6 +325,121 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
             float q[D], dOi[D];
 #pragma unroll
             for (int c = 0; c < D; ++c) { q[c] = sQ[c * 64 + lane]; dOi[c] = sDO[c * 64 + lane]; }
+            if constexpr (STATS) {
+                const float* prow = sPosH + lane * PLD;
+                const float Li = sSt[lane], Dv = sSt[128 + lane];
+                const lg_v2f L2v = (lg_v2f){Li, Li}, Dv2 = (lg_v2f){Dv, Dv};
+                lg_v2f dq2[D];
+#pragma unroll
+                for (int c = 0; c < D; ++c) dq2[c] = (lg_v2f){0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const float4 pr4 = reinterpret_cast<const float4*>(prow)[g];
+                    lg_v2f sp0 = (lg_v2f){pr4.x, pr4.y}, sp1 = (lg_v2f){pr4.z, pr4.w};
+                    lg_v2f dP0 = (lg_v2f){0.f, 0.f}, dP1 = (lg_v2f){0.f, 0.f};
+                    float4 kv[D];
+#pragma unroll
+                    for (int c = 0; c < D; ++c) {
+                        kv[c] = reinterpret_cast<const float4*>(sK)[c * 16 + g];
+                        const float4 vv = reinterpret_cast<const float4*>(sV)[c * 16 + g];
+                        const lg_v2f qq = (lg_v2f){q[c], q[c]}, dd = (lg_v2f){dOi[c], dOi[c]};
+                        sp0 = qq * (lg_v2f){kv[c].x, kv[c].y} + sp0;
+                        sp1 = qq * (lg_v2f){kv[c].z, kv[c].w} + sp1;
+                        dP0 = dd * (lg_v2f){vv.x, vv.y} + dP0;
+                        dP1 = dd * (lg_v2f){vv.z, vv.w} + dP1;
+                    }
+                    const lg_v2f e0 = sp0 - L2v, e1 = sp1 - L2v;
+                    const lg_v2f P0 = (lg_v2f){__builtin_amdgcn_exp2f(e0.x), __builtin_amdgcn_exp2f(e0.y)};
+                    const lg_v2f P1 = (lg_v2f){__builtin_amdgcn_exp2f(e1.x), __builtin_amdgcn_exp2f(e1.y)};
+                    const lg_v2f dS0 = P0 * (dP0 - Dv2), dS1 = P1 * (dP1 - Dv2);
+#pragma unroll
+                    for (int c = 0; c < D; ++c) {
+                        dq2[c] = dS0 * (lg_v2f){kv[c].x, kv[c].y} + dq2[c];
+                        dq2[c] = dS1 * (lg_v2f){kv[c].z, kv[c].w} + dq2[c];
+                    }
+                    PASS_FENCE(g);
+                }
+#pragma unroll
+                for (int c = 0; c < D; ++c) dqkv[c] = (dq2[c].x + dq2[c].y) * scale;
+            } else {
+#if LG_ATTNF_DPP
+            const int l15 = lane & 15;
+            float Kr[4][D], Vr[4][D];   // [r][c] = k / v channel c of token 16 r + (lane & 15)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < D; ++c) { Kr[r][c] = sK[c * 64 + 16 * r + l15]; Vr[r][c] = sV[c * 64 + 16 * r + l15]; }
+            const float* prow = sPosH + lane * PLD;
+            float sc[64];
+            float mx = -3.0e38f;
+            static_for<16>([&](auto gg) {
+                constexpr int g = decltype(gg)::value, r = g >> 2, n0 = 4 * (g & 3);
+                const float4 pr4 = reinterpret_cast<const float4*>(prow)[g];
+                float s0 = pr4.x, s1 = pr4.y, s2 = pr4.z, s3 = pr4.w;
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    s0 = fmac_bc<n0>(s0, Kr[r][c], q[c]);
+                    s1 = fmac_bc<n0 + 1>(s1, Kr[r][c], q[c]);
+                    s2 = fmac_bc<n0 + 2>(s2, Kr[r][c], q[c]);
+                    s3 = fmac_bc<n0 + 3>(s3, Kr[r][c], q[c]);
+                }
+                sc[4 * g] = s0; sc[4 * g + 1] = s1; sc[4 * g + 2] = s2; sc[4 * g + 3] = s3;
+                mx = fmaxf(mx, fmaxf(fmaxf(s0, s1), fmaxf(s2, s3)));
+                PASS_FENCE(g);
+            });
+            float le = 0.f, lo = 0.f;   // even / odd keys: the two halves of the packed sum of rounds 4 - 5 (same additions in the same order)
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                sc[2 * k] = __builtin_amdgcn_exp2f(sc[2 * k] - mx);
+                sc[2 * k + 1] = __builtin_amdgcn_exp2f(sc[2 * k + 1] - mx);
+                le += sc[2 * k]; lo += sc[2 * k + 1];
+            }
+            const float inv = __builtin_amdgcn_rcpf(le + lo);
+            float Oe[D], Oo[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) { Oe[c] = 0.f; Oo[c] = 0.f; }
+            static_for<16>([&](auto gg) {
+                constexpr int g = decltype(gg)::value, r = g >> 2, n0 = 4 * (g & 3);
+                sc[4 * g] *= inv; sc[4 * g + 1] *= inv; sc[4 * g + 2] *= inv; sc[4 * g + 3] *= inv;
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    Oe[c] = fmac_bc<n0>(Oe[c], Vr[r][c], sc[4 * g]);
+                    Oo[c] = fmac_bc<n0 + 1>(Oo[c], Vr[r][c], sc[4 * g + 1]);
+                    Oe[c] = fmac_bc<n0 + 2>(Oe[c], Vr[r][c], sc[4 * g + 2]);
+                    Oo[c] = fmac_bc<n0 + 3>(Oo[c], Vr[r][c], sc[4 * g + 3]);
+                }
+                PASS_FENCE(g);
+            });
+            float O[D];
+            float Dv = 0.f;   // D_i = sum_j P_ij dP_ij = dO_i . O_i
+#pragma unroll
+            for (int c = 0; c < D; ++c) { O[c] = Oe[c] + Oo[c]; Dv += dOi[c] * O[c]; }
+            float dqe[D], dqo[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) { dqe[c] = 0.f; dqo[c] = 0.f; }
+            static_for<16>([&](auto gg) {
+                constexpr int g = decltype(gg)::value, r = g >> 2, n0 = 4 * (g & 3);
+                float dP0 = 0.f, dP1 = 0.f, dP2 = 0.f, dP3 = 0.f;
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    dP0 = fmac_bc<n0>(dP0, Vr[r][c], dOi[c]);
+                    dP1 = fmac_bc<n0 + 1>(dP1, Vr[r][c], dOi[c]);
+                    dP2 = fmac_bc<n0 + 2>(dP2, Vr[r][c], dOi[c]);
+                    dP3 = fmac_bc<n0 + 3>(dP3, Vr[r][c], dOi[c]);
+                }
+                const float dS0 = sc[4 * g] * (dP0 - Dv), dS1 = sc[4 * g + 1] * (dP1 - Dv), dS2 = sc[4 * g + 2] * (dP2 - Dv), dS3 = sc[4 * g + 3] * (dP3 - Dv);
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    dqe[c] = fmac_bc<n0>(dqe[c], Kr[r][c], dS0);
+                    dqo[c] = fmac_bc<n0 + 1>(dqo[c], Kr[r][c], dS1);
+                    dqe[c] = fmac_bc<n0 + 2>(dqe[c], Kr[r][c], dS2);
+                    dqo[c] = fmac_bc<n0 + 3>(dqo[c], Kr[r][c], dS3);
+                }
+                PASS_FENCE(g);
+            });
+#pragma unroll
+            for (int c = 0; c < D; ++c) dqkv[c] = (dqe[c] + dqo[c]) * scale;
+#else
             const float* prow = sPosH + lane * PLD;
             lg_v2f sc[32];
             float mx = -3.0e38f;
@@ -365,11 +530,13 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
             }
 #pragma unroll
             for (int c = 0; c < D; ++c) dqkv[c] = (dq2[c].x + dq2[c].y) * scale;
+#endif
             // this head's attention output into the window's cat image (proj input: B operand of the proj weight-gradient product)
             *reinterpret_cast<float4*>(sCat + lane * E + D * hd) = make_float4(O[0], O[1], O[2], O[3]);
             sSt[lane] = mx;
             sSt[64 + lane] = inv;
             sSt[128 + lane] = Dv;
+                    }
         }
         STAMP(3);
         // the epilogue's global operands of this group, requested across pass 2
@@ -395,6 +562,64 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
             // ---------------- pass 2: lane = key j, packed over QUERY pairs
             // the lane's own k / v as FULL register pairs: a splat by op_sel reads one half of a pair whose other half the allocator
             // gives to anything -- here to the destinations of the loads in flight, and the wait for those then sits in front of pass 2
+#if LG_ATTNF_DPP
+            const int l15 = lane & 15;
+            float Qr[4][D], dOr[4][D], Mr[4], Ir[4], Dr[4];   // q / dO channel c and the row statistics of query 16 r + (lane & 15)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int c = 0; c < D; ++c) { Qr[r][c] = sQ[c * 64 + 16 * r + l15]; dOr[r][c] = sDO[c * 64 + 16 * r + l15]; }
+                Mr[r] = sSt[16 * r + l15]; Ir[r] = sSt[64 + 16 * r + l15]; Dr[r] = sSt[128 + 16 * r + l15];
+            }
+            float kj[D], vj[D], dke[D], dko[D], dve[D], dvo[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) { kj[c] = sK[c * 64 + lane]; vj[c] = sV[c * 64 + lane]; dke[c] = 0.f; dko[c] = 0.f; dve[c] = 0.f; dvo[c] = 0.f; }
+            const float* pcol = sPosH + lane;
+            static_for<16>([&](auto gg) {
+                constexpr int g = decltype(gg)::value, r = g >> 2, n0 = 4 * (g & 3);
+                float t0 = pcol[(4 * g) * PLD], t1 = pcol[(4 * g + 1) * PLD], t2 = pcol[(4 * g + 2) * PLD], t3 = pcol[(4 * g + 3) * PLD];
+                float dP0 = 0.f, dP1 = 0.f, dP2 = 0.f, dP3 = 0.f;
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    t0 = fmac_bc<n0>(t0, Qr[r][c], kj[c]);
+                    t1 = fmac_bc<n0 + 1>(t1, Qr[r][c], kj[c]);
+                    t2 = fmac_bc<n0 + 2>(t2, Qr[r][c], kj[c]);
+                    t3 = fmac_bc<n0 + 3>(t3, Qr[r][c], kj[c]);
+                    dP0 = fmac_bc<n0>(dP0, dOr[r][c], vj[c]);
+                    dP1 = fmac_bc<n0 + 1>(dP1, dOr[r][c], vj[c]);
+                    dP2 = fmac_bc<n0 + 2>(dP2, dOr[r][c], vj[c]);
+                    dP3 = fmac_bc<n0 + 3>(dP3, dOr[r][c], vj[c]);
+                }
+                const float P0 = mul_bc<n0>(__builtin_amdgcn_exp2f(sub_bc<n0>(t0, Mr[r])), Ir[r]);
+                const float P1 = mul_bc<n0 + 1>(__builtin_amdgcn_exp2f(sub_bc<n0 + 1>(t1, Mr[r])), Ir[r]);
+                const float P2 = mul_bc<n0 + 2>(__builtin_amdgcn_exp2f(sub_bc<n0 + 2>(t2, Mr[r])), Ir[r]);
+                const float P3 = mul_bc<n0 + 3>(__builtin_amdgcn_exp2f(sub_bc<n0 + 3>(t3, Mr[r])), Ir[r]);
+                const float dS0 = P0 * sub_bc<n0>(dP0, Dr[r]), dS1 = P1 * sub_bc<n0 + 1>(dP1, Dr[r]);
+                const float dS2 = P2 * sub_bc<n0 + 2>(dP2, Dr[r]), dS3 = P3 * sub_bc<n0 + 3>(dP3, Dr[r]);
+#ifdef LG_DEGRADE_DPOS   // diagnostic variant only (never in the product build): a 5 % error in what enters the pos_emb gradient -- what
+                        // tests/test_gpu_benchsize.py::test_cancelling_sum_gradient_kinds_band_against_band must turn red on
+                dpacc[2 * g] += (lg_v2f){dS0, dS1} * 1.05f;
+                dpacc[2 * g + 1] += (lg_v2f){dS2, dS3} * 1.05f;
+#else
+                dpacc[2 * g] += (lg_v2f){dS0, dS1};
+                dpacc[2 * g + 1] += (lg_v2f){dS2, dS3};
+#endif
+                PASS_FENCE(g);
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    dve[c] = fmac_bc<n0>(dve[c], dOr[r][c], P0);
+                    dvo[c] = fmac_bc<n0 + 1>(dvo[c], dOr[r][c], P1);
+                    dve[c] = fmac_bc<n0 + 2>(dve[c], dOr[r][c], P2);
+                    dvo[c] = fmac_bc<n0 + 3>(dvo[c], dOr[r][c], P3);
+                    dke[c] = fmac_bc<n0>(dke[c], Qr[r][c], dS0);
+                    dko[c] = fmac_bc<n0 + 1>(dko[c], Qr[r][c], dS1);
+                    dke[c] = fmac_bc<n0 + 2>(dke[c], Qr[r][c], dS2);
+                    dko[c] = fmac_bc<n0 + 3>(dko[c], Qr[r][c], dS3);
+                }
+            });
+#pragma unroll
+            for (int c = 0; c < D; ++c) { dqkv[4 + c] = (dke[c] + dko[c]) * LN2; dqkv[8 + c] = dve[c] + dvo[c]; }   // sQ carries log2(e)
+#else
             lg_v2f kj2[D], vj2[D];
             lg_v2f dk2[D], dv2[D];
 #pragma unroll
@@ -421,11 +646,13 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
                     dP1 = vv * (lg_v2f){doi[c].z, doi[c].w} + dP1;
                 }
                 const float4 smx = reinterpret_cast<const float4*>(sSt)[g];
-                const float4 sinv = reinterpret_cast<const float4*>(sSt)[16 + g];
+                float4 sinv = make_float4(1.f, 1.f, 1.f, 1.f);
+                if constexpr (!STATS) sinv = reinterpret_cast<const float4*>(sSt)[16 + g];
                 const float4 sdv = reinterpret_cast<const float4*>(sSt)[32 + g];
                 const lg_v2f e0 = t0 - (lg_v2f){smx.x, smx.y}, e1 = t1 - (lg_v2f){smx.z, smx.w};
-                const lg_v2f P0 = (lg_v2f){__builtin_amdgcn_exp2f(e0.x), __builtin_amdgcn_exp2f(e0.y)} * (lg_v2f){sinv.x, sinv.y};
-                const lg_v2f P1 = (lg_v2f){__builtin_amdgcn_exp2f(e1.x), __builtin_amdgcn_exp2f(e1.y)} * (lg_v2f){sinv.z, sinv.w};
+                lg_v2f P0 = (lg_v2f){__builtin_amdgcn_exp2f(e0.x), __builtin_amdgcn_exp2f(e0.y)};
+                lg_v2f P1 = (lg_v2f){__builtin_amdgcn_exp2f(e1.x), __builtin_amdgcn_exp2f(e1.y)};
+                if constexpr (!STATS) { P0 *= (lg_v2f){sinv.x, sinv.y}; P1 *= (lg_v2f){sinv.z, sinv.w}; }   // (STATS: the row's log-sum-exp is in smx)
                 const lg_v2f dS0 = P0 * (dP0 - (lg_v2f){sdv.x, sdv.y}), dS1 = P1 * (dP1 - (lg_v2f){sdv.z, sdv.w});
 #ifdef LG_DEGRADE_DPOS   // diagnostic variant only (never in the product build): a 5 % error in what enters the pos_emb gradient -- what
                         // tests/test_gpu_benchsize.py::test_cancelling_sum_gradient_kinds_band_against_band must turn red on
@@ -446,6 +673,7 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
             }
 #pragma unroll
             for (int c = 0; c < D; ++c) { dqkv[4 + c] = (dk2[c].x + dk2[c].y) * LN2; dqkv[8 + c] = dv2[c].x + dv2[c].y; }   // sQ carries log2(e)
+        #endif
         }
         STAMP(4);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -721,7 +949,8 @@ int launch_attn_bwd_f(int e, const AttnBwdFArgs& a, hipStream_t s) {
     const size_t lds = (size_t)F_LDS_FLOATS * sizeof(float);
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        hipError_t er = hipFuncSetAttribute((const void*)k_attn_bwd_f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t er = hipFuncSetAttribute((const void*)k_attn_bwd_f<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (er == hipSuccess) er = hipFuncSetAttribute((const void*)k_attn_bwd_f<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (er != hipSuccess) { lg_set_error("attn_bwd_f: hipFuncSetAttribute: %s", hipGetErrorString(er)); return (int)er; }
         attr_once.done();
     }
@@ -730,7 +959,9 @@ int launch_attn_bwd_f(int e, const AttnBwdFArgs& a, hipStream_t s) {
     AttnBwdFArgs ak = a;
     ak.rcp_nwx = (unsigned)((1ull << 32) / (unsigned)(a.w / 8)) + 1u;   // floor(n / d) = umulhi(n, 2^32 / d + 1) for n d < 2^32
     ak.rcp_nwy = (unsigned)((1ull << 32) / (unsigned)(a.h / 8)) + 1u;
-    k_attn_bwd_f<<<grid, F_NT, lds, s>>>(ak, nwin, ngroups);
+    if ((a.so == nullptr) != (a.sl == nullptr)) { lg_set_error("attn_bwd_f: the forward's row statistics come as a pair (so, sl)"); return -2; }
+    if (a.so) k_attn_bwd_f<true><<<grid, F_NT, lds, s>>>(ak, nwin, ngroups);
+    else k_attn_bwd_f<false><<<grid, F_NT, lds, s>>>(ak, nwin, ngroups);
     LG_CHECK_LAUNCH();
     // partial rows -> gradients (+=), in the block's deferred reduce launch
     ReduceJob j;

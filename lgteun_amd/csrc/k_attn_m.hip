@@ -130,16 +130,17 @@ __device__ __forceinline__ u32x4_t build_frag(const Pat<NP> (&pat)[CH], int k) {
 // Element (lane = (g, r), slot s = 8 k + j) of tile `tile`: product s / CH (A-side piece table: the weights are always the "W" factor),
 // input channel 16 (chl >> 2) + 4 g + (chl & 3) with chl = s % CH -- the lane map of the activation fragments -- of output channel
 // oc_of(tile, r) (negative: a zero row).  ALL threads of the block call it.
-template <int NP, int CH, int NK, int NTILE, class OC>
-__device__ __forceinline__ void stage_w(u32x4_t* dst, const float* __restrict__ W, int ldw, int kdim, OC oc_of, float wscale = 1.0f) {
-    constexpr int NPROD = nprod(NP);
-    constexpr int NF = NTILE * NK;              // fragments; thread tid owns dword (tid & 3) of lane (tid >> 2) in every one of them
-    constexpr int CHUNK = NF < 16 ? NF : 16;    // loads in flight per thread and round (every load of a round is requested before its first store)
-    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
-    const int i = threadIdx.x & 3, ln = threadIdx.x >> 2, g = ln >> 4, r = ln & 15;
-#pragma unroll
-    for (int f0 = 0; f0 < NF; f0 += CHUNK) {
-        float w0[CHUNK], w1[CHUNK];
+template <int NP, int CH, int NK, int NTILE>
+struct WStage {
+    static constexpr int NPROD = nprod(NP);
+    static constexpr int NF = NTILE * NK;              // fragments; thread tid owns dword (tid & 3) of lane (tid >> 2) in every one of them
+    static constexpr int CHUNK = NF < 16 ? NF : 16;    // loads in flight per thread and round (every load of a round is requested before its first store)
+    static constexpr bool SPLIT = NF <= 16;            // few fragments: ld() requests them all and st() stores them, so that the caller can put the requests of
+                                                       // EVERY table of its prologue in front of the first wait (one round trip instead of one per table)
+    float w0[CHUNK], w1[CHUNK];
+    template <class OC>
+    __device__ __forceinline__ void ld_chunk(int f0, const float* __restrict__ W, int ldw, int kdim, OC oc_of) {
+        const int i = threadIdx.x & 3, ln = threadIdx.x >> 2, g = ln >> 4, r = ln & 15;
 #pragma unroll
         for (int j = 0; j < CHUNK; ++j) {
             const int f = f0 + j < NF ? f0 + j : NF - 1, k = f % NK, tile = f / NK;
@@ -149,6 +150,11 @@ __device__ __forceinline__ void stage_w(u32x4_t* dst, const float* __restrict__ 
             const float* src = W + (ok ? (size_t)oc * ldw + ic : 0);
             w0[j] = src[0]; w1[j] = src[1];     // unconditional (index 0, 1 for the zero slots): no exec-masked branch, no wait at a join
         }
+    }
+    template <class OC>
+    __device__ __forceinline__ void st_chunk(int f0, u32x4_t* dst, int kdim, OC oc_of, float wscale) {
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
+        const int i = threadIdx.x & 3, ln = threadIdx.x >> 2, g = ln >> 4, r = ln & 15;
 #pragma unroll
         for (int j = 0; j < CHUNK; ++j) {
             if (f0 + j >= NF) break;
@@ -162,7 +168,22 @@ __device__ __forceinline__ void stage_w(u32x4_t* dst, const float* __restrict__ 
             d32[f * 256 + threadIdx.x] = ok ? val : 0u;
         }
     }
-}
+    template <class OC>
+    __device__ __forceinline__ void ld(const float* __restrict__ W, int ldw, int kdim, OC oc_of) {
+        if constexpr (SPLIT) ld_chunk(0, W, ldw, kdim, oc_of);
+    }
+    template <class OC>
+    __device__ __forceinline__ void st(u32x4_t* dst, const float* __restrict__ W, int ldw, int kdim, OC oc_of, float wscale = 1.0f) {
+        if constexpr (SPLIT) st_chunk(0, dst, kdim, oc_of, wscale);
+        else {
+#pragma unroll
+            for (int f0 = 0; f0 < NF; f0 += CHUNK) {
+                ld_chunk(f0, W, ldw, kdim, oc_of);
+                st_chunk(f0, dst, kdim, oc_of, wscale);
+            }
+        }
+    }
+};
 
 template <int HC>
 struct Geo {
@@ -217,38 +238,55 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
     float sy = 1.f, sw = 1.f, sq = 1.f, sk = 1.f;
     if (NP == 2) { sy = a.scales[0]; sw = a.scales[1]; sq = a.scales[2]; sk = a.scales[3]; }
     const float syw = sy * sw, inv_yw = 1.0f / syw, sqk = sq * sk, inv_qk = 1.0f / sqk;
-    // ---- once per (persistent) workgroup: pos_emb in fragment order, the weight fragments
-    {
-        float4 pv[8];
+    // ---- once per (persistent) workgroup: pos_emb in fragment order, the weight fragments, the lane constants.  Every request of the prologue goes out
+    // before its first wait (as pos -> store -> table -> store -> table -> ... it was seven dependent round trips per launch at HC = 8)
+    float4 pv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int u = j * 256 + threadIdx.x, ln = u & 63, kt = (u >> 6) & 3, qt = (u >> 8) & 3, h = u >> 10;
-            pv[j] = *reinterpret_cast<const float4*>(a.pos + ((h * 64 + 16 * qt + (ln & 15)) * 64 + 16 * kt + 4 * (ln >> 4)));
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)   // scores live in the log2 domain
-            sPos[j * 256 + threadIdx.x] = make_float4(pv[j].x * (LOG2E * sqk), pv[j].y * (LOG2E * sqk), pv[j].z * (LOG2E * sqk), pv[j].w * (LOG2E * sqk));   // (NP = 2: the score accumulator holds s_q s_k S)
+    for (int j = 0; j < 8; ++j) {
+        const int u = j * 256 + threadIdx.x, ln = u & 63, kt = (u >> 6) & 3, qt = (u >> 8) & 3, h = u >> 10;
+        pv[j] = *reinterpret_cast<const float4*>(a.pos + ((h * 64 + 16 * qt + (ln & 15)) * 64 + 16 * kt + 4 * (ln >> 4)));
     }
-    stage_w<NPQ, CHY, NKQ, MTQK>(sWqk, a.qkvw, HC, HC, [](int t, int r) { return G::qk_oc(t, r); }, sw);
-    stage_w<NPQ, CHY, NKQ, NTV>(sWv, a.qkvw, HC, HC, [](int t, int r) { return G::v_oc(t, r); }, sw);
-    stage_w<NPP, CHC, NKP, MTP>(sWp, a.projw, E, E, [](int t, int r) { return 16 * t + r; });
+    auto oc_qk = [](int t, int r) { return G::qk_oc(t, r); };
+    auto oc_v = [](int t, int r) { return G::v_oc(t, r); };
+    auto oc_p = [](int t, int r) { return 16 * t + r; };
+    WStage<NPQ, CHY, NKQ, MTQK> wsq;
+    WStage<NPQ, CHY, NKQ, NTV> wsv;
+    WStage<NPP, CHC, NKP, MTP> wsp;
+    wsq.ld(a.qkvw, HC, HC, oc_qk);
+    wsv.ld(a.qkvw, HC, HC, oc_v);
+    wsp.ld(a.projw, E, E, oc_p);
     // lane constants: biases as initial accumulators, LayerNorm affine of the lane's local-half channels
     float bqk[MTQK][4], bv[NTV], bp[MTP][4], gam[CHY], bet[CHY];
 #pragma unroll
     for (int mt = 0; mt < MTQK; ++mt)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) bqk[mt][v] = a.qkvb[G::qk_oc(mt, 4 * g + v)] * syw;
+        for (int v = 0; v < 4; ++v) bqk[mt][v] = a.qkvb[G::qk_oc(mt, 4 * g + v)];
 #pragma unroll
-    for (int nt = 0; nt < NTV; ++nt) { const int oc = G::v_oc(nt, c); bv[nt] = oc >= 0 ? a.qkvb[oc] * syw : ((c & 3) == 0 ? 1.0f : 0.f); }
-    // HC = 8: the v tile has eight idle columns.  Columns 8 and 12 are ONES (zero weights, bias 1, left unscaled): rows 8 and 12 of O^T = the
-    // softmax denominators of the tile's queries, on lane groups 2 and 3 -- one v_permlane32_swap brings them to groups 0 (head 0) and 1 (head 1)
-    constexpr bool ONES = HC == 8;
+    for (int nt = 0; nt < NTV; ++nt) { const int oc = G::v_oc(nt, c); bv[nt] = a.qkvb[oc >= 0 ? oc : 0]; }
 #pragma unroll
     for (int mt = 0; mt < MTP; ++mt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) bp[mt][v] = a.projb[16 * mt + 4 * g + v];
 #pragma unroll
-    for (int i = 0; i < CHY; ++i) { const int ch = 16 * (i >> 2) + 4 * g + (i & 3); gam[i] = a.ln1g[ch] * sy; bet[i] = a.ln1b[ch] * sy; }
+    for (int i = 0; i < CHY; ++i) { const int ch = 16 * (i >> 2) + 4 * g + (i & 3); gam[i] = a.ln1g[ch]; bet[i] = a.ln1b[ch]; }
+    __builtin_amdgcn_sched_barrier(0);   // requests above, conversions and stores below
+#pragma unroll
+    for (int j = 0; j < 8; ++j)   // scores live in the log2 domain
+        sPos[j * 256 + threadIdx.x] = make_float4(pv[j].x * (LOG2E * sqk), pv[j].y * (LOG2E * sqk), pv[j].z * (LOG2E * sqk), pv[j].w * (LOG2E * sqk));   // (NP = 2: the score accumulator holds s_q s_k S)
+    wsq.st(sWqk, a.qkvw, HC, HC, oc_qk, sw);
+    wsv.st(sWv, a.qkvw, HC, HC, oc_v, sw);
+    wsp.st(sWp, a.projw, E, E, oc_p);
+#pragma unroll
+    for (int mt = 0; mt < MTQK; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) bqk[mt][v] *= syw;
+    // HC = 8: the v tile has eight idle columns.  Columns 8 and 12 are ONES (zero weights, bias 1, left unscaled): rows 8 and 12 of O^T = the
+    // softmax denominators of the tile's queries, on lane groups 2 and 3 -- one v_permlane32_swap brings them to groups 0 (head 0) and 1 (head 1)
+    constexpr bool ONES = HC == 8;
+#pragma unroll
+    for (int nt = 0; nt < NTV; ++nt) { const int oc = G::v_oc(nt, c); bv[nt] = oc >= 0 ? bv[nt] * syw : ((c & 3) == 0 ? 1.0f : 0.f); }
+#pragma unroll
+    for (int i = 0; i < CHY; ++i) { gam[i] *= sy; bet[i] *= sy; }
     __syncthreads();
     AM_STAMP(0);
 
@@ -440,6 +478,14 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
                 const float f = __builtin_amdgcn_ldexpf(__builtin_amdgcn_rcpf(l), -sh) * inv_yw;     // (v carries s_y s_w)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) cat[qt][mo][v] = mine ? acc[v] * f : cat[qt][mo][v];
+                if constexpr (HC == 8) {
+                    if (a.save_o && mine) {   // saving launch: what k_attn_bwd_f would otherwise re-derive with a reduction pass of its own.  p = 2^(s - L) / 1 with
+                                              // L = log2(sum_j 2^s_j) = log2(l) - c0 (l = sum of the 2^(s + c0)); lanes of group h hold head h's four channels of query c
+                        const long pix = pix0 + qt * tstep;
+                        *reinterpret_cast<float4*>(a.save_o + pix * HC + 4 * h) = make_float4(acc[0] * f, acc[1] * f, acc[2] * f, acc[3] * f);
+                        a.save_l[pix * 2 + h] = __builtin_amdgcn_logf(l) - c0;
+                    }
+                }
             }
         }
 

@@ -249,6 +249,7 @@ static int mixer_half_bwd(const lg_plan* pl, const float* P, float* G, int st, i
         af.d_pos = G + pl->blk(st, j, B_POS); af.d_qkvw = G + pl->blk(st, j, B_QKVW); af.d_qkvb = G + pl->blk(st, j, B_QKVB);
         af.d_projw = G + pl->blk(st, j, B_PROJW); af.d_ln1g = G + pl->blk(st, j, B_LN1G); af.d_ln1b = G + pl->blk(st, j, B_LN1B);
         af.B = B; af.h = fb.h; af.w = fb.w;
+        if (pl->attn_saves_stats(e)) { af.so = fb.att_o; af.sl = fb.att_l; }   // left by the forward's saving launch (block_mixer_fwd)
         return launch_attn_bwd_f(e, af, s);
     }
     ProjO2BwdArgs po;

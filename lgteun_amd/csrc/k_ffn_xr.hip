@@ -173,9 +173,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         xp_first = *reinterpret_cast<const float4*>(a1.x + ((b * h + y) * (long)w + x) * E + 4 * g);
     }
     // ---- once per (persistent) workgroup: weight fragments, taps, biases
+    float4 lng, lnb;
     {
         const int t = threadIdx.x, ln = t >> 2, i = t & 3, lg = ln >> 4, lr = ln & 15;
         // every value is requested before the first store
+        // taps, biases, LayerNorm affines: requested with the weights, from clamped indices (as a `for (k = t; ...; k += 256)` loop and two `if (t < n)`
+        // blocks this was five further dependent round trips: 5 k of a launch's ~ 160 k cycles went to the staging)
+        constexpr int NTP = (N1 * 9 + 255) / 256;
+        float tp[NTP];
+#pragma unroll
+        for (int j = 0; j < NTP; ++j) {
+            const int k = min(t + 256 * j, N1 * 9 - 1);
+            tp[j] = a2.dww[(4 * (k / 36) + (k & 3)) * 9 + (k % 36) / 4];   // [quad][tap][u] <- dww[4 quad + u][tap]
+        }
+        const int tn = t < N1 ? t : N1 - 1, te = t < E ? t : E - 1;
+        const float pb1 = a1.b1[tn], pb2 = a1.b2[tn], pdwb = a2.dwb[tn], pb3 = a2.b3[te];
+        const float* const ng = a2.g ? a2.n1g : a2.b3;   // no planar half: any valid address, value unused
+        const float* const nb_ = a2.g ? a2.n1b : a2.b3;
+        const float png = ng[te], pnb = nb_[te];
+        lng = *reinterpret_cast<const float4*>(a1.ln2g + 4 * g);
+        lnb = *reinterpret_cast<const float4*>(a1.ln2b + 4 * g);
         float2 v1[4], v2[8], v3[2];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) v1[mt] = *reinterpret_cast<const float2*>(a1.w1 + (size_t)(16 * mt + lr) * E + 4 * lg + 2 * (i & 1));
@@ -186,6 +203,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) v3[s] = *reinterpret_cast<const float2*>(a2.w3 + (size_t)lr * N1 + 16 * (2 * s + (i >> 1)) + 4 * lg + 2 * (i & 1));
+        __builtin_amdgcn_sched_barrier(0);   // every request above this line, every conversion and store below it
         uint32_t* d32 = reinterpret_cast<uint32_t*>(sW);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {   // GEMM1 (K = 16): two piece products share one 32-deep instruction: A = {w_lo | w_hi}, {w_hi | 0} against B = {x_hi | x_lo}, {x_hi | 0}
@@ -208,16 +226,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             d32[(NF1 + NF2 + 2 * s) * 256 + t] = hi;
             d32[(NF1 + NF2 + 2 * s + 1) * 256 + t] = lo;
         }
-        for (int k = t; k < N1 * 9; k += 256) sTaps[k] = a2.dww[(4 * (k / 36) + (k & 3)) * 9 + (k % 36) / 4];   // [quad][tap][u] <- dww[4 quad + u][tap]
-        if (t < N1) { sPar[P_B1 + t] = a1.b1[t] * S1; sPar[P_B2 + t] = a1.b2[t] * S2; sPar[P_DWB + t] = a2.dwb[t]; }
+#pragma unroll
+        for (int j = 0; j < NTP; ++j) asm volatile("" : "+v"(tp[j]));   // (or the load of the last, partial trip sinks into its store's `if`, with a wait of its own)
+#pragma unroll
+        for (int j = 0; j < NTP; ++j)
+            if (t + 256 * j < N1 * 9) sTaps[t + 256 * j] = tp[j];
+        if (t < N1) { sPar[P_B1 + t] = pb1 * S1; sPar[P_B2 + t] = pb2 * S2; sPar[P_DWB + t] = pdwb; }
         if (t < E) {
-            sPar[P_B3 + t] = a2.b3[t] * S3;
-            sPar[P_N1G + t] = a2.g ? a2.n1g[t] : 0.f;
-            sPar[P_N1B + t] = a2.g ? a2.n1b[t] : 0.f;
+            sPar[P_B3 + t] = pb3 * S3;
+            sPar[P_N1G + t] = a2.g ? png : 0.f;
+            sPar[P_N1B + t] = a2.g ? pnb : 0.f;
         }
     }
     // LayerNorm affine of the lane's four channels, with the operand scale folded in
-    float4 lng = *reinterpret_cast<const float4*>(a1.ln2g + 4 * g), lnb = *reinterpret_cast<const float4*>(a1.ln2b + 4 * g);
     lng = make_float4(lng.x * sx, lng.y * sx, lng.z * sx, lng.w * sx);
     lnb = make_float4(lnb.x * sx, lnb.y * sx, lnb.z * sx, lnb.w * sx);
     __syncthreads();

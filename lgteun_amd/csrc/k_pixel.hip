@@ -55,19 +55,32 @@ __global__ __launch_bounds__(256) void k_resample_dw(DwArgs a) {
     if constexpr (EPI == 2) {
         const size_t hw = (size_t)a.ho * a.wo;
         const float* __restrict__ zb = a.z + (size_t)b * a.C * hw;
+        // all band planes of the thread's four pixels are requested before the first one is used (a run-time `for (cc < C)` loop kept one load + wait
+        // per band: C dependent round trips per pixel); C <= 8 (launcher), bands beyond C repeat the last plane with a zero weight
+        constexpr int CMAX = 8;
+        float zv[4][CMAX], pn[4], rwv[CMAX];
+#pragma unroll
+        for (int cc = 0; cc < CMAX; ++cc) rwv[cc] = cc < a.C ? a.rw[cc < a.C ? cc : 0] : 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = threadIdx.x + 256 * k;
             const int oy = ty0 + (i >> 5), ox = tx0 + (i & 31);
             const size_t pix = (oy < a.ho && ox < a.wo) ? (size_t)oy * a.wo + ox : 0;
-            float r = a.rb[0];
+#pragma unroll
+            for (int cc = 0; cc < CMAX; ++cc) zv[k][cc] = zb[(size_t)(cc < a.C ? cc : a.C - 1) * hw + pix];
+            pn[k] = a.pan[(size_t)b * hw + pix];
+        }
+        const float rb0 = a.rb[0];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float r = rb0;
             zc[k] = 0.f;
-            for (int cc = 0; cc < a.C; ++cc) {
-                const float zv = zb[cc * hw + pix];
-                r += a.rw[cc] * zv;
-                if (cc == c) zc[k] = zv;
+#pragma unroll
+            for (int cc = 0; cc < CMAX; ++cc) {
+                if (cc < a.C) r += rwv[cc] * zv[k][cc];   // (same order of additions as the band loop)
+                zc[k] = cc == c ? zv[k][cc] : zc[k];
             }
-            rzp[k] = r - a.pan[(size_t)b * hw + pix];
+            rzp[k] = r - pn[k];
         }
     }
     if constexpr (MODE == 1) resample_tile34<1>(in, a.hi, a.wi, a.ho, a.wo, ty0, tx0, U, rs_scratch);
@@ -114,6 +127,7 @@ __global__ __launch_bounds__(256) void k_resample_dw(DwArgs a) {
 int launch_resample_dw(int mode, int epi, const DwArgs& a, hipStream_t s) {
     ProfScope prof__(LG_K_DATASTEP, s);
     dim3 grid((a.wo + 31) / 32, (a.ho + 31) / 32, a.planes);
+    if (epi == 2 && a.C > 8) { lg_set_error("resample_dw: the fused update holds at most 8 bands per pixel (C=%d)", a.C); return -2; }
 #define LG_RDW(M, E) k_resample_dw<M, E><<<grid, 256, 0, s>>>(a)
     if (mode == 0 && epi == 0) LG_RDW(0, 0);
     else if (mode == 0 && epi == 1) LG_RDW(0, 1);
@@ -336,15 +350,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     __shared__ float4 srcb[NS * Q];                          // [NS][2E] level-1 pixels
     __shared__ __attribute__((aligned(16))) float vb[NS * LDV];   // [NS][E] up-conv of them (no bias)
     __shared__ float sFw[E * 2 * E], sFb[2 * E];   // fusion weight | up bias, fusion bias (synchronised by the barriers below)
-    {   // all three arrays requested before the first store
-        float vw[(E * 2 * E + 255) / 256], vu[1], vf[1];
-        lds_stage_ld<256, E * 2 * E>(vw, a.fw);
-        lds_stage_ld<256, E>(vu, a.upb);
-        lds_stage_ld<256, E>(vf, a.fb);
-        lds_stage_st<256, E * 2 * E>(sFw, vw);
-        lds_stage_st<256, E>(sFb, vu);
-        lds_stage_st<256, E>(sFb + E, vf);
-    }
     const int hi = a.H / 2, wi = a.W / 2;
     int t = blockIdx.x;
     const int tx_i = t % tiles_x;
@@ -353,17 +358,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const long b = t / tiles_y;
     const int Y0 = ty_i * TY, X0 = tx_i * TX;
     const int sy0 = Y0 / 2 - 2, sx0 = X0 / 2 - 2;
-    for (int i = threadIdx.x; i < NS * Q; i += 256) {
-        const int px = i / Q, k = i - px * Q;
-        const int ly = px / SX, lx = px - ly * SX;
-        const int yy = clampi(sy0 + ly, 0, hi - 1), xx = clampi(sx0 + lx, 0, wi - 1);
-        srcb[i] = reinterpret_cast<const float4*>(a.xb + ((b * hi + yy) * (long)wi + xx) * (2 * E))[k];
-    }
-    // this thread's row of the up-conv weight (output channel n = tid % E for every item it handles)
     const int n_own = threadIdx.x % E;
     float4 wrow[Q];
+    {   // every source piece of the thread is requested before the first one is stored: as a `for (i = tid; i < NS * Q; i += 256)` loop the compiler
+        // kept one load + wait + store per trip -- ten dependent HBM round trips per workgroup at e = 32 (the kernel ran at 2.5 x its HBM time)
+        constexpr int NPC = NS * Q / 256;
+        static_assert(NS * Q % 256 == 0, "source tile = whole trips of the workgroup");
+        float4 sv[NPC];
 #pragma unroll
-    for (int k = 0; k < Q; ++k) wrow[k] = reinterpret_cast<const float4*>(a.upw + n_own * 2 * E)[k];
+        for (int j = 0; j < NPC; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            const int px = i / Q, k = i - px * Q;
+            const int ly = px / SX, lx = px - ly * SX;
+            const int yy = clampi(sy0 + ly, 0, hi - 1), xx = clampi(sx0 + lx, 0, wi - 1);
+            sv[j] = reinterpret_cast<const float4*>(a.xb + ((b * hi + yy) * (long)wi + xx) * (2 * E))[k];
+        }
+        // this thread's row of the up-conv weight (output channel n = tid % E for every item it handles) and the three parameter arrays behind
+        // them, in the same round trip (all requested before the first store)
+#pragma unroll
+        for (int k = 0; k < Q; ++k) wrow[k] = reinterpret_cast<const float4*>(a.upw + n_own * 2 * E)[k];
+        float vw[(E * 2 * E + 255) / 256], vu[1], vf[1];
+        lds_stage_ld<256, E * 2 * E>(vw, a.fw);
+        lds_stage_ld<256, E>(vu, a.upb);
+        lds_stage_ld<256, E>(vf, a.fb);
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) srcb[threadIdx.x + 256 * j] = sv[j];
+        lds_stage_st<256, E * 2 * E>(sFw, vw);
+        lds_stage_st<256, E>(sFb, vu);
+        lds_stage_st<256, E>(sFb + E, vf);
+    }
     __syncthreads();
     for (int it = threadIdx.x; it < NS * E; it += 256) {
         const int px = it / E;

@@ -108,6 +108,8 @@ struct AttnArgs {
     int dropout;
     uint64_t seed;
     int bf16;           // k_attn_m: 1 = one round-to-nearest piece per operand (precision = 'bf16'), 0 = fp32-equivalent split arithmetic
+    float* save_o = nullptr;         // k_attn_m, e = 16, saving launch (round 6): [P,e/2] attention output before proj (head-major = the local half of cat) and
+    float* save_l = nullptr;         // [P,2] log2-domain log-sum-exp of the score rows, for k_attn_bwd_f (which then skips its reduction pass); null: not written
     const float* scales = nullptr;   // k_attn_m: this block's static operand scales { s_y, s_w, s_q, s_k } (k_ffn_prep.hip, round 6): to_qkv and Q K^T on f16 pairs; nullptr: bf16 triples
 };
 int launch_attn(int e, const AttnArgs& a, hipStream_t s);     // round 2's kernel: lane = token, every product on the vector pipe (LG_VAR_ATTN_FWD_VALU)

@@ -23,9 +23,27 @@ __device__ __forceinline__ void resample_tile34(const float* __restrict__ in, in
     float* Hh = scratch + SR * SP;
     const int sy0 = MODE == 1 ? (ty0 >> 1) - 2 : 2 * ty0 - 3;   // pre-clamp source coordinate of S[0][0]
     const int sx0 = MODE == 1 ? (tx0 >> 1) - 2 : 2 * tx0 - 3;
-    for (int i = threadIdx.x; i < SR * SR; i += 256) {
-        const int sy = i / SR, sx = i - sy * SR;
-        S[sy * SP + sx] = in[(size_t)clampi(sy0 + sy, 0, hi - 1) * wi + clampi(sx0 + sx, 0, wi - 1)];
+    {   // the window in rounds of up to four values per thread, every value of a round requested before its first store (one load + wait + store per
+        // trip is one dependent round trip per trip)
+        constexpr int NTR = (SR * SR + 255) / 256, RND = NTR < 4 ? NTR : 4;
+#pragma unroll 1
+        for (int t0 = 0; t0 < NTR; t0 += RND) {
+            float v[RND];
+#pragma unroll
+            for (int j = 0; j < RND; ++j) {
+                const int i = min((t0 + j) * 256 + (int)threadIdx.x, SR * SR - 1);
+                const int sy = i / SR, sx = i - sy * SR;
+                v[j] = in[(size_t)clampi(sy0 + sy, 0, hi - 1) * wi + clampi(sx0 + sx, 0, wi - 1)];
+            }
+#pragma unroll
+            for (int j = 0; j < RND; ++j) asm volatile("" : "+v"(v[j]));   // (or a partial trip's load sinks into its store's `if`)
+#pragma unroll
+            for (int j = 0; j < RND; ++j) {
+                const int i = (t0 + j) * 256 + (int)threadIdx.x;
+                const int sy = i / SR, sx = i - sy * SR;
+                if (i < SR * SR) S[sy * SP + sx] = v[j];
+            }
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < SR * 34; i += 256) {

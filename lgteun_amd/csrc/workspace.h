@@ -22,6 +22,7 @@ struct BlockBufs {
     float *g, *o2;     // planar [B,e/2,h,w]
     float *amp, *pha;  // saved spectrum [B,e/2,h,w/2+1] (train)
     float* sgn;        // saved sign of the irfft2 output [B,e/2,h,w] (train)
+    float *att_o, *att_l;  // e = 16, train: the local mixer's attention output [B,h,w,e/2] and score-row log-sum-exp [B,h,w,2] (k_attn_m -> k_attn_bwd_f)
     float *a1, *g1, *h2, *a3, *g3;  // [B,h,w,4e]: gelu(h1), gelu'(h1), h2, gelu(h3), gelu'(h3)  (a*, g* train only)
 };
 
@@ -51,7 +52,7 @@ static inline NetBufs stage_view(const NetBufs& nb, int i) {
     auto mv = [sh](float*& p) { if (p) p = reinterpret_cast<float*>(reinterpret_cast<char*>(p) + sh); };
     for (int j = 0; j < 5; ++j) {
         BlockBufs& b = v.blk[j];
-        mv(b.xin); mv(b.xmid); mv(b.xout); mv(b.g); mv(b.o2); mv(b.amp); mv(b.pha); mv(b.sgn);
+        mv(b.xin); mv(b.xmid); mv(b.xout); mv(b.g); mv(b.o2); mv(b.amp); mv(b.pha); mv(b.sgn); mv(b.att_o); mv(b.att_l);
         mv(b.a1); mv(b.g1); mv(b.h2); mv(b.a3); mv(b.g3);
     }
     mv(v.x0); mv(v.u_down); mv(v.t_up);
@@ -97,12 +98,15 @@ static inline void carve(const lg_plan* plan, int B, int train, void* base, NetB
             bb.amp = cv.take(B * (e / 2) * bb.h * (bb.w / 2 + 1));
             bb.pha = cv.take(B * (e / 2) * bb.h * (bb.w / 2 + 1));
             bb.sgn = cv.take(B * P * e / 2);
+            bb.att_o = e == 16 ? cv.take(B * P * e / 2) : nullptr;
+            bb.att_l = e == 16 ? cv.take(B * P * 2) : nullptr;
             bb.a1 = cv.take(B * P * 4 * e);
             bb.g1 = cv.take(B * P * 4 * e);
             bb.h2 = cv.take(B * P * 4 * e);
             bb.a3 = cv.take(B * P * 4 * e);
             bb.g3 = cv.take(B * P * 4 * e);
         } else {
+            bb.att_o = bb.att_l = nullptr;
             bb.amp = bb.pha = bb.sgn = bb.a1 = bb.g1 = bb.a3 = bb.g3 = nullptr;
             bb.h2 = shared_h2;
         }

@@ -114,6 +114,7 @@ def test_variant_word_from_the_diagnostic_environment_variables():
     assert _lib.variant_from_env({'LG_FFT': 'full'}) == _lib.LG_VAR_FFT_FULL
     assert _lib.variant_from_env({'LG_FFN_BWD_SPLIT': 'bf16x3'}) == _lib.LG_VAR_FFN_BWD_BF16X3
     assert _lib.variant_from_env({'LG_ATTN_BWD_CORE': 'm'}) == _lib.LG_VAR_ATTN_BWD_CORE_M
+    assert _lib.variant_from_env({'LG_ATTN_BWD_STATS': 'recompute'}) == _lib.LG_VAR_ATTN_BWD_RESTATS == 1 << 16
     hdr = open(os.path.join(ROOT, 'include', 'lgteun_hip.h')).read()
     for name in ('LG_VAR_FFN_STRIP', 'LG_VAR_FFN_TILE', 'LG_VAR_FFN_XP'):
         assert int(re.search(rf'#define {name} (\d+)u', hdr).group(1)) == getattr(_lib, name)

@@ -433,6 +433,38 @@ def test_fused_attention_backward_agrees_with_the_round3_path(drop, monkeypatch)
         assert float((a - b).norm()) <= tol * float(a.norm()) + 1e-10, (drop, eng.names[i], float((a - b).norm()), float(a.norm()))
 
 
+@pytest.mark.parametrize('drop', [False, True])
+def test_attention_backward_on_the_forwards_row_statistics_agrees_with_its_own_reduction_pass(drop, monkeypatch):
+    """round 6: k_attn_bwd_f<STATS> reads the log-sum-exp of every score row and the attention output that k_attn_m's saving launch left (one loop over
+    the keys in pass 1) -- against the same kernel re-deriving both with its reduction pass (LG_ATTN_BWD_STATS=recompute, rounds 4 - 5) on a whole train
+    step, with and without dropout: every live gradient tensor to rounding (the forward's statistics come out of split 16-bit products, the backward's
+    own out of fp32 multiply-adds: the two differ by ~1e-6 of a score)"""
+    from gpu_helpers import make_module
+    from lgteun_amd.engine import LG_FLAG_DROPOUT, LG_FLAG_SAVE, LG_FLAG_FAITHFUL
+    ms, pan, gt = (T(a).cuda() for a in dw.make_inputs(3, 4, 16, 24, seed=12, kind='smooth'))
+    flags = (LG_FLAG_DROPOUT if drop else 0) | LG_FLAG_SAVE | LG_FLAG_FAITHFUL
+
+    def grads():
+        net = make_module(4, 2)
+        eng = net.engine()
+        y, saved = eng.forward_raw(ms, pan, flags, seed=4321)
+        r = torch.randn(y.shape, generator=torch.Generator(device='cpu').manual_seed(6)).cuda()
+        g = torch.zeros_like(eng.flat)
+        eng.backward_raw(saved, r, g, flags, seed=4321)
+        return y.clone(), g, eng
+    monkeypatch.delenv('LG_ATTN_BWD_STATS', raising=False)
+    y1, g1, eng = grads()
+    monkeypatch.setenv('LG_ATTN_BWD_STATS', 'recompute')          # read once per plan: a fresh module builds a fresh plan
+    y0, g0, _ = grads()
+    assert torch.equal(y0, y1)                                    # the forward's output does not depend on what it saves
+    assert float(g0.abs().max()) > 0 and bool(torch.isfinite(g1).all())
+    for i in eng.live_idx:
+        o, n = eng.offsets[i], eng.params[i].numel()
+        a, b = g0[o:o + n].double(), g1[o:o + n].double()
+        tol = 2e-4 if eng.names[i].endswith(('pos_emb', 'conv_amp.0.bias', 'conv_pha.0.bias')) else 2e-5   # the cancelling sums
+        assert float((a - b).norm()) <= tol * float(a.norm()) + 1e-10, (drop, eng.names[i], float((a - b).norm()), float(a.norm()))
+
+
 @pytest.mark.parametrize('C', [4, 8])
 def test_one_launch_data_step_agrees_with_the_tile_kernels_on_a_train_step(C, monkeypatch):
     """k_dstep.hip (round 4: the data step of a 128 x 128 plane as one pixelwise + one plane-in-LDS launch per direction) against the four + nine
