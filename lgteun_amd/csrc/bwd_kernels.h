@@ -320,6 +320,8 @@ struct AttnBwdArgs {
     float *d_qkvw, *d_qkvb;   // e = 16 (attn_bwd_fuses_qkv): to_qkv's weight / bias gradients are accumulated in the epilogue kernel (+=); y1 may be null
     float* part;        // scratch: per-workgroup partial sums, attn_bwd_part_floats(e) floats
     int B, h, w;
+    const float* so = nullptr;   // [P,e/2] the forward's attention output (pre-proj, head-major) and
+    const float* sl = nullptr;   // [P,2] log-sum-exp of its score rows (log2 domain), left by k_attn_m's saving launch (round 6); both null: k_attn_bwd_core re-derives them
     float* stats = nullptr;   // k_attn_bwd_core_m only: [P][2 heads][4] row statistics between its two launches
     int core_m = 0;     // 1 (lg_config.variant LG_VAR_ATTN_BWD_CORE_M): the matrix-pipe core k_attn_bwd_core_m at e = 32 instead of the vector-pipe k_attn_bwd_core
 };

@@ -56,8 +56,8 @@ struct lg_plan {
     bool ffn_h3_recompute(int e) const { return e == 16 && ffn_bwd_x(e) && cfg.precision == 0 && !dwbwd_tile && ffn_h3_re && !ffn_xs && ffn_f16x2(e); }
     int ffn_xs;        // A/B switch (lg_config.variant LG_VAR_FFN_XS; Python side: LG_FFN_FWD=xs): rounds 2 - 5's channel-split k_ffn_xs at e = 16 instead of the register-chain k_ffn_xr
     int attn_bf16x3;   // A/B switch (lg_config.variant LG_VAR_ATTN_BF16X3; Python side: LG_ATTN_SPLIT=bf16x3): to_qkv and Q K^T of k_attn_m on three bf16 pieces / six products (round 5) instead of f16 pairs with static scales (round 6)
-    // the live stage's e = 16 local mixer leaves its row log-sum-exp and attention output for k_attn_bwd_f (fp32-equivalent mode, matrix-pipe forward)
-    bool attn_saves_stats(int e) const { return e == 16 && cfg.precision == 0 && !attn_bwd_old && !attn_fwd_valu && !attn_restats; }
+    // the live stage's local mixers leave their row log-sum-exp and attention output for k_attn_bwd_f / k_attn_bwd_core (fp32-equivalent mode, matrix-pipe forward)
+    bool attn_saves_stats(int e) const { return cfg.precision == 0 && !attn_fwd_valu && !attn_restats && !(e == 32 && attn_bwd_core_m); }
     bool attn_f16x2() const { return cfg.precision == 0 && !attn_bf16x3 && !attn_fwd_valu && ffn_tile == 0 && !ffn_bf16x3; }   // (the scales ride in the FFN prep launch: the f16-pair FFN arithmetic must be on)
     int attn_fwd_valu; // A/B switch (lg_config.variant LG_VAR_ATTN_FWD_VALU; Python side: LG_ATTN_FWD=valu): round 2's vector-pipe k_attn instead of the matrix-pipe k_attn_m
     int dstep_tiles; // A/B switch (lg_config.variant LG_VAR_DSTEP_TILES; Python side: LG_DSTEP=tiles): the tile kernels of the data step also where the one-launch

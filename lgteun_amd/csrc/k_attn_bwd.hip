@@ -13,7 +13,9 @@
 #include "kernels.h"
 #include "bwd_kernels.h"
 
-template <int HC, int NW>
+// STATS (round 6): the forward's saving launch left the log-sum-exp of every score row (log2 domain, a.sl) and the attention output (a.so): pass 1 is then ONE loop
+// over the keys (scores -> P = 2^(s - L) -> dP -> dS -> dq) that reads k and v once; D_i = dO_i . O_i and the cat image come out of the prologue (k_attn_bwd_f.hip).
+template <int HC, int NW, bool STATS>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HC == 32 ? 1 : 2))) void k_attn_bwd_core(AttnBwdArgs a, int nwin, int ngroups) {
     // blockIdx.y = head: the two heads of a window are independent, so each workgroup keeps only one head's pos_emb /
     // dpos / K,V,Q,dO tiles in LDS -> half the LDS, twice the waves per CU.
@@ -108,6 +110,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HC == 3
 #pragma unroll
                 for (int c = 0; c < HC; ++c) o2v[c] = a.o2[(b * HC + c) * hw + s];
             }
+            float4 Of[D / 4];
+            float Lrow = 0.f;
+            if constexpr (STATS) {
+#pragma unroll
+                for (int k = 0; k < D / 4; ++k) Of[k] = reinterpret_cast<const float4*>(a.so + p * HC + hd * D)[k];
+                Lrow = a.sl[p * 2 + hd];
+            }
             {
                 float xv[E];
 #pragma unroll
@@ -150,12 +159,24 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HC == 3
                     const float4 v = dq4[k];
                     dym[4 * k] = v.x; dym[4 * k + 1] = v.y; dym[4 * k + 2] = v.z; dym[4 * k + 3] = v.w;
                 }
+                float Dsum = 0.f;
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
                     float acc = 0.f;
 #pragma unroll
                     for (int n = 0; n < E; ++n) acc += sWp[k * E + n] * dym[n];
                     sDO[k * 64 + lane] = acc;
+                    if constexpr (STATS) {
+                        const float4 o4 = Of[k >> 2];
+                        Dsum += acc * ((k & 3) == 0 ? o4.x : (k & 3) == 1 ? o4.y : (k & 3) == 2 ? o4.z : o4.w);
+                    }
+                }
+                if constexpr (STATS) {   // row statistics of (token = lane, head hd) for both passes; the head's attention output into the proj-input image
+                    sSt[lane] = Lrow;
+                    sSt[128 + lane] = Dsum;
+                    float4* co = reinterpret_cast<float4*>(a.cat + p * E + hd * D);
+#pragma unroll
+                    for (int c4 = 0; c4 < D / 4; ++c4) co[c4] = Of[c4];
                 }
                 if (hd == 0) {   // global-mixer half of the proj input, and the zero padding of the dqkv rows
                     float* co = a.cat + p * E;
@@ -177,8 +198,41 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HC == 3
 #pragma unroll
             for (int c = 0; c < D; ++c) { q[c] = sQ[c * 64 + lane]; dOi[c] = sDO[c * 64 + lane]; }
             const float* prow = sPos + lane * PLD;
+            lg_v2f dq2[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) dq2[c] = (lg_v2f){0.f, 0.f};
+            float O[D], mx = 0.f, inv = 1.f, Dv = 0.f;
+            if constexpr (STATS) {
+                const float Li = sSt[lane];
+                Dv = sSt[128 + lane];
+                const lg_v2f L2v = (lg_v2f){Li, Li}, Dv2 = (lg_v2f){Dv, Dv};
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    lg_v2f sp[NP], dP[NP], kv[D][NP];
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) { sp[u] = (lg_v2f){prow[TG * g + 2 * u], prow[TG * g + 2 * u + 1]}; dP[u] = (lg_v2f){0.f, 0.f}; }
+#pragma unroll
+                    for (int c = 0; c < D; ++c) {
+                        lg_v2f vv[NP];
+                        ld_tokens(sK, c, g, kv[c]);
+                        ld_tokens(sV, c, g, vv);
+                        const lg_v2f qq = (lg_v2f){q[c], q[c]}, dd = (lg_v2f){dOi[c], dOi[c]};
+#pragma unroll
+                        for (int u = 0; u < NP; ++u) { sp[u] = qq * kv[c][u] + sp[u]; dP[u] = dd * vv[u] + dP[u]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        const lg_v2f e = sp[u] - L2v;
+                        const lg_v2f P = (lg_v2f){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+                        const lg_v2f dS = P * (dP[u] - Dv2);
+#pragma unroll
+                        for (int c = 0; c < D; ++c) dq2[c] = dS * kv[c][u] + dq2[c];
+                    }
+                    if ((TG * (g + 1)) % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
             lg_v2f sc[32];
-            float mx = -3.0e38f;
+            mx = -3.0e38f;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 lg_v2f sp[NP];
@@ -205,7 +259,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HC == 3
                 sc[g] = (lg_v2f){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
                 l2 += sc[g];
             }
-            const float inv = __builtin_amdgcn_rcpf(l2.x + l2.y);
+            inv = __builtin_amdgcn_rcpf(l2.x + l2.y);
             const lg_v2f inv2 = (lg_v2f){inv, inv};
             lg_v2f O2[D];   // (even keys, odd keys) partials
 #pragma unroll
@@ -224,15 +278,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HC == 3
                 }
                 if ((TG * (g + 1)) % 8 == 0) __builtin_amdgcn_sched_barrier(0);
             }
-            float O[D];
-            float Dv = 0.f;
 #pragma unroll
             for (int c = 0; c < D; ++c) { O[c] = O2[c].x + O2[c].y; Dv += dOi[c] * O[c]; }
             asm volatile("" ::: "memory");   // re-read K / V from LDS below instead of keeping 64 x 2D values live
             const lg_v2f Dv2 = (lg_v2f){Dv, Dv};
-            lg_v2f dq2[D];
-#pragma unroll
-            for (int c = 0; c < D; ++c) dq2[c] = (lg_v2f){0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 lg_v2f dP[NP], kv[D][NP];
@@ -255,6 +304,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HC == 3
                 }
                 if ((TG * (g + 1)) % 8 == 0) __builtin_amdgcn_sched_barrier(0);
             }
+            }
             float dqh[D];
 #pragma unroll
             for (int c = 0; c < D; ++c) dqh[c] = dq2[c].x + dq2[c].y;
@@ -262,12 +312,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HC == 3
             float4* dq_o = reinterpret_cast<float4*>(a.dqkv + p * DQLD + hd * D);  // aliasing destinations compiled to 2 D dword stores)
 #pragma unroll
             for (int c4 = 0; c4 < D / 4; ++c4) {
-                co[c4] = make_float4(O[4 * c4], O[4 * c4 + 1], O[4 * c4 + 2], O[4 * c4 + 3]);
+                if constexpr (!STATS) co[c4] = make_float4(O[4 * c4], O[4 * c4 + 1], O[4 * c4 + 2], O[4 * c4 + 3]);
                 dq_o[c4] = make_float4(dqh[4 * c4] * scale, dqh[4 * c4 + 1] * scale, dqh[4 * c4 + 2] * scale, dqh[4 * c4 + 3] * scale);
             }
-            sSt[lane] = mx;
-            sSt[64 + lane] = inv;
-            sSt[128 + lane] = Dv;
+            if constexpr (!STATS) {
+                sSt[lane] = mx;
+                sSt[64 + lane] = inv;
+                sSt[128 + lane] = Dv;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();   // per-wave tiles: no workgroup barrier needed
@@ -293,13 +345,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(HC == 3
                 }
                 lg_v2f smx[NP], sinv[NP], sdv[NP];   // row max (log2 domain), 1 / row sum, D_i of the TG queries
                 ld_tokens(sSt, 0, g, smx);
-                ld_tokens(sSt, 1, g, sinv);
+                if constexpr (!STATS) ld_tokens(sSt, 1, g, sinv);
                 ld_tokens(sSt, 2, g, sdv);
                 lg_v2f P[NP], dS[NP];
 #pragma unroll
                 for (int u = 0; u < NP; ++u) {
                     const lg_v2f e = t[u] - smx[u];
-                    P[u] = (lg_v2f){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} * sinv[u];
+                    P[u] = (lg_v2f){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+                    if constexpr (!STATS) P[u] *= sinv[u];   // (STATS: smx holds the row's log-sum-exp)
                     dS[u] = P[u] * (dP[u] - sdv[u]);
                     dpacc[NP * g + u] += dS[u];
                 }
@@ -580,7 +633,8 @@ static int launch_attn_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
     size_t lds = (size_t)(2 * 64 * 65 + NW * (4 * 64 * (HC / 2) + 64 * 4)) * sizeof(float);
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_attn_bwd_core<HC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn_bwd_core<HC, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_attn_bwd_core<HC, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
         if (e != hipSuccess) { lg_set_error("attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_once.done();
     }
@@ -589,7 +643,9 @@ static int launch_attn_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
         int rc = launch_attn_bwd_core_m(2 * HC, a, grid, nwin, ngroups, s);
         if (rc) return rc;
     } else {
-        k_attn_bwd_core<HC, NW><<<dim3(grid, 2), NW * 64, lds, s>>>(a, nwin, ngroups);
+        if ((a.so == nullptr) != (a.sl == nullptr)) { lg_set_error("attn_bwd: the forward's row statistics come as a pair (so, sl)"); return -2; }
+        if (a.so) k_attn_bwd_core<HC, NW, true><<<dim3(grid, 2), NW * 64, lds, s>>>(a, nwin, ngroups);
+        else k_attn_bwd_core<HC, NW, false><<<dim3(grid, 2), NW * 64, lds, s>>>(a, nwin, ngroups);
         LG_CHECK_LAUNCH();
     }
     const long total = (long)a.B * a.h * a.w;

@@ -478,13 +478,12 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
                 const float f = __builtin_amdgcn_ldexpf(__builtin_amdgcn_rcpf(l), -sh) * inv_yw;     // (v carries s_y s_w)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) cat[qt][mo][v] = mine ? acc[v] * f : cat[qt][mo][v];
-                if constexpr (HC == 8) {
-                    if (a.save_o && mine) {   // saving launch: what k_attn_bwd_f would otherwise re-derive with a reduction pass of its own.  p = 2^(s - L) / 1 with
-                                              // L = log2(sum_j 2^s_j) = log2(l) - c0 (l = sum of the 2^(s + c0)); lanes of group h hold head h's four channels of query c
-                        const long pix = pix0 + qt * tstep;
-                        *reinterpret_cast<float4*>(a.save_o + pix * HC + 4 * h) = make_float4(acc[0] * f, acc[1] * f, acc[2] * f, acc[3] * f);
-                        a.save_l[pix * 2 + h] = __builtin_amdgcn_logf(l) - c0;
-                    }
+                if (a.save_o && mine) {   // saving launch: what the backward would otherwise re-derive with a reduction pass of its own.  p = 2^(s - L) with
+                                          // L = log2(sum_j 2^s_j) = log2(l) - c0 (l = sum of the 2^(s + c0)); this lane holds channels cb .. cb + 3 of query c
+                    const long pix = pix0 + qt * tstep;
+                    const int cb = (HC >= 32 ? 16 * h : 0) + 4 * g;
+                    *reinterpret_cast<float4*>(a.save_o + pix * HC + cb) = make_float4(acc[0] * f, acc[1] * f, acc[2] * f, acc[3] * f);
+                    if (HC >= 32 ? g == 0 : (HC == 16 ? (g & 1) == 0 : true)) a.save_l[pix * 2 + h] = __builtin_amdgcn_logf(l) - c0;
                 }
             }
         }

@@ -271,6 +271,7 @@ static int mixer_half_bwd(const lg_plan* pl, const float* P, float* G, int st, i
     if (attn_bwd_fuses_qkv(e)) at.y1 = nullptr;   // the epilogue kernel forms y1 itself and accumulates the to_qkv weight gradient
     if (!at.part) return -3;
     at.B = B; at.h = fb.h; at.w = fb.w; at.core_m = pl->attn_bwd_core_m; at.stats = bb.attn_stats;
+    if (pl->attn_saves_stats(e) && !(e == 32 && pl->attn_bwd_core_m)) { at.so = fb.att_o; at.sl = fb.att_l; }   // left by the forward's saving launch (block_mixer_fwd)
     RC(launch_attn_bwd(e, at, s));
     const int grid = attn_bwd_grid(e, B, fb.h, fb.w);
     RC(launch_reduce_slab(bb.dpos_slab, grid, 1, 2 * 64 * 64, G + pl->blk(st, j, B_POS), 2 * 64 * 64, 1, 2 * 64 * 64, s));

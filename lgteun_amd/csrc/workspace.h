@@ -22,7 +22,7 @@ struct BlockBufs {
     float *g, *o2;     // planar [B,e/2,h,w]
     float *amp, *pha;  // saved spectrum [B,e/2,h,w/2+1] (train)
     float* sgn;        // saved sign of the irfft2 output [B,e/2,h,w] (train)
-    float *att_o, *att_l;  // e = 16, train: the local mixer's attention output [B,h,w,e/2] and score-row log-sum-exp [B,h,w,2] (k_attn_m -> k_attn_bwd_f)
+    float *att_o, *att_l;  // train: the local mixer's attention output [B,h,w,e/2] and score-row log-sum-exp [B,h,w,2] (k_attn_m -> k_attn_bwd_f)
     float *a1, *g1, *h2, *a3, *g3;  // [B,h,w,4e]: gelu(h1), gelu'(h1), h2, gelu(h3), gelu'(h3)  (a*, g* train only)
 };
 
@@ -98,8 +98,8 @@ static inline void carve(const lg_plan* plan, int B, int train, void* base, NetB
             bb.amp = cv.take(B * (e / 2) * bb.h * (bb.w / 2 + 1));
             bb.pha = cv.take(B * (e / 2) * bb.h * (bb.w / 2 + 1));
             bb.sgn = cv.take(B * P * e / 2);
-            bb.att_o = e == 16 ? cv.take(B * P * e / 2) : nullptr;
-            bb.att_l = e == 16 ? cv.take(B * P * 2) : nullptr;
+            bb.att_o = cv.take(B * P * e / 2);
+            bb.att_l = cv.take(B * P * 2);
             bb.a1 = cv.take(B * P * 4 * e);
             bb.g1 = cv.take(B * P * 4 * e);
             bb.h2 = cv.take(B * P * 4 * e);

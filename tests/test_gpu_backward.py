@@ -433,19 +433,19 @@ def test_fused_attention_backward_agrees_with_the_round3_path(drop, monkeypatch)
         assert float((a - b).norm()) <= tol * float(a.norm()) + 1e-10, (drop, eng.names[i], float((a - b).norm()), float(a.norm()))
 
 
-@pytest.mark.parametrize('drop', [False, True])
-def test_attention_backward_on_the_forwards_row_statistics_agrees_with_its_own_reduction_pass(drop, monkeypatch):
-    """round 6: k_attn_bwd_f<STATS> reads the log-sum-exp of every score row and the attention output that k_attn_m's saving launch left (one loop over
+@pytest.mark.parametrize('drop,C', [(False, 4), (True, 4), (False, 8), (True, 8)])
+def test_attention_backward_on_the_forwards_row_statistics_agrees_with_its_own_reduction_pass(drop, C, monkeypatch):
+    """round 6: k_attn_bwd_f<STATS> (e = 16) and k_attn_bwd_core<.., STATS> (e = 32, 64: C = 4 has a 32-wide bottleneck, C = 8 is 32 / 64 wide) read the log-sum-exp of every score row and the attention output that k_attn_m's saving launch left (one loop over
     the keys in pass 1) -- against the same kernel re-deriving both with its reduction pass (LG_ATTN_BWD_STATS=recompute, rounds 4 - 5) on a whole train
     step, with and without dropout: every live gradient tensor to rounding (the forward's statistics come out of split 16-bit products, the backward's
     own out of fp32 multiply-adds: the two differ by ~1e-6 of a score)"""
     from gpu_helpers import make_module
     from lgteun_amd.engine import LG_FLAG_DROPOUT, LG_FLAG_SAVE, LG_FLAG_FAITHFUL
-    ms, pan, gt = (T(a).cuda() for a in dw.make_inputs(3, 4, 16, 24, seed=12, kind='smooth'))
+    ms, pan, gt = (T(a).cuda() for a in dw.make_inputs(3, C, 16, 24, seed=12, kind='smooth'))
     flags = (LG_FLAG_DROPOUT if drop else 0) | LG_FLAG_SAVE | LG_FLAG_FAITHFUL
 
     def grads():
-        net = make_module(4, 2)
+        net = make_module(C, 2)
         eng = net.engine()
         y, saved = eng.forward_raw(ms, pan, flags, seed=4321)
         r = torch.randn(y.shape, generator=torch.Generator(device='cpu').manual_seed(6)).cuda()
@@ -462,7 +462,7 @@ def test_attention_backward_on_the_forwards_row_statistics_agrees_with_its_own_r
         o, n = eng.offsets[i], eng.params[i].numel()
         a, b = g0[o:o + n].double(), g1[o:o + n].double()
         tol = 2e-4 if eng.names[i].endswith(('pos_emb', 'conv_amp.0.bias', 'conv_pha.0.bias')) else 2e-5   # the cancelling sums
-        assert float((a - b).norm()) <= tol * float(a.norm()) + 1e-10, (drop, eng.names[i], float((a - b).norm()), float(a.norm()))
+        assert float((a - b).norm()) <= tol * float(a.norm()) + 1e-10, (drop, C, eng.names[i], float((a - b).norm()), float(a.norm()))
 
 
 @pytest.mark.parametrize('C', [4, 8])
@@ -537,6 +537,7 @@ def test_matrix_pipe_attention_backward_core_agrees_with_the_vector_pipe_core(C,
         eng = net.engine()
         eng.train_step(ms, pan, gt, opt)
         return eng.gflat.clone(), eng
+    monkeypatch.setenv('LG_ATTN_BWD_STATS', 'recompute')             # both cores re-derive the softmax row statistics (the matrix-pipe core always does): what differs is the core alone
     monkeypatch.delenv('LG_ATTN_BWD_CORE', raising=False)
     g0, eng = grads()
     monkeypatch.setenv('LG_ATTN_BWD_CORE', 'm')                      # read once per plan: a fresh module builds a fresh plan
