@@ -100,7 +100,7 @@ extern "C" int lg_prof_read(double* total_ms, int64_t* launches) {
     return 0;
 }
 extern "C" const char* lg_kernel_name(int32_t k) {
-    static const char* names[LG_K_COUNT] = {"none", "k_ffn1", "fused FFN forward (k_ffn_xs e=16 / k_ffn_x32 e=32 / k_ffn1_x64+k_ffn2_x64 e=64)", "k_fftmix", "k_attn", "k_upfuse", "k_down", "k_embed", "k_tail",
+    static const char* names[LG_K_COUNT] = {"none", "k_ffn1", "fused FFN forward (k_ffn_xr e=16 / k_ffn_x32 e=32 / k_ffn1_x64+k_ffn2_x64 e=64)", "k_fftmix", "k_attn", "k_upfuse", "k_down", "k_embed", "k_tail",
                                             "k_resample_dw", "k_ffn1_bwd", "k_ffn2_bwd", "k_fftmix_bwd", "k_attn_bwd", "k_wgrad"};
     return (k >= 0 && k < LG_K_COUNT) ? names[k] : "?";
 }

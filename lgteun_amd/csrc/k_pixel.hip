@@ -344,9 +344,20 @@ int launch_down(int E, const DownArgs& a, hipStream_t s) {
 // resample (both are linear and the taps sum to 1, so conv(resample(x)) = resample(conv(x)) up to fp32 rounding; the bias is
 // added after the resample): the conv runs on a quarter of the pixels and the 16-tap gather reads E channels from LDS instead of
 // 2E channels from HBM with one address per lane (that gather was 280 scattered load instructions per wave, 126 us per call).
+#ifdef LG_UPF_STAMPS   // diagnostic variant (bash tools/mkvariant.sh upf_stamps k_pixel.hip -DLG_UPF_STAMPS; tools/upf_stamps.py): s_memtime at the phase borders, every wave
+__device__ unsigned long long g_upf_stamps[4096 * 4 * 12];
+#define USTAMP(i) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)); \
+                       if (blockIdx.x < 4096) g_upf_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 12 + (i)] = t__; } while (0)
+extern "C" __attribute__((visibility("default"))) int lg_debug_upf_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_upf_stamps), sizeof(g_upf_stamps));
+}
+#else
+#define USTAMP(i) do { } while (0)
+#endif
 template <int E>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_upfuse(UpFuseArgs a, int tiles_x, int tiles_y) {
     constexpr int TY = 8, TX = 32, SY = TY / 2 + 4, SX = TX / 2 + 4, NS = SY * SX /*160*/, LDV = E + 4, Q = 2 * E / 4;
+    USTAMP(0);
     __shared__ float4 srcb[NS * Q];                          // [NS][2E] level-1 pixels
     __shared__ __attribute__((aligned(16))) float vb[NS * LDV];   // [NS][E] up-conv of them (no bias)
     __shared__ float sFw[E * 2 * E], sFb[2 * E];   // fusion weight | up bias, fusion bias (synchronised by the barriers below)
@@ -388,6 +399,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         lds_stage_st<256, E>(sFb + E, vf);
     }
     __syncthreads();
+    USTAMP(1);
     for (int it = threadIdx.x; it < NS * E; it += 256) {
         const int px = it / E;
         float v = 0.f;
@@ -399,6 +411,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         vb[px * LDV + n_own] = v;
     }
     __syncthreads();
+    USTAMP(2);
     const int ly = threadIdx.x / TX, lx = threadIdx.x - ly * TX;
     const int oy = Y0 + ly, ox = X0 + lx;
     const bool inimg = oy < a.H && ox < a.W;
@@ -444,6 +457,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
 #pragma unroll
     for (int n = 0; n < E; ++n) tt[n] += sFb[n];
+    USTAMP(3);
     // ---- fusion 1x1 conv (2E -> E) on the matrix cores: out[px][n] = bf[n] + sum_k Wf[n][E + k] skip[px][k] + sum_k Wf[n][k] t[px][k].
     // The pixel rows pass through the exchange buffer anyway (skip comes in coalesced, t / y go out coalesced), so they ARE the A operand
     // of v_mfma_f32_16x16x4_f32 (row pitch E + 4: conflict-free ds_read_b32), the weights sit in registers as B fragments and wave w
@@ -491,14 +505,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         *reinterpret_cast<float4*>(stg + px * LDT + 4 * (i - px * Q4)) = skc[k];
     }
     __syncthreads();
+    USTAMP(4);
     gemm_half(1);
+    USTAMP(5);
     __syncthreads();
     // t rows (up path): this thread's pixel vector -> exchange buffer
 #pragma unroll
     for (int k = 0; k < Q4; ++k) *reinterpret_cast<float4*>(stg + threadIdx.x * LDT + 4 * k) = make_float4(tt[4 * k], tt[4 * k + 1], tt[4 * k + 2], tt[4 * k + 3]);
     __syncthreads();
+    USTAMP(6);
     if (a.t_save) rows_out(a.t_save);
     gemm_half(0);
+    USTAMP(7);
     __syncthreads();
     // output rows: accumulator layout (lane (r, g): pixels 4g + v, channel r) -> exchange buffer
 #pragma unroll
@@ -508,7 +526,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int v = 0; v < 4; ++v) stg[(64 * wave_ + 16 * mt + 4 * g_ + v) * LDT + nt * 16 + r_] = acc[mt][nt][v];
     __syncthreads();
+    USTAMP(8);
     rows_out(a.y);
+    USTAMP(9);
     if (a.g && inimg) {
         float o[E];
 #pragma unroll
@@ -518,6 +538,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         }
         emit_g<E>(o, a.n1g, a.n1b, a.g, b, (long)oy * a.W + ox, (long)a.H * a.W);
     }
+    USTAMP(10);
 }
 
 int launch_upfuse(int E, const UpFuseArgs& a, hipStream_t s) {
