@@ -210,7 +210,7 @@ __device__ unsigned long long am_stamps[1024][4][8];
 #define AM_STAMP(i) do { } while (0)
 #endif
 template <int HC, int NP>
-__global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, int nwin, int nquads) {
+__global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, int nwin, int nquads, int uneven) {
     using namespace am;
     using G = Geo<HC>;
     constexpr int E = G::E, D = G::D, DG = G::DG, NCH = G::NCH, NY = G::NY, MTQK = G::MTQK, NTV = G::NTV;
@@ -297,7 +297,13 @@ __global__ __launch_bounds__(256, (HC <= 16 ? 2 : 1)) void k_attn_m(AttnArgs a, 
     const int lx = lpix * E + 4 * g;                 // ... its first chunk in x / y (floats)
     const int tstep = 2 * a.w;                       // pixels per token tile
 
-    for (int quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
+    // uneven (launcher: 512 resident workgroups, eight window quads per pair): the dispatcher places workgroups 0 .. 255 one per CU before the second 256 and the SIMD
+    // arbiter issues the older wave first, so a CU's first workgroup runs faster than its second (k_ffn_xr.hip has the measurement): it takes 5 of the pair's 8 quads
+    const int half = (int)gridDim.x >> 1, first = (int)blockIdx.x < half ? 1 : 0;
+    const int nmine = uneven ? (first ? uneven : 8 - uneven) : 0x7fffffff;
+    const int q0 = uneven ? (first ? (int)blockIdx.x : half * uneven + ((int)blockIdx.x - half)) : (int)blockIdx.x;
+    const int qstep = uneven ? half : (int)gridDim.x;
+    for (int quad = q0, kq = 0; quad < nquads && kq < nmine; quad += qstep, ++kq) {
         const int win = quad * 4 + __builtin_amdgcn_readfirstlane(wave);   // provably wave-uniform: window origins stay in scalar registers
         if (win >= nwin) continue;   // no barrier inside the loop
         const int wx = win % nwx, rr = win / nwx, wy = rr % nwy;
@@ -560,7 +566,11 @@ static int launch_attn_m_t(const AttnArgs& a, hipStream_t s) {
     const int cap = ncu * per_cu;
     const int rounds = (nquads + cap - 1) / cap;
     const int grid = nquads < cap ? nquads : (nquads + rounds - 1) / rounds;
-    k_attn_m<HC, NP><<<grid, 256, lds, s>>>(a, nwin, nquads);
+#ifndef LG_ATTN_UNEVEN
+#define LG_ATTN_UNEVEN 5
+#endif
+    const int uneven = (per_cu == 2 && grid == 512 && nquads == 4 * grid && nwin == 4 * nquads) ? LG_ATTN_UNEVEN : 0;   // the measured shape only
+    k_attn_m<HC, NP><<<grid, 256, lds, s>>>(a, nwin, nquads, uneven == 4 ? 0 : uneven);
     LG_CHECK_LAUNCH();
     return 0;
 }

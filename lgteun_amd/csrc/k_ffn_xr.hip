@@ -47,6 +47,25 @@ extern "C" __attribute__((visibility("default"))) int lg_debug_xr_stamps(unsigne
 #define XSTAMP(i) do { } while (0)
 #endif
 
+// Two workgroups share a CU and the SIMD arbiter issues the OLDER wave first: unthrottled, the workgroup that was dispatched first runs as if it were alone
+// (13.1 k cycles per step) while the other gets what is left (24 k per step), finishes 40 % later and spends the end of the launch alone on a half-empty CU
+// (stamps: profiles/r06_ffn_xr_fairness.txt -- lifetimes of the 512 workgroups exactly bimodal, 105 k / 148 k cycles).  XR_TAKE_TURNS() is placed behind the
+// step's barriers (where lgkmcnt is drained anyway, so that reading the clock stalls nothing): it raises or lowers the wave's user priority by a bit of the
+// clock XOR the parity of the wave's slot on its SIMD -- the two waves of a SIMD take turns of 2^LG_XR_TURN cycles, both workgroups advance at the same mean
+// rate and finish together.
+#ifndef LG_XR_TURN
+#define LG_XR_TURN 0       // A/B build: 14 = turns of 2^14 cycles (measured: lifetimes 125 k / 147 k instead of 105 k / 148 k, step 5.299 -> 5.286 ms; the uneven split below does better)
+#endif
+#ifndef LG_XR_UNEVEN
+#define LG_XR_UNEVEN 16   // rows (per 64-row strip) moved from the second workgroup of a CU to the first; 0: even strips
+#endif
+#define XR_TAKE_TURNS() do { if (LG_XR_TURN) { \
+        const unsigned long long tt__ = __builtin_amdgcn_s_memtime(); \
+        if ((((unsigned)(tt__ >> LG_XR_TURN)) ^ slot_par) & 1u) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); } } while (0)
+// which of the two waves of its SIMD a wave is: one toggling word per (XCD, SE, SH, CU, SIMD) -- the first wave to arrive reads b, the second 1 - b, whatever the
+// launches before left there (zero-initialised once with the module; no reset, no dependence on how the dispatcher numbers wave slots)
+__device__ unsigned g_xr_turn[8192];
+
 namespace xr {
 
 constexpr int E = 16, N1 = 64, TX = 16, HX = 18, TY = 8, RING = 10, LDR = 68;
@@ -137,7 +156,7 @@ __device__ __forceinline__ lg_v2f geluN(lg_v2f x, const GK& k) {
 // SAVE: 0 nothing; 3 the pre-activations h2 and h3 (the backward re-computes h1 from x: k_ffn1_bwd_xs) -- the two modes of the default path
 template <int SAVE, int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn_xr(Ffn1Args a1, Ffn2Args a2, int tiles_x, int strips_y, int nstrips,
-                                                                                       int SH) {
+                                                                                       int SH, int dS) {
     using namespace xr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* ring = reinterpret_cast<float*>(smem_raw + OFF_RING);             // [RING * HX][LDR] h2
@@ -146,6 +165,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     float* sPar = reinterpret_cast<float*>(smem_raw + OFF_PAR);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c_ = lane & 15, c = c_;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);   // provably wave-uniform: branches on it are scalar branches
+    unsigned slot_par = 0;
+    if (LG_XR_TURN) {   // requested first thing, used behind the first step's barrier
+        const unsigned hw = __builtin_amdgcn_s_getreg((12 - 1) << 11 | 4 << 6 | 4);    // HW_REG_HW_ID (4) bits [15:4]: simd [1:0], pipe [3:2], cu [7:4], sh [8], se [11:9]
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 - 1) << 11 | 0 << 6 | 20);   // HW_REG_XCC_ID (20) bits [2:0]
+        const unsigned key = (xcc << 10) | (((hw >> 9) & 7u) << 7) | (((hw >> 8) & 1u) << 6) | (((hw >> 4) & 15u) << 2) | (hw & 3u);
+        unsigned old_ = 0;
+        if (lane == 0) old_ = atomicXor(&g_xr_turn[key & 8191u], 1u);
+        slot_par = (unsigned)__builtin_amdgcn_readfirstlane((int)old_) & 1u;
+    }
     const int h = a2.h, w = a2.w;
     // operand scales (k_ffn_prep.hip; k_ffn_x.hip has the derivation): S1 h1, S2 h2, S3 (...) in the accumulators
     constexpr bool BF = NP == 1;
@@ -159,17 +187,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const GeluK gk1 = gelu_k(0.70710678118654752440f / S1, 0.5f * sa1 / S1), gk3 = gelu_k(0.70710678118654752440f, 0.5f * sa3);   // S1 h1 -> s_a1 gelu(h1); h3 -> s_a3 gelu(h3)
 #endif
 
+    // strip -> (column strip, sample, rows [Y0, Yend)).  dS != 0 (launcher: exactly two strips per CU, one per workgroup): the rows of two vertically adjacent
+    // strips are split UNEVENLY, SH + dS to the strip of a workgroup of the first half of the grid and SH - dS to its neighbour's in the second half.  The
+    // dispatcher places workgroups 0 .. 255 one per CU before the second 256, and the SIMD arbiter issues the OLDER wave first: the first workgroup of a CU runs as
+    // if it were alone (13.1 k cycles per step), the second gets what is left (24 k per step) and used to finish 40 % later, alone on a half-empty CU
+    // (profiles/r06_ffn_xr_fairness.txt: lifetimes 105 k / 148 k cycles, all of 0 .. 255 in the first group).  With 10 : 6 steps both are done at ~135 k.
+    auto strip_geo = [&](int strip, int& tx_i, long& b, int& Y0, int& Yend) {
+        if (dS) {
+            const int half = nstrips >> 1, shortone = strip >= half ? 1 : 0;
+            int p_ = strip - (shortone ? half : 0);
+            tx_i = p_ % tiles_x;
+            p_ /= tiles_x;
+            const int hy2 = strips_y >> 1, ky = p_ % hy2;
+            b = p_ / hy2;
+            Y0 = ky * 2 * SH + (shortone ? SH + dS : 0);
+            Yend = min(Y0 + (shortone ? SH - dS : SH + dS), h);
+        } else {
+            int t_ = strip;
+            tx_i = t_ % tiles_x;
+            t_ /= tiles_x;
+            const int sy = t_ % strips_y;
+            b = t_ / strips_y;
+            Y0 = sy * SH;
+            Yend = min(Y0 + SH, h);
+        }
+    };
     XSTAMP_AT(9, 0);
     // the prologue's x vector of this workgroup's FIRST strip: requested now, its HBM round trip runs under the table staging
     float4 xp_first;
     {
-        int t_ = blockIdx.x;
-        const int tx_i = t_ % tiles_x;
-        t_ /= tiles_x;
-        const int sy = t_ % strips_y;
-        const long b = t_ / strips_y;
+        int tx_i, Y0f, Yendf;
+        long b;
+        strip_geo(blockIdx.x, tx_i, b, Y0f, Yendf);
         const int m = 16 * (wave < 3 ? wave : 0) + c, hy = m / HX, hx = m - hy * HX;
-        const int y = clampi(sy * SH - 1 + hy, 0, h - 1), x = clampi(tx_i * TX + hx - 1, 0, w - 1);
+        const int y = clampi(Y0f - 1 + hy, 0, h - 1), x = clampi(tx_i * TX + hx - 1, 0, w - 1);
         xp_first = *reinterpret_cast<const float4*>(a1.x + ((b * h + y) * (long)w + x) * E + 4 * g);
     }
     // ---- once per (persistent) workgroup: weight fragments, taps, biases
@@ -246,16 +297,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 
 #pragma unroll 1
     for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
-        int t_ = strip;
-        const int tx_i = t_ % tiles_x;
-        t_ /= tiles_x;
-        const int sy = t_ % strips_y;
+        int tx_i, Y0, Yend;
+        long b;
+        strip_geo(strip, tx_i, b, Y0, Yend);
 #ifdef LG_XR_SAMEX   // diagnostic: every workgroup reads (and writes) sample 0 (results wrong)
-        const long b = 0;
-#else
-        const long b = t_ / strips_y;
+        b = 0;
 #endif
-        const int x0 = tx_i * TX, Y0 = sy * SH, Yend = min(Y0 + SH, h);
+        const int x0 = tx_i * TX;
 
         // x vector of the lane's pixel of halo block blk of the row block starting at ya: unconditional, from a clamped (always valid) address
         auto xload = [&](int ya, int blk) -> float4 {
@@ -559,6 +607,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             // next step's halo operands: in flight across the spatial phase (clamped addresses: harmless behind the last step)
             xh[0] = xload(y0 + TY + 1, 2 * wave); xh[1] = xload(y0 + TY + 1, 2 * wave + 1); xh[2] = xload(y0 + TY + 1, 8);
             __syncthreads();     // ring rows y0 - 1 .. y0 + 8 complete (but for the ninth block's second half)
+            XR_TAKE_TURNS();
             XSTAMP(3);
             if (role == 3) ninth_add(part9, geo9);
             // ---- spatial phase: tile rows ty0, ty0 + 1: dw3x3 over the ring -> gelu -> GEMM3 -> + bias + residual -> y (+ planar LN half)
@@ -684,6 +733,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             }
             XSTAMP(4);
             __syncthreads();     // the ring rows this step read are free for the next step's halo pass
+            XR_TAKE_TURNS();
             XSTAMP(5);
         }   // steps of the strip
     }   // strips of this workgroup
@@ -712,11 +762,14 @@ int launch_ffn_xr(const Ffn1Args& a1, const Ffn2Args& a2, hipStream_t s) {
     const int strips_y = (a2.h + SH - 1) / SH;
     const int nstrips = a2.B * tiles_x * strips_y;
     const int grid = nstrips < LG_XR_GRID ? nstrips : LG_XR_GRID;
+    // uneven split of strip pairs (strip_geo in the kernel): only in the shape it was measured in -- one strip per workgroup, exactly two workgroups per CU
+    int dS = 0;
+    if (LG_XR_UNEVEN && nstrips == LG_XR_GRID && LG_XR_GRID == 512 && (strips_y & 1) == 0 && SH >= 32 && a2.h % (2 * SH) == 0) dS = (SH * LG_XR_UNEVEN / 64 + 7) / 8 * 8;
     if (a1.hbf) {    // precision = 'bf16'
-        if (save) k_ffn_xr<3, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
-        else k_ffn_xr<0, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
-    } else if (save) k_ffn_xr<3, 2><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
-    else k_ffn_xr<0, 2><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH);
+        if (save) k_ffn_xr<3, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH, dS);
+        else k_ffn_xr<0, 1><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH, dS);
+    } else if (save) k_ffn_xr<3, 2><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH, dS);
+    else k_ffn_xr<0, 2><<<grid, 256, LDS_BYTES, s>>>(a1, a2, tiles_x, strips_y, nstrips, SH, dS);
     LG_CHECK_LAUNCH();
     return 0;
 }

@@ -47,3 +47,17 @@ print(f'   end of step 7: p10 {np.percentile(end, 10):.0f}  p50 {np.percentile(e
 for si in range(8):
     a = (st[:, 0, si, 0] - base)[ok]
     print(f'   step {si} begins: p10 {np.percentile(a, 10):.0f}  p50 {np.percentile(a, 50):.0f}  p90 {np.percentile(a, 90):.0f}')
+# are the two workgroups of a CU treated alike?  lifetime (first step's begin -> last step's end) per workgroup, and the per-step durations of the fast and the slow half
+life = (st[:, 0, 7, 5] - st[:, 0, 0, 0])[ok]
+print(f' workgroup lifetime over 8 steps: p5 {np.percentile(life, 5):.0f}  p25 {np.percentile(life, 25):.0f}  p50 {np.percentile(life, 50):.0f}  p75 {np.percentile(life, 75):.0f}  p95 {np.percentile(life, 95):.0f}')
+med = np.median(life)
+fast, slow = life <= med, life > med
+stepd = (st[:, 0, :8, 5] - st[:, 0, :8, 0])[ok]
+print('   step durations, faster half of the workgroups:', *[f'{v:8.0f}' for v in stepd[fast].mean(axis=0)])
+print('   step durations, slower half of the workgroups:', *[f'{v:8.0f}' for v in stepd[slow].mean(axis=0)])
+print('   histogram of lifetimes (ticks):', np.histogram(life, bins=10))
+# does dispatch order decide who is the older workgroup of a CU?  lifetime against blockIdx
+idx = np.arange(512)[ok]
+lo, hi = life[idx < 256], life[idx >= 256]
+print(f' lifetime of workgroups 0..255: mean {lo.mean():.0f} (min {lo.min():.0f}, max {lo.max():.0f});  256..511: mean {hi.mean():.0f} (min {hi.min():.0f}, max {hi.max():.0f})')
+print(f' even blockIdx: mean {life[idx % 2 == 0].mean():.0f};  odd: {life[idx % 2 == 1].mean():.0f}')
