@@ -173,7 +173,7 @@ __device__ __forceinline__ WFrag16 wfrag16(const float* W, int K, int k0, float 
 __device__ __forceinline__ float kb_pow2_below(float bound) { return __builtin_amdgcn_ldexpf(1.0f, 15 - __builtin_amdgcn_frexp_expf(bound)); }
 
 template <int E, int NP>
-__global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn1_bwd_xs(Ffn1BwdXArgs a, long ntiles) {
+__global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn1_bwd_xs(Ffn1BwdXArgs a, long ntiles, int uneven) {
     using C = KB<E>;
     constexpr int N1 = C::N1, NW = C::NW, NT = C::NT, LDP = C::LDP, LPP = C::LPP, D2_PIECE = C::D2_PIECE, XN_PIECE = C::XN_PIECE, D1T_PIECE = C::D1T_PIECE;
     constexpr int KB2 = N1 / 32;       // 32-deep K blocks of dh2 W2
@@ -238,13 +238,20 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
         xnx = *reinterpret_cast<const float4*>(a.x + (p0 + lpx) * E + 4 * lq);
         dyn = *reinterpret_cast<const float4*>(a.dy + (p0 + lpx) * E + 4 * lq);
     };
-    if ((long)blockIdx.x < ntiles) issue(blockIdx.x);
+    // uneven (launcher: two resident workgroups per CU, ntiles a multiple of 16 per pair): the workgroup a CU received first runs faster than its second (the SIMD
+    // arbiter issues the older wave first; k_ffn_xr.hip has the measurement), so of every 16 tiles of a pair it takes `uneven`
+    const int half = (int)gridDim.x >> 1, first = (int)blockIdx.x < half ? 1 : 0;
+    const long per = uneven ? ntiles / (8 * (long)gridDim.x) : 0;                       // sixteenths of a pair's tiles
+    const long nmine = uneven ? per * (first ? uneven : 16 - uneven) : (1l << 60);
+    const long t0 = uneven ? (first ? (long)blockIdx.x : (long)half * per * uneven + ((long)blockIdx.x - half)) : (long)blockIdx.x;
+    const long tstep = uneven ? half : (long)gridDim.x;
+    if (t0 < ntiles) issue(t0);
 
 #pragma unroll 1
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (long tile = t0, kt = 0; tile < ntiles && kt < nmine; tile += tstep, ++kt) {
         const long p0 = tile * NPX;
 #ifdef LG_STAMPS
-        const bool stamp_on = tile == (long)blockIdx.x + 2 * (long)gridDim.x;
+        const bool stamp_on = kt == 2;
 #endif
         STAMP(0);
         // ---- loader: dh2 -> pieces -> D2 ; LN(x) -> pieces -> XN (the previous tile's readers of both are behind its second barrier)
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(KB<E>::NT) __attribute__((amdgpu_waves_per_eu(2))) 
                 *reinterpret_cast<u32x2_t*>(dst + 2 * XN_PIECE) = q3;
             }
         }
-        if (tile + (long)gridDim.x < ntiles) issue(tile + gridDim.x);   // next tile's operands: in flight during the GEMM phase
+        if (tile + tstep < ntiles && kt + 1 < nmine) issue(tile + tstep);   // next tile's operands: in flight during the GEMM phase
         STAMP(1);
         __syncthreads();
         STAMP(2);
@@ -466,9 +473,13 @@ int launch_t(const Ffn1BwdXArgs& a, hipStream_t s) {
     const long ntiles = a.P / NPX;
     const int cap = ffn1_bwd_x_wgs(E);
     const int grid = (int)(ntiles < cap ? ntiles : cap);
-    if (a.hbf) k_ffn1_bwd_xs<E, 1><<<grid, C::NT, C::LDS_BYTES, s>>>(a, ntiles);      // precision = 'bf16': plain bf16 operands, dh2 stored as bf16
-    else if (a.scales) k_ffn1_bwd_xs<E, 2><<<grid, C::NT, C::LDS_BYTES, s>>>(a, ntiles);   // f16 pairs, scaled operands
-    else k_ffn1_bwd_xs<E, 3><<<grid, C::NT, C::LDS_BYTES, s>>>(a, ntiles);
+#ifndef LG_FFN1B_UNEVEN
+#define LG_FFN1B_UNEVEN 9
+#endif
+    const int uneven = (E == 16 && grid == 512 && ntiles % (8 * (long)grid) == 0 && LG_FFN1B_UNEVEN != 8) ? LG_FFN1B_UNEVEN : 0;   // the measured shape only (two workgroups per CU)
+    if (a.hbf) k_ffn1_bwd_xs<E, 1><<<grid, C::NT, C::LDS_BYTES, s>>>(a, ntiles, uneven);      // precision = 'bf16': plain bf16 operands, dh2 stored as bf16
+    else if (a.scales) k_ffn1_bwd_xs<E, 2><<<grid, C::NT, C::LDS_BYTES, s>>>(a, ntiles, uneven);   // f16 pairs, scaled operands
+    else k_ffn1_bwd_xs<E, 3><<<grid, C::NT, C::LDS_BYTES, s>>>(a, ntiles, uneven);
     LG_CHECK_LAUNCH();
     // the slab rows, summed in a fixed order by the deferred reduce launch
     ReduceJob j;

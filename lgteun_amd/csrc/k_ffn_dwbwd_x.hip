@@ -100,7 +100,7 @@ __device__ __forceinline__ bf16x8_t lds_x8(const uint16_t* p) { return __builtin
 
 // NP = 3: fp32 storage of h2 / h3 / dh2, fp32-equivalent split products; NP = 1 (precision = 'bf16'): bf16 storage (hstore.h), plain bf16 products
 template <int E, int NP>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn_dw_bwd_xs(FfnDwBwdXArgs a, int tiles_x, int strips_y, int nstrips, int SH) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void k_ffn_dw_bwd_xs(FfnDwBwdXArgs a, int tiles_x, int strips_y, int nstrips, int SH, int dS) {
     using C = KA<E>;
     constexpr int N1 = C::N1, LQ = C::LQ, NV = C::NV, DY_PIECE = C::DY_PIECE, DY_SLOT = C::DY_SLOT;
     constexpr int PPL = 4, RPW = 2, NM = E / 16;       // P2: consecutive pixels of a tile row per lane, tile rows per wave; 16-row tiles of dW3
@@ -141,12 +141,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void k_
     float dmx = 0.f;     // max |dh2| of this thread's stores (a.dh2_max: the operand scale of k_ffn1_bwd_xs's f16-pair products)
 #pragma unroll 1
     for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
-    int t = strip;
-    const int tx_i = t % tiles_x;
-    t /= tiles_x;
-    const int sy = t % strips_y;
-    const long b = t / strips_y;
-    const int x0 = tx_i * TX, Y0 = sy * SH, Yend = min(Y0 + SH, h);
+    // dS != 0 (launcher: one strip per workgroup, two workgroups per CU): vertically adjacent strips are SH + dS rows for a workgroup of the first half of the grid and
+    // SH - dS for its neighbour's in the second half -- the workgroup a CU received first runs faster (k_ffn_xr.hip strip_geo has the measurement)
+    int tx_i, Y0, Yend;
+    long b;
+    if (dS) {
+        const int half = nstrips >> 1, shortone = strip >= half ? 1 : 0;
+        int p_ = strip - (shortone ? half : 0);
+        tx_i = p_ % tiles_x;
+        p_ /= tiles_x;
+        const int hy2 = strips_y >> 1, ky = p_ % hy2;
+        b = p_ / hy2;
+        Y0 = ky * 2 * SH + (shortone ? SH + dS : 0);
+        Yend = min(Y0 + (shortone ? SH - dS : SH + dS), h);
+    } else {
+        int t = strip;
+        tx_i = t % tiles_x;
+        t /= tiles_x;
+        const int sy = t % strips_y;
+        b = t / strips_y;
+        Y0 = sy * SH;
+        Yend = min(Y0 + SH, h);
+    }
+    const int x0 = tx_i * TX;
 #ifdef LG_STAMPS
     bool stamp_on = false;
 #endif
@@ -462,8 +479,13 @@ static int launch_dw_t(const FfnDwBwdXArgs& a, hipStream_t s) {
     const int nstrips = a.B * tiles_x * strips_y;
     const int gx = nstrips < wgs ? nstrips : wgs;
     const dim3 grid(gx, C::NHALF);
-    if (a.hbf) k_ffn_dw_bwd_xs<E, 1><<<grid, NT, C::LDS_BYTES, s>>>(a, tiles_x, strips_y, nstrips, SH);   // precision = 'bf16'
-    else k_ffn_dw_bwd_xs<E, 3><<<grid, NT, C::LDS_BYTES, s>>>(a, tiles_x, strips_y, nstrips, SH);
+#ifndef LG_DWB_UNEVEN
+#define LG_DWB_UNEVEN 0   // measured: even strips 110.5 us, 9 : 7 steps 113.2, 10 : 6 110.5 -- this kernel gains nothing from the uneven split (unlike k_ffn_xr, k_attn_m, k_ffn1_bwd_xs)
+#endif
+    int dS = 0;   // uneven strip pairs: the measured shape only (e = 16: one strip per workgroup, exactly two workgroups per CU)
+    if (LG_DWB_UNEVEN && E == 16 && nstrips == wgs && wgs == 512 && (strips_y & 1) == 0 && SH >= 32 && a.h % (2 * SH) == 0) dS = (SH * LG_DWB_UNEVEN / 64 + 7) / 8 * 8;
+    if (a.hbf) k_ffn_dw_bwd_xs<E, 1><<<grid, NT, C::LDS_BYTES, s>>>(a, tiles_x, strips_y, nstrips, SH, dS);   // precision = 'bf16'
+    else k_ffn_dw_bwd_xs<E, 3><<<grid, NT, C::LDS_BYTES, s>>>(a, tiles_x, strips_y, nstrips, SH, dS);
     LG_CHECK_LAUNCH();
     // the slab rows of each channel half, summed in a fixed order by the deferred reduce launch
     ReduceJob j;
