@@ -50,6 +50,12 @@ extern "C" __attribute__((visibility("default"))) int lg_debug_kf_stamps(unsigne
                           // Measured SLOWER (142.7 against 124.7 us): a DPP multiply-add issues at the 4-cycle rate of the SDWA / conversion class and does ONE
                           // multiply-add per lane where v_pk_fma_f32 does two in 4.7 cycles -- the LDS pipe was relieved, the vector pipe got twice the work
 #endif
+#ifndef LG_ATTNF_PRIO
+#define LG_ATTNF_PRIO 1
+#endif
+// (one opaque asm statement with its own scalar branch inside: as a C++ `if` around two s_setprio builtins the basic block was split in front of each pass and the
+// register allocator spilled 470 registers)
+#define ATTNF_PRIO(lead) do { if (LG_ATTNF_PRIO) asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n\ts_branch 2f\n1:\ts_setprio 3\n2:" :: "s"(__builtin_amdgcn_readfirstlane((int)(lead))) : "scc"); } while (0)
 #define PASS_FENCE(g) do { if (LG_ATTNF_SB && ((g) % LG_ATTNF_SB) == LG_ATTNF_SB - 1) __builtin_amdgcn_sched_barrier(0); } while (0)
 namespace {
 #ifndef LG_ATTNF_NS
@@ -139,6 +145,7 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
     constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int uw = __builtin_amdgcn_readfirstlane(wave);   // provably wave-uniform
     const int ws = wave >> 1, hd = wave & 1;
     float* const sPosH = smem + hd * 64 * PLD;                 // pos_emb[hd][i][j] * log2(e)
     float* const sWq = smem + F_OFF_WQ;
@@ -319,6 +326,10 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
         STAMP(1);
         lds_barrier();   // B1: the tiles of every wave are complete
         STAMP(2);
+        // The two waves of a SIMD (wave w and w + 4: slots of different windows) are not served alike: the arbiter issues the OLDER one first (stamps of round 4: pass 1
+        // takes waves 0 - 3 10 k cycles and waves 4 - 7 13.4 k, and the first four then wait 5.8 k at the barrier).  LG_ATTNF_PRIO: the older half leads in pass 1, the
+        // younger half in pass 2 -- each wave has the SIMD for one of the two long passes and both halves reach the barrier together.
+        ATTNF_PRIO(uw < 4);
         float dqkv[12];
         {
             // ---------------- pass 1: lane = query i, packed over KEY pairs (as k_attn_bwd_core)
@@ -539,6 +550,7 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
                     }
         }
         STAMP(3);
+        ATTNF_PRIO(uw >= 4);
         // the epilogue's global operands of this group, requested across pass 2
         float4 ex0, ex1, ed0, ed1;
         uint32_t ekw;
@@ -676,6 +688,7 @@ __global__ __launch_bounds__(F_NT) __attribute__((amdgpu_waves_per_eu(2))) void 
         #endif
         }
         STAMP(4);
+        if (LG_ATTNF_PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();   // every lane is done with the wave's K / V / Q / dO tiles: they become the dqkv image
         {   // the next group's prologue operands (a repeat of this group's addresses when there is no next one)
