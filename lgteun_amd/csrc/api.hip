@@ -282,10 +282,10 @@ static int pos_transpose_stages(const lg_plan* pl, const float* P, int st0, int 
         for (int j = 0; j < 5; ++j, ++n) { src[n] = P + pl->blk(st, j, B_POS); dst[n] = posT_all + ((size_t)st * 5 + j) * 2 * 64 * 64; }
     return launch_pos_transpose_n(n, src, dst, s);
 }
-// what the LGTs of stages [st0, st1) need in front of their first kernel: the transposed pos_emb tables (round 2's vector-pipe mixer and the
-// backward kernels read them) and the operand scales of the f16-pair FFN arithmetic -- one launch each for all stages of the call
+// what the LGTs of stages [st0, st1) need in front of their first kernel: the transposed pos_emb tables (round 2's vector-pipe mixer alone reads
+// them) and the operand scales of the f16-pair FFN arithmetic -- one launch each for all stages of the call
 static int prep_stages(const lg_plan* pl, const float* P, int st0, int st1, NetBufs& nb, hipStream_t s) {
-    int rc = pos_transpose_stages(pl, P, st0, st1, nb.posT, s);
+    int rc = pl->attn_fwd_valu ? pos_transpose_stages(pl, P, st0, st1, nb.posT, s) : 0;   // only round 2's vector-pipe forward (LG_ATTN_FWD=valu) reads the transposed tables
     if (rc || st1 <= st0) return rc;
     const int E = 4 * pl->cfg.C;
     if (pl->ffn_f16x2(E) || pl->ffn_f16x2(2 * E)) {
