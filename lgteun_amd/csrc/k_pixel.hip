@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
         // writes 1 KB of consecutive bytes (lane -> (pixel 16 j + lane / Q4, quad lane % Q4)); as one row per lane a store instruction is
         // 64 separate 16-byte pieces at a 64- / 128-byte stride
         constexpr int Q4 = E / 4, LDT = E + 4;
-        __shared__ __attribute__((aligned(16))) float tr[4][64 * LDT];
+            __shared__ __attribute__((aligned(16))) float tr[4][64 * LDT];
         const int lane = threadIdx.x & 63;
         float* mine = tr[threadIdx.x >> 6];
 #pragma unroll
@@ -347,7 +347,7 @@ int launch_down(int E, const DownArgs& a, hipStream_t s) {
 #ifdef LG_UPF_STAMPS   // diagnostic variant (bash tools/mkvariant.sh upf_stamps k_pixel.hip -DLG_UPF_STAMPS; tools/upf_stamps.py): s_memtime at the phase borders, every wave
 __device__ unsigned long long g_upf_stamps[4096 * 4 * 12];
 #define USTAMP(i) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)); \
-                       if (blockIdx.x < 4096) g_upf_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 12 + (i)] = t__; } while (0)
+                       g_upf_stamps[((blockIdx.x & 4095) * 4 + (threadIdx.x >> 6)) * 12 + (i)] = t__; } while (0)   /* branch-free: a conditional store splits the blocks and spills */
 extern "C" __attribute__((visibility("default"))) int lg_debug_upf_stamps(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_upf_stamps), sizeof(g_upf_stamps));
 }
@@ -355,10 +355,12 @@ extern "C" __attribute__((visibility("default"))) int lg_debug_upf_stamps(unsign
 #define USTAMP(i) do { } while (0)
 #endif
 template <int E>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_upfuse(UpFuseArgs a, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 16 ? 4 : 2, E == 16 ? 4 : 2))) void k_upfuse(UpFuseArgs a, int tiles_x, int tiles_y) {   // e = 16: 38 KB of LDS and ~100 registers -- four workgroups per CU, some loading while others compute
     constexpr int TY = 8, TX = 32, SY = TY / 2 + 4, SX = TX / 2 + 4, NS = SY * SX /*160*/, LDV = E + 4, Q = 2 * E / 4;
     USTAMP(0);
-    __shared__ float4 srcb[NS * Q];                          // [NS][2E] level-1 pixels
+    constexpr int QP = Q + 1;                                // padded pixel pitch in 16-byte units: 2E + 4 floats = 4 mod 64, so the 16 rows of an MFMA A-operand read
+                                                             // (lane (r, g): pixel r of the tile, channel 4 ks + g) sit on 16 different banks
+    __shared__ float4 srcb[NS * QP];                         // [NS][2E (+4)] level-1 pixels
     __shared__ __attribute__((aligned(16))) float vb[NS * LDV];   // [NS][E] up-conv of them (no bias)
     __shared__ float sFw[E * 2 * E], sFb[2 * E];   // fusion weight | up bias, fusion bias (synchronised by the barriers below)
     const int hi = a.H / 2, wi = a.W / 2;
@@ -369,12 +371,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const long b = t / tiles_y;
     const int Y0 = ty_i * TY, X0 = tx_i * TX;
     const int sy0 = Y0 / 2 - 2, sx0 = X0 / 2 - 2;
-    const int n_own = threadIdx.x % E;
-    float4 wrow[Q];
+    // The up-path 1x1 conv (2E -> E on the NS source pixels) runs on the matrix cores (round 6): out[px][n] = sum_k src[px][k] Wu[n][k] as
+    // v_mfma_f32_16x16x4_f32 products (exact fp32 multiply-adds) with the source tile as the A operand straight out of LDS and the lane's slices of Wu in
+    // registers as B fragments.  As 64-deep dot products per thread fed by two-address broadcast reads of the tile (16 ds_read_b128 per item) it was 40 % of
+    // the workgroup's life at e = 32 (stamps: 25.7 k of 64.7 k cycles, tools/upf_stamps.py): every such read costs the LDS pipe 8 cycles for 32 useful bytes.
+    constexpr int NMU = NS / 16, NTU = E / 16, KSU = 2 * E / 4, NT2 = NMU * NTU;     // pixel tiles, channel tiles, k-steps, (pixel tile, channel tile) units
+    static_assert(NS % 16 == 0, "source tile = whole MFMA row tiles");
+    const int ul_ = threadIdx.x & 63, uw_ = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), ur_ = ul_ & 15, ug_ = ul_ >> 4;
+    float bu[NTU][KSU];
+    constexpr int Q4 = E / 4, LDT = E + 4;
+    float4 skc[Q4];
+    bool cok[Q4];
     {   // every source piece of the thread is requested before the first one is stored: as a `for (i = tid; i < NS * Q; i += 256)` loop the compiler
         // kept one load + wait + store per trip -- ten dependent HBM round trips per workgroup at e = 32 (the kernel ran at 2.5 x its HBM time)
         constexpr int NPC = NS * Q / 256;
         static_assert(NS * Q % 256 == 0, "source tile = whole trips of the workgroup");
+        // the skip rows of the tile (coalesced: thread t takes the float4 items t, t + 256, ... of the tile's rows): requested first, consumed behind the up-conv
+        // and the resample.  (Measured both ways: requested behind the source tile -- so that the in-order counter lets the tile be waited for alone -- the workgroup lives
+        // 51 k cycles, requested first 44.5 k: all 512 resident workgroups load at once, the phase is the chip's bandwidth, not a latency.)
+#pragma unroll
+        for (int k = 0; k < Q4; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            const int px = i / Q4, row = px / TX, col = px - row * TX;
+            cok[k] = Y0 + row < a.H && X0 + col < a.W;
+            skc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cok[k]) skc[k] = reinterpret_cast<const float4*>(a.skip + ((b * a.H + Y0 + row) * (long)a.W + X0 + col) * E)[i - px * Q4];
+        }
         float4 sv[NPC];
 #pragma unroll
         for (int j = 0; j < NPC; ++j) {
@@ -384,31 +406,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             const int yy = clampi(sy0 + ly, 0, hi - 1), xx = clampi(sx0 + lx, 0, wi - 1);
             sv[j] = reinterpret_cast<const float4*>(a.xb + ((b * hi + yy) * (long)wi + xx) * (2 * E))[k];
         }
-        // this thread's row of the up-conv weight (output channel n = tid % E for every item it handles) and the three parameter arrays behind
-        // them, in the same round trip (all requested before the first store)
+        // the lane's B fragments of the up-conv weight (B[k = 4 ks + g][column r] = Wu[16 nt + r][4 ks + g]) and the three parameter arrays behind them, in the
+        // same round trip (all requested before the first store)
 #pragma unroll
-        for (int k = 0; k < Q; ++k) wrow[k] = reinterpret_cast<const float4*>(a.upw + n_own * 2 * E)[k];
+        for (int nt = 0; nt < NTU; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < KSU; ++ks) bu[nt][ks] = a.upw[(16 * nt + ur_) * 2 * E + 4 * ks + ug_];
         float vw[(E * 2 * E + 255) / 256], vu[1], vf[1];
         lds_stage_ld<256, E * 2 * E>(vw, a.fw);
         lds_stage_ld<256, E>(vu, a.upb);
         lds_stage_ld<256, E>(vf, a.fb);
 #pragma unroll
-        for (int j = 0; j < NPC; ++j) srcb[threadIdx.x + 256 * j] = sv[j];
+        for (int j = 0; j < NPC; ++j) {
+            const int i = threadIdx.x + 256 * j, px = i / Q;
+            srcb[px * QP + (i - px * Q)] = sv[j];
+        }
         lds_stage_st<256, E * 2 * E>(sFw, vw);
         lds_stage_st<256, E>(sFb, vu);
         lds_stage_st<256, E>(sFb + E, vf);
     }
     __syncthreads();
     USTAMP(1);
-    for (int it = threadIdx.x; it < NS * E; it += 256) {
-        const int px = it / E;
-        float v = 0.f;
+    {
+        typedef float f32x4u __attribute__((ext_vector_type(4)));
+        const float* srcf = reinterpret_cast<const float*>(srcb);
+        // a unit's KSU A values are requested together, the next unit's behind a scheduling fence in front of this unit's MFMAs (left alone the compiler read
+        // one value, waited, issued two MFMAs, read the next ...: 7.2 k cycles for 80 MFMAs per wave)
+        constexpr int NU = (NT2 + 3) / 4;
+        float av[2][KSU];
+        auto a_ld = [&](int i, float (&v)[KSU]) {
+            const int t2 = min(uw_ + 4 * i, NT2 - 1);        // (clamped: the last round of a wave without a unit re-reads a valid tile and stores nothing)
+            const float* ap = srcf + (16 * (t2 / NTU) + ur_) * (4 * QP) + ug_;
 #pragma unroll
-        for (int k = 0; k < Q; ++k) {
-            const float4 sv = srcb[px * Q + k];
-            v += wrow[k].x * sv.x + wrow[k].y * sv.y + wrow[k].z * sv.z + wrow[k].w * sv.w;
+            for (int ks = 0; ks < KSU; ++ks) v[ks] = ap[4 * ks];
+        };
+        a_ld(0, av[0]);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int t2 = uw_ + 4 * i;                      // wave-uniform: the units are dealt round-robin to the four waves
+            if (i + 1 < NU) a_ld(i + 1, av[(i + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int t2c = min(t2, NT2 - 1), mt = t2c / NTU, nt = t2c - mt * NTU;
+            f32x4u acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KSU; ++ks) {
+                float bsel = bu[0][ks];
+#pragma unroll
+                for (int q = 1; q < NTU; ++q) bsel = nt == q ? bu[q][ks] : bsel;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][ks], bsel, acc, 0, 0, 0);
+            }
+            if (t2 < NT2) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) vb[(16 * mt + 4 * ug_ + v) * LDV + 16 * nt + ur_] = acc[v];
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        vb[px * LDV + n_own] = v;
     }
     __syncthreads();
     USTAMP(2);
@@ -420,19 +472,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     // contiguous floats) and the per-pixel vectors are exchanged through LDS (a thread reading / writing its own 64-byte pixel vector
     // touches 64 scattered 16-byte pieces per wave-instruction).  The skip rows are requested here, early: their latency hides under
     // the resample; they go to LDS once the source-pixel buffer (srcb) is dead.
-    constexpr int Q4 = E / 4, LDT = E + 4;
     float* stg = reinterpret_cast<float*>(srcb);          // [256][LDT] exchange buffer (srcb is dead after the up-conv above)
     static_assert(sizeof(srcb) >= 256 * LDT * sizeof(float), "exchange buffer fits the source-pixel buffer");
-    float4 skc[Q4];
-    bool cok[Q4];
-#pragma unroll
-    for (int k = 0; k < Q4; ++k) {
-        const int i = threadIdx.x + 256 * k;
-        const int px = i / Q4, row = px / TX, col = px - row * TX;
-        cok[k] = Y0 + row < a.H && X0 + col < a.W;
-        skc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cok[k]) skc[k] = reinterpret_cast<const float4*>(a.skip + ((b * a.H + Y0 + row) * (long)a.W + X0 + col) * E)[i - px * Q4];
-    }
     int iy0, ix0;
     float wy[4], wx[4];
     resample_plan<1>(min(oy, a.H - 1), iy0, wy);
@@ -440,19 +481,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     float tt[E];
 #pragma unroll
     for (int n = 0; n < E; ++n) tt[n] = 0.f;
+    {   // the 16 taps, double-buffered by hand: the next tap's E / 4 vectors are requested before this tap's multiply-adds and a scheduling fence keeps them
+        // there.  Left to itself the compiler read every vector into ONE register quad -- read, wait, four multiply-adds, read, wait ... : 128 dependent LDS
+        // round trips per thread, 16.3 k of the workgroup's 54 k cycles at e = 32 (tools/upf_stamps.py)
+        constexpr int Q4t = E / 4;
+        float4 tv[2][Q4t];
+        const int base_y = iy0 - 1 - sy0, base_x = ix0 - 1 - sx0;   // local row / column of tap (0, 0) (the LDS tile already holds border-clamped pixels)
+        auto tap_ld = [&](int tp, float4 (&v)[Q4t]) {
+            const float4* vr = reinterpret_cast<const float4*>(vb + ((base_y + (tp >> 2)) * SX + base_x + (tp & 3)) * LDV);
 #pragma unroll
-    for (int ta = 0; ta < 4; ++ta) {
-        const int sl_y = iy0 - 1 + ta - sy0;   // local row (the LDS tile already holds border-clamped pixels)
+            for (int k = 0; k < Q4t; ++k) v[k] = vr[k];
+        };
+        tap_ld(0, tv[0]);
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb) {
-            const int sl_x = ix0 - 1 + tb - sx0;
-            const float wgt = wy[ta] * wx[tb];
-            const float4* vr = reinterpret_cast<const float4*>(vb + (sl_y * SX + sl_x) * LDV);
+        for (int tp = 0; tp < 16; ++tp) {
+            if (tp + 1 < 16) tap_ld(tp + 1, tv[(tp + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const float wgt = wy[tp >> 2] * wx[tp & 3];
 #pragma unroll
-            for (int k = 0; k < E / 4; ++k) {
-                const float4 v = vr[k];
+            for (int k = 0; k < Q4t; ++k) {
+                const float4 v = tv[tp & 1][k];
                 tt[4 * k] += wgt * v.x; tt[4 * k + 1] += wgt * v.y; tt[4 * k + 2] += wgt * v.z; tt[4 * k + 3] += wgt * v.w;
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
@@ -478,15 +529,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) { const float bz = sFb[E + nt * 16 + r_]; acc[mt][nt] = (f32x4_){bz, bz, bz, bz}; }
-    auto gemm_half = [&](int hf) {
+    auto gemm_half = [&](int hf) {   // a row tile's KS A values requested together, the next tile's in front of this tile's MFMAs
+        float ga[2][KS];
+        auto g_ld = [&](int mt, float (&v)[KS]) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+            for (int ks = 0; ks < KS; ++ks) v[ks] = stg[(64 * wave_ + 16 * mt + r_) * LDT + 4 * ks + g_];
+        };
+        g_ld(0, ga[0]);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const float av = stg[(64 * wave_ + 16 * mt + r_) * LDT + 4 * ks + g_];
+        for (int mt = 0; mt < 4; ++mt) {
+            if (mt + 1 < 4) g_ld(mt + 1, ga[(mt + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[hf][nt][ks], acc[mt][nt], 0, 0, 0);
-            }
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[mt & 1][ks], bw[hf][nt][ks], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     auto rows_out = [&](float* dst) {   // coalesced store of the tile's rows from the exchange buffer
 #pragma unroll
