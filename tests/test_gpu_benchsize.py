@@ -468,3 +468,34 @@ def test_f16_pair_ffn_backward_holds_fp32_accuracy_at_extreme_scales(case, gscal
             e2, e3 = (float((got[sp][k].reshape(ref.shape) - ref).norm()) for sp in ('f16x2', 'bf16x3'))
             assert e2 <= 2.0 * e3 + 5e-7 * rn + 1e-30, (case, gscale, blk, k, e2 / max(rn, 1e-300), e3 / max(rn, 1e-300))
     monkeypatch.delenv('LG_FFN_BWD_SPLIT', raising=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('which', [1, 2])
+def test_uneven_work_split_of_the_bench_shape_changes_no_result(which):
+    """round 6: at exactly two resident workgroups per CU (32 pairs of 128 x 128 at e = 16) the first workgroup of a CU gets more of the work --
+    10 : 6 strip steps in k_ffn_xr, 5 : 3 window quads in k_attn_m, 9 : 7 tiles in k_ffn1_bwd_xs -- and 16 pairs take the even partition.  Half-block
+    forward and backward (which = 1: mixer, 2: feed_forward) of the 32-pair batch against the same samples as two 16-pair calls: y and dx are per-pixel
+    results and must be BITWISE the same; parameter gradients are sums over all pixels (per-workgroup partial sums in a different partition): the two
+    halves' sum to rounding"""
+    from gpu_helpers import Ops, make_module
+    net = make_module(4, 1)
+    ops = Ops(net, 128, 128)
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.standard_normal((32, 128, 128, 16)).astype(np.float32)).cuda()
+    dy = torch.from_numpy(rng.standard_normal((32, 128, 128, 16)).astype(np.float32)).cuda()
+    y = ops.block(0, 0, which, x).clone()
+    dx, g = ops.block_bwd(0, 0, which, x, dy)
+    dx, g = dx.clone(), g.clone()
+    ya = ops.block(0, 0, which, x[:16].contiguous()).clone()
+    yb = ops.block(0, 0, which, x[16:].contiguous()).clone()
+    assert torch.equal(y[:16], ya) and torch.equal(y[16:], yb)
+    dxa, ga = ops.block_bwd(0, 0, which, x[:16].contiguous(), dy[:16].contiguous())
+    dxa, ga = dxa.clone(), ga.clone()
+    dxb, gb = ops.block_bwd(0, 0, which, x[16:].contiguous(), dy[16:].contiguous())
+    assert torch.equal(dx[:16], dxa) and torch.equal(dx[16:], dxb)
+    gs = (ga.double() + gb.double())
+    live = g.abs() > 0
+    assert bool(live.any())
+    err = float((g.double() - gs).norm() / gs.norm())
+    assert err < 2e-6, err
